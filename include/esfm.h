@@ -1,0 +1,268 @@
+/*
+ * esfm.h -- C ABI of the MI355X-native EasySFM hot path (libesfm_hip.so).
+ *
+ * The reference (YuePanEdward/EasySFM) has no plugin/FFI layer: its de-facto
+ * boundary for this path is three C++ member functions called from
+ * cpp_code/test/sfm.cpp (the pair loop :140-161 and the BA sites :262,:314,:325):
+ *
+ *   FeatureMatching::matchFeaturesORB   cpp_code/include/feature_matching.h:17-18
+ *   FeatureMatching::matchFeaturesSURF  cpp_code/include/feature_matching.h:20-21
+ *   BundleAdjustment::doSFMBA           cpp_code/include/ba.h:84
+ *
+ * Every entry point below is what a binding for one of those call sites would
+ * bind (plain pointers and sizes, no C++/torch/OpenCV types).  INTEGRATION.md
+ * shows the few lines a maintainer adds to feature_matching.cpp / ba.cpp.
+ *
+ * Conventions
+ *   - return value: ESFM_OK (0) or a negative esfm_status; nothing throws.
+ *   - esfm_last_error() returns a thread-local, human-readable message for
+ *     the last failing call on this thread.
+ *   - "host" pointers are ordinary CPU memory; "_dev" entry points take HIP
+ *     device pointers that are already resident in HBM and enqueue all work on
+ *     the context's stream without synchronising (the caller synchronises).
+ *   - one esfm_ctx per host thread and per GPU; a context is not thread-safe.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point fails with ESFM_ERR_NO_DEVICE.
+ */
+#ifndef ESFM_H_
+#define ESFM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESFM_VERSION_MAJOR 0
+#define ESFM_VERSION_MINOR 1
+
+typedef enum esfm_status {
+    ESFM_OK = 0,
+    ESFM_ERR_INVALID_ARG = -1,
+    ESFM_ERR_NO_DEVICE = -2,   /* no HIP device / not gfx950 / HIP runtime error at init */
+    ESFM_ERR_HIP = -3,         /* a HIP runtime call failed; see esfm_last_error()        */
+    ESFM_ERR_OOM = -4,
+    ESFM_ERR_UNSUPPORTED = -5, /* e.g. descriptor width the kernels are not built for     */
+    ESFM_ERR_NUMERIC = -6,     /* BA: non-finite input or an unusable linear system       */
+    ESFM_ERR_COMM = -7         /* BA: the all-reduce callback reported failure             */
+} esfm_status;
+
+typedef struct esfm_ctx esfm_ctx;
+
+/* ---- library / context -------------------------------------------------- */
+
+/* "major.minor" of the ABI above. */
+const char *esfm_version(void);
+/* Message for the last error raised on the calling thread ("" if none). */
+const char *esfm_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int esfm_device_count(void);
+
+/* Creates a context on HIP device `device`.  `hip_stream` is a hipStream_t the
+ * caller owns (e.g. torch.cuda.current_stream().cuda_stream) or NULL, in which
+ * case the context creates and owns a non-blocking stream. */
+int esfm_ctx_create(int device, void *hip_stream, esfm_ctx **out);
+int esfm_ctx_destroy(esfm_ctx *ctx);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int esfm_ctx_synchronize(esfm_ctx *ctx);
+/* The hipStream_t the context enqueues on (for HIP-event timing by the caller). */
+void *esfm_ctx_stream(esfm_ctx *ctx);
+
+/* ---- pairwise matching ---------- */
+
+/*
+ * 2-NN search, the replacement for
+ *   matcher.knnMatch(q.descriptors, t.descriptors, nn2, 2)
+ * at cpp_code/src/feature_matching.cpp:125 (SURF, float L2; exact brute force
+ * as in python_code/feature_match.py:33-34) and :80 (ORB, "BruteForce-Hamming").
+ *
+ * Output for query row i: idx[2*i+k], dist[2*i+k], k = 0 (nearest), 1 (second).
+ * Ordering rule: ascending (distance, train index); ties go to the lower
+ * train index.  L2 distance = sqrtf of the float squared distance summed in the
+ * order documented in oracle/match_ref.c; Hamming distance is the exact bit
+ * count as float.  Missing neighbours (nt < 2) are reported as idx -1,
+ * dist FLT_MAX.  Host pointers.
+ */
+int esfm_knn2_l2_f32(esfm_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim,
+                     int32_t *idx /*2*nq*/, float *dist /*2*nq*/);
+int esfm_knn2_hamming(esfm_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
+                      int32_t *idx /*2*nq*/, float *dist /*2*nq*/);
+
+/*
+ * Whole body of FeatureMatching::matchFeaturesSURF / matchFeaturesORB
+ * (cpp_code/src/feature_matching.cpp:115-142 / :71-97) minus printing and GUI:
+ * 2-NN, then keep query i iff (double)d0 < ratio * (double)d1 (:133 / :88),
+ * survivors in ascending query order.  Writes at most nq entries to each output
+ * array (cv::DMatch::queryIdx, ::trainIdx, ::distance) and the count to *n_out.
+ * With nt < 2 (undefined behaviour in the reference) nothing is emitted.
+ * Host pointers.
+ */
+int esfm_match_l2_f32(esfm_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim, double ratio,
+                      int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
+int esfm_match_hamming(esfm_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes,
+                       double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
+
+/*
+ * Batched form of the pair loop cpp_code/test/sfm.cpp:140-161: all descriptor
+ * sets live in ONE device buffer (`desc_dev`, rows concatenated, row stride =
+ * dim floats or nbytes bytes); set s owns rows [set_row_offset[s],
+ * set_row_offset[s+1]).  pairs[2*p] = query set, pairs[2*p+1] = train set
+ * (the reference uses query = later frame i, train = earlier frame j < i).
+ *
+ * Outputs are device buffers: pair p owns the slice
+ * [out_offset[p], out_offset[p] + nq_p) of query_idx/train_idx/distance, of
+ * which the first n_out[p] entries are valid, query-ascending.  out_offset is
+ * a HOST array of n_pairs+1 entries filled by the call (exclusive prefix sum
+ * of nq_p), so the device arrays need sum(nq_p) entries.
+ * set_row_offset and pairs are HOST arrays.  Work is enqueued on the context's
+ * stream; the call does not synchronise.
+ */
+typedef enum esfm_metric { ESFM_L2_F32 = 0, ESFM_HAMMING = 1 } esfm_metric;
+
+int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
+                         const int32_t *set_row_offset, int n_sets, int width /*dim or nbytes*/,
+                         const int32_t *pairs, int n_pairs, double ratio,
+                         int32_t *query_idx_dev, int32_t *train_idx_dev, float *distance_dev,
+                         int32_t *n_out_dev /*n_pairs*/, int64_t *out_offset /*host, n_pairs+1*/);
+
+/* Same pass, but returns the raw 2-NN table instead of the filtered list:
+ * knn_idx_dev / knn_dist_dev hold 2 entries per query row, pair p at
+ * [2*out_offset[p], 2*(out_offset[p]+nq_p)). */
+int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
+                        const int32_t *set_row_offset, int n_sets, int width,
+                        const int32_t *pairs, int n_pairs,
+                        int32_t *knn_idx_dev, float *knn_dist_dev, int64_t *out_offset);
+
+/* Counters of the last L2 batched call on this context (after a synchronise):
+ * queries whose MFMA candidate list could not be certified and were re-scanned
+ * exactly (see DESIGN.md "certified re-rank").  For tests and profiling. */
+int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned);
+
+/* Host-only helper (no GPU needed): the (i, j<i) pair list of sfm.cpp:140-143
+ * for n_frames frames, restricted to shard `rank` of `world` by a cost-balanced
+ * partition (cost = nq*nt when rows_per_frame is given, else 1).  Writes pairs
+ * (query=i, train=j) to pairs_out (capacity n_frames*(n_frames-1)/2 pairs) and
+ * returns the number written, or a negative esfm_status. */
+int esfm_shard_pair_list(int n_frames, const int32_t *rows_per_frame /*or NULL*/, int rank, int world,
+                         int32_t *pairs_out);
+
+/* ---- bundle adjustment (SURVEY.md section 8 rows a-4 .. a-8) ------------- */
+
+/* Solver options.  Defaults (esfm_ba_options_default) are what
+ * cpp_code/src/ba.cpp:146-151,201-204 sets plus Ceres' own defaults for
+ * TRUST_REGION / LEVENBERG_MARQUARDT / DENSE_SCHUR ([upstream]). */
+typedef struct esfm_ba_options {
+    int32_t max_num_iterations;            /* 50      ba.cpp:202                     */
+    int32_t jacobi_scaling;                /* 1                                      */
+    int32_t max_num_consecutive_invalid_steps; /* 5                                  */
+    int32_t verbose;                       /* 1 = print Ceres-like progress lines     */
+    double cauchy_a;                       /* 0.5     ba.cpp:150; <= 0: squared loss  */
+    double initial_trust_region_radius;    /* 1e4                                    */
+    double max_trust_region_radius;        /* 1e16                                   */
+    double min_trust_region_radius;        /* 1e-32                                  */
+    double min_relative_decrease;          /* 1e-3                                   */
+    double min_lm_diagonal;                /* 1e-6                                   */
+    double max_lm_diagonal;                /* 1e32                                   */
+    double function_tolerance;             /* 1e-6                                   */
+    double gradient_tolerance;             /* 1e-10                                  */
+    double parameter_tolerance;            /* 1e-8                                   */
+} esfm_ba_options;
+
+typedef enum esfm_ba_termination {
+    ESFM_BA_CONVERGENCE = 0,     /* a tolerance was reached                   */
+    ESFM_BA_NO_CONVERGENCE = 1,  /* max_num_iterations reached                */
+    ESFM_BA_FAILURE = 2          /* too many invalid steps / numeric failure  */
+} esfm_ba_termination;
+
+typedef struct esfm_ba_iteration {
+    int32_t iteration;
+    int32_t step_is_valid;
+    int32_t step_is_successful;
+    int32_t reserved;
+    double cost;                 /* as Ceres logs it: candidate cost on a rejected step */
+    double cost_change;
+    double gradient_max_norm;
+    double step_norm;
+    double relative_decrease;    /* "tr_ratio" */
+    double trust_region_radius;  /* radius AFTER this iteration's update */
+    double model_cost_change;
+} esfm_ba_iteration;
+
+#define ESFM_BA_MAX_LOG 256
+
+typedef struct esfm_ba_summary {
+    int32_t termination;         /* esfm_ba_termination */
+    int32_t num_iterations;      /* entries in `iterations` minus 1 = LM iterations run */
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    int32_t num_active_cameras;  /* cameras / points with at least one observation */
+    int32_t num_active_points;
+    double initial_cost;
+    double final_cost;
+    double solve_seconds;        /* wall time of the LM loop (inputs already resident) */
+    esfm_ba_iteration iterations[ESFM_BA_MAX_LOG]; /* [0] is iteration 0 */
+} esfm_ba_summary;
+
+void esfm_ba_options_default(esfm_ba_options *opt);
+
+/* In-place SUM all-reduce over `count` doubles at device pointer `buf_dev`,
+ * ordered on `hip_stream`.  Return 0 on success.  Used only when the caller
+ * shards observations over several GPUs (one rank per GPU); NULL = single GPU.
+ * A torch.distributed (RCCL) implementation is in easysfm_amd/ba.py. */
+typedef int (*esfm_allreduce_fn)(void *user, double *buf_dev, int64_t count, void *hip_stream);
+
+/*
+ * The replacement for setBAProblem's parameter packing + solveBA's
+ * ceres::Solve (cpp_code/src/ba.cpp:58-114, :132-212) with calibration fixed
+ * (ReprojectErrorTerm_fixcalib, cpp_code/include/ba.h:108-164):
+ *
+ *   residual_k = uv_k - project(K[cam_k], AngleAxis(cams[cam_k][0..2]) * pts[pt_k] + cams[cam_k][3..5])
+ *   cost = 1/2 * sum_k rho(|residual_k|^2),  rho = Cauchy(a)  (ba.cpp:150)
+ *
+ * minimised by Levenberg-Marquardt with point-block Schur elimination
+ * (DENSE_SCHUR, ba.cpp:201).  cams (6 doubles per camera: angle-axis, then
+ * translation) and pts (3 doubles per point) are updated in place; parameter
+ * blocks with no observation are left bit-identical.  K4_per_cam holds
+ * fx, cx, fy, cy per camera (the four entries ba.h:142-143 reads).
+ * Observations may come in any order.  Host pointers.
+ *
+ * Multi-GPU: each rank passes its own shard of the observations (all cameras,
+ * all points, n_obs = local count) and the same allreduce callback; every rank
+ * ends with identical cams and the full pts.
+ */
+int esfm_ba_solve(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs,
+                  const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv /*2*n_obs*/,
+                  const float *K4_per_cam /*4*n_cam*/,
+                  double *cams /*6*n_cam*/, double *pts /*3*n_pt*/,
+                  const esfm_ba_options *options /*NULL = defaults*/,
+                  esfm_allreduce_fn allreduce /*or NULL*/, void *allreduce_user,
+                  esfm_ba_summary *summary /*or NULL*/);
+
+/* Resident form: upload once, iterate many times (what bench.py times). */
+typedef struct esfm_ba_problem esfm_ba_problem;
+
+int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs,
+                           const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                           const float *K4_per_cam, const double *cams, const double *pts,
+                           esfm_ba_problem **out);
+/* Re-upload the parameter vector (restart from a new initial guess). */
+int esfm_ba_problem_set_params(esfm_ba_problem *p, const double *cams, const double *pts);
+int esfm_ba_problem_solve(esfm_ba_problem *p, const esfm_ba_options *options,
+                          esfm_allreduce_fn allreduce, void *allreduce_user, esfm_ba_summary *summary);
+int esfm_ba_problem_get_params(esfm_ba_problem *p, double *cams, double *pts);
+int esfm_ba_problem_destroy(esfm_ba_problem *p);
+
+/* One evaluation of the robustified cost 1/2 sum rho(|r|^2) at the problem's
+ * current parameters (tests, and the candidate-cost kernel in isolation). */
+int esfm_ba_problem_cost(esfm_ba_problem *p, double cauchy_a, double *cost);
+
+/* Host-only helper (no GPU needed): assigns each point to one of `world`
+ * shards so that observation counts balance (greedy over points in index
+ * order), writing shard_of_point[n_pt].  Observations follow their point. */
+int esfm_ba_shard_points(int n_pt, int n_obs, const int32_t *pt_idx, int world, int32_t *shard_of_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESFM_H_ */

@@ -1,0 +1,245 @@
+"""ctypes front-end of the CPU oracle (oracle/match_ref.c, oracle/ba_ref.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (easysfm_amd/) never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[C.CDLL] = None
+_LIB_PATH: Optional[str] = None
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+class BAOptions(C.Structure):
+    """Mirror of esfm_ba_options (include/esfm.h)."""
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("verbose", C.c_int32),
+        ("cauchy_a", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+    ]
+
+
+class BAIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32),
+        ("step_is_valid", C.c_int32),
+        ("step_is_successful", C.c_int32),
+        ("reserved", C.c_int32),
+        ("cost", C.c_double),
+        ("cost_change", C.c_double),
+        ("gradient_max_norm", C.c_double),
+        ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+        ("model_cost_change", C.c_double),
+    ]
+
+
+BA_MAX_LOG = 256
+
+
+class BASummary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int32),
+        ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("num_active_cameras", C.c_int32),
+        ("num_active_points", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("solve_seconds", C.c_double),
+        ("iterations", BAIteration * BA_MAX_LOG),
+    ]
+
+
+def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
+    path = os.path.join(_HERE, out)
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
+    if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+        subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return path
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """Load (building if needed) the oracle shared library and set signatures."""
+    global _LIB, _LIB_PATH
+    if path is None:
+        path = os.path.join(_HERE, "libesfm_oracle.so")
+        if not os.path.exists(path):
+            build()
+    if _LIB is not None and _LIB_PATH == path:
+        return _LIB
+    lib = C.CDLL(path)
+    lib.esfm_ref_l2sqr.restype = C.c_float
+    lib.esfm_ref_l2sqr.argtypes = [_f32p, _f32p, C.c_int]
+    lib.esfm_ref_knn2_l2_f32.restype = None
+    lib.esfm_ref_knn2_l2_f32.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _i32p, _f32p]
+    lib.esfm_ref_knn2_hamming.restype = None
+    lib.esfm_ref_knn2_hamming.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, _i32p, _f32p]
+    lib.esfm_ref_ratio_filter.restype = C.c_int
+    lib.esfm_ref_ratio_filter.argtypes = [_i32p, _f32p, C.c_int, C.c_double, _i32p, _i32p, _f32p]
+    lib.esfm_ref_num_threads.restype = C.c_int
+    lib.esfm_ref_ba_residual_jac.restype = None
+    lib.esfm_ref_ba_residual_jac.argtypes = [_f64p, _f64p, _f32p, _f32p, _f64p, _f64p, _f64p]
+    lib.esfm_ref_ba_cost.restype = C.c_double
+    lib.esfm_ref_ba_cost.argtypes = [C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p, C.c_double]
+    lib.esfm_ref_ba_options_default.restype = None
+    lib.esfm_ref_ba_options_default.argtypes = [C.POINTER(BAOptions)]
+    lib.esfm_ref_ba_solve.restype = C.c_int
+    lib.esfm_ref_ba_solve.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p,
+                                      C.POINTER(BAOptions), C.POINTER(BASummary)]
+    lib.esfm_ref_ba_partial_reduced.restype = C.c_int
+    lib.esfm_ref_ba_partial_reduced.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p,
+                                                C.c_double, C.c_double, _f64p, _f64p, C.c_int, _f64p, _f64p]
+    lib.esfm_ref_ba_column_sqnorms.restype = C.c_int
+    lib.esfm_ref_ba_column_sqnorms.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p,
+                                               C.c_double, _f64p, _f64p]
+    _LIB, _LIB_PATH = lib, path
+    return lib
+
+
+# ----------------------------------------------------------------------------- matching
+def knn2_l2(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+    nq, dim = q.shape if q.ndim == 2 else (0, t.shape[1])
+    nt = t.shape[0]
+    idx = np.empty(2 * nq, np.int32); dist = np.empty(2 * nq, np.float32)
+    load().esfm_ref_knn2_l2_f32(q.reshape(-1), nq, t.reshape(-1), nt, dim, idx, dist)
+    return idx.reshape(nq, 2), dist.reshape(nq, 2)
+
+
+def knn2_hamming(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    nq, nb = q.shape
+    nt = t.shape[0]
+    idx = np.empty(2 * nq, np.int32); dist = np.empty(2 * nq, np.float32)
+    load().esfm_ref_knn2_hamming(q.reshape(-1), nq, t.reshape(-1), nt, nb, idx, dist)
+    return idx.reshape(nq, 2), dist.reshape(nq, 2)
+
+
+def ratio_filter(idx: np.ndarray, dist: np.ndarray, ratio: float):
+    nq = idx.shape[0]
+    qi = np.empty(max(nq, 1), np.int32); ti = np.empty(max(nq, 1), np.int32); d = np.empty(max(nq, 1), np.float32)
+    n = load().esfm_ref_ratio_filter(np.ascontiguousarray(idx, np.int32).reshape(-1),
+                                     np.ascontiguousarray(dist, np.float32).reshape(-1), nq, float(ratio), qi, ti, d)
+    return qi[:n].copy(), ti[:n].copy(), d[:n].copy()
+
+
+def match_l2(q, t, ratio=0.5):
+    """matchFeaturesSURF with exact brute force (feature_matching.cpp:115-142)."""
+    idx, dist = knn2_l2(q, t)
+    return ratio_filter(idx, dist, ratio)
+
+
+def match_hamming(q, t, ratio=0.8):
+    """matchFeaturesORB (feature_matching.cpp:71-97)."""
+    idx, dist = knn2_hamming(q, t)
+    return ratio_filter(idx, dist, ratio)
+
+
+def l2sqr(a, b) -> float:
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return float(load().esfm_ref_l2sqr(a, b, a.size))
+
+
+# ----------------------------------------------------------------------------- BA
+def ba_default_options() -> BAOptions:
+    o = BAOptions()
+    load().esfm_ref_ba_options_default(C.byref(o))
+    return o
+
+
+def ba_residual_jac(cam, pt, K4, uv):
+    r = np.empty(2); Jc = np.empty(12); Jp = np.empty(6)
+    load().esfm_ref_ba_residual_jac(np.ascontiguousarray(cam, np.float64), np.ascontiguousarray(pt, np.float64),
+                                    np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(uv, np.float32),
+                                    r, Jc, Jp)
+    return r, Jc.reshape(2, 6), Jp.reshape(2, 3)
+
+
+def ba_cost(cam_idx, pt_idx, uv, K4, cams, pts, cauchy_a=0.5) -> float:
+    return float(load().esfm_ref_ba_cost(len(cam_idx), np.ascontiguousarray(cam_idx, np.int32),
+                                         np.ascontiguousarray(pt_idx, np.int32),
+                                         np.ascontiguousarray(uv, np.float32).reshape(-1),
+                                         np.ascontiguousarray(K4, np.float32).reshape(-1),
+                                         np.ascontiguousarray(cams, np.float64).reshape(-1),
+                                         np.ascontiguousarray(pts, np.float64).reshape(-1), float(cauchy_a)))
+
+
+def ba_solve(cam_idx, pt_idx, uv, K4, cams, pts, options: Optional[BAOptions] = None):
+    """ceres::Solve restatement.  Returns (cams, pts, summary); inputs are not modified."""
+    cams = np.array(cams, np.float64, copy=True).reshape(-1, 6)
+    pts = np.array(pts, np.float64, copy=True).reshape(-1, 3)
+    summ = BASummary()
+    opt = options if options is not None else ba_default_options()
+    rc = load().esfm_ref_ba_solve(cams.shape[0], pts.shape[0], len(cam_idx),
+                                  np.ascontiguousarray(cam_idx, np.int32), np.ascontiguousarray(pt_idx, np.int32),
+                                  np.ascontiguousarray(uv, np.float32).reshape(-1),
+                                  np.ascontiguousarray(K4, np.float32).reshape(-1),
+                                  cams.reshape(-1), pts.reshape(-1), C.byref(opt), C.byref(summ))
+    if rc != 0:
+        raise RuntimeError(f"esfm_ref_ba_solve failed with {rc}")
+    return cams, pts, summ
+
+
+def ba_partial_reduced(n_cam, n_pt, cam_idx, pt_idx, uv, K4, cams, pts, cauchy_a, radius, diag_c, diag_p,
+                       add_cam_diag: bool):
+    n = 6 * n_cam
+    Sm = np.zeros(n * n); rhs = np.zeros(n)
+    rc = load().esfm_ref_ba_partial_reduced(n_cam, n_pt, len(cam_idx), np.ascontiguousarray(cam_idx, np.int32),
+                                            np.ascontiguousarray(pt_idx, np.int32),
+                                            np.ascontiguousarray(uv, np.float32).reshape(-1),
+                                            np.ascontiguousarray(K4, np.float32).reshape(-1),
+                                            np.ascontiguousarray(cams, np.float64).reshape(-1),
+                                            np.ascontiguousarray(pts, np.float64).reshape(-1),
+                                            float(cauchy_a), float(radius),
+                                            np.ascontiguousarray(diag_c, np.float64).reshape(-1),
+                                            np.ascontiguousarray(diag_p, np.float64).reshape(-1),
+                                            int(add_cam_diag), Sm, rhs)
+    if rc != 0:
+        raise RuntimeError("esfm_ref_ba_partial_reduced failed")
+    return Sm.reshape(n, n), rhs
+
+
+def ba_column_sqnorms(n_cam, n_pt, cam_idx, pt_idx, uv, K4, cams, pts, cauchy_a):
+    nc = np.zeros(6 * n_cam); npp = np.zeros(3 * n_pt)
+    rc = load().esfm_ref_ba_column_sqnorms(n_cam, n_pt, len(cam_idx), np.ascontiguousarray(cam_idx, np.int32),
+                                           np.ascontiguousarray(pt_idx, np.int32),
+                                           np.ascontiguousarray(uv, np.float32).reshape(-1),
+                                           np.ascontiguousarray(K4, np.float32).reshape(-1),
+                                           np.ascontiguousarray(cams, np.float64).reshape(-1),
+                                           np.ascontiguousarray(pts, np.float64).reshape(-1), float(cauchy_a), nc, npp)
+    if rc != 0:
+        raise RuntimeError("esfm_ref_ba_column_sqnorms failed")
+    return nc, npp
+
+
+def iterations(summ: BASummary):
+    return [summ.iterations[i] for i in range(min(summ.num_iterations + 1, BA_MAX_LOG))]
