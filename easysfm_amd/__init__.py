@@ -1,0 +1,14 @@
+"""easysfm_amd -- MI355X-native hot path of EasySFM (pairwise descriptor matching + bundle adjustment).
+
+The compute lives in libesfm_hip.so (hand-written HIP for gfx950 behind the C ABI of include/esfm.h);
+this package is the Python-side mirror of the reference's FeatureMatching / BundleAdjustment interface.
+Importing the package does not touch the GPU; the shared library is loaded on first use and there is
+no CPU fallback.
+"""
+from ._lib import BAOptions, BASummary, Context, EsfmError, ESFM_HAMMING, ESFM_L2_F32, LIB_PATH, lib  # noqa: F401
+from .types import DMatch, Frame, SparsePointCloud  # noqa: F401
+from .matching import (DescriptorBank, FeatureMatching, PairMatcher, knn_match_hamming, knn_match_l2,  # noqa: F401
+                       match_hamming, match_l2, shard_pair_list)
+from .ba import BAProblem, BundleAdjustment, ba_solve, default_options, shard_points, torch_allreduce_callback  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,177 @@
+"""ctypes binding of libesfm_hip.so (include/esfm.h).
+
+The shared library is the product: HIP kernels for gfx950 behind a C ABI.  This
+module only loads it and declares signatures.  There is no CPU fallback: if the
+library is missing, or no MI355X is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesfm_hip.so")
+
+ESFM_OK = 0
+ESFM_L2_F32 = 0
+ESFM_HAMMING = 1
+ESFM_REDUCE_SUM = 0
+ESFM_REDUCE_MAX = 1
+BA_MAX_LOG = 256
+
+STATUS_NAMES = {
+    0: "ESFM_OK", -1: "ESFM_ERR_INVALID_ARG", -2: "ESFM_ERR_NO_DEVICE", -3: "ESFM_ERR_HIP", -4: "ESFM_ERR_OOM",
+    -5: "ESFM_ERR_UNSUPPORTED", -6: "ESFM_ERR_NUMERIC", -7: "ESFM_ERR_COMM",
+}
+
+# every symbol include/esfm.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTED_SYMBOLS = [
+    "esfm_version", "esfm_last_error", "esfm_device_count", "esfm_ctx_create", "esfm_ctx_destroy",
+    "esfm_ctx_synchronize", "esfm_ctx_stream",
+    "esfm_knn2_l2_f32", "esfm_knn2_hamming", "esfm_match_l2_f32", "esfm_match_hamming",
+    "esfm_match_pairs_dev", "esfm_knn2_pairs_dev", "esfm_match_last_stats", "esfm_shard_pair_list",
+    "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
+    "esfm_ba_problem_solve", "esfm_ba_problem_get_params", "esfm_ba_problem_destroy", "esfm_ba_problem_cost",
+    "esfm_ba_shard_points",
+]
+
+
+class EsfmError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class BAOptions(C.Structure):
+    """esfm_ba_options (include/esfm.h)."""
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32), ("verbose", C.c_int32),
+        ("cauchy_a", C.c_double), ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+    ]
+
+
+class BAIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("reserved", C.c_int32),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double), ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double), ("model_cost_change", C.c_double),
+    ]
+
+
+class BASummary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int32), ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32), ("num_active_cameras", C.c_int32), ("num_active_points", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_seconds", C.c_double),
+        ("iterations", BAIteration * BA_MAX_LOG),
+    ]
+
+    def log(self):
+        return [self.iterations[i] for i in range(min(self.num_iterations + 1, BA_MAX_LOG))]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libesfm_hip.so (built by __graft_entry__.build() / easysfm_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C easysfm_amd/csrc`). "
+            "easysfm_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, f32p, f64p, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    L.esfm_version.restype = C.c_char_p
+    L.esfm_last_error.restype = C.c_char_p
+    L.esfm_device_count.restype = C.c_int
+    L.esfm_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.esfm_ctx_destroy.argtypes = [vp]
+    L.esfm_ctx_synchronize.argtypes = [vp]
+    L.esfm_ctx_stream.argtypes = [vp]
+    L.esfm_ctx_stream.restype = vp
+    L.esfm_knn2_l2_f32.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.esfm_knn2_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.esfm_match_l2_f32.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, i32p]
+    L.esfm_match_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, i32p]
+    L.esfm_match_pairs_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp]
+    L.esfm_knn2_pairs_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.esfm_match_last_stats.argtypes = [vp, i64p, i64p]
+    L.esfm_shard_pair_list.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]
+    L.esfm_ba_options_default.argtypes = [C.POINTER(BAOptions)]
+    L.esfm_ba_options_default.restype = None
+    L.esfm_ba_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(BAOptions), ALLREDUCE_FN, vp,
+                                C.POINTER(BASummary)]
+    L.esfm_ba_problem_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.esfm_ba_problem_set_params.argtypes = [vp, vp, vp]
+    L.esfm_ba_problem_solve.argtypes = [vp, C.POINTER(BAOptions), ALLREDUCE_FN, vp, C.POINTER(BASummary)]
+    L.esfm_ba_problem_get_params.argtypes = [vp, vp, vp]
+    L.esfm_ba_problem_destroy.argtypes = [vp]
+    L.esfm_ba_problem_cost.argtypes = [vp, C.c_double, f64p]
+    L.esfm_ba_shard_points.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("esfm_device_count",):
+            pass
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != ESFM_OK:
+        raise EsfmError(status, lib().esfm_last_error().decode("utf-8", "replace"))
+
+
+class Context:
+    """esfm_ctx: one per host thread and GPU.  `stream` is a hipStream_t handle (int), e.g.
+    torch.cuda.current_stream().cuda_stream; None lets the library own a stream."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        L = lib()
+        self._h = C.c_void_p()
+        check(L.esfm_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("context destroyed")
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return int(lib().esfm_ctx_stream(self.handle) or 0)
+
+    def synchronize(self) -> None:
+        check(lib().esfm_ctx_synchronize(self.handle))
+
+    def close(self) -> None:
+        if self._h:
+            lib().esfm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0, None)
+    return _default_ctx

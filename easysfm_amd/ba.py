@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's bundle-adjustment interface over the C ABI.
+
+``BundleAdjustment`` keeps the member names and argument meaning of cpp_code/include/ba.h:28-106
+(initBA, setBAProblem, solveBA, doSFMBA); ``ba_solve`` is the array-level call that maps 1:1 onto
+``esfm_ba_solve``.  The LM/Schur solve runs in libesfm_hip.so on the GPU; the only arithmetic done
+here is the reference's own host-side packing (Rodrigues conversion, float truncation on write-back).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import ALLREDUCE_FN, BAOptions, BASummary, Context, ESFM_REDUCE_MAX, ESFM_REDUCE_SUM, check, default_context, lib
+from .types import Frame, SparsePointCloud
+
+
+def default_options() -> BAOptions:
+    o = BAOptions()
+    lib().esfm_ba_options_default(C.byref(o))
+    return o
+
+
+def _p(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+_NULL_ALLREDUCE = C.cast(None, ALLREDUCE_FN)
+
+
+class _DevArray:
+    """Zero-copy view of a device pointer for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def torch_allreduce_callback(group=None):
+    """esfm_allreduce_fn backed by torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+    The solver's context must have been created on torch's current stream, so that the collective
+    is ordered after the kernels that produced the buffer and before the ones that consume it."""
+    import torch
+    import torch.distributed as dist
+
+    def _cb(user, buf, count, op, stream):
+        try:
+            t = torch.as_tensor(_DevArray(buf, count), device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == ESFM_REDUCE_SUM else dist.ReduceOp.MAX, group=group)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print(f"[easysfm_amd] all-reduce callback failed: {e!r}", flush=True)
+            return 1
+
+    return ALLREDUCE_FN(_cb)
+
+
+class BAProblem:
+    """Resident problem (esfm_ba_problem): upload once, solve/iterate many times."""
+
+    def __init__(self, cam_idx, pt_idx, uv, K4, cams, pts, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self.cam_idx = np.ascontiguousarray(cam_idx, np.int32).reshape(-1)
+        self.pt_idx = np.ascontiguousarray(pt_idx, np.int32).reshape(-1)
+        self.uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        self.K4 = np.ascontiguousarray(K4, np.float32).reshape(-1, 4)
+        cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        self.n_cam, self.n_pt, self.n_obs = cams.shape[0], pts.shape[0], self.cam_idx.shape[0]
+        if self.K4.shape[0] != self.n_cam or self.pt_idx.shape[0] != self.n_obs or self.uv.shape[0] != self.n_obs:
+            raise ValueError("inconsistent BA array sizes")
+        self._h = C.c_void_p()
+        check(lib().esfm_ba_problem_create(self.ctx.handle, self.n_cam, self.n_pt, self.n_obs, _p(self.cam_idx), _p(self.pt_idx),
+                                           _p(self.uv), _p(self.K4), _p(cams), _p(pts), C.byref(self._h)))
+
+    def set_params(self, cams, pts) -> None:
+        cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6); pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        check(lib().esfm_ba_problem_set_params(self._h, _p(cams), _p(pts)))
+
+    def solve(self, options: Optional[BAOptions] = None, allreduce=None) -> BASummary:
+        summ = BASummary()
+        opt = options if options is not None else default_options()
+        cb = allreduce if allreduce is not None else _NULL_ALLREDUCE
+        check(lib().esfm_ba_problem_solve(self._h, C.byref(opt), cb, None, C.byref(summ)))
+        return summ
+
+    def get_params(self) -> Tuple[np.ndarray, np.ndarray]:
+        cams = np.empty((self.n_cam, 6), np.float64); pts = np.empty((self.n_pt, 3), np.float64)
+        check(lib().esfm_ba_problem_get_params(self._h, _p(cams), _p(pts)))
+        return cams, pts
+
+    def cost(self, cauchy_a: float = 0.5) -> float:
+        c = C.c_double(0.0)
+        check(lib().esfm_ba_problem_cost(self._h, float(cauchy_a), C.byref(c)))
+        return c.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().esfm_ba_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ba_solve(cam_idx, pt_idx, uv, K4, cams, pts, options: Optional[BAOptions] = None, ctx: Optional[Context] = None,
+             allreduce=None) -> Tuple[np.ndarray, np.ndarray, BASummary]:
+    """esfm_ba_solve: returns (cams, pts, summary); the inputs are not modified."""
+    prob = BAProblem(cam_idx, pt_idx, uv, K4, cams, pts, ctx)
+    try:
+        summ = prob.solve(options, allreduce)
+        c, p = prob.get_params()
+    finally:
+        prob.close()
+    return c, p, summ
+
+
+def shard_points(n_pt: int, pt_idx, world: int) -> np.ndarray:
+    """Point -> shard assignment balanced by observation count (host-only, no GPU)."""
+    pt_idx = np.ascontiguousarray(pt_idx, np.int32)
+    out = np.zeros(max(n_pt, 1), np.int32)
+    check(lib().esfm_ba_shard_points(int(n_pt), len(pt_idx), _p(pt_idx), int(world), _p(out)))
+    return out[:n_pt]
+
+
+# ------------------------------------------------------------------------------------------------
+# cv::Rodrigues as the reference uses it (ba.cpp:82 matrix -> vector, :239 vector -> matrix).
+def rotation_to_angle_axis(R: np.ndarray) -> np.ndarray:
+    R = np.asarray(R, np.float64)
+    # orthonormalise first, as OpenCV does (R = U V^T) [upstream calib3d Rodrigues]
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    r = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.sqrt((r * r).sum() * 0.25)
+    c = np.clip((np.trace(R) - 1.0) * 0.5, -1.0, 1.0)
+    theta = np.arccos(c)
+    if s < 1e-5:
+        if c > 0:
+            return np.zeros(3)
+        t = (np.diag(R) + 1.0) * 0.5
+        v = np.sqrt(np.maximum(t, 0.0))
+        if R[0, 1] < 0: v[1] = -v[1]
+        if R[0, 2] < 0: v[2] = -v[2]
+        if (R[1, 2] > 0) != (v[1] * v[2] > 0): v[2] = -v[2]
+        return v * (theta / max(np.linalg.norm(v), 1e-300))
+    return r * (0.5 * theta / s)
+
+
+def angle_axis_to_rotation(aa: np.ndarray) -> np.ndarray:
+    aa = np.asarray(aa, np.float64)
+    theta = np.linalg.norm(aa)
+    if theta < np.finfo(np.float64).eps:
+        return np.eye(3)
+    k = aa / theta
+    c, s = np.cos(theta), np.sin(theta)
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return c * np.eye(3) + (1 - c) * np.outer(k, k) + s * Kx
+
+
+class BundleAdjustment:
+    """Mirror of p3dv::BundleAdjustment (ba.h:28-106)."""
+
+    def __init__(self, ctx: Optional[Context] = None, options: Optional[BAOptions] = None):
+        self._ctx = ctx
+        self.options = options
+        self.initBA()
+
+    def initBA(self) -> bool:
+        """ba.h:59-75."""
+        self.point_index_ = np.zeros(0, np.int32)
+        self.camera_index_ = np.zeros(0, np.int32)
+        self.points_2d_ = np.zeros((0, 2), np.float32)
+        self.calibs_: List[np.ndarray] = []
+        self.num_cameras_ = 0
+        self.num_points_ = 0
+        self.num_parameters_ = 0
+        self.num_observations_ = 0
+        self.ref_process_camera_id_ = -1
+        self.parameters_ = np.zeros(0, np.float64)
+        self.summary: Optional[BASummary] = None
+        return True
+
+    def setBAProblem(self, frames: Sequence[Frame], process_frame_id: Sequence[bool], sfm_sparse_points: SparsePointCloud,
+                     fix_calib_tolerance_BA: float = 0.0, reference_frame_id: int = -1) -> bool:
+        """ba.cpp:12-130.  Same observation list, in the same order (camera-major, point index
+        ascending), as the reference's O(Ncam*Npts*Nkp) triple loop (:22-56), derived with an
+        O(N log N) join: for every registered frame, each point picks the FIRST keypoint j with
+        unique_pixel_has_match[j] and unique_pixel_ids[j] == unique_point_ids[k] (the `break` at :44)."""
+        pid = np.asarray(sfm_sparse_points.unique_point_ids, np.int64)
+        self.num_points_ = len(pid)
+        cams_i, pts_i, uv = [], [], []
+        self.num_cameras_ = 0
+        for i, fr in enumerate(frames):
+            if process_frame_id[i]:  # 0 = registered
+                continue
+            self.calibs_.append(np.asarray(fr.K_cam, np.float32))
+            ids = np.asarray(fr.unique_pixel_ids, np.int64)
+            cand = np.nonzero(np.asarray(fr.unique_pixel_has_match, bool))[0]
+            if len(cand) and len(pid):
+                cid = ids[cand]
+                order = np.lexsort((cand, cid))            # by id, then lowest keypoint index first
+                cid_s, cand_s = cid[order], cand[order]
+                first = np.ones(len(cid_s), bool); first[1:] = cid_s[1:] != cid_s[:-1]
+                u_id, u_j = cid_s[first], cand_s[first]
+                pos = np.searchsorted(u_id, pid)
+                pos_c = np.minimum(pos, len(u_id) - 1)
+                hit = u_id[pos_c] == pid
+                k_idx = np.nonzero(hit)[0]
+                j_idx = u_j[pos_c[hit]]
+                cams_i.append(np.full(len(k_idx), self.num_cameras_, np.int32))
+                pts_i.append(k_idx.astype(np.int32))
+                uv.append(np.asarray(fr.keypoints, np.float32).reshape(-1, 2)[j_idx])
+            if i == reference_frame_id:
+                self.ref_process_camera_id_ = self.num_cameras_
+            self.num_cameras_ += 1
+        self.camera_index_ = np.concatenate(cams_i) if cams_i else np.zeros(0, np.int32)
+        self.point_index_ = np.concatenate(pts_i) if pts_i else np.zeros(0, np.int32)
+        self.points_2d_ = np.concatenate(uv) if uv else np.zeros((0, 2), np.float32)
+        self.num_observations_ = len(self.camera_index_)
+        self.num_parameters_ = 6 * self.num_cameras_ + 3 * self.num_points_ + (4 if fix_calib_tolerance_BA != 0 else 0)
+        par = np.zeros(self.num_parameters_, np.float64)
+        k = 0
+        for i, fr in enumerate(frames):
+            if process_frame_id[i]:
+                continue
+            pose = np.asarray(fr.pose_cam, np.float32)
+            rvec = rotation_to_angle_axis(pose[:3, :3]).astype(np.float32)   # cv::Rodrigues on a CV_32F matrix (:82)
+            par[6 * k:6 * k + 3] = rvec.astype(np.float64)
+            par[6 * k + 3:6 * k + 6] = pose[:3, 3].astype(np.float64)
+            k += 1
+        xyz = np.asarray(sfm_sparse_points.xyz, np.float32).reshape(-1, 3)
+        par[6 * self.num_cameras_:6 * self.num_cameras_ + 3 * self.num_points_] = xyz.astype(np.float64).reshape(-1)
+        if fix_calib_tolerance_BA != 0 and self.calibs_:
+            K0 = self.calibs_[0]
+            par[-4:] = [K0[0, 0], K0[0, 2], K0[1, 1], K0[1, 2]]
+        self.parameters_ = par
+        return 2 * self.num_observations_ > self.num_parameters_   # "Ready to solve" (:120-129)
+
+    def solveBA(self, fix_calib_tolerance_BA: float = 0.0) -> bool:
+        """ba.cpp:132-212 with calibration fixed (the only mode every BASELINE config uses)."""
+        if fix_calib_tolerance_BA != 0 or self.ref_process_camera_id_ >= 0:
+            raise NotImplementedError("free-intrinsics / fixed-reference-camera BA (ba.cpp:155-196, run_zurich.sh only) "
+                                      "is the 'next' row f-4 of SURVEY.md section 8 and is not built yet")
+        nc, npt = self.num_cameras_, self.num_points_
+        K4 = np.array([[K[0, 0], K[0, 2], K[1, 1], K[1, 2]] for K in self.calibs_], np.float32).reshape(-1, 4)
+        cams = self.parameters_[:6 * nc].reshape(nc, 6)
+        pts = self.parameters_[6 * nc:6 * nc + 3 * npt].reshape(npt, 3)
+        c, p, summ = ba_solve(self.camera_index_, self.point_index_, self.points_2d_, K4, cams, pts, self.options,
+                              self._ctx or default_context())
+        self.parameters_[:6 * nc] = c.reshape(-1)
+        self.parameters_[6 * nc:6 * nc + 3 * npt] = p.reshape(-1)
+        self.summary = summ
+        return True
+
+    def doSFMBA(self, frames: Sequence[Frame], process_frame_id: Sequence[bool], sfm_sparse_points: SparsePointCloud,
+                fix_calib_tolerance_BA: float = 0.0, reference_frame_id: int = -1) -> bool:
+        """ba.cpp:214-288: initBA, setBAProblem, solveBA, then the float write-back (:223-281)."""
+        self.initBA()
+        self.setBAProblem(frames, process_frame_id, sfm_sparse_points, fix_calib_tolerance_BA, reference_frame_id)
+        self.solveBA(fix_calib_tolerance_BA)
+        k = 0
+        for i, fr in enumerate(frames):
+            if process_frame_id[i]:
+                continue
+            rvec = self.parameters_[6 * k:6 * k + 3].astype(np.float32)                 # :235-237 (float)
+            pose = np.array(fr.pose_cam, np.float32, copy=True)
+            pose[:3, :3] = angle_axis_to_rotation(rvec.astype(np.float64)).astype(np.float32)
+            pose[:3, 3] = self.parameters_[6 * k + 3:6 * k + 6].astype(np.float32)      # :244-246
+            fr.pose_cam = pose
+            k += 1
+        nc, npt = self.num_cameras_, self.num_points_
+        sfm_sparse_points.xyz = self.parameters_[6 * nc:6 * nc + 3 * npt].reshape(npt, 3).astype(np.float32)  # :277-279
+        return True

@@ -1,0 +1,448 @@
+// C-ABI entry points for bundle adjustment (include/esfm.h, rows a-4..a-8 of SURVEY.md section 8).
+// The Levenberg-Marquardt control flow restates Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy
+// with DENSE_SCHUR, which is what BundleAdjustment::solveBA configures (reference
+// cpp_code/src/ba.cpp:146-151, :201-206); the oracle (oracle/ba_ref.c) documents the upstream rules.
+// All arithmetic on the observations runs in ba_kernels.hip; this file only sequences kernels, reads
+// back a handful of scalars per iteration and takes the accept/reject decision.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cfloat>
+#include <vector>
+
+#include "ba_kernels.hpp"
+
+using esfm::BADev;
+
+struct esfm_ba_problem {
+    esfm_ctx *ctx = nullptr;
+    BADev d;
+    std::vector<void *> allocs;
+    std::vector<double> cam_nobs_local;  // this rank's observation count per camera
+    bool params_swapped = false;
+};
+
+namespace {
+
+template <class T> int dev_alloc(esfm_ba_problem *p, T **out, size_t count)
+{
+    void *ptr = nullptr;
+    const size_t bytes = sizeof(T) * std::max<size_t>(count, 1);
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) {
+        esfm::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;
+    }
+    p->allocs.push_back(ptr);
+    *out = reinterpret_cast<T *>(ptr);
+    return ESFM_OK;
+}
+
+void options_default(esfm_ba_options *o)
+{
+    o->max_num_iterations = 50;  // ba.cpp:202
+    o->jacobi_scaling = 1;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->verbose = 0;
+    o->cauchy_a = 0.5;  // ba.cpp:150
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+}
+
+struct Solver {
+    esfm_ba_problem *P;
+    esfm_ba_options opt;
+    esfm_allreduce_fn ar;
+    void *ar_user;
+    hipStream_t st;
+    double h[esfm::SC_COUNT];
+
+    int allreduce(double *buf, int64_t count, int op)
+    {
+        if (!ar || count <= 0) return ESFM_OK;
+        if (ar(ar_user, buf, count, op, reinterpret_cast<void *>(st)) != 0) {
+            esfm::set_error("all-reduce callback failed");
+            return ESFM_ERR_COMM;
+        }
+        return ESFM_OK;
+    }
+    int zero_scal() { ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st)); return ESFM_OK; }
+    // SUM the partial-sum slots and MAX the gradient slot across ranks, then fetch all scalars.
+    int fetch_scal()
+    {
+        if (int rc = allreduce(P->d.scal, esfm::SC_SUM_COUNT, ESFM_REDUCE_SUM)) return rc;
+        if (int rc = allreduce(P->d.scal + esfm::SC_GMAX, 1, ESFM_REDUCE_MAX)) return rc;
+        ESFM_HIP_TRY(hipMemcpyAsync(h, P->d.scal, sizeof(double) * esfm::SC_COUNT, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipStreamSynchronize(st));
+        return ESFM_OK;
+    }
+    // residuals + Jacobian at x, per-camera sums, per-point blocks; leaves cost/gmax in h[].
+    int linearize(bool use_scaling, double radius)
+    {
+        const BADev &d = P->d;
+        if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling)) return rc;
+        if (int rc = allreduce(d.camacc, (int64_t)esfm::ba_camacc_doubles(d.n_cam), ESFM_REDUCE_SUM)) return rc;
+        if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, true)) return rc;
+        return ESFM_OK;
+    }
+};
+
+int fill_ones(hipStream_t st, double *dst, size_t n)
+{
+    std::vector<double> ones(n, 1.0);
+    if (n == 0) return ESFM_OK;
+    ESFM_HIP_TRY(hipMemcpyAsync(dst, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    return ESFM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void esfm_ba_options_default(esfm_ba_options *opt) { if (opt) options_default(opt); }
+
+int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
+                           const float *obs_uv, const float *K4_per_cam, const double *cams, const double *pts,
+                           esfm_ba_problem **out)
+{
+    if (!ctx || !out) { esfm::set_error("ctx/out is NULL"); return ESFM_ERR_INVALID_ARG; }
+    *out = nullptr;
+    ESFM_REQUIRE(n_cam >= 0 && n_pt >= 0 && n_obs >= 0, "negative size");
+    ESFM_REQUIRE(n_obs == 0 || (cam_idx && pt_idx && obs_uv), "observation arrays are NULL");
+    ESFM_REQUIRE(n_cam == 0 || (K4_per_cam && cams), "camera arrays are NULL");
+    ESFM_REQUIRE(n_pt == 0 || pts, "pts is NULL");
+    ESFM_REQUIRE((int64_t)6 * n_cam < 46000, "reduced system too large for this build (6 n_cam < 46000)");
+    for (int k = 0; k < n_obs; ++k)
+        ESFM_REQUIRE(cam_idx[k] >= 0 && cam_idx[k] < n_cam && pt_idx[k] >= 0 && pt_idx[k] < n_pt, "observation index out of range");
+    for (size_t i = 0; i < (size_t)6 * n_cam; ++i) if (!std::isfinite(cams[i])) { esfm::set_error("non-finite camera parameter"); return ESFM_ERR_NUMERIC; }
+    for (size_t i = 0; i < (size_t)3 * n_pt; ++i) if (!std::isfinite(pts[i])) { esfm::set_error("non-finite point parameter"); return ESFM_ERR_NUMERIC; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+
+    // group observations by point (counting sort, stable: keeps the caller's order inside a point)
+    std::vector<int32_t> pt_start((size_t)n_pt + 1, 0), order((size_t)n_obs), s_cam((size_t)n_obs), s_pt((size_t)n_obs);
+    std::vector<float> s_uv((size_t)2 * n_obs);
+    for (int k = 0; k < n_obs; ++k) pt_start[(size_t)pt_idx[k] + 1]++;
+    for (int p = 0; p < n_pt; ++p) pt_start[(size_t)p + 1] += pt_start[(size_t)p];
+    {
+        std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
+        for (int k = 0; k < n_obs; ++k) order[(size_t)fill[(size_t)pt_idx[k]]++] = k;
+    }
+    auto P = new esfm_ba_problem();
+    P->ctx = ctx;
+    P->cam_nobs_local.assign((size_t)n_cam, 0.0);
+    for (int t = 0; t < n_obs; ++t) {
+        const int k = order[(size_t)t];
+        s_cam[(size_t)t] = cam_idx[k]; s_pt[(size_t)t] = pt_idx[k];
+        s_uv[2 * (size_t)t] = obs_uv[2 * (size_t)k]; s_uv[2 * (size_t)t + 1] = obs_uv[2 * (size_t)k + 1];
+        P->cam_nobs_local[(size_t)cam_idx[k]] += 1.0;
+    }
+    BADev &d = P->d;
+    d.n_cam = n_cam; d.n_pt = n_pt; d.n_obs = n_obs;
+    const size_t no = (size_t)n_obs, nc6 = (size_t)6 * n_cam, np3 = (size_t)3 * n_pt;
+    int rc = ESFM_OK;
+    auto A = [&](auto **ptr, size_t count) { if (rc == ESFM_OK) rc = dev_alloc(P, ptr, count); };
+    A(&d.obs_cam, no); A(&d.obs_pt, no); A(&d.obs_uv, no); A(&d.pt_start, (size_t)n_pt + 1); A(&d.K4, (size_t)n_cam);
+    A(&d.cam_nobs, (size_t)n_cam);
+    A(&d.x_c, nc6); A(&d.x_p, np3); A(&d.cand_c, nc6); A(&d.cand_p, np3); A(&d.x0_p, np3);
+    A(&d.Jc, 12 * no); A(&d.Jp, 6 * no); A(&d.res, 2 * no);
+    A(&d.scale_c, nc6); A(&d.scale_p, np3);
+    A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3);
+    A(&d.camacc, esfm::ba_camacc_doubles(n_cam)); A(&d.red, esfm::ba_red_doubles(n_cam));
+    A(&d.y_c, nc6); A(&d.scal, (size_t)esfm::SC_COUNT);
+    A(&d.chol, (nc6 + 1) * (nc6 + 2) / 2 + 2);
+    if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
+    hipStream_t st = ctx->stream;
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        if (rc == ESFM_OK && bytes) {
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) { esfm::set_error("hipMemcpyAsync H2D failed: %s", hipGetErrorString(e)); rc = ESFM_ERR_HIP; }
+        }
+    };
+    up(d.obs_cam, s_cam.data(), sizeof(int32_t) * no); up(d.obs_pt, s_pt.data(), sizeof(int32_t) * no);
+    up(d.obs_uv, s_uv.data(), sizeof(float) * 2 * no); up(d.pt_start, pt_start.data(), sizeof(int32_t) * ((size_t)n_pt + 1));
+    up(d.K4, K4_per_cam, sizeof(float) * 4 * (size_t)n_cam);
+    up(d.x_c, cams, sizeof(double) * nc6); up(d.x_p, pts, sizeof(double) * np3);
+    if (rc == ESFM_OK && hipStreamSynchronize(st) != hipSuccess) { esfm::set_error("stream sync failed"); rc = ESFM_ERR_HIP; }
+    if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
+    *out = P;
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_set_params(esfm_ba_problem *P, const double *cams, const double *pts)
+{
+    if (!P || (!cams && P->d.n_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(P->ctx)) return rc;
+    hipStream_t st = P->ctx->stream;
+    if (P->d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_c, cams, sizeof(double) * 6 * (size_t)P->d.n_cam, hipMemcpyHostToDevice, st));
+    if (P->d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_p, pts, sizeof(double) * 3 * (size_t)P->d.n_pt, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_get_params(esfm_ba_problem *P, double *cams, double *pts)
+{
+    if (!P || (!cams && P->d.n_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(P->ctx)) return rc;
+    hipStream_t st = P->ctx->stream;
+    if (P->d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(cams, P->d.x_c, sizeof(double) * 6 * (size_t)P->d.n_cam, hipMemcpyDeviceToHost, st));
+    if (P->d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(pts, P->d.x_p, sizeof(double) * 3 * (size_t)P->d.n_pt, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_destroy(esfm_ba_problem *P)
+{
+    if (!P) return ESFM_OK;
+    if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
+    for (void *p : P->allocs) (void)hipFree(p);
+    delete P;
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_cost(esfm_ba_problem *P, double cauchy_a, double *cost)
+{
+    if (!P || !cost) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(P->ctx)) return rc;
+    hipStream_t st = P->ctx->stream;
+    ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
+    if (int rc = esfm::ba_cost(st, P->d, P->ctx->num_cu, P->d.x_c, P->d.x_p, cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD)) return rc;
+    double h[esfm::SC_COUNT];
+    ESFM_HIP_TRY(hipMemcpyAsync(h, P->d.scal, sizeof(h), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    *cost = h[esfm::SC_CAND_BAD] > 0.0 ? DBL_MAX : h[esfm::SC_CAND_COST];
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, esfm_allreduce_fn allreduce, void *allreduce_user,
+                          esfm_ba_summary *sum)
+{
+    if (!P) { esfm::set_error("problem is NULL"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(P->ctx)) return rc;
+    esfm_ba_summary local_sum;
+    if (!sum) sum = &local_sum;
+    memset(sum, 0, sizeof(*sum));
+    Solver S;
+    S.P = P; S.ar = allreduce; S.ar_user = allreduce_user; S.st = P->ctx->stream;
+    if (options) S.opt = *options; else options_default(&S.opt);
+    const esfm_ba_options &opt = S.opt;
+    ESFM_REQUIRE(opt.initial_trust_region_radius > 0.0 && opt.max_num_iterations >= 0, "bad options");
+    BADev &d = P->d;
+    hipStream_t st = S.st;
+    const bool multi = allreduce != nullptr;
+    double *h = S.h;
+
+    // camera observation counts over all shards; Jacobi scaling starts at 1
+    if (d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(d.cam_nobs, P->cam_nobs_local.data(), sizeof(double) * (size_t)d.n_cam, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = S.allreduce(d.cam_nobs, d.n_cam, ESFM_REDUCE_SUM)) return rc;
+    if (int rc = fill_ones(st, d.scale_c, (size_t)6 * d.n_cam)) return rc;
+    if (int rc = fill_ones(st, d.scale_p, (size_t)3 * d.n_pt)) return rc;
+    if (multi && d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(d.x0_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
+    {
+        std::vector<double> cn((size_t)d.n_cam);
+        if (d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(cn.data(), d.cam_nobs, sizeof(double) * (size_t)d.n_cam, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> ps((size_t)d.n_pt + 1);
+        ESFM_HIP_TRY(hipMemcpyAsync(ps.data(), d.pt_start, sizeof(int32_t) * ((size_t)d.n_pt + 1), hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipStreamSynchronize(st));
+        for (double v : cn) sum->num_active_cameras += v > 0.0;
+        for (int p = 0; p < d.n_pt; ++p) sum->num_active_points += ps[(size_t)p + 1] > ps[(size_t)p];
+    }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    auto finish = [&](int rc) {
+        sum->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    };
+
+    // ---- iteration 0 (TrustRegionMinimizer::IterationZero) ----
+    double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+    if (int rc = S.zero_scal()) return finish(rc);
+    if (int rc = esfm::ba_param_sqnorm(st, d)) return finish(rc);
+    if (int rc = S.linearize(false, radius)) return finish(rc);
+    if (opt.jacobi_scaling) {
+        if (int rc = esfm::ba_jacobi_scaling(st, d)) return finish(rc);
+        // keep |x|^2, restart the other accumulators, and linearise again with scaled columns
+        ESFM_HIP_TRY(hipMemsetAsync(d.scal, 0, sizeof(double) * esfm::SC_XNORM_SQ_PT, st));
+        ESFM_HIP_TRY(hipMemsetAsync(d.scal + esfm::SC_LIN_BAD, 0, sizeof(double) * (esfm::SC_SUM_COUNT - esfm::SC_LIN_BAD), st));
+        ESFM_HIP_TRY(hipMemsetAsync(d.scal + esfm::SC_GMAX, 0, sizeof(double), st));
+        if (int rc = S.linearize(true, radius)) return finish(rc);
+    }
+    if (int rc = esfm::ba_camera_gradient(st, d)) return finish(rc);
+    if (int rc = S.fetch_scal()) return finish(rc);
+    if (h[esfm::SC_LIN_BAD] > 0.0) {
+        esfm::set_error("non-finite residual or Jacobian at the initial point");
+        sum->termination = ESFM_BA_FAILURE;
+        return finish(ESFM_ERR_NUMERIC);
+    }
+    double x_cost = h[esfm::SC_COST];
+    double gmax = h[esfm::SC_GMAX];
+    double x_norm = std::sqrt(h[esfm::SC_XNORM_SQ_PT] + h[esfm::SC_XNORM_SQ_CAM]);
+    double prep_radius = radius;  // radius the per-point inverses were built with
+    bool reuse_diagonal = false;  // the LM diagonal is a function of J only; kept for parity with the strategy's state
+    int n_invalid = 0;
+    sum->initial_cost = x_cost;
+    {
+        esfm_ba_iteration &it = sum->iterations[0];
+        it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1; it.cost = x_cost;
+        it.gradient_max_norm = gmax; it.trust_region_radius = radius;
+    }
+    sum->num_iterations = 0; sum->num_successful_steps = 1;
+    if (opt.verbose)
+        printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e  % .2e  % .2e  % .2e  % .2e  % .2e\n",
+               0, x_cost, 0.0, gmax, 0.0, 0.0, radius);
+    bool terminated = false;
+    int rc_final = ESFM_OK;
+    if (gmax <= opt.gradient_tolerance) { sum->termination = ESFM_BA_CONVERGENCE; terminated = true; }
+
+    // ---- main loop (TrustRegionMinimizer::Minimize) ----
+    int iter = 0;
+    double last_gmax = gmax;
+    while (!terminated) {
+        if (iter >= opt.max_num_iterations) { sum->termination = ESFM_BA_NO_CONVERGENCE; break; }
+        if (radius <= opt.min_trust_region_radius) { sum->termination = ESFM_BA_CONVERGENCE; break; }
+        ++iter;
+        esfm_ba_iteration cur;
+        memset(&cur, 0, sizeof(cur));
+        cur.iteration = iter; cur.gradient_max_norm = last_gmax;
+        // LevenbergMarquardtStrategy::ComputeStep: D^2 = clamp(diag(J'J)) / radius, then the Schur solve
+        if (prep_radius != radius) {
+            if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false)) return finish(rc);
+            prep_radius = radius;
+        }
+        ESFM_HIP_TRY(hipMemsetAsync(d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
+        if (int rc = esfm::ba_schur(st, d)) return finish(rc);
+        if (int rc = S.allreduce(d.red, (int64_t)esfm::ba_red_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
+        if (int rc = esfm::ba_solve_reduced(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal)) return finish(rc);
+        if (int rc = esfm::ba_camera_step(st, d)) return finish(rc);
+        if (int rc = esfm::ba_backsub(st, d)) return finish(rc);
+        if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD)) return finish(rc);
+        if (int rc = S.fetch_scal()) return finish(rc);
+        reuse_diagonal = true;
+        const double model_cost_change = h[esfm::SC_MODEL_CHANGE];
+        const double step_norm = std::sqrt(h[esfm::SC_STEP_SQ_PT] + h[esfm::SC_STEP_SQ_CAM]);
+        const double cand_norm = std::sqrt(h[esfm::SC_CAND_SQ_PT] + h[esfm::SC_CAND_SQ_CAM]);
+        const bool lin_ok = h[esfm::SC_CHOL_FAIL] == 0.0 && h[esfm::SC_PT_SINGULAR] == 0.0 && std::isfinite(model_cost_change) &&
+                            std::isfinite(step_norm);
+        cur.model_cost_change = model_cost_change;
+        cur.step_is_valid = lin_ok && (model_cost_change > 0.0);
+        if (!cur.step_is_valid) {
+            // HandleInvalidStep + StepIsInvalid
+            if (++n_invalid >= opt.max_num_consecutive_invalid_steps) { sum->termination = ESFM_BA_FAILURE; terminated = true; }
+            radius *= 0.5; reuse_diagonal = true;
+            cur.cost = x_cost; cur.trust_region_radius = radius;
+            sum->num_unsuccessful_steps++;
+            if (iter < ESFM_BA_MAX_LOG) sum->iterations[iter] = cur;
+            sum->num_iterations = iter;
+            continue;
+        }
+        n_invalid = 0;
+        const double cand_cost = h[esfm::SC_CAND_BAD] > 0.0 ? DBL_MAX : h[esfm::SC_CAND_COST];
+        cur.step_norm = step_norm;
+        cur.cost_change = x_cost - cand_cost;
+        auto log_and_stop = [&]() {
+            sum->termination = ESFM_BA_CONVERGENCE; terminated = true;
+            cur.cost = x_cost; cur.trust_region_radius = radius;
+            if (iter < ESFM_BA_MAX_LOG) sum->iterations[iter] = cur;
+            sum->num_iterations = iter;
+        };
+        // ParameterToleranceReached / FunctionToleranceReached: tested before acceptance, step not applied
+        if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { log_and_stop(); break; }
+        if (std::fabs(cur.cost_change) <= opt.function_tolerance * x_cost) { log_and_stop(); break; }
+        cur.relative_decrease = (x_cost - cand_cost) / model_cost_change;
+        if (cur.relative_decrease > opt.min_relative_decrease) {
+            // HandleSuccessfulStep: x <- candidate (pointer swap), re-linearise
+            std::swap(d.x_c, d.cand_c); std::swap(d.x_p, d.cand_p);
+            P->params_swapped = !P->params_swapped;
+            x_norm = cand_norm;
+            const double q = 2.0 * cur.relative_decrease - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - q * q * q);
+            radius = std::min(opt.max_trust_region_radius, radius);
+            decrease_factor = 2.0; reuse_diagonal = false;
+            if (int rc = S.zero_scal()) return finish(rc);
+            if (int rc = S.linearize(opt.jacobi_scaling != 0, radius)) return finish(rc);
+            prep_radius = radius;
+            if (int rc = esfm::ba_camera_gradient(st, d)) return finish(rc);
+            if (int rc = S.fetch_scal()) return finish(rc);
+            if (h[esfm::SC_LIN_BAD] > 0.0) {
+                esfm::set_error("non-finite residual or Jacobian after an accepted step");
+                sum->termination = ESFM_BA_FAILURE; rc_final = ESFM_ERR_NUMERIC; terminated = true;
+            }
+            x_cost = h[esfm::SC_COST];
+            gmax = h[esfm::SC_GMAX]; last_gmax = gmax;
+            cur.step_is_successful = 1; cur.cost = x_cost; cur.gradient_max_norm = gmax;
+            sum->num_successful_steps++;
+            if (gmax <= opt.gradient_tolerance) { sum->termination = ESFM_BA_CONVERGENCE; terminated = true; }
+        } else {
+            // HandleUnsuccessfulStep + StepRejected
+            cur.step_is_successful = 0; cur.cost = cand_cost;
+            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            sum->num_unsuccessful_steps++;
+        }
+        cur.trust_region_radius = radius;
+        if (iter < ESFM_BA_MAX_LOG) sum->iterations[iter] = cur;
+        sum->num_iterations = iter;
+        if (opt.verbose)
+            printf("%4d % .6e  % .2e  % .2e  % .2e  % .2e  % .2e\n", iter, cur.cost, cur.cost_change, cur.gradient_max_norm, cur.step_norm,
+                   cur.relative_decrease, radius);
+    }
+    (void)reuse_diagonal;
+    sum->final_cost = x_cost;
+    if (multi && d.n_pt) {
+        // every rank ends with the full point set: sum the owners' deltas
+        if (int rc = esfm::ba_points_delta(st, d, true)) return finish(rc);
+        if (int rc = S.allreduce(d.x_p, (int64_t)3 * d.n_pt, ESFM_REDUCE_SUM)) return finish(rc);
+        if (int rc = esfm::ba_points_delta(st, d, false)) return finish(rc);
+    }
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    return finish(rc_final);
+}
+
+int esfm_ba_solve(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                  const float *K4_per_cam, double *cams, double *pts, const esfm_ba_options *options, esfm_allreduce_fn allreduce,
+                  void *allreduce_user, esfm_ba_summary *summary)
+{
+    esfm_ba_problem *P = nullptr;
+    if (int rc = esfm_ba_problem_create(ctx, n_cam, n_pt, n_obs, cam_idx, pt_idx, obs_uv, K4_per_cam, cams, pts, &P)) return rc;
+    int rc = esfm_ba_problem_solve(P, options, allreduce, allreduce_user, summary);
+    if (rc == ESFM_OK || rc == ESFM_ERR_NUMERIC) {
+        const int rc2 = esfm_ba_problem_get_params(P, cams, pts);
+        if (rc == ESFM_OK) rc = rc2;
+    }
+    esfm_ba_problem_destroy(P);
+    return rc;
+}
+
+// Greedy balance of observation counts over shards, points in index order.
+int esfm_ba_shard_points(int n_pt, int n_obs, const int32_t *pt_idx, int world, int32_t *shard_of_point)
+{
+    if (n_pt < 0 || n_obs < 0 || world < 1 || (n_obs && !pt_idx) || (n_pt && !shard_of_point)) {
+        esfm::set_error("esfm_ba_shard_points: bad arguments");
+        return ESFM_ERR_INVALID_ARG;
+    }
+    std::vector<int64_t> cnt((size_t)n_pt, 0);
+    for (int k = 0; k < n_obs; ++k) {
+        if (pt_idx[k] < 0 || pt_idx[k] >= n_pt) { esfm::set_error("point index out of range"); return ESFM_ERR_INVALID_ARG; }
+        cnt[(size_t)pt_idx[k]]++;
+    }
+    // contiguous ranges with ~n_obs/world observations each: keeps a shard's points (and their
+    // observations, which are sorted by point on the device) contiguous
+    const double target = world > 0 ? (double)n_obs / world : 0.0;
+    int shard = 0;
+    int64_t acc = 0;
+    for (int p = 0; p < n_pt; ++p) {
+        if (shard < world - 1 && (double)acc >= target * (shard + 1)) ++shard;
+        shard_of_point[p] = shard;
+        acc += cnt[(size_t)p];
+    }
+    return ESFM_OK;
+}
+
+}  // extern "C"

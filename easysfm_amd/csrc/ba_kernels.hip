@@ -1,0 +1,727 @@
+// Bundle-adjustment kernels for gfx950 (MI355X): the device side of the replacement for
+// BundleAdjustment::solveBA's ceres::Solve (reference cpp_code/src/ba.cpp:132-212) with the cost
+// functor ReprojectErrorTerm_fixcalib (cpp_code/include/ba.h:108-164).  All arithmetic is f64,
+// like Ceres; observations and intrinsics are f32 inputs, like the reference (ba.h:162-163).
+//
+//   ba_linearize_kernel    residual + analytic Jacobian + Cauchy corrector per observation
+//                          (the "Jacobian sweep": streams 16 B in, 160 B out per observation),
+//                          plus the per-camera F'F / F'r sums
+//   ba_point_prep_kernel   per point: E'E, E'r, (E'E + D^2)^-1
+//   ba_schur_kernel        per observation: point-block Schur complement into the reduced system
+//   ba_chol_solve_kernel   dense Cholesky of the reduced camera system + both triangular solves
+//   ba_backsub_kernel      per point: back-substitution, candidate point, model cost change
+//   ba_cost_kernel         robustified cost of a parameter vector (candidate evaluation)
+//
+// The LM control flow (accept/reject, radius) lives in ba_api.cpp.  DESIGN.md "Bundle adjustment".
+#include "ba_kernels.hpp"
+
+#include <float.h>
+
+namespace esfm {
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double *lds /*>= 4 doubles*/)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += lds[w];
+    return s;
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
+{
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// ceres::CauchyLoss::Evaluate [upstream]; a <= 0 selects the trivial (squared) loss.
+__device__ __forceinline__ void loss_eval(double a, double s, double &rho0, double &rho1)
+{
+    if (a <= 0.0) { rho0 = s; rho1 = 1.0; return; }
+    const double b = a * a, c = 1.0 / b;
+    const double sum = 1.0 + s * c, inv = 1.0 / sum;
+    rho0 = b * log(sum);
+    rho1 = inv > DBL_MIN ? inv : DBL_MIN;
+}
+
+// Rotate-and-translate of ReprojectErrorTerm_fixcalib (ba.h:131-135): p = AngleAxisRotatePoint(a, X) + t,
+// with ceres' two branches [upstream rotation.h].  Optionally the derivatives dp/dX (R) and dp/da (Ja):
+// with alpha = sin/theta, beta = (1-cos)/theta^2,
+//   p = cos X + alpha a x X + beta a (a.X)
+//   dp/da_k = -alpha a_k X + gamma a_k (a x X) + alpha (e_k x X) + delta a_k (a.X) a + beta (e_k (a.X) + a X_k)
+//   gamma = (cos - alpha)/theta^2, delta = (alpha - 2 beta)/theta^2.
+template <bool DERIV>
+__device__ __forceinline__ void transform_point(const double *__restrict__ cam, const double *__restrict__ X, double p[3],
+                                                double R[9], double Ja[9])
+{
+    const double a0 = cam[0], a1 = cam[1], a2 = cam[2];
+    const double X0 = X[0], X1 = X[1], X2 = X[2];
+    const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
+    const double c0 = a1 * X2 - a2 * X1, c1 = a2 * X0 - a0 * X2, c2 = a0 * X1 - a1 * X0;  // a x X
+    if (theta2 > DBL_EPSILON) {
+        const double theta = sqrt(theta2);
+        double s, c;
+        sincos(theta, &s, &c);
+        const double ti = 1.0 / theta;
+        const double w0 = a0 * ti, w1 = a1 * ti, w2 = a2 * ti;
+        const double tmp = (w0 * X0 + w1 * X1 + w2 * X2) * (1.0 - c);
+        p[0] = X0 * c + (w1 * X2 - w2 * X1) * s + w0 * tmp;
+        p[1] = X1 * c + (w2 * X0 - w0 * X2) * s + w1 * tmp;
+        p[2] = X2 * c + (w0 * X1 - w1 * X0) * s + w2 * tmp;
+        if (DERIV) {
+            const double ti2 = ti * ti;
+            const double alpha = s * ti, beta = (1.0 - c) * ti2, gamma = (c - alpha) * ti2, delta = (alpha - 2.0 * beta) * ti2;
+            const double aX = a0 * X0 + a1 * X1 + a2 * X2;
+            R[0] = c + beta * a0 * a0;       R[1] = -alpha * a2 + beta * a0 * a1; R[2] = alpha * a1 + beta * a0 * a2;
+            R[3] = alpha * a2 + beta * a1 * a0; R[4] = c + beta * a1 * a1;       R[5] = -alpha * a0 + beta * a1 * a2;
+            R[6] = -alpha * a1 + beta * a2 * a0; R[7] = alpha * a0 + beta * a2 * a1; R[8] = c + beta * a2 * a2;
+            const double av[3] = {a0, a1, a2}, Xv[3] = {X0, X1, X2}, cv[3] = {c0, c1, c2};
+            // e_k x X, k = 0,1,2 (columns)
+            const double ex[3][3] = {{0.0, -X2, X1}, {X2, 0.0, -X0}, {-X1, X0, 0.0}};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double ak = av[k];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double v = -alpha * ak * Xv[i] + gamma * ak * cv[i] + alpha * ex[k][i] + delta * ak * aX * av[i] + beta * av[i] * Xv[k];
+                    if (i == k) v += beta * aX;
+                    Ja[3 * i + k] = v;
+                }
+            }
+        }
+    } else {
+        p[0] = X0 + c0; p[1] = X1 + c1; p[2] = X2 + c2;
+        if (DERIV) {
+            R[0] = 1.0; R[1] = -a2; R[2] = a1; R[3] = a2; R[4] = 1.0; R[5] = -a0; R[6] = -a1; R[7] = a0; R[8] = 1.0;
+            Ja[0] = 0.0; Ja[1] = X2;  Ja[2] = -X1;
+            Ja[3] = -X2; Ja[4] = 0.0; Ja[5] = X0;
+            Ja[6] = X1;  Ja[7] = -X0; Ja[8] = 0.0;
+        }
+    }
+    p[0] += cam[3]; p[1] += cam[4]; p[2] += cam[5];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobian sweep.  PRIV: per-camera sums go through an LDS-private copy first (n_cam * 27 doubles),
+// so global f64 atomics are one per camera entry per workgroup instead of 27 per observation.
+template <bool PRIV>
+__global__ __launch_bounds__(256) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [8] reduction scratch, then PRIV: [n_cam*27]
+    double *red = lds;
+    double *priv = lds + 8;
+    const int tid = threadIdx.x;
+    const int n_obs = d.n_obs;
+    if (PRIV) {
+        for (int e = tid; e < d.n_cam * 27; e += 256) priv[e] = 0.0;
+        __syncthreads();
+    }
+    double cost = 0.0, bad = 0.0;
+    for (int k = blockIdx.x * 256 + tid; k < n_obs; k += gridDim.x * 256) {
+        const int c = d.obs_cam[k], p = d.obs_pt[k];
+        const float2 uv = d.obs_uv[k];
+        const float4 K = d.K4[c];
+        double cam[6], X[3], pt[3], R[9], Ja[9];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cam[i] = d.x_c[6 * (size_t)c + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) X[i] = d.x_p[3 * (size_t)p + i];
+        transform_point<true>(cam, X, pt, R, Ja);
+        const double iz = 1.0 / pt[2];
+        const double x = pt[0] * iz, y = pt[1] * iz;
+        const double fx = (double)K.x, cx = (double)K.y, fy = (double)K.z, cy = (double)K.w;
+        double r0 = (double)uv.x - (x * fx + cx);
+        double r1 = (double)uv.y - (y * fy + cy);
+        // d r / d p  (rows)
+        const double g0[3] = {-fx * iz, 0.0, fx * x * iz};
+        const double g1[3] = {0.0, -fy * iz, fy * y * iz};
+        double Jc[12], Jp[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jc[j] = g0[0] * Ja[j] + g0[1] * Ja[3 + j] + g0[2] * Ja[6 + j];
+            Jc[6 + j] = g1[0] * Ja[j] + g1[1] * Ja[3 + j] + g1[2] * Ja[6 + j];
+            Jc[3 + j] = g0[j];
+            Jc[9 + j] = g1[j];
+            Jp[j] = g0[0] * R[j] + g0[1] * R[3 + j] + g0[2] * R[6 + j];
+            Jp[3 + j] = g1[0] * R[j] + g1[1] * R[3 + j] + g1[2] * R[6 + j];
+        }
+        const double s = r0 * r0 + r1 * r1;
+        bool fin = isfinite(s);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fin = fin && isfinite(Jc[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fin = fin && isfinite(Jp[i]);
+        if (!fin) {
+            bad += 1.0; r0 = r1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
+        } else {
+            double rho0, rho1;
+            loss_eval(cauchy_a, s, rho0, rho1);
+            cost += 0.5 * rho0;
+            const double sq = sqrt(rho1);  // corrector, rho'' <= 0 branch [upstream corrector.cc]
+            r0 *= sq; r1 *= sq;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double sc = use_scaling ? sq * d.scale_c[6 * (size_t)c + i] : sq;
+                Jc[i] *= sc; Jc[6 + i] *= sc;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double sp = use_scaling ? sq * d.scale_p[3 * (size_t)p + i] : sq;
+                Jp[i] *= sp; Jp[3 + i] *= sp;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d.Jc[(size_t)i * n_obs + k] = Jc[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d.Jp[(size_t)i * n_obs + k] = Jp[i];
+        d.res[k] = r0; d.res[(size_t)n_obs + k] = r1;
+        // per-camera sums: F'F upper triangle (21) and F'r (6)
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+                const double v = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+                if (PRIV) atomicAdd(&priv[c * 27 + e], v);
+                else { atomicAdd(&d.camacc[36 * (size_t)c + 6 * a + b], v); if (a != b) atomicAdd(&d.camacc[36 * (size_t)c + 6 * b + a], v); }
+                ++e;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double v = Jc[a] * r0 + Jc[6 + a] * r1;
+            if (PRIV) atomicAdd(&priv[c * 27 + 21 + a], v);
+            else atomicAdd(&d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + a], v);
+        }
+    }
+    const double cs = block_sum(cost, red);
+    const double bs = block_sum(bad, red);
+    if (tid == 0) { atomicAdd(&d.scal[SC_COST], cs); if (bs > 0.0) atomicAdd(&d.scal[SC_LIN_BAD], bs); }
+    if (PRIV) {
+        __syncthreads();
+        for (int e = tid; e < d.n_cam * 27; e += 256) {
+            const double v = priv[e];
+            if (v == 0.0) continue;
+            const int c = e / 27, q = e % 27;
+            if (q >= 21) { atomicAdd(&d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)], v); continue; }
+            // unpack upper-triangle index q -> (a, b)
+            int a = 0, rem = q;
+            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+            const int b = a + rem;
+            atomicAdd(&d.camacc[36 * (size_t)c + 6 * a + b], v);
+            if (a != b) atomicAdd(&d.camacc[36 * (size_t)c + 6 * b + a], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per point: E'E, E'r (only when the Jacobian is fresh), then M^-1 = (E'E + clamp(diag)/radius)^-1
+// via a 3x3 Cholesky (ceres InvertPSDMatrix), M^-1 E'r, and the point part of max|gradient|.
+__global__ __launch_bounds__(256) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh)
+{
+    __shared__ double red[8];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double gmax = 0.0, sing = 0.0;
+    if (p < d.n_pt) {
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        if (e > b) {
+            double A[6], g[3];
+            if (fresh) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) A[i] = 0.0;
+                g[0] = g[1] = g[2] = 0.0;
+                const size_t n = d.n_obs;
+                for (int k = b; k < e; ++k) {
+                    const double j0 = d.Jp[k], j1 = d.Jp[n + k], j2 = d.Jp[2 * n + k];
+                    const double j3 = d.Jp[3 * n + k], j4 = d.Jp[4 * n + k], j5 = d.Jp[5 * n + k];
+                    const double r0 = d.res[k], r1 = d.res[n + k];
+                    A[0] += j0 * j0 + j3 * j3; A[1] += j0 * j1 + j3 * j4; A[2] += j0 * j2 + j3 * j5;
+                    A[3] += j1 * j1 + j4 * j4; A[4] += j1 * j2 + j4 * j5; A[5] += j2 * j2 + j5 * j5;
+                    g[0] += j0 * r0 + j3 * r1; g[1] += j1 * r0 + j4 * r1; g[2] += j2 * r0 + j5 * r1;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d.EtE[6 * (size_t)p + i] = A[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    d.Etr[3 * (size_t)p + i] = g[i];
+                    gmax = fmax(gmax, fabs(g[i] / d.scale_p[3 * (size_t)p + i]));  // gradient of the unscaled problem
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) A[i] = d.EtE[6 * (size_t)p + i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) g[i] = d.Etr[3 * (size_t)p + i];
+            }
+            // M = E'E + D^2, D^2 = clamp(diag(E'E)) / radius  (levenberg_marquardt_strategy.cc)
+            const double m00 = A[0] + fmin(fmax(A[0], min_diag), max_diag) / radius;
+            const double m11 = A[3] + fmin(fmax(A[3], min_diag), max_diag) / radius;
+            const double m22 = A[5] + fmin(fmax(A[5], min_diag), max_diag) / radius;
+            const double m10 = A[1], m20 = A[2], m21 = A[4];
+            double Mi[6] = {0, 0, 0, 0, 0, 0};
+            bool ok = m00 > 0.0;
+            const double l00 = sqrt(m00);
+            const double l10 = m10 / l00, l20 = m20 / l00;
+            const double t11 = m11 - l10 * l10;
+            ok = ok && (t11 > 0.0);
+            const double l11 = sqrt(t11);
+            const double l21 = (m21 - l20 * l10) / l11;
+            const double t22 = m22 - l20 * l20 - l21 * l21;
+            ok = ok && (t22 > 0.0);
+            const double l22 = sqrt(t22);
+            if (ok) {
+                const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+                const double i10 = -l10 * i00 * i11;
+                const double i21 = -l21 * i11 * i22;
+                const double i20 = -(l20 * i00 + l21 * i10) * i22;
+                Mi[0] = i00 * i00 + i10 * i10 + i20 * i20;  // xx
+                Mi[1] = i10 * i11 + i20 * i21;              // xy
+                Mi[2] = i20 * i22;                          // xz
+                Mi[3] = i11 * i11 + i21 * i21;              // yy
+                Mi[4] = i21 * i22;                          // yz
+                Mi[5] = i22 * i22;                          // zz
+            } else {
+                sing = 1.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d.Minv[6 * (size_t)p + i] = Mi[i];
+            d.Aig[3 * (size_t)p + 0] = Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2];
+            d.Aig[3 * (size_t)p + 1] = Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2];
+            d.Aig[3 * (size_t)p + 2] = Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2];
+        }
+    }
+    if (fresh) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+        if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], gmax);
+    }
+    const double ss = block_sum(sing, red);
+    if (threadIdx.x == 0 && ss > 0.0) atomicAdd(&d.scal[SC_PT_SINGULAR], ss);
+}
+
+// Jacobi scaling 1/(1 + sqrt(squared column norm)) from the unscaled linearisation
+// (trust_region_minimizer.cc, iteration 0).  Point norms = diag(E'E); camera norms = diag(F'F).
+__global__ void ba_jacobi_scaling_kernel(BADev d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * d.n_pt) {
+        const int p = i / 3, a = i % 3;
+        const int di = a == 0 ? 0 : (a == 1 ? 3 : 5);
+        const bool active = d.pt_start[p + 1] > d.pt_start[p];
+        d.scale_p[i] = active ? 1.0 / (1.0 + sqrt(d.EtE[6 * (size_t)p + di])) : 1.0;
+    }
+    if (i < 6 * d.n_cam) {
+        const int c = i / 6, a = i % 6;
+        d.scale_c[i] = 1.0 / (1.0 + sqrt(d.camacc[36 * (size_t)c + 7 * a]));
+    }
+}
+
+// Camera part of max|gradient| (needs the all-reduced F'r).
+__global__ void ba_camera_gradient_kernel(BADev d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double g = 0.0;
+    if (i < 6 * d.n_cam) g = fabs(d.camacc[36 * (size_t)d.n_cam + i] / d.scale_c[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
+    if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point-block Schur complement (schur_eliminator_impl.h [upstream]).  Thread i owns observation i of
+// point p: W_i = F_i'E_i, Y_i = W_i M^-1; rhs_corr[c_i] -= W_i M^-1 E'r; and for every observation j of
+// the same point with camera(j) <= camera(i):  S[c_i][c_j] -= Y_i W_j'.  Only blocks on or below the
+// block diagonal are produced (the factorisation reads the lower triangle).
+__global__ __launch_bounds__(256) void ba_schur_kernel(BADev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_obs) return;
+    const size_t n_obs = d.n_obs;
+    const int n = 6 * d.n_cam;
+    const int p = d.obs_pt[i], ci = d.obs_cam[i];
+    double Jc[12], Jp[6];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n_obs + i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) Jp[a] = d.Jp[a * n_obs + i];
+    const double *Mi = d.Minv + 6 * (size_t)p;
+    const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
+    const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+    double Y[18];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
+        const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
+        const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
+        atomicAdd(&d.red[(size_t)n * n + 6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2));
+        Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
+        Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
+        Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+    }
+    const int b = d.pt_start[p], e = d.pt_start[p + 1];
+    for (int j = b; j < e; ++j) {
+        const int cj = d.obs_cam[j];
+        if (cj > ci) continue;
+        double Fj[12], Ej[6];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
+        double *Sb = d.red + (size_t)(6 * ci) * n + 6 * cj;
+#pragma unroll
+        for (int c2 = 0; c2 < 6; ++c2) {
+            const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
+            const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
+            const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                atomicAdd(&Sb[(size_t)a * n + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense solve of the reduced camera system (DENSE_SCHUR's Cholesky):
+//   (F'F + D_c^2 + S_schur) y = F'r + rhs_corr
+// One workgroup, left-looking Cholesky on a packed lower matrix with the right-hand side carried
+// as row n (so the forward substitution comes for free), then the backward substitution.
+// LDS_STORE: the packed matrix lives in LDS (n <= ~185), otherwise in d.chol (global).
+constexpr int kCholThreads = 1024;
+constexpr int kCholLPR = 4;  // lanes cooperating on one row's dot product
+
+template <bool LDS_STORE>
+__global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, double radius, double min_diag, double max_diag)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = 6 * d.n_cam;
+    const size_t tot = (size_t)(n + 1) * (n + 2) / 2;
+    double *L = LDS_STORE ? smem : d.chol;  // packed lower, (n+1) rows; row n = rhs
+    // failure flag kept inside the dynamic region (a static __shared__ object in front of it would
+    // shift the f64 array off its 8-byte alignment)
+    volatile double *failp = LDS_STORE ? (smem + tot) : smem;
+    const int tid = threadIdx.x;
+    if (tid == 0) *failp = 0.0;
+    const double *S = d.red;
+    const double *rc = d.red + (size_t)n * n;
+    const double *FtF = d.camacc;
+    const double *Ftr = d.camacc + 36 * (size_t)d.n_cam;
+    // assemble
+    for (size_t e = tid; e < tot; e += kCholThreads) {
+        // unpack e -> (i, k), k <= i
+        int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+        while ((size_t)(i + 1) * (i + 2) / 2 <= e) ++i;
+        while ((size_t)i * (i + 1) / 2 > e) --i;
+        const int k = (int)(e - (size_t)i * (i + 1) / 2);
+        double v;
+        if (i < n) {
+            v = S[(size_t)i * n + k];
+            if (i / 6 == k / 6) {
+                const int c = i / 6;
+                v += FtF[36 * (size_t)c + 6 * (i % 6) + (k % 6)];
+                if (i == k) v += fmin(fmax(FtF[36 * (size_t)c + 7 * (i % 6)], min_diag), max_diag) / radius;
+            }
+        } else {
+            v = (k < n) ? (Ftr[k] + rc[k]) : 0.0;
+        }
+        L[e] = v;
+    }
+    __syncthreads();
+    const int grp = tid / kCholLPR, sub = tid % kCholLPR, ngrp = kCholThreads / kCholLPR;
+    for (int j = 0; j < n; ++j) {
+        const double *Lj = L + (size_t)j * (j + 1) / 2;
+        // diagonal: every group computes it redundantly? no -- group 0 computes, then broadcast through L
+        if (grp == 0) {
+            double s = 0.0;
+            for (int k = sub; k < j; k += kCholLPR) s += Lj[k] * Lj[k];
+#pragma unroll
+            for (int o = kCholLPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (sub == 0) {
+                const double dd = Lj[j] - s;
+                if (!(dd > 0.0) || !isfinite(dd)) *failp = 1.0;
+                L[(size_t)j * (j + 1) / 2 + j] = sqrt(dd > 0.0 ? dd : 1.0);
+            }
+        }
+        __syncthreads();
+        const double inv = 1.0 / Lj[j];
+        for (int i = j + 1 + grp; i <= n; i += ngrp) {
+            double *Li = L + (size_t)i * (i + 1) / 2;
+            double s = 0.0;
+            for (int k = sub; k < j; k += kCholLPR) s += Li[k] * Lj[k];
+#pragma unroll
+            for (int o = kCholLPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (sub == 0) Li[j] = (Li[j] - s) * inv;
+        }
+        __syncthreads();
+    }
+    // backward substitution L' y = z, z = row n.  Column-oriented: once y_i is known, z_k -= L[i][k] y_i.
+    double *z = L + (size_t)n * (n + 1) / 2;
+    for (int i = n - 1; i >= 0; --i) {
+        const double *Li = L + (size_t)i * (i + 1) / 2;
+        const double yi = z[i] / Li[i];
+        __syncthreads();
+        if (tid == 0) z[i] = yi;
+        for (int k = tid; k < i; k += kCholThreads) z[k] -= Li[k] * yi;
+        __syncthreads();
+    }
+    const bool fail = *failp != 0.0;
+    for (int i = tid; i < n; i += kCholThreads) d.y_c[i] = fail ? 0.0 : z[i];
+    if (tid == 0 && fail) d.scal[SC_CHOL_FAIL] = 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate cameras: x + (-y) .* scaling for cameras that have observations; step/candidate norms.
+__global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
+{
+    __shared__ double red[8];
+    double ssq = 0.0, csq = 0.0;
+    for (int i = threadIdx.x; i < 6 * d.n_cam; i += 256) {
+        const bool active = d.cam_nobs[i / 6] > 0.0;
+        const double x = d.x_c[i];
+        const double cnd = active ? x + (-d.y_c[i]) * d.scale_c[i] : x;
+        d.cand_c[i] = cnd;
+        if (active) { const double df = x - cnd; ssq += df * df; csq += cnd * cnd; }
+    }
+    const double a = block_sum(ssq, red);
+    const double b = block_sum(csq, red);
+    if (threadIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = a; d.scal[SC_CAND_SQ_CAM] = b; }
+}
+
+// Back-substitution per point: y_p = M^-1 (E'r - sum_i E_i'F_i y_c), step = -y, candidate point,
+// and this point's share of model_cost_change = -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BADev d)
+{
+    __shared__ double red[8];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double mc = 0.0, ssq = 0.0, csq = 0.0;
+    if (p < d.n_pt) {
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        const size_t n = d.n_obs;
+        double xp[3] = {d.x_p[3 * (size_t)p], d.x_p[3 * (size_t)p + 1], d.x_p[3 * (size_t)p + 2]};
+        if (e > b) {
+            double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
+            for (int k = b; k < e; ++k) {
+                const int c = d.obs_cam[k];
+                double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double yc = d.y_c[6 * c + a];
+                    f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) g[a] -= d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
+            }
+            const double *Mi = d.Minv + 6 * (size_t)p;
+            const double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]),
+                                  -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
+                                  -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
+            for (int k = b; k < e; ++k) {
+                const int c = d.obs_cam[k];
+                double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double sc = -d.y_c[6 * c + a];
+                    m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
+                mc -= m0 * (d.res[k] + m0 / 2.0) + m1 * (d.res[n + k] + m1 / 2.0);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double cnd = xp[a] + sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double df = xp[a] - cnd;
+                ssq += df * df; csq += cnd * cnd;
+                d.cand_p[3 * (size_t)p + a] = cnd;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d.cand_p[3 * (size_t)p + a] = xp[a];
+        }
+    }
+    const double s0 = block_sum(mc, red);
+    const double s1 = block_sum(ssq, red);
+    const double s2 = block_sum(csq, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&d.scal[SC_MODEL_CHANGE], s0);
+        atomicAdd(&d.scal[SC_STEP_SQ_PT], s1);
+        atomicAdd(&d.scal[SC_CAND_SQ_PT], s2);
+    }
+}
+
+// Robustified cost 1/2 sum rho(|r|^2) of (cams, pts) over this rank's observations.
+__global__ __launch_bounds__(256) void ba_cost_kernel(BADev d, const double *__restrict__ cams, const double *__restrict__ pts,
+                                                      double cauchy_a, int slot, int bad_slot)
+{
+    __shared__ double red[8];
+    double cost = 0.0, bad = 0.0;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < d.n_obs; k += gridDim.x * 256) {
+        const int c = d.obs_cam[k], p = d.obs_pt[k];
+        const float2 uv = d.obs_uv[k];
+        const float4 K = d.K4[c];
+        double cam[6], X[3], pt[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cam[i] = cams[6 * (size_t)c + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) X[i] = pts[3 * (size_t)p + i];
+        transform_point<false>(cam, X, pt, nullptr, nullptr);
+        const double x = pt[0] / pt[2], y = pt[1] / pt[2];
+        const double r0 = (double)uv.x - (x * (double)K.x + (double)K.y);
+        const double r1 = (double)uv.y - (y * (double)K.z + (double)K.w);
+        const double s = r0 * r0 + r1 * r1;
+        if (!isfinite(s)) { bad += 1.0; continue; }
+        double rho0, rho1;
+        loss_eval(cauchy_a, s, rho0, rho1);
+        cost += 0.5 * rho0;
+    }
+    const double cs = block_sum(cost, red);
+    const double bs = block_sum(bad, red);
+    if (threadIdx.x == 0) { atomicAdd(&d.scal[slot], cs); if (bs > 0.0) atomicAdd(&d.scal[bad_slot], bs); }
+}
+
+// |x|^2 over the parameter blocks that take part in the problem (Ceres drops unused blocks).
+__global__ __launch_bounds__(256) void ba_param_sqnorm_kernel(BADev d)
+{
+    __shared__ double red[8];
+    double sp = 0.0, sc = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * d.n_pt; i += gridDim.x * 256) {
+        const int p = i / 3;
+        if (d.pt_start[p + 1] > d.pt_start[p]) sp += d.x_p[i] * d.x_p[i];
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 6 * d.n_cam; i += 256)
+            if (d.cam_nobs[i / 6] > 0.0) sc += d.x_c[i] * d.x_c[i];
+    const double a = block_sum(sp, red);
+    const double b = block_sum(sc, red);
+    if (threadIdx.x == 0) { atomicAdd(&d.scal[SC_XNORM_SQ_PT], a); if (blockIdx.x == 0) d.scal[SC_XNORM_SQ_CAM] = b; }
+}
+
+// Multi-GPU merge of the point blocks: each rank owns the points it has observations for.
+//   to_delta: x_p <- (owned ? x_p - x0_p : 0)   (then SUM all-reduce)
+//   else    : x_p <- x0_p + x_p
+__global__ void ba_points_delta_kernel(BADev d, int to_delta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * d.n_pt) return;
+    const int p = i / 3;
+    if (to_delta) d.x_p[i] = (d.pt_start[p + 1] > d.pt_start[p]) ? d.x_p[i] - d.x0_p[i] : 0.0;
+    else d.x_p[i] = d.x0_p[i] + d.x_p[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+#define LAUNCH_CHECK() ESFM_HIP_TRY(hipGetLastError())
+
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling)
+{
+    ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
+    if (d.n_obs <= 0) return ESFM_OK;
+    const size_t priv_bytes = sizeof(double) * (8 + (size_t)d.n_cam * 27);
+    const bool priv = priv_bytes <= 64 * 1024;
+    const int grid = std::min(div_up(d.n_obs, 256), std::max(1, num_cu) * 8);
+    if (priv)
+        hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(256), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0);
+    else
+        hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(grid), dim3(256), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh)
+{
+    if (d.n_pt <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_jacobi_scaling(hipStream_t st, const BADev &d)
+{
+    const int m = std::max(3 * d.n_pt, 6 * d.n_cam);
+    if (m <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_jacobi_scaling_kernel, dim3(div_up(m, 256)), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_camera_gradient(hipStream_t st, const BADev &d)
+{
+    if (d.n_cam <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_camera_gradient_kernel, dim3(div_up(6 * d.n_cam, 256)), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_schur(hipStream_t st, const BADev &d)
+{
+    ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
+    if (d.n_obs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
+{
+    if (d.n_cam <= 0) return ESFM_OK;
+    const int n = 6 * d.n_cam;
+    const size_t bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + 2);
+    if (bytes <= 150 * 1024) {
+        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_chol_solve_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(ba_chol_solve_kernel<true>, dim3(1), dim3(kCholThreads), bytes, st, d, radius, min_diag, max_diag);
+    } else {
+        hipLaunchKernelGGL(ba_chol_solve_kernel<false>, dim3(1), dim3(kCholThreads), 2 * sizeof(double), st, d, radius, min_diag, max_diag);
+    }
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_camera_step(hipStream_t st, const BADev &d)
+{
+    hipLaunchKernelGGL(ba_camera_step_kernel, dim3(1), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_backsub(hipStream_t st, const BADev &d)
+{
+    if (d.n_pt <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot)
+{
+    if (d.n_obs <= 0) return ESFM_OK;
+    const int grid = std::min(div_up(d.n_obs, 256), std::max(1, num_cu) * 8);
+    hipLaunchKernelGGL(ba_cost_kernel, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_param_sqnorm(hipStream_t st, const BADev &d)
+{
+    const int grid = std::max(1, std::min(div_up(3LL * d.n_pt, 256), 1024));
+    hipLaunchKernelGGL(ba_param_sqnorm_kernel, dim3(grid), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_points_delta(hipStream_t st, const BADev &d, bool to_delta)
+{
+    if (d.n_pt <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_points_delta_kernel, dim3(div_up(3LL * d.n_pt, 256)), dim3(256), 0, st, d, to_delta ? 1 : 0);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+}  // namespace esfm

@@ -1,0 +1,69 @@
+// Launch interface between ba_api.cpp (LM control loop on the host) and ba_kernels.hip.
+#pragma once
+
+#include "common.hpp"
+
+namespace esfm {
+
+// Scalar accumulators in BADev::scal (doubles).
+//   [0, SC_SUM_COUNT)   : partial sums over this rank's observations/points -> SUM all-reduce
+//   [SC_REPL0, SC_GMAX) : quantities every rank computes identically (camera blocks) -> no reduce
+//   SC_GMAX             : max |gradient| over this rank's points and all cameras  -> MAX all-reduce
+enum BAScalar {
+    SC_COST = 0, SC_CAND_COST = 1, SC_MODEL_CHANGE = 2, SC_STEP_SQ_PT = 3, SC_CAND_SQ_PT = 4, SC_XNORM_SQ_PT = 5,
+    SC_LIN_BAD = 6, SC_CAND_BAD = 7, SC_PT_SINGULAR = 8, SC_SUM_COUNT = 12,
+    SC_REPL0 = 12, SC_STEP_SQ_CAM = 12, SC_CAND_SQ_CAM = 13, SC_XNORM_SQ_CAM = 14, SC_CHOL_FAIL = 15,
+    SC_GMAX = 16, SC_COUNT = 24
+};
+
+// Device-resident bundle-adjustment problem.  Observations are sorted by point (CSR), so a
+// point's observations are contiguous: obs k in [pt_start[p], pt_start[p+1]) belongs to point p.
+struct BADev {
+    int n_cam = 0, n_pt = 0, n_obs = 0;
+    // structure (static per problem)
+    int32_t *obs_cam = nullptr;   // [n_obs] camera of sorted observation k
+    int32_t *obs_pt = nullptr;    // [n_obs] point of sorted observation k
+    float2 *obs_uv = nullptr;     // [n_obs] observed pixel (float, reference points_2d_)
+    int32_t *pt_start = nullptr;  // [n_pt+1]
+    float4 *K4 = nullptr;         // [n_cam] fx, cx, fy, cy
+    double *cam_nobs = nullptr;   // [n_cam] observation count over ALL shards (double: all-reduced)
+    // parameters
+    double *x_c = nullptr, *x_p = nullptr;        // current point   [6 n_cam], [3 n_pt]
+    double *cand_c = nullptr, *cand_p = nullptr;  // candidate point
+    double *x0_p = nullptr;                       // points at solve() entry (multi-GPU merge)
+    // linearisation (loss-corrected, column-scaled), SoA: J[a * n_obs + k]
+    double *Jc = nullptr;   // 12 arrays: row 0 cols 0..5, then row 1 cols 0..5
+    double *Jp = nullptr;   // 6 arrays: row 0 cols 0..2, row 1 cols 0..2
+    double *res = nullptr;  // 2 arrays
+    double *scale_c = nullptr, *scale_p = nullptr;  // Jacobi scaling [6 n_cam], [3 n_pt]
+    double *EtE = nullptr;   // [6 n_pt] E'E upper (xx,xy,xz,yy,yz,zz); its diagonal = point column norms
+    double *Etr = nullptr;   // [3 n_pt]
+    double *Minv = nullptr;  // [6 n_pt] (E'E + D_p^2)^-1
+    double *Aig = nullptr;   // [3 n_pt] Minv * Etr
+    // per-camera normal-equation pieces, one contiguous SUM all-reduce buffer:
+    //   camacc = FtF (36 per camera, full symmetric) | Ftr (6 per camera)
+    double *camacc = nullptr;
+    // Schur part of the reduced system, one contiguous SUM all-reduce buffer:
+    //   red = S_schur (n*n, only blocks with row camera >= column camera are written) | rhs_corr (n)
+    double *red = nullptr;
+    double *y_c = nullptr;   // [6 n_cam] solution of the reduced system
+    double *scal = nullptr;  // [SC_COUNT]
+    double *chol = nullptr;  // [(n+1)(n+2)/2] packed-lower work matrix for large n
+};
+
+inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
+inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
+
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling);
+int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian);
+int ba_jacobi_scaling(hipStream_t st, const BADev &d);
+int ba_camera_gradient(hipStream_t st, const BADev &d);
+int ba_schur(hipStream_t st, const BADev &d);
+int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
+int ba_camera_step(hipStream_t st, const BADev &d);
+int ba_backsub(hipStream_t st, const BADev &d);
+int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot);
+int ba_param_sqnorm(hipStream_t st, const BADev &d);
+int ba_points_delta(hipStream_t st, const BADev &d, bool to_delta);
+
+}  // namespace esfm

@@ -1,0 +1,74 @@
+// Shared host-side plumbing of libesfm_hip.so: context, error reporting, device scratch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/esfm.h"
+
+namespace esfm {
+
+// Thread-local last-error text behind esfm_last_error().
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define ESFM_HIP_TRY(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            ::esfm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                              __LINE__);                                                        \
+            return e__ == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;                    \
+        }                                                                                       \
+    } while (0)
+
+#define ESFM_REQUIRE(cond, msg)                     \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::esfm::set_error("%s: %s", __func__, msg); \
+            return ESFM_ERR_INVALID_ARG;            \
+        }                                           \
+    } while (0)
+
+// A grow-only device buffer (scratch reused across calls; 288 GB of HBM makes
+// holding on to the high-water mark the right trade).
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+}  // namespace esfm
+
+struct esfm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cu = 256;
+    // matching scratch
+    esfm::DevBuf norms, pair_tab, knn_idx, knn_dist, flagged, counters, stage_a, stage_b, stage_c, stage_d, stage_e;
+    esfm::DevBuf setmax;
+    // pinned host staging for small tables / counters
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    int64_t last_n_queries = 0;
+    size_t last_pair_bytes = 0;
+    int pin(size_t bytes);
+};
+
+namespace esfm {
+inline int set_device(const esfm_ctx *ctx)
+{
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { set_error("hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e)); return ESFM_ERR_HIP; }
+    return ESFM_OK;
+}
+}  // namespace esfm

@@ -1,0 +1,134 @@
+// Context / error plumbing of libesfm_hip.so (include/esfm.h, "library / context").
+#include "common.hpp"
+
+namespace esfm {
+
+static thread_local char g_err[1024] = {0};
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+const char *get_error() { return g_err; }
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return ESFM_OK;
+    // grow geometrically so alternating sizes do not thrash hipMalloc
+    size_t want = bytes + bytes / 4 + 256;
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        ptr = nullptr;
+        return e == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;
+    }
+    cap = want;
+    return ESFM_OK;
+}
+
+void DevBuf::release()
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+}  // namespace esfm
+
+int esfm_ctx::pin(size_t bytes)
+{
+    if (bytes <= pinned_cap) return ESFM_OK;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr; pinned_cap = 0;
+    size_t want = bytes * 2 + 4096;
+    hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) { esfm::set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); return ESFM_ERR_OOM; }
+    pinned_cap = want;
+    return ESFM_OK;
+}
+
+extern "C" {
+
+const char *esfm_version(void)
+{
+    static char v[32];
+    snprintf(v, sizeof(v), "%d.%d", ESFM_VERSION_MAJOR, ESFM_VERSION_MINOR);
+    return v;
+}
+
+const char *esfm_last_error(void) { return esfm::get_error(); }
+
+int esfm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int esfm_ctx_create(int device, void *hip_stream, esfm_ctx **out)
+{
+    if (!out) { esfm::set_error("esfm_ctx_create: out is NULL"); return ESFM_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        esfm::set_error("no HIP device available (%s); libesfm_hip has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return ESFM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { esfm::set_error("device %d out of range [0,%d)", device, n); return ESFM_ERR_INVALID_ARG; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { esfm::set_error("hipGetDeviceProperties failed"); return ESFM_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        esfm::set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return ESFM_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) { esfm::set_error("hipSetDevice(%d) failed", device); return ESFM_ERR_NO_DEVICE; }
+    esfm_ctx *c = new esfm_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        c->owns_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            esfm::set_error("hipStreamCreate failed");
+            delete c;
+            return ESFM_ERR_HIP;
+        }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return ESFM_OK;
+}
+
+int esfm_ctx_destroy(esfm_ctx *ctx)
+{
+    if (!ctx) return ESFM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    esfm::DevBuf *bufs[] = {&ctx->norms, &ctx->pair_tab, &ctx->knn_idx, &ctx->knn_dist, &ctx->flagged, &ctx->counters,
+                            &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->stage_e, &ctx->setmax};
+    for (auto *b : bufs) b->release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ESFM_OK;
+}
+
+int esfm_ctx_synchronize(esfm_ctx *ctx)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+    ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ESFM_OK;
+}
+
+void *esfm_ctx_stream(esfm_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
+}  // extern "C"

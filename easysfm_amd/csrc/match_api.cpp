@@ -1,0 +1,298 @@
+// C-ABI entry points for pairwise matching (include/esfm.h, rows a-1..a-3 of SURVEY.md section 8).
+// Host logic only: argument checks, the pair table, scratch management, kernel sequencing.
+#include <algorithm>
+#include <cfloat>
+#include <vector>
+
+#include "match_kernels.hpp"
+
+using esfm::PairDesc;
+
+namespace {
+
+constexpr int kL2QueryBlock = 128;       // queries per workgroup in l2_knn_mfma_kernel
+constexpr int kHammingQueryBlock = 256;  // queries per workgroup in hamming_knn_kernel
+
+struct PairPlan {
+    std::vector<PairDesc> tab;
+    int n_blocks = 0;
+    int64_t total_queries = 0;
+    int64_t total_rows = 0;
+};
+
+int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, int n_pairs, int query_block,
+              int64_t *out_offset, PairPlan *plan)
+{
+    ESFM_REQUIRE(set_row_offset != nullptr && n_sets >= 1, "set_row_offset/n_sets");
+    ESFM_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs != nullptr), "pairs/n_pairs");
+    ESFM_REQUIRE(set_row_offset[0] == 0, "set_row_offset[0] must be 0");
+    for (int s = 0; s < n_sets; ++s) ESFM_REQUIRE(set_row_offset[s + 1] >= set_row_offset[s], "set_row_offset must be non-decreasing");
+    plan->total_rows = set_row_offset[n_sets];
+    plan->tab.resize((size_t)n_pairs);
+    int64_t off = 0;
+    int64_t blk = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
+        ESFM_REQUIRE(qs >= 0 && qs < n_sets && ts >= 0 && ts < n_sets, "pair refers to a set out of range");
+        PairDesc &d = plan->tab[(size_t)p];
+        d.q_row0 = set_row_offset[qs]; d.nq = set_row_offset[qs + 1] - set_row_offset[qs];
+        d.t_row0 = set_row_offset[ts]; d.nt = set_row_offset[ts + 1] - set_row_offset[ts];
+        ESFM_REQUIRE(d.nt < (1 << 22), "train sets are limited to 2^22-1 rows");
+        d.out_off = off; d.blk_off = (int32_t)blk; d.pad = 0;
+        if (out_offset) out_offset[p] = off;
+        off += d.nq;
+        blk += (d.nq + query_block - 1) / query_block;
+        ESFM_REQUIRE(blk < (int64_t)1 << 31, "too many workgroups for one launch; split the pair list");
+    }
+    if (out_offset) out_offset[n_pairs] = off;
+    plan->n_blocks = (int)blk;
+    plan->total_queries = off;
+    return ESFM_OK;
+}
+
+// Upload the pair table through a pinned staging buffer.  The context remembers the last table:
+// an identical pair list (the common case in a loop over the same frames) is not re-sent.
+int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
+{
+    const size_t bytes = plan.tab.size() * sizeof(PairDesc);
+    if (bytes == 0) { *dev_tab = nullptr; return ESFM_OK; }
+    if (ctx->pair_tab.cap >= bytes && ctx->pinned_cap >= bytes && ctx->last_pair_bytes == bytes &&
+        memcmp(ctx->pinned, plan.tab.data(), bytes) == 0) {
+        *dev_tab = ctx->pair_tab.as<PairDesc>();
+        return ESFM_OK;
+    }
+    // the pinned buffer may still be the source of an in-flight copy: drain before rewriting it
+    ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = ctx->pin(bytes)) return rc;
+    if (int rc = ctx->pair_tab.reserve(bytes)) return rc;
+    memcpy(ctx->pinned, plan.tab.data(), bytes);
+    ctx->last_pair_bytes = bytes;
+    ESFM_HIP_TRY(hipMemcpyAsync(ctx->pair_tab.ptr, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev_tab = ctx->pair_tab.as<PairDesc>();
+    return ESFM_OK;
+}
+
+// 2-NN table for every query of every pair, written to knn_idx/knn_dist (device, 2 per query).
+int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width, const PairPlan &plan,
+              const PairDesc *dev_tab, int32_t *knn_idx, float *knn_dist)
+{
+    const int n_pairs = (int)plan.tab.size();
+    if (n_pairs == 0 || plan.total_queries == 0) return ESFM_OK;
+    hipStream_t st = ctx->stream;
+    if (metric == ESFM_L2_F32) {
+        const float *desc = reinterpret_cast<const float *>(desc_dev);
+        if (int rc = ctx->counters.reserve(64)) return rc;
+        ESFM_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 64, st));
+        ctx->last_n_queries = plan.total_queries;
+        if (esfm::l2_mfma_supported(width)) {
+            if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
+            const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
+            if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
+            if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
+            if (int rc = esfm::launch_l2_knn_mfma(st, width, desc, ctx->norms.as<float>(), dev_tab, n_pairs, plan.n_blocks, knn_idx,
+                                                  knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))
+                return rc;
+            // certificate failures: exact scan, grid-stride over the device-side count (no host sync)
+            const int grid = (int)std::min<int64_t>(plan.total_queries, 8 * (int64_t)ctx->num_cu);
+            if (int rc = esfm::launch_l2_exact_scan(st, width, desc, dev_tab, n_pairs, ctx->flagged.as<int32_t>(),
+                                                    ctx->counters.as<int32_t>(), plan.total_queries, grid, knn_idx, knn_dist))
+                return rc;
+        } else {
+            // no MFMA build for this width: exact scan of every query (correct, not fast)
+            const int grid = (int)std::min<int64_t>(plan.total_queries, 64 * (int64_t)ctx->num_cu);
+            if (int rc = esfm::launch_l2_exact_scan(st, width, desc, dev_tab, n_pairs, nullptr, ctx->counters.as<int32_t>(),
+                                                    plan.total_queries, grid, knn_idx, knn_dist))
+                return rc;
+        }
+        return ESFM_OK;
+    }
+    if (metric == ESFM_HAMMING) {
+        if (!esfm::hamming_supported(width)) {
+            esfm::set_error("hamming descriptors must be 16, 32 or 64 bytes (got %d)", width);
+            return ESFM_ERR_UNSUPPORTED;
+        }
+        return esfm::launch_hamming_knn(st, width, desc_dev, dev_tab, n_pairs, plan.n_blocks, knn_idx, knn_dist);
+    }
+    esfm::set_error("unknown metric %d", (int)metric);
+    return ESFM_ERR_INVALID_ARG;
+}
+
+int check_common(esfm_ctx *ctx, esfm_metric metric, int width)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    if (metric != ESFM_L2_F32 && metric != ESFM_HAMMING) { esfm::set_error("unknown metric %d", (int)metric); return ESFM_ERR_INVALID_ARG; }
+    if (width <= 0) { esfm::set_error("descriptor width must be positive"); return ESFM_ERR_INVALID_ARG; }
+    return esfm::set_device(ctx);
+}
+
+// Host-pointer single pair: stage [train rows | query rows] into one device buffer, run the
+// batched path with the pair (1, 0), copy back.
+int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const void *t, int nt, int width, bool filtered,
+                double ratio, int32_t *o_a, int32_t *o_b, float *o_c, int32_t *n_out)
+{
+    if (int rc = check_common(ctx, metric, width)) return rc;
+    ESFM_REQUIRE(nq >= 0 && nt >= 0, "negative row count");
+    ESFM_REQUIRE(nq == 0 || q != nullptr, "q is NULL");
+    ESFM_REQUIRE(nt == 0 || t != nullptr, "t is NULL");
+    if (n_out) *n_out = 0;
+    if (nq == 0) return ESFM_OK;
+    const size_t row_bytes = metric == ESFM_L2_F32 ? sizeof(float) * (size_t)width : (size_t)width;
+    const size_t tb = row_bytes * (size_t)nt, qb = row_bytes * (size_t)nq;
+    if (int rc = ctx->stage_a.reserve(tb + qb + 16)) return rc;
+    hipStream_t st = ctx->stream;
+    char *d = ctx->stage_a.as<char>();
+    if (tb) ESFM_HIP_TRY(hipMemcpyAsync(d, t, tb, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(hipMemcpyAsync(d + tb, q, qb, hipMemcpyHostToDevice, st));
+    const int32_t offs[3] = {0, nt, nt + nq};
+    const int32_t pr[2] = {1, 0};
+    int64_t out_off[2];
+    PairPlan plan;
+    if (int rc = make_plan(offs, 2, pr, 1, metric == ESFM_L2_F32 ? kL2QueryBlock : kHammingQueryBlock, out_off, &plan)) return rc;
+    const PairDesc *dev_tab = nullptr;
+    if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
+    if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)nq)) return rc;
+    if (int rc = ctx->knn_dist.reserve(sizeof(float) * 2 * (size_t)nq)) return rc;
+    if (int rc = knn2_core(ctx, metric, d, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>())) return rc;
+    if (!filtered) {
+        ESFM_HIP_TRY(hipMemcpyAsync(o_a, ctx->knn_idx.ptr, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipMemcpyAsync(o_c, ctx->knn_dist.ptr, sizeof(float) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipStreamSynchronize(st));
+        return ESFM_OK;
+    }
+    if (int rc = ctx->stage_b.reserve(sizeof(int32_t) * (size_t)nq)) return rc;
+    if (int rc = ctx->stage_c.reserve(sizeof(int32_t) * (size_t)nq)) return rc;
+    if (int rc = ctx->stage_d.reserve(sizeof(float) * (size_t)nq)) return rc;
+    if (int rc = ctx->stage_e.reserve(sizeof(int32_t))) return rc;
+    if (int rc = esfm::launch_ratio_compact(st, dev_tab, 1, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio,
+                                            ctx->stage_b.as<int32_t>(), ctx->stage_c.as<int32_t>(), ctx->stage_d.as<float>(),
+                                            ctx->stage_e.as<int32_t>()))
+        return rc;
+    int32_t n = 0;
+    ESFM_HIP_TRY(hipMemcpyAsync(&n, ctx->stage_e.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    if (n > 0) {
+        ESFM_HIP_TRY(hipMemcpyAsync(o_a, ctx->stage_b.ptr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipMemcpyAsync(o_b, ctx->stage_c.ptr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipMemcpyAsync(o_c, ctx->stage_d.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (n_out) *n_out = n;
+    return ESFM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esfm_knn2_l2_f32(esfm_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim, int32_t *idx, float *dist)
+{
+    if (nq > 0 && (!idx || !dist)) { esfm::set_error("idx/dist is NULL"); return ESFM_ERR_INVALID_ARG; }
+    return single_pair(ctx, ESFM_L2_F32, q, nq, t, nt, dim, false, 0.0, idx, nullptr, dist, nullptr);
+}
+
+int esfm_knn2_hamming(esfm_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes, int32_t *idx, float *dist)
+{
+    if (nq > 0 && (!idx || !dist)) { esfm::set_error("idx/dist is NULL"); return ESFM_ERR_INVALID_ARG; }
+    return single_pair(ctx, ESFM_HAMMING, q, nq, t, nt, nbytes, false, 0.0, idx, nullptr, dist, nullptr);
+}
+
+int esfm_match_l2_f32(esfm_ctx *ctx, const float *q, int nq, const float *t, int nt, int dim, double ratio,
+                      int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
+{
+    if (!n_out || (nq > 0 && (!query_idx || !train_idx || !distance))) { esfm::set_error("output pointer is NULL"); return ESFM_ERR_INVALID_ARG; }
+    return single_pair(ctx, ESFM_L2_F32, q, nq, t, nt, dim, true, ratio, query_idx, train_idx, distance, n_out);
+}
+
+int esfm_match_hamming(esfm_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int nbytes, double ratio,
+                       int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
+{
+    if (!n_out || (nq > 0 && (!query_idx || !train_idx || !distance))) { esfm::set_error("output pointer is NULL"); return ESFM_ERR_INVALID_ARG; }
+    return single_pair(ctx, ESFM_HAMMING, q, nq, t, nt, nbytes, true, ratio, query_idx, train_idx, distance, n_out);
+}
+
+int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
+                        int width, const int32_t *pairs, int n_pairs, int32_t *knn_idx_dev, float *knn_dist_dev,
+                        int64_t *out_offset)
+{
+    if (int rc = check_common(ctx, metric, width)) return rc;
+    ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
+    PairPlan plan;
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : kHammingQueryBlock,
+                           out_offset, &plan))
+        return rc;
+    if (plan.total_queries == 0) return ESFM_OK;
+    ESFM_REQUIRE(desc_dev && knn_idx_dev && knn_dist_dev, "device pointer is NULL");
+    const PairDesc *dev_tab = nullptr;
+    if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
+    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev);
+}
+
+int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
+                         int width, const int32_t *pairs, int n_pairs, double ratio, int32_t *query_idx_dev,
+                         int32_t *train_idx_dev, float *distance_dev, int32_t *n_out_dev, int64_t *out_offset)
+{
+    if (int rc = check_common(ctx, metric, width)) return rc;
+    ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
+    PairPlan plan;
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : kHammingQueryBlock,
+                           out_offset, &plan))
+        return rc;
+    if (n_pairs == 0) return ESFM_OK;
+    ESFM_REQUIRE(n_out_dev != nullptr, "n_out_dev is NULL");
+    ESFM_REQUIRE(plan.total_queries == 0 || (desc_dev && query_idx_dev && train_idx_dev && distance_dev), "device pointer is NULL");
+    const PairDesc *dev_tab = nullptr;
+    if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
+    if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(plan.total_queries, 1))) return rc;
+    if (int rc = ctx->knn_dist.reserve(sizeof(float) * 2 * (size_t)std::max<int64_t>(plan.total_queries, 1))) return rc;
+    if (int rc = knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>())) return rc;
+    return esfm::launch_ratio_compact(ctx->stream, dev_tab, n_pairs, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio,
+                                      query_idx_dev, train_idx_dev, distance_dev, n_out_dev);
+}
+
+int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+    int32_t c = 0;
+    if (ctx->counters.ptr) {
+        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (n_queries) *n_queries = ctx->last_n_queries;
+    if (n_rescanned) *n_rescanned = c;
+    return ESFM_OK;
+}
+
+// Pair list of the reference's loop (sfm.cpp:140-143), sharded.  Greedy longest-processing-time
+// over pairs sorted by descending cost keeps shards within one pair's cost of each other; inside a
+// shard the reference order (i ascending, j ascending) is kept so results concatenate trivially.
+int esfm_shard_pair_list(int n_frames, const int32_t *rows_per_frame, int rank, int world, int32_t *pairs_out)
+{
+    if (n_frames < 0 || world < 1 || rank < 0 || rank >= world || !pairs_out) {
+        esfm::set_error("esfm_shard_pair_list: bad arguments");
+        return ESFM_ERR_INVALID_ARG;
+    }
+    struct Item { int i, j; double cost; };
+    std::vector<Item> items;
+    items.reserve((size_t)n_frames * (size_t)std::max(n_frames - 1, 0) / 2);
+    for (int i = 0; i < n_frames; ++i)
+        for (int j = 0; j < i; ++j)
+            items.push_back({i, j, rows_per_frame ? (double)rows_per_frame[i] * (double)rows_per_frame[j] : 1.0});
+    std::vector<int> order(items.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[(size_t)a].cost > items[(size_t)b].cost; });
+    std::vector<double> load((size_t)world, 0.0);
+    std::vector<char> mine(items.size(), 0);
+    for (int k : order) {
+        int best = 0;
+        for (int w = 1; w < world; ++w) if (load[(size_t)w] < load[(size_t)best]) best = w;
+        load[(size_t)best] += items[(size_t)k].cost;
+        if (best == rank) mine[(size_t)k] = 1;
+    }
+    int n = 0;
+    for (size_t k = 0; k < items.size(); ++k)
+        if (mine[k]) { pairs_out[2 * n] = items[k].i; pairs_out[2 * n + 1] = items[k].j; ++n; }
+    return n;
+}
+
+}  // extern "C"

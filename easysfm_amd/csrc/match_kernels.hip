@@ -1,0 +1,518 @@
+// Pairwise descriptor matching on gfx950 (MI355X): the replacement for the
+// knnMatch(...,2) + Lowe ratio loop of FeatureMatching::matchFeaturesSURF / ORB
+// (reference cpp_code/src/feature_matching.cpp:115-142 and :71-97), batched over
+// the pair loop of cpp_code/test/sfm.cpp:140-161.
+//
+// L2 (SURF, float):
+//   l2_row_norms_kernel      |t|^2 per descriptor row
+//   l2_knn_mfma_kernel       distance GEMM on v_mfma_f32_32x32x2_f32 with a fused
+//                            per-lane top-3 epilogue, then an exact re-rank of the
+//                            6 candidates per query in the oracle's summation
+//                            order and a rounding-error certificate
+//   l2_exact_scan_kernel     exact brute-force scan for the (rare) queries the
+//                            certificate rejects, and for widths without an MFMA build
+// Hamming (ORB, 256-bit):
+//   hamming_knn_kernel       XOR + popcount, (distance,index) packed into one u32 key
+// Both:
+//   ratio_compact_kernel     ratio test in double + ordered compaction per pair
+//
+// DESIGN.md "Matching" explains the data layout and the certificate.
+#include "match_kernels.hpp"
+
+#include <float.h>
+
+namespace esfm {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+
+__device__ __forceinline__ int xcd_remap(int bid, int nb)
+{
+    // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8).  Give each XCD a
+    // contiguous range of logical blocks so that the blocks sharing one pair's train set hit the
+    // same 4 MiB L2.  Bijective for any nb.
+    const int q = nb >> 3, r = nb & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+__device__ __forceinline__ int find_pair_by_block(const PairDesc *pairs, int n_pairs, int lb)
+{
+    int lo = 0, hi = n_pairs - 1;  // last p with blk_off[p] <= lb
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (pairs[mid].blk_off <= lb) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int find_pair_by_query(const PairDesc *pairs, int n_pairs, long long gq)
+{
+    int lo = 0, hi = n_pairs - 1;  // last p with out_off[p] <= gq
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (pairs[mid].out_off <= gq) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Squared L2 distance in the oracle's canonical order (oracle/match_ref.c esfm_ref_l2sqr):
+// 8 partial sums over blocks of 8, separate multiply and add (no FMA), (acc[c]+acc[c+4]) summed
+// left to right, then the scalar tail.  Bit-exact with the CPU restatement.
+template <bool VEC>
+__device__ __forceinline__ float l2sqr_canonical(const float *__restrict__ a, const float *__restrict__ b, int n)
+{
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j <= n - 8; j += 8) {
+        float av[8], bv[8];
+        if (VEC) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(a + j), a1 = *reinterpret_cast<const float4 *>(a + j + 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(b + j), b1 = *reinterpret_cast<const float4 *>(b + j + 4);
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w; av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { av[c] = a[j + c]; bv[c] = b[j + c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = __fsub_rn(av[c], bv[c]);
+            acc[c] = __fadd_rn(acc[c], __fmul_rn(t, t));
+        }
+    }
+    const float s0 = __fadd_rn(acc[0], acc[4]);
+    const float s1 = __fadd_rn(acc[1], acc[5]);
+    const float s2 = __fadd_rn(acc[2], acc[6]);
+    const float s3 = __fadd_rn(acc[3], acc[7]);
+    float d = __fadd_rn(s0, s1);
+    d = __fadd_rn(d, s2);
+    d = __fadd_rn(d, s3);
+    for (; j < n; ++j) {
+        const float t = __fsub_rn(a[j], b[j]);
+        d = __fadd_rn(d, __fmul_rn(t, t));
+    }
+    return d;
+}
+
+// (distance, index) ordered pair; "better" = the order a stable ascending scan with strict-<
+// insertion produces (OpenCV batchDistance): smaller distance, ties to the lower train index.
+struct Cand { float d; int i; float d2; };
+
+__device__ __forceinline__ bool cand_better(float d, int i, const Cand &b)
+{
+    return (i >= 0) && (b.i < 0 || d < b.d || (d == b.d && i < b.i));
+}
+
+__device__ __forceinline__ void best2_insert(Cand &b0, Cand &b1, float d, int i, float d2)
+{
+    if (cand_better(d, i, b1)) {
+        if (cand_better(d, i, b0)) { b1 = b0; b0.d = d; b0.i = i; b0.d2 = d2; }
+        else { b1.d = d; b1.i = i; b1.d2 = d2; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// |row|^2 for every descriptor row (float chain; only used by the approximate pass + certificate)
+__global__ void l2_row_norms_kernel(const float *__restrict__ desc, int dim, long long n_rows, float *__restrict__ norms)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const float *p = desc + r * dim;
+    float s = 0.f;
+    for (int k = 0; k < dim; ++k) s = fmaf(p[k], p[k], s);
+    norms[r] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA distance pass.
+//
+// One workgroup (4 waves) owns QB = 128 query rows of one pair and streams the whole train set
+// through LDS in tiles of TT = 64 rows.  Each wave owns 32 queries for the entire kernel: their
+// descriptors, scaled by -2, stay in HALF = DIM/2 VGPRs per lane as the MFMA B operand
+// (lane l: query l&31, features [HALF*(l>>5), HALF*(l>>5)+HALF)).  A train sub-tile of 32 rows is
+// the A operand, read from LDS with ds_read_b128 (XOR-swizzled 16-B slots: conflict-free).  The
+// accumulator starts at |t|^2, so after DIM/2 MFMAs D[t][q] = |t|^2 - 2 q.t  (= d^2 - |q|^2) with
+// no epilogue arithmetic.  C/D layout: lane l, reg r -> train row (r&3)+8*(r>>2)+4*(l>>5), query
+// l&31, i.e. the 16 values in a lane belong to ONE query, so the running top-3 is lane-local.
+template <int DIM>
+__global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restrict__ desc, const float *__restrict__ norms,
+                                                          const PairDesc *__restrict__ pairs, int n_pairs,
+                                                          int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
+                                                          int32_t *__restrict__ flagged, int32_t *__restrict__ counters,
+                                                          int flag_cap)
+{
+    constexpr int QB = 128, TT = 64, HALF = DIM / 2, NCH = HALF / 4, SLOTS = DIM / 4;
+    constexpr int STAGE = TT * SLOTS / 256;  // float4 per thread per tile
+    static_assert(DIM % 8 == 0 && STAGE >= 1, "DIM");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *lds_tile = reinterpret_cast<float4 *>(smem);                       // [2][TT*SLOTS]
+    float *lds_norm = reinterpret_cast<float *>(smem + 2 * TT * SLOTS * 16);   // [2][TT]
+    float *lds_red = lds_norm + 2 * TT;                                        // [4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = find_pair_by_block(pairs, n_pairs, lb);
+    const PairDesc pd = pairs[pi];
+    const int nq = pd.nq, nt = pd.nt;
+    const float *__restrict__ Q = desc + (size_t)pd.q_row0 * DIM;
+    const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
+    const float *__restrict__ tn = norms + pd.t_row0;
+    const int qrow = (lb - pd.blk_off) * QB + wave * 32 + j;
+    const bool qvalid = qrow < nq;
+
+    // B operand: this lane's half of its query row, times -2 (exact scaling).
+    float breg[HALF];
+    {
+        const float4 *qp = reinterpret_cast<const float4 *>(Q + (size_t)(qvalid ? qrow : 0) * DIM + h * HALF);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float4 v = qvalid ? qp[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            breg[4 * c + 0] = -2.f * v.x; breg[4 * c + 1] = -2.f * v.y; breg[4 * c + 2] = -2.f * v.z; breg[4 * c + 3] = -2.f * v.w;
+        }
+    }
+
+    // running top-3 (approximate key s = |t|^2 - 2 q.t, code = 16*subtile + reg)
+    float v0 = INFINITY, v1 = INFINITY, v2 = INFINITY;
+    int c0 = -1, c1 = -1, c2 = -1;
+    float tmax = 0.f;  // max |t|^2 seen by this thread (threads < TT only)
+
+    const int ntiles = (nt + TT - 1) / TT;
+    float4 stage[STAGE];
+    float stage_n = INFINITY;
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < STAGE; ++i) {
+            const int s = tid + 256 * i, row = s / SLOTS, slot = s % SLOTS, t = tile * TT + row;
+            stage[i] = (t < nt) ? *reinterpret_cast<const float4 *>(T + (size_t)t * DIM + slot * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < TT) { const int t = tile * TT + tid; stage_n = (t < nt) ? tn[t] : INFINITY; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < STAGE; ++i) {
+            const int s = tid + 256 * i, row = s / SLOTS, slot = s % SLOTS;
+            lds_tile[buf * TT * SLOTS + row * SLOTS + (slot ^ (row & 15))] = stage[i];
+        }
+        if (tid < TT) { lds_norm[buf * TT + tid] = stage_n; if (stage_n < INFINITY) tmax = fmaxf(tmax, stage_n); }
+    };
+
+    if (ntiles > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) gload(tile + 1);  // in flight under the MFMAs below
+#pragma unroll
+        for (int sub = 0; sub < TT / 32; ++sub) {
+            floatx16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 n4 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + sub * 32 + 8 * g + 4 * h]);
+                acc[4 * g + 0] = n4.x; acc[4 * g + 1] = n4.y; acc[4 * g + 2] = n4.z; acc[4 * g + 3] = n4.w;
+            }
+            const int row = sub * 32 + j;
+            float4 a[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) a[c] = lds_tile[buf * TT * SLOTS + row * SLOTS + ((h * NCH + c) ^ (row & 15))];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, breg[4 * c + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, breg[4 * c + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, breg[4 * c + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, breg[4 * c + 3], acc, 0, 0, 0);
+            }
+            const int code_base = (tile * (TT / 32) + sub) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s = acc[r];
+                const int code = code_base + r;
+                const bool l2 = s < v2, l1 = s < v1, l0 = s < v0;
+                c2 = l1 ? c1 : (l2 ? code : c2);
+                c1 = l0 ? c0 : (l1 ? code : c1);
+                c0 = l0 ? code : c0;
+                v2 = __builtin_amdgcn_fmed3f(v1, v2, s);
+                v1 = __builtin_amdgcn_fmed3f(v0, v1, s);
+                v0 = fminf(v0, s);
+            }
+        }
+        if (tile + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // max |t|^2 over the train set (for the certificate's error bound)
+    {
+        float m = tmax;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) lds_red[wave] = m;
+        __syncthreads();
+        tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
+    }
+
+    // ---- exact re-rank of this lane's 3 candidates in the oracle's order ----
+    Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
+    float ed[3], ed2[3];
+    int ei[3];
+    {
+        const int cc[3] = {c0, c1, c2};
+        const float *qp = Q + (size_t)(qvalid ? qrow : 0) * DIM;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            ei[m] = -1; ed[m] = FLT_MAX; ed2[m] = 0.f;
+            if (cc[m] >= 0 && qvalid) {
+                const int r = cc[m] & 15;
+                const int t = (cc[m] >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
+                ei[m] = t; ed2[m] = d2; ed[m] = __fsqrt_rn(d2);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) best2_insert(b0, b1, ed[m], ei[m], ed2[m]);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const float pd_ = __shfl_xor(ed[m], 32), pd2 = __shfl_xor(ed2[m], 32);
+        const int pi_ = __shfl_xor(ei[m], 32);
+        best2_insert(b0, b1, pd_, pi_, pd2);
+    }
+    const float tau = fminf(v2, __shfl_xor(v2, 32));  // every train outside the 6 candidates has s >= tau
+
+    if (qvalid && h == 0) {
+        const size_t o = 2 * ((size_t)pd.out_off + qrow);
+        knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
+        knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
+        // Certificate: |(|q|^2 + s(t)) - D(t)| <= eps for every train t, with
+        // eps = 2^-16 (|q|^2 + max|t|^2); the candidate set provably contains the two best iff
+        // |q|^2 + tau - eps exceeds the second best exact d^2 by more than sqrt's rounding can hide.
+        bool certified = !(tau < INFINITY);
+        if (!certified && b1.i >= 0) {
+            const double qn = (double)norms[pd.q_row0 + qrow];
+            const double eps = (qn + (double)tmax) * (1.0 / 65536.0);
+            certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
+        }
+        if (!certified) {
+            const int slot = atomicAdd(&counters[0], 1);
+            if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact brute-force 2-NN for listed queries (flagged != NULL: entries [0, counters[0])) or for
+// every query of every pair (flagged == NULL: entries [0, total_queries)).  One workgroup per
+// entry, threads stride over the train rows, lexicographic (distance, index) reduction.
+template <bool VEC>
+__global__ __launch_bounds__(256) void l2_exact_scan_kernel(const float *__restrict__ desc, int dim,
+                                                            const PairDesc *__restrict__ pairs, int n_pairs,
+                                                            const int32_t *__restrict__ flagged,
+                                                            const int32_t *__restrict__ counters, long long total_queries,
+                                                            int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+{
+    __shared__ float s_d[2][256];
+    __shared__ int s_i[2][256];
+    const int tid = threadIdx.x;
+    const long long n_entries = flagged ? (long long)counters[0] : total_queries;
+    for (long long e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        int pi, qrow;
+        if (flagged) { pi = flagged[2 * e]; qrow = flagged[2 * e + 1]; }
+        else { pi = find_pair_by_query(pairs, n_pairs, e); qrow = (int)(e - pairs[pi].out_off); }
+        const PairDesc pd = pairs[pi];
+        const float *q = desc + ((size_t)pd.q_row0 + qrow) * dim;
+        const float *T = desc + (size_t)pd.t_row0 * dim;
+        Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
+        for (int t = tid; t < pd.nt; t += 256) {
+            const float d2 = l2sqr_canonical<VEC>(q, T + (size_t)t * dim, dim);
+            best2_insert(b0, b1, __fsqrt_rn(d2), t, d2);
+        }
+        s_d[0][tid] = b0.d; s_i[0][tid] = b0.i; s_d[1][tid] = b1.d; s_i[1][tid] = b1.i;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) {
+                Cand a0 = {s_d[0][tid], s_i[0][tid], 0.f}, a1 = {s_d[1][tid], s_i[1][tid], 0.f};
+                best2_insert(a0, a1, s_d[0][tid + w], s_i[0][tid + w], 0.f);
+                best2_insert(a0, a1, s_d[1][tid + w], s_i[1][tid + w], 0.f);
+                s_d[0][tid] = a0.d; s_i[0][tid] = a0.i; s_d[1][tid] = a1.d; s_i[1][tid] = a1.i;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const size_t o = 2 * ((size_t)pd.out_off + qrow);
+            knn_idx[o] = s_i[0][0]; knn_idx[o + 1] = s_i[1][0];
+            knn_dist[o] = s_i[0][0] >= 0 ? s_d[0][0] : FLT_MAX;
+            knn_dist[o + 1] = s_i[1][0] >= 0 ? s_d[1][0] : FLT_MAX;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hamming 2-NN (ORB).  One thread per query row, descriptor words in VGPRs; the train row is
+// wave-uniform, so it is fetched through the scalar cache (s_load) and XOR'd against the VGPRs.
+// key = distance << 22 | train index: one u32 min orders by (distance, index) exactly.
+template <int NW>
+__global__ __launch_bounds__(256) void hamming_knn_kernel(const uint32_t *__restrict__ desc, const PairDesc *__restrict__ pairs,
+                                                          int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+{
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = find_pair_by_block(pairs, n_pairs, lb);
+    const PairDesc pd = pairs[pi];
+    const int qrow = (lb - pd.blk_off) * 256 + threadIdx.x;
+    const bool qvalid = qrow < pd.nq;
+    uint32_t qw[NW];
+    {
+        const uint32_t *qp = desc + ((size_t)pd.q_row0 + (qvalid ? qrow : 0)) * NW;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) qw[w] = qp[w];
+    }
+    const uint32_t *__restrict__ T = desc + (size_t)pd.t_row0 * NW;
+    uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    const int nt = pd.nt;
+#pragma unroll 4
+    for (int t = 0; t < nt; ++t) {
+        const uint32_t *tp = T + (size_t)t * NW;  // wave-uniform address
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) d += __popc(qw[w] ^ tp[w]);
+        const uint32_t key = (d << 22) | (uint32_t)t;
+        const uint32_t hi = max(k0, key);
+        k0 = min(k0, key);
+        k1 = min(k1, hi);
+    }
+    if (qvalid) {
+        const size_t o = 2 * ((size_t)pd.out_off + qrow);
+        const bool h0 = nt >= 1, h1 = nt >= 2;
+        knn_idx[o] = h0 ? (int)(k0 & 0x3FFFFFu) : -1;
+        knn_idx[o + 1] = h1 ? (int)(k1 & 0x3FFFFFu) : -1;
+        knn_dist[o] = h0 ? (float)(k0 >> 22) : FLT_MAX;
+        knn_dist[o + 1] = h1 ? (float)(k1 >> 22) : FLT_MAX;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lowe ratio test (feature_matching.cpp:88 / :133: float < double * float, i.e. in double) and an
+// order-preserving compaction: one workgroup per pair, survivors written query-ascending.
+__global__ __launch_bounds__(256) void ratio_compact_kernel(const PairDesc *__restrict__ pairs, const int32_t *__restrict__ knn_idx,
+                                                            const float *__restrict__ knn_dist, double ratio,
+                                                            int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
+                                                            float *__restrict__ distance, int32_t *__restrict__ n_out)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const PairDesc pd = pairs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < pd.nq; q0 += 256) {
+        const int q = q0 + tid;
+        bool pass = false;
+        int ti = -1; float d0 = 0.f;
+        if (q < pd.nq) {
+            const size_t o = 2 * ((size_t)pd.out_off + q);
+            const int i0 = knn_idx[o], i1 = knn_idx[o + 1];
+            d0 = knn_dist[o];
+            const float d1 = knn_dist[o + 1];
+            ti = i0;
+            pass = (i0 >= 0) && (i1 >= 0) && ((double)d0 < ratio * (double)d1);
+        }
+        const unsigned long long m = __ballot(pass);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (pass) {
+            const size_t o = (size_t)pd.out_off + off + before;
+            query_idx[o] = q; train_idx[o] = ti; distance[o] = d0;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) n_out[blockIdx.x] = s_base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+int launch_l2_norms(hipStream_t st, const float *desc, int dim, long long n_rows, float *norms)
+{
+    if (n_rows <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(l2_row_norms_kernel, dim3(div_up(n_rows, 256)), dim3(256), 0, st, desc, dim, n_rows, norms);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+bool l2_mfma_supported(int dim) { return dim == 64 || dim == 128; }
+
+int launch_l2_knn_mfma(hipStream_t st, int dim, const float *desc, const float *norms, const PairDesc *pairs, int n_pairs,
+                       int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)
+{
+    if (n_blocks <= 0) return ESFM_OK;
+    if (dim == 64) {
+        constexpr size_t lds = 2 * 64 * 16 * 16 + 2 * 64 * 4 + 16;
+        hipLaunchKernelGGL(l2_knn_mfma_kernel<64>, dim3(n_blocks), dim3(256), lds, st, desc, norms, pairs, n_pairs, knn_idx,
+                           knn_dist, flagged, counters, flag_cap);
+    } else if (dim == 128) {
+        constexpr size_t lds = 2 * 64 * 32 * 16 + 2 * 64 * 4 + 16;
+        hipLaunchKernelGGL(l2_knn_mfma_kernel<128>, dim3(n_blocks), dim3(256), lds, st, desc, norms, pairs, n_pairs, knn_idx,
+                           knn_dist, flagged, counters, flag_cap);
+    } else {
+        set_error("l2 MFMA kernel is built for dim 64 and 128 only (got %d)", dim);
+        return ESFM_ERR_UNSUPPORTED;
+    }
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairDesc *pairs, int n_pairs,
+                         const int32_t *flagged, const int32_t *counters, long long total_queries, int grid,
+                         int32_t *knn_idx, float *knn_dist)
+{
+    if (grid <= 0) return ESFM_OK;
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(l2_exact_scan_kernel<true>, dim3(grid), dim3(256), 0, st, desc, dim, pairs, n_pairs, flagged, counters,
+                           total_queries, knn_idx, knn_dist);
+    else
+        hipLaunchKernelGGL(l2_exact_scan_kernel<false>, dim3(grid), dim3(256), 0, st, desc, dim, pairs, n_pairs, flagged, counters,
+                           total_queries, knn_idx, knn_dist);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+bool hamming_supported(int nbytes) { return nbytes == 16 || nbytes == 32 || nbytes == 64; }
+
+int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, const PairDesc *pairs, int n_pairs, int n_blocks,
+                       int32_t *knn_idx, float *knn_dist)
+{
+    if (n_blocks <= 0) return ESFM_OK;
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(desc);
+    if (nbytes == 32)
+        hipLaunchKernelGGL(hamming_knn_kernel<8>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);
+    else if (nbytes == 64)
+        hipLaunchKernelGGL(hamming_knn_kernel<16>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);
+    else if (nbytes == 16)
+        hipLaunchKernelGGL(hamming_knn_kernel<4>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);
+    else {
+        set_error("hamming kernel is built for 16/32/64-byte descriptors (got %d)", nbytes);
+        return ESFM_ERR_UNSUPPORTED;
+    }
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
+                         double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(n_pairs), dim3(256), 0, st, pairs, knn_idx, knn_dist, ratio, query_idx,
+                       train_idx, distance, n_out);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+}  // namespace esfm

@@ -1,0 +1,31 @@
+// Launch interface between match_api.cpp (host logic) and match_kernels.hip (gfx950 kernels).
+#pragma once
+
+#include "common.hpp"
+
+namespace esfm {
+
+// One image pair of the pair loop (cpp_code/test/sfm.cpp:140-161), rows counted in the
+// concatenated descriptor buffer.
+struct PairDesc {
+    int32_t q_row0, nq;   // query set: first row, row count
+    int32_t t_row0, nt;   // train set
+    int64_t out_off;      // first output slot of this pair (exclusive prefix sum of nq)
+    int32_t blk_off;      // first workgroup of this pair in the knn launch
+    int32_t pad;
+};
+
+int launch_l2_norms(hipStream_t st, const float *desc, int dim, long long n_rows, float *norms);
+bool l2_mfma_supported(int dim);
+int launch_l2_knn_mfma(hipStream_t st, int dim, const float *desc, const float *norms, const PairDesc *pairs, int n_pairs,
+                       int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap);
+int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairDesc *pairs, int n_pairs,
+                         const int32_t *flagged, const int32_t *counters, long long total_queries, int grid,
+                         int32_t *knn_idx, float *knn_dist);
+bool hamming_supported(int nbytes);
+int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, const PairDesc *pairs, int n_pairs, int n_blocks,
+                       int32_t *knn_idx, float *knn_dist);
+int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
+                         double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
+
+}  // namespace esfm

@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's matching interface over the C ABI.
+
+``FeatureMatching.matchFeaturesSURF / matchFeaturesORB`` keep the names, argument meaning and
+append-to-``matches`` behaviour of cpp_code/include/feature_matching.h:17-21 (bodies:
+cpp_code/src/feature_matching.cpp:71-97, :115-142).  ``match_all_pairs`` is the batched pair loop of
+cpp_code/test/sfm.cpp:140-161 with descriptors resident in HBM.  All compute happens in
+libesfm_hip.so; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ESFM_HAMMING, ESFM_L2_F32, Context, check, default_context, lib
+from .types import DMatch, Frame
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def _as_desc(a, dtype) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype)
+    if a.ndim != 2:
+        raise ValueError("descriptors must be a 2-D array [rows, width]")
+    return a
+
+
+def knn_match_l2(q, t, ctx: Optional[Context] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """knnMatch(q, t, out, 2) under NORM_L2 (exact brute force).  Returns (idx[nq,2], dist[nq,2])."""
+    ctx = ctx or default_context()
+    q = _as_desc(q, np.float32); t = _as_desc(t, np.float32)
+    if q.shape[1] != t.shape[1]:
+        raise ValueError("descriptor widths differ")
+    nq = q.shape[0]
+    idx = np.full((nq, 2), -1, np.int32); dist = np.zeros((nq, 2), np.float32)
+    check(lib().esfm_knn2_l2_f32(ctx.handle, _ptr(q), nq, _ptr(t), t.shape[0], q.shape[1], _ptr(idx), _ptr(dist)))
+    return idx, dist
+
+
+def knn_match_hamming(q, t, ctx: Optional[Context] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """knnMatch(q, t, out, 2) for "BruteForce-Hamming".  Returns (idx[nq,2], dist[nq,2])."""
+    ctx = ctx or default_context()
+    q = _as_desc(q, np.uint8); t = _as_desc(t, np.uint8)
+    if q.shape[1] != t.shape[1]:
+        raise ValueError("descriptor widths differ")
+    nq = q.shape[0]
+    idx = np.full((nq, 2), -1, np.int32); dist = np.zeros((nq, 2), np.float32)
+    check(lib().esfm_knn2_hamming(ctx.handle, _ptr(q), nq, _ptr(t), t.shape[0], q.shape[1], _ptr(idx), _ptr(dist)))
+    return idx, dist
+
+
+def _match(fn, q, t, ratio, ctx):
+    nq = q.shape[0]
+    qi = np.empty(max(nq, 1), np.int32); ti = np.empty(max(nq, 1), np.int32); d = np.empty(max(nq, 1), np.float32)
+    n = C.c_int32(0)
+    check(fn(ctx.handle, _ptr(q), nq, _ptr(t), t.shape[0], q.shape[1], float(ratio), _ptr(qi), _ptr(ti), _ptr(d), C.byref(n)))
+    return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
+
+
+def match_l2(q, t, ratio: float = 0.5, ctx: Optional[Context] = None):
+    """2-NN + Lowe ratio for float descriptors; returns (queryIdx, trainIdx, distance) arrays."""
+    ctx = ctx or default_context()
+    return _match(lib().esfm_match_l2_f32, _as_desc(q, np.float32), _as_desc(t, np.float32), ratio, ctx)
+
+
+def match_hamming(q, t, ratio: float = 0.8, ctx: Optional[Context] = None):
+    ctx = ctx or default_context()
+    return _match(lib().esfm_match_hamming, _as_desc(q, np.uint8), _as_desc(t, np.uint8), ratio, ctx)
+
+
+class FeatureMatching:
+    """Mirror of p3dv::FeatureMatching's matching members (feature_matching.h:17-21)."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> Context:
+        return self._ctx or default_context()
+
+    def matchFeaturesORB(self, cur_frame_1: Frame, cur_frame_2: Frame, matches: List[DMatch],
+                         ratio_thre: float = 0.8, show: bool = False) -> bool:
+        """feature_matching.cpp:71-97.  Query = cur_frame_1, train = cur_frame_2; survivors are
+        APPENDED to `matches` (the reference never clears it, :90)."""
+        qi, ti, d = match_hamming(cur_frame_1.descriptors, cur_frame_2.descriptors, ratio_thre, self.ctx)
+        matches.extend(DMatch(int(a), int(b), float(c)) for a, b, c in zip(qi, ti, d))
+        return True
+
+    def matchFeaturesSURF(self, cur_frame_1: Frame, cur_frame_2: Frame, matches: List[DMatch],
+                          ratio_thre: float = 0.5, show: bool = False) -> bool:
+        """feature_matching.cpp:115-142 with the exact brute-force matcher the Python prototype
+        uses (feature_match.py:33-34) instead of the approximate FlannBasedMatcher (:120)."""
+        qi, ti, d = match_l2(cur_frame_1.descriptors, cur_frame_2.descriptors, ratio_thre, self.ctx)
+        matches.extend(DMatch(int(a), int(b), float(c)) for a, b, c in zip(qi, ti, d))
+        return True
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PairMatches:
+    """Result of a batched call: pair p owns out slice [offset[p], offset[p] + n_out[p])."""
+    pairs: np.ndarray        # int32 [n_pairs, 2] (query set, train set)
+    offset: np.ndarray       # int64 [n_pairs + 1]
+    n_out: "object"          # device int32 [n_pairs]   (torch tensor)
+    query_idx: "object"      # device int32 [sum nq]
+    train_idx: "object"      # device int32
+    distance: "object"       # device float32
+
+    def to_host(self) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+        n = self.n_out.cpu().numpy()
+        q = self.query_idx.cpu().numpy(); t = self.train_idx.cpu().numpy(); d = self.distance.cpu().numpy()
+        out = []
+        for p in range(len(self.pairs)):
+            o = int(self.offset[p]); k = int(n[p])
+            out.append((q[o:o + k].copy(), t[o:o + k].copy(), d[o:o + k].copy()))
+        return out
+
+
+class DescriptorBank:
+    """All descriptor sets of a reconstruction, concatenated in one HBM buffer (torch owns the
+    memory; the kernels see a raw device pointer)."""
+
+    def __init__(self, sets: Sequence[np.ndarray], metric: int, device: str = "cuda:0"):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible: DescriptorBank needs a GPU (easysfm_amd has no CPU fallback)")
+        self.metric = metric
+        dt = np.float32 if metric == ESFM_L2_F32 else np.uint8
+        sets = [_as_desc(s, dt) for s in sets]
+        widths = {s.shape[1] for s in sets}
+        if len(widths) != 1:
+            raise ValueError("all descriptor sets must have the same width")
+        self.width = widths.pop()
+        self.rows = np.array([s.shape[0] for s in sets], np.int32)
+        self.row_offset = np.zeros(len(sets) + 1, np.int32)
+        np.cumsum(self.rows, out=self.row_offset[1:])
+        host = np.concatenate(sets, axis=0) if sets else np.zeros((0, self.width), dt)
+        self.device = torch.device(device)
+        self.data = torch.from_numpy(host).to(self.device)
+
+    @property
+    def n_sets(self) -> int:
+        return len(self.rows)
+
+
+class PairMatcher:
+    """Batched pair loop (sfm.cpp:140-161): one call matches a whole pair list on one GPU.
+    Output buffers are allocated once and reused across calls."""
+
+    def __init__(self, bank: DescriptorBank, pairs: np.ndarray, ctx: Optional[Context] = None):
+        import torch
+        self.bank = bank
+        self.pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        self.torch = torch
+        dev_index = bank.device.index or 0
+        if ctx is None:
+            with torch.cuda.device(dev_index):
+                ctx = Context(dev_index, torch.cuda.current_stream().cuda_stream)
+        self.ctx = ctx
+        total = int(bank.rows[self.pairs[:, 0]].sum()) if len(self.pairs) else 0
+        self.total_queries = total
+        dev = bank.device
+        self.query_idx = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        self.train_idx = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        self.distance = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+        self.n_out = torch.zeros(max(len(self.pairs), 1), dtype=torch.int32, device=dev)
+        self.offset = np.zeros(len(self.pairs) + 1, np.int64)
+        self.knn_idx = None
+        self.knn_dist = None
+
+    def match(self, ratio: float) -> PairMatches:
+        """Enqueue the whole pair list; does not synchronise."""
+        b = self.bank
+        check(lib().esfm_match_pairs_dev(
+            self.ctx.handle, b.metric, C.c_void_p(b.data.data_ptr()), _ptr(b.row_offset), b.n_sets, b.width,
+            _ptr(self.pairs), len(self.pairs), float(ratio),
+            C.c_void_p(self.query_idx.data_ptr()), C.c_void_p(self.train_idx.data_ptr()),
+            C.c_void_p(self.distance.data_ptr()), C.c_void_p(self.n_out.data_ptr()), _ptr(self.offset)))
+        return PairMatches(self.pairs, self.offset, self.n_out, self.query_idx, self.train_idx, self.distance)
+
+    def knn2(self):
+        """Raw 2-NN table of every pair: (idx[sum nq, 2], dist[sum nq, 2]) device tensors."""
+        torch = self.torch
+        b = self.bank
+        if self.knn_idx is None:
+            self.knn_idx = torch.empty((max(self.total_queries, 1), 2), dtype=torch.int32, device=b.device)
+            self.knn_dist = torch.empty((max(self.total_queries, 1), 2), dtype=torch.float32, device=b.device)
+        check(lib().esfm_knn2_pairs_dev(
+            self.ctx.handle, b.metric, C.c_void_p(b.data.data_ptr()), _ptr(b.row_offset), b.n_sets, b.width,
+            _ptr(self.pairs), len(self.pairs), C.c_void_p(self.knn_idx.data_ptr()), C.c_void_p(self.knn_dist.data_ptr()),
+            _ptr(self.offset)))
+        return self.knn_idx, self.knn_dist
+
+    def stats(self) -> Tuple[int, int]:
+        """(queries, queries re-scanned exactly) of the last L2 call; synchronises."""
+        a = C.c_int64(0); b = C.c_int64(0)
+        check(lib().esfm_match_last_stats(self.ctx.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def shard_pair_list(n_frames: int, rows_per_frame: Optional[np.ndarray], rank: int, world: int) -> np.ndarray:
+    """This rank's share of the (i, j<i) pair list (host-only, no GPU)."""
+    cap = n_frames * (n_frames - 1) // 2
+    out = np.zeros((max(cap, 1), 2), np.int32)
+    rows = None if rows_per_frame is None else np.ascontiguousarray(rows_per_frame, np.int32)
+    n = lib().esfm_shard_pair_list(int(n_frames), _ptr(rows) if rows is not None else None, int(rank), int(world), _ptr(out))
+    if n < 0:
+        check(n)
+    return out[:n].copy()

@@ -206,11 +206,17 @@ typedef struct esfm_ba_summary {
 
 void esfm_ba_options_default(esfm_ba_options *opt);
 
-/* In-place SUM all-reduce over `count` doubles at device pointer `buf_dev`,
- * ordered on `hip_stream`.  Return 0 on success.  Used only when the caller
- * shards observations over several GPUs (one rank per GPU); NULL = single GPU.
- * A torch.distributed (RCCL) implementation is in easysfm_amd/ba.py. */
-typedef int (*esfm_allreduce_fn)(void *user, double *buf_dev, int64_t count, void *hip_stream);
+/* In-place all-reduce over `count` doubles at device pointer `buf_dev`, ordered
+ * on `hip_stream`; op = ESFM_REDUCE_SUM or ESFM_REDUCE_MAX.  Return 0 on success.
+ * Used only when the caller shards observations over several GPUs (one rank per
+ * GPU); NULL = single GPU.  A torch.distributed (RCCL) implementation is in
+ * easysfm_amd/ba.py.  Per LM iteration the solver issues one SUM over the
+ * reduced camera system ((6 n_cam)^2 + 6 n_cam doubles), one SUM over the
+ * per-camera F'F / F'r blocks (42 n_cam doubles, accepted steps only), and SUM /
+ * MAX over a handful of scalars. */
+#define ESFM_REDUCE_SUM 0
+#define ESFM_REDUCE_MAX 1
+typedef int (*esfm_allreduce_fn)(void *user, double *buf_dev, int64_t count, int op, void *hip_stream);
 
 /*
  * The replacement for setBAProblem's parameter packing + solveBA's

@@ -1,0 +1,180 @@
+"""Parity of the HIP matching path (through the C ABI) against the CPU oracle.  Bit-exact: indices
+AND distances (float bit patterns)."""
+import numpy as np
+import pytest
+
+import easysfm_amd as E
+from easysfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _check_knn_l2(ctx, oracle, q, t):
+    idx, dist = E.knn_match_l2(q, t, ctx)
+    ridx, rdist = oracle.knn2_l2(q, t)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(_bits(dist), _bits(rdist))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (5, 3), (33, 31), (64, 64), (129, 200), (500, 1000), (1000, 777)])
+def test_l2_knn_bitexact_ragged(gpu_ctx, oracle_lib, nq, nt):
+    rng = np.random.default_rng(nq * 1000 + nt)
+    q = rng.standard_normal((nq, 64)).astype(np.float32)
+    t = rng.standard_normal((nt, 64)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)
+
+
+def test_l2_empty_and_tiny_train(gpu_ctx, oracle_lib):
+    q = np.random.default_rng(0).standard_normal((10, 64)).astype(np.float32)
+    for nt in (0, 1):
+        t = np.random.default_rng(1).standard_normal((nt, 64)).astype(np.float32)
+        idx, dist = E.knn_match_l2(q, t, gpu_ctx)
+        ridx, rdist = oracle_lib.knn2_l2(q, t)
+        assert np.array_equal(idx, ridx) and np.array_equal(_bits(dist), _bits(rdist))
+        qi, ti, d = E.match_l2(q, t, 0.9, gpu_ctx)
+        assert len(qi) == 0  # reference is UB here; defined as "emit nothing"
+    qi, ti, d = E.match_l2(np.zeros((0, 64), np.float32), q, 0.5, gpu_ctx)
+    assert len(qi) == 0
+
+
+def test_l2_duplicates_and_ties(gpu_ctx, oracle_lib):
+    """Exact duplicates in the train set (distance-0 ties and equal-distance ties): the lower train
+    index must win; more duplicates than the kernel keeps candidates forces the exact re-scan."""
+    rng = np.random.default_rng(7)
+    base = rng.standard_normal((50, 64)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    t = np.concatenate([base, base[:20], base[:20], base[:10], base[:10], base[:10], base[:10], base[:10]], axis=0)
+    perm = rng.permutation(len(t)); t = t[perm]
+    q = np.concatenate([base[:30], base[:30] + 1e-4 * rng.standard_normal((30, 64)).astype(np.float32)], axis=0)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)
+
+
+def test_l2_near_ties(gpu_ctx, oracle_lib):
+    """Train rows that differ from each other by a few ulps: arg-min and the second neighbour must
+    follow the oracle's summation order, not the GEMM's."""
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal((200, 64)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = np.repeat(q[:100], 6, axis=0)
+    t = t * (1.0 + rng.integers(-3, 4, size=t.shape) * np.float32(6e-8))
+    t = np.concatenate([t, rng.standard_normal((300, 64)).astype(np.float32) * 0.1], axis=0).astype(np.float32)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t[rng.permutation(len(t))])
+
+
+def test_l2_unnormalised_and_dim128(gpu_ctx, oracle_lib):
+    rng = np.random.default_rng(11)
+    q = (rng.standard_normal((300, 64)) * rng.uniform(0.1, 30, (300, 1))).astype(np.float32)
+    t = (rng.standard_normal((400, 64)) * rng.uniform(0.1, 30, (400, 1))).astype(np.float32)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)
+    q = rng.standard_normal((150, 128)).astype(np.float32); t = rng.standard_normal((333, 128)).astype(np.float32)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)     # extended SURF
+    q = rng.standard_normal((40, 36)).astype(np.float32); t = rng.standard_normal((90, 36)).astype(np.float32)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)     # no MFMA build: exact-scan path
+    q = rng.standard_normal((40, 37)).astype(np.float32); t = rng.standard_normal((90, 37)).astype(np.float32)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)     # odd width: scalar tail of the canonical sum
+
+
+@pytest.mark.parametrize("ratio", [0.5, 0.7, 0.8, 1.0])
+def test_l2_match_surf_like(gpu_ctx, oracle_lib, ratio):
+    s = synth.surf_like_sets(2, 1500, pool=2048, seed_base=100)
+    qi, ti, d = E.match_l2(s[1], s[0], ratio, gpu_ctx)
+    rq, rt, rd = oracle_lib.match_l2(s[1], s[0], ratio)
+    assert len(rq) > 0
+    assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(_bits(d), _bits(rd))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (3, 2), (64, 65), (257, 300), (1000, 999)])
+def test_hamming_knn_bitexact(gpu_ctx, oracle_lib, nq, nt):
+    rng = np.random.default_rng(nq + 31 * nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    idx, dist = E.knn_match_hamming(q, t, gpu_ctx)
+    ridx, rdist = oracle_lib.knn2_hamming(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+
+
+def test_hamming_forced_ties(gpu_ctx, oracle_lib):
+    """All-equal rows and few distinct distances: ties for first AND second place everywhere."""
+    rng = np.random.default_rng(5)
+    t = np.zeros((300, 32), np.uint8)
+    t[::3, 0] = 1; t[1::3, 1] = 3
+    q = np.zeros((100, 32), np.uint8); q[50:, 5] = 0xFF
+    idx, dist = E.knn_match_hamming(q, t, gpu_ctx)
+    ridx, rdist = oracle_lib.knn2_hamming(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    for ratio in (0.5, 0.8, 1.0, 2.0):   # d0 == ratio*d1 must be rejected (strict <)
+        a = E.match_hamming(q, t, ratio, gpu_ctx); b = oracle_lib.match_hamming(q, t, ratio)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for nb in (16, 64):
+        q2 = rng.integers(0, 256, (77, nb), dtype=np.uint8); t2 = rng.integers(0, 256, (130, nb), dtype=np.uint8)
+        idx, dist = E.knn_match_hamming(q2, t2, gpu_ctx)
+        ridx, rdist = oracle_lib.knn2_hamming(q2, t2)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+
+
+def test_hamming_match_orb_like(gpu_ctx, oracle_lib):
+    o = synth.orb_like_sets(2, 2000, pool=4096, seed_base=300)
+    a = E.match_hamming(o[1], o[0], 0.8, gpu_ctx); b = oracle_lib.match_hamming(o[1], o[0], 0.8)
+    assert len(b[0]) > 0 and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_feature_matching_mirror_appends(gpu_ctx, oracle_lib):
+    """matchFeaturesSURF/ORB keep the reference's signature and append to `matches` (:90,:135)."""
+    s = synth.surf_like_sets(2, 400, pool=512, seed_base=40)
+    f1 = E.Frame(frame_id=1, descriptors=s[1]); f2 = E.Frame(frame_id=0, descriptors=s[0])
+    fm = E.FeatureMatching(gpu_ctx)
+    matches = [E.DMatch(-1, -1, 0.0)]
+    assert fm.matchFeaturesSURF(f1, f2, matches) is True
+    rq, rt, rd = oracle_lib.match_l2(s[1], s[0], 0.5)
+    assert matches[0].queryIdx == -1 and len(matches) == 1 + len(rq)
+    assert [m.queryIdx for m in matches[1:]] == rq.tolist() and [m.trainIdx for m in matches[1:]] == rt.tolist()
+    o = synth.orb_like_sets(2, 400, pool=512, seed_base=41)
+    f1.descriptors, f2.descriptors = o[1], o[0]
+    m2 = []
+    fm.matchFeaturesORB(f1, f2, m2)
+    rq, rt, rd = oracle_lib.match_hamming(o[1], o[0], 0.8)
+    assert [(m.queryIdx, m.trainIdx, m.distance) for m in m2] == list(zip(rq.tolist(), rt.tolist(), rd.tolist()))
+
+
+def test_batched_pairs_match_single_calls(gpu_ctx, oracle_lib):
+    """esfm_match_pairs_dev over a ragged set list == per-pair oracle results, in pair order."""
+    rng = np.random.default_rng(3)
+    sizes = [300, 0, 513, 128, 77]
+    sets = []
+    for i, n in enumerate(sizes):
+        x = rng.standard_normal((n, 64)).astype(np.float32)
+        x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+        sets.append(x)
+    sets[2][:100] = sets[0][:100] + 0.02 * rng.standard_normal((100, 64)).astype(np.float32)
+    pairs = synth.all_pairs(len(sizes))
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
+    pm = E.PairMatcher(bank, pairs)
+    res = pm.match(0.8).to_host()
+    for (i, j), (qi, ti, d) in zip(pairs, res):
+        rq, rt, rd = oracle_lib.match_l2(sets[i], sets[j], 0.8) if len(sets[i]) else (np.zeros(0, np.int32),) * 3
+        assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(_bits(d), _bits(rd))
+    n_q, n_rescan = pm.stats()
+    assert n_q == sum(sizes[i] for i, _ in pairs)
+    assert 0 <= n_rescan <= n_q
+
+
+def test_full_size_properties(gpu_ctx, oracle_lib):
+    """BASELINE size (4096 x 4096 x 64): size-independent checks -- a query that IS a train row
+    finds it at distance 0; a sample of rows agrees with the oracle bit for bit; permuting the train
+    set permutes the indices."""
+    s = synth.surf_like_sets(2, 4096, pool=16384, seed_base=1000)
+    q, t = s[1].copy(), s[0]
+    q[:64] = t[100:164]
+    idx, dist = E.knn_match_l2(q, t, gpu_ctx)
+    assert np.array_equal(idx[:64, 0], np.arange(100, 164)) and np.all(dist[:64, 0] == 0.0)
+    rows = np.random.default_rng(0).choice(4096, 256, replace=False)
+    ridx, rdist = oracle_lib.knn2_l2(q[rows], t)
+    assert np.array_equal(idx[rows], ridx) and np.array_equal(_bits(dist[rows]), _bits(rdist))
+    perm = np.random.default_rng(1).permutation(4096)
+    idx2, dist2 = E.knn_match_l2(q, t[perm], gpu_ctx)
+    assert np.array_equal(_bits(dist2), _bits(dist))
+    same = dist[:, 0] != dist[:, 1]
+    assert np.array_equal(perm[idx2[same, 0]], idx[same, 0])
