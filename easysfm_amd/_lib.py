@@ -90,6 +90,14 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C easysfm_amd/csrc`). "
             "easysfm_amd has no CPU fallback.")
+    # Load order matters: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.  If the
+    # system copy under /opt/rocm were mapped first (through this library's DT_NEEDED) and torch's
+    # afterwards, the process would hold two HIP runtimes and the second one finds no device.
+    # Importing torch first makes both resolve to the single copy torch ships.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing (device memory, streams, torch.distributed), not a requirement
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32p, f32p, f64p, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
     L.esfm_version.restype = C.c_char_p
@@ -139,8 +147,21 @@ class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         L = lib()
         self._h = C.c_void_p()
+        self.torch_stream = None
         check(L.esfm_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = int(device)
+
+    @classmethod
+    def on_torch_stream(cls, device: int = 0) -> "Context":
+        """Context bound to a dedicated torch.cuda.Stream (kept alive in .torch_stream), so torch ops
+        and collectives issued under ``with torch.cuda.stream(ctx.torch_stream)`` are ordered with the
+        library's kernels.  (torch's default stream has handle 0, which the C ABI reads as "create
+        your own stream", hence the dedicated one.)"""
+        import torch
+        ts = torch.cuda.Stream(device=device)
+        ctx = cls(device, ts.cuda_stream)
+        ctx.torch_stream = ts
+        return ctx
 
     @property
     def handle(self) -> C.c_void_p:

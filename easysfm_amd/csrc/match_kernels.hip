@@ -96,6 +96,11 @@ __device__ __forceinline__ float l2sqr_canonical(const float *__restrict__ a, co
     return d;
 }
 
+// Correctly rounded f32 square root.  NOT __fsqrt_rn: in this toolchain that maps to
+// __ocml_native_sqrt_f32 (about 1 ulp), while sqrtf is IEEE-exact under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt and matches the CPU's sqrtss bit for bit.
+__device__ __forceinline__ float sqrt_rn_f32(float x) { return sqrtf(x); }
+
 // (distance, index) ordered pair; "better" = the order a stable ascending scan with strict-<
 // insertion produces (OpenCV batchDistance): smaller distance, ties to the lower train index.
 struct Cand { float d; int i; float d2; };
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
                 const int r = cc[m] & 15;
                 const int t = (cc[m] >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
-                ei[m] = t; ed2[m] = d2; ed[m] = __fsqrt_rn(d2);
+                ei[m] = t; ed2[m] = d2; ed[m] = sqrt_rn_f32(d2);
             }
         }
     }
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void l2_exact_scan_kernel(const float *__restr
         Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
         for (int t = tid; t < pd.nt; t += 256) {
             const float d2 = l2sqr_canonical<VEC>(q, T + (size_t)t * dim, dim);
-            best2_insert(b0, b1, __fsqrt_rn(d2), t, d2);
+            best2_insert(b0, b1, sqrt_rn_f32(d2), t, d2);
         }
         s_d[0][tid] = b0.d; s_i[0][tid] = b0.i; s_d[1][tid] = b1.d; s_i[1][tid] = b1.i;
         __syncthreads();

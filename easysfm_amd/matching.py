@@ -110,8 +110,11 @@ class PairMatches:
     query_idx: "object"      # device int32 [sum nq]
     train_idx: "object"      # device int32
     distance: "object"       # device float32
+    ctx: "object" = None
 
     def to_host(self) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+        if self.ctx is not None:
+            self.ctx.synchronize()
         n = self.n_out.cpu().numpy()
         q = self.query_idx.cpu().numpy(); t = self.train_idx.cpu().numpy(); d = self.distance.cpu().numpy()
         out = []
@@ -159,8 +162,7 @@ class PairMatcher:
         self.torch = torch
         dev_index = bank.device.index or 0
         if ctx is None:
-            with torch.cuda.device(dev_index):
-                ctx = Context(dev_index, torch.cuda.current_stream().cuda_stream)
+            ctx = Context.on_torch_stream(dev_index)
         self.ctx = ctx
         total = int(bank.rows[self.pairs[:, 0]].sum()) if len(self.pairs) else 0
         self.total_queries = total
@@ -168,10 +170,11 @@ class PairMatcher:
         self.query_idx = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         self.train_idx = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         self.distance = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
-        self.n_out = torch.zeros(max(len(self.pairs), 1), dtype=torch.int32, device=dev)
+        self.n_out = torch.empty(max(len(self.pairs), 1), dtype=torch.int32, device=dev)
         self.offset = np.zeros(len(self.pairs) + 1, np.int64)
         self.knn_idx = None
         self.knn_dist = None
+        torch.cuda.synchronize(dev)   # the bank upload ran on torch's stream; kernels run on ctx's
 
     def match(self, ratio: float) -> PairMatches:
         """Enqueue the whole pair list; does not synchronise."""
@@ -181,7 +184,7 @@ class PairMatcher:
             _ptr(self.pairs), len(self.pairs), float(ratio),
             C.c_void_p(self.query_idx.data_ptr()), C.c_void_p(self.train_idx.data_ptr()),
             C.c_void_p(self.distance.data_ptr()), C.c_void_p(self.n_out.data_ptr()), _ptr(self.offset)))
-        return PairMatches(self.pairs, self.offset, self.n_out, self.query_idx, self.train_idx, self.distance)
+        return PairMatches(self.pairs, self.offset, self.n_out, self.query_idx, self.train_idx, self.distance, self.ctx)
 
     def knn2(self):
         """Raw 2-NN table of every pair: (idx[sum nq, 2], dist[sum nq, 2]) device tensors."""

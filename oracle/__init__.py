@@ -195,8 +195,8 @@ def ba_cost(cam_idx, pt_idx, uv, K4, cams, pts, cauchy_a=0.5) -> float:
 
 def ba_solve(cam_idx, pt_idx, uv, K4, cams, pts, options: Optional[BAOptions] = None):
     """ceres::Solve restatement.  Returns (cams, pts, summary); inputs are not modified."""
-    cams = np.array(cams, np.float64, copy=True).reshape(-1, 6)
-    pts = np.array(pts, np.float64, copy=True).reshape(-1, 3)
+    cams = np.array(cams, np.float64, copy=True, order="C").reshape(-1, 6)
+    pts = np.array(pts, np.float64, copy=True, order="C").reshape(-1, 3)
     summ = BASummary()
     opt = options if options is not None else ba_default_options()
     rc = load().esfm_ref_ba_solve(cams.shape[0], pts.shape[0], len(cam_idx),
