@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput of easysfm_amd on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the all-pairs SURF-64f matcher (2-NN + Lowe ratio, bit-exact with the
+oracle) over this rank's share of the image-pair list, descriptors already resident in HBM.
+N = 1 runs BASELINE.json configs[1] at its metric size: 25 images x 4096 features x 64 floats,
+300 pairs per step (workload "M-SURF-4k").  N > 1 keeps per-GPU work fixed:
+F images with F(F-1)/2 >= 300 N pairs, pair list partitioned over ranks, no data-path collective.
+The second half of the metric, bundle-adjustment LM iterations/s on 25 cameras x 30k points
+(240k observations, workload "BA-25"), is measured in the same process and reported under "ba".
+
+Rank 0 prints ONE JSON line.  `value` = image pairs matched per second over all ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 acc
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.29 TB/s measured copy)
+METRIC = "image-pairs matched/s (4096 SURF feats/img) + BA LM iters/s (25 cams, 30k pts)"
+N_FEATS, DIM = 4096, 64
+
+
+def frames_for(world: int) -> int:
+    f = 25
+    while f * (f - 1) // 2 < 300 * world:
+        f += 1
+    return f
+
+
+def cpu_baseline_match(sets, budget_s: float = 12.0):
+    """Oracle (exact brute-force 2-NN + ratio, OpenMP over query rows like OpenCV's BFMatcher) on the
+    host cores, on whole 4096 x 4096 pairs of the same workload until ~budget_s have elapsed."""
+    import oracle
+    path = oracle.build(arch="native", out="libesfm_oracle_native.so")
+    oracle.load(path)
+    cores = os.cpu_count() or 1
+    oracle.set_num_threads(cores)
+    n, t0 = 0, time.perf_counter()
+    pairs = [(i, j) for i in range(len(sets)) for j in range(i)]
+    while True:
+        i, j = pairs[n % len(pairs)]
+        oracle.match_l2(sets[i], sets[j], 0.5)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": n / el, "unit": "image-pairs/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{n} pairs of 4096x4096x64 (M-SURF-4k) in {el:.1f}s, OpenMP over query rows"}
+
+
+def cpu_baseline_ba(scene, iters: int = 3):
+    import oracle
+    threads = min(4, os.cpu_count() or 1)   # ceres_options_->num_threads = 4 (reference ba.cpp:203)
+    oracle.set_num_threads(threads)
+    opt = oracle.ba_default_options()
+    opt.max_num_iterations = iters; opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
+    _, _, s = oracle.ba_solve(scene.cam_idx, scene.pt_idx, scene.uv, scene.K4, scene.cams0, scene.pts0, opt)
+    oracle.set_num_threads(os.cpu_count() or 1)
+    return {"value": s.num_iterations / s.solve_seconds, "unit": "LM iters/s", "cores": threads, "kind": "port",
+            "sample": f"{s.num_iterations} LM iterations of BA-25 (25 cams, 30k pts, 240k obs) in {s.solve_seconds:.1f}s"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ba-iters", type=int, default=50, help="LM iterations timed for the BA half of the metric")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        print("[bench] no GPU visible: easysfm_amd has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import easysfm_amd as E
+    from easysfm_amd import _lib, synth
+
+    # ---------------------------------------------------------------- matching workload
+    n_frames = frames_for(world)
+    sets = synth.surf_like_sets(n_frames, N_FEATS, pool=16384, seed_base=1000)
+    rows = np.full(n_frames, N_FEATS, np.int32)
+    pairs = E.shard_pair_list(n_frames, rows, rank, world)
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32, device=f"cuda:{local_rank}")
+    pm = E.PairMatcher(bank, pairs)
+    ctx = pm.ctx
+    ratio = 0.5  # matchFeaturesSURF default (feature_matching.h:21)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pm.match(ratio)
+    barrier()
+    ctx.set_kernel_timing(True)
+    ctx.kernel_time(_lib.K_L2_KNN); ctx.kernel_time(_lib.K_L2_RESCAN)   # drain
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pm.match(ratio)
+    ctx.synchronize()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = ctx.kernel_time(_lib.K_L2_KNN)
+    r_ms, r_n = ctx.kernel_time(_lib.K_L2_RESCAN)
+    ctx.set_kernel_timing(False)
+    n_q, n_rescan = pm.stats()
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    npairs = torch.tensor([float(len(pairs))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(npairs, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    total_pairs = float(npairs.item())
+    value = total_pairs * args.steps / elapsed
+
+    # correctness spot check (outside the timed region): one pair against the oracle, bit for bit
+    verified = None
+    if rank == 0:
+        try:
+            import oracle
+            res = pm.match(ratio).to_host()
+            i, j = pairs[0]
+            rq, rt, rd = oracle.match_l2(sets[i][:512], sets[j], ratio)
+            q, t, d = res[0]
+            m = q < 512
+            verified = bool(np.array_equal(q[m], rq) and np.array_equal(t[m], rt) and
+                            np.array_equal(d[m].view(np.uint32), rd.view(np.uint32)))
+        except Exception as e:  # the checker must never take the measurement down
+            verified = f"check failed to run: {e!r}"
+
+    flops_per_launch = 2.0 * float(len(pairs)) * N_FEATS * N_FEATS * DIM
+    avg_kernel_s = (k_ms / max(k_n, 1)) * 1e-3
+    achieved = flops_per_launch / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("l2_knn_mfma_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": "l2_knn_mfma_kernel<64>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "avg_launch_ms": avg_kernel_s * 1e3, "launches": k_n,
+                "algorithmic_flops_per_launch": flops_per_launch,
+                "rescan_kernel_avg_ms": (r_ms / max(r_n, 1)), "rescanned_queries_per_step": n_rescan, "queries_per_step": n_q}
+
+    out = {
+        "metric": METRIC, "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "M-SURF-4k all-pairs SURF-64f match (2-NN + ratio 0.5), "
+                               f"{n_frames} imgs x {N_FEATS} feats x {DIM} f32, {int(total_pairs)} pairs/step, "
+                               "pair list partitioned over ranks, no collective",
+                   "pairs_per_step": int(total_pairs), "features_per_image": N_FEATS, "descriptor_dim": DIM, "ratio": ratio},
+        "roofline": roofline, "verified_vs_oracle": verified,
+    }
+
+    # ---------------------------------------------------------------- BA half of the metric
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
+
+    if not args.no_ba:
+        watchdog = threading.Timer(240.0, lambda: (out.setdefault("ba", {"error": "BA leg timed out"}), emit(), os._exit(0)))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            scene = synth.ba_scene(25, 30000, 8, radius=10.0, extent=2.0, seed=4000)
+            if world > 1:
+                shard = E.shard_points(scene.n_pt, scene.pt_idx, world)
+                keep = shard[scene.pt_idx] == rank
+                ci, pi, uv = scene.cam_idx[keep], scene.pt_idx[keep], scene.uv[keep]
+                cb = E.torch_allreduce_callback()
+            else:
+                ci, pi, uv, cb = scene.cam_idx, scene.pt_idx, scene.uv, None
+            bctx = E.Context.on_torch_stream(local_rank)
+            with torch.cuda.stream(bctx.torch_stream):
+                prob = E.BAProblem(ci, pi, uv, scene.K4, scene.cams0, scene.pts0, bctx)
+                opt = E.default_options()
+                opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
+                opt.max_num_iterations = 3
+                prob.solve(opt, cb)                     # warm-up (allocations, code objects, RCCL channels)
+                prob.set_params(scene.cams0, scene.pts0)
+                opt.max_num_iterations = args.ba_iters
+                barrier()
+                bctx.set_kernel_timing(True)
+                bctx.kernel_time(_lib.K_BA_LINEARIZE); bctx.kernel_time(_lib.K_BA_SCHUR); bctx.kernel_time(_lib.K_BA_SOLVE)
+                tb = time.perf_counter()
+                summ = prob.solve(opt, cb)
+                bctx.synchronize()
+                if world > 1:
+                    dist.barrier()
+                ba_el = time.perf_counter() - tb
+                l_ms, l_n = bctx.kernel_time(_lib.K_BA_LINEARIZE)
+                s_ms, s_n = bctx.kernel_time(_lib.K_BA_SCHUR)
+                c_ms, c_n = bctx.kernel_time(_lib.K_BA_SOLVE)
+                bctx.set_kernel_timing(False)
+            tt2 = torch.tensor([ba_el], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+            ba_el = float(tt2.item())
+            n_obs_local = len(ci)
+            sweep_bytes = 176.0 * n_obs_local + 48.0 * scene.n_cam + 24.0 * scene.n_pt   # SURVEY 8d compulsory bytes
+            lin_s = (l_ms / max(l_n, 1)) * 1e-3
+            out["ba"] = {
+                "metric": "BA LM iters/s", "value": summ.num_iterations / ba_el, "unit": "LM iters/s",
+                "lm_iterations": summ.num_iterations, "seconds": ba_el, "n_gpus": world,
+                "scaling": "strong" if world > 1 else "n/a",
+                "config": {"workload": "BA-25: 25 cams x 30000 pts x 240000 obs (8 obs/pt), Cauchy(0.5), DENSE_SCHUR-style LM",
+                           "obs_sharded_by_point": world > 1, "allreduce": "RCCL sum of reduced camera system" if world > 1 else None},
+                "initial_cost": summ.initial_cost, "final_cost": summ.final_cost,
+                "successful_steps": summ.num_successful_steps, "unsuccessful_steps": summ.num_unsuccessful_steps,
+                "roofline": {"bound": "hbm", "kernel": "ba_linearize_kernel", "achieved": sweep_bytes / lin_s / 1e9 if lin_s > 0 else 0.0,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0, "traffic": None,
+                             "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes},
+                "schur_kernel_avg_ms": s_ms / max(s_n, 1), "solve_kernel_avg_ms": c_ms / max(c_n, 1),
+            }
+            prob.close()
+        except Exception as e:
+            out["ba"] = {"error": repr(e)}
+        watchdog.cancel()
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_match(sets)
+            if "ba" in out and "error" not in out["ba"]:
+                out["ba"]["cpu_baseline"] = cpu_baseline_ba(synth.ba_scene(25, 30000, 8, radius=10.0, extent=2.0, seed=4000))
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    emit()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

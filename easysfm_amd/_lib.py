@@ -18,6 +18,7 @@ ESFM_L2_F32 = 0
 ESFM_HAMMING = 1
 ESFM_REDUCE_SUM = 0
 ESFM_REDUCE_MAX = 1
+K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN = range(6)
 BA_MAX_LOG = 256
 
 STATUS_NAMES = {
@@ -28,7 +29,7 @@ STATUS_NAMES = {
 # every symbol include/esfm.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "esfm_version", "esfm_last_error", "esfm_device_count", "esfm_ctx_create", "esfm_ctx_destroy",
-    "esfm_ctx_synchronize", "esfm_ctx_stream",
+    "esfm_ctx_synchronize", "esfm_ctx_stream", "esfm_ctx_set_kernel_timing", "esfm_ctx_kernel_time",
     "esfm_knn2_l2_f32", "esfm_knn2_hamming", "esfm_match_l2_f32", "esfm_match_hamming",
     "esfm_match_pairs_dev", "esfm_knn2_pairs_dev", "esfm_match_last_stats", "esfm_shard_pair_list",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
@@ -108,6 +109,8 @@ def lib() -> C.CDLL:
     L.esfm_ctx_synchronize.argtypes = [vp]
     L.esfm_ctx_stream.argtypes = [vp]
     L.esfm_ctx_stream.restype = vp
+    L.esfm_ctx_set_kernel_timing.argtypes = [vp, C.c_int]
+    L.esfm_ctx_kernel_time.argtypes = [vp, C.c_int, f64p, i64p]
     L.esfm_knn2_l2_f32.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     L.esfm_knn2_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     L.esfm_match_l2_f32.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, i32p]
@@ -175,6 +178,15 @@ class Context:
 
     def synchronize(self) -> None:
         check(lib().esfm_ctx_synchronize(self.handle))
+
+    def set_kernel_timing(self, enable: bool) -> None:
+        check(lib().esfm_ctx_set_kernel_timing(self.handle, 1 if enable else 0))
+
+    def kernel_time(self, kernel_id: int):
+        """(total_ms, launches) of the hipEvent-bracketed launches of `kernel_id` since the last call."""
+        ms = C.c_double(0.0); n = C.c_int64(0)
+        check(lib().esfm_ctx_kernel_time(self.handle, int(kernel_id), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def close(self) -> None:
         if self._h:

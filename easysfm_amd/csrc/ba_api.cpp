@@ -87,7 +87,10 @@ struct Solver {
     int linearize(bool use_scaling, double radius)
     {
         const BADev &d = P->d;
-        if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling)) return rc;
+        {
+            esfm::KernelTimer tm(P->ctx, ESFM_K_BA_LINEARIZE);
+            if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling)) return rc;
+        }
         if (int rc = allreduce(d.camacc, (int64_t)esfm::ba_camacc_doubles(d.n_cam), ESFM_REDUCE_SUM)) return rc;
         if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, true)) return rc;
         return ESFM_OK;
@@ -318,9 +321,15 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             prep_radius = radius;
         }
         ESFM_HIP_TRY(hipMemsetAsync(d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
-        if (int rc = esfm::ba_schur(st, d)) return finish(rc);
+        {
+            esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SCHUR);
+            if (int rc = esfm::ba_schur(st, d)) return finish(rc);
+        }
         if (int rc = S.allreduce(d.red, (int64_t)esfm::ba_red_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
-        if (int rc = esfm::ba_solve_reduced(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal)) return finish(rc);
+        {
+            esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SOLVE);
+            if (int rc = esfm::ba_solve_reduced(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal)) return finish(rc);
+        }
         if (int rc = esfm::ba_camera_step(st, d)) return finish(rc);
         if (int rc = esfm::ba_backsub(st, d)) return finish(rc);
         if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD)) return finish(rc);

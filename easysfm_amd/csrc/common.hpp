@@ -62,9 +62,23 @@ struct esfm_ctx {
     int64_t last_n_queries = 0;
     size_t last_pair_bytes = 0;
     int pin(size_t bytes);
+    // optional per-kernel hipEvent timing (esfm_ctx_set_kernel_timing)
+    bool timing = false;
+    struct TimedLaunch { int id; hipEvent_t a, b; };
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t take_event();
+    void time_begin(int id);
+    void time_end();
 };
 
 namespace esfm {
+// RAII bracket: records events around a launch when timing is enabled, otherwise does nothing.
+struct KernelTimer {
+    esfm_ctx *c;
+    KernelTimer(esfm_ctx *ctx, int id) : c(ctx && ctx->timing ? ctx : nullptr) { if (c) c->time_begin(id); }
+    ~KernelTimer() { if (c) c->time_end(); }
+};
 inline int set_device(const esfm_ctx *ctx)
 {
     hipError_t e = hipSetDevice(ctx->device);

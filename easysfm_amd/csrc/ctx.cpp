@@ -52,7 +52,50 @@ int esfm_ctx::pin(size_t bytes)
     return ESFM_OK;
 }
 
+hipEvent_t esfm_ctx::take_event()
+{
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void esfm_ctx::time_begin(int id)
+{
+    TimedLaunch t{id, take_event(), take_event()};
+    (void)hipEventRecord(t.a, stream);
+    timed.push_back(t);
+}
+
+void esfm_ctx::time_end()
+{
+    if (!timed.empty()) (void)hipEventRecord(timed.back().b, stream);
+}
+
 extern "C" {
+
+int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    ctx->timing = enable != 0;
+    return ESFM_OK;
+}
+
+int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches)
+{
+    if (!ctx || !total_ms || !launches || kernel_id < 0 || kernel_id >= ESFM_K_COUNT) { esfm::set_error("bad argument"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+    ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<esfm_ctx::TimedLaunch> keep;
+    for (auto &t : ctx->timed) {
+        if (t.id != kernel_id) { keep.push_back(t); continue; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { *total_ms += (double)ms; *launches += 1; }
+        ctx->event_pool.push_back(t.a); ctx->event_pool.push_back(t.b);
+    }
+    ctx->timed.swap(keep);
+    return ESFM_OK;
+}
 
 const char *esfm_version(void)
 {
@@ -116,6 +159,8 @@ int esfm_ctx_destroy(esfm_ctx *ctx)
                             &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->stage_e, &ctx->setmax};
     for (auto *b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ESFM_OK;

@@ -89,11 +89,15 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
             if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
-            if (int rc = esfm::launch_l2_knn_mfma(st, width, desc, ctx->norms.as<float>(), dev_tab, n_pairs, plan.n_blocks, knn_idx,
-                                                  knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))
-                return rc;
+            {
+                esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
+                if (int rc = esfm::launch_l2_knn_mfma(st, width, desc, ctx->norms.as<float>(), dev_tab, n_pairs, plan.n_blocks, knn_idx,
+                                                      knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))
+                    return rc;
+            }
             // certificate failures: exact scan, grid-stride over the device-side count (no host sync)
             const int grid = (int)std::min<int64_t>(plan.total_queries, 8 * (int64_t)ctx->num_cu);
+            esfm::KernelTimer tm(ctx, ESFM_K_L2_RESCAN);
             if (int rc = esfm::launch_l2_exact_scan(st, width, desc, dev_tab, n_pairs, ctx->flagged.as<int32_t>(),
                                                     ctx->counters.as<int32_t>(), plan.total_queries, grid, knn_idx, knn_dist))
                 return rc;
@@ -111,6 +115,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             esfm::set_error("hamming descriptors must be 16, 32 or 64 bytes (got %d)", width);
             return ESFM_ERR_UNSUPPORTED;
         }
+        esfm::KernelTimer tm(ctx, ESFM_K_HAMMING_KNN);
         return esfm::launch_hamming_knn(st, width, desc_dev, dev_tab, n_pairs, plan.n_blocks, knn_idx, knn_dist);
     }
     esfm::set_error("unknown metric %d", (int)metric);

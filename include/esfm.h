@@ -69,6 +69,23 @@ int esfm_ctx_synchronize(esfm_ctx *ctx);
 /* The hipStream_t the context enqueues on (for HIP-event timing by the caller). */
 void *esfm_ctx_stream(esfm_ctx *ctx);
 
+/* Per-kernel device timing (measurement only; off by default).  When enabled,
+ * the library brackets each launch of the kernels below with hipEvents on the
+ * context's stream.  esfm_ctx_kernel_time() synchronises the stream, adds the
+ * elapsed times of all launches since the last call for that kernel to
+ * *total_ms / *launches (caller zero-initialises) and recycles the events. */
+typedef enum esfm_kernel_id {
+    ESFM_K_L2_KNN = 0,        /* l2_knn_mfma_kernel: MFMA distance pass + fused top-k + re-rank */
+    ESFM_K_HAMMING_KNN = 1,   /* hamming_knn_kernel                                             */
+    ESFM_K_BA_LINEARIZE = 2,  /* ba_linearize_kernel: the Jacobian sweep                        */
+    ESFM_K_BA_SCHUR = 3,      /* ba_schur_kernel                                                */
+    ESFM_K_BA_SOLVE = 4,      /* ba_chol_solve_kernel                                           */
+    ESFM_K_L2_RESCAN = 5,     /* l2_exact_scan_kernel                                           */
+    ESFM_K_COUNT = 6
+} esfm_kernel_id;
+int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
+int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+
 /* ---- pairwise matching ---------- */
 
 /*

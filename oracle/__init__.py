@@ -106,6 +106,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_ratio_filter.restype = C.c_int
     lib.esfm_ref_ratio_filter.argtypes = [_i32p, _f32p, C.c_int, C.c_double, _i32p, _i32p, _f32p]
     lib.esfm_ref_num_threads.restype = C.c_int
+    lib.esfm_ref_set_num_threads.restype = None
+    lib.esfm_ref_set_num_threads.argtypes = [C.c_int]
     lib.esfm_ref_ba_residual_jac.restype = None
     lib.esfm_ref_ba_residual_jac.argtypes = [_f64p, _f64p, _f32p, _f32p, _f64p, _f64p, _f64p]
     lib.esfm_ref_ba_cost.restype = C.c_double
@@ -123,6 +125,14 @@ def load(path: Optional[str] = None) -> C.CDLL:
                                                C.c_double, _f64p, _f64p]
     _LIB, _LIB_PATH = lib, path
     return lib
+
+
+def set_num_threads(n: int) -> None:
+    load().esfm_ref_set_num_threads(int(n))
+
+
+def num_threads() -> int:
+    return int(load().esfm_ref_num_threads())
 
 
 # ----------------------------------------------------------------------------- matching

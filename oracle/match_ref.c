@@ -177,6 +177,15 @@ int esfm_ref_match_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt, i
     return esfm_ref_ratio_filter(scratch_idx, scratch_dist, nq, ratio, query_idx, train_idx, distance);
 }
 
+void esfm_ref_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int esfm_ref_num_threads(void)
 {
 #ifdef _OPENMP
