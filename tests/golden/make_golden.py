@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ (run once in the build container; outputs are
+committed).  The reference ships no tests or fixtures and cannot be built/imported here (SURVEY.md
+section 8c), so these vectors come from a SECOND, independent restatement of the reference
+semantics written in numpy / torch -- different code, different linear algebra -- against which the
+C oracle (oracle/*.c) is pinned by tests/test_oracle_golden.py:
+
+  match_hamming_cases.npz   hand-built ORB-like sets (forced ties for 1st/2nd place, all-equal rows,
+                            nt in {0,1,2,3}, ratio boundary d0 == ratio*d1, sizes not multiples of 64);
+                            expected 2-NN by stable integer argsort, ratio filter in float64
+  match_l2_cases.npz        unit-norm 64-D sets with planted near-duplicates and exact duplicates;
+                            expected 2-NN from a numpy float32 evaluation of the canonical summation
+                            order (vectorised over pairs, same operation order), stable argsort
+  ba_jacobian_cases.npz     residual + Jacobians of the reprojection functor (ba.h:113-153) by torch
+                            autograd in float64, including the small-angle branch
+  ba_lm_trace.npz           4 cameras / 50 points (Cauchy) and 5 cameras / 120 points (squared loss, far start, with
+                            rejected steps): cost / radius / step norm /
+                            accept flag per iteration from a dense (no Schur) numpy LM that solves
+                            (J'J + D^2) y = J'r with numpy.linalg, plus the zero-noise known answer
+
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from easysfm_amd import synth  # noqa: E402  (seeded generators only; no GPU)
+
+
+# ------------------------------------------------------------------------------------------------ matching
+def knn2_from_matrix(D: np.ndarray):
+    """Two smallest per row by (value, column) -- what an ascending scan with strict-< insertion yields."""
+    nq, nt = D.shape
+    idx = np.full((nq, 2), -1, np.int32)
+    dist = np.full((nq, 2), np.finfo(np.float32).max, np.float32)
+    if nt:
+        order = np.argsort(D, axis=1, kind="stable")[:, :2]
+        k = order.shape[1]
+        idx[:, :k] = order
+        dist[:, :k] = np.take_along_axis(D, order, 1).astype(np.float32)
+    return idx, dist
+
+
+def ratio_filter(idx, dist, ratio):
+    keep = (idx[:, 0] >= 0) & (idx[:, 1] >= 0) & (dist[:, 0].astype(np.float64) < ratio * dist[:, 1].astype(np.float64))
+    q = np.nonzero(keep)[0].astype(np.int32)
+    return q, idx[keep, 0], dist[keep, 0]
+
+
+def hamming_matrix(q, t):
+    if len(t) == 0:
+        return np.zeros((len(q), 0), np.int64)
+    return np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(-1).astype(np.int64)
+
+
+def l2_matrix_canonical(q, t):
+    """float32 distances, canonical order: 8 partial sums over blocks of 8 (mul and add separate),
+    (acc[c]+acc[c+4]) summed left to right, scalar tail, then sqrt -- vectorised over all pairs."""
+    q = q.astype(np.float32); t = t.astype(np.float32)
+    nq, dim = q.shape
+    nt = t.shape[0]
+    if nt == 0:
+        return np.zeros((nq, 0), np.float32)
+    acc = np.zeros((nq, nt, 8), np.float32)
+    nb = dim // 8
+    for b in range(nb):
+        d = q[:, None, 8 * b:8 * b + 8] - t[None, :, 8 * b:8 * b + 8]
+        acc = acc + d * d
+    s = [acc[..., c] + acc[..., c + 4] for c in range(4)]
+    d2 = ((s[0] + s[1]) + s[2]) + s[3]
+    for j in range(8 * nb, dim):
+        d = q[:, None, j] - t[None, :, j]
+        d2 = d2 + d * d
+    return np.sqrt(d2).astype(np.float32)
+
+
+def make_hamming():
+    rng = np.random.default_rng(12345)
+    cases = {}
+    # 0: forced ties
+    t = np.zeros((70, 32), np.uint8); t[::3, 0] = 1; t[1::3, 1] = 3
+    q = np.zeros((37, 32), np.uint8); q[20:, 5] = 0xFF
+    cases["ties"] = (q, t)
+    # 1: all rows equal
+    cases["all_equal"] = (np.full((9, 32), 0xA5, np.uint8), np.full((13, 32), 0xA5, np.uint8))
+    # 2..5: tiny train sets
+    for nt in (0, 1, 2, 3):
+        cases[f"nt{nt}"] = (rng.integers(0, 256, (5, 32), dtype=np.uint8), rng.integers(0, 256, (nt, 32), dtype=np.uint8))
+    # 6: ratio boundary: d0 = 4, d1 = 5 (0.8 * 5 == 4 exactly -> must be rejected), d0 = 3, d1 = 5 accepted
+    t = np.zeros((2, 32), np.uint8); t[0, 0] = 0x0F; t[1, 0] = 0x1F
+    q = np.zeros((2, 32), np.uint8); q[1, 0] = 0x01
+    cases["boundary"] = (q, t)
+    # 7: random, sizes not multiples of 64
+    o = synth.orb_like_sets(2, 131, pool=97, seed_base=7000)
+    cases["random"] = (o[1], o[0][:101])
+    out = {}
+    for name, (q, t) in cases.items():
+        idx, dist = knn2_from_matrix(hamming_matrix(q, t))
+        out[f"{name}.q"] = q; out[f"{name}.t"] = t; out[f"{name}.idx"] = idx; out[f"{name}.dist"] = dist
+        for r in (0.5, 0.8, 1.0):
+            a, b, c = ratio_filter(idx, dist, r)
+            out[f"{name}.m{r}.q"] = a; out[f"{name}.m{r}.t"] = b; out[f"{name}.m{r}.d"] = c
+    np.savez_compressed(os.path.join(HERE, "match_hamming_cases.npz"), **out)
+
+
+def make_l2():
+    rng = np.random.default_rng(54321)
+    cases = {}
+    s = synth.surf_like_sets(2, 90, pool=64, seed_base=8000)
+    cases["surf_like"] = (s[1], s[0][:77])
+    base = s[0][:20]
+    t = np.concatenate([base, base[:10], base[:5] * np.float32(1.0 + 1e-7), rng.standard_normal((30, 64)).astype(np.float32) * 0.2])
+    t = t[rng.permutation(len(t))].astype(np.float32)
+    q = np.concatenate([base[:12], base[:12] + 1e-4 * rng.standard_normal((12, 64)).astype(np.float32)]).astype(np.float32)
+    cases["duplicates"] = (q, t)
+    for nt in (0, 1, 2):
+        cases[f"nt{nt}"] = (s[1][:4], s[0][:nt])
+    cases["dim37"] = (rng.standard_normal((11, 37)).astype(np.float32), rng.standard_normal((23, 37)).astype(np.float32))
+    out = {}
+    near = []
+    for name, (q, t) in cases.items():
+        D = l2_matrix_canonical(q, t)
+        idx, dist = knn2_from_matrix(D)
+        out[f"{name}.q"] = q; out[f"{name}.t"] = t; out[f"{name}.idx"] = idx; out[f"{name}.dist"] = dist
+        for r in (0.5, 0.8):
+            a, b, c = ratio_filter(idx, dist, r)
+            out[f"{name}.m{r}.q"] = a; out[f"{name}.m{r}.t"] = b; out[f"{name}.m{r}.d"] = c
+        if D.shape[1] >= 2:
+            u = dist.view(np.uint32).astype(np.int64)
+            near.append(int(np.sum(np.abs(u[:, 0] - u[:, 1]) < 4)))
+    out["near_tie_audit"] = np.array(near)   # queries whose two best distances are < 4 ulp apart, per case
+    np.savez_compressed(os.path.join(HERE, "match_l2_cases.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------ BA
+def torch_residual(cam, pt, K4, uv):
+    """ReprojectErrorTerm_fixcalib (ba.h:113-153) in torch float64, both AngleAxisRotatePoint branches."""
+    import torch
+    aa, tr = cam[:3], cam[3:]
+    theta2 = (aa * aa).sum()
+    if theta2.item() > np.finfo(np.float64).eps:
+        theta = torch.sqrt(theta2)
+        w = aa / theta
+        p = pt * torch.cos(theta) + torch.linalg.cross(w, pt) * torch.sin(theta) + w * (w @ pt) * (1.0 - torch.cos(theta))
+    else:
+        p = pt + torch.linalg.cross(aa, pt)
+    p = p + tr
+    u = p[0] / p[2] * float(K4[0]) + float(K4[1])
+    v = p[1] / p[2] * float(K4[2]) + float(K4[3])
+    return torch.stack([float(uv[0]) - u, float(uv[1]) - v])
+
+
+def make_ba_jacobians():
+    import torch
+    rng = np.random.default_rng(777)
+    K4 = np.array(synth.FOUNTAIN_K4, np.float32)
+    cams, pts, uvs, rs, Jcs, Jps = [], [], [], [], [], []
+    for i in range(24):
+        cam = np.concatenate([rng.standard_normal(3) * (0.8 if i % 3 else 1e-3), rng.standard_normal(3)])
+        if i in (0, 1):
+            cam[:3] = 0.0 if i == 0 else np.array([1e-9, -2e-9, 5e-10])   # small-angle branch
+        pt = rng.uniform(-2, 2, 3) + np.array([0, 0, 8.0])
+        uv = rng.uniform(0, 700, 2).astype(np.float32)
+        c = torch.tensor(cam, dtype=torch.float64, requires_grad=True)
+        p = torch.tensor(pt, dtype=torch.float64, requires_grad=True)
+        r = torch_residual(c, p, K4, uv)
+        Jc = np.zeros((2, 6)); Jp = np.zeros((2, 3))
+        for k in range(2):
+            g = torch.autograd.grad(r[k], [c, p], retain_graph=True)
+            Jc[k] = g[0].numpy(); Jp[k] = g[1].numpy()
+        cams.append(cam); pts.append(pt); uvs.append(uv); rs.append(r.detach().numpy()); Jcs.append(Jc); Jps.append(Jp)
+    np.savez_compressed(os.path.join(HERE, "ba_jacobian_cases.npz"), cams=np.array(cams), pts=np.array(pts), uvs=np.array(uvs),
+                        K4=K4, r=np.array(rs), Jc=np.array(Jcs), Jp=np.array(Jps))
+
+
+def dense_lm(sc, max_iter, cauchy_a=0.5):
+    """Dense restatement of Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy (no Schur
+    complement: the damped normal equations are solved whole).  Rules: oracle/ba_ref.c header."""
+    import torch
+    n_cam, n_pt, n_obs = sc.n_cam, sc.n_pt, sc.n_obs
+    npar = 6 * n_cam + 3 * n_pt
+
+    def evaluate(x, jac):
+        cams = x[:6 * n_cam].reshape(n_cam, 6); pts = x[6 * n_cam:].reshape(n_pt, 3)
+        r = np.zeros(2 * n_obs); J = np.zeros((2 * n_obs, npar)) if jac else None
+        cost = 0.0
+        for k in range(n_obs):
+            c, p = int(sc.cam_idx[k]), int(sc.pt_idx[k])
+            ct = torch.tensor(cams[c], dtype=torch.float64, requires_grad=jac)
+            pt = torch.tensor(pts[p], dtype=torch.float64, requires_grad=jac)
+            res = torch_residual(ct, pt, sc.K4[c], sc.uv[k])
+            rv = res.detach().numpy()
+            s = float(rv @ rv)
+            if cauchy_a > 0:
+                b = cauchy_a ** 2
+                rho0 = b * np.log1p(s / b); rho1 = max(1.0 / (1.0 + s / b), np.finfo(np.float64).tiny)
+            else:
+                rho0, rho1 = s, 1.0
+            cost += 0.5 * rho0
+            sq = np.sqrt(rho1)
+            r[2 * k:2 * k + 2] = rv * sq
+            if jac:
+                for i in range(2):
+                    g = torch.autograd.grad(res[i], [ct, pt], retain_graph=True)
+                    J[2 * k + i, 6 * c:6 * c + 6] = g[0].numpy() * sq
+                    J[2 * k + i, 6 * n_cam + 3 * p:6 * n_cam + 3 * p + 3] = g[1].numpy() * sq
+        return cost, r, J
+
+    x = np.concatenate([sc.cams0.ravel(), sc.pts0.ravel()])
+    cost, r, J = evaluate(x, True)
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
+    J = J * scale
+    radius, nu = 1e4, 2.0
+    x_norm = np.linalg.norm(x)
+    log = [dict(cost=cost, radius=radius, step_norm=0.0, ok=1, gmax=np.abs((J / scale).T @ r).max())]
+    diag = None
+    reuse = False
+    for it in range(1, max_iter + 1):
+        if not reuse:
+            diag = np.clip((J * J).sum(0), 1e-6, 1e32)
+        A = J.T @ J + np.diag(diag / radius)
+        y = np.linalg.solve(A, J.T @ r)
+        step = -y
+        reuse = True
+        m = J @ step
+        mcc = -m @ (r + m / 2.0)
+        cand = x + step * scale
+        ccost, _, _ = evaluate(cand, False)
+        step_norm = np.linalg.norm(x - cand)
+        if step_norm <= 1e-8 * (x_norm + 1e-8) or abs(cost - ccost) <= 1e-6 * cost:
+            log.append(dict(cost=cost, radius=radius, step_norm=step_norm, ok=0, gmax=log[-1]["gmax"], stop=1)); break
+        rho = (cost - ccost) / mcc
+        if rho > 1e-3:
+            x = cand; x_norm = np.linalg.norm(x)
+            cost, r, J = evaluate(x, True)
+            g = np.abs(J.T @ r).max()
+            J = J * scale
+            radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)); nu = 2.0; reuse = False
+            log.append(dict(cost=cost, radius=radius, step_norm=step_norm, ok=1, gmax=g))
+        else:
+            radius /= nu; nu *= 2.0
+            log.append(dict(cost=ccost, radius=radius, step_norm=step_norm, ok=0, gmax=log[-1]["gmax"]))
+    return x, log
+
+
+def make_ba_trace():
+    out = {}
+    for tag, a, shape, iters, kw in (("cauchy", 0.5, (4, 50, 3), 10, dict(seed=31)),
+                                     ("squared_rejects", -1.0, (5, 120, 4), 12,
+                                      dict(seed=12, start_noise=(0.5, 2.0, 2.0), outlier_frac=0.0))):
+        sc = synth.ba_scene(*shape, **kw)
+        x, log = dense_lm(sc, iters, a)
+        for f in ("cam_idx", "pt_idx", "uv", "K4", "cams0", "pts0"):
+            out[f"{tag}.{f}"] = getattr(sc, f)
+        out[f"{tag}.cauchy_a"] = np.float64(a)
+        out[f"{tag}.cost"] = np.array([e["cost"] for e in log])
+        out[f"{tag}.radius"] = np.array([e["radius"] for e in log])
+        out[f"{tag}.step_norm"] = np.array([e["step_norm"] for e in log])
+        out[f"{tag}.ok"] = np.array([e["ok"] for e in log])
+        out[f"{tag}.gmax"] = np.array([e["gmax"] for e in log])
+        out[f"{tag}.x_final"] = x
+        print(tag, "pattern", "".join(str(e["ok"]) for e in log), "cost", log[0]["cost"], "->", log[-1]["cost"])
+    # known answer: exact observations at ground truth
+    sc = synth.ba_scene(4, 30, 3, seed=32, uv_noise=0.0, outlier_frac=0.0, start_noise=(0, 0, 0))
+    for f in ("cam_idx", "pt_idx", "uv", "K4", "cams_gt", "pts_gt"):
+        out[f"zero.{f}"] = getattr(sc, f)
+    np.savez_compressed(os.path.join(HERE, "ba_lm_trace.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_hamming()
+    make_l2()
+    make_ba_jacobians()
+    make_ba_trace()
+    print("golden vectors written to", HERE)

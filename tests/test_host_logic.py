@@ -1,0 +1,98 @@
+"""Host-side logic above the C ABI that needs no GPU: pair-list / point sharding and the reference's
+observation derivation (setBAProblem, ba.cpp:22-56).  CPU only."""
+import numpy as np
+import pytest
+
+import easysfm_amd as E
+from easysfm_amd import synth
+
+
+def test_pair_list_is_the_reference_loop():
+    p = E.shard_pair_list(6, None, 0, 1)
+    assert p.tolist() == [[i, j] for i in range(6) for j in range(i)]     # sfm.cpp:140-143: query i, train j < i
+    assert np.array_equal(p, synth.all_pairs(6))
+    assert len(E.shard_pair_list(1, None, 0, 1)) == 0 and len(E.shard_pair_list(0, None, 0, 1)) == 0
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_pair_shards_partition_and_balance(world):
+    rows = np.random.default_rng(world).integers(500, 5000, 40).astype(np.int32)
+    shards = [E.shard_pair_list(40, rows, r, world) for r in range(world)]
+    allp = np.concatenate(shards)
+    assert len(allp) == 40 * 39 // 2
+    assert len({tuple(x) for x in allp.tolist()}) == len(allp)            # disjoint, complete
+    cost = [float((rows[s[:, 0]].astype(np.float64) * rows[s[:, 1]]).sum()) for s in shards]
+    assert max(cost) - min(cost) <= float(rows.max()) ** 2                 # within one pair's cost
+    for s in shards:                                                       # reference order kept inside a shard
+        key = s[:, 0].astype(np.int64) * 1000 + s[:, 1]
+        assert np.all(np.diff(key) > 0)
+
+
+def test_point_shards_balance_observations():
+    sc = synth.ba_scene(10, 1000, 6, seed=1)
+    for world in (2, 4, 8):
+        sh = E.shard_points(sc.n_pt, sc.pt_idx, world)
+        assert sh.min() == 0 and sh.max() == world - 1 and np.all(np.diff(sh) >= 0)
+        cnt = np.bincount(sh[sc.pt_idx], minlength=world)
+        assert cnt.sum() == sc.n_obs and cnt.max() - cnt.min() <= 2 * 6
+
+
+def _triple_loop(frames, process, cloud):
+    """The reference's own O(Ncam*Npts*Nkp) derivation, ba.cpp:22-56, verbatim semantics."""
+    cams, pts, uv = [], [], []
+    ncam = 0
+    for i, fr in enumerate(frames):
+        if process[i]:
+            continue
+        for k in range(len(cloud.unique_point_ids)):
+            for j in range(len(fr.unique_pixel_ids)):
+                if fr.unique_pixel_has_match[j] and fr.unique_pixel_ids[j] == cloud.unique_point_ids[k]:
+                    uv.append(fr.keypoints[j]); pts.append(k); cams.append(ncam)
+                    break
+        ncam += 1
+    return np.array(cams, np.int32), np.array(pts, np.int32), np.array(uv, np.float32).reshape(-1, 2)
+
+
+def test_setBAProblem_matches_reference_triple_loop():
+    rng = np.random.default_rng(4)
+    frames, process = [], []
+    for i in range(5):
+        n = int(rng.integers(20, 60))
+        fr = E.Frame(frame_id=i, keypoints=rng.uniform(0, 700, (n, 2)).astype(np.float32))
+        fr.unique_pixel_ids = rng.integers(0, 40, n)          # many duplicates: the `break` picks the first
+        fr.unique_pixel_has_match = rng.random(n) < 0.6
+        fr.pose_cam = np.eye(4, dtype=np.float32); fr.pose_cam[:3, 3] = rng.standard_normal(3)
+        fr.K_cam = np.array([[700, 0, 380], [0, 701, 250], [0, 0, 1]], np.float32)
+        frames.append(fr); process.append(bool(i == 3))
+    cloud = E.SparsePointCloud(xyz=rng.standard_normal((35, 3)).astype(np.float32),
+                               unique_point_ids=rng.permutation(45)[:35])
+    ba = E.BundleAdjustment.__new__(E.BundleAdjustment)
+    ba._ctx = None; ba.options = None
+    ba.initBA()
+    ready = ba.setBAProblem(frames, process, cloud)
+    c, p, uv = _triple_loop(frames, process, cloud)
+    assert ba.num_cameras_ == 4 and ba.num_points_ == 35
+    assert np.array_equal(ba.camera_index_, c) and np.array_equal(ba.point_index_, p) and np.array_equal(ba.points_2d_, uv)
+    assert ba.num_parameters_ == 6 * 4 + 3 * 35 and ready == (2 * len(c) > ba.num_parameters_)
+    # parameter packing (ba.cpp:70-104): angle-axis of the float pose, translation, then float points
+    assert np.allclose(ba.parameters_[3:6], frames[0].pose_cam[:3, 3]) and np.allclose(ba.parameters_[:3], 0)
+    assert np.array_equal(ba.parameters_[24:].reshape(-1, 3), cloud.xyz.astype(np.float64))
+
+
+def test_rodrigues_roundtrip():
+    from easysfm_amd.ba import angle_axis_to_rotation, rotation_to_angle_axis
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        aa = rng.standard_normal(3) * rng.uniform(0, 3.0)
+        R = angle_axis_to_rotation(aa)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+        assert np.allclose(angle_axis_to_rotation(rotation_to_angle_axis(R)), R, atol=1e-9)
+    assert np.allclose(rotation_to_angle_axis(np.eye(3)), 0)
+
+
+def test_unsupported_modes_fail_loudly():
+    ba = E.BundleAdjustment.__new__(E.BundleAdjustment)
+    ba._ctx = None; ba.options = None
+    ba.initBA()
+    with pytest.raises(NotImplementedError):
+        ba.solveBA(20.0)
