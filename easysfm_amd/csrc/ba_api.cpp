@@ -161,6 +161,8 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     A(&d.camacc, esfm::ba_camacc_doubles(n_cam)); A(&d.red, esfm::ba_red_doubles(n_cam));
     A(&d.y_c, nc6); A(&d.scal, (size_t)esfm::SC_COUNT);
     A(&d.chol, (nc6 + 1) * (nc6 + 2) / 2 + 2);
+    d.slab_cap = esfm::ba_schur_slab_doubles(n_cam, ctx->num_cu);
+    if (d.slab_cap) A(&d.slabs, d.slab_cap);
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     hipStream_t st = ctx->stream;
     auto up = [&](void *dst, const void *src, size_t bytes) {
@@ -323,7 +325,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         ESFM_HIP_TRY(hipMemsetAsync(d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
         {
             esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SCHUR);
-            if (int rc = esfm::ba_schur(st, d)) return finish(rc);
+            if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap)) return finish(rc);
         }
         if (int rc = S.allreduce(d.red, (int64_t)esfm::ba_red_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
         {

@@ -388,6 +388,87 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d)
     }
 }
 
+// Small-camera-count variant (the metric configuration: 25 cameras): the whole lower-block-triangular
+// Schur matrix fits in LDS (n_cam (n_cam+1)/2 blocks of 36 doubles + the 6 n_cam right-hand side), so
+// each workgroup accumulates its observations' contributions with LDS f64 atomics (ds_add_f64) and
+// then stores its private copy as one coalesced slab; ba_schur_reduce_kernel sums the slabs in a fixed
+// order and unpacks them into the n x n layout.  No global atomics.
+__global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__restrict__ slabs, int slab_doubles)
+{
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // [nblk*36] blocks, then [n] rhs_corr
+    const int tid = threadIdx.x;
+    const int n = 6 * d.n_cam;
+    const int nblk = d.n_cam * (d.n_cam + 1) / 2;
+    for (int e = tid; e < slab_doubles; e += 1024) sl[e] = 0.0;
+    __syncthreads();
+    double *srhs = sl + (size_t)nblk * 36;
+    const size_t n_obs = d.n_obs;
+    for (int i = blockIdx.x * 1024 + tid; i < d.n_obs; i += gridDim.x * 1024) {
+        const int p = d.obs_pt[i], ci = d.obs_cam[i];
+        double Jc[12], Jp[6];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n_obs + i];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jp[a] = d.Jp[a * n_obs + i];
+        const double *Mi = d.Minv + 6 * (size_t)p;
+        const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
+        const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+        double Y[18];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
+            const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
+            const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
+            atomicAdd(&srhs[6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2));
+            Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
+            Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
+            Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+        }
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        for (int j = b; j < e; ++j) {
+            const int cj = d.obs_cam[j];
+            if (cj > ci) continue;
+            double Fj[12], Ej[6];
+#pragma unroll
+            for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
+            double *Sb = sl + (size_t)(ci * (ci + 1) / 2 + cj) * 36;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) {
+                const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
+                const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
+                const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                    atomicAdd(&Sb[a * 6 + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
+            }
+        }
+    }
+    __syncthreads();
+    double *out = slabs + (size_t)blockIdx.x * slab_doubles;
+    for (int e = tid; e < slab_doubles; e += 1024) out[e] = sl[e];
+    (void)n;
+}
+
+// Sum the per-workgroup slabs (fixed order) and scatter into red = S_schur (n x n) | rhs_corr (n).
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const double *__restrict__ slabs, int slab_doubles, int n_slabs)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= slab_doubles) return;
+    double s = 0.0;
+    for (int b = 0; b < n_slabs; ++b) s += slabs[(size_t)b * slab_doubles + e];
+    const int n = 6 * d.n_cam;
+    const int nblk = d.n_cam * (d.n_cam + 1) / 2;
+    if (e >= nblk * 36) { d.red[(size_t)n * n + (e - nblk * 36)] = s; return; }
+    const int blk = e / 36, r = e % 36;
+    int ci = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+    while ((ci + 1) * (ci + 2) / 2 <= blk) ++ci;
+    while (ci * (ci + 1) / 2 > blk) --ci;
+    const int cj = blk - ci * (ci + 1) / 2;
+    d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6] = s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dense solve of the reduced camera system (DENSE_SCHUR's Cholesky):
 //   (F'F + D_c^2 + S_schur) y = F'r + rhs_corr
@@ -659,10 +740,23 @@ int ba_camera_gradient(hipStream_t st, const BADev &d)
     return ESFM_OK;
 }
 
-int ba_schur(hipStream_t st, const BADev &d)
+int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles)
 {
     ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
     if (d.n_obs <= 0) return ESFM_OK;
+    const int nblk = d.n_cam * (d.n_cam + 1) / 2;
+    const int slab_doubles = nblk * 36 + 6 * d.n_cam;
+    const size_t lds_bytes = sizeof(double) * (size_t)slab_doubles;
+    const int n_slabs = std::max(1, std::min(num_cu, div_up(d.n_obs, 1024)));
+    if (lds_bytes <= 156 * 1024 && slabs && (size_t)n_slabs * slab_doubles <= slab_capacity_doubles) {
+        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(1024), lds_bytes, st, d, slabs, slab_doubles);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(div_up(slab_doubles, 256)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs);
+        LAUNCH_CHECK();
+        return ESFM_OK;
+    }
     hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
     LAUNCH_CHECK();
     return ESFM_OK;

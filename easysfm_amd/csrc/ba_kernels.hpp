@@ -49,6 +49,8 @@ struct BADev {
     double *y_c = nullptr;   // [6 n_cam] solution of the reduced system
     double *scal = nullptr;  // [SC_COUNT]
     double *chol = nullptr;  // [(n+1)(n+2)/2] packed-lower work matrix for large n
+    double *slabs = nullptr; // per-workgroup Schur slabs (small n_cam only)
+    size_t slab_cap = 0;
 };
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
@@ -58,7 +60,13 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian);
 int ba_jacobi_scaling(hipStream_t st, const BADev &d);
 int ba_camera_gradient(hipStream_t st, const BADev &d);
-int ba_schur(hipStream_t st, const BADev &d);
+// slabs: scratch for the LDS-privatised variant (n_cam small), >= ba_schur_slab_doubles(n_cam, num_cu) doubles, or NULL
+int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles);
+inline size_t ba_schur_slab_doubles(int n_cam, int num_cu)
+{
+    const size_t per = (size_t)n_cam * (n_cam + 1) / 2 * 36 + 6 * (size_t)n_cam;
+    return per * sizeof(double) <= 156 * 1024 ? per * (size_t)num_cu : 0;
+}
 int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
 int ba_camera_step(hipStream_t st, const BADev &d);
 int ba_backsub(hipStream_t st, const BADev &d);
