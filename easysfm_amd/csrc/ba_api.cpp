@@ -163,6 +163,10 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     A(&d.chol, (nc6 + 1) * (nc6 + 2) / 2 + 2);
     d.slab_cap = esfm::ba_schur_slab_doubles(n_cam, ctx->num_cu);
     if (d.slab_cap) A(&d.slabs, d.slab_cap);
+    if ((size_t)n_cam * 27 * sizeof(double) <= 60 * 1024) {
+        d.lin_slab_cap = (size_t)n_cam * 27 * 2 * (size_t)ctx->num_cu;
+        A(&d.lin_slabs, d.lin_slab_cap);
+    }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     hipStream_t st = ctx->stream;
     auto up = [&](void *dst, const void *src, size_t bytes) {

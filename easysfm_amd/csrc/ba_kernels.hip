@@ -39,6 +39,30 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
     atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
 }
 
+// Sum of entry e over n_slabs per-workgroup slabs, computed by a 32 x 8 thread tile: thread (ent, grp)
+// adds slabs grp, grp+8, ... (independent loads, coalesced across ent), then the 8 partial sums are
+// combined in a fixed order through LDS.  Deterministic; returns the total to the grp == 0 threads.
+constexpr int kRedEnt = 32, kRedGrp = 8;
+__device__ __forceinline__ double slab_sum(const double *__restrict__ slabs, int per, int n_slabs, int e, double *lds /*[256]*/)
+{
+    const int grp = threadIdx.x / kRedEnt;
+    double v0 = 0.0, v1 = 0.0;
+    if (e < per) {
+        int b = grp;
+        for (; b + kRedGrp < n_slabs; b += 2 * kRedGrp) {
+            v0 += slabs[(size_t)b * per + e];
+            v1 += slabs[(size_t)(b + kRedGrp) * per + e];
+        }
+        if (b < n_slabs) v0 += slabs[(size_t)b * per + e];
+    }
+    lds[threadIdx.x] = v0 + v1;
+    __syncthreads();
+    double t = 0.0;
+    if (grp == 0)
+        for (int g = 0; g < kRedGrp; ++g) t += lds[g * kRedEnt + (threadIdx.x % kRedEnt)];
+    return t;
+}
+
 // ceres::CauchyLoss::Evaluate [upstream]; a <= 0 selects the trivial (squared) loss.
 __device__ __forceinline__ void loss_eval(double a, double s, double &rho0, double &rho1)
 {
@@ -109,8 +133,10 @@ __device__ __forceinline__ void transform_point(const double *__restrict__ cam, 
 // ---------------------------------------------------------------------------------------------
 // Jacobian sweep.  PRIV: per-camera sums go through an LDS-private copy first (n_cam * 27 doubles),
 // so global f64 atomics are one per camera entry per workgroup instead of 27 per observation.
+constexpr int kLinThreads = 512;
+
 template <bool PRIV>
-__global__ __launch_bounds__(256) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling)
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, double *__restrict__ slabs)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [8] reduction scratch, then PRIV: [n_cam*27]
     double *red = lds;
@@ -118,11 +144,11 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BADev d, double cauch
     const int tid = threadIdx.x;
     const int n_obs = d.n_obs;
     if (PRIV) {
-        for (int e = tid; e < d.n_cam * 27; e += 256) priv[e] = 0.0;
+        for (int e = tid; e < d.n_cam * 27; e += kLinThreads) priv[e] = 0.0;
         __syncthreads();
     }
     double cost = 0.0, bad = 0.0;
-    for (int k = blockIdx.x * 256 + tid; k < n_obs; k += gridDim.x * 256) {
+    for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
         const int c = d.obs_cam[k], p = d.obs_pt[k];
         const float2 uv = d.obs_uv[k];
         const float4 K = d.K4[c];
@@ -207,29 +233,37 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BADev d, double cauch
     const double bs = block_sum(bad, red);
     if (tid == 0) { atomicAdd(&d.scal[SC_COST], cs); if (bs > 0.0) atomicAdd(&d.scal[SC_LIN_BAD], bs); }
     if (PRIV) {
+        // one coalesced slab per workgroup; ba_camacc_reduce_kernel sums them in a fixed order
         __syncthreads();
-        for (int e = tid; e < d.n_cam * 27; e += 256) {
-            const double v = priv[e];
-            if (v == 0.0) continue;
-            const int c = e / 27, q = e % 27;
-            if (q >= 21) { atomicAdd(&d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)], v); continue; }
-            // unpack upper-triangle index q -> (a, b)
-            int a = 0, rem = q;
-            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-            const int b = a + rem;
-            atomicAdd(&d.camacc[36 * (size_t)c + 6 * a + b], v);
-            if (a != b) atomicAdd(&d.camacc[36 * (size_t)c + 6 * b + a], v);
-        }
+        double *out = slabs + (size_t)blockIdx.x * d.n_cam * 27;
+        for (int e = tid; e < d.n_cam * 27; e += kLinThreads) out[e] = priv[e];
     }
+}
+
+// camacc = sum over slabs, unpacked: F'F (36 per camera, both triangles) | F'r (6 per camera)
+__global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const double *__restrict__ slabs, int n_slabs)
+{
+    __shared__ double lds[256];
+    const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
+    const int per = d.n_cam * 27;
+    const double v = slab_sum(slabs, per, n_slabs, e, lds);
+    if (threadIdx.x >= kRedEnt || e >= per) return;
+    const int c = e / 27, q = e % 27;
+    if (q >= 21) { d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)] = v; return; }
+    int a = 0, rem = q;
+    while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+    const int b2 = a + rem;
+    d.camacc[36 * (size_t)c + 6 * a + b2] = v;
+    d.camacc[36 * (size_t)c + 6 * b2 + a] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Per point: E'E, E'r (only when the Jacobian is fresh), then M^-1 = (E'E + clamp(diag)/radius)^-1
 // via a 3x3 Cholesky (ceres InvertPSDMatrix), M^-1 E'r, and the point part of max|gradient|.
-__global__ __launch_bounds__(256) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh)
+__global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh)
 {
     __shared__ double red[8];
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x * 64 + threadIdx.x;
     double gmax = 0.0, sing = 0.0;
     if (p < d.n_pt) {
         const int b = d.pt_start[p], e = d.pt_start[p + 1];
@@ -454,10 +488,10 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
 // Sum the per-workgroup slabs (fixed order) and scatter into red = S_schur (n x n) | rhs_corr (n).
 __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const double *__restrict__ slabs, int slab_doubles, int n_slabs)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= slab_doubles) return;
-    double s = 0.0;
-    for (int b = 0; b < n_slabs; ++b) s += slabs[(size_t)b * slab_doubles + e];
+    __shared__ double lds[256];
+    const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
+    const double s = slab_sum(slabs, slab_doubles, n_slabs, e, lds);
+    if (threadIdx.x >= kRedEnt || e >= slab_doubles) return;
     const int n = 6 * d.n_cam;
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
     if (e >= nblk * 36) { d.red[(size_t)n * n + (e - nblk * 36)] = s; return; }
@@ -476,27 +510,32 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const dou
 // as row n (so the forward substitution comes for free), then the backward substitution.
 // LDS_STORE: the packed matrix lives in LDS (n <= ~185), otherwise in d.chol (global).
 constexpr int kCholThreads = 1024;
-constexpr int kCholLPR = 4;  // lanes cooperating on one row's dot product
+constexpr int kCholNB = 8;  // panel width
 
+// Blocked left-looking Cholesky, one workgroup.  Per panel of kCholNB columns:
+//   A  all waves: subtract the contribution of the already-factored columns from the panel
+//      (one dot product per panel entry, rows j0..n; row n is the right-hand side)
+//   B  wave 0 alone factors the panel column by column (wave-synchronous, no s_barrier)
+// i.e. 2 barriers per panel instead of 2 per column.  The backward substitution is blocked the same way.
 template <bool LDS_STORE>
 __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, double radius, double min_diag, double max_diag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = 6 * d.n_cam;
     const size_t tot = (size_t)(n + 1) * (n + 2) / 2;
-    double *L = LDS_STORE ? smem : d.chol;  // packed lower, (n+1) rows; row n = rhs
+    double *L = LDS_STORE ? smem : d.chol;            // packed lower, (n+1) rows; row n = rhs
+    double *rd = LDS_STORE ? (smem + tot) : smem;     // [n] reciprocal diagonal of L
     // failure flag kept inside the dynamic region (a static __shared__ object in front of it would
     // shift the f64 array off its 8-byte alignment)
-    volatile double *failp = LDS_STORE ? (smem + tot) : smem;
-    const int tid = threadIdx.x;
+    volatile double *failp = rd + n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *failp = 0.0;
     const double *S = d.red;
     const double *rc = d.red + (size_t)n * n;
     const double *FtF = d.camacc;
     const double *Ftr = d.camacc + 36 * (size_t)d.n_cam;
-    // assemble
+    // assemble: L = F'F + D_c^2 + S_schur (lower), row n = F'r + rhs_corr
     for (size_t e = tid; e < tot; e += kCholThreads) {
-        // unpack e -> (i, k), k <= i
         int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
         while ((size_t)(i + 1) * (i + 2) / 2 <= e) ++i;
         while ((size_t)i * (i + 1) / 2 > e) --i;
@@ -515,41 +554,90 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
         L[e] = v;
     }
     __syncthreads();
-    const int grp = tid / kCholLPR, sub = tid % kCholLPR, ngrp = kCholThreads / kCholLPR;
-    for (int j = 0; j < n; ++j) {
-        const double *Lj = L + (size_t)j * (j + 1) / 2;
-        // diagonal: every group computes it redundantly? no -- group 0 computes, then broadcast through L
-        if (grp == 0) {
-            double s = 0.0;
-            for (int k = sub; k < j; k += kCholLPR) s += Lj[k] * Lj[k];
-#pragma unroll
-            for (int o = kCholLPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (sub == 0) {
-                const double dd = Lj[j] - s;
-                if (!(dd > 0.0) || !isfinite(dd)) *failp = 1.0;
-                L[(size_t)j * (j + 1) / 2 + j] = sqrt(dd > 0.0 ? dd : 1.0);
+    auto row = [&](int i) -> double * { return L + (size_t)i * (i + 1) / 2; };
+
+    for (int j0 = 0; j0 < n; j0 += kCholNB) {
+        const int nb = min(kCholNB, n - j0);
+        if (j0 > 0) {
+            const int nrows = n - j0 + 1;
+            for (int e = tid; e < nrows * nb; e += kCholThreads) {
+                const int i = j0 + e / nb, col = j0 + e % nb;
+                if (col > i) continue;   // above the diagonal (row n >= every col)
+                const double *Li = row(i), *Lc = row(col);
+                double s0 = 0.0, s1 = 0.0;
+                int k = 0;
+                for (; k + 1 < j0; k += 2) { s0 += Li[k] * Lc[k]; s1 += Li[k + 1] * Lc[k + 1]; }
+                if (k < j0) s0 += Li[k] * Lc[k];
+                row(i)[col] -= s0 + s1;
             }
         }
         __syncthreads();
-        const double inv = 1.0 / Lj[j];
-        for (int i = j + 1 + grp; i <= n; i += ngrp) {
-            double *Li = L + (size_t)i * (i + 1) / 2;
-            double s = 0.0;
-            for (int k = sub; k < j; k += kCholLPR) s += Li[k] * Lj[k];
+        // B1: wave 0 factors the nb x nb diagonal block in registers (lane r = block row r)
+        if (wave == 0) {
+            const int r = lane;
+            double a[kCholNB];
 #pragma unroll
-            for (int o = kCholLPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (sub == 0) Li[j] = (Li[j] - s) * inv;
+            for (int c = 0; c < kCholNB; ++c) a[c] = (r < nb && c <= r) ? row(j0 + r)[j0 + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < kCholNB; ++c) {
+                if (c < nb) {
+                    const double piv = __shfl(a[c], c);
+                    if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *failp = 1.0; }
+                    const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
+                    a[c] = (r == c) ? piv * rinv : a[c] * rinv;
+                    if (lane == c) rd[j0 + c] = rinv;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < kCholNB; ++c2) {
+                        const double l2 = __shfl(a[c], c2);   // L[j0+c2][j0+c]
+                        if (r >= c2) a[c2] -= a[c] * l2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kCholNB; ++c)
+                if (r < nb && c <= r) row(j0 + r)[j0 + c] = a[c];
+        }
+        __syncthreads();
+        // B2: every row below the block (and the rhs row) solves against the block's transpose
+        for (int i = j0 + nb + tid; i <= n; i += kCholThreads) {
+            double *Li = row(i);
+            double x[kCholNB];
+#pragma unroll
+            for (int c = 0; c < kCholNB; ++c) x[c] = c < nb ? Li[j0 + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < kCholNB; ++c) {
+                if (c < nb) {
+                    const double *Lc = row(j0 + c) + j0;
+                    double v = x[c];
+#pragma unroll
+                    for (int c1 = 0; c1 < c; ++c1) v -= x[c1] * Lc[c1];
+                    x[c] = v * rd[j0 + c];
+                    Li[j0 + c] = x[c];
+                }
+            }
         }
         __syncthreads();
     }
-    // backward substitution L' y = z, z = row n.  Column-oriented: once y_i is known, z_k -= L[i][k] y_i.
-    double *z = L + (size_t)n * (n + 1) / 2;
-    for (int i = n - 1; i >= 0; --i) {
-        const double *Li = L + (size_t)i * (i + 1) / 2;
-        const double yi = z[i] / Li[i];
+    // backward substitution L' y = z (z = row n), panels from the bottom
+    double *z = row(n);
+    const int last = ((n - 1) / kCholNB) * kCholNB;
+    for (int j0 = last; j0 >= 0; j0 -= kCholNB) {
+        const int nb = min(kCholNB, n - j0);
+        if (wave == 0) {
+            for (int i = j0 + nb - 1; i >= j0; --i) {
+                const double yi = z[i] * rd[i];
+                if (lane == 0) z[i] = yi;
+                const double *Li = row(i);
+                for (int k = j0 + lane; k < i; k += 64) z[k] -= Li[k] * yi;
+                if (!LDS_STORE) __threadfence_block();
+            }
+        }
         __syncthreads();
-        if (tid == 0) z[i] = yi;
-        for (int k = tid; k < i; k += kCholThreads) z[k] -= Li[k] * yi;
+        for (int k = tid; k < j0; k += kCholThreads) {
+            double s = 0.0;
+            for (int i = j0; i < j0 + nb; ++i) s += row(i)[k] * z[i];
+            z[k] -= s;
+        }
         __syncthreads();
     }
     const bool fail = *failp != 0.0;
@@ -577,10 +665,10 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
 
 // Back-substitution per point: y_p = M^-1 (E'r - sum_i E_i'F_i y_c), step = -y, candidate point,
 // and this point's share of model_cost_change = -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BADev d)
+__global__ __launch_bounds__(64) void ba_backsub_kernel(BADev d)
 {
     __shared__ double red[8];
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x * 64 + threadIdx.x;
     double mc = 0.0, ssq = 0.0, csq = 0.0;
     if (p < d.n_pt) {
         const int b = d.pt_start[p], e = d.pt_start[p + 1];
@@ -702,15 +790,19 @@ static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / 
 
 int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling)
 {
-    ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
-    if (d.n_obs <= 0) return ESFM_OK;
+    if (d.n_obs <= 0) { ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st)); return ESFM_OK; }
     const size_t priv_bytes = sizeof(double) * (8 + (size_t)d.n_cam * 27);
-    const bool priv = priv_bytes <= 64 * 1024;
-    const int grid = std::min(div_up(d.n_obs, 256), std::max(1, num_cu) * 8);
-    if (priv)
-        hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(256), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0);
-    else
-        hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(grid), dim3(256), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0);
+    const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
+    const bool priv = priv_bytes <= 64 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
+    if (priv) {
+        hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid);
+    } else {
+        ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
+        hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(grid), dim3(kLinThreads), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0,
+                           (double *)nullptr);
+    }
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -718,7 +810,7 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh)
 {
     if (d.n_pt <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0);
+    hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0);
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -753,7 +845,7 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(1024), lds_bytes, st, d, slabs, slab_doubles);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(div_up(slab_doubles, 256)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs);
+        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs);
         LAUNCH_CHECK();
         return ESFM_OK;
     }
@@ -766,13 +858,13 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
 {
     if (d.n_cam <= 0) return ESFM_OK;
     const int n = 6 * d.n_cam;
-    const size_t bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + 2);
+    const size_t bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + n + 2);
     if (bytes <= 150 * 1024) {
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_chol_solve_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(ba_chol_solve_kernel<true>, dim3(1), dim3(kCholThreads), bytes, st, d, radius, min_diag, max_diag);
     } else {
-        hipLaunchKernelGGL(ba_chol_solve_kernel<false>, dim3(1), dim3(kCholThreads), 2 * sizeof(double), st, d, radius, min_diag, max_diag);
+        hipLaunchKernelGGL(ba_chol_solve_kernel<false>, dim3(1), dim3(kCholThreads), sizeof(double) * (size_t)(n + 2), st, d, radius, min_diag, max_diag);
     }
     LAUNCH_CHECK();
     return ESFM_OK;
@@ -788,7 +880,7 @@ int ba_camera_step(hipStream_t st, const BADev &d)
 int ba_backsub(hipStream_t st, const BADev &d)
 {
     if (d.n_pt <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d);
     LAUNCH_CHECK();
     return ESFM_OK;
 }

@@ -51,6 +51,8 @@ struct BADev {
     double *chol = nullptr;  // [(n+1)(n+2)/2] packed-lower work matrix for large n
     double *slabs = nullptr; // per-workgroup Schur slabs (small n_cam only)
     size_t slab_cap = 0;
+    double *lin_slabs = nullptr;  // per-workgroup F'F / F'r slabs of the Jacobian sweep (27 n_cam each)
+    size_t lin_slab_cap = 0;
 };
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
