@@ -1,0 +1,320 @@
+// C++ host mirror of the reference's hot-path interface over the C ABI (include/esfm.h).
+//
+// Same class and member names, argument meaning, defaults and error behaviour as
+//   p3dv::FeatureMatching::matchFeaturesORB / matchFeaturesSURF   cpp_code/include/feature_matching.h:17-21
+//   p3dv::BundleAdjustment::{initBA,setBAProblem,solveBA,doSFMBA}  cpp_code/include/ba.h:59-84
+// with the OpenCV / PCL / Eigen value types of cpp_code/include/utility.h:21-102 replaced by the
+// plain structs below (the image has none of those libraries).  Header-only; link libesfm_hip.so.
+// All compute happens on the GPU behind the C ABI; there is no CPU fallback here.
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/esfm.h"
+
+namespace p3dv {
+
+// ---- value types (utility.h) ------------------------------------------------------------------
+struct DMatch {  // cv::DMatch
+    int queryIdx = -1, trainIdx = -1, imgIdx = 0;
+    float distance = 0.f;
+    DMatch() = default;
+    DMatch(int q, int t, int img, float d) : queryIdx(q), trainIdx(t), imgIdx(img), distance(d) {}
+};
+
+struct Point2f { float x = 0.f, y = 0.f; };
+struct KeyPoint { Point2f pt; };  // cv::KeyPoint (only .pt is read on this path, ba.cpp:37)
+
+// cv::Mat restricted to what descriptors need: CV_32F (SURF, N x 64) or CV_8U (ORB, N x 32), continuous
+struct DescMat {
+    enum Type { F32 = 0, U8 = 1 };
+    int rows = 0, cols = 0;
+    Type type = F32;
+    std::vector<uint8_t> bytes;
+    void create(int r, int c, Type t) { rows = r; cols = c; type = t; bytes.assign(size_t(r) * c * (t == F32 ? 4 : 1), 0); }
+    template <class T> T *ptr(int r = 0) { return reinterpret_cast<T *>(bytes.data()) + size_t(r) * cols; }
+    template <class T> const T *ptr(int r = 0) const { return reinterpret_cast<const T *>(bytes.data()) + size_t(r) * cols; }
+};
+
+template <int R, int C> struct Matf {  // Eigen::Matrix<float,R,C>, (r,c) access
+    float v[R * C];
+    Matf() { for (auto &x : v) x = 0.f; }
+    float &operator()(int r, int c) { return v[r * C + c]; }
+    float operator()(int r, int c) const { return v[r * C + c]; }
+    static Matf Identity() { Matf m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.f; return m; }
+};
+using Matrix3f = Matf<3, 3>;
+using Matrix4f = Matf<4, 4>;
+
+struct frame_t {  // utility.h:21-55
+    unsigned int frame_id = 0;
+    std::string image_file_path;
+    std::vector<KeyPoint> keypoints;
+    DescMat descriptors;
+    std::vector<int> unique_pixel_ids;
+    std::vector<bool> unique_pixel_has_match;
+    Matrix4f pose_cam = Matrix4f::Identity();
+    Matrix3f K_cam = Matrix3f::Identity();
+    frame_t() = default;
+    frame_t(unsigned int id, const std::string &path) : frame_id(id), image_file_path(path) {}
+    bool init_pixel_ids()
+    {
+        unique_pixel_ids.assign(keypoints.size(), -1);
+        unique_pixel_has_match.assign(keypoints.size(), false);
+        return true;
+    }
+};
+
+struct PointXYZRGB { float x = 0, y = 0, z = 0; uint8_t r = 0, g = 0, b = 0; };  // pcl::PointXYZRGB
+
+struct pointcloud_sparse_t {  // utility.h:88-102 (rgb_pointcloud->points flattened)
+    std::vector<PointXYZRGB> points;
+    std::vector<int> unique_point_ids;
+    std::vector<int> is_inlier;
+};
+
+// ---- library context ----------------------------------------------------------------------------
+class EsfmError : public std::runtime_error {
+public:
+    int status;
+    EsfmError(int s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+inline esfm_ctx *default_ctx()
+{
+    static thread_local esfm_ctx *ctx = nullptr;
+    if (!ctx) {
+        int rc = esfm_ctx_create(0, nullptr, &ctx);
+        if (rc != ESFM_OK) throw EsfmError(rc, esfm_last_error());
+    }
+    return ctx;
+}
+
+// ---- matching (feature_matching.h:17-21) ----------------------------------------------------------
+class FeatureMatching {
+public:
+    bool matchFeaturesORB(frame_t &cur_frame_1, frame_t &cur_frame_2, std::vector<DMatch> &matches, double ratio_thre = 0.8,
+                          bool show = false)
+    {
+        return run(cur_frame_1, cur_frame_2, matches, ratio_thre, true, "ORB");
+    }
+
+    bool matchFeaturesSURF(frame_t &cur_frame_1, frame_t &cur_frame_2, std::vector<DMatch> &matches, double ratio_thre = 0.5,
+                           bool show = false)
+    {
+        return run(cur_frame_1, cur_frame_2, matches, ratio_thre, false, "SURF");
+    }
+
+    bool quiet = false;  // the reference prints timing lines (feature_matching.cpp:96-97,141-142)
+
+private:
+    bool run(frame_t &f1, frame_t &f2, std::vector<DMatch> &matches, double ratio, bool hamming, const char *tag)
+    {
+        const DescMat &q = f1.descriptors, &t = f2.descriptors;
+        if (q.rows > 0 && t.rows > 0 && (q.cols != t.cols || q.type != t.type)) { std::cerr << "descriptor shapes differ\n"; return false; }
+        if ((hamming && q.type != DescMat::U8) || (!hamming && q.type != DescMat::F32)) { std::cerr << "wrong descriptor type\n"; return false; }
+        auto tic = std::chrono::steady_clock::now();
+        std::vector<int32_t> qi(size_t(std::max(q.rows, 1))), ti(size_t(std::max(q.rows, 1)));
+        std::vector<float> d(size_t(std::max(q.rows, 1)));
+        int32_t n = 0;
+        int rc = hamming ? esfm_match_hamming(default_ctx(), q.ptr<uint8_t>(), q.rows, t.ptr<uint8_t>(), t.rows, q.cols, ratio, qi.data(),
+                                              ti.data(), d.data(), &n)
+                         : esfm_match_l2_f32(default_ctx(), q.ptr<float>(), q.rows, t.ptr<float>(), t.rows, q.cols, ratio, qi.data(),
+                                             ti.data(), d.data(), &n);
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        const size_t before = matches.size();
+        for (int k = 0; k < n; ++k) matches.push_back(DMatch(qi[size_t(k)], ti[size_t(k)], 0, d[size_t(k)]));  // appended (:90, :135)
+        if (!quiet) {
+            std::chrono::duration<double> dt = std::chrono::steady_clock::now() - tic;
+            std::cout << "match " << tag << " cost = " << dt.count() << " seconds. " << std::endl;
+            std::cout << "# Correspondence: Initial [ " << q.rows << " ]  Filtered by Lowe ratio test [ " << matches.size() - before
+                      << " ]" << std::endl;
+        }
+        return true;
+    }
+};
+
+// ---- cv::Rodrigues as used at ba.cpp:82 (matrix -> vector) and :239 (vector -> matrix) -------------
+inline void rotation_to_angle_axis(const double R[9], double aa[3])
+{
+    const double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double theta = std::acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { aa[0] = aa[1] = aa[2] = 0.0; return; }
+        double v[3] = {std::sqrt(std::max((R[0] + 1) * 0.5, 0.0)), std::sqrt(std::max((R[4] + 1) * 0.5, 0.0)),
+                       std::sqrt(std::max((R[8] + 1) * 0.5, 0.0))};
+        if (R[1] < 0) v[1] = -v[1];
+        if (R[2] < 0) v[2] = -v[2];
+        if ((R[5] > 0) != (v[1] * v[2] > 0)) v[2] = -v[2];
+        const double nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int i = 0; i < 3; ++i) aa[i] = v[i] * (theta / std::max(nrm, 1e-300));
+        return;
+    }
+    const double k = 0.5 * theta / s;
+    aa[0] = rx * k; aa[1] = ry * k; aa[2] = rz * k;
+}
+
+inline void angle_axis_to_rotation(const double aa[3], double R[9])
+{
+    const double theta = std::sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+    if (theta < 2.2204460492503131e-16) { for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    const double k[3] = {aa[0] / theta, aa[1] / theta, aa[2] / theta};
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1.0 - c;
+    R[0] = c + c1 * k[0] * k[0]; R[1] = c1 * k[0] * k[1] - s * k[2]; R[2] = c1 * k[0] * k[2] + s * k[1];
+    R[3] = c1 * k[1] * k[0] + s * k[2]; R[4] = c + c1 * k[1] * k[1]; R[5] = c1 * k[1] * k[2] - s * k[0];
+    R[6] = c1 * k[2] * k[0] - s * k[1]; R[7] = c1 * k[2] * k[1] + s * k[0]; R[8] = c + c1 * k[2] * k[2];
+}
+
+// ---- bundle adjustment (ba.h:28-106) -----------------------------------------------------------------
+class BundleAdjustment {
+public:
+    BundleAdjustment() { initBA(); esfm_ba_options_default(&options_); }
+
+    int num_observations() const { return num_observations_; }
+    double *mutable_cameras() { return parameters_.data(); }
+    double *mutable_points() { return parameters_.data() + 6 * num_cameras_; }
+
+    bool initBA()  // ba.h:59-75
+    {
+        point_index_.clear(); camera_index_.clear(); points_2d_.clear(); calibs_.clear(); parameters_.clear();
+        num_cameras_ = num_points_ = num_parameters_ = num_observations_ = 0;
+        ref_process_camera_id_ = -1;
+        if (verbose) std::cout << "Bundle Ajustment parameters initialization done." << std::endl;
+        return true;
+    }
+
+    // ba.cpp:12-130.  Same observation list in the same order (camera-major, point index ascending; for a
+    // point the FIRST keypoint with has_match and a matching id, the `break` at :44) as the reference's
+    // O(Ncam*Npts*Nkp) triple loop, derived with one hash map per frame.
+    bool setBAProblem(std::vector<frame_t> &frames, std::vector<bool> &process_frame_id, pointcloud_sparse_t &sfm_sparse_points,
+                      double fix_calib_tolerance_BA, int reference_frame_id)
+    {
+        num_observations_ = 0; num_cameras_ = 0;
+        num_points_ = int(sfm_sparse_points.unique_point_ids.size());
+        for (size_t i = 0; i < frames.size(); ++i) {
+            if (process_frame_id[i]) continue;  // 0 = registered
+            calibs_.push_back(frames[i].K_cam);
+            std::unordered_map<int, int> first_kp;  // track id -> lowest keypoint index with has_match
+            const frame_t &fr = frames[i];
+            for (size_t j = 0; j < fr.unique_pixel_ids.size(); ++j)
+                if (fr.unique_pixel_has_match[j]) first_kp.emplace(fr.unique_pixel_ids[j], int(j));  // emplace keeps the first
+            for (int k = 0; k < num_points_; ++k) {
+                auto it = first_kp.find(sfm_sparse_points.unique_point_ids[size_t(k)]);
+                if (it == first_kp.end()) continue;
+                points_2d_.push_back(fr.keypoints[size_t(it->second)].pt);
+                point_index_.push_back(k);
+                camera_index_.push_back(num_cameras_);
+                ++num_observations_;
+            }
+            if (int(i) == reference_frame_id) ref_process_camera_id_ = num_cameras_;
+            ++num_cameras_;
+        }
+        num_parameters_ = 6 * num_cameras_ + 3 * num_points_ + (fix_calib_tolerance_BA != 0 ? 4 : 0);
+        parameters_.assign(size_t(num_parameters_), 0.0);
+        int k = 0;
+        for (size_t i = 0; i < frames.size(); ++i) {
+            if (process_frame_id[i]) continue;
+            double R[9], aa[3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = double(frames[i].pose_cam(r, c));
+            rotation_to_angle_axis(R, aa);
+            for (int a = 0; a < 3; ++a) {
+                parameters_[size_t(6 * k + a)] = double(float(aa[a]));  // rot_vec is CV_32F (:86-88)
+                parameters_[size_t(6 * k + 3 + a)] = double(frames[i].pose_cam(a, 3));
+            }
+            ++k;
+        }
+        for (int i = 0; i < num_points_; ++i) {
+            const PointXYZRGB &p = sfm_sparse_points.points[size_t(i)];
+            parameters_[size_t(6 * num_cameras_ + 3 * i)] = p.x;
+            parameters_[size_t(6 * num_cameras_ + 3 * i + 1)] = p.y;
+            parameters_[size_t(6 * num_cameras_ + 3 * i + 2)] = p.z;
+        }
+        if (fix_calib_tolerance_BA != 0 && !calibs_.empty()) {
+            parameters_[size_t(num_parameters_ - 4)] = calibs_[0](0, 0); parameters_[size_t(num_parameters_ - 3)] = calibs_[0](0, 2);
+            parameters_[size_t(num_parameters_ - 2)] = calibs_[0](1, 1); parameters_[size_t(num_parameters_ - 1)] = calibs_[0](1, 2);
+        }
+        if (verbose) {
+            std::cout << "Find [ " << num_observations_ << " ] Observations in total." << std::endl;
+            std::cout << "There are [ " << num_cameras_ << " ] cameras and [ " << num_points_ << " ] 3D points." << std::endl;
+        }
+        return 2 * num_observations_ > num_parameters_;  // "Ready to solve" (:120-129)
+    }
+
+    // ba.cpp:132-212 with calibration fixed: ceres::Solve -> esfm_ba_solve.
+    bool solveBA(double fix_calib_tolerance_BA)
+    {
+        if (fix_calib_tolerance_BA != 0 || ref_process_camera_id_ >= 0) {
+            std::cerr << "free-intrinsics / fixed-reference-camera BA (ba.cpp:155-196) is not built (SURVEY 8 row f-4)" << std::endl;
+            return false;
+        }
+        std::vector<float> K4(size_t(4 * num_cameras_));
+        for (int c = 0; c < num_cameras_; ++c) {
+            K4[size_t(4 * c)] = calibs_[size_t(c)](0, 0); K4[size_t(4 * c + 1)] = calibs_[size_t(c)](0, 2);
+            K4[size_t(4 * c + 2)] = calibs_[size_t(c)](1, 1); K4[size_t(4 * c + 3)] = calibs_[size_t(c)](1, 2);
+        }
+        options_.verbose = verbose ? 1 : 0;  // minimizer_progress_to_stdout (:204)
+        int rc = esfm_ba_solve(default_ctx(), num_cameras_, num_points_, num_observations_, camera_index_.data(), point_index_.data(),
+                               reinterpret_cast<const float *>(points_2d_.data()), K4.data(), mutable_cameras(), mutable_points(),
+                               &options_, nullptr, nullptr, &summary_);
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        return true;
+    }
+
+    // ba.cpp:214-288
+    bool doSFMBA(std::vector<frame_t> &frames, std::vector<bool> &process_frame_id, pointcloud_sparse_t &sfm_sparse_points,
+                 double fix_calib_tolerance_BA = 0.0, int reference_frame_id = -1)
+    {
+        auto tic = std::chrono::steady_clock::now();
+        initBA();
+        setBAProblem(frames, process_frame_id, sfm_sparse_points, fix_calib_tolerance_BA, reference_frame_id);
+        const bool ok = solveBA(fix_calib_tolerance_BA);
+        int k = 0;
+        for (size_t i = 0; i < frames.size(); ++i) {
+            if (process_frame_id[i]) continue;
+            const double aa[3] = {double(float(parameters_[size_t(6 * k)])), double(float(parameters_[size_t(6 * k + 1)])),
+                                  double(float(parameters_[size_t(6 * k + 2)]))};  // rot_vec float (:235-237)
+            double R[9];
+            angle_axis_to_rotation(aa, R);
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) frames[i].pose_cam(r, c) = float(R[3 * r + c]);
+                frames[i].pose_cam(r, 3) = float(parameters_[size_t(6 * k + 3 + r)]);
+            }
+            ++k;
+        }
+        for (int i = 0; i < num_points_; ++i) {  // :277-279, float truncation
+            sfm_sparse_points.points[size_t(i)].x = float(parameters_[size_t(6 * num_cameras_ + 3 * i)]);
+            sfm_sparse_points.points[size_t(i)].y = float(parameters_[size_t(6 * num_cameras_ + 3 * i + 1)]);
+            sfm_sparse_points.points[size_t(i)].z = float(parameters_[size_t(6 * num_cameras_ + 3 * i + 2)]);
+        }
+        if (verbose) {
+            std::chrono::duration<double> dt = std::chrono::steady_clock::now() - tic;
+            std::cout << "Bundle Ajustment cost = " << dt.count() << " seconds. " << std::endl << "Bundle Ajustment done." << std::endl;
+        }
+        return ok;
+    }
+
+    bool verbose = false;
+    esfm_ba_options options_;
+    esfm_ba_summary summary_;
+    // the reference's private state (ba.h:86-105), public here for the tests
+    int num_cameras_ = 0, num_points_ = 0, num_observations_ = 0, num_parameters_ = 0;
+    std::vector<int> point_index_, camera_index_;
+    std::vector<double> parameters_;  // [6 per camera (rot, tran) | 3 per point | optional fx,cx,fy,cy]
+    std::vector<Point2f> points_2d_;
+    std::vector<Matrix3f> calibs_;
+    int ref_process_camera_id_ = -1;
+};
+
+}  // namespace p3dv

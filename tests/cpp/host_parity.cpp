@@ -1,0 +1,142 @@
+// GPU parity test of the C++ host mirror (easysfm_amd/host/esfm_host.hpp) against the CPU oracle.
+// Test infrastructure: links BOTH libesfm_hip.so (product) and libesfm_oracle.so (checker).
+// Reads like a test of the reference's own classes: frame_t in, std::vector<DMatch> out.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "../../easysfm_amd/host/esfm_host.hpp"
+
+extern "C" {
+void esfm_ref_knn2_l2_f32(const float *, int, const float *, int, int, int32_t *, float *);
+void esfm_ref_knn2_hamming(const uint8_t *, int, const uint8_t *, int, int, int32_t *, float *);
+int esfm_ref_ratio_filter(const int32_t *, const float *, int, double, int32_t *, int32_t *, float *);
+int esfm_ref_ba_solve(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *,
+                      const esfm_ba_options *, esfm_ba_summary *);
+}
+
+using namespace p3dv;
+
+#define CHECK(c)                                                              \
+    do {                                                                      \
+        if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } \
+    } while (0)
+
+static void fill_surf(frame_t &f, int n, std::mt19937 &rng, const frame_t *like)
+{
+    std::normal_distribution<float> g(0.f, 1.f);
+    f.descriptors.create(n, 64, DescMat::F32);
+    for (int r = 0; r < n; ++r) {
+        float *p = f.descriptors.ptr<float>(r);
+        double nn = 0;
+        for (int c = 0; c < 64; ++c) {
+            p[c] = (like && r < like->descriptors.rows / 2) ? like->descriptors.ptr<float>(r)[c] + 0.05f * g(rng) : g(rng);
+            nn += double(p[c]) * p[c];
+        }
+        const float inv = float(1.0 / std::sqrt(nn));
+        for (int c = 0; c < 64; ++c) p[c] *= inv;
+    }
+}
+
+int main()
+{
+    std::mt19937 rng(123);
+    // ---- matchFeaturesSURF -------------------------------------------------------------------------
+    frame_t f2(0, "a.png"), f1(1, "b.png");
+    fill_surf(f2, 900, rng, nullptr);
+    fill_surf(f1, 1100, rng, &f2);
+    FeatureMatching fm; fm.quiet = true;
+    std::vector<DMatch> matches(1);            // pre-existing entry: the reference appends (:135)
+    CHECK(fm.matchFeaturesSURF(f1, f2, matches));
+    {
+        std::vector<int32_t> idx(2 * 1100), qi(1100), ti(1100); std::vector<float> dist(2 * 1100), d(1100);
+        esfm_ref_knn2_l2_f32(f1.descriptors.ptr<float>(), 1100, f2.descriptors.ptr<float>(), 900, 64, idx.data(), dist.data());
+        int n = esfm_ref_ratio_filter(idx.data(), dist.data(), 1100, 0.5, qi.data(), ti.data(), d.data());
+        CHECK(n > 50 && int(matches.size()) == n + 1);
+        for (int k = 0; k < n; ++k) {
+            const DMatch &m = matches[size_t(k + 1)];
+            CHECK(m.queryIdx == qi[size_t(k)] && m.trainIdx == ti[size_t(k)] && m.imgIdx == 0);
+            CHECK(std::memcmp(&m.distance, &d[size_t(k)], 4) == 0);
+        }
+        std::printf("matchFeaturesSURF: %d matches, bit-exact\n", n);
+    }
+    // ---- matchFeaturesORB --------------------------------------------------------------------------
+    {
+        frame_t o2(0, "a"), o1(1, "b");
+        o2.descriptors.create(700, 32, DescMat::U8); o1.descriptors.create(650, 32, DescMat::U8);
+        for (auto &b : o2.descriptors.bytes) b = uint8_t(rng());
+        for (int r = 0; r < 650; ++r)
+            for (int c = 0; c < 32; ++c) {
+                uint8_t v = r < 300 ? o2.descriptors.ptr<uint8_t>(r)[c] : uint8_t(rng());
+                if (r < 300) for (int bit = 0; bit < 8; ++bit) if (rng() % 100 < 8) v ^= uint8_t(1u << bit);
+                o1.descriptors.ptr<uint8_t>(r)[c] = v;
+            }
+        std::vector<DMatch> m2;
+        CHECK(fm.matchFeaturesORB(o1, o2, m2));
+        std::vector<int32_t> idx(2 * 650), qi(650), ti(650); std::vector<float> dist(2 * 650), d(650);
+        esfm_ref_knn2_hamming(o1.descriptors.ptr<uint8_t>(), 650, o2.descriptors.ptr<uint8_t>(), 700, 32, idx.data(), dist.data());
+        int n = esfm_ref_ratio_filter(idx.data(), dist.data(), 650, 0.8, qi.data(), ti.data(), d.data());
+        CHECK(n > 50 && int(m2.size()) == n);
+        for (int k = 0; k < n; ++k) CHECK(m2[size_t(k)].queryIdx == qi[size_t(k)] && m2[size_t(k)].trainIdx == ti[size_t(k)] && m2[size_t(k)].distance == d[size_t(k)]);
+        std::printf("matchFeaturesORB: %d matches, exact\n", n);
+    }
+    // ---- doSFMBA -----------------------------------------------------------------------------------
+    {
+        const int NC = 5, NP = 150;
+        std::normal_distribution<double> g(0.0, 1.0);
+        std::uniform_real_distribution<double> U(-1.5, 1.5);
+        std::vector<frame_t> frames;
+        std::vector<bool> process(NC + 1, false);
+        process[NC] = true;                     // last frame not registered yet
+        pointcloud_sparse_t cloud;
+        std::vector<double> X(3 * NP);
+        for (int p = 0; p < NP; ++p) { X[size_t(3 * p)] = U(rng); X[size_t(3 * p + 1)] = U(rng); X[size_t(3 * p + 2)] = U(rng) + 9.0; }
+        for (int p = 0; p < NP; ++p) {
+            PointXYZRGB q; q.x = float(X[size_t(3 * p)] + 0.03 * g(rng)); q.y = float(X[size_t(3 * p + 1)] + 0.03 * g(rng)); q.z = float(X[size_t(3 * p + 2)] + 0.03 * g(rng));
+            cloud.points.push_back(q); cloud.unique_point_ids.push_back(1000 + p);
+        }
+        for (int c = 0; c <= NC; ++c) {
+            frame_t fr(unsigned(c), "x");
+            fr.K_cam(0, 0) = 689.87f; fr.K_cam(0, 2) = 380.17f; fr.K_cam(1, 1) = 691.04f; fr.K_cam(1, 2) = 251.70f; fr.K_cam(2, 2) = 1.f;
+            const double aa[3] = {0.05 * c, -0.08 * c, 0.02 * c}, t[3] = {0.4 * c, -0.1 * c, 0.05 * c};
+            double R[9]; angle_axis_to_rotation(aa, R);
+            for (int p = 0; p < NP; ++p) {
+                if ((p + c) % 5 == 0) continue;  // not every camera sees every point
+                const double *x = &X[size_t(3 * p)];
+                double pc[3]; for (int r = 0; r < 3; ++r) pc[r] = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2] + t[r];
+                KeyPoint kp; kp.pt.x = float(pc[0] / pc[2] * 689.87 + 380.17 + 0.4 * g(rng)); kp.pt.y = float(pc[1] / pc[2] * 691.04 + 251.70 + 0.4 * g(rng));
+                fr.keypoints.push_back(kp); fr.unique_pixel_ids.push_back(1000 + p); fr.unique_pixel_has_match.push_back(c != 0 || p % 2 == 0);
+            }
+            const double aan[3] = {aa[0] + 0.01 * g(rng), aa[1] + 0.01 * g(rng), aa[2] + 0.01 * g(rng)};
+            angle_axis_to_rotation(aan, R);
+            for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) fr.pose_cam(r, k) = float(R[3 * r + k]); fr.pose_cam(r, 3) = float(t[r] + 0.03 * g(rng)); }
+            frames.push_back(fr);
+        }
+        BundleAdjustment ba;
+        ba.options_.max_num_iterations = 6;
+        std::vector<frame_t> frames0 = frames; pointcloud_sparse_t cloud0 = cloud;
+        CHECK(ba.doSFMBA(frames, process, cloud));
+        CHECK(ba.num_cameras_ == NC && ba.num_observations_ > 2 * NC);
+        // same problem through the oracle from the packed start the host built
+        BundleAdjustment ref; ref.initBA(); ref.setBAProblem(frames0, process, cloud0, 0.0, -1);
+        std::vector<float> K4(size_t(4 * NC));
+        for (int c = 0; c < NC; ++c) { K4[size_t(4 * c)] = 689.87f; K4[size_t(4 * c + 1)] = 380.17f; K4[size_t(4 * c + 2)] = 691.04f; K4[size_t(4 * c + 3)] = 251.70f; }
+        esfm_ba_options opt; esfm_ba_options_default(&opt); opt.max_num_iterations = 6;
+        esfm_ba_summary rs;
+        CHECK(esfm_ref_ba_solve(NC, NP, ref.num_observations_, ref.camera_index_.data(), ref.point_index_.data(),
+                                reinterpret_cast<const float *>(ref.points_2d_.data()), K4.data(), ref.mutable_cameras(), ref.mutable_points(), &opt, &rs) == 0);
+        CHECK(ba.summary_.num_iterations == rs.num_iterations);
+        for (int i = 0; i <= rs.num_iterations; ++i)
+            CHECK(std::fabs(ba.summary_.iterations[i].cost - rs.iterations[i].cost) <= 1e-9 * std::fabs(rs.iterations[i].cost));
+        double worst = 0;
+        for (int i = 0; i < ba.num_parameters_; ++i) worst = std::max(worst, std::fabs(ba.parameters_[size_t(i)] - ref.parameters_[size_t(i)]));
+        CHECK(worst < 1e-6);
+        CHECK(frames[NC].pose_cam(0, 3) == frames0[NC].pose_cam(0, 3));   // unregistered frame untouched
+        for (int p = 0; p < NP; ++p) CHECK(std::fabs(cloud.points[size_t(p)].x - float(ref.parameters_[size_t(6 * NC + 3 * p)])) <= 1e-5f);
+        std::printf("doSFMBA: %d observations, %d LM iterations, cost %.6f -> %.6f, max |dparam| vs oracle %.2e\n", ba.num_observations_,
+                    ba.summary_.num_iterations, ba.summary_.initial_cost, ba.summary_.final_cost, worst);
+    }
+    std::printf("HOST PARITY OK\n");
+    return 0;
+}
