@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libesfm_hip.so")
+# ESFM_LIB: developer override to A/B an experimental build of the same ABI (never a CPU library)
+LIB_PATH = os.environ.get("ESFM_LIB") or os.path.join(_HERE, "libesfm_hip.so")
 
 ESFM_OK = 0
 ESFM_L2_F32 = 0

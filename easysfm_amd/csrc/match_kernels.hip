@@ -179,21 +179,68 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         }
     }
 
-    // running top-3 (approximate key s = |t|^2 - 2 q.t, code = 16*subtile + reg)
-    float v0 = INFINITY, v1 = INFINITY, v2 = INFINITY;
-    int c0 = -1, c1 = -1, c2 = -1;
+    // Running top-3, two levels.
+    //
+    // On gfx950 the f32-input MFMA runs at the f32 VECTOR rate and VALU work does NOT hide under it
+    // (measured: every VALU instruction next to v_mfma_f32_32x32x2_f32 adds ~3 cycles per SIMD), so
+    // the fold is budgeted in instructions per element.  Level 1 (per element, 4 VALU ops, no
+    // compares): the low 8 mantissa bits of s are replaced by an 8-bit position code
+    // (key = (s & ~0xFF) | code, one v_and_or_b32) and the three smallest keys of the current
+    // 512-row segment are kept with v_med3_f32 / v_med3_f32 / v_min -- as floats, the keys order like
+    // s truncated to 15 mantissa bits.  Level 2 (once per segment = 256 elements per lane): the three
+    // segment keys are decoded to (key, train row) and merged into the lane's master top-3 with the
+    // compare/select chain.  The truncation error (< 2^-14 |key|) is charged to the certificate.
+    constexpr float kBig = 3.0e38f;       // finite "empty slot" sentinel; padded train rows carry |t|^2 = kBig too
+    constexpr int kSegSub = 16;           // sub-tiles (32 rows) per segment -> 8-bit codes
+    float k0 = kBig, k1 = kBig, k2 = kBig;             // segment keys
+    float v0 = kBig, v1 = kBig, v2 = kBig;             // master keys
+    int c0 = -1, c1 = -1, c2 = -1;                     // master train rows
     float tmax = 0.f;  // max |t|^2 seen by this thread (threads < TT only)
+    const unsigned kmask = 0xFFFFFF00u;
+    auto fold = [&](float s, int code) {
+        const float key = __uint_as_float((__float_as_uint(s) & kmask) | (unsigned)code);
+        k2 = __builtin_amdgcn_fmed3f(k1, k2, key);
+        k1 = __builtin_amdgcn_fmed3f(k0, k1, key);
+        k0 = __builtin_amdgcn_fmed3f(k0, key, -kBig);   // min without the NaN-quieting v_max pair
+    };
+    auto master_insert = [&](float key, int seg_sub0) {
+        // decode: code = 16 * (sub-tile within segment) + accumulator register
+        const int code = (int)(__float_as_uint(key) & 0xFFu);
+        const int r = code & 15;
+        const int t = (seg_sub0 + (code >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool live = key < 1.0e38f;
+        const bool l2 = live && key < v2, l1 = live && key < v1, l0 = live && key < v0;
+        const int t2 = l2 ? t : c2;
+        const int t1 = l1 ? t : c1;
+        c2 = l1 ? c1 : t2;
+        c1 = l0 ? c0 : t1;
+        c0 = l0 ? t : c0;
+        const float n2 = l2 ? key : v2;
+        const float n1 = l1 ? key : v1;
+        v2 = l1 ? v1 : n2;
+        v1 = l0 ? v0 : n1;
+        v0 = l0 ? key : v0;
+    };
+    auto flush = [&](int seg_sub0) {
+        master_insert(k0, seg_sub0); master_insert(k1, seg_sub0); master_insert(k2, seg_sub0);
+        k0 = k1 = k2 = kBig;
+    };
 
     const int ntiles = (nt + TT - 1) / TT;
     float4 stage[STAGE];
-    float stage_n = INFINITY;
+    float stage_n = kBig;
+    // branch-free (clamped address + select)
     auto gload = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < STAGE; ++i) {
             const int s = tid + 256 * i, row = s / SLOTS, slot = s % SLOTS, t = tile * TT + row;
-            stage[i] = (t < nt) ? *reinterpret_cast<const float4 *>(T + (size_t)t * DIM + slot * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4 *>(T + (size_t)min(t, nt - 1) * DIM + slot * 4);
+            const bool ok = t < nt;
+            stage[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
-        if (tid < TT) { const int t = tile * TT + tid; stage_n = (t < nt) ? tn[t] : INFINITY; }
+        const int t = tile * TT + (tid & (TT - 1));
+        const float nv = tn[min(t, nt - 1)];
+        stage_n = (t < nt) ? nv : kBig;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -201,51 +248,54 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
             const int s = tid + 256 * i, row = s / SLOTS, slot = s % SLOTS;
             lds_tile[buf * TT * SLOTS + row * SLOTS + (slot ^ (row & 15))] = stage[i];
         }
-        if (tid < TT) { lds_norm[buf * TT + tid] = stage_n; if (stage_n < INFINITY) tmax = fmaxf(tmax, stage_n); }
+        if (tid < TT) { lds_norm[buf * TT + tid] = stage_n; if (stage_n < 1.0e38f) tmax = fmaxf(tmax, stage_n); }
     };
 
     if (ntiles > 0) { gload(0); lstore(0); }
     __syncthreads();
 
+    static_assert(TT == 64, "two 32-row sub-tiles per tile");
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) gload(tile + 1);  // in flight under the MFMAs below
+        gload(min(tile + 1, ntiles - 1));  // next tile in flight under the MFMAs below (last trip: harmless re-load)
+        floatx16 acc0, acc1;
 #pragma unroll
-        for (int sub = 0; sub < TT / 32; ++sub) {
-            floatx16 acc;
+        for (int g = 0; g < 4; ++g) {
+            const float4 n0 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + 8 * g + 4 * h]);
+            const float4 n1 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + 32 + 8 * g + 4 * h]);
+            acc0[4 * g + 0] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
+            acc1[4 * g + 0] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
+        }
+        float4 a0[NCH], a1[NCH];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 n4 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + sub * 32 + 8 * g + 4 * h]);
-                acc[4 * g + 0] = n4.x; acc[4 * g + 1] = n4.y; acc[4 * g + 2] = n4.z; acc[4 * g + 3] = n4.w;
-            }
-            const int row = sub * 32 + j;
-            float4 a[NCH];
+        for (int c = 0; c < NCH; ++c) {
+            a0[c] = lds_tile[buf * TT * SLOTS + j * SLOTS + ((h * NCH + c) ^ (j & 15))];
+            a1[c] = lds_tile[buf * TT * SLOTS + (32 + j) * SLOTS + ((h * NCH + c) ^ (j & 15))];   // (32+j)&15 == j&15
+        }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) a[c] = lds_tile[buf * TT * SLOTS + row * SLOTS + ((h * NCH + c) ^ (row & 15))];
+        for (int c = 0; c < NCH; ++c) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].x, breg[4 * c + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].x, breg[4 * c + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].y, breg[4 * c + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].y, breg[4 * c + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].z, breg[4 * c + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].z, breg[4 * c + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].w, breg[4 * c + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].w, breg[4 * c + 3], acc1, 0, 0, 0);
+        }
+        {
+            const int sub = 2 * tile;                 // global sub-tile index of acc0
+            const int cb = __builtin_amdgcn_readfirstlane((sub % kSegSub) * 16);   // code base inside the segment (SGPR)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, breg[4 * c + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, breg[4 * c + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, breg[4 * c + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, breg[4 * c + 3], acc, 0, 0, 0);
-            }
-            const int code_base = (tile * (TT / 32) + sub) * 16;
+            for (int r = 0; r < 16; ++r) fold(acc0[r], cb + r);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float s = acc[r];
-                const int code = code_base + r;
-                const bool l2 = s < v2, l1 = s < v1, l0 = s < v0;
-                c2 = l1 ? c1 : (l2 ? code : c2);
-                c1 = l0 ? c0 : (l1 ? code : c1);
-                c0 = l0 ? code : c0;
-                v2 = __builtin_amdgcn_fmed3f(v1, v2, s);
-                v1 = __builtin_amdgcn_fmed3f(v0, v1, s);
-                v0 = fminf(v0, s);
-            }
+            for (int r = 0; r < 16; ++r) fold(acc1[r], cb + 16 + r);
+            if ((sub + 2) % kSegSub == 0) flush(sub + 2 - kSegSub);
         }
         if (tile + 1 < ntiles) lstore(buf ^ 1);
         __syncthreads();
     }
+    if (ntiles > 0 && (2 * ntiles) % kSegSub != 0) flush((2 * ntiles / kSegSub) * kSegSub);
 
     // max |t|^2 over the train set (for the certificate's error bound)
     {
@@ -268,8 +318,7 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         for (int m = 0; m < 3; ++m) {
             ei[m] = -1; ed[m] = FLT_MAX; ed2[m] = 0.f;
             if (cc[m] >= 0 && qvalid) {
-                const int r = cc[m] & 15;
-                const int t = (cc[m] >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int t = cc[m];
                 const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
                 ei[m] = t; ed2[m] = d2; ed[m] = sqrt_rn_f32(d2);
             }
@@ -289,13 +338,14 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         const size_t o = 2 * ((size_t)pd.out_off + qrow);
         knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
         knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
-        // Certificate: |(|q|^2 + s(t)) - D(t)| <= eps for every train t, with
-        // eps = 2^-16 (|q|^2 + max|t|^2); the candidate set provably contains the two best iff
-        // |q|^2 + tau - eps exceeds the second best exact d^2 by more than sqrt's rounding can hide.
-        bool certified = !(tau < INFINITY);
+        // Certificate: |(|q|^2 + s(t)) - D(t)| <= 2^-16 (|q|^2 + max|t|^2) for every train t, and
+        // every train outside the candidates has key >= tau, hence s >= tau - 2^-14 |tau| (truncation);
+        // the candidate set provably contains the two best iff |q|^2 + tau - eps exceeds the second
+        // best exact d^2 by more than sqrt's rounding can hide.
+        bool certified = !(tau < 1.0e38f);   // an empty slot in either lane: every train row is a candidate
         if (!certified && b1.i >= 0) {
             const double qn = (double)norms[pd.q_row0 + qrow];
-            const double eps = (qn + (double)tmax) * (1.0 / 65536.0);
+            const double eps = (qn + (double)tmax) * (1.0 / 65536.0) + fabs((double)tau) * (1.0 / 16384.0);
             certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
         }
         if (!certified) {
