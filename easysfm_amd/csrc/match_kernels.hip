@@ -141,14 +141,14 @@ __global__ void l2_row_norms_kernel(const float *__restrict__ desc, int dim, lon
 // accumulator starts at |t|^2, so after DIM/2 MFMAs D[t][q] = |t|^2 - 2 q.t  (= d^2 - |q|^2) with
 // no epilogue arithmetic.  C/D layout: lane l, reg r -> train row (r&3)+8*(r>>2)+4*(l>>5), query
 // l&31, i.e. the 16 values in a lane belong to ONE query, so the running top-3 is lane-local.
-template <int DIM>
+template <int DIM, int TT>
 __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restrict__ desc, const float *__restrict__ norms,
                                                           const PairDesc *__restrict__ pairs, int n_pairs,
                                                           int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                           int32_t *__restrict__ flagged, int32_t *__restrict__ counters,
                                                           int flag_cap)
 {
-    constexpr int QB = 128, TT = 64, HALF = DIM / 2, NCH = HALF / 4, SLOTS = DIM / 4;
+    constexpr int QB = 128, HALF = DIM / 2, NCH = HALF / 4, SLOTS = DIM / 4;
     constexpr int STAGE = TT * SLOTS / 256;  // float4 per thread per tile
     static_assert(DIM % 8 == 0 && STAGE >= 1, "DIM");
 
@@ -196,9 +196,11 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
     float v0 = kBig, v1 = kBig, v2 = kBig;             // master keys
     int c0 = -1, c1 = -1, c2 = -1;                     // master train rows
     float tmax = 0.f;  // max |t|^2 seen by this thread (threads < TT only)
-    const unsigned kmask = 0xFFFFFF00u;
-    auto fold = [&](float s, int code) {
-        const float key = __uint_as_float((__float_as_uint(s) & kmask) | (unsigned)code);
+    unsigned kmask = 0xFFFFFF00u;
+    asm volatile("" : "+v"(kmask));   // keep the mask in a VGPR: v_and_or_b32 can then take the code as its one SGPR operand
+    auto fold = [&](float s, int code /* wave-uniform */) {
+        float key;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(s), "v"(kmask), "s"(code));
         k2 = __builtin_amdgcn_fmed3f(k1, k2, key);
         k1 = __builtin_amdgcn_fmed3f(k0, k1, key);
         k0 = __builtin_amdgcn_fmed3f(k0, key, -kBig);   // min without the NaN-quieting v_max pair
@@ -254,37 +256,43 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
     if (ntiles > 0) { gload(0); lstore(0); }
     __syncthreads();
 
-    static_assert(TT == 64, "two 32-row sub-tiles per tile");
+    static_assert(TT % 64 == 0 && TT <= 256, "a tile is a whole number of 64-row sub-tile pairs");
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         gload(min(tile + 1, ntiles - 1));  // next tile in flight under the MFMAs below (last trip: harmless re-load)
-        floatx16 acc0, acc1;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 n0 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + 8 * g + 4 * h]);
-            const float4 n1 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + 32 + 8 * g + 4 * h]);
-            acc0[4 * g + 0] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
-            acc1[4 * g + 0] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
-        }
-        float4 a0[NCH], a1[NCH];
+        for (int sp = 0; sp < TT / 64; ++sp) {
+            const int base = sp * 64;
+            floatx16 acc0, acc1;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            a0[c] = lds_tile[buf * TT * SLOTS + j * SLOTS + ((h * NCH + c) ^ (j & 15))];
-            a1[c] = lds_tile[buf * TT * SLOTS + (32 + j) * SLOTS + ((h * NCH + c) ^ (j & 15))];   // (32+j)&15 == j&15
-        }
+            for (int g = 0; g < 4; ++g) {
+                const float4 n0 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + base + 8 * g + 4 * h]);
+                const float4 n1 = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + base + 32 + 8 * g + 4 * h]);
+                acc0[4 * g + 0] = n0.x; acc0[4 * g + 1] = n0.y; acc0[4 * g + 2] = n0.z; acc0[4 * g + 3] = n0.w;
+                acc1[4 * g + 0] = n1.x; acc1[4 * g + 1] = n1.y; acc1[4 * g + 2] = n1.z; acc1[4 * g + 3] = n1.w;
+            }
+            float4 a0[NCH], a1[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].x, breg[4 * c + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].x, breg[4 * c + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].y, breg[4 * c + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].y, breg[4 * c + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].z, breg[4 * c + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].z, breg[4 * c + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].w, breg[4 * c + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].w, breg[4 * c + 3], acc1, 0, 0, 0);
-        }
-        {
-            const int sub = 2 * tile;                 // global sub-tile index of acc0
+            for (int c = 0; c < NCH; ++c) {   // (base + 32 + j) & 15 == j & 15
+                a0[c] = lds_tile[buf * TT * SLOTS + (base + j) * SLOTS + ((h * NCH + c) ^ (j & 15))];
+                a1[c] = lds_tile[buf * TT * SLOTS + (base + 32 + j) * SLOTS + ((h * NCH + c) ^ (j & 15))];
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].x, breg[4 * c + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].x, breg[4 * c + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].y, breg[4 * c + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].y, breg[4 * c + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].z, breg[4 * c + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].z, breg[4 * c + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c].w, breg[4 * c + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c].w, breg[4 * c + 3], acc1, 0, 0, 0);
+            }
+            // The fold reads the accumulators from inline asm, for which hipcc pads no hazards: an MFMA's
+            // result needs ~18 wait states (16-pass op) before a non-MFMA reader.  Routing both
+            // accumulators through this statement orders every fold after the last MFMA plus the pad.
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+            const int sub = tile * (TT / 32) + 2 * sp;  // global sub-tile index of acc0
             const int cb = __builtin_amdgcn_readfirstlane((sub % kSegSub) * 16);   // code base inside the segment (SGPR)
 #pragma unroll
             for (int r = 0; r < 16; ++r) fold(acc0[r], cb + r);
@@ -295,7 +303,10 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         if (tile + 1 < ntiles) lstore(buf ^ 1);
         __syncthreads();
     }
-    if (ntiles > 0 && (2 * ntiles) % kSegSub != 0) flush((2 * ntiles / kSegSub) * kSegSub);
+    {
+        const int nsub = ntiles * (TT / 32);
+        if (nsub % kSegSub != 0) flush((nsub / kSegSub) * kSegSub);
+    }
 
     // max |t|^2 over the train set (for the certificate's error bound)
     {
@@ -508,13 +519,16 @@ int launch_l2_knn_mfma(hipStream_t st, int dim, const float *desc, const float *
                        int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)
 {
     if (n_blocks <= 0) return ESFM_OK;
+    // train tile = 128 rows (one barrier per 128 MFMAs per wave); LDS = 2 x TT x DIM x 4 B + norms
     if (dim == 64) {
-        constexpr size_t lds = 2 * 64 * 16 * 16 + 2 * 64 * 4 + 16;
-        hipLaunchKernelGGL(l2_knn_mfma_kernel<64>, dim3(n_blocks), dim3(256), lds, st, desc, norms, pairs, n_pairs, knn_idx,
+        constexpr int TT = 128;
+        constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16;
+        hipLaunchKernelGGL((l2_knn_mfma_kernel<64, TT>), dim3(n_blocks), dim3(256), lds, st, desc, norms, pairs, n_pairs, knn_idx,
                            knn_dist, flagged, counters, flag_cap);
     } else if (dim == 128) {
-        constexpr size_t lds = 2 * 64 * 32 * 16 + 2 * 64 * 4 + 16;
-        hipLaunchKernelGGL(l2_knn_mfma_kernel<128>, dim3(n_blocks), dim3(256), lds, st, desc, norms, pairs, n_pairs, knn_idx,
+        constexpr int TT = 64;
+        constexpr size_t lds = 2 * TT * 32 * 16 + 2 * TT * 4 + 16;
+        hipLaunchKernelGGL((l2_knn_mfma_kernel<128, TT>), dim3(n_blocks), dim3(256), lds, st, desc, norms, pairs, n_pairs, knn_idx,
                            knn_dist, flagged, counters, flag_cap);
     } else {
         set_error("l2 MFMA kernel is built for dim 64 and 128 only (got %d)", dim);
