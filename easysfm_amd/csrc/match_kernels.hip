@@ -231,14 +231,18 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
     const int ntiles = (nt + TT - 1) / TT;
     float4 stage[STAGE];
     float stage_n = kBig;
-    // branch-free (clamped address + select)
+    // Staging loads go through a buffer descriptor over the train set: rows past nt read as zeros in
+    // hardware, the per-thread byte offset is one loop-invariant VGPR and the tile offset is scalar, so
+    // a tile costs no address VALU (VALU does not overlap the f32 MFMA, every instruction counts).
+    const __amdgpu_buffer_rsrc_t trsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(T), 0, nt * DIM * 4, 0x00020000);
+    const int voff = (tid / SLOTS) * (DIM * 4) + (tid % SLOTS) * 16;   // row-in-pass * row bytes + slot * 16
     auto gload = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < STAGE; ++i) {
-            const int s = tid + 256 * i, row = s / SLOTS, slot = s % SLOTS, t = tile * TT + row;
-            const float4 v = *reinterpret_cast<const float4 *>(T + (size_t)min(t, nt - 1) * DIM + slot * 4);
-            const bool ok = t < nt;
-            stage[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            const int soff = (tile * TT + i * (256 / SLOTS)) * (DIM * 4);   // wave-uniform
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(trsrc, voff, soff, 0);
+            stage[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
         const int t = tile * TT + (tid & (TT - 1));
         const float nv = tn[min(t, nt - 1)];
