@@ -166,14 +166,18 @@ def main() -> int:
     flops_per_launch = 2.0 * float(len(pairs)) * N_FEATS * N_FEATS * DIM
     avg_kernel_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = flops_per_launch / avg_kernel_s / 1e12 if avg_kernel_s > 0 else 0.0
-    traffic = None
+    # HBM/fabric bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs of this command, gfx950 correction applied; see profiles/traffic.json)
+    traffic = traffic_ba = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("l2_knn_mfma_kernel_bytes_per_launch")
+            tj = json.load(open(tf))
+            traffic = tj.get("l2_knn_mfma_kernel_bytes_per_launch")
+            traffic_ba = tj.get("ba_linearize_kernel_bytes_per_launch")
         except Exception:
-            traffic = None
-    roofline = {"bound": "mfma", "kernel": "l2_knn_mfma_kernel<64>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+            traffic = traffic_ba = None
+    roofline = {"bound": "mfma", "kernel": "l2_knn_mfma_kernel<64,128>", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "avg_launch_ms": avg_kernel_s * 1e3, "launches": k_n,
                 "algorithmic_flops_per_launch": flops_per_launch,
@@ -250,7 +254,7 @@ def main() -> int:
                 "successful_steps": summ.num_successful_steps, "unsuccessful_steps": summ.num_unsuccessful_steps,
                 "roofline": {"bound": "hbm", "kernel": "ba_linearize_kernel", "achieved": sweep_bytes / lin_s / 1e9 if lin_s > 0 else 0.0,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0, "traffic": None,
+                             "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0, "traffic": traffic_ba,
                              "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes},
                 "schur_kernel_avg_ms": s_ms / max(s_n, 1), "solve_kernel_avg_ms": c_ms / max(c_n, 1),
             }

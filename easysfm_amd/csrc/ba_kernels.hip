@@ -788,18 +788,22 @@ __global__ void ba_points_delta_kernel(BADev d, int to_delta)
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 #define LAUNCH_CHECK() ESFM_HIP_TRY(hipGetLastError())
 
-int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling)
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx)
 {
     if (d.n_obs <= 0) { ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st)); return ESFM_OK; }
     const size_t priv_bytes = sizeof(double) * (8 + (size_t)d.n_cam * 27);
     const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
     const bool priv = priv_bytes <= 64 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
     if (priv) {
-        hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
+        {
+            KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone (not the slab reduction)
+            hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
+        }
         LAUNCH_CHECK();
         hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid);
     } else {
         ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
+        KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);
         hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(grid), dim3(kLinThreads), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0,
                            (double *)nullptr);
     }

@@ -58,7 +58,7 @@ struct BADev {
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
 inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
 
-int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling);
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx);
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian);
 int ba_jacobi_scaling(hipStream_t st, const BADev &d);
 int ba_camera_gradient(hipStream_t st, const BADev &d);
