@@ -157,7 +157,7 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3);
     A(&d.camacc, esfm::ba_camacc_doubles(n_cam)); A(&d.red, esfm::ba_red_doubles(n_cam));
     A(&d.y_c, nc6); A(&d.scal, (size_t)esfm::SC_COUNT);
-    A(&d.chol, (nc6 + 1) * (nc6 + 2) / 2 + 2);
+    A(&d.chol, std::max((nc6 + 1) * (nc6 + 2) / 2 + 2, esfm::ba_chol_large_doubles(n_cam)));
     d.slab_cap = esfm::ba_schur_slab_doubles(n_cam, ctx->num_cu);
     if (d.slab_cap) A(&d.slabs, d.slab_cap);
     if ((size_t)n_cam * 27 * sizeof(double) <= 60 * 1024) {

@@ -1,0 +1,221 @@
+// Dense solve of the reduced camera system when it does not fit one workgroup's LDS (n = 6 n_cam > ~185;
+// BASELINE config 5: 512 cameras, n = 3072).  Blocked right-looking Cholesky on 64 x 64 f64 tiles across the
+// whole chip, the right-hand side carried as an extra block row (forward substitution for free), then a
+// blocked backward substitution.  This is DENSE_SCHUR's factorisation step (reference cpp_code/src/ba.cpp:201,
+// Ceres' Eigen LLT [upstream]) for large camera counts.
+//
+//   chol_assemble_kernel   W = F'F + D_c^2 + S_schur (lower), rhs row = F'r + rhs_corr, identity padding
+//   chol_panel_kernel(k)   every workgroup factors the diagonal tile (k,k) redundantly in LDS, then solves its
+//                          own 64-row tile (i,k) against it; workgroup 0 stores L_kk
+//   chol_update_kernel(k)  trailing update C_ij -= A_ik A_jk' for k < j <= i (rhs block row included)
+//   chol_back_kernel(k)    y_k = L_kk^-T z_k (redundantly per workgroup), z_b -= L_kb' y_k for b < k
+#include "ba_kernels.hpp"
+
+namespace esfm {
+
+constexpr int CB = 64;          // tile edge
+constexpr int CLD = CB + 1;     // LDS leading dimension (f64, odd: conflict-free column access)
+
+__global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__restrict__ W, int ld, int nb, double radius,
+                                                            double min_diag, double max_diag)
+{
+    const int n = 6 * d.n_cam;
+    const long long rows = (long long)(nb + 1) * CB;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * ld) return;
+    const int i = (int)(e / ld), j = (int)(e % ld);
+    double v = 0.0;
+    if (i < n) {
+        if (j <= i) {
+            v = d.red[(size_t)i * n + j];
+            if (i / 6 == j / 6) {
+                const int c = i / 6;
+                v += d.camacc[36 * (size_t)c + 6 * (i % 6) + (j % 6)];
+                if (i == j) v += fmin(fmax(d.camacc[36 * (size_t)c + 7 * (i % 6)], min_diag), max_diag) / radius;
+            }
+        }
+    } else if (i < nb * CB) {
+        v = (i == j) ? 1.0 : 0.0;  // padding rows: identity
+    } else if (i == nb * CB) {
+        v = (j < n) ? d.camacc[36 * (size_t)d.n_cam + j] + d.red[(size_t)n * n + j] : 0.0;  // rhs row
+    }
+    W[(size_t)i * ld + j] = v;
+}
+
+// In-LDS Cholesky of a 64 x 64 tile (lower), 256 threads.  Returns false through *fail on a non-positive pivot.
+__device__ __forceinline__ void factor_tile_lds(double *L, volatile int *fail)
+{
+    const int tid = threadIdx.x;
+    for (int j = 0; j < CB; ++j) {
+        __syncthreads();
+        const double piv = L[j * CLD + j];
+        if (!(piv > 0.0) || !isfinite(piv)) { if (tid == 0) *fail = 1; }
+        const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
+        __syncthreads();
+        // scale column j (rows >= j)
+        if (tid < CB && tid >= j) L[tid * CLD + j] = (tid == j) ? piv * rinv : L[tid * CLD + j] * rinv;
+        __syncthreads();
+        // rank-1 update of the trailing lower triangle: (r, c), j < c <= r
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e / CB, c = e % CB;
+            if (c > j && c <= r) L[r * CLD + c] -= L[r * CLD + j] * L[c * CLD + j];
+        }
+    }
+    __syncthreads();
+}
+
+// Ldiag: factored diagonal tiles, kept OUT of W: other workgroups of the same launch still read the unfactored (k,k) tile
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, int nb, int k,
+                                                         double *__restrict__ scal)
+{
+    __shared__ double Lkk[CB * CLD];
+    __shared__ double A[CB * CLD];
+    __shared__ int fail;
+    const int tid = threadIdx.x;
+    const int bi = k + blockIdx.x;  // block row handled by this workgroup (k .. nb, nb = rhs block)
+    if (tid == 0) fail = 0;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        Lkk[r * CLD + c] = (c <= r) ? W[(size_t)(k * CB + r) * ld + k * CB + c] : 0.0;
+    }
+    factor_tile_lds(Lkk, &fail);
+    if (bi == k) {
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e / CB, c = e % CB;
+            Ldiag[(size_t)k * CB * CB + e] = (c <= r) ? Lkk[r * CLD + c] : 0.0;
+        }
+        if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
+        return;
+    }
+    // X L_kk' = A_ik : row r of X by forward substitution, 4 lanes per row share each dot product
+    for (int e = tid; e < CB * CB; e += 256) A[(e / CB) * CLD + (e % CB)] = W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)];
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;
+    volatile double *x = A + r * CLD;   // written by the row's lane 0, read by its 3 partners: no register caching
+    for (int c = 0; c < CB; ++c) {
+        double s = 0.0;
+        for (int c1 = q; c1 < c; c1 += 4) s += x[c1] * Lkk[c * CLD + c1];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q == 0) x[c] = (x[c] - s) / Lkk[c * CLD + c];
+        // the 4 lanes of a row sit in one wave; LDS ops of a wave execute in order, so the next c sees x[c]
+    }
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += 256) W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)] = A[(e / CB) * CLD + (e % CB)];
+}
+
+// C_ij -= A_ik A_jk'  for the tiles k < j <= i <= nb (j <= nb-1).  256 threads, 4 x 4 outputs per thread.
+__global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W, int ld, int nb, int k)
+{
+    __shared__ double Ai[CB * CLD];
+    __shared__ double Aj[CB * CLD];
+    // linear tile id -> (i, j): tiles of block row i (k+1 .. nb) are j = k+1 .. min(i, nb-1)
+    const int m = nb - k - 1;  // square trailing block rows
+    int t = blockIdx.x, i, j;
+    const int tri = m * (m + 1) / 2;
+    if (t < tri) {
+        int ri = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
+        while (ri * (ri + 1) / 2 > t) --ri;
+        i = k + 1 + ri; j = k + 1 + (t - ri * (ri + 1) / 2);
+    } else {
+        i = nb; j = k + 1 + (t - tri);
+    }
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        Ai[r * CLD + c] = W[(size_t)(i * CB + r) * ld + k * CB + c];
+        Aj[r * CLD + c] = W[(size_t)(j * CB + r) * ld + k * CB + c];
+    }
+    __syncthreads();
+    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+    double acc[4][4] = {{0}};
+    for (int kk = 0; kk < CB; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = Ai[(tr + u) * CLD + kk]; b[u] = Aj[(tc + u) * CLD + kk]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = tr + u, c = tc + v;
+            if (i != j || c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] -= acc[u][v];
+        }
+}
+
+// Backward substitution step k: z = rhs row (row nb*CB of W).  Every workgroup solves L_kk' y_k = z_k (one wave),
+// workgroup b < k then applies z_b -= L_kb' y_k; workgroup k stores y_k.
+__global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, const double *__restrict__ Ldiag, int ld, int nb, int k)
+{
+    __shared__ double Lkk[CB * CLD];
+    __shared__ volatile double y[CB];
+    const int tid = threadIdx.x;
+    double *z = W + (size_t)nb * CB * ld;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        Lkk[r * CLD + c] = Ldiag[(size_t)k * CB * CB + e];
+    }
+    if (tid < CB) y[tid] = z[k * CB + tid];
+    __syncthreads();
+    if (tid < CB) {  // one wave; lane = row index
+        for (int c = CB - 1; c >= 0; --c) {
+            const double yc = y[c] / Lkk[c * CLD + c];
+            if (tid == c) y[c] = yc;
+            if (tid < c) y[tid] -= Lkk[c * CLD + tid] * yc;
+        }
+    }
+    __syncthreads();
+    const int b = blockIdx.x;
+    if (b == k) { if (tid < CB) z[k * CB + tid] = y[tid]; return; }
+    // z_b[t] -= sum_r L[k*CB + r][b*CB + t] * y[r]; 4 row-groups per column, reduced through LDS
+    __shared__ double part[4][CB];
+    const int t = tid & 63, g = tid >> 6;
+    double s = 0.0;
+    for (int r = g; r < CB; r += 4) s += W[(size_t)(k * CB + r) * ld + b * CB + t] * y[r];
+    part[g][t] = s;
+    __syncthreads();
+    if (tid < CB) z[b * CB + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
+
+__global__ void chol_extract_kernel(BADev d, const double *__restrict__ W, int ld, int nb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 6 * d.n_cam;
+    if (i >= n) return;
+    const bool fail = d.scal[SC_CHOL_FAIL] != 0.0;
+    d.y_c[i] = fail ? 0.0 : W[(size_t)nb * CB * ld + i];
+}
+
+size_t ba_chol_large_doubles(int n_cam)
+{
+    const int n = 6 * n_cam, nb = (n + CB - 1) / CB;
+    return (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * CB * CB;
+}
+
+int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
+{
+    const int n = 6 * d.n_cam, nb = (n + CB - 1) / CB, ld = nb * CB;
+    double *W = d.chol;
+    double *Ldiag = W + (size_t)(nb + 1) * CB * ld;
+    const long long tot = (long long)(nb + 1) * CB * ld;
+    hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag);
+    ESFM_HIP_TRY(hipGetLastError());
+    for (int k = 0; k < nb; ++k) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(nb - k + 1), dim3(256), 0, st, W, Ldiag, ld, nb, k, d.scal);
+        const int m = nb - k - 1;
+        const int tiles = m * (m + 1) / 2 + m;
+        if (tiles > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tiles), dim3(256), 0, st, W, ld, nb, k);
+    }
+    ESFM_HIP_TRY(hipGetLastError());
+    for (int k = nb - 1; k >= 0; --k) hipLaunchKernelGGL(chol_back_kernel, dim3(k + 1), dim3(256), 0, st, W, Ldiag, ld, nb, k);
+    hipLaunchKernelGGL(chol_extract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, W, ld, nb);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+}  // namespace esfm

@@ -868,7 +868,7 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(ba_chol_solve_kernel<true>, dim3(1), dim3(kCholThreads), bytes, st, d, radius, min_diag, max_diag);
     } else {
-        hipLaunchKernelGGL(ba_chol_solve_kernel<false>, dim3(1), dim3(kCholThreads), sizeof(double) * (size_t)(n + 2), st, d, radius, min_diag, max_diag);
+        return ba_solve_reduced_large(st, d, radius, min_diag, max_diag);
     }
     LAUNCH_CHECK();
     return ESFM_OK;

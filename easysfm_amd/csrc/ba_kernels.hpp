@@ -70,6 +70,10 @@ inline size_t ba_schur_slab_doubles(int n_cam, int num_cu)
     return per * sizeof(double) <= 156 * 1024 ? per * (size_t)num_cu : 0;
 }
 int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
+// multi-workgroup blocked Cholesky for systems beyond one workgroup's LDS (ba_chol_large.hip); d.chol must hold
+// ba_chol_large_doubles(n_cam) doubles
+int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
+size_t ba_chol_large_doubles(int n_cam);
 int ba_camera_step(hipStream_t st, const BADev &d);
 int ba_backsub(hipStream_t st, const BADev &d);
 int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot);
