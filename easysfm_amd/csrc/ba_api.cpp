@@ -6,6 +6,7 @@
 // back a handful of scalars per iteration and takes the accept/reject decision.
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cfloat>
 #include <vector>
@@ -160,9 +161,31 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     A(&d.chol, std::max((nc6 + 1) * (nc6 + 2) / 2 + 2, esfm::ba_chol_large_doubles(n_cam)));
     d.slab_cap = esfm::ba_schur_slab_doubles(n_cam, ctx->num_cu);
     if (d.slab_cap) A(&d.slabs, d.slab_cap);
-    if ((size_t)n_cam * 27 * sizeof(double) <= 60 * 1024) {
+    if ((size_t)n_cam * 27 * sizeof(double) <= 149 * 1024) {
         d.lin_slab_cap = (size_t)n_cam * 27 * 2 * (size_t)ctx->num_cu;
         A(&d.lin_slabs, d.lin_slab_cap);
+    }
+    // Windowed Schur for large camera counts: order points by their lowest camera, cut the observation stream into
+    // ~2 chunks per CU.  (Structure only; built once per problem.)
+    std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0;
+    if (d.slab_cap == 0 && n_obs > 0) {
+        std::vector<int32_t> min_cam((size_t)n_pt, INT32_MAX), perm;
+        for (int t = 0; t < n_obs; ++t) min_cam[(size_t)s_pt[(size_t)t]] = std::min(min_cam[(size_t)s_pt[(size_t)t]], s_cam[(size_t)t]);
+        perm.reserve((size_t)n_pt);
+        for (int p = 0; p < n_pt; ++p) if (pt_start[(size_t)p + 1] > pt_start[(size_t)p]) perm.push_back(p);
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return min_cam[(size_t)a] < min_cam[(size_t)b]; });
+        const int want_chunks = std::max(1, 2 * ctx->num_cu);
+        const int64_t per = std::max<int64_t>(1024, ((int64_t)n_obs + want_chunks - 1) / want_chunks);
+        slot_obs.reserve((size_t)n_obs);
+        int64_t in_chunk = 0;
+        for (int p : perm) {
+            if (chunk_slot.empty() || in_chunk >= per) { chunk_slot.push_back((int32_t)slot_obs.size()); chunk_cam0.push_back(min_cam[(size_t)p]); in_chunk = 0; }
+            for (int t = pt_start[(size_t)p]; t < pt_start[(size_t)p + 1]; ++t) slot_obs.push_back(t);
+            in_chunk += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+        }
+        chunk_slot.push_back((int32_t)slot_obs.size());
+        d.n_chunks = (int)chunk_cam0.size();
+        A(&d.slot_obs, slot_obs.size()); A(&d.chunk_slot, chunk_slot.size()); A(&d.chunk_cam0, chunk_cam0.size());
     }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     hipStream_t st = ctx->stream;
@@ -175,6 +198,11 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     up(d.obs_cam, s_cam.data(), sizeof(int32_t) * no); up(d.obs_pt, s_pt.data(), sizeof(int32_t) * no);
     up(d.obs_uv, s_uv.data(), sizeof(float) * 2 * no); up(d.pt_start, pt_start.data(), sizeof(int32_t) * ((size_t)n_pt + 1));
     up(d.K4, K4_per_cam, sizeof(float) * 4 * (size_t)n_cam);
+    if (d.n_chunks) {
+        up(d.slot_obs, slot_obs.data(), sizeof(int32_t) * slot_obs.size());
+        up(d.chunk_slot, chunk_slot.data(), sizeof(int32_t) * chunk_slot.size());
+        up(d.chunk_cam0, chunk_cam0.data(), sizeof(int32_t) * chunk_cam0.size());
+    }
     up(d.x_c, cams, sizeof(double) * nc6); up(d.x_p, pts, sizeof(double) * np3);
     if (rc == ESFM_OK && hipStreamSynchronize(st) != hipSuccess) { esfm::set_error("stream sync failed"); rc = ESFM_ERR_HIP; }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }

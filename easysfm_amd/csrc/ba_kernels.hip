@@ -485,6 +485,97 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
     (void)n;
 }
 
+// Large camera counts: the Schur matrix does not fit LDS, but a workgroup that walks points ordered by their
+// lowest camera only touches a narrow band of it.  Each workgroup owns one chunk of that point order and an
+// LDS window of kWinCams consecutive cameras starting at the chunk's lowest one: contributions whose two
+// cameras fall inside the window are accumulated with LDS f64 atomics, the few that do not (wide baselines,
+// ring wrap-around) go straight to global f64 atomics; the window is flushed once at the end.
+constexpr int kWinCams = 28;
+constexpr int kWinBlocks = kWinCams * (kWinCams + 1) / 2;
+
+__global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d)
+{
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // [kWinBlocks*36] blocks, then [6*kWinCams] rhs_corr
+    const int tid = threadIdx.x;
+    const int n = 6 * d.n_cam;
+    const int chunk = blockIdx.x;
+    const int s0 = d.chunk_slot[chunk], s1 = d.chunk_slot[chunk + 1];
+    const int cw = d.chunk_cam0[chunk];
+    constexpr int kWinDoubles = kWinBlocks * 36 + 6 * kWinCams;
+    for (int e = tid; e < kWinDoubles; e += 1024) sl[e] = 0.0;
+    __syncthreads();
+    double *srhs = sl + kWinBlocks * 36;
+    const size_t n_obs = d.n_obs;
+    for (int s = s0 + tid; s < s1; s += 1024) {
+        const int i = d.slot_obs[s];
+        const int p = d.obs_pt[i], ci = d.obs_cam[i];
+        double Jc[12], Jp[6];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n_obs + i];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Jp[a] = d.Jp[a * n_obs + i];
+        const double *Mi = d.Minv + 6 * (size_t)p;
+        const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
+        const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+        const int wi = ci - cw;
+        const bool in_i = wi >= 0 && wi < kWinCams;
+        double Y[18];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
+            const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
+            const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
+            const double rv = -(w0 * ag0 + w1 * ag1 + w2 * ag2);
+            if (in_i) atomicAdd(&srhs[6 * wi + a], rv); else atomicAdd(&d.red[(size_t)n * n + 6 * ci + a], rv);
+            Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
+            Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
+            Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+        }
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        for (int j = b; j < e; ++j) {
+            const int cj = d.obs_cam[j];
+            if (cj > ci) continue;
+            double Fj[12], Ej[6];
+#pragma unroll
+            for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
+            const int wj = cj - cw;
+            const bool in_w = in_i && wj >= 0;   // cj <= ci < cw + kWinCams
+            double *Sl = sl + (size_t)(wi * (wi + 1) / 2 + wj) * 36;
+            double *Sg = d.red + (size_t)(6 * ci) * n + 6 * cj;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) {
+                const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
+                const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
+                const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double v = -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2);
+                    if (in_w) atomicAdd(&Sl[a * 6 + c2], v); else atomicAdd(&Sg[(size_t)a * n + c2], v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush the window
+    for (int e = tid; e < kWinBlocks * 36; e += 1024) {
+        const double v = sl[e];
+        if (v == 0.0) continue;
+        const int blk = e / 36, r = e % 36;
+        int wi = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+        while ((wi + 1) * (wi + 2) / 2 <= blk) ++wi;
+        while (wi * (wi + 1) / 2 > blk) --wi;
+        const int wj = blk - wi * (wi + 1) / 2;
+        const int ci = cw + wi, cj = cw + wj;
+        if (ci < d.n_cam) atomicAdd(&d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6], v);
+    }
+    for (int e = tid; e < 6 * kWinCams; e += 1024) {
+        const double v = srhs[e];
+        if (v != 0.0 && cw + e / 6 < d.n_cam) atomicAdd(&d.red[(size_t)n * n + 6 * cw + e], v);
+    }
+}
+
 // Sum the per-workgroup slabs (fixed order) and scatter into red = S_schur (n x n) | rhs_corr (n).
 __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const double *__restrict__ slabs, int slab_doubles, int n_slabs)
 {
@@ -793,8 +884,10 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     if (d.n_obs <= 0) { ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st)); return ESFM_OK; }
     const size_t priv_bytes = sizeof(double) * (8 + (size_t)d.n_cam * 27);
     const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
-    const bool priv = priv_bytes <= 64 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
+    const bool priv = priv_bytes <= 150 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
     if (priv) {
+        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_linearize_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv_bytes));
         {
             KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone (not the slab reduction)
             hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
@@ -850,6 +943,14 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(1024), lds_bytes, st, d, slabs, slab_doubles);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs);
+        LAUNCH_CHECK();
+        return ESFM_OK;
+    }
+    if (d.n_chunks > 0 && d.slot_obs) {
+        constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * 36 + 6 * kWinCams);
+        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_window_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+        hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d);
         LAUNCH_CHECK();
         return ESFM_OK;
     }

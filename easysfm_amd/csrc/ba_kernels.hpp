@@ -51,6 +51,11 @@ struct BADev {
     double *chol = nullptr;  // [(n+1)(n+2)/2] packed-lower work matrix for large n
     double *slabs = nullptr; // per-workgroup Schur slabs (small n_cam only)
     size_t slab_cap = 0;
+    // windowed Schur (n_cam too large for the LDS-resident matrix): points ordered by lowest camera, cut in chunks
+    int n_chunks = 0;
+    int32_t *slot_obs = nullptr;    // [n_obs] observation indices in chunk order
+    int32_t *chunk_slot = nullptr;  // [n_chunks+1] first slot of each chunk
+    int32_t *chunk_cam0 = nullptr;  // [n_chunks] lowest camera of the chunk = window base
     double *lin_slabs = nullptr;  // per-workgroup F'F / F'r slabs of the Jacobian sweep (27 n_cam each)
     size_t lin_slab_cap = 0;
 };
