@@ -42,66 +42,97 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
     W[(size_t)i * ld + j] = v;
 }
 
-// In-LDS Cholesky of a 64 x 64 tile (lower), 256 threads.  Returns false through *fail on a non-positive pivot.
-__device__ __forceinline__ void factor_tile_lds(double *L, volatile int *fail)
+// In-LDS Cholesky of a 64 x 64 tile (lower), 256 threads, blocked by 8 columns (2 barriers + 1 per panel
+// instead of 3 per column): (A) all threads subtract the already-factored columns from the panel by dot
+// products, (B1) wave 0 factors the 8 x 8 diagonal block in registers with __shfl, (B2) the rows below solve
+// against it.  rd[] receives the reciprocal diagonal.  *fail is raised on a non-positive pivot.
+constexpr int FB = 8;
+// rows: CB for the diagonal tile alone, 2*CB when a panel tile is stacked below it (rows CB..2CB-1 then come out as
+// X = A L^-T, the triangular solve, at no extra barriers).
+__device__ __forceinline__ void factor_tile_lds(double *L, double *rd, volatile int *fail, int rows)
 {
-    const int tid = threadIdx.x;
-    for (int j = 0; j < CB; ++j) {
-        __syncthreads();
-        const double piv = L[j * CLD + j];
-        if (!(piv > 0.0) || !isfinite(piv)) { if (tid == 0) *fail = 1; }
-        const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
-        __syncthreads();
-        // scale column j (rows >= j)
-        if (tid < CB && tid >= j) L[tid * CLD + j] = (tid == j) ? piv * rinv : L[tid * CLD + j] * rinv;
-        __syncthreads();
-        // rank-1 update of the trailing lower triangle: (r, c), j < c <= r
-        for (int e = tid; e < CB * CB; e += 256) {
-            const int r = e / CB, c = e % CB;
-            if (c > j && c <= r) L[r * CLD + c] -= L[r * CLD + j] * L[c * CLD + j];
-        }
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads();
+    for (int j0 = 0; j0 < CB; j0 += FB) {
+        if (j0 > 0) {
+            for (int e = tid; e < (rows - j0) * FB; e += 256) {
+                const int i = j0 + e / FB, col = j0 + e % FB;
+                if (col > i) continue;
+                const double *Li = L + i * CLD, *Lc = L + col * CLD;
+                double s0 = 0.0, s1 = 0.0;
+                for (int k = 0; k < j0; k += 2) { s0 += Li[k] * Lc[k]; s1 += Li[k + 1] * Lc[k + 1]; }   // j0 is a multiple of 8
+                L[i * CLD + col] -= s0 + s1;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int r = lane;
+            double a[FB];
+#pragma unroll
+            for (int c = 0; c < FB; ++c) a[c] = (r < FB && c <= r) ? L[(j0 + r) * CLD + j0 + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < FB; ++c) {
+                const double piv = __shfl(a[c], c);
+                if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *fail = 1; }
+                const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
+                a[c] = (r == c) ? piv * rinv : a[c] * rinv;
+                if (lane == c) rd[j0 + c] = rinv;
+#pragma unroll
+                for (int c2 = c + 1; c2 < FB; ++c2) {
+                    const double l2 = __shfl(a[c], c2);
+                    if (r >= c2) a[c2] -= a[c] * l2;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < FB; ++c)
+                if (r < FB && c <= r) L[(j0 + r) * CLD + j0 + c] = a[c];
+        }
+        __syncthreads();
+        for (int i = j0 + FB + tid; i < rows; i += 256) {
+            double *Li = L + i * CLD;
+            double x[FB];
+#pragma unroll
+            for (int c = 0; c < FB; ++c) x[c] = Li[j0 + c];
+#pragma unroll
+            for (int c = 0; c < FB; ++c) {
+                const double *Lc = L + (j0 + c) * CLD + j0;
+                double v = x[c];
+#pragma unroll
+                for (int c1 = 0; c1 < c; ++c1) v -= x[c1] * Lc[c1];
+                x[c] = v * rd[j0 + c];
+                Li[j0 + c] = x[c];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Ldiag: factored diagonal tiles, kept OUT of W: other workgroups of the same launch still read the unfactored (k,k) tile
 __global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, int nb, int k,
                                                          double *__restrict__ scal)
 {
-    __shared__ double Lkk[CB * CLD];
-    __shared__ double A[CB * CLD];
+    __shared__ double T[2 * CB * CLD];   // rows 0..63: diagonal tile (k,k); rows 64..127: this workgroup's tile (i,k)
+    __shared__ double rd[CB];
     __shared__ int fail;
     const int tid = threadIdx.x;
     const int bi = k + blockIdx.x;  // block row handled by this workgroup (k .. nb, nb = rhs block)
     if (tid == 0) fail = 0;
     for (int e = tid; e < CB * CB; e += 256) {
         const int r = e / CB, c = e % CB;
-        Lkk[r * CLD + c] = (c <= r) ? W[(size_t)(k * CB + r) * ld + k * CB + c] : 0.0;
+        T[r * CLD + c] = (c <= r) ? W[(size_t)(k * CB + r) * ld + k * CB + c] : 0.0;
+        if (bi != k) T[(CB + r) * CLD + c] = W[(size_t)(bi * CB + r) * ld + k * CB + c];
     }
-    factor_tile_lds(Lkk, &fail);
+    factor_tile_lds(T, rd, &fail, bi == k ? CB : 2 * CB);
     if (bi == k) {
         for (int e = tid; e < CB * CB; e += 256) {
             const int r = e / CB, c = e % CB;
-            Ldiag[(size_t)k * CB * CB + e] = (c <= r) ? Lkk[r * CLD + c] : 0.0;
+            Ldiag[(size_t)k * (CB * CB + CB) + e] = (c <= r) ? T[r * CLD + c] : 0.0;
         }
+        if (tid < CB) Ldiag[(size_t)k * (CB * CB + CB) + CB * CB + tid] = rd[tid];   // reciprocal diagonal for the back-substitution
         if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
         return;
     }
-    // X L_kk' = A_ik : row r of X by forward substitution, 4 lanes per row share each dot product
-    for (int e = tid; e < CB * CB; e += 256) A[(e / CB) * CLD + (e % CB)] = W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)];
-    __syncthreads();
-    const int r = tid >> 2, q = tid & 3;
-    volatile double *x = A + r * CLD;   // written by the row's lane 0, read by its 3 partners: no register caching
-    for (int c = 0; c < CB; ++c) {
-        double s = 0.0;
-        for (int c1 = q; c1 < c; c1 += 4) s += x[c1] * Lkk[c * CLD + c1];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (q == 0) x[c] = (x[c] - s) / Lkk[c * CLD + c];
-        // the 4 lanes of a row sit in one wave; LDS ops of a wave execute in order, so the next c sees x[c]
-    }
-    __syncthreads();
-    for (int e = tid; e < CB * CB; e += 256) W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)] = A[(e / CB) * CLD + (e % CB)];
+    for (int e = tid; e < CB * CB; e += 256) W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)] = T[(CB + e / CB) * CLD + (e % CB)];
 }
 
 // C_ij -= A_ik A_jk'  for the tiles k < j <= i <= nb (j <= nb-1).  256 threads, 4 x 4 outputs per thread.
@@ -153,21 +184,24 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W
 __global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, const double *__restrict__ Ldiag, int ld, int nb, int k)
 {
     __shared__ double Lkk[CB * CLD];
-    __shared__ volatile double y[CB];
+    __shared__ double y[CB];
+    __shared__ double rd[CB];
     const int tid = threadIdx.x;
     double *z = W + (size_t)nb * CB * ld;
     for (int e = tid; e < CB * CB; e += 256) {
         const int r = e / CB, c = e % CB;
-        Lkk[r * CLD + c] = Ldiag[(size_t)k * CB * CB + e];
+        Lkk[r * CLD + c] = Ldiag[(size_t)k * (CB * CB + CB) + e];
     }
-    if (tid < CB) y[tid] = z[k * CB + tid];
+    if (tid < CB) rd[tid] = Ldiag[(size_t)k * (CB * CB + CB) + CB * CB + tid];
     __syncthreads();
-    if (tid < CB) {  // one wave; lane = row index
+    if (tid < CB) {  // one wave; lane = row index, its y value lives in a register
+        double yl = z[k * CB + tid];
         for (int c = CB - 1; c >= 0; --c) {
-            const double yc = y[c] / Lkk[c * CLD + c];
-            if (tid == c) y[c] = yc;
-            if (tid < c) y[tid] -= Lkk[c * CLD + tid] * yc;
+            const double yc = __shfl(yl, c) * rd[c];
+            if (tid == c) yl = yc;
+            if (tid < c) yl -= Lkk[c * CLD + tid] * yc;
         }
+        y[tid] = yl;
     }
     __syncthreads();
     const int b = blockIdx.x;
@@ -194,7 +228,7 @@ __global__ void chol_extract_kernel(BADev d, const double *__restrict__ W, int l
 size_t ba_chol_large_doubles(int n_cam)
 {
     const int n = 6 * n_cam, nb = (n + CB - 1) / CB;
-    return (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * CB * CB;
+    return (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * (CB * CB + CB);
 }
 
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
