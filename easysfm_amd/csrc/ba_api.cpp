@@ -155,7 +155,7 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     A(&d.x_c, nc6); A(&d.x_p, np3); A(&d.cand_c, nc6); A(&d.cand_p, np3); A(&d.x0_p, np3);
     A(&d.Jc, 12 * no); A(&d.Jp, 6 * no); A(&d.res, 2 * no);
     A(&d.scale_c, nc6); A(&d.scale_p, np3);
-    A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3);
+    A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3); A(&d.gE, np3);
     A(&d.camacc, esfm::ba_camacc_doubles(n_cam)); A(&d.red, esfm::ba_red_doubles(n_cam));
     A(&d.y_c, nc6); A(&d.scal, (size_t)esfm::SC_COUNT);
     A(&d.chol, std::max((nc6 + 1) * (nc6 + 2) / 2 + 2, esfm::ba_chol_large_doubles(n_cam)));

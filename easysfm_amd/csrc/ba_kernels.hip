@@ -9,7 +9,7 @@
 //   ba_point_prep_kernel   per point: E'E, E'r, (E'E + D^2)^-1
 //   ba_schur_kernel        per observation: point-block Schur complement into the reduced system
 //   ba_chol_solve_kernel   dense Cholesky of the reduced camera system + both triangular solves
-//   ba_backsub_kernel      per point: back-substitution, candidate point, model cost change
+//   ba_backsub_*_kernel    back-substitution (observation-parallel, 2 passes), candidate point, model cost change
 //   ba_cost_kernel         robustified cost of a parameter vector (candidate evaluation)
 //
 // The LM control flow (accept/reject, radius) lives in ba_api.cpp.  DESIGN.md "Bundle adjustment".
@@ -754,56 +754,58 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
     if (threadIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = a; d.scal[SC_CAND_SQ_CAM] = b; }
 }
 
-// Back-substitution per point: y_p = M^-1 (E'r - sum_i E_i'F_i y_c), step = -y, candidate point,
-// and this point's share of model_cost_change = -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).
-__global__ __launch_bounds__(64) void ba_backsub_kernel(BADev d)
+// Back-substitution, observation-parallel so that every J access is a coalesced SoA stream:
+//   pass 1 (ba_backsub_accum_kernel)  gE[p] += E_k' (F_k y_c)           3 f64 atomics per observation
+//   pass 2 (ba_backsub_apply_kernel)  s_p = -M^-1 (E'r - gE[p]) (recomputed per observation, 12 cached loads),
+//                                     model_cost_change -= (J s).(r + J s / 2)  (trust_region_minimizer.cc),
+//                                     and the first observation of each point writes the candidate point.
+__global__ __launch_bounds__(256) void ba_backsub_accum_kernel(BADev d)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.n_obs) return;
+    const size_t n = d.n_obs;
+    const int c = d.obs_cam[k], p = d.obs_pt[k];
+    double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double yc = d.y_c[6 * c + a];
+        f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) atomicAdd(&d.gE[3 * (size_t)p + a], d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1);
+}
+
+__global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
 {
     __shared__ double red[8];
-    const int p = blockIdx.x * 64 + threadIdx.x;
+    const int k = blockIdx.x * 256 + threadIdx.x;
     double mc = 0.0, ssq = 0.0, csq = 0.0;
-    if (p < d.n_pt) {
-        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+    if (k < d.n_obs) {
         const size_t n = d.n_obs;
-        double xp[3] = {d.x_p[3 * (size_t)p], d.x_p[3 * (size_t)p + 1], d.x_p[3 * (size_t)p + 2]};
-        if (e > b) {
-            double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
-            for (int k = b; k < e; ++k) {
-                const int c = d.obs_cam[k];
-                double f0 = 0.0, f1 = 0.0;
+        const int c = d.obs_cam[k], p = d.obs_pt[k];
+        const double g0 = d.Etr[3 * (size_t)p] - d.gE[3 * (size_t)p], g1 = d.Etr[3 * (size_t)p + 1] - d.gE[3 * (size_t)p + 1],
+                     g2 = d.Etr[3 * (size_t)p + 2] - d.gE[3 * (size_t)p + 2];
+        const double *Mi = d.Minv + 6 * (size_t)p;
+        const double sp[3] = {-(Mi[0] * g0 + Mi[1] * g1 + Mi[2] * g2), -(Mi[1] * g0 + Mi[3] * g1 + Mi[4] * g2),
+                              -(Mi[2] * g0 + Mi[4] * g1 + Mi[5] * g2)};
+        double m0 = 0.0, m1 = 0.0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double yc = d.y_c[6 * c + a];
-                    f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
-                }
+        for (int a = 0; a < 6; ++a) {
+            const double sc = -d.y_c[6 * c + a];
+            m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
+        }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) g[a] -= d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
-            }
-            const double *Mi = d.Minv + 6 * (size_t)p;
-            const double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]),
-                                  -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
-                                  -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
-            for (int k = b; k < e; ++k) {
-                const int c = d.obs_cam[k];
-                double m0 = 0.0, m1 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double sc = -d.y_c[6 * c + a];
-                    m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
-                mc -= m0 * (d.res[k] + m0 / 2.0) + m1 * (d.res[n + k] + m1 / 2.0);
-            }
+        for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
+        mc = -(m0 * (d.res[k] + m0 / 2.0) + m1 * (d.res[n + k] + m1 / 2.0));
+        if (k == d.pt_start[p]) {   // one writer per point
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const double cnd = xp[a] + sp[a] * d.scale_p[3 * (size_t)p + a];
-                const double df = xp[a] - cnd;
+                const double xp = d.x_p[3 * (size_t)p + a];
+                const double cnd = xp + sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double df = xp - cnd;
                 ssq += df * df; csq += cnd * cnd;
                 d.cand_p[3 * (size_t)p + a] = cnd;
             }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) d.cand_p[3 * (size_t)p + a] = xp[a];
         }
     }
     const double s0 = block_sum(mc, red);
@@ -985,7 +987,13 @@ int ba_camera_step(hipStream_t st, const BADev &d)
 int ba_backsub(hipStream_t st, const BADev &d)
 {
     if (d.n_pt <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d);
+    // points without observations keep their value; observed ones are overwritten by pass 2
+    ESFM_HIP_TRY(hipMemcpyAsync(d.cand_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
+    ESFM_HIP_TRY(hipMemsetAsync(d.gE, 0, sizeof(double) * 3 * (size_t)d.n_pt, st));
+    if (d.n_obs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_backsub_accum_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ba_backsub_apply_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
     LAUNCH_CHECK();
     return ESFM_OK;
 }

@@ -40,6 +40,7 @@ struct BADev {
     double *Etr = nullptr;   // [3 n_pt]
     double *Minv = nullptr;  // [6 n_pt] (E'E + D_p^2)^-1
     double *Aig = nullptr;   // [3 n_pt] Minv * Etr
+    double *gE = nullptr;    // [3 n_pt] sum_k E_k' F_k y_c (back-substitution scratch)
     // per-camera normal-equation pieces, one contiguous SUM all-reduce buffer:
     //   camacc = FtF (36 per camera, full symmetric) | Ftr (6 per camera)
     double *camacc = nullptr;
