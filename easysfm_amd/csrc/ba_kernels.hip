@@ -754,6 +754,69 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
     if (threadIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = a; d.scal[SC_CAND_SQ_CAM] = b; }
 }
 
+// Back-substitution, point-parallel variant (one thread per point; fewer, fatter threads: faster below ~1M
+// observations, where the observation-parallel passes are launch/atomic bound): y_p = M^-1 (E'r - sum_i E_i'F_i y_c), step = -y, candidate point,
+// and this point's share of model_cost_change = -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).
+__global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
+{
+    __shared__ double red[8];
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    double mc = 0.0, ssq = 0.0, csq = 0.0;
+    if (p < d.n_pt) {
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        const size_t n = d.n_obs;
+        double xp[3] = {d.x_p[3 * (size_t)p], d.x_p[3 * (size_t)p + 1], d.x_p[3 * (size_t)p + 2]};
+        if (e > b) {
+            double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
+            for (int k = b; k < e; ++k) {
+                const int c = d.obs_cam[k];
+                double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double yc = d.y_c[6 * c + a];
+                    f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) g[a] -= d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
+            }
+            const double *Mi = d.Minv + 6 * (size_t)p;
+            const double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]),
+                                  -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
+                                  -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
+            for (int k = b; k < e; ++k) {
+                const int c = d.obs_cam[k];
+                double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const double sc = -d.y_c[6 * c + a];
+                    m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
+                mc -= m0 * (d.res[k] + m0 / 2.0) + m1 * (d.res[n + k] + m1 / 2.0);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double cnd = xp[a] + sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double df = xp[a] - cnd;
+                ssq += df * df; csq += cnd * cnd;
+                d.cand_p[3 * (size_t)p + a] = cnd;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d.cand_p[3 * (size_t)p + a] = xp[a];
+        }
+    }
+    const double s0 = block_sum(mc, red);
+    const double s1 = block_sum(ssq, red);
+    const double s2 = block_sum(csq, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&d.scal[SC_MODEL_CHANGE], s0);
+        atomicAdd(&d.scal[SC_STEP_SQ_PT], s1);
+        atomicAdd(&d.scal[SC_CAND_SQ_PT], s2);
+    }
+}
+
 // Back-substitution, observation-parallel so that every J access is a coalesced SoA stream:
 //   pass 1 (ba_backsub_accum_kernel)  gE[p] += E_k' (F_k y_c)           3 f64 atomics per observation
 //   pass 2 (ba_backsub_apply_kernel)  s_p = -M^-1 (E'r - gE[p]) (recomputed per observation, 12 cached loads),
@@ -987,6 +1050,11 @@ int ba_camera_step(hipStream_t st, const BADev &d)
 int ba_backsub(hipStream_t st, const BADev &d)
 {
     if (d.n_pt <= 0) return ESFM_OK;
+    if (d.n_obs < (1 << 20)) {
+        hipLaunchKernelGGL(ba_backsub_point_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d);
+        LAUNCH_CHECK();
+        return ESFM_OK;
+    }
     // points without observations keep their value; observed ones are overwritten by pass 2
     ESFM_HIP_TRY(hipMemcpyAsync(d.cand_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
     ESFM_HIP_TRY(hipMemsetAsync(d.gE, 0, sizeof(double) * 3 * (size_t)d.n_pt, st));
