@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void hamming_knn_kernel(const uint32_t *__rest
     const uint32_t *__restrict__ T = desc + (size_t)pd.t_row0 * NW;
     uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
     const int nt = pd.nt;
-#pragma unroll 4
+#pragma unroll 16
     for (int t = 0; t < nt; ++t) {
         const uint32_t *tp = T + (size_t)t * NW;  // wave-uniform address
         uint32_t d = 0;
