@@ -150,3 +150,22 @@ def ba_scene(n_cam: int, n_pt: int, obs_per_pt: int, radius: float = 10.0, exten
     return BAScene(cam_idx=np.ascontiguousarray(cam_idx, np.int32), pt_idx=np.ascontiguousarray(pt_idx, np.int32),
                    uv=np.ascontiguousarray(uv, np.float32), K4=np.ascontiguousarray(K4, np.float32),
                    cams0=cams0, pts0=pts0, cams_gt=cams, pts_gt=pts)
+
+
+def in_reference_frame(sc: BAScene, ref: int) -> BAScene:
+    """Re-express the scene in camera `ref`'s frame, so that camera `ref` sits at the origin with zero rotation --
+    how the reference's pipeline holds its reference frame (ba.cpp:155-162 bounds its pose to +-1e-10).
+    The start values are moved with the START pose of `ref`, the ground truth with its true pose."""
+    def move(cams, pts):
+        R0, t0 = aa_to_R(cams[ref, :3]), cams[ref, 3:]
+        out_c = np.zeros_like(cams)
+        for c in range(cams.shape[0]):
+            Rc = aa_to_R(cams[c, :3]) @ R0.T
+            out_c[c, :3] = _rodrigues_to_aa(Rc)
+            out_c[c, 3:] = cams[c, 3:] - Rc @ t0
+        out_c[ref] = 0.0
+        return out_c, pts @ R0.T + t0
+    cams0, pts0 = move(sc.cams0, sc.pts0)
+    cams_gt, pts_gt = move(sc.cams_gt, sc.pts_gt)
+    return BAScene(cam_idx=sc.cam_idx, pt_idx=sc.pt_idx, uv=sc.uv, K4=sc.K4, cams0=cams0, pts0=pts0,
+                   cams_gt=cams_gt, pts_gt=pts_gt)

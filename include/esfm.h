@@ -196,7 +196,7 @@ typedef struct esfm_ba_iteration {
     int32_t iteration;
     int32_t step_is_valid;
     int32_t step_is_successful;
-    int32_t reserved;
+    int32_t line_search_steps;   /* Armijo contractions this iteration (bounds-constrained problems only) */
     double cost;                 /* as Ceres logs it: candidate cost on a rejected step */
     double cost_change;
     double gradient_max_norm;

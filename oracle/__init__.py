@@ -47,7 +47,7 @@ class BAIteration(C.Structure):
         ("iteration", C.c_int32),
         ("step_is_valid", C.c_int32),
         ("step_is_successful", C.c_int32),
-        ("reserved", C.c_int32),
+        ("line_search_steps", C.c_int32),
         ("cost", C.c_double),
         ("cost_change", C.c_double),
         ("gradient_max_norm", C.c_double),
@@ -117,6 +117,16 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_ba_solve.restype = C.c_int
     lib.esfm_ref_ba_solve.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p,
                                       C.POINTER(BAOptions), C.POINTER(BASummary)]
+    lib.esfm_ref_ba_solve_ex.restype = C.c_int
+    lib.esfm_ref_ba_solve_ex.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, C.c_void_p, _f64p, _f64p,
+                                         C.c_void_p, C.c_double, C.c_int, C.c_double,
+                                         C.POINTER(BAOptions), C.POINTER(BASummary)]
+    lib.esfm_ref_ba_residual_jac_calib.restype = None
+    lib.esfm_ref_ba_residual_jac_calib.argtypes = [_f64p, _f64p, _f64p, _f32p, _f64p, _f64p, _f64p, _f64p]
+    lib.esfm_ref_ba_cost_calib.restype = C.c_double
+    lib.esfm_ref_ba_cost_calib.argtypes = [C.c_int, _i32p, _i32p, _f32p, _f64p, _f64p, _f64p, C.c_double]
+    lib.esfm_ref_ls_next_step.restype = C.c_double
+    lib.esfm_ref_ls_next_step.argtypes = [C.c_double] * 2 + [C.c_double] * 3 + [C.c_int] + [C.c_double] * 3 + [C.c_int] + [C.c_double] * 2
     lib.esfm_ref_ba_partial_reduced.restype = C.c_int
     lib.esfm_ref_ba_partial_reduced.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p,
                                                 C.c_double, C.c_double, _f64p, _f64p, C.c_int, _f64p, _f64p]
@@ -217,6 +227,54 @@ def ba_solve(cam_idx, pt_idx, uv, K4, cams, pts, options: Optional[BAOptions] = 
     if rc != 0:
         raise RuntimeError(f"esfm_ref_ba_solve failed with {rc}")
     return cams, pts, summ
+
+
+def ba_residual_jac_calib(cam, pt, calib, uv):
+    """Free-intrinsics functor (ba.h:170-222): r[2], Jc[2,6], Jp[2,3], Jk[2,4]."""
+    r = np.empty(2); Jc = np.empty(12); Jp = np.empty(6); Jk = np.empty(8)
+    load().esfm_ref_ba_residual_jac_calib(np.ascontiguousarray(cam, np.float64), np.ascontiguousarray(pt, np.float64),
+                                          np.ascontiguousarray(calib, np.float64), np.ascontiguousarray(uv, np.float32),
+                                          r, Jc, Jp, Jk)
+    return r, Jc.reshape(2, 6), Jp.reshape(2, 3), Jk.reshape(2, 4)
+
+
+def ba_cost_calib(cam_idx, pt_idx, uv, calib, cams, pts, cauchy_a=0.5) -> float:
+    return float(load().esfm_ref_ba_cost_calib(len(cam_idx), np.ascontiguousarray(cam_idx, np.int32),
+                                               np.ascontiguousarray(pt_idx, np.int32),
+                                               np.ascontiguousarray(uv, np.float32).reshape(-1),
+                                               np.ascontiguousarray(calib, np.float64).reshape(-1),
+                                               np.ascontiguousarray(cams, np.float64).reshape(-1),
+                                               np.ascontiguousarray(pts, np.float64).reshape(-1), float(cauchy_a)))
+
+
+def ba_solve_ex(cam_idx, pt_idx, uv, K4, cams, pts, calib=None, calib_tol: float = 0.0, ref_cam: int = -1,
+                ref_threshold: float = 1e-10, options: Optional[BAOptions] = None):
+    """solveBA with the reference's optional pieces: free shared intrinsics bounded to +-calib_tol (ba.cpp:167-196)
+    and/or a reference camera bounded to +-ref_threshold (ba.cpp:155-162).  Returns (cams, pts, calib, summary)."""
+    cams = np.array(cams, np.float64, copy=True, order="C").reshape(-1, 6)
+    pts = np.array(pts, np.float64, copy=True, order="C").reshape(-1, 3)
+    cal = None if calib is None else np.array(calib, np.float64, copy=True, order="C").reshape(4)
+    K = None if K4 is None else np.ascontiguousarray(K4, np.float32).reshape(-1)
+    summ = BASummary()
+    opt = options if options is not None else ba_default_options()
+    rc = load().esfm_ref_ba_solve_ex(cams.shape[0], pts.shape[0], len(cam_idx),
+                                     np.ascontiguousarray(cam_idx, np.int32), np.ascontiguousarray(pt_idx, np.int32),
+                                     np.ascontiguousarray(uv, np.float32).reshape(-1),
+                                     None if K is None else K.ctypes.data_as(C.c_void_p),
+                                     cams.reshape(-1), pts.reshape(-1),
+                                     None if cal is None else cal.ctypes.data_as(C.c_void_p), float(calib_tol),
+                                     int(ref_cam), float(ref_threshold), C.byref(opt), C.byref(summ))
+    if rc != 0:
+        raise RuntimeError(f"esfm_ref_ba_solve_ex failed with {rc}")
+    return cams, pts, cal, summ
+
+
+def ls_next_step(f0, g0, prev, cur, min_step, max_step) -> float:
+    """Next Armijo trial step; prev / cur = (x, value, gradient) or None when invalid."""
+    xp, fp, gp = prev if prev is not None else (0.0, 0.0, 0.0)
+    xc, fc, gc = cur if cur is not None else (0.0, 0.0, 0.0)
+    return float(load().esfm_ref_ls_next_step(f0, g0, xp, fp, gp, int(prev is not None), xc, fc, gc,
+                                              int(cur is not None), min_step, max_step))
 
 
 def ba_partial_reduced(n_cam, n_pt, cam_idx, pt_idx, uv, K4, cams, pts, cauchy_a, radius, diag_c, diag_p,

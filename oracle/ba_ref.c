@@ -13,8 +13,10 @@
  *     exactly as ceres::AutoDiffCostFunction<...,2,6,3> (ba.h:155-159) would,
  *     including ceres::AngleAxisRotatePoint's two branches [upstream rotation.h];
  *   - the problem set-up of BundleAdjustment::solveBA (cpp_code/src/ba.cpp:140-151):
- *     one residual block + CauchyLoss(0.5) per observation, no bounds when
- *     ba_calib_change_tolerance == 0 and no reference frame;
+ *     one residual block + CauchyLoss(0.5) per observation; with a reference frame its six
+ *     parameters are bounded to +-1e-10 (ba.cpp:155-162); with ba_calib_change_tolerance != 0 the
+ *     functor is ReprojectErrorTerm_updatecalib (ba.h:170-222) over a shared intrinsics block
+ *     bounded to its initial value +- tolerance (ba.cpp:167-196) -- esfm_ref_ba_solve_ex;
  *   - the solver options ba.cpp:201-204 (DENSE_SCHUR, 50 iterations) on top of
  *     Ceres defaults [upstream, from memory of ceres 1.14
  *     trust_region_minimizer.cc / levenberg_marquardt_strategy.cc /
@@ -52,8 +54,10 @@
 #include "../include/esfm.h"
 
 /* ------------------------------------------------------------------------- */
-/* forward-mode dual numbers with 9 partials (6 camera + 3 point), ceres::Jet */
-#define NJ 9
+/* forward-mode dual numbers with 13 partials (6 camera + 3 point + 4 intrinsics), ceres::Jet.
+ * The fixed-intrinsics functor uses the first 9 (AutoDiffCostFunction<...,2,6,3>, ba.h:155-159), the
+ * free-intrinsics functor all 13 (AutoDiffCostFunction<...,2,6,3,4>, ba.h:218-222). */
+#define NJ 13
 typedef struct { double a; double v[NJ]; } jet;
 
 static inline jet jconst(double a) { jet r; r.a = a; for (int i = 0; i < NJ; ++i) r.v[i] = 0.0; return r; }
@@ -92,29 +96,46 @@ static void jet_angle_axis_rotate(const jet aa[3], const jet pt[3], jet out[3])
     }
 }
 
-/* ReprojectErrorTerm_fixcalib::operator() (ba.h:113-153) on jets.
- * cam[6] = angle-axis, translation; K4 = fx, cx, fy, cy (float, ba.h:142-143);
- * uv = observed pixel (float, ba.h:145-146).  r[2], Jc[2][6], Jp[2][3]. */
-void esfm_ref_ba_residual_jac(const double *cam, const double *pt, const float *K4, const float *uv,
-                              double *r, double *Jc, double *Jp)
+/* ReprojectErrorTerm_fixcalib::operator() (ba.h:113-153) and ReprojectErrorTerm_updatecalib::operator()
+ * (ba.h:170-216) on jets: the two functors differ only in where fx, cx, fy, cy come from -- constants taken from
+ * the float calibration matrix (ba.h:142-143), or the shared 4-parameter block cam_calib = fx, cx, fy, cy
+ * (ba.h:199-202).  cam[6] = angle-axis, translation; uv = observed pixel (float, ba.h:145-146 / 208-209).
+ * r[2], Jc[2][6], Jp[2][3], Jk[2][4] (Jk only when calib != NULL). */
+static void residual_jac_any(const double *cam, const double *pt, const float *K4, const double *calib,
+                             const float *uv, double *r, double *Jc, double *Jp, double *Jk)
 {
-    jet aa[3], tr[3], X[3], p[3];
+    jet aa[3], tr[3], X[3], p[3], in[4];
     for (int k = 0; k < 3; ++k) { aa[k] = jvar(cam[k], k); tr[k] = jvar(cam[3 + k], 3 + k); X[k] = jvar(pt[k], 6 + k); }
+    for (int k = 0; k < 4; ++k) in[k] = calib ? jvar(calib[k], 9 + k) : jconst((double)K4[k]);
     jet_angle_axis_rotate(aa, X, p);
     for (int k = 0; k < 3; ++k) p[k] = jadd(p[k], tr[k]);
     jet x = jdiv(p[0], p[2]);
     jet y = jdiv(p[1], p[2]);
-    jet u = jadd(jmul(x, jconst((double)K4[0])), jconst((double)K4[1]));
-    jet v = jadd(jmul(y, jconst((double)K4[2])), jconst((double)K4[3]));
+    jet u = jadd(jmul(x, in[0]), in[1]);
+    jet v = jadd(jmul(y, in[2]), in[3]);
     jet r0 = jsub(jconst((double)uv[0]), u);
     jet r1 = jsub(jconst((double)uv[1]), v);
     r[0] = r0.a; r[1] = r1.a;
     if (Jc) for (int k = 0; k < 6; ++k) { Jc[k] = r0.v[k]; Jc[6 + k] = r1.v[k]; }
     if (Jp) for (int k = 0; k < 3; ++k) { Jp[k] = r0.v[6 + k]; Jp[3 + k] = r1.v[6 + k]; }
+    if (Jk && calib) for (int k = 0; k < 4; ++k) { Jk[k] = r0.v[9 + k]; Jk[4 + k] = r1.v[9 + k]; }
+}
+
+void esfm_ref_ba_residual_jac(const double *cam, const double *pt, const float *K4, const float *uv,
+                              double *r, double *Jc, double *Jp)
+{
+    residual_jac_any(cam, pt, K4, NULL, uv, r, Jc, Jp, NULL);
+}
+
+/* free-intrinsics functor (ba.h:170-222): calib = fx, cx, fy, cy doubles; Jk[2][4] */
+void esfm_ref_ba_residual_jac_calib(const double *cam, const double *pt, const double *calib, const float *uv,
+                                    double *r, double *Jc, double *Jp, double *Jk)
+{
+    residual_jac_any(cam, pt, NULL, calib, uv, r, Jc, Jp, Jk);
 }
 
 /* Residual only (candidate-cost evaluation), plain doubles, same formulas. */
-static void residual_only(const double *cam, const double *pt, const float *K4, const float *uv, double *r)
+static void residual_only(const double *cam, const double *pt, const double *in4, const float *uv, double *r)
 {
     double theta2 = cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2];
     double p[3];
@@ -130,8 +151,8 @@ static void residual_only(const double *cam, const double *pt, const float *K4, 
     }
     p[0] += cam[3]; p[1] += cam[4]; p[2] += cam[5];
     double x = p[0] / p[2], y = p[1] / p[2];
-    r[0] = (double)uv[0] - (x * (double)K4[0] + (double)K4[1]);
-    r[1] = (double)uv[1] - (y * (double)K4[2] + (double)K4[3]);
+    r[0] = (double)uv[0] - (x * in4[0] + in4[1]);
+    r[1] = (double)uv[1] - (y * in4[2] + in4[3]);
 }
 
 /* ceres::CauchyLoss::Evaluate [upstream loss_function.cc]; a <= 0: trivial loss. */
@@ -148,16 +169,18 @@ static inline void loss_eval(double a, double s, double rho[3])
 /* Robustified cost 1/2 sum rho(|r|^2) (ceres ResidualBlock::Evaluate). Returns
  * DBL_MAX when any residual is non-finite (Ceres: evaluation fails -> candidate
  * cost = max double, trust_region_minimizer.cc ComputeCandidatePointAndEvaluateCost). */
-double esfm_ref_ba_cost(int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
-                        const float *K4, const double *cams, const double *pts, double cauchy_a)
+static double cost_any(int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                       const float *K4, const double *calib, const double *cams, const double *pts, double cauchy_a)
 {
     double cost = 0.0; int bad = 0;
 #ifdef _OPENMP
 #pragma omp parallel for reduction(+ : cost) reduction(| : bad) schedule(static)
 #endif
     for (int k = 0; k < n_obs; ++k) {
-        double r[2], rho[3];
-        residual_only(cams + 6 * (size_t)cam_idx[k], pts + 3 * (size_t)pt_idx[k], K4 + 4 * (size_t)cam_idx[k], obs_uv + 2 * (size_t)k, r);
+        double r[2], rho[3], in4[4];
+        if (calib) { in4[0] = calib[0]; in4[1] = calib[1]; in4[2] = calib[2]; in4[3] = calib[3]; }
+        else { const float *K = K4 + 4 * (size_t)cam_idx[k]; in4[0] = (double)K[0]; in4[1] = (double)K[1]; in4[2] = (double)K[2]; in4[3] = (double)K[3]; }
+        residual_only(cams + 6 * (size_t)cam_idx[k], pts + 3 * (size_t)pt_idx[k], in4, obs_uv + 2 * (size_t)k, r);
         double s = r[0] * r[0] + r[1] * r[1];
         if (!isfinite(s)) { bad |= 1; continue; }
         loss_eval(cauchy_a, s, rho);
@@ -166,9 +189,25 @@ double esfm_ref_ba_cost(int n_obs, const int32_t *cam_idx, const int32_t *pt_idx
     return bad ? DBL_MAX : cost;
 }
 
+double esfm_ref_ba_cost(int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                        const float *K4, const double *cams, const double *pts, double cauchy_a)
+{
+    return cost_any(n_obs, cam_idx, pt_idx, obs_uv, K4, NULL, cams, pts, cauchy_a);
+}
+
+double esfm_ref_ba_cost_calib(int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                              const double *calib, const double *cams, const double *pts, double cauchy_a)
+{
+    return cost_any(n_obs, cam_idx, pt_idx, obs_uv, NULL, calib, cams, pts, cauchy_a);
+}
+
 /* ------------------------------------------------------------------------- */
+/* The unknowns are split as Ceres' Schur ordering splits them: e-blocks = points, f-blocks = cameras followed,
+ * when the intrinsics are free (ba.cpp:169-196), by the shared 4-parameter block fx, cx, fy, cy.  All "f" arrays
+ * below have nf = 6 n_cam + 4 has_calib entries: camera c at [6c, 6c+6), intrinsics at [6 n_cam, 6 n_cam + 4). */
 typedef struct {
     int n_cam, n_pt, n_obs;
+    int has_calib, nf;
     const int32_t *cam_idx, *pt_idx; const float *uv, *K4;
     /* observations grouped by point (CSR) */
     int32_t *pt_start; /* n_pt+1 */
@@ -177,54 +216,76 @@ typedef struct {
     /* linearisation at x (corrected by the loss, columns scaled) */
     double *Jc;  /* 12 per obs, [2][6] */
     double *Jp;  /* 6 per obs, [2][3]  */
+    double *Jk;  /* 8 per obs, [2][4]; intrinsics columns (has_calib only) */
     double *r;   /* 2 per obs */
-    double *scale_c, *scale_p; /* Jacobi scaling, 6*n_cam, 3*n_pt */
+    double *scale_c, *scale_p; /* Jacobi scaling, nf, 3*n_pt */
     double *diag_c, *diag_p;   /* LM diagonal (squared column norms, clamped) */
+    double *grad_c, *grad_p;   /* gradient J'r of the UNSCALED problem at the last linearisation */
 } ba_state;
 
-/* Evaluate residuals + Jacobians at (cams, pts), apply the corrector
+/* ParameterBlock::Plus tail [upstream parameter_block.h]: project onto the box, lower bound first. */
+static inline double clamp_box(double v, const double *lo, const double *up, size_t i)
+{
+    if (lo) v = fmax(v, lo[i]);
+    if (up) v = fmin(v, up[i]);
+    return v;
+}
+
+/* Evaluate residuals + Jacobians at (xf, pts), apply the corrector
  * (corrector.cc: rho''<=0 -> scale both by sqrt(rho')), return cost; gradient
  * max-norm of the UNSCALED problem in *gmax (trust_region_minimizer.cc
- * EvaluateGradientAndJacobian: gradient before column scaling). */
-static double linearize(ba_state *S, const double *cams, const double *pts, double cauchy_a,
-                        int apply_scaling, double *gmax_out, int *ok)
+ * EvaluateGradientAndJacobian: gradient before column scaling; with bounds the
+ * norm of x - Plus(x, -gradient), i.e. the projected gradient step). */
+static double linearize(ba_state *S, const double *xf, const double *pts, double cauchy_a,
+                        int apply_scaling, const double *lo, const double *up, double *gmax_out, int *ok)
 {
     double cost = 0.0; int bad = 0;
-    double *gc = (double *)calloc((size_t)6 * S->n_cam, sizeof(double));
-    double *gp = (double *)calloc((size_t)3 * S->n_pt, sizeof(double));
+    const double *calib = S->has_calib ? xf + 6 * (size_t)S->n_cam : NULL;
+    double *gc = S->grad_c, *gp = S->grad_p;
+    memset(gc, 0, sizeof(double) * (size_t)S->nf);
+    memset(gp, 0, sizeof(double) * 3 * (size_t)S->n_pt);
 #ifdef _OPENMP
 #pragma omp parallel for reduction(+ : cost) reduction(| : bad) schedule(static)
 #endif
     for (int k = 0; k < S->n_obs; ++k) {
-        double r[2], Jc[12], Jp[6], rho[3];
+        double r[2], Jc[12], Jp[6], Jk[8], rho[3];
         int c = S->cam_idx[k], p = S->pt_idx[k];
-        esfm_ref_ba_residual_jac(cams + 6 * (size_t)c, pts + 3 * (size_t)p, S->K4 + 4 * (size_t)c, S->uv + 2 * (size_t)k, r, Jc, Jp);
+        residual_jac_any(xf + 6 * (size_t)c, pts + 3 * (size_t)p, S->K4 ? S->K4 + 4 * (size_t)c : NULL, calib,
+                         S->uv + 2 * (size_t)k, r, Jc, Jp, Jk);
         double s = r[0] * r[0] + r[1] * r[1];
         int fin = isfinite(s);
         for (int i = 0; i < 12; ++i) fin &= isfinite(Jc[i]);
         for (int i = 0; i < 6; ++i) fin &= isfinite(Jp[i]);
+        if (calib) for (int i = 0; i < 8; ++i) fin &= isfinite(Jk[i]);
         if (!fin) { bad |= 1; continue; }
         loss_eval(cauchy_a, s, rho);
         cost += 0.5 * rho[0];
         double sq = sqrt(rho[1]);
         for (int i = 0; i < 12; ++i) S->Jc[12 * (size_t)k + i] = Jc[i] * sq;
         for (int i = 0; i < 6; ++i) S->Jp[6 * (size_t)k + i] = Jp[i] * sq;
+        if (calib) for (int i = 0; i < 8; ++i) S->Jk[8 * (size_t)k + i] = Jk[i] * sq;
         S->r[2 * (size_t)k] = r[0] * sq; S->r[2 * (size_t)k + 1] = r[1] * sq;
     }
     *ok = !bad;
-    if (bad) { free(gc); free(gp); return DBL_MAX; }
+    if (bad) return DBL_MAX;
     /* gradient g = J' r (serial: deterministic order) */
     for (int k = 0; k < S->n_obs; ++k) {
         const double *Jc = S->Jc + 12 * (size_t)k, *Jp = S->Jp + 6 * (size_t)k, *r = S->r + 2 * (size_t)k;
         int c = S->cam_idx[k], p = S->pt_idx[k];
         for (int i = 0; i < 6; ++i) gc[6 * (size_t)c + i] += Jc[i] * r[0] + Jc[6 + i] * r[1];
         for (int i = 0; i < 3; ++i) gp[3 * (size_t)p + i] += Jp[i] * r[0] + Jp[3 + i] * r[1];
+        if (calib) {
+            const double *Jk = S->Jk + 8 * (size_t)k;
+            for (int i = 0; i < 4; ++i) gc[6 * (size_t)S->n_cam + i] += Jk[i] * r[0] + Jk[4 + i] * r[1];
+        }
     }
     double gmax = 0.0;
-    for (size_t i = 0; i < (size_t)6 * S->n_cam; ++i) if (fabs(gc[i]) > gmax) gmax = fabs(gc[i]);
+    for (size_t i = 0; i < (size_t)S->nf; ++i) {
+        double a = (lo || up) ? fabs(xf[i] - clamp_box(xf[i] - gc[i], lo, up, i)) : fabs(gc[i]);
+        if (a > gmax) gmax = a;
+    }
     for (size_t i = 0; i < (size_t)3 * S->n_pt; ++i) if (fabs(gp[i]) > gmax) gmax = fabs(gp[i]);
     *gmax_out = gmax;
-    free(gc); free(gp);
     if (apply_scaling) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
@@ -234,6 +295,7 @@ static double linearize(ba_state *S, const double *cams, const double *pts, doub
             for (int row = 0; row < 2; ++row) {
                 for (int i = 0; i < 6; ++i) S->Jc[12 * (size_t)k + 6 * row + i] *= S->scale_c[6 * (size_t)c + i];
                 for (int i = 0; i < 3; ++i) S->Jp[6 * (size_t)k + 3 * row + i] *= S->scale_p[3 * (size_t)p + i];
+                if (calib) for (int i = 0; i < 4; ++i) S->Jk[8 * (size_t)k + 4 * row + i] *= S->scale_c[6 * (size_t)S->n_cam + i];
             }
         }
     }
@@ -243,13 +305,17 @@ static double linearize(ba_state *S, const double *cams, const double *pts, doub
 /* Squared column norms of the stored Jacobian. */
 static void column_sqnorms(const ba_state *S, double *nc, double *np)
 {
-    memset(nc, 0, sizeof(double) * 6 * (size_t)S->n_cam);
+    memset(nc, 0, sizeof(double) * (size_t)S->nf);
     memset(np, 0, sizeof(double) * 3 * (size_t)S->n_pt);
     for (int k = 0; k < S->n_obs; ++k) {
         const double *Jc = S->Jc + 12 * (size_t)k, *Jp = S->Jp + 6 * (size_t)k;
         int c = S->cam_idx[k], p = S->pt_idx[k];
         for (int i = 0; i < 6; ++i) nc[6 * (size_t)c + i] += Jc[i] * Jc[i] + Jc[6 + i] * Jc[6 + i];
         for (int i = 0; i < 3; ++i) np[3 * (size_t)p + i] += Jp[i] * Jp[i] + Jp[3 + i] * Jp[3 + i];
+        if (S->has_calib) {
+            const double *Jk = S->Jk + 8 * (size_t)k;
+            for (int i = 0; i < 4; ++i) nc[6 * (size_t)S->n_cam + i] += Jk[i] * Jk[i] + Jk[4 + i] * Jk[4 + i];
+        }
     }
 }
 
@@ -308,18 +374,32 @@ static int chol_solve(double *A, double *b, int n)
     return 1;
 }
 
+/* The f-block columns one observation touches: its camera's 6 and, with free intrinsics, the shared 4.
+ * h0/h1 = the two Jacobian rows restricted to those columns. */
+static inline int obs_fcols(const ba_state *S, int k, int cols[10], double h0[10], double h1[10])
+{
+    const double *Jc = S->Jc + 12 * (size_t)k;
+    const int c = S->cam_idx[k];
+    for (int a = 0; a < 6; ++a) { cols[a] = 6 * c + a; h0[a] = Jc[a]; h1[a] = Jc[6 + a]; }
+    if (!S->has_calib) return 6;
+    const double *Jk = S->Jk + 8 * (size_t)k;
+    for (int a = 0; a < 4; ++a) { cols[6 + a] = 6 * S->n_cam + a; h0[6 + a] = Jk[a]; h1[6 + a] = Jk[4 + a]; }
+    return 10;
+}
+
 /*
- * Reduced camera system of the damped normal equations (schur_eliminator_impl.h):
- *   S   = sum F'F + D_c^2 - sum_p W_p (E'E + D_p^2)^-1 W_p',  W_p = sum F_i'E_i
+ * Reduced f-block system of the damped normal equations (schur_eliminator_impl.h):
+ *   S   = sum F'F + D_f^2 - sum_p W_p (E'E + D_p^2)^-1 W_p',  W_p = sum F_i'E_i
  *   rhs = sum F'r - sum_p W_p (E'E + D_p^2)^-1 E'r
  * over the observations of this state only (a shard builds a partial system;
- * D_c^2 is added iff add_cam_diag).  S is (6 n_cam)^2 row-major, full symmetric.
+ * D_f^2 is added iff add_cam_diag).  S is nf x nf row-major, full symmetric.
+ * F_i is the observation's Jacobian over its f-block columns (camera, and the intrinsics when free).
  * EtEinv (9/pt) and Etr (3/pt) are kept for the back-substitution.
  */
 static void reduced_point(const ba_state *S, int p, double radius, double *Sm, double *rhs,
                           double *EtEinv, double *Etr, int *ok)
 {
-    const int n = 6 * S->n_cam;
+    const int n = S->nf;
     int b = S->pt_start[p], e = S->pt_start[p + 1];
     if (b == e) return;
     double A[9] = {0}, g[3] = {0};
@@ -339,32 +419,36 @@ static void reduced_point(const ba_state *S, int p, double radius, double *Sm, d
     double Aig[3];
     for (int i = 0; i < 3; ++i) Aig[i] = Ai[3 * i] * g[0] + Ai[3 * i + 1] * g[1] + Ai[3 * i + 2] * g[2];
     for (int t = b; t < e; ++t) {
-        int k = S->order[t], ci = S->cam_idx[k];
-        const double *Jc = S->Jc + 12 * (size_t)k, *Jp = S->Jp + 6 * (size_t)k, *r = S->r + 2 * (size_t)k;
-        /* W_i = F_i' E_i (6x3); F'F and F'r */
-        double W[18];
-        for (int a = 0; a < 6; ++a)
-            for (int j = 0; j < 3; ++j) W[3 * a + j] = Jc[a] * Jp[j] + Jc[6 + a] * Jp[3 + j];
-        for (int a = 0; a < 6; ++a) {
-            for (int c2 = 0; c2 < 6; ++c2)
-                Sm[(size_t)(6 * ci + a) * n + 6 * ci + c2] += Jc[a] * Jc[c2] + Jc[6 + a] * Jc[6 + c2];
-            rhs[6 * ci + a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
-            rhs[6 * ci + a] -= W[3 * a] * Aig[0] + W[3 * a + 1] * Aig[1] + W[3 * a + 2] * Aig[2];
+        int k = S->order[t];
+        const double *Jp = S->Jp + 6 * (size_t)k, *r = S->r + 2 * (size_t)k;
+        int ci[10]; double h0[10], h1[10];
+        const int m = obs_fcols(S, k, ci, h0, h1);
+        /* W_i = F_i' E_i (m x 3); F'F and F'r */
+        double W[30];
+        for (int a = 0; a < m; ++a)
+            for (int j = 0; j < 3; ++j) W[3 * a + j] = h0[a] * Jp[j] + h1[a] * Jp[3 + j];
+        for (int a = 0; a < m; ++a) {
+            for (int c2 = 0; c2 < m; ++c2)
+                Sm[(size_t)ci[a] * n + ci[c2]] += h0[a] * h0[c2] + h1[a] * h1[c2];
+            rhs[ci[a]] += h0[a] * r[0] + h1[a] * r[1];
+            rhs[ci[a]] -= W[3 * a] * Aig[0] + W[3 * a + 1] * Aig[1] + W[3 * a + 2] * Aig[2];
         }
-        /* Y = W_i Ai (6x3) */
-        double Y[18];
-        for (int a = 0; a < 6; ++a)
+        /* Y = W_i Ai (m x 3) */
+        double Y[30];
+        for (int a = 0; a < m; ++a)
             for (int j = 0; j < 3; ++j)
                 Y[3 * a + j] = W[3 * a] * Ai[j] + W[3 * a + 1] * Ai[3 + j] + W[3 * a + 2] * Ai[6 + j];
         for (int t2 = b; t2 < e; ++t2) {
-            int k2 = S->order[t2], cj = S->cam_idx[k2];
-            const double *Jc2 = S->Jc + 12 * (size_t)k2, *Jp2 = S->Jp + 6 * (size_t)k2;
-            double W2[18]; /* W_j[c2][m] */
-            for (int c2 = 0; c2 < 6; ++c2)
-                for (int m = 0; m < 3; ++m) W2[3 * c2 + m] = Jc2[c2] * Jp2[m] + Jc2[6 + c2] * Jp2[3 + m];
-            for (int a = 0; a < 6; ++a)
-                for (int c2 = 0; c2 < 6; ++c2)
-                    Sm[(size_t)(6 * ci + a) * n + 6 * cj + c2] -=
+            int k2 = S->order[t2];
+            const double *Jp2 = S->Jp + 6 * (size_t)k2;
+            int cj[10]; double g0[10], g1[10];
+            const int m2 = obs_fcols(S, k2, cj, g0, g1);
+            double W2[30]; /* W_j[c2][m] */
+            for (int c2 = 0; c2 < m2; ++c2)
+                for (int q = 0; q < 3; ++q) W2[3 * c2 + q] = g0[c2] * Jp2[q] + g1[c2] * Jp2[3 + q];
+            for (int a = 0; a < m; ++a)
+                for (int c2 = 0; c2 < m2; ++c2)
+                    Sm[(size_t)ci[a] * n + cj[c2]] -=
                         Y[3 * a] * W2[3 * c2] + Y[3 * a + 1] * W2[3 * c2 + 1] + Y[3 * a + 2] * W2[3 * c2 + 2];
         }
     }
@@ -373,7 +457,7 @@ static void reduced_point(const ba_state *S, int p, double radius, double *Sm, d
 static int build_reduced(const ba_state *S, double radius, int add_cam_diag,
                          double *Sm, double *rhs, double *EtEinv, double *Etr)
 {
-    const int n = 6 * S->n_cam;
+    const int n = S->nf;
     const size_t nn = (size_t)n * n;
     memset(Sm, 0, sizeof(double) * nn);
     memset(rhs, 0, sizeof(double) * (size_t)n);
@@ -412,15 +496,6 @@ static int build_reduced(const ba_state *S, double radius, int add_cam_diag,
     return ok;
 }
 
-/* Exported for the sharding test (tests/test_ba_sharding_gloo.py): partial
- * reduced system + LM diagonal pieces of an observation subset, linearised at
- * (cams, pts) with NO Jacobi scaling and a caller-supplied LM diagonal
- * (diag_c, diag_p = squared column norms, already clamped). */
-int esfm_ref_ba_partial_reduced(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
-                                const float *obs_uv, const float *K4, const double *cams, const double *pts,
-                                double cauchy_a, double radius, const double *diag_c, const double *diag_p,
-                                int add_cam_diag, double *Sm /*(6nc)^2*/, double *rhs /*6nc*/);
-
 static void group_by_point(ba_state *S)
 {
     S->pt_start = (int32_t *)calloc((size_t)S->n_pt + 1, sizeof(int32_t));
@@ -437,23 +512,33 @@ static void group_by_point(ba_state *S)
 static void state_alloc(ba_state *S)
 {
     size_t no = S->n_obs > 0 ? S->n_obs : 1;
+    S->nf = 6 * S->n_cam + (S->has_calib ? 4 : 0);
+    size_t nf = S->nf > 0 ? (size_t)S->nf : 1, np3 = 3 * (size_t)(S->n_pt > 0 ? S->n_pt : 1);
     S->Jc = (double *)malloc(sizeof(double) * 12 * no);
     S->Jp = (double *)malloc(sizeof(double) * 6 * no);
+    S->Jk = S->has_calib ? (double *)malloc(sizeof(double) * 8 * no) : NULL;
     S->r = (double *)malloc(sizeof(double) * 2 * no);
-    S->scale_c = (double *)malloc(sizeof(double) * 6 * (size_t)S->n_cam);
-    S->scale_p = (double *)malloc(sizeof(double) * 3 * (size_t)S->n_pt);
-    S->diag_c = (double *)calloc(6 * (size_t)S->n_cam, sizeof(double));
-    S->diag_p = (double *)calloc(3 * (size_t)S->n_pt, sizeof(double));
-    for (size_t i = 0; i < 6 * (size_t)S->n_cam; ++i) S->scale_c[i] = 1.0;
-    for (size_t i = 0; i < 3 * (size_t)S->n_pt; ++i) S->scale_p[i] = 1.0;
+    S->scale_c = (double *)malloc(sizeof(double) * nf);
+    S->scale_p = (double *)malloc(sizeof(double) * np3);
+    S->diag_c = (double *)calloc(nf, sizeof(double));
+    S->diag_p = (double *)calloc(np3, sizeof(double));
+    S->grad_c = (double *)calloc(nf, sizeof(double));
+    S->grad_p = (double *)calloc(np3, sizeof(double));
+    for (size_t i = 0; i < nf; ++i) S->scale_c[i] = 1.0;
+    for (size_t i = 0; i < np3; ++i) S->scale_p[i] = 1.0;
 }
 
 static void state_free(ba_state *S)
 {
     free(S->pt_start); free(S->order); free(S->cam_nobs);
-    free(S->Jc); free(S->Jp); free(S->r); free(S->scale_c); free(S->scale_p); free(S->diag_c); free(S->diag_p);
+    free(S->Jc); free(S->Jp); free(S->Jk); free(S->r); free(S->scale_c); free(S->scale_p); free(S->diag_c); free(S->diag_p);
+    free(S->grad_c); free(S->grad_p);
 }
 
+/* Exported for the sharding test (tests/test_sharding_gloo.py): partial
+ * reduced system + LM diagonal pieces of an observation subset, linearised at
+ * (cams, pts) with NO Jacobi scaling and a caller-supplied LM diagonal
+ * (diag_c, diag_p = squared column norms, already clamped). */
 int esfm_ref_ba_partial_reduced(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
                                 const float *obs_uv, const float *K4, const double *cams, const double *pts,
                                 double cauchy_a, double radius, const double *diag_c, const double *diag_p,
@@ -463,7 +548,7 @@ int esfm_ref_ba_partial_reduced(int n_cam, int n_pt, int n_obs, const int32_t *c
     S.n_cam = n_cam; S.n_pt = n_pt; S.n_obs = n_obs; S.cam_idx = cam_idx; S.pt_idx = pt_idx; S.uv = obs_uv; S.K4 = K4;
     group_by_point(&S); state_alloc(&S);
     double gmax; int ok;
-    linearize(&S, cams, pts, cauchy_a, 0, &gmax, &ok);
+    linearize(&S, cams, pts, cauchy_a, 0, NULL, NULL, &gmax, &ok);
     memcpy(S.diag_c, diag_c, sizeof(double) * 6 * (size_t)n_cam);
     memcpy(S.diag_p, diag_p, sizeof(double) * 3 * (size_t)n_pt);
     double *EtEinv = (double *)malloc(sizeof(double) * 9 * (size_t)n_pt);
@@ -483,7 +568,7 @@ int esfm_ref_ba_column_sqnorms(int n_cam, int n_pt, int n_obs, const int32_t *ca
     S.n_cam = n_cam; S.n_pt = n_pt; S.n_obs = n_obs; S.cam_idx = cam_idx; S.pt_idx = pt_idx; S.uv = obs_uv; S.K4 = K4;
     group_by_point(&S); state_alloc(&S);
     double gmax; int ok;
-    linearize(&S, cams, pts, cauchy_a, 0, &gmax, &ok);
+    linearize(&S, cams, pts, cauchy_a, 0, NULL, NULL, &gmax, &ok);
     column_sqnorms(&S, nc, np);
     state_free(&S);
     return ok ? 0 : -1;
@@ -513,10 +598,204 @@ void esfm_ref_ba_options_default(esfm_ba_options *o)
     o->parameter_tolerance = 1e-8;
 }
 
-/* ceres::Solve for the problem ba.cpp:140-151 builds (see header). */
-int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
-                      const float *obs_uv, const float *K4, double *cams, double *pts,
-                      const esfm_ba_options *opt_in, esfm_ba_summary *sum)
+/* ------------------------------------------------------------------------- */
+/* Armijo line search of the bounds-constrained trust-region loop [upstream line_search.cc ArmijoLineSearch::DoSearch,
+ * polynomial.cc MinimizeInterpolatingPolynomial; Ceres defaults: CUBIC interpolation, sufficient decrease 1e-4,
+ * step contraction within [1e-3, 0.6], min step size 1e-9, at most 20 iterations].
+ * Polynomials are stored lowest degree first. */
+typedef struct { double x, value, gradient; int value_valid, gradient_valid; } ls_sample;
+
+static double poly_eval(const double *c, int deg, double x)
+{
+    double v = c[deg];
+    for (int i = deg - 1; i >= 0; --i) v = v * x + c[i];
+    return v;
+}
+
+/* solve the (n x n) system A c = b with full pivoting (FindInterpolatingPolynomial uses fullPivLu) */
+static int solve_full_pivot(double *A, double *b, int n, double *x)
+{
+    int perm[8];
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int pr = k, pc = k; double best = 0.0;
+        for (int i = k; i < n; ++i) for (int j = k; j < n; ++j) if (fabs(A[i * n + j]) > best) { best = fabs(A[i * n + j]); pr = i; pc = j; }
+        if (best == 0.0) return 0;
+        if (pr != k) { for (int j = 0; j < n; ++j) { double t = A[k * n + j]; A[k * n + j] = A[pr * n + j]; A[pr * n + j] = t; } double t = b[k]; b[k] = b[pr]; b[pr] = t; }
+        if (pc != k) { for (int i = 0; i < n; ++i) { double t = A[i * n + k]; A[i * n + k] = A[i * n + pc]; A[i * n + pc] = t; } int t = perm[k]; perm[k] = perm[pc]; perm[pc] = t; }
+        for (int i = k + 1; i < n; ++i) {
+            double f = A[i * n + k] / A[k * n + k];
+            for (int j = k; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    double y[8];
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int j = i + 1; j < n; ++j) s -= A[i * n + j] * y[j];
+        y[i] = s / A[i * n + i];
+    }
+    for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+    return 1;
+}
+
+/* polynomial through the samples' values (and gradients where valid); returns the degree */
+static int fit_polynomial(const ls_sample *smp, int ns, double *coef)
+{
+    int ncon = 0;
+    for (int i = 0; i < ns; ++i) ncon += (smp[i].value_valid ? 1 : 0) + (smp[i].gradient_valid ? 1 : 0);
+    const int n = ncon;
+    double A[64], b[8];
+    int row = 0;
+    for (int i = 0; i < ns; ++i) {
+        if (smp[i].value_valid) {
+            double pw = 1.0;
+            for (int j = 0; j < n; ++j) { A[row * n + j] = pw; pw *= smp[i].x; }
+            b[row++] = smp[i].value;
+        }
+        if (smp[i].gradient_valid) {
+            double pw = 1.0;
+            A[row * n] = 0.0;
+            for (int j = 1; j < n; ++j) { A[row * n + j] = (double)j * pw; pw *= smp[i].x; }
+            b[row++] = smp[i].gradient;
+        }
+    }
+    if (!solve_full_pivot(A, b, n, coef)) return -1;
+    return n - 1;
+}
+
+/* real roots of q (degree deg, lowest first) inside [a, b]; returns the count.  Roots are isolated between
+ * consecutive critical points and refined by bisection. */
+static int real_roots_in(const double *q, int deg, double a, double b, double *roots)
+{
+    while (deg > 0 && q[deg] == 0.0) --deg;
+    if (deg <= 0) return 0;
+    if (deg == 1) { double r = -q[0] / q[1]; if (r >= a && r <= b) { roots[0] = r; return 1; } return 0; }
+    double dq[8];
+    for (int i = 1; i <= deg; ++i) dq[i - 1] = (double)i * q[i];
+    double crit[8];
+    int nc = real_roots_in(dq, deg - 1, a, b, crit);
+    for (int i = 1; i < nc; ++i) { double v = crit[i]; int j = i - 1; while (j >= 0 && crit[j] > v) { crit[j + 1] = crit[j]; --j; } crit[j + 1] = v; }
+    double brk[10]; int nb = 0;
+    brk[nb++] = a; for (int i = 0; i < nc; ++i) brk[nb++] = crit[i]; brk[nb++] = b;
+    int nr = 0;
+    for (int i = 0; i + 1 < nb; ++i) {
+        double l = brk[i], u = brk[i + 1];
+        if (!(u > l)) continue;
+        double fl = poly_eval(q, deg, l), fu = poly_eval(q, deg, u);
+        if (fl == 0.0) { if (nr == 0 || roots[nr - 1] != l) roots[nr++] = l; continue; }
+        if (fu == 0.0) { if (i + 2 == nb) roots[nr++] = u; continue; }
+        if ((fl < 0.0) == (fu < 0.0)) continue;
+        for (int it = 0; it < 200 && u - l > 0.0; ++it) {
+            double mid = 0.5 * (l + u);
+            if (mid == l || mid == u) break;
+            double fm = poly_eval(q, deg, mid);
+            if (fm == 0.0) { l = u = mid; break; }
+            if ((fm < 0.0) == (fl < 0.0)) { l = mid; fl = fm; } else { u = mid; }
+        }
+        roots[nr++] = 0.5 * (l + u);
+    }
+    return nr;
+}
+
+/* polynomial.cc MinimizePolynomial: midpoint, the two ends, then the derivative's roots inside the interval.
+ * For a quadratic derivative the candidates follow FindQuadraticPolynomialRoots (including the real part of a
+ * complex pair, which Ceres also tries); for higher degrees only the real roots are tried. */
+static double minimize_polynomial(const double *c, int deg, double xmin, double xmax)
+{
+    double best_x = (xmin + xmax) / 2.0, best_v = poly_eval(c, deg, best_x);
+    double v = poly_eval(c, deg, xmin); if (v < best_v) { best_v = v; best_x = xmin; }
+    v = poly_eval(c, deg, xmax); if (v < best_v) { best_v = v; best_x = xmax; }
+    if (deg <= 1) return best_x;
+    double d[8]; int dd = deg - 1;
+    for (int i = 1; i <= deg; ++i) d[i - 1] = (double)i * c[i];
+    while (dd > 0 && d[dd] == 0.0) --dd;
+    double roots[8]; int nr = 0;
+    if (dd == 1) { roots[nr++] = -d[0] / d[1]; }
+    else if (dd == 2) {
+        const double qa = d[2], qb = d[1], qc = d[0];
+        const double D = qb * qb - 4.0 * qa * qc, sD = sqrt(fabs(D));
+        if (D >= 0.0) {
+            if (qb >= 0.0) { roots[nr++] = (-qb - sD) / (2.0 * qa); roots[nr++] = (2.0 * qc) / (-qb - sD); }
+            else { roots[nr++] = (2.0 * qc) / (-qb + sD); roots[nr++] = (-qb + sD) / (2.0 * qa); }
+        } else { roots[nr++] = -qb / (2.0 * qa); }
+    } else if (dd > 2) nr = real_roots_in(d, dd, xmin, xmax, roots);
+    for (int i = 0; i < nr; ++i) {
+        if (!(roots[i] >= xmin && roots[i] <= xmax)) continue;
+        v = poly_eval(c, deg, roots[i]);
+        if (v < best_v) { best_v = v; best_x = roots[i]; }
+    }
+    return best_x;
+}
+
+/* line_search.cc InterpolatingPolynomialMinimizingStepSize, CUBIC */
+static double ls_next_step(const ls_sample *initial, const ls_sample *previous, const ls_sample *current,
+                           double min_step, double max_step)
+{
+    if (!current->value_valid || !current->gradient_valid)
+        return fmin(fmax(current->x * 0.5, min_step), max_step);
+    ls_sample smp[3]; int ns = 0;
+    smp[ns++] = *initial; smp[ns++] = *current;
+    if (previous->value_valid) smp[ns++] = *previous;
+    double coef[8];
+    int deg = fit_polynomial(smp, ns, coef);
+    if (deg < 0) return fmin(fmax(current->x * 0.5, min_step), max_step);
+    return minimize_polynomial(coef, deg, min_step, max_step);
+}
+
+/* exported so the product's host-side restatement of the same search can be checked on polynomials alone */
+double esfm_ref_ls_next_step(double f0, double g0, double xp, double fp, double gp, int prev_valid,
+                             double xc, double fc, double gc, int cur_valid, double min_step, double max_step)
+{
+    ls_sample ini = { 0.0, f0, g0, 1, 1 }, prev = { xp, fp, gp, prev_valid, prev_valid }, cur = { xc, fc, gc, cur_valid, cur_valid };
+    return ls_next_step(&ini, &prev, &cur, min_step, max_step);
+}
+
+/* value and directional derivative of the cost along delta at Plus(x, t delta) [line_search.cc
+ * LineSearchFunction::Evaluate: gradient of the objective at the projected point, dotted with the direction] */
+static int ls_evaluate(const ba_state *S, const double *xf, const double *xp, const double *df, const double *dp,
+                       const double *lo, const double *up, double t, double cauchy_a,
+                       double *tf, double *tp, double *value, double *gradient)
+{
+    for (int i = 0; i < S->nf; ++i) tf[i] = clamp_box(xf[i] + t * df[i], lo, up, (size_t)i);
+    for (size_t i = 0; i < 3 * (size_t)S->n_pt; ++i) tp[i] = xp[i] + t * dp[i];
+    const double *calib = S->has_calib ? tf + 6 * (size_t)S->n_cam : NULL;
+    double cost = 0.0, g = 0.0; int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : cost, g) reduction(| : bad) schedule(static)
+#endif
+    for (int k = 0; k < S->n_obs; ++k) {
+        double r[2], Jc[12], Jp[6], Jk[8], rho[3];
+        int c = S->cam_idx[k], p = S->pt_idx[k];
+        residual_jac_any(tf + 6 * (size_t)c, tp + 3 * (size_t)p, S->K4 ? S->K4 + 4 * (size_t)c : NULL, calib,
+                         S->uv + 2 * (size_t)k, r, Jc, Jp, Jk);
+        double s = r[0] * r[0] + r[1] * r[1];
+        if (!isfinite(s)) { bad |= 1; continue; }
+        loss_eval(cauchy_a, s, rho);
+        cost += 0.5 * rho[0];
+        double m0 = 0.0, m1 = 0.0;
+        for (int a = 0; a < 6; ++a) { m0 += Jc[a] * df[6 * c + a]; m1 += Jc[6 + a] * df[6 * c + a]; }
+        for (int a = 0; a < 3; ++a) { m0 += Jp[a] * dp[3 * (size_t)p + a]; m1 += Jp[3 + a] * dp[3 * (size_t)p + a]; }
+        if (calib) for (int a = 0; a < 4; ++a) { m0 += Jk[a] * df[6 * S->n_cam + a]; m1 += Jk[4 + a] * df[6 * S->n_cam + a]; }
+        g += rho[1] * (r[0] * m0 + r[1] * m1);
+    }
+    *value = cost; *gradient = g;
+    return !bad && isfinite(cost) && isfinite(g);
+}
+
+/* ceres::Solve for the problem ba.cpp:140-196 builds (see header).
+ *   calib      NULL: fixed intrinsics K4 per camera (ba.cpp:142-164)
+ *              else: shared free intrinsics fx, cx, fy, cy (ba.cpp:167-196), in/out, bounded to the initial value
+ *              +- calib_tol (ba.cpp:190-194; calib_tol <= 0 is rejected: lower >= upper is infeasible for Ceres)
+ *   ref_cam    >= 0: every parameter of that camera is bounded to [-ref_thr, +ref_thr] (ba.cpp:155-162 / 181-188;
+ *              the reference uses 1e-10), < 0: none
+ * With any bound the trust-region loop is Ceres' constrained variant: x projected at iteration 0, projected
+ * gradient norm, Plus() projects, and an Armijo line search along the LM step before the candidate is evaluated
+ * (trust_region_minimizer.cc DoLineSearch). */
+int esfm_ref_ba_solve_ex(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
+                         const float *obs_uv, const float *K4, double *cams, double *pts,
+                         double *calib, double calib_tol, int ref_cam, double ref_thr,
+                         const esfm_ba_options *opt_in, esfm_ba_summary *sum)
 {
     esfm_ba_options opt;
     if (opt_in) opt = *opt_in; else esfm_ref_ba_options_default(&opt);
@@ -524,37 +803,62 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
     memset(sum, 0, sizeof(*sum));
     for (int k = 0; k < n_obs; ++k)
         if (cam_idx[k] < 0 || cam_idx[k] >= n_cam || pt_idx[k] < 0 || pt_idx[k] >= n_pt) return -1;
+    if (calib && !(calib_tol > 0.0)) return -1;
+    if (!calib && !K4) return -1;
+    if (ref_cam >= n_cam) return -1;
+    if (ref_cam >= 0 && !(ref_thr > 0.0)) return -1;
 
     ba_state S; memset(&S, 0, sizeof(S));
-    S.n_cam = n_cam; S.n_pt = n_pt; S.n_obs = n_obs; S.cam_idx = cam_idx; S.pt_idx = pt_idx; S.uv = obs_uv; S.K4 = K4;
+    S.n_cam = n_cam; S.n_pt = n_pt; S.n_obs = n_obs; S.cam_idx = cam_idx; S.pt_idx = pt_idx; S.uv = obs_uv;
+    S.K4 = calib ? NULL : K4; S.has_calib = calib != NULL;
     group_by_point(&S); state_alloc(&S);
-    const int n = 6 * n_cam;
+    const int n = S.nf;
+    const size_t n1 = n > 0 ? (size_t)n : 1, np3 = 3 * (size_t)(n_pt > 0 ? n_pt : 1);
     int nact_c = 0, nact_p = 0;
     for (int c = 0; c < n_cam; ++c) nact_c += S.cam_nobs[c] > 0;
     for (int p = 0; p < n_pt; ++p) nact_p += S.pt_start[p + 1] > S.pt_start[p];
     sum->num_active_cameras = nact_c; sum->num_active_points = nact_p;
 
-    double *x_c = cams, *x_p = pts; /* current point lives in the caller's arrays */
-    double *cand_c = (double *)malloc(sizeof(double) * 6 * (size_t)n_cam);
-    double *cand_p = (double *)malloc(sizeof(double) * 3 * (size_t)n_pt);
-    double *Sm = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (n > 0 ? n : 1));
-    double *rhs = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-    double *EtEinv = (double *)malloc(sizeof(double) * 9 * (size_t)(n_pt > 0 ? n_pt : 1));
-    double *Etr = (double *)malloc(sizeof(double) * 3 * (size_t)(n_pt > 0 ? n_pt : 1));
-    double *step_c = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-    double *step_p = (double *)malloc(sizeof(double) * 3 * (size_t)(n_pt > 0 ? n_pt : 1));
-    double *nc = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-    double *np = (double *)malloc(sizeof(double) * 3 * (size_t)(n_pt > 0 ? n_pt : 1));
+    double *x_c = (double *)malloc(sizeof(double) * n1); /* f-block unknowns: cameras | intrinsics */
+    double *x_p = pts;                                   /* points live in the caller's array */
+    memcpy(x_c, cams, sizeof(double) * 6 * (size_t)n_cam);
+    if (calib) memcpy(x_c + 6 * (size_t)n_cam, calib, sizeof(double) * 4);
+    char *act_f = (char *)calloc(n1, 1);
+    for (int c = 0; c < n_cam; ++c) if (S.cam_nobs[c] > 0) for (int i = 0; i < 6; ++i) act_f[6 * c + i] = 1;
+    if (calib && n_obs > 0) for (int i = 0; i < 4; ++i) act_f[6 * n_cam + i] = 1;
+    /* bounds (only on active blocks: Ceres drops unused blocks together with their bounds) */
+    double *lo = NULL, *up = NULL;
+    int constrained = 0;
+    if ((calib && n_obs > 0) || (ref_cam >= 0 && S.cam_nobs[ref_cam] > 0)) {
+        constrained = 1;
+        lo = (double *)malloc(sizeof(double) * n1); up = (double *)malloc(sizeof(double) * n1);
+        for (int i = 0; i < n; ++i) { lo[i] = -INFINITY; up[i] = INFINITY; }
+        if (ref_cam >= 0 && S.cam_nobs[ref_cam] > 0) for (int i = 0; i < 6; ++i) { lo[6 * ref_cam + i] = -ref_thr; up[6 * ref_cam + i] = ref_thr; }
+        if (calib && n_obs > 0) for (int i = 0; i < 4; ++i) { lo[6 * n_cam + i] = calib[i] - calib_tol; up[6 * n_cam + i] = calib[i] + calib_tol; }
+    }
+    double *cand_c = (double *)malloc(sizeof(double) * n1);
+    double *cand_p = (double *)malloc(sizeof(double) * np3);
+    double *Sm = (double *)malloc(sizeof(double) * n1 * n1);
+    double *rhs = (double *)malloc(sizeof(double) * n1);
+    double *EtEinv = (double *)malloc(sizeof(double) * 3 * np3);
+    double *Etr = (double *)malloc(sizeof(double) * np3);
+    double *step_c = (double *)malloc(sizeof(double) * n1);
+    double *step_p = (double *)malloc(sizeof(double) * np3);
+    double *delta_c = (double *)malloc(sizeof(double) * n1);
+    double *delta_p = (double *)malloc(sizeof(double) * np3);
+    double *nc = (double *)malloc(sizeof(double) * n1);
+    double *np = (double *)malloc(sizeof(double) * np3);
 
     double t0 = now_sec();
     int rc = 0;
     /* ---- iteration 0 (TrustRegionMinimizer::IterationZero) ---- */
+    if (constrained) for (int i = 0; i < n; ++i) if (act_f[i]) x_c[i] = clamp_box(x_c[i], lo, up, (size_t)i);
     double x_norm = 0.0;
-    for (int c = 0; c < n_cam; ++c) if (S.cam_nobs[c] > 0) for (int i = 0; i < 6; ++i) x_norm += x_c[6 * c + i] * x_c[6 * c + i];
+    for (int i = 0; i < n; ++i) if (act_f[i]) x_norm += x_c[i] * x_c[i];
     for (int p = 0; p < n_pt; ++p) if (S.pt_start[p + 1] > S.pt_start[p]) for (int i = 0; i < 3; ++i) x_norm += x_p[3 * (size_t)p + i] * x_p[3 * (size_t)p + i];
     x_norm = sqrt(x_norm);
     double gmax = 0.0; int ok = 1;
-    double x_cost = linearize(&S, x_c, x_p, opt.cauchy_a, 0, &gmax, &ok);
+    double x_cost = linearize(&S, x_c, x_p, opt.cauchy_a, 0, lo, up, &gmax, &ok);
     if (!ok) { sum->termination = ESFM_BA_FAILURE; rc = -6; goto done; }
     if (opt.jacobi_scaling) {
         column_sqnorms(&S, nc, np);
@@ -565,6 +869,7 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
             for (int row = 0; row < 2; ++row) {
                 for (int i = 0; i < 6; ++i) S.Jc[12 * (size_t)k + 6 * row + i] *= S.scale_c[6 * (size_t)c + i];
                 for (int i = 0; i < 3; ++i) S.Jp[6 * (size_t)k + 3 * row + i] *= S.scale_p[3 * (size_t)p + i];
+                if (calib) for (int i = 0; i < 4; ++i) S.Jk[8 * (size_t)k + 4 * row + i] *= S.scale_c[6 * (size_t)n_cam + i];
             }
         }
     }
@@ -596,20 +901,22 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
         }
         int lin_ok = build_reduced(&S, radius, 1, Sm, rhs, EtEinv, Etr);
         /* inactive cameras: identity rows so the factorisation is defined; their step is 0 */
-        for (int c = 0; c < n_cam; ++c) if (S.cam_nobs[c] == 0) for (int i = 0; i < 6; ++i) { rhs[6 * c + i] = 0.0; }
+        for (int i = 0; i < n; ++i) if (!act_f[i]) rhs[i] = 0.0;
         if (lin_ok) lin_ok = chol_solve(Sm, rhs, n);
         if (lin_ok) {
             for (int i = 0; i < n; ++i) { step_c[i] = -rhs[i]; lin_ok &= isfinite(step_c[i]); }
-            /* back-substitution: y_p = (E'E+D^2)^-1 (E'r - sum E'F y_c) */
+            /* back-substitution: y_p = (E'E+D^2)^-1 (E'r - sum E'F y_f) */
             for (int p = 0; p < n_pt; ++p) {
                 int b = S.pt_start[p], e = S.pt_start[p + 1];
                 if (b == e) { step_p[3 * (size_t)p] = step_p[3 * (size_t)p + 1] = step_p[3 * (size_t)p + 2] = 0.0; continue; }
                 double g[3] = { Etr[3 * (size_t)p], Etr[3 * (size_t)p + 1], Etr[3 * (size_t)p + 2] };
                 for (int t = b; t < e; ++t) {
-                    int k = S.order[t], c = cam_idx[k];
-                    const double *Jc = S.Jc + 12 * (size_t)k, *Jp = S.Jp + 6 * (size_t)k;
-                    double f0 = 0.0, f1 = 0.0; /* F y_c */
-                    for (int a = 0; a < 6; ++a) { f0 += Jc[a] * rhs[6 * c + a]; f1 += Jc[6 + a] * rhs[6 * c + a]; }
+                    int k = S.order[t];
+                    const double *Jp = S.Jp + 6 * (size_t)k;
+                    int ci[10]; double h0[10], h1[10];
+                    const int m = obs_fcols(&S, k, ci, h0, h1);
+                    double f0 = 0.0, f1 = 0.0; /* F y_f */
+                    for (int a = 0; a < m; ++a) { f0 += h0[a] * rhs[ci[a]]; f1 += h1[a] * rhs[ci[a]]; }
                     for (int i = 0; i < 3; ++i) g[i] -= Jp[i] * f0 + Jp[3 + i] * f1;
                 }
                 const double *Ai = EtEinv + 9 * (size_t)p;
@@ -623,10 +930,12 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
         double model_cost_change = 0.0;
         if (lin_ok) {
             for (int k = 0; k < n_obs; ++k) {
-                int c = cam_idx[k], p = pt_idx[k];
-                const double *Jc = S.Jc + 12 * (size_t)k, *Jp = S.Jp + 6 * (size_t)k, *r = S.r + 2 * (size_t)k;
+                int p = pt_idx[k];
+                const double *Jp = S.Jp + 6 * (size_t)k, *r = S.r + 2 * (size_t)k;
+                int ci[10]; double h0[10], h1[10];
+                const int m = obs_fcols(&S, k, ci, h0, h1);
                 double m0 = 0.0, m1 = 0.0;
-                for (int a = 0; a < 6; ++a) { m0 += Jc[a] * step_c[6 * c + a]; m1 += Jc[6 + a] * step_c[6 * c + a]; }
+                for (int a = 0; a < m; ++a) { m0 += h0[a] * step_c[ci[a]]; m1 += h1[a] * step_c[ci[a]]; }
                 for (int a = 0; a < 3; ++a) { m0 += Jp[a] * step_p[3 * (size_t)p + a]; m1 += Jp[3 + a] * step_p[3 * (size_t)p + a]; }
                 model_cost_change -= m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0);
             }
@@ -644,22 +953,48 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
             continue;
         }
         n_invalid = 0;
-        /* candidate = x + step .* scaling */
-        double step_norm = 0.0;
-        for (int i = 0; i < n; ++i) {
-            cand_c[i] = x_c[i] + step_c[i] * S.scale_c[i];
-            if (S.cam_nobs[i / 6] > 0) { double d = x_c[i] - cand_c[i]; step_norm += d * d; } else cand_c[i] = x_c[i];
-        }
+        /* delta = step .* scaling (zero on blocks that are not part of the problem) */
+        for (int i = 0; i < n; ++i) delta_c[i] = act_f[i] ? step_c[i] * S.scale_c[i] : 0.0;
         for (int p = 0; p < n_pt; ++p) {
             int active = S.pt_start[p + 1] > S.pt_start[p];
-            for (int i = 0; i < 3; ++i) {
-                size_t j = 3 * (size_t)p + i;
-                if (active) { cand_p[j] = x_p[j] + step_p[j] * S.scale_p[j]; double d = x_p[j] - cand_p[j]; step_norm += d * d; }
-                else cand_p[j] = x_p[j];
+            for (int i = 0; i < 3; ++i) { size_t j = 3 * (size_t)p + i; delta_p[j] = active ? step_p[j] * S.scale_p[j] : 0.0; }
+        }
+        if (constrained) {
+            /* TrustRegionMinimizer::DoLineSearch: Armijo search from step size 1 along delta */
+            double g0 = 0.0, dmax = 0.0;
+            for (int i = 0; i < n; ++i) { g0 += S.grad_c[i] * delta_c[i]; dmax = fmax(dmax, fabs(delta_c[i])); }
+            for (size_t i = 0; i < 3 * (size_t)n_pt; ++i) { g0 += S.grad_p[i] * delta_p[i]; dmax = fmax(dmax, fabs(delta_p[i])); }
+            ls_sample initial = { 0.0, x_cost, g0, 1, 1 }, previous = { 0.0, 0.0, 0.0, 0, 0 }, current = { 1.0, 0.0, 0.0, 0, 0 };
+            current.value_valid = current.gradient_valid =
+                ls_evaluate(&S, x_c, x_p, delta_c, delta_p, lo, up, current.x, opt.cauchy_a, cand_c, cand_p, &current.value, &current.gradient);
+            int ls_it = 0, ls_ok = 1;
+            while (!current.value_valid || current.value > x_cost + 1e-4 * g0 * current.x) {
+                if (++ls_it >= 20) { ls_ok = 0; break; }
+                double t = ls_next_step(&initial, &previous, &current, 1e-3 * current.x, 0.6 * current.x);
+                if (t * dmax < 1e-9) { ls_ok = 0; break; }
+                previous = current;
+                current.x = t;
+                current.value_valid = current.gradient_valid =
+                    ls_evaluate(&S, x_c, x_p, delta_c, delta_p, lo, up, current.x, opt.cauchy_a, cand_c, cand_p, &current.value, &current.gradient);
+            }
+            cur.line_search_steps = ls_it;
+            if (ls_ok && current.x != 1.0) {
+                for (int i = 0; i < n; ++i) delta_c[i] *= current.x;
+                for (size_t i = 0; i < 3 * (size_t)n_pt; ++i) delta_p[i] *= current.x;
             }
         }
+        /* candidate = Plus(x, delta) */
+        double step_norm = 0.0;
+        for (int i = 0; i < n; ++i) {
+            cand_c[i] = act_f[i] ? clamp_box(x_c[i] + delta_c[i], lo, up, (size_t)i) : x_c[i];
+            double d = x_c[i] - cand_c[i]; step_norm += d * d;
+        }
+        for (size_t j = 0; j < 3 * (size_t)n_pt; ++j) {
+            cand_p[j] = x_p[j] + delta_p[j];
+            double d = x_p[j] - cand_p[j]; step_norm += d * d;
+        }
         step_norm = sqrt(step_norm);
-        double cand_cost = esfm_ref_ba_cost(n_obs, cam_idx, pt_idx, obs_uv, K4, cand_c, cand_p, opt.cauchy_a);
+        double cand_cost = cost_any(n_obs, cam_idx, pt_idx, obs_uv, S.K4, calib ? cand_c + 6 * (size_t)n_cam : NULL, cand_c, cand_p, opt.cauchy_a);
         cur.step_norm = step_norm;
         cur.cost_change = x_cost - cand_cost;
         /* ParameterToleranceReached */
@@ -684,10 +1019,10 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
             memcpy(x_c, cand_c, sizeof(double) * (size_t)n);
             memcpy(x_p, cand_p, sizeof(double) * 3 * (size_t)n_pt);
             x_norm = 0.0;
-            for (int c = 0; c < n_cam; ++c) if (S.cam_nobs[c] > 0) for (int i = 0; i < 6; ++i) x_norm += x_c[6 * c + i] * x_c[6 * c + i];
+            for (int i = 0; i < n; ++i) if (act_f[i]) x_norm += x_c[i] * x_c[i];
             for (int p = 0; p < n_pt; ++p) if (S.pt_start[p + 1] > S.pt_start[p]) for (int i = 0; i < 3; ++i) x_norm += x_p[3 * (size_t)p + i] * x_p[3 * (size_t)p + i];
             x_norm = sqrt(x_norm);
-            x_cost = linearize(&S, x_c, x_p, opt.cauchy_a, opt.jacobi_scaling, &gmax, &ok);
+            x_cost = linearize(&S, x_c, x_p, opt.cauchy_a, opt.jacobi_scaling, lo, up, &gmax, &ok);
             if (!ok) { sum->termination = ESFM_BA_FAILURE; rc = -6; terminated = 1; }
             last_gmax = gmax;
             cur.step_is_successful = 1; cur.cost = x_cost; cur.gradient_max_norm = gmax;
@@ -711,8 +1046,20 @@ int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, co
     }
     sum->final_cost = x_cost;
 done:
+    memcpy(cams, x_c, sizeof(double) * 6 * (size_t)n_cam);
+    if (calib) memcpy(calib, x_c + 6 * (size_t)n_cam, sizeof(double) * 4);
     sum->solve_seconds = now_sec() - t0;
-    free(cand_c); free(cand_p); free(Sm); free(rhs); free(EtEinv); free(Etr); free(step_c); free(step_p); free(nc); free(np);
+    free(x_c); free(act_f); free(lo); free(up);
+    free(cand_c); free(cand_p); free(Sm); free(rhs); free(EtEinv); free(Etr); free(step_c); free(step_p);
+    free(delta_c); free(delta_p); free(nc); free(np);
     state_free(&S);
     return rc;
+}
+
+/* ceres::Solve for the problem ba.cpp:140-151 builds: fixed intrinsics, no reference camera. */
+int esfm_ref_ba_solve(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
+                      const float *obs_uv, const float *K4, double *cams, double *pts,
+                      const esfm_ba_options *opt_in, esfm_ba_summary *sum)
+{
+    return esfm_ref_ba_solve_ex(n_cam, n_pt, n_obs, cam_idx, pt_idx, obs_uv, K4, cams, pts, NULL, 0.0, -1, 0.0, opt_in, sum);
 }

@@ -17,6 +17,11 @@ C oracle (oracle/*.c) is pinned by tests/test_oracle_golden.py:
                             rejected steps): cost / radius / step norm /
                             accept flag per iteration from a dense (no Schur) numpy LM that solves
                             (J'J + D^2) y = J'r with numpy.linalg, plus the zero-noise known answer
+  ba_lm_constrained.npz     the bounds-constrained variants of solveBA (ba.cpp:155-162 reference camera, ba.cpp:167-196
+                            free shared intrinsics within +-tolerance): the same dense LM with the intrinsics as four more
+                            columns (ba.h:170-222 by torch autograd), projection onto the box, projected gradient norm
+                            and the Armijo line search with cubic interpolation (numpy.linalg.solve for the
+                            interpolating polynomial, numpy.roots for its critical points)
 
     python tests/golden/make_golden.py
 """
@@ -250,6 +255,188 @@ def dense_lm(sc, max_iter, cauchy_a=0.5):
     return x, log
 
 
+def torch_residual_calib(cam, pt, calib, uv):
+    """ReprojectErrorTerm_updatecalib (ba.h:170-216): calib = fx, cx, fy, cy as a differentiable tensor."""
+    import torch
+    aa, tr = cam[:3], cam[3:]
+    theta2 = (aa * aa).sum()
+    if theta2.item() > np.finfo(np.float64).eps:
+        theta = torch.sqrt(theta2)
+        w = aa / theta
+        p = pt * torch.cos(theta) + torch.linalg.cross(w, pt) * torch.sin(theta) + w * (w @ pt) * (1.0 - torch.cos(theta))
+    else:
+        p = pt + torch.linalg.cross(aa, pt)
+    p = p + tr
+    u = p[0] / p[2] * calib[0] + calib[1]
+    v = p[1] / p[2] * calib[2] + calib[3]
+    return torch.stack([float(uv[0]) - u, float(uv[1]) - v])
+
+
+def armijo_next_step(f0, g0, prev, cur, lo, hi):
+    """line_search.cc InterpolatingPolynomialMinimizingStepSize (CUBIC) + polynomial.cc MinimizePolynomial.
+    prev / cur = (x, f, g) or None."""
+    if cur is None:
+        raise ValueError
+    rows, rhs = [], []
+    samples = [(0.0, f0, g0), cur] + ([prev] if prev is not None else [])
+    n = 2 * len(samples)
+    for (x, f, g) in samples:
+        rows.append([x ** j for j in range(n)]); rhs.append(f)
+        rows.append([0.0] + [j * x ** (j - 1) for j in range(1, n)]); rhs.append(g)
+    coef = np.linalg.solve(np.array(rows), np.array(rhs))          # lowest degree first
+    poly = np.polynomial.Polynomial(coef)
+    cands = [(lo + hi) / 2.0, lo, hi]
+    droots = np.roots(poly.deriv().coef[::-1])
+    cands += [float(np.real(z)) for z in droots if lo <= np.real(z) <= hi]   # Ceres tries real parts of all roots
+    best = cands[0]
+    for c in cands[1:]:
+        if poly(c) < poly(best):
+            best = c
+    return best
+
+
+def dense_lm_constrained(sc, max_iter, cauchy_a, calib0=None, calib_tol=0.0, ref_cam=-1, ref_thr=1e-10):
+    """dense_lm + Ceres' bounds handling (trust_region_minimizer.cc: IterationZero projection, projected gradient
+    norm, DoLineSearch, Plus() projects).  Unknown vector: cameras | points | (fx, cx, fy, cy)."""
+    import torch
+    n_cam, n_pt, n_obs = sc.n_cam, sc.n_pt, sc.n_obs
+    free = calib0 is not None
+    npar = 6 * n_cam + 3 * n_pt + (4 if free else 0)
+    ko = 6 * n_cam + 3 * n_pt
+    lo = np.full(npar, -np.inf); up = np.full(npar, np.inf)
+    if ref_cam >= 0:
+        lo[6 * ref_cam:6 * ref_cam + 6] = -ref_thr; up[6 * ref_cam:6 * ref_cam + 6] = ref_thr
+    if free:
+        lo[ko:] = np.asarray(calib0) - calib_tol; up[ko:] = np.asarray(calib0) + calib_tol
+
+    def plus(x, d):
+        return np.minimum(np.maximum(x + d, lo), up)
+
+    def evaluate(x, jac):
+        cams = x[:6 * n_cam].reshape(n_cam, 6); pts = x[6 * n_cam:ko].reshape(n_pt, 3)
+        r = np.zeros(2 * n_obs); J = np.zeros((2 * n_obs, npar)) if jac else None
+        cost = 0.0
+        kt = torch.tensor(x[ko:], dtype=torch.float64, requires_grad=jac) if free else None
+        for k in range(n_obs):
+            c, p = int(sc.cam_idx[k]), int(sc.pt_idx[k])
+            ct = torch.tensor(cams[c], dtype=torch.float64, requires_grad=jac)
+            pt = torch.tensor(pts[p], dtype=torch.float64, requires_grad=jac)
+            res = torch_residual_calib(ct, pt, kt, sc.uv[k]) if free else torch_residual(ct, pt, sc.K4[c], sc.uv[k])
+            rv = res.detach().numpy()
+            sq_norm = float(rv @ rv)
+            if cauchy_a > 0:
+                b = cauchy_a ** 2
+                rho0 = b * np.log1p(sq_norm / b); rho1 = max(1.0 / (1.0 + sq_norm / b), np.finfo(np.float64).tiny)
+            else:
+                rho0, rho1 = sq_norm, 1.0
+            cost += 0.5 * rho0
+            sq = np.sqrt(rho1)
+            r[2 * k:2 * k + 2] = rv * sq
+            if jac:
+                for i in range(2):
+                    g = torch.autograd.grad(res[i], [ct, pt] + ([kt] if free else []), retain_graph=True)
+                    J[2 * k + i, 6 * c:6 * c + 6] = g[0].numpy() * sq
+                    J[2 * k + i, 6 * n_cam + 3 * p:6 * n_cam + 3 * p + 3] = g[1].numpy() * sq
+                    if free:
+                        J[2 * k + i, ko:] = g[2].numpy() * sq
+        return cost, r, J
+
+    def pgrad_norm(x, g):
+        return np.abs(x - plus(x, -g)).max()
+
+    x = np.concatenate([sc.cams0.ravel(), sc.pts0.ravel()] + ([np.asarray(calib0, np.float64)] if free else []))
+    x = plus(x, 0.0)
+    cost, r, J = evaluate(x, True)
+    grad = J.T @ r
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
+    J = J * scale
+    radius, nu = 1e4, 2.0
+    x_norm = np.linalg.norm(x)
+    log = [dict(cost=cost, radius=radius, step_norm=0.0, ok=1, gmax=pgrad_norm(x, grad), ls=0)]
+    reuse = False
+    diag = None
+    for it in range(1, max_iter + 1):
+        if not reuse:
+            diag = np.clip((J * J).sum(0), 1e-6, 1e32)
+        A = J.T @ J + np.diag(diag / radius)
+        step = -np.linalg.solve(A, J.T @ r)
+        reuse = True
+        m = J @ step
+        mcc = -m @ (r + m / 2.0)
+        delta = step * scale
+        # DoLineSearch (Armijo, from step size 1)
+        g0 = grad @ delta
+        dmax = np.abs(delta).max()
+
+        def phi(t):
+            xt = plus(x, t * delta)
+            f, rr, JJ = evaluate(xt, True)
+            return f, (JJ.T @ rr) @ delta
+
+        prev, cur, n_ls, ls_ok = None, None, 0, True
+        f, g = phi(1.0); cur = (1.0, f, g)
+        while cur[1] > cost + 1e-4 * g0 * cur[0]:
+            n_ls += 1
+            if n_ls >= 20:
+                ls_ok = False; break
+            t = armijo_next_step(cost, g0, prev, cur, 1e-3 * cur[0], 0.6 * cur[0])
+            if t * dmax < 1e-9:
+                ls_ok = False; break
+            prev = cur
+            f, g = phi(t); cur = (t, f, g)
+        if ls_ok:
+            delta = delta * cur[0]
+        cand = plus(x, delta)
+        ccost, _, _ = evaluate(cand, False)
+        step_norm = np.linalg.norm(x - cand)
+        if step_norm <= 1e-8 * (x_norm + 1e-8) or abs(cost - ccost) <= 1e-6 * cost:
+            log.append(dict(cost=cost, radius=radius, step_norm=step_norm, ok=0, gmax=log[-1]["gmax"], ls=n_ls, stop=1)); break
+        rho = (cost - ccost) / mcc
+        if rho > 1e-3:
+            x = cand; x_norm = np.linalg.norm(x)
+            cost, r, J = evaluate(x, True)
+            grad = J.T @ r
+            J = J * scale
+            radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)); nu = 2.0; reuse = False
+            log.append(dict(cost=cost, radius=radius, step_norm=step_norm, ok=1, gmax=pgrad_norm(x, grad), ls=n_ls))
+        else:
+            radius /= nu; nu *= 2.0
+            log.append(dict(cost=ccost, radius=radius, step_norm=step_norm, ok=0, gmax=log[-1]["gmax"], ls=n_ls))
+    return x, log
+
+
+def make_ba_constrained():
+    out = {}
+    K = np.array(synth.FOUNTAIN_K4, np.float64)
+    cases = (
+        # free intrinsics, loose box (bounds never active), Cauchy
+        ("calib_loose", 0.5, (4, 60, 3), 8, dict(seed=41), K * np.array([1.02, 0.99, 0.98, 1.01]), 100.0, -1),
+        # free intrinsics, tight box (fx / fy hit the bound; the line search contracts)
+        ("calib_tight", 0.5, (4, 60, 3), 10, dict(seed=41), K * np.array([1.03, 0.99, 0.97, 1.01]), 6.0, -1),
+        # reference camera held at the origin by +-1e-10 bounds, fixed intrinsics
+        ("refcam", 0.5, (4, 60, 3), 8, dict(seed=43), None, 0.0, 0),
+        # both, squared loss
+        ("both_squared", -1.0, (5, 80, 4), 8, dict(seed=44, outlier_frac=0.0), K * np.array([0.98, 1.01, 1.02, 0.99]), 10.0, 0),
+    )
+    for tag, a, shape, iters, kw, calib0, tol, ref in cases:
+        sc = synth.ba_scene(*shape, **kw)
+        if ref >= 0:
+            sc = synth.in_reference_frame(sc, ref)   # the reference pipeline keeps its reference frame at the origin
+        x, log = dense_lm_constrained(sc, iters, a, calib0, tol, ref)
+        for f in ("cam_idx", "pt_idx", "uv", "K4", "cams0", "pts0"):
+            out[f"{tag}.{f}"] = getattr(sc, f)
+        out[f"{tag}.cauchy_a"] = np.float64(a)
+        out[f"{tag}.calib0"] = np.zeros(0) if calib0 is None else np.asarray(calib0, np.float64)
+        out[f"{tag}.calib_tol"] = np.float64(tol)
+        out[f"{tag}.ref_cam"] = np.int32(ref)
+        for key in ("cost", "radius", "step_norm", "ok", "gmax", "ls"):
+            out[f"{tag}.{key}"] = np.array([e[key] for e in log])
+        out[f"{tag}.x_final"] = x
+        print(tag, "pattern", "".join(str(e["ok"]) for e in log), "ls", [e["ls"] for e in log],
+              "cost", log[0]["cost"], "->", log[-1]["cost"])
+    np.savez_compressed(os.path.join(HERE, "ba_lm_constrained.npz"), **out)
+
+
 def make_ba_trace():
     out = {}
     for tag, a, shape, iters, kw in (("cauchy", 0.5, (4, 50, 3), 10, dict(seed=31)),
@@ -279,4 +466,5 @@ if __name__ == "__main__":
     make_l2()
     make_ba_jacobians()
     make_ba_trace()
+    make_ba_constrained()
     print("golden vectors written to", HERE)

@@ -111,6 +111,42 @@ def test_ba_lm_trace_golden(oracle_lib, tag):
     assert np.allclose(x, z[f"{tag}.x_final"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["calib_loose", "calib_tight", "refcam", "both_squared"])
+def test_ba_constrained_trace_golden(oracle_lib, tag):
+    """Bounds-constrained solveBA (ba.cpp:155-196: reference camera +-1e-10, free intrinsics +-tolerance): the Schur-based
+    C oracle == the dense numpy LM with projection and Armijo line search of make_golden.py."""
+    z = np.load(os.path.join(GOLD, "ba_lm_constrained.npz"))
+    opt = oracle_lib.ba_default_options()
+    n = len(z[f"{tag}.cost"]) - 1
+    opt.max_num_iterations = n
+    opt.cauchy_a = float(z[f"{tag}.cauchy_a"])
+    calib0 = z[f"{tag}.calib0"]
+    free = calib0.size == 4
+    cams, pts, cal, s = oracle_lib.ba_solve_ex(z[f"{tag}.cam_idx"], z[f"{tag}.pt_idx"], z[f"{tag}.uv"],
+                                               None if free else z[f"{tag}.K4"], z[f"{tag}.cams0"], z[f"{tag}.pts0"],
+                                               calib=calib0 if free else None, calib_tol=float(z[f"{tag}.calib_tol"]),
+                                               ref_cam=int(z[f"{tag}.ref_cam"]), options=opt)
+    log = oracle_lib.iterations(s)
+    assert len(log) == n + 1
+    assert [it.step_is_successful for it in log] == z[f"{tag}.ok"].tolist()
+    assert [it.line_search_steps for it in log] == z[f"{tag}.ls"].tolist()
+    for it, c, rad, sn, gm in zip(log, z[f"{tag}.cost"], z[f"{tag}.radius"], z[f"{tag}.step_norm"], z[f"{tag}.gmax"]):
+        assert abs(it.cost - c) <= (1e-8 if it.step_is_successful else 1e-6) * abs(c), (it.iteration, it.cost, c)
+        assert abs(it.trust_region_radius - rad) <= 1e-6 * rad, it.iteration
+        assert abs(it.step_norm - sn) <= 1e-4 * max(sn, 1e-6), it.iteration
+        assert abs(it.gradient_max_norm - gm) <= 1e-5 * max(gm, 1e-6), it.iteration
+    x = np.concatenate([cams.ravel(), pts.ravel()] + ([cal] if free else []))
+    assert np.allclose(x, z[f"{tag}.x_final"], rtol=1e-4, atol=1e-5)
+    if free:
+        tol = float(z[f"{tag}.calib_tol"])
+        assert np.all(cal >= calib0 - tol) and np.all(cal <= calib0 + tol)
+    if tag == "calib_tight":
+        assert np.any(np.isclose(np.abs(cal - calib0), float(z[f"{tag}.calib_tol"]), rtol=0, atol=1e-12))   # a bound is active
+        assert sum(z[f"{tag}.ls"]) > 0
+    if int(z[f"{tag}.ref_cam"]) >= 0:
+        assert np.all(np.abs(cams[int(z[f"{tag}.ref_cam"])]) <= 1e-10)
+
+
 def test_ba_zero_noise_known_answer(oracle_lib):
     z = np.load(os.path.join(GOLD, "ba_lm_trace.npz"))
     c = oracle_lib.ba_cost(z["zero.cam_idx"], z["zero.pt_idx"], z["zero.uv"], z["zero.K4"], z["zero.cams_gt"], z["zero.pts_gt"])
