@@ -59,7 +59,7 @@ class BAOptions(C.Structure):
 
 class BAIteration(C.Structure):
     _fields_ = [
-        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("reserved", C.c_int32),
+        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("line_search_steps", C.c_int32),
         ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double), ("step_norm", C.c_double),
         ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double), ("model_cost_change", C.c_double),
     ]
@@ -125,6 +125,14 @@ def lib() -> C.CDLL:
     L.esfm_ba_solve.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(BAOptions), ALLREDUCE_FN, vp,
                                 C.POINTER(BASummary)]
     L.esfm_ba_problem_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.esfm_ba_problem_create_free_calib.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, vp, vp, C.POINTER(C.c_void_p)]
+    L.esfm_ba_problem_set_calib.argtypes = [C.c_void_p, vp, C.c_double]
+    L.esfm_ba_problem_get_calib.argtypes = [C.c_void_p, vp]
+    L.esfm_ba_problem_fix_camera.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.esfm_ba_solve_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, C.c_double,
+                                   C.POINTER(BAOptions), ALLREDUCE_FN, vp, C.POINTER(BASummary)]
+    L.esfm_ba_line_search_next_step.restype = C.c_double
+    L.esfm_ba_line_search_next_step.argtypes = [C.c_double] * 5 + [C.c_int] + [C.c_double] * 3 + [C.c_int]
     L.esfm_ba_problem_set_params.argtypes = [vp, vp, vp]
     L.esfm_ba_problem_solve.argtypes = [vp, C.POINTER(BAOptions), ALLREDUCE_FN, vp, C.POINTER(BASummary)]
     L.esfm_ba_problem_get_params.argtypes = [vp, vp, vp]

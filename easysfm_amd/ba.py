@@ -56,22 +56,51 @@ def torch_allreduce_callback(group=None):
 
 
 class BAProblem:
-    """Resident problem (esfm_ba_problem): upload once, solve/iterate many times."""
+    """Resident problem (esfm_ba_problem): upload once, solve/iterate many times.
 
-    def __init__(self, cam_idx, pt_idx, uv, K4, cams, pts, ctx: Optional[Context] = None):
+    ``calib`` (fx, cx, fy, cy) switches to the free shared intrinsics of ReprojectErrorTerm_updatecalib (ba.h:170-222),
+    bounded to ``calib +- calib_tol`` (ba.cpp:190-194); ``K4`` is then ignored.  ``ref_cam >= 0`` bounds that camera's
+    six parameters to ``+-ref_threshold`` (ba.cpp:155-162)."""
+
+    def __init__(self, cam_idx, pt_idx, uv, K4, cams, pts, ctx: Optional[Context] = None, calib=None, calib_tol: float = 0.0,
+                 ref_cam: int = -1, ref_threshold: float = 1e-10):
         self.ctx = ctx or default_context()
         self.cam_idx = np.ascontiguousarray(cam_idx, np.int32).reshape(-1)
         self.pt_idx = np.ascontiguousarray(pt_idx, np.int32).reshape(-1)
         self.uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
-        self.K4 = np.ascontiguousarray(K4, np.float32).reshape(-1, 4)
         cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6)
         pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
         self.n_cam, self.n_pt, self.n_obs = cams.shape[0], pts.shape[0], self.cam_idx.shape[0]
-        if self.K4.shape[0] != self.n_cam or self.pt_idx.shape[0] != self.n_obs or self.uv.shape[0] != self.n_obs:
+        self.free_calib = calib is not None
+        if self.pt_idx.shape[0] != self.n_obs or self.uv.shape[0] != self.n_obs:
             raise ValueError("inconsistent BA array sizes")
         self._h = C.c_void_p()
-        check(lib().esfm_ba_problem_create(self.ctx.handle, self.n_cam, self.n_pt, self.n_obs, _p(self.cam_idx), _p(self.pt_idx),
-                                           _p(self.uv), _p(self.K4), _p(cams), _p(pts), C.byref(self._h)))
+        if self.free_calib:
+            cal = np.ascontiguousarray(calib, np.float64).reshape(4)
+            check(lib().esfm_ba_problem_create_free_calib(self.ctx.handle, self.n_cam, self.n_pt, self.n_obs, _p(self.cam_idx),
+                                                          _p(self.pt_idx), _p(self.uv), _p(cal), float(calib_tol), _p(cams), _p(pts),
+                                                          C.byref(self._h)))
+        else:
+            self.K4 = np.ascontiguousarray(K4, np.float32).reshape(-1, 4)
+            if self.K4.shape[0] != self.n_cam:
+                raise ValueError("inconsistent BA array sizes")
+            check(lib().esfm_ba_problem_create(self.ctx.handle, self.n_cam, self.n_pt, self.n_obs, _p(self.cam_idx), _p(self.pt_idx),
+                                               _p(self.uv), _p(self.K4), _p(cams), _p(pts), C.byref(self._h)))
+        if ref_cam >= 0:
+            self.fix_camera(ref_cam, ref_threshold)
+
+    def fix_camera(self, cam: int, threshold: float = 1e-10) -> None:
+        """Hold camera `cam` inside [-threshold, threshold]^6 (the reference frame, ba.cpp:134, :155-162); cam < 0 releases."""
+        check(lib().esfm_ba_problem_fix_camera(self._h, int(cam), float(threshold)))
+
+    def set_calib(self, calib, calib_tol: float) -> None:
+        cal = np.ascontiguousarray(calib, np.float64).reshape(4)
+        check(lib().esfm_ba_problem_set_calib(self._h, _p(cal), float(calib_tol)))
+
+    def get_calib(self) -> np.ndarray:
+        cal = np.empty(4, np.float64)
+        check(lib().esfm_ba_problem_get_calib(self._h, _p(cal)))
+        return cal
 
     def set_params(self, cams, pts) -> None:
         cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 6); pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
@@ -116,6 +145,28 @@ def ba_solve(cam_idx, pt_idx, uv, K4, cams, pts, options: Optional[BAOptions] = 
     finally:
         prob.close()
     return c, p, summ
+
+
+def ba_solve_ex(cam_idx, pt_idx, uv, K4, cams, pts, calib=None, calib_tol: float = 0.0, ref_cam: int = -1,
+                ref_threshold: float = 1e-10, options: Optional[BAOptions] = None, ctx: Optional[Context] = None, allreduce=None):
+    """solveBA with the optional free intrinsics / reference camera (esfm_ba_solve_ex).
+    Returns (cams, pts, calib or None, summary)."""
+    prob = BAProblem(cam_idx, pt_idx, uv, K4, cams, pts, ctx, calib=calib, calib_tol=calib_tol, ref_cam=ref_cam,
+                     ref_threshold=ref_threshold)
+    try:
+        summ = prob.solve(options, allreduce)
+        c, p = prob.get_params()
+        k = prob.get_calib() if prob.free_calib else None
+    finally:
+        prob.close()
+    return c, p, k, summ
+
+
+def line_search_next_step(f0: float, g0: float, prev, cur) -> float:
+    """Host-only: next Armijo trial step (esfm_ba_line_search_next_step); prev / cur = (x, f, g) or None."""
+    xp, fp, gp = prev if prev is not None else (0.0, 0.0, 0.0)
+    xc, fc, gc = cur if cur is not None else (0.0, 0.0, 0.0)
+    return float(lib().esfm_ba_line_search_next_step(f0, g0, xp, fp, gp, int(prev is not None), xc, fc, gc, int(cur is not None)))
 
 
 def shard_points(n_pt: int, pt_idx, world: int) -> np.ndarray:
@@ -240,18 +291,21 @@ class BundleAdjustment:
         return 2 * self.num_observations_ > self.num_parameters_   # "Ready to solve" (:120-129)
 
     def solveBA(self, fix_calib_tolerance_BA: float = 0.0) -> bool:
-        """ba.cpp:132-212 with calibration fixed (the only mode every BASELINE config uses)."""
-        if fix_calib_tolerance_BA != 0 or self.ref_process_camera_id_ >= 0:
-            raise NotImplementedError("free-intrinsics / fixed-reference-camera BA (ba.cpp:155-196, run_zurich.sh only) "
-                                      "is the 'next' row f-4 of SURVEY.md section 8 and is not built yet")
+        """ba.cpp:132-212: fixed intrinsics (:142-164) or the shared free intrinsics bounded to +-tolerance (:167-196);
+        the reference frame, if one was named in setBAProblem, is bounded to +-1e-10 (:134, :155-162)."""
+        fixed_threshold = 1e-10   # ba.cpp:134
         nc, npt = self.num_cameras_, self.num_points_
         K4 = np.array([[K[0, 0], K[0, 2], K[1, 1], K[1, 2]] for K in self.calibs_], np.float32).reshape(-1, 4)
         cams = self.parameters_[:6 * nc].reshape(nc, 6)
         pts = self.parameters_[6 * nc:6 * nc + 3 * npt].reshape(npt, 3)
-        c, p, summ = ba_solve(self.camera_index_, self.point_index_, self.points_2d_, K4, cams, pts, self.options,
-                              self._ctx or default_context())
+        calib = self.parameters_[-4:].copy() if fix_calib_tolerance_BA != 0 else None
+        c, p, k, summ = ba_solve_ex(self.camera_index_, self.point_index_, self.points_2d_, K4, cams, pts, calib=calib,
+                                    calib_tol=float(fix_calib_tolerance_BA), ref_cam=self.ref_process_camera_id_,
+                                    ref_threshold=fixed_threshold, options=self.options, ctx=self._ctx or default_context())
         self.parameters_[:6 * nc] = c.reshape(-1)
         self.parameters_[6 * nc:6 * nc + 3 * npt] = p.reshape(-1)
+        if k is not None:
+            self.parameters_[-4:] = k
         self.summary = summ
         return True
 
@@ -271,6 +325,10 @@ class BundleAdjustment:
             pose[:3, 3] = self.parameters_[6 * k + 3:6 * k + 6].astype(np.float32)      # :244-246
             fr.pose_cam = pose
             k += 1
+            if fix_calib_tolerance_BA != 0:                                            # :250-256 (float K_cam)
+                K = np.array(fr.K_cam, np.float32, copy=True)
+                K[0, 0], K[0, 2], K[1, 1], K[1, 2] = self.parameters_[-4:].astype(np.float32)
+                fr.K_cam = K
         nc, npt = self.num_cameras_, self.num_points_
         sfm_sparse_points.xyz = self.parameters_[6 * nc:6 * nc + 3 * npt].reshape(npt, 3).astype(np.float32)  # :277-279
         return True

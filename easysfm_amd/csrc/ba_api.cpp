@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ba_kernels.hpp"
+#include "ba_linesearch.hpp"
 
 using esfm::BADev;
 
@@ -19,8 +20,12 @@ struct esfm_ba_problem {
     esfm_ctx *ctx = nullptr;
     BADev d;
     std::vector<void *> allocs;
-    std::vector<double> cam_nobs_local;  // this rank's observation count per camera
+    std::vector<double> cam_nobs_local;  // this rank's observation count per camera-side block
     bool params_swapped = false;
+    // box bounds (reference ba.cpp:155-162 reference camera, ba.cpp:190-194 intrinsics); +-inf where there is none
+    int ref_cam = -1;
+    double ref_threshold = 0.0;
+    double calib_center[4] = {0, 0, 0, 0}, calib_tol = 0.0;
 };
 
 namespace {
@@ -79,7 +84,7 @@ struct Solver {
     int fetch_scal()
     {
         if (int rc = allreduce(P->d.scal, esfm::SC_SUM_COUNT, ESFM_REDUCE_SUM)) return rc;
-        if (int rc = allreduce(P->d.scal + esfm::SC_GMAX, 1, ESFM_REDUCE_MAX)) return rc;
+        if (int rc = allreduce(P->d.scal + esfm::SC_GMAX, esfm::SC_MAX_COUNT, ESFM_REDUCE_MAX)) return rc;
         ESFM_HIP_TRY(hipMemcpyAsync(h, P->d.scal, sizeof(double) * esfm::SC_COUNT, hipMemcpyDeviceToHost, st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         return ESFM_OK;
@@ -104,26 +109,26 @@ int fill_ones(hipStream_t st, double *dst, size_t n)
     return ESFM_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-void esfm_ba_options_default(esfm_ba_options *opt) { if (opt) options_default(opt); }
-
-int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
-                           const float *obs_uv, const float *K4_per_cam, const double *cams, const double *pts,
-                           esfm_ba_problem **out)
+// calib == NULL: fixed per-camera intrinsics K4_per_cam; else the shared free block fx, cx, fy, cy, carried as one more
+// 6-wide camera-side block behind the n_real cameras (ba_kernels.hpp).
+int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
+                const float *obs_uv, const float *K4_per_cam, const double *calib, double calib_tol, const double *cams,
+                const double *pts, esfm_ba_problem **out)
 {
     if (!ctx || !out) { esfm::set_error("ctx/out is NULL"); return ESFM_ERR_INVALID_ARG; }
     *out = nullptr;
-    ESFM_REQUIRE(n_cam >= 0 && n_pt >= 0 && n_obs >= 0, "negative size");
+    ESFM_REQUIRE(n_real >= 0 && n_pt >= 0 && n_obs >= 0, "negative size");
     ESFM_REQUIRE(n_obs == 0 || (cam_idx && pt_idx && obs_uv), "observation arrays are NULL");
-    ESFM_REQUIRE(n_cam == 0 || (K4_per_cam && cams), "camera arrays are NULL");
+    ESFM_REQUIRE(n_real == 0 || ((K4_per_cam || calib) && cams), "camera arrays are NULL");
     ESFM_REQUIRE(n_pt == 0 || pts, "pts is NULL");
+    // Ceres rejects a variable block whose lower bound is not below its upper bound (Program::IsFeasible)
+    ESFM_REQUIRE(!calib || calib_tol > 0.0, "intrinsics tolerance must be positive");
+    if (calib) for (int i = 0; i < 4; ++i) if (!std::isfinite(calib[i])) { esfm::set_error("non-finite intrinsics"); return ESFM_ERR_NUMERIC; }
+    const int n_cam = n_real + (calib ? 1 : 0);   // 6-wide blocks of the reduced system
     ESFM_REQUIRE((int64_t)6 * n_cam < 46000, "reduced system too large for this build (6 n_cam < 46000)");
     for (int k = 0; k < n_obs; ++k)
-        ESFM_REQUIRE(cam_idx[k] >= 0 && cam_idx[k] < n_cam && pt_idx[k] >= 0 && pt_idx[k] < n_pt, "observation index out of range");
-    for (size_t i = 0; i < (size_t)6 * n_cam; ++i) if (!std::isfinite(cams[i])) { esfm::set_error("non-finite camera parameter"); return ESFM_ERR_NUMERIC; }
+        ESFM_REQUIRE(cam_idx[k] >= 0 && cam_idx[k] < n_real && pt_idx[k] >= 0 && pt_idx[k] < n_pt, "observation index out of range");
+    for (size_t i = 0; i < (size_t)6 * n_real; ++i) if (!std::isfinite(cams[i])) { esfm::set_error("non-finite camera parameter"); return ESFM_ERR_NUMERIC; }
     for (size_t i = 0; i < (size_t)3 * n_pt; ++i) if (!std::isfinite(pts[i])) { esfm::set_error("non-finite point parameter"); return ESFM_ERR_NUMERIC; }
     if (int rc = esfm::set_device(ctx)) return rc;
 
@@ -139,6 +144,11 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     auto P = new esfm_ba_problem();
     P->ctx = ctx;
     P->cam_nobs_local.assign((size_t)n_cam, 0.0);
+    if (calib) {
+        P->cam_nobs_local[(size_t)n_real] = (double)n_obs;   // every observation involves the intrinsics block
+        for (int i = 0; i < 4; ++i) P->calib_center[i] = calib[i];
+        P->calib_tol = calib_tol;
+    }
     for (int t = 0; t < n_obs; ++t) {
         const int k = order[(size_t)t];
         s_cam[(size_t)t] = cam_idx[k]; s_pt[(size_t)t] = pt_idx[k];
@@ -147,10 +157,13 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     }
     BADev &d = P->d;
     d.n_cam = n_cam; d.n_pt = n_pt; d.n_obs = n_obs;
+    d.n_real_cam = n_real; d.has_calib = calib ? 1 : 0;
     const size_t no = (size_t)n_obs, nc6 = (size_t)6 * n_cam, np3 = (size_t)3 * n_pt;
     int rc = ESFM_OK;
     auto A = [&](auto **ptr, size_t count) { if (rc == ESFM_OK) rc = dev_alloc(P, ptr, count); };
-    A(&d.obs_cam, no); A(&d.obs_pt, no); A(&d.obs_uv, no); A(&d.pt_start, (size_t)n_pt + 1); A(&d.K4, (size_t)n_cam);
+    A(&d.obs_cam, no); A(&d.obs_pt, no); A(&d.obs_uv, no); A(&d.pt_start, (size_t)n_pt + 1); A(&d.K4, (size_t)n_real);
+    if (calib) A(&d.Jk, 4 * no);
+    A(&d.lo_c, nc6); A(&d.up_c, nc6); A(&d.delta_c, nc6); A(&d.delta_p, np3);
     A(&d.cam_nobs, (size_t)n_cam);
     A(&d.x_c, nc6); A(&d.x_p, np3); A(&d.cand_c, nc6); A(&d.cand_p, np3); A(&d.x0_p, np3);
     A(&d.Jc, 12 * no); A(&d.Jp, 6 * no); A(&d.res, 2 * no);
@@ -197,25 +210,94 @@ int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const 
     };
     up(d.obs_cam, s_cam.data(), sizeof(int32_t) * no); up(d.obs_pt, s_pt.data(), sizeof(int32_t) * no);
     up(d.obs_uv, s_uv.data(), sizeof(float) * 2 * no); up(d.pt_start, pt_start.data(), sizeof(int32_t) * ((size_t)n_pt + 1));
-    up(d.K4, K4_per_cam, sizeof(float) * 4 * (size_t)n_cam);
+    if (!calib) up(d.K4, K4_per_cam, sizeof(float) * 4 * (size_t)n_real);
+    const double calib_block[6] = {calib ? calib[0] : 0.0, calib ? calib[1] : 0.0, calib ? calib[2] : 0.0, calib ? calib[3] : 0.0, 0.0, 0.0};
+    if (calib) up(d.x_c + 6 * (size_t)n_real, calib_block, sizeof(calib_block));
     if (d.n_chunks) {
         up(d.slot_obs, slot_obs.data(), sizeof(int32_t) * slot_obs.size());
         up(d.chunk_slot, chunk_slot.data(), sizeof(int32_t) * chunk_slot.size());
         up(d.chunk_cam0, chunk_cam0.data(), sizeof(int32_t) * chunk_cam0.size());
     }
-    up(d.x_c, cams, sizeof(double) * nc6); up(d.x_p, pts, sizeof(double) * np3);
+    up(d.x_c, cams, sizeof(double) * 6 * (size_t)n_real); up(d.x_p, pts, sizeof(double) * np3);
     if (rc == ESFM_OK && hipStreamSynchronize(st) != hipSuccess) { esfm::set_error("stream sync failed"); rc = ESFM_ERR_HIP; }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     *out = P;
     return ESFM_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+void esfm_ba_options_default(esfm_ba_options *opt) { if (opt) options_default(opt); }
+
+int esfm_ba_problem_create(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
+                           const float *obs_uv, const float *K4_per_cam, const double *cams, const double *pts,
+                           esfm_ba_problem **out)
+{
+    if (n_cam > 0 && !K4_per_cam) { esfm::set_error("K4_per_cam is NULL"); return ESFM_ERR_INVALID_ARG; }
+    return create_impl(ctx, n_cam, n_pt, n_obs, cam_idx, pt_idx, obs_uv, K4_per_cam, nullptr, 0.0, cams, pts, out);
+}
+
+int esfm_ba_problem_create_free_calib(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx,
+                                      const float *obs_uv, const double *calib4, double calib_tolerance, const double *cams,
+                                      const double *pts, esfm_ba_problem **out)
+{
+    if (!calib4) { esfm::set_error("calib4 is NULL"); return ESFM_ERR_INVALID_ARG; }
+    return create_impl(ctx, n_cam, n_pt, n_obs, cam_idx, pt_idx, obs_uv, nullptr, calib4, calib_tolerance, cams, pts, out);
+}
+
+int esfm_ba_problem_set_calib(esfm_ba_problem *P, const double *calib4, double calib_tolerance)
+{
+    if (!P || !calib4) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    ESFM_REQUIRE(P->d.has_calib, "problem was created with fixed intrinsics");
+    ESFM_REQUIRE(calib_tolerance > 0.0, "intrinsics tolerance must be positive");
+    for (int i = 0; i < 4; ++i) if (!std::isfinite(calib4[i])) { esfm::set_error("non-finite intrinsics"); return ESFM_ERR_NUMERIC; }
+    if (int rc = esfm::set_device(P->ctx)) return rc;
+    for (int i = 0; i < 4; ++i) P->calib_center[i] = calib4[i];
+    P->calib_tol = calib_tolerance;
+    ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_c + 6 * (size_t)P->d.n_real_cam, calib4, sizeof(double) * 4, hipMemcpyHostToDevice, P->ctx->stream));
+    ESFM_HIP_TRY(hipStreamSynchronize(P->ctx->stream));
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_get_calib(esfm_ba_problem *P, double *calib4)
+{
+    if (!P || !calib4) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    ESFM_REQUIRE(P->d.has_calib, "problem was created with fixed intrinsics");
+    if (int rc = esfm::set_device(P->ctx)) return rc;
+    ESFM_HIP_TRY(hipMemcpyAsync(calib4, P->d.x_c + 6 * (size_t)P->d.n_real_cam, sizeof(double) * 4, hipMemcpyDeviceToHost, P->ctx->stream));
+    ESFM_HIP_TRY(hipStreamSynchronize(P->ctx->stream));
+    return ESFM_OK;
+}
+
+int esfm_ba_problem_fix_camera(esfm_ba_problem *P, int cam, double threshold)
+{
+    if (!P) { esfm::set_error("problem is NULL"); return ESFM_ERR_INVALID_ARG; }
+    ESFM_REQUIRE(cam < P->d.n_real_cam, "camera index out of range");
+    ESFM_REQUIRE(cam < 0 || threshold > 0.0, "threshold must be positive");
+    P->ref_cam = cam < 0 ? -1 : cam;
+    P->ref_threshold = cam < 0 ? 0.0 : threshold;
+    return ESFM_OK;
+}
+
+double esfm_ba_line_search_next_step(double f0, double g0, double x_prev, double f_prev, double g_prev, int prev_valid,
+                                     double x_cur, double f_cur, double g_cur, int cur_valid)
+{
+    namespace ls = esfm::linesearch;
+    ls::Sample ini, prev, cur;
+    ini.x = 0.0; ini.f = f0; ini.g = g0; ini.valid = true;
+    prev.x = x_prev; prev.f = f_prev; prev.g = g_prev; prev.valid = prev_valid != 0;
+    cur.x = x_cur; cur.f = f_cur; cur.g = g_cur; cur.valid = cur_valid != 0;
+    return ls::next_step(ini, prev, cur);
+}
+
 int esfm_ba_problem_set_params(esfm_ba_problem *P, const double *cams, const double *pts)
 {
-    if (!P || (!cams && P->d.n_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    if (!P || (!cams && P->d.n_real_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(P->ctx)) return rc;
     hipStream_t st = P->ctx->stream;
-    if (P->d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_c, cams, sizeof(double) * 6 * (size_t)P->d.n_cam, hipMemcpyHostToDevice, st));
+    if (P->d.n_real_cam) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_c, cams, sizeof(double) * 6 * (size_t)P->d.n_real_cam, hipMemcpyHostToDevice, st));
     if (P->d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_p, pts, sizeof(double) * 3 * (size_t)P->d.n_pt, hipMemcpyHostToDevice, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
@@ -223,10 +305,10 @@ int esfm_ba_problem_set_params(esfm_ba_problem *P, const double *cams, const dou
 
 int esfm_ba_problem_get_params(esfm_ba_problem *P, double *cams, double *pts)
 {
-    if (!P || (!cams && P->d.n_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
+    if (!P || (!cams && P->d.n_real_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(P->ctx)) return rc;
     hipStream_t st = P->ctx->stream;
-    if (P->d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(cams, P->d.x_c, sizeof(double) * 6 * (size_t)P->d.n_cam, hipMemcpyDeviceToHost, st));
+    if (P->d.n_real_cam) ESFM_HIP_TRY(hipMemcpyAsync(cams, P->d.x_c, sizeof(double) * 6 * (size_t)P->d.n_real_cam, hipMemcpyDeviceToHost, st));
     if (P->d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(pts, P->d.x_p, sizeof(double) * 3 * (size_t)P->d.n_pt, hipMemcpyDeviceToHost, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
@@ -286,9 +368,29 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         std::vector<int32_t> ps((size_t)d.n_pt + 1);
         ESFM_HIP_TRY(hipMemcpyAsync(ps.data(), d.pt_start, sizeof(int32_t) * ((size_t)d.n_pt + 1), hipMemcpyDeviceToHost, st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
-        for (double v : cn) sum->num_active_cameras += v > 0.0;
+        for (int c = 0; c < d.n_real_cam; ++c) sum->num_active_cameras += cn[(size_t)c] > 0.0;
         for (int p = 0; p < d.n_pt; ++p) sum->num_active_points += ps[(size_t)p + 1] > ps[(size_t)p];
+        // box bounds, only on blocks that take part in the problem (Ceres drops unused blocks with their bounds)
+        std::vector<double> lo((size_t)6 * d.n_cam, -INFINITY), up((size_t)6 * d.n_cam, INFINITY);
+        d.constrained = 0;
+        if (P->ref_cam >= 0 && cn[(size_t)P->ref_cam] > 0.0) {
+            for (int i = 0; i < 6; ++i) { lo[6 * (size_t)P->ref_cam + i] = -P->ref_threshold; up[6 * (size_t)P->ref_cam + i] = P->ref_threshold; }
+            d.constrained = 1;
+        }
+        if (d.has_calib && cn[(size_t)d.n_real_cam] > 0.0) {
+            for (int i = 0; i < 4; ++i) {
+                lo[6 * (size_t)d.n_real_cam + i] = P->calib_center[i] - P->calib_tol;
+                up[6 * (size_t)d.n_real_cam + i] = P->calib_center[i] + P->calib_tol;
+            }
+            d.constrained = 1;
+        }
+        if (d.n_cam) {
+            ESFM_HIP_TRY(hipMemcpyAsync(d.lo_c, lo.data(), sizeof(double) * lo.size(), hipMemcpyHostToDevice, st));
+            ESFM_HIP_TRY(hipMemcpyAsync(d.up_c, up.data(), sizeof(double) * up.size(), hipMemcpyHostToDevice, st));
+            ESFM_HIP_TRY(hipStreamSynchronize(st));
+        }
     }
+    const bool constrained = d.constrained != 0;
 
     const auto t0 = std::chrono::steady_clock::now();
     auto finish = [&](int rc) {
@@ -299,6 +401,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     // ---- iteration 0 (TrustRegionMinimizer::IterationZero) ----
     double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
     if (int rc = S.zero_scal()) return finish(rc);
+    if (constrained) { if (int rc = esfm::ba_project_cameras(st, d)) return finish(rc); }   // x <- Plus(x, 0)
     if (int rc = esfm::ba_param_sqnorm(st, d)) return finish(rc);
     if (int rc = S.linearize(false, radius)) return finish(rc);
     if (opt.jacobi_scaling) {
@@ -355,6 +458,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         {
             esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SCHUR);
             if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap)) return finish(rc);
+            if (int rc = esfm::ba_schur_calib(st, d)) return finish(rc);
         }
         if (int rc = S.allreduce(d.red, (int64_t)esfm::ba_red_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
         {
@@ -363,12 +467,13 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         }
         if (int rc = esfm::ba_camera_step(st, d)) return finish(rc);
         if (int rc = esfm::ba_backsub(st, d)) return finish(rc);
-        if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD)) return finish(rc);
+        // the candidate at full step; bounded problems also need the slope there for the line search
+        if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, constrained)) return finish(rc);
         if (int rc = S.fetch_scal()) return finish(rc);
         reuse_diagonal = true;
         const double model_cost_change = h[esfm::SC_MODEL_CHANGE];
-        const double step_norm = std::sqrt(h[esfm::SC_STEP_SQ_PT] + h[esfm::SC_STEP_SQ_CAM]);
-        const double cand_norm = std::sqrt(h[esfm::SC_CAND_SQ_PT] + h[esfm::SC_CAND_SQ_CAM]);
+        double step_norm = std::sqrt(h[esfm::SC_STEP_SQ_PT] + h[esfm::SC_STEP_SQ_CAM]);
+        double cand_norm = std::sqrt(h[esfm::SC_CAND_SQ_PT] + h[esfm::SC_CAND_SQ_CAM]);
         const bool lin_ok = h[esfm::SC_CHOL_FAIL] == 0.0 && h[esfm::SC_PT_SINGULAR] == 0.0 && std::isfinite(model_cost_change) &&
                             std::isfinite(step_norm);
         cur.model_cost_change = model_cost_change;
@@ -384,6 +489,41 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             continue;
         }
         n_invalid = 0;
+        if (constrained) {
+            // TrustRegionMinimizer::DoLineSearch: Armijo search from step size 1 along delta; every trial is one
+            // take-step + cost-with-slope pass over the observations and one scalar read-back.
+            namespace ls = esfm::linesearch;
+            const double g0 = h[esfm::SC_GDOTD], dmax = h[esfm::SC_DMAX];
+            auto sample_from_h = [&](double x) {
+                ls::Sample s;
+                s.x = x; s.f = h[esfm::SC_CAND_COST]; s.g = h[esfm::SC_LS_GRAD];
+                s.valid = h[esfm::SC_CAND_BAD] == 0.0 && std::isfinite(s.f) && std::isfinite(s.g);
+                return s;
+            };
+            auto evaluate_at = [&](double t, bool slope) -> int {
+                if (int rc = S.zero_scal()) return rc;
+                if (int rc = esfm::ba_take_step(st, d, t)) return rc;
+                if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, slope)) return rc;
+                return S.fetch_scal();
+            };
+            ls::Sample initial, previous, current = sample_from_h(1.0);
+            initial.x = 0.0; initial.f = x_cost; initial.g = g0; initial.valid = true;
+            int ls_it = 0;
+            bool ls_ok = true;
+            while (!current.valid || current.f > x_cost + ls::kSufficientDecrease * g0 * current.x) {
+                if (++ls_it >= ls::kMaxIterations) { ls_ok = false; break; }
+                const double t = ls::next_step(initial, previous, current);
+                if (t * dmax < ls::kMinStepSize) { ls_ok = false; break; }
+                previous = current;
+                if (int rc = evaluate_at(t, true)) return finish(rc);
+                current = sample_from_h(t);
+            }
+            cur.line_search_steps = ls_it;
+            // a failed search leaves delta as it was: back to the full step
+            if (!ls_ok && current.x != 1.0) { if (int rc = evaluate_at(1.0, false)) return finish(rc); }
+            step_norm = std::sqrt(h[esfm::SC_STEP_SQ_PT] + h[esfm::SC_STEP_SQ_CAM]);
+            cand_norm = std::sqrt(h[esfm::SC_CAND_SQ_PT] + h[esfm::SC_CAND_SQ_CAM]);
+        }
         const double cand_cost = h[esfm::SC_CAND_BAD] > 0.0 ? DBL_MAX : h[esfm::SC_CAND_COST];
         cur.step_norm = step_norm;
         cur.cost_change = x_cost - cand_cost;
@@ -454,6 +594,24 @@ int esfm_ba_solve(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *
     int rc = esfm_ba_problem_solve(P, options, allreduce, allreduce_user, summary);
     if (rc == ESFM_OK || rc == ESFM_ERR_NUMERIC) {
         const int rc2 = esfm_ba_problem_get_params(P, cams, pts);
+        if (rc == ESFM_OK) rc = rc2;
+    }
+    esfm_ba_problem_destroy(P);
+    return rc;
+}
+
+int esfm_ba_solve_ex(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                     const float *K4_per_cam, double *cams, double *pts, double *calib4, double calib_tolerance, int ref_cam,
+                     double ref_threshold, const esfm_ba_options *options, esfm_allreduce_fn allreduce, void *allreduce_user,
+                     esfm_ba_summary *summary)
+{
+    esfm_ba_problem *P = nullptr;
+    if (int rc = create_impl(ctx, n_cam, n_pt, n_obs, cam_idx, pt_idx, obs_uv, K4_per_cam, calib4, calib_tolerance, cams, pts, &P)) return rc;
+    int rc = esfm_ba_problem_fix_camera(P, ref_cam, ref_threshold);
+    if (rc == ESFM_OK) rc = esfm_ba_problem_solve(P, options, allreduce, allreduce_user, summary);
+    if (rc == ESFM_OK || rc == ESFM_ERR_NUMERIC) {
+        int rc2 = esfm_ba_problem_get_params(P, cams, pts);
+        if (rc2 == ESFM_OK && calib4) rc2 = esfm_ba_problem_get_calib(P, calib4);
         if (rc == ESFM_OK) rc = rc2;
     }
     esfm_ba_problem_destroy(P);

@@ -130,6 +130,46 @@ __device__ __forceinline__ void transform_point(const double *__restrict__ cam, 
     p[0] += cam[3]; p[1] += cam[4]; p[2] += cam[5];
 }
 
+// fx, cx, fy, cy of camera c: the camera's float calibration (ba.h:142-143), or the shared free block, which is
+// stored behind the real cameras of the camera-side parameter vector `cams` (ba.h:199-202).
+__device__ __forceinline__ void load_intrinsics(const BADev &d, const double *__restrict__ cams, int c, double in4[4])
+{
+    if (d.has_calib) {
+        const double *kp = cams + 6 * (size_t)d.n_real_cam;
+        in4[0] = kp[0]; in4[1] = kp[1]; in4[2] = kp[2]; in4[3] = kp[3];
+    } else {
+        const float4 K = d.K4[c];
+        in4[0] = (double)K.x; in4[1] = (double)K.y; in4[2] = (double)K.z; in4[3] = (double)K.w;
+    }
+}
+
+// Residual and analytic Jacobian of the reprojection functor (ba.h:113-153 / 170-216) at (cam, X):
+// r = uv - (x fx + cx, y fy + cy), x = p0/p2, y = p1/p2, p = R(a) X + t.  Jc[2][6], Jp[2][3]; xn, yn = x, y.
+__device__ __forceinline__ void reproject_jac(const double cam[6], const double X[3], const double in4[4], float2 uv,
+                                              double &r0, double &r1, double Jc[12], double Jp[6], double &xn, double &yn)
+{
+    double pt[3], R[9], Ja[9];
+    transform_point<true>(cam, X, pt, R, Ja);
+    const double iz = 1.0 / pt[2];
+    const double x = pt[0] * iz, y = pt[1] * iz;
+    const double fx = in4[0], cx = in4[1], fy = in4[2], cy = in4[3];
+    r0 = (double)uv.x - (x * fx + cx);
+    r1 = (double)uv.y - (y * fy + cy);
+    // d r / d p  (rows)
+    const double g0[3] = {-fx * iz, 0.0, fx * x * iz};
+    const double g1[3] = {0.0, -fy * iz, fy * y * iz};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Jc[j] = g0[0] * Ja[j] + g0[1] * Ja[3 + j] + g0[2] * Ja[6 + j];
+        Jc[6 + j] = g1[0] * Ja[j] + g1[1] * Ja[3 + j] + g1[2] * Ja[6 + j];
+        Jc[3 + j] = g0[j];
+        Jc[9 + j] = g1[j];
+        Jp[j] = g0[0] * R[j] + g0[1] * R[3 + j] + g0[2] * R[6 + j];
+        Jp[3 + j] = g1[0] * R[j] + g1[1] * R[3 + j] + g1[2] * R[6 + j];
+    }
+    xn = x; yn = y;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Jacobian sweep.  PRIV: per-camera sums go through an LDS-private copy first (n_cam * 27 doubles),
 // so global f64 atomics are one per camera entry per workgroup instead of 27 per observation.
@@ -148,46 +188,36 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
         __syncthreads();
     }
     double cost = 0.0, bad = 0.0;
+    double kacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
         const int c = d.obs_cam[k], p = d.obs_pt[k];
         const float2 uv = d.obs_uv[k];
-        const float4 K = d.K4[c];
-        double cam[6], X[3], pt[3], R[9], Ja[9];
+        double in4[4];
+        load_intrinsics(d, d.x_c, c, in4);
+        double cam[6], X[3];
 #pragma unroll
         for (int i = 0; i < 6; ++i) cam[i] = d.x_c[6 * (size_t)c + i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) X[i] = d.x_p[3 * (size_t)p + i];
-        transform_point<true>(cam, X, pt, R, Ja);
-        const double iz = 1.0 / pt[2];
-        const double x = pt[0] * iz, y = pt[1] * iz;
-        const double fx = (double)K.x, cx = (double)K.y, fy = (double)K.z, cy = (double)K.w;
-        double r0 = (double)uv.x - (x * fx + cx);
-        double r1 = (double)uv.y - (y * fy + cy);
-        // d r / d p  (rows)
-        const double g0[3] = {-fx * iz, 0.0, fx * x * iz};
-        const double g1[3] = {0.0, -fy * iz, fy * y * iz};
-        double Jc[12], Jp[6];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Jc[j] = g0[0] * Ja[j] + g0[1] * Ja[3 + j] + g0[2] * Ja[6 + j];
-            Jc[6 + j] = g1[0] * Ja[j] + g1[1] * Ja[3 + j] + g1[2] * Ja[6 + j];
-            Jc[3 + j] = g0[j];
-            Jc[9 + j] = g1[j];
-            Jp[j] = g0[0] * R[j] + g0[1] * R[3 + j] + g0[2] * R[6 + j];
-            Jp[3 + j] = g1[0] * R[j] + g1[1] * R[3 + j] + g1[2] * R[6 + j];
-        }
+        double r0, r1, Jc[12], Jp[6], xn, yn;
+        reproject_jac(cam, X, in4, uv, r0, r1, Jc, Jp, xn, yn);
+        // intrinsics columns (ba.h:199-206): u = x fx + cx, v = y fy + cy
+        double Jk[4] = {-xn, -1.0, -yn, -1.0};
         const double s = r0 * r0 + r1 * r1;
         bool fin = isfinite(s);
 #pragma unroll
         for (int i = 0; i < 12; ++i) fin = fin && isfinite(Jc[i]);
 #pragma unroll
         for (int i = 0; i < 6; ++i) fin = fin && isfinite(Jp[i]);
+        fin = fin && isfinite(xn) && isfinite(yn);
         if (!fin) {
             bad += 1.0; r0 = r1 = 0.0;
 #pragma unroll
             for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Jk[i] = 0.0;
         } else {
             double rho0, rho1;
             loss_eval(cauchy_a, s, rho0, rho1);
@@ -204,6 +234,18 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
                 const double sp = use_scaling ? sq * d.scale_p[3 * (size_t)p + i] : sq;
                 Jp[i] *= sp; Jp[3 + i] *= sp;
             }
+            if (d.has_calib) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Jk[i] *= use_scaling ? sq * d.scale_c[6 * (size_t)d.n_real_cam + i] : sq;
+            }
+        }
+        if (d.has_calib) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d.Jk[(size_t)i * n_obs + k] = Jk[i];
+            // G'G (upper triangle of the 4x4: rows fx, cx | fy, cy never mix) and G'r, kept in registers over the sweep
+            kacc[0] += Jk[0] * Jk[0]; kacc[1] += Jk[0] * Jk[1]; kacc[2] += Jk[1] * Jk[1];
+            kacc[3] += Jk[2] * Jk[2]; kacc[4] += Jk[2] * Jk[3]; kacc[5] += Jk[3] * Jk[3];
+            kacc[6] += Jk[0] * r0; kacc[7] += Jk[1] * r0; kacc[8] += Jk[2] * r1; kacc[9] += Jk[3] * r1;
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) d.Jc[(size_t)i * n_obs + k] = Jc[i];
@@ -232,6 +274,23 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
     const double cs = block_sum(cost, red);
     const double bs = block_sum(bad, red);
     if (tid == 0) { atomicAdd(&d.scal[SC_COST], cs); if (bs > 0.0) atomicAdd(&d.scal[SC_LIN_BAD], bs); }
+    if (d.has_calib) {
+        // the intrinsics block's F'F / F'r entries: every observation hits the same 10 sums, so they are reduced
+        // over the workgroup instead of through atomics.  Packed index of (a, b), a <= b: a*6 - a(a-1)/2 + b - a.
+        const int kc = d.n_real_cam;
+        const int slot[10] = {0, 1, 6, 11, 12, 15, 21, 22, 23, 24};
+        const int ra[10] = {0, 0, 1, 2, 2, 3, 0, 1, 2, 3}, rb[10] = {0, 1, 1, 2, 3, 3, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const double v = block_sum(kacc[q], red);
+            if (tid != 0) continue;
+            if (PRIV) priv[kc * 27 + slot[q]] += v;
+            else if (q < 6) {
+                atomicAdd(&d.camacc[36 * (size_t)kc + 6 * ra[q] + rb[q]], v);
+                if (ra[q] != rb[q]) atomicAdd(&d.camacc[36 * (size_t)kc + 6 * rb[q] + ra[q]], v);
+            } else atomicAdd(&d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)kc + ra[q]], v);
+        }
+    }
     if (PRIV) {
         // one coalesced slab per workgroup; ba_camacc_reduce_kernel sums them in a fixed order
         __syncthreads();
@@ -363,7 +422,15 @@ __global__ void ba_camera_gradient_kernel(BADev d)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double g = 0.0;
-    if (i < 6 * d.n_cam) g = fabs(d.camacc[36 * (size_t)d.n_cam + i] / d.scale_c[i]);
+    if (i < 6 * d.n_cam) {
+        g = d.camacc[36 * (size_t)d.n_cam + i] / d.scale_c[i];
+        if (d.constrained) {
+            // bounded problems: norm of x - Plus(x, -gradient)  (trust_region_minimizer.cc, projected gradient step)
+            const double x = d.x_c[i];
+            g = x - fmin(fmax(x - g, d.lo_c[i]), d.up_c[i]);
+        }
+        g = fabs(g);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
     if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], g);
@@ -576,6 +643,98 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d)
     }
 }
 
+// Free intrinsics: the block row of the reduced system that belongs to fx, cx, fy, cy (block index n_real_cam).
+// One thread per point p.  With G_i the intrinsics columns of observation i (2 x 4, two non-zeros per row),
+//   Wk_p = sum_i G_i'E_i (4x3), Yk = Wk_p M^-1:
+//   S[k][k]   -= Yk Wk_p'            rhs[k] -= Wk_p M^-1 E'r
+//   S[k][c_j] -= Yk W_j'  + G_j'F_j  for every observation j of p  (the second term is the F'F cross block)
+// The camera-indexed part goes through an LDS copy of the block row (4 x 6 n_real_cam) when it fits, the 14 sums
+// every point shares through a workgroup reduction; both are then added into d.red.  Runs after ba_schur.
+__global__ __launch_bounds__(256) void ba_schur_calib_kernel(BADev d, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // [8] reduction scratch, then use_lds: [4 * 6 n_real_cam]
+    double *red = sl;
+    double *rowblk = sl + 8;
+    const int tid = threadIdx.x;
+    const int nr = d.n_real_cam, n = 6 * d.n_cam, kap = 6 * nr, roww = 6 * nr;
+    if (use_lds) {
+        for (int e = tid; e < 4 * roww; e += 256) rowblk[e] = 0.0;
+        __syncthreads();
+    }
+    double acc[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) acc[q] = 0.0;
+    const int p = blockIdx.x * 256 + tid;
+    if (p < d.n_pt) {
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        if (e > b) {
+            const size_t no = d.n_obs;
+            double Wk[4][3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) Wk[a][0] = Wk[a][1] = Wk[a][2] = 0.0;
+            for (int k = b; k < e; ++k) {
+                const double k0 = d.Jk[k], k1 = d.Jk[no + k], k2 = d.Jk[2 * no + k], k3 = d.Jk[3 * no + k];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const double e0 = d.Jp[m * no + k], e1 = d.Jp[(3 + m) * no + k];
+                    Wk[0][m] += k0 * e0; Wk[1][m] += k1 * e0; Wk[2][m] += k2 * e1; Wk[3][m] += k3 * e1;
+                }
+            }
+            const double *Mi = d.Minv + 6 * (size_t)p;
+            const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
+            const double ag[3] = {d.Aig[3 * (size_t)p], d.Aig[3 * (size_t)p + 1], d.Aig[3 * (size_t)p + 2]};
+            double Yk[4][3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) Yk[a][m] = Wk[a][0] * M[m] + Wk[a][1] * M[3 + m] + Wk[a][2] * M[6 + m];
+                acc[10 + a] = -(Wk[a][0] * ag[0] + Wk[a][1] * ag[1] + Wk[a][2] * ag[2]);
+            }
+            {
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 <= a; ++b2) acc[q++] = -(Yk[a][0] * Wk[b2][0] + Yk[a][1] * Wk[b2][1] + Yk[a][2] * Wk[b2][2]);
+            }
+            for (int k = b; k < e; ++k) {
+                const int c = d.obs_cam[k];
+                const double kk[4] = {d.Jk[k], d.Jk[no + k], d.Jk[2 * no + k], d.Jk[3 * no + k]};
+                double Ej[6];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) Ej[m] = d.Jp[m * no + k];
+#pragma unroll
+                for (int c2 = 0; c2 < 6; ++c2) {
+                    const double f0 = d.Jc[c2 * no + k], f1 = d.Jc[(6 + c2) * no + k];
+                    const double w0 = f0 * Ej[0] + f1 * Ej[3], w1 = f0 * Ej[1] + f1 * Ej[4], w2 = f0 * Ej[2] + f1 * Ej[5];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const double v = (a < 2 ? kk[a] * f0 : kk[a] * f1) - (Yk[a][0] * w0 + Yk[a][1] * w1 + Yk[a][2] * w2);
+                        if (use_lds) atomicAdd(&rowblk[a * roww + 6 * c + c2], v);
+                        else atomicAdd(&d.red[(size_t)(kap + a) * n + 6 * c + c2], v);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        const double v = block_sum(acc[q], red);
+        if (tid != 0 || v == 0.0) continue;
+        if (q >= 10) { atomicAdd(&d.red[(size_t)n * n + kap + (q - 10)], v); continue; }
+        int a = 0, rem = q;
+        while (rem > a) { rem -= a + 1; ++a; }
+        atomicAdd(&d.red[(size_t)(kap + a) * n + kap + rem], v);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int e = tid; e < 4 * roww; e += 256) {
+            const double v = rowblk[e];
+            if (v != 0.0) atomicAdd(&d.red[(size_t)(kap + e / roww) * n + (e % roww)], v);
+        }
+    }
+}
+
 // Sum the per-workgroup slabs (fixed order) and scatter into red = S_schur (n x n) | rhs_corr (n).
 __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const double *__restrict__ slabs, int slab_doubles, int n_slabs)
 {
@@ -741,17 +900,29 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
 __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
 {
     __shared__ double red[8];
-    double ssq = 0.0, csq = 0.0;
+    double ssq = 0.0, csq = 0.0, dmax = 0.0;
     for (int i = threadIdx.x; i < 6 * d.n_cam; i += 256) {
         const bool active = d.cam_nobs[i / 6] > 0.0;
         const double x = d.x_c[i];
-        const double cnd = active ? x + (-d.y_c[i]) * d.scale_c[i] : x;
+        const double dl = active ? (-d.y_c[i]) * d.scale_c[i] : 0.0;
+        double cnd = active ? x + dl : x;
+        if (d.constrained) {
+            // ParameterBlock::Plus projects onto the box (lower bound first) [upstream parameter_block.h]
+            if (active) cnd = fmin(fmax(cnd, d.lo_c[i]), d.up_c[i]);
+            d.delta_c[i] = dl;
+            dmax = fmax(dmax, fabs(dl));
+        }
         d.cand_c[i] = cnd;
         if (active) { const double df = x - cnd; ssq += df * df; csq += cnd * cnd; }
     }
     const double a = block_sum(ssq, red);
     const double b = block_sum(csq, red);
     if (threadIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = a; d.scal[SC_CAND_SQ_CAM] = b; }
+    if (d.constrained) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+        if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
+    }
 }
 
 // Back-substitution, point-parallel variant (one thread per point; fewer, fatter threads: faster below ~1M
@@ -761,7 +932,12 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
 {
     __shared__ double red[8];
     const int p = blockIdx.x * 64 + threadIdx.x;
-    double mc = 0.0, ssq = 0.0, csq = 0.0;
+    double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0;
+    double yk[4] = {0.0, 0.0, 0.0, 0.0};
+    if (d.has_calib) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) yk[a] = d.y_c[6 * d.n_real_cam + a];
+    }
     if (p < d.n_pt) {
         const int b = d.pt_start[p], e = d.pt_start[p + 1];
         const size_t n = d.n_obs;
@@ -775,6 +951,10 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
                 for (int a = 0; a < 6; ++a) {
                     const double yc = d.y_c[6 * c + a];
                     f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
+                }
+                if (d.has_calib) {
+                    f0 += d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+                    f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
                 }
 #pragma unroll
                 for (int a = 0; a < 3; ++a) g[a] -= d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
@@ -791,20 +971,31 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
                     const double sc = -d.y_c[6 * c + a];
                     m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
                 }
+                if (d.has_calib) {
+                    m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+                    m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+                }
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
-                mc -= m0 * (d.res[k] + m0 / 2.0) + m1 * (d.res[n + k] + m1 / 2.0);
+                const double r0 = d.res[k], r1 = d.res[n + k];
+                mc -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
+                gd += m0 * r0 + m1 * r1;
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const double cnd = xp[a] + sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double dl = sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double cnd = xp[a] + dl;
                 const double df = xp[a] - cnd;
                 ssq += df * df; csq += cnd * cnd;
                 d.cand_p[3 * (size_t)p + a] = cnd;
+                if (d.constrained) { d.delta_p[3 * (size_t)p + a] = dl; dmax = fmax(dmax, fabs(dl)); }
             }
         } else {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) d.cand_p[3 * (size_t)p + a] = xp[a];
+            for (int a = 0; a < 3; ++a) {
+                d.cand_p[3 * (size_t)p + a] = xp[a];
+                if (d.constrained) d.delta_p[3 * (size_t)p + a] = 0.0;
+            }
         }
     }
     const double s0 = block_sum(mc, red);
@@ -814,6 +1005,13 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
         atomicAdd(&d.scal[SC_MODEL_CHANGE], s0);
         atomicAdd(&d.scal[SC_STEP_SQ_PT], s1);
         atomicAdd(&d.scal[SC_CAND_SQ_PT], s2);
+    }
+    if (d.constrained) {
+        const double s3 = block_sum(gd, red);
+        if (threadIdx.x == 0) atomicAdd(&d.scal[SC_GDOTD], s3);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+        if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
     }
 }
 
@@ -834,6 +1032,11 @@ __global__ __launch_bounds__(256) void ba_backsub_accum_kernel(BADev d)
         const double yc = d.y_c[6 * c + a];
         f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
     }
+    if (d.has_calib) {
+        const double *yk = d.y_c + 6 * d.n_real_cam;
+        f0 += d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+        f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) atomicAdd(&d.gE[3 * (size_t)p + a], d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1);
 }
@@ -842,7 +1045,7 @@ __global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
 {
     __shared__ double red[8];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    double mc = 0.0, ssq = 0.0, csq = 0.0;
+    double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0;
     if (k < d.n_obs) {
         const size_t n = d.n_obs;
         const int c = d.obs_cam[k], p = d.obs_pt[k];
@@ -857,17 +1060,26 @@ __global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
             const double sc = -d.y_c[6 * c + a];
             m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
         }
+        if (d.has_calib) {
+            const double *yk = d.y_c + 6 * d.n_real_cam;
+            m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+            m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
-        mc = -(m0 * (d.res[k] + m0 / 2.0) + m1 * (d.res[n + k] + m1 / 2.0));
+        const double r0 = d.res[k], r1 = d.res[n + k];
+        mc = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
+        gd = m0 * r0 + m1 * r1;
         if (k == d.pt_start[p]) {   // one writer per point
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const double xp = d.x_p[3 * (size_t)p + a];
-                const double cnd = xp + sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double dl = sp[a] * d.scale_p[3 * (size_t)p + a];
+                const double cnd = xp + dl;
                 const double df = xp - cnd;
                 ssq += df * df; csq += cnd * cnd;
                 d.cand_p[3 * (size_t)p + a] = cnd;
+                if (d.constrained) { d.delta_p[3 * (size_t)p + a] = dl; dmax = fmax(dmax, fabs(dl)); }
             }
         }
     }
@@ -879,36 +1091,110 @@ __global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
         atomicAdd(&d.scal[SC_STEP_SQ_PT], s1);
         atomicAdd(&d.scal[SC_CAND_SQ_PT], s2);
     }
+    if (d.constrained) {
+        const double s3 = block_sum(gd, red);
+        if (threadIdx.x == 0) atomicAdd(&d.scal[SC_GDOTD], s3);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
+        if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
+    }
 }
 
 // Robustified cost 1/2 sum rho(|r|^2) of (cams, pts) over this rank's observations.
+// SLOPE: also d/dt cost(Plus(x, t delta)) at this point = gradient . delta = sum rho' r.(J delta), the derivative
+// the Armijo search's cubic interpolation uses [upstream line_search.cc LineSearchFunction::Evaluate].
+template <bool SLOPE>
 __global__ __launch_bounds__(256) void ba_cost_kernel(BADev d, const double *__restrict__ cams, const double *__restrict__ pts,
                                                       double cauchy_a, int slot, int bad_slot)
 {
     __shared__ double red[8];
-    double cost = 0.0, bad = 0.0;
+    double cost = 0.0, bad = 0.0, slope = 0.0;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < d.n_obs; k += gridDim.x * 256) {
         const int c = d.obs_cam[k], p = d.obs_pt[k];
         const float2 uv = d.obs_uv[k];
-        const float4 K = d.K4[c];
-        double cam[6], X[3], pt[3];
+        double in4[4];
+        load_intrinsics(d, cams, c, in4);
+        double cam[6], X[3];
 #pragma unroll
         for (int i = 0; i < 6; ++i) cam[i] = cams[6 * (size_t)c + i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) X[i] = pts[3 * (size_t)p + i];
-        transform_point<false>(cam, X, pt, nullptr, nullptr);
-        const double x = pt[0] / pt[2], y = pt[1] / pt[2];
-        const double r0 = (double)uv.x - (x * (double)K.x + (double)K.y);
-        const double r1 = (double)uv.y - (y * (double)K.z + (double)K.w);
+        double r0, r1, m0 = 0.0, m1 = 0.0;
+        if (SLOPE) {
+            double Jc[12], Jp[6], xn, yn;
+            reproject_jac(cam, X, in4, uv, r0, r1, Jc, Jp, xn, yn);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { const double dl = d.delta_c[6 * (size_t)c + a]; m0 += Jc[a] * dl; m1 += Jc[6 + a] * dl; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const double dl = d.delta_p[3 * (size_t)p + a]; m0 += Jp[a] * dl; m1 += Jp[3 + a] * dl; }
+            if (d.has_calib) {
+                const double *dk = d.delta_c + 6 * (size_t)d.n_real_cam;
+                m0 -= xn * dk[0] + dk[1];
+                m1 -= yn * dk[2] + dk[3];
+            }
+        } else {
+            double pt[3];
+            transform_point<false>(cam, X, pt, nullptr, nullptr);
+            const double x = pt[0] / pt[2], y = pt[1] / pt[2];
+            r0 = (double)uv.x - (x * in4[0] + in4[1]);
+            r1 = (double)uv.y - (y * in4[2] + in4[3]);
+        }
         const double s = r0 * r0 + r1 * r1;
         if (!isfinite(s)) { bad += 1.0; continue; }
         double rho0, rho1;
         loss_eval(cauchy_a, s, rho0, rho1);
         cost += 0.5 * rho0;
+        if (SLOPE) slope += rho1 * (r0 * m0 + r1 * m1);
     }
     const double cs = block_sum(cost, red);
     const double bs = block_sum(bad, red);
     if (threadIdx.x == 0) { atomicAdd(&d.scal[slot], cs); if (bs > 0.0) atomicAdd(&d.scal[bad_slot], bs); }
+    if (SLOPE) {
+        const double ss = block_sum(slope, red);
+        if (threadIdx.x == 0) atomicAdd(&d.scal[SC_LS_GRAD], ss);
+    }
+}
+
+// candidate = Plus(x, t delta): cameras (projected onto the box) by workgroup 0, points by all; step / candidate norms.
+__global__ __launch_bounds__(256) void ba_take_step_kernel(BADev d, double t)
+{
+    __shared__ double red[8];
+    double ssq = 0.0, csq = 0.0, ssc = 0.0, csc = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * d.n_pt; i += gridDim.x * 256) {
+        const int p = i / 3;
+        const double x = d.x_p[i];
+        if (d.pt_start[p + 1] > d.pt_start[p]) {
+            const double cnd = x + t * d.delta_p[i];
+            const double df = x - cnd;
+            ssq += df * df; csq += cnd * cnd;
+            d.cand_p[i] = cnd;
+        } else d.cand_p[i] = x;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 6 * d.n_cam; i += 256) {
+            const double x = d.x_c[i];
+            if (d.cam_nobs[i / 6] > 0.0) {
+                const double cnd = fmin(fmax(x + t * d.delta_c[i], d.lo_c[i]), d.up_c[i]);
+                const double df = x - cnd;
+                ssc += df * df; csc += cnd * cnd;
+                d.cand_c[i] = cnd;
+            } else d.cand_c[i] = x;
+        }
+    const double a = block_sum(ssq, red);
+    const double b = block_sum(csq, red);
+    const double c = block_sum(ssc, red);
+    const double e = block_sum(csc, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&d.scal[SC_STEP_SQ_PT], a); atomicAdd(&d.scal[SC_CAND_SQ_PT], b);
+        if (blockIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = c; d.scal[SC_CAND_SQ_CAM] = e; }
+    }
+}
+
+// x_c <- projection onto the box (TrustRegionMinimizer::IterationZero: Plus(x, 0))
+__global__ void ba_project_cameras_kernel(BADev d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * d.n_cam && d.cam_nobs[i / 6] > 0.0) d.x_c[i] = fmin(fmax(d.x_c[i], d.lo_c[i]), d.up_c[i]);
 }
 
 // |x|^2 over the parameter blocks that take part in the problem (Ceres drops unused blocks).
@@ -1066,11 +1352,40 @@ int ba_backsub(hipStream_t st, const BADev &d)
     return ESFM_OK;
 }
 
-int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot)
+int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot,
+            bool with_slope)
 {
     if (d.n_obs <= 0) return ESFM_OK;
     const int grid = std::min(div_up(d.n_obs, 256), std::max(1, num_cu) * 8);
-    hipLaunchKernelGGL(ba_cost_kernel, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot);
+    if (with_slope) hipLaunchKernelGGL(ba_cost_kernel<true>, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot);
+    else hipLaunchKernelGGL(ba_cost_kernel<false>, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_take_step(hipStream_t st, const BADev &d, double t)
+{
+    const int grid = std::max(1, std::min(div_up(3LL * d.n_pt, 256), 1024));
+    hipLaunchKernelGGL(ba_take_step_kernel, dim3(grid), dim3(256), 0, st, d, t);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_project_cameras(hipStream_t st, const BADev &d)
+{
+    if (d.n_cam <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_project_cameras_kernel, dim3(div_up(6 * d.n_cam, 256)), dim3(256), 0, st, d);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_schur_calib(hipStream_t st, const BADev &d)
+{
+    if (!d.has_calib || d.n_pt <= 0 || d.n_obs <= 0) return ESFM_OK;
+    const size_t row_bytes = sizeof(double) * (8 + (size_t)4 * 6 * d.n_real_cam);
+    const bool use_lds = row_bytes <= 64 * 1024;
+    const size_t lds = use_lds ? row_bytes : sizeof(double) * 8;
+    hipLaunchKernelGGL(ba_schur_calib_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), lds, st, d, use_lds ? 1 : 0);
     LAUNCH_CHECK();
     return ESFM_OK;
 }

@@ -11,15 +11,27 @@ namespace esfm {
 //   SC_GMAX             : max |gradient| over this rank's points and all cameras  -> MAX all-reduce
 enum BAScalar {
     SC_COST = 0, SC_CAND_COST = 1, SC_MODEL_CHANGE = 2, SC_STEP_SQ_PT = 3, SC_CAND_SQ_PT = 4, SC_XNORM_SQ_PT = 5,
-    SC_LIN_BAD = 6, SC_CAND_BAD = 7, SC_PT_SINGULAR = 8, SC_SUM_COUNT = 12,
+    SC_LIN_BAD = 6, SC_CAND_BAD = 7, SC_PT_SINGULAR = 8,
+    SC_GDOTD = 9,     // gradient . delta = sum_obs r.(J step): initial slope of the Armijo search (bounded problems)
+    SC_LS_GRAD = 10,  // slope of the cost along delta at a line-search trial point
+    SC_SUM_COUNT = 12,
     SC_REPL0 = 12, SC_STEP_SQ_CAM = 12, SC_CAND_SQ_CAM = 13, SC_XNORM_SQ_CAM = 14, SC_CHOL_FAIL = 15,
-    SC_GMAX = 16, SC_COUNT = 24
+    SC_GMAX = 16,     // max |gradient| (projected gradient step with bounds)
+    SC_DMAX = 17,     // max |delta| over this rank's points and all camera-side unknowns
+    SC_MAX_COUNT = 2, SC_COUNT = 24
 };
 
 // Device-resident bundle-adjustment problem.  Observations are sorted by point (CSR), so a
 // point's observations are contiguous: obs k in [pt_start[p], pt_start[p+1]) belongs to point p.
+//
+// Free shared intrinsics (ReprojectErrorTerm_updatecalib, reference ba.h:170-222): the block fx, cx, fy, cy rides as
+// one more 6-wide camera-side block (two padding unknowns with zero Jacobian columns) behind the real cameras, so
+// n_cam = n_real_cam + has_calib is the number of 6-wide blocks of the reduced system and every per-block array
+// (x_c, scale_c, camacc, red, y_c ...) simply has one more block; observations only ever name real cameras.
 struct BADev {
     int n_cam = 0, n_pt = 0, n_obs = 0;
+    int n_real_cam = 0, has_calib = 0;
+    int constrained = 0;          // any box bound on a camera-side unknown (lo_c / up_c hold +-inf elsewhere)
     // structure (static per problem)
     int32_t *obs_cam = nullptr;   // [n_obs] camera of sorted observation k
     int32_t *obs_pt = nullptr;    // [n_obs] point of sorted observation k
@@ -35,6 +47,9 @@ struct BADev {
     double *Jc = nullptr;   // 12 arrays: row 0 cols 0..5, then row 1 cols 0..5
     double *Jp = nullptr;   // 6 arrays: row 0 cols 0..2, row 1 cols 0..2
     double *res = nullptr;  // 2 arrays
+    double *Jk = nullptr;   // has_calib, 4 arrays: d r0/d fx, d r0/d cx, d r1/d fy, d r1/d cy (the other four are 0)
+    double *lo_c = nullptr, *up_c = nullptr;          // box bounds [6 n_cam]
+    double *delta_c = nullptr, *delta_p = nullptr;    // the LM step in parameter units, [6 n_cam], [3 n_pt]
     double *scale_c = nullptr, *scale_p = nullptr;  // Jacobi scaling [6 n_cam], [3 n_pt]
     double *EtE = nullptr;   // [6 n_pt] E'E upper (xx,xy,xz,yy,yz,zz); its diagonal = point column norms
     double *Etr = nullptr;   // [3 n_pt]
@@ -80,9 +95,17 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
 // ba_chol_large_doubles(n_cam) doubles
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
 size_t ba_chol_large_doubles(int n_cam);
+// intrinsics row/column block of the reduced system (has_calib): runs after ba_schur, adds into d.red
+int ba_schur_calib(hipStream_t st, const BADev &d);
 int ba_camera_step(hipStream_t st, const BADev &d);
 int ba_backsub(hipStream_t st, const BADev &d);
-int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot);
+// with_slope: also the derivative of the cost along (delta_c, delta_p) at (cams, pts) into SC_LS_GRAD
+int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot,
+            bool with_slope = false);
+// candidate = Plus(x, t * delta) (projected onto the box) and its norms
+int ba_take_step(hipStream_t st, const BADev &d, double t);
+// x_c <- projection of x_c onto the box
+int ba_project_cameras(hipStream_t st, const BADev &d);
 int ba_param_sqnorm(hipStream_t st, const BADev &d);
 int ba_points_delta(hipStream_t st, const BADev &d, bool to_delta);
 

@@ -90,9 +90,42 @@ def test_rodrigues_roundtrip():
     assert np.allclose(rotation_to_angle_axis(np.eye(3)), 0)
 
 
-def test_unsupported_modes_fail_loudly():
+def test_free_calib_needs_the_gpu_library():
+    """No CPU fallback: without a GPU the free-intrinsics solve raises from the C ABI instead of computing elsewhere."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
     ba = E.BundleAdjustment.__new__(E.BundleAdjustment)
     ba._ctx = None; ba.options = None
     ba.initBA()
-    with pytest.raises(NotImplementedError):
+    ba.parameters_ = np.array([700.0, 380.0, 700.0, 250.0])
+    with pytest.raises(E.EsfmError):
         ba.solveBA(20.0)
+
+
+def test_line_search_step_rule_matches_oracle(oracle_lib):
+    """The Armijo step-length rule (cubic / quintic interpolation, polynomial.cc) is host arithmetic on both sides:
+    product (esfm_ba_line_search_next_step) == oracle on random samples, including invalid trials."""
+    from easysfm_amd.ba import line_search_next_step
+    rng = np.random.default_rng(5)
+    n_poly = 0
+    for it in range(400):
+        f0 = rng.uniform(1, 100); g0 = -rng.uniform(0.1, 50)
+        xc = rng.uniform(1e-3, 1.0)
+        cur = (xc, f0 + rng.uniform(-1, 5) * abs(g0) * xc, rng.uniform(-3, 3) * abs(g0))
+        prev = None
+        if it % 3 == 0:
+            xp = xc / rng.uniform(0.05, 0.6)
+            prev = (xp, f0 + rng.uniform(-1, 5) * abs(g0) * xp, rng.uniform(-3, 3) * abs(g0))
+        if it % 17 == 0:
+            # an invalid trial carries only its step size: both halve it
+            got = E._lib.lib().esfm_ba_line_search_next_step(f0, g0, 0.0, 0.0, 0.0, 0, xc, 0.0, 0.0, 0)
+            ref = oracle_lib.load().esfm_ref_ls_next_step(f0, g0, 0.0, 0.0, 0.0, 0, xc, 0.0, 0.0, 0, 1e-3 * xc, 0.6 * xc)
+            assert got == pytest.approx(0.5 * xc) and ref == pytest.approx(0.5 * xc)
+            continue
+        got = line_search_next_step(f0, g0, prev, cur)
+        ref = oracle_lib.ls_next_step(f0, g0, prev, cur, 1e-3 * xc, 0.6 * xc)
+        assert 1e-3 * xc <= got <= 0.6 * xc
+        assert got == pytest.approx(ref, rel=1e-9, abs=1e-12), (it, f0, g0, prev, cur)
+        n_poly += 1
+    assert n_poly > 300
