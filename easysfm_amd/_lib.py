@@ -35,7 +35,8 @@ EXPORTED_SYMBOLS = [
     "esfm_match_pairs_dev", "esfm_knn2_pairs_dev", "esfm_match_last_stats", "esfm_shard_pair_list",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
     "esfm_ba_problem_solve", "esfm_ba_problem_get_params", "esfm_ba_problem_destroy", "esfm_ba_problem_cost",
-    "esfm_ba_shard_points",
+    "esfm_ba_shard_points", "esfm_ba_problem_create_free_calib", "esfm_ba_problem_set_calib", "esfm_ba_problem_get_calib",
+    "esfm_ba_problem_fix_camera", "esfm_ba_solve_ex", "esfm_ba_line_search_next_step",
 ]
 
 

@@ -252,22 +252,23 @@ public:
         return 2 * num_observations_ > num_parameters_;  // "Ready to solve" (:120-129)
     }
 
-    // ba.cpp:132-212 with calibration fixed: ceres::Solve -> esfm_ba_solve.
+    double *mutable_calib() { return parameters_.data() + 6 * num_cameras_ + 3 * num_points_; }   // ba.h:45
+
+    // ba.cpp:132-212: ceres::Solve -> esfm_ba_solve_ex.  Fixed intrinsics (:142-164) or the shared free block bounded to
+    // +- tolerance (:167-196); a reference frame named in setBAProblem is bounded to +-1e-10 (:134, :155-162).
     bool solveBA(double fix_calib_tolerance_BA)
     {
-        if (fix_calib_tolerance_BA != 0 || ref_process_camera_id_ >= 0) {
-            std::cerr << "free-intrinsics / fixed-reference-camera BA (ba.cpp:155-196) is not built (SURVEY 8 row f-4)" << std::endl;
-            return false;
-        }
+        const double fixed_threshold = 1e-10;  // :134
         std::vector<float> K4(size_t(4 * num_cameras_));
         for (int c = 0; c < num_cameras_; ++c) {
             K4[size_t(4 * c)] = calibs_[size_t(c)](0, 0); K4[size_t(4 * c + 1)] = calibs_[size_t(c)](0, 2);
             K4[size_t(4 * c + 2)] = calibs_[size_t(c)](1, 1); K4[size_t(4 * c + 3)] = calibs_[size_t(c)](1, 2);
         }
         options_.verbose = verbose ? 1 : 0;  // minimizer_progress_to_stdout (:204)
-        int rc = esfm_ba_solve(default_ctx(), num_cameras_, num_points_, num_observations_, camera_index_.data(), point_index_.data(),
-                               reinterpret_cast<const float *>(points_2d_.data()), K4.data(), mutable_cameras(), mutable_points(),
-                               &options_, nullptr, nullptr, &summary_);
+        int rc = esfm_ba_solve_ex(default_ctx(), num_cameras_, num_points_, num_observations_, camera_index_.data(), point_index_.data(),
+                                  reinterpret_cast<const float *>(points_2d_.data()), K4.data(), mutable_cameras(), mutable_points(),
+                                  fix_calib_tolerance_BA != 0 ? mutable_calib() : nullptr, fix_calib_tolerance_BA,
+                                  ref_process_camera_id_, fixed_threshold, &options_, nullptr, nullptr, &summary_);
         if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
         return true;
     }
@@ -292,7 +293,18 @@ public:
                 frames[i].pose_cam(r, 3) = float(parameters_[size_t(6 * k + 3 + r)]);
             }
             ++k;
+            if (fix_calib_tolerance_BA != 0) {  // :250-256
+                frames[i].K_cam(0, 0) = float(parameters_[size_t(num_parameters_ - 4)]);
+                frames[i].K_cam(0, 2) = float(parameters_[size_t(num_parameters_ - 3)]);
+                frames[i].K_cam(1, 1) = float(parameters_[size_t(num_parameters_ - 2)]);
+                frames[i].K_cam(1, 2) = float(parameters_[size_t(num_parameters_ - 1)]);
+            }
         }
+        if (verbose && fix_calib_tolerance_BA != 0)
+            std::cout << "Calib intrinsic parameters after BA:" << std::endl
+                      << "[fx:" << parameters_[size_t(num_parameters_ - 4)] << " ,cx:" << parameters_[size_t(num_parameters_ - 3)]
+                      << " ,fy:" << parameters_[size_t(num_parameters_ - 2)] << " ,cy:" << parameters_[size_t(num_parameters_ - 1)] << " ]"
+                      << std::endl;
         for (int i = 0; i < num_points_; ++i) {  // :277-279, float truncation
             sfm_sparse_points.points[size_t(i)].x = float(parameters_[size_t(6 * num_cameras_ + 3 * i)]);
             sfm_sparse_points.points[size_t(i)].y = float(parameters_[size_t(6 * num_cameras_ + 3 * i + 1)]);

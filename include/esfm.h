@@ -280,6 +280,46 @@ int esfm_ba_problem_destroy(esfm_ba_problem *p);
  * current parameters (tests, and the candidate-cost kernel in isolation). */
 int esfm_ba_problem_cost(esfm_ba_problem *p, double cauchy_a, double *cost);
 
+/* ---- free shared intrinsics and box bounds ----------------------------------------------------
+ * BundleAdjustment::solveBA(fix_calib_tolerance_BA != 0) (ba.cpp:167-196): the cost functor becomes
+ * ReprojectErrorTerm_updatecalib (ba.h:170-222) over ONE shared parameter block fx, cx, fy, cy
+ * (ba.cpp:107-113 takes it from calibs_[0]; ba.h:199-202 fixes the order), bounded to its initial value
+ * +- tolerance (ba.cpp:190-194).  Independently, the reference frame's six pose parameters are bounded to
+ * [-1e-10, +1e-10] (ba.cpp:134, :155-162 / :181-188), i.e. held at the origin.  With any bound Ceres runs its
+ * constrained trust-region loop (projection onto the box, projected gradient norm, Armijo line search along
+ * the LM step); esfm_ba_iteration.line_search_steps reports the contractions per iteration.
+ *
+ * esfm_ba_problem_create_free_calib: as esfm_ba_problem_create, without per-camera K4 and with calib4[4] =
+ * fx, cx, fy, cy (doubles, as parameters_ holds them) and calib_tolerance > 0 (Ceres rejects an empty box).
+ * The multi-GPU rules are unchanged: every rank passes the same calib4; the intrinsics ride in the all-reduced
+ * reduced system like one more camera. */
+int esfm_ba_problem_create_free_calib(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs,
+                                      const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                                      const double *calib4, double calib_tolerance,
+                                      const double *cams, const double *pts, esfm_ba_problem **out);
+/* new start value and box centre of the intrinsics (problems created with free intrinsics only) */
+int esfm_ba_problem_set_calib(esfm_ba_problem *p, const double *calib4, double calib_tolerance);
+int esfm_ba_problem_get_calib(esfm_ba_problem *p, double *calib4);
+/* Bound all six parameters of camera `cam` to [-threshold, +threshold] for the following solves
+ * (ba.cpp:155-162 with threshold = 1e-10); cam < 0 removes the bound. */
+int esfm_ba_problem_fix_camera(esfm_ba_problem *p, int cam, double threshold);
+
+/* One-shot solveBA with the optional pieces: calib4 NULL = fixed intrinsics K4_per_cam, else free shared
+ * intrinsics (in/out, K4_per_cam ignored); ref_cam < 0 = no reference camera. */
+int esfm_ba_solve_ex(esfm_ctx *ctx, int n_cam, int n_pt, int n_obs,
+                     const int32_t *cam_idx, const int32_t *pt_idx, const float *obs_uv,
+                     const float *K4_per_cam, double *cams, double *pts,
+                     double *calib4, double calib_tolerance, int ref_cam, double ref_threshold,
+                     const esfm_ba_options *options, esfm_allreduce_fn allreduce, void *allreduce_user,
+                     esfm_ba_summary *summary);
+
+/* The step-length rule of that line search alone (host arithmetic, no GPU): next trial step after the trial
+ * (x_cur, f_cur, g_cur) failed the sufficient-decrease test, given the start point (0, f0, g0) and optionally
+ * the trial before; *_valid = 0 marks a sample whose evaluation failed.  [upstream line_search.cc
+ * InterpolatingPolynomialMinimizingStepSize, CUBIC] */
+double esfm_ba_line_search_next_step(double f0, double g0, double x_prev, double f_prev, double g_prev, int prev_valid,
+                                     double x_cur, double f_cur, double g_cur, int cur_valid);
+
 /* Host-only helper (no GPU needed): assigns each point to one of `world`
  * shards so that observation counts balance (greedy over points in index
  * order), writing shard_of_point[n_pt].  Observations follow their point. */

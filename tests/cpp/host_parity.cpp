@@ -12,6 +12,8 @@ extern "C" {
 void esfm_ref_knn2_l2_f32(const float *, int, const float *, int, int, int32_t *, float *);
 void esfm_ref_knn2_hamming(const uint8_t *, int, const uint8_t *, int, int, int32_t *, float *);
 int esfm_ref_ratio_filter(const int32_t *, const float *, int, double, int32_t *, int32_t *, float *);
+int esfm_ref_ba_solve_ex(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *, double *, double,
+                         int, double, const esfm_ba_options *, esfm_ba_summary *);
 int esfm_ref_ba_solve(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *,
                       const esfm_ba_options *, esfm_ba_summary *);
 }
@@ -136,6 +138,34 @@ int main()
         for (int p = 0; p < NP; ++p) CHECK(std::fabs(cloud.points[size_t(p)].x - float(ref.parameters_[size_t(6 * NC + 3 * p)])) <= 1e-5f);
         std::printf("doSFMBA: %d observations, %d LM iterations, cost %.6f -> %.6f, max |dparam| vs oracle %.2e\n", ba.num_observations_,
                     ba.summary_.num_iterations, ba.summary_.initial_cost, ba.summary_.final_cost, worst);
+
+        // ---- doSFMBA(frames, ..., fix_calib_tolerance_BA = 20, reference_frame_id = 0)  (ba.cpp:155-196) ----
+        std::vector<frame_t> fr2 = frames0; pointcloud_sparse_t cl2 = cloud0;
+        for (auto &f : fr2) { f.K_cam(0, 0) *= 1.02f; f.K_cam(1, 1) *= 0.99f; }   // start the shared intrinsics off
+        std::vector<frame_t> fr2_0 = fr2;
+        BundleAdjustment bc;
+        bc.options_.max_num_iterations = 6;
+        CHECK(bc.doSFMBA(fr2, process, cl2, 20.0, 0));
+        CHECK(bc.ref_process_camera_id_ == 0 && bc.num_parameters_ == 6 * NC + 3 * NP + 4);
+        BundleAdjustment rc2; rc2.initBA(); rc2.setBAProblem(fr2_0, process, cloud0, 20.0, 0);
+        esfm_ba_summary rs2;
+        CHECK(esfm_ref_ba_solve_ex(NC, NP, rc2.num_observations_, rc2.camera_index_.data(), rc2.point_index_.data(),
+                                   reinterpret_cast<const float *>(rc2.points_2d_.data()), nullptr, rc2.mutable_cameras(), rc2.mutable_points(),
+                                   rc2.mutable_calib(), 20.0, 0, 1e-10, &opt, &rs2) == 0);
+        CHECK(bc.summary_.num_iterations == rs2.num_iterations);
+        for (int i = 0; i <= rs2.num_iterations; ++i) {
+            CHECK(std::fabs(bc.summary_.iterations[i].cost - rs2.iterations[i].cost) <= 1e-9 * std::fabs(rs2.iterations[i].cost));
+            CHECK(bc.summary_.iterations[i].line_search_steps == rs2.iterations[i].line_search_steps);
+        }
+        double worst2 = 0;
+        for (int i = 0; i < bc.num_parameters_; ++i) worst2 = std::max(worst2, std::fabs(bc.parameters_[size_t(i)] - rc2.parameters_[size_t(i)]));
+        CHECK(worst2 < 1e-5);
+        for (int i = 0; i < 6; ++i) CHECK(std::fabs(bc.parameters_[size_t(i)]) <= 1e-10);          // reference frame held at the origin
+        for (int c = 0; c < NC; ++c) CHECK(fr2[size_t(c)].K_cam(0, 0) == float(bc.parameters_[size_t(bc.num_parameters_ - 4)]));   // :250-256
+        CHECK(fr2[NC].K_cam(0, 0) == fr2_0[NC].K_cam(0, 0));                                         // unregistered frame keeps its K
+        CHECK(std::fabs(double(fr2[0].K_cam(0, 0)) - double(fr2_0[0].K_cam(0, 0))) <= 20.0 + 1e-3);
+        std::printf("doSFMBA free calib + reference frame: cost %.6f -> %.6f, fx %.3f -> %.3f, max |dparam| vs oracle %.2e\n",
+                    bc.summary_.initial_cost, bc.summary_.final_cost, double(fr2_0[0].K_cam(0, 0)), double(fr2[0].K_cam(0, 0)), worst2);
     }
     std::printf("HOST PARITY OK\n");
     return 0;

@@ -20,7 +20,10 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, backend, q):
+CALIB0 = [703.67, 376.37, 677.22, 254.22]     # shared intrinsics start, ~2 % off the scene's
+
+
+def _worker(rank, world, port, backend, q, constrained=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -39,25 +42,34 @@ def _worker(rank, world, port, backend, q):
         keep = shard[sc.pt_idx] == rank
         ctx = E.Context.on_torch_stream(0)
         opt = E.default_options(); opt.max_num_iterations = 6
+        cal = None
         with torch.cuda.stream(ctx.torch_stream):
-            cams, pts, summ = E.ba_solve(sc.cam_idx[keep], sc.pt_idx[keep], sc.uv[keep], sc.K4, sc.cams0, sc.pts0, opt, ctx,
-                                         allreduce=E.torch_allreduce_callback())
-        q.put((rank, "ok", cams, pts, [it.cost for it in summ.log()], summ.num_active_points))
+            if constrained:
+                sc = synth.in_reference_frame(sc, 0)
+                opt.max_num_iterations = 8
+                cams, pts, cal, summ = E.ba_solve_ex(sc.cam_idx[keep], sc.pt_idx[keep], sc.uv[keep], None, sc.cams0, sc.pts0,
+                                                     calib=CALIB0, calib_tol=8.0, ref_cam=0, options=opt, ctx=ctx,
+                                                     allreduce=E.torch_allreduce_callback())
+            else:
+                cams, pts, summ = E.ba_solve(sc.cam_idx[keep], sc.pt_idx[keep], sc.uv[keep], sc.K4, sc.cams0, sc.pts0, opt, ctx,
+                                             allreduce=E.torch_allreduce_callback())
+        q.put((rank, "ok", cams, pts, [it.cost for it in summ.log()], summ.num_active_points, cal,
+               [it.line_search_steps for it in summ.log()]))
         dist.barrier()
     except Exception:
         import traceback
-        q.put((rank, "FAIL: " + traceback.format_exc(), None, None, None, None))
+        q.put((rank, "FAIL: " + traceback.format_exc(), None, None, None, None, None, None))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
 
 
-def _run(world, backend):
+def _run(world, backend, constrained=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, constrained)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -79,7 +91,7 @@ def test_sharded_ba_two_ranks_matches_single(gpu_ctx):
     sc, (cams, pts, summ) = _single()
     res = _run(2, "gloo")
     ref_cost = [it.cost for it in summ.log()]
-    for rank, _, c, p, costs, n_active in res:
+    for rank, _, c, p, costs, n_active, _cal, _ls in res:
         assert len(costs) == len(ref_cost)
         assert np.allclose(costs, ref_cost, rtol=1e-9)               # every rank sees the global cost trace
         assert np.allclose(c, cams, rtol=1e-6, atol=1e-6)             # replicated cameras
@@ -92,6 +104,28 @@ def test_sharded_ba_two_ranks_matches_single(gpu_ctx):
 def test_rccl_backend_single_rank(gpu_ctx):
     """The nccl (RCCL) process group + the device-pointer callback, world size 1."""
     sc, (cams, pts, summ) = _single()
-    (rank, _, c, p, costs, n_active), = _run(1, "nccl")
+    (rank, _, c, p, costs, n_active, _cal, _ls), = _run(1, "nccl")
     assert np.allclose(costs, [it.cost for it in summ.log()], rtol=1e-12)
     assert np.allclose(c, cams, rtol=1e-9, atol=1e-12) and np.allclose(p, pts, rtol=1e-9, atol=1e-12)
+
+
+def test_sharded_constrained_ba_two_ranks_matches_single(gpu_ctx):
+    """Free shared intrinsics (tight box, so the line search contracts) + reference camera, observations sharded over two
+    ranks: the intrinsics block rides in the all-reduced reduced system and F'F sums, the line-search scalars (slope, max
+    |delta|) in the SUM / MAX scalar reductions -- every rank must take the same decisions as the single-GPU solve."""
+    import easysfm_amd as E
+    from easysfm_amd import synth
+    sc = synth.in_reference_frame(synth.ba_scene(8, 600, 5, seed=21), 0)
+    opt = E.default_options(); opt.max_num_iterations = 8
+    cams, pts, cal, summ = E.ba_solve_ex(sc.cam_idx, sc.pt_idx, sc.uv, None, sc.cams0, sc.pts0, calib=CALIB0, calib_tol=8.0,
+                                         ref_cam=0, options=opt, ctx=E.Context(0, None))
+    res = _run(2, "gloo", constrained=True)
+    ref_cost = [it.cost for it in summ.log()]
+    ref_ls = [it.line_search_steps for it in summ.log()]
+    for rank, _, c, p, costs, n_active, k, ls in res:
+        assert ls == ref_ls
+        assert np.allclose(costs, ref_cost, rtol=1e-9)
+        assert np.allclose(k, cal, rtol=1e-9, atol=1e-7)
+        assert np.allclose(c, cams, rtol=1e-6, atol=1e-6) and np.allclose(p, pts, rtol=1e-6, atol=1e-6)
+        assert np.all(np.abs(c[0]) <= 1e-10)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][6], res[1][6])
