@@ -12,4 +12,6 @@ from .matching import (DescriptorBank, FeatureMatching, PairMatcher, knn_match_h
 from .ba import (BAProblem, BundleAdjustment, ba_solve, ba_solve_ex, default_options, line_search_next_step, shard_points,  # noqa: F401
                  torch_allreduce_callback)
 
+from .cloud import CProceesing, read_ply_vertices, sor_filter, write_ply  # noqa: F401
+
 __version__ = "0.1.0"

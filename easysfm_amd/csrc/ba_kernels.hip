@@ -175,7 +175,7 @@ __device__ __forceinline__ void reproject_jac(const double cam[6], const double 
 // so global f64 atomics are one per camera entry per workgroup instead of 27 per observation.
 constexpr int kLinThreads = 512;
 
-template <bool PRIV>
+template <bool PRIV, bool CALIB>
 __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, double *__restrict__ slabs)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [8] reduction scratch, then PRIV: [n_cam*27]
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
                 const double sp = use_scaling ? sq * d.scale_p[3 * (size_t)p + i] : sq;
                 Jp[i] *= sp; Jp[3 + i] *= sp;
             }
-            if (d.has_calib) {
+            if (CALIB) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) Jk[i] *= use_scaling ? sq * d.scale_c[6 * (size_t)d.n_real_cam + i] : sq;
             }
         }
-        if (d.has_calib) {
+        if (CALIB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) d.Jk[(size_t)i * n_obs + k] = Jk[i];
             // G'G (upper triangle of the 4x4: rows fx, cx | fy, cy never mix) and G'r, kept in registers over the sweep
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
     const double cs = block_sum(cost, red);
     const double bs = block_sum(bad, red);
     if (tid == 0) { atomicAdd(&d.scal[SC_COST], cs); if (bs > 0.0) atomicAdd(&d.scal[SC_LIN_BAD], bs); }
-    if (d.has_calib) {
+    if (CALIB) {
         // the intrinsics block's F'F / F'r entries: every observation hits the same 10 sums, so they are reduced
         // over the workgroup instead of through atomics.  Packed index of (a, b), a <= b: a*6 - a(a-1)/2 + b - a.
         const int kc = d.n_real_cam;
@@ -1237,19 +1237,19 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
     const bool priv = priv_bytes <= 150 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
     if (priv) {
-        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_linearize_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv_bytes));
+        auto kern = d.has_calib ? &ba_linearize_kernel<true, true> : &ba_linearize_kernel<true, false>;
+        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv_bytes));
         {
             KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone (not the slab reduction)
-            hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
         }
         LAUNCH_CHECK();
         hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid);
     } else {
         ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
         KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);
-        hipLaunchKernelGGL(ba_linearize_kernel<false>, dim3(grid), dim3(kLinThreads), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0,
-                           (double *)nullptr);
+        auto kern = d.has_calib ? &ba_linearize_kernel<false, true> : &ba_linearize_kernel<false, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0, (double *)nullptr);
     }
     LAUNCH_CHECK();
     return ESFM_OK;

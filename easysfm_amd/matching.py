@@ -99,6 +99,52 @@ class FeatureMatching:
         matches.extend(DMatch(int(a), int(b), float(c)) for a, b, c in zip(qi, ti, d))
         return True
 
+    # ---- frame selection (feature_matching.cpp:160-268): integer logic on the track matrix, host side ----
+    def findInitializeFramePair(self, feature_track_matrix, frames, img_match_graph, min_track_num_init: int = 100,
+                                max_depth_baseline_ratio_init: float = 50.0):
+        """feature_matching.cpp:160-229 (defaults feature_matching.h:26).  feature_track_matrix: [n_frames, n_unique] bool (frame sees track);
+        img_match_graph[i][j].appro_depth (or a 2-D array of depths): depth / baseline of pair (i, j < i).
+        Returns (found, initialization_frame_1, initialization_frame_2, depth_init).  The pair maximising the sum, over
+        the tracks both frames see, of the number of frames that see the track; ties go to the LATER pair in (i, j < i)
+        order (`>=` at :203); pairs whose depth / baseline exceeds the limit are skipped (:193-194)."""
+        T = np.asarray(feature_track_matrix, bool)
+        n_frames = len(frames)
+        T = T[:n_frames]
+        weight = T.sum(axis=0).astype(np.int64)                    # point_track_frame_num (:172-180)
+        score = (T.astype(np.int64) * weight[None, :]) @ T.T.astype(np.int64)
+
+        def depth(i, j):
+            e = img_match_graph[i][j]
+            return float(getattr(e, "appro_depth", e))
+
+        best, f1, f2, d_init = int(min_track_num_init), 0, 0, None
+        for i in range(n_frames):
+            for j in range(i):
+                d = depth(i, j)
+                if d > max_depth_baseline_ratio_init:
+                    continue
+                if score[i, j] >= best:
+                    best, f1, f2, d_init = int(score[i, j]), i, j, d
+        if f1 == f2:
+            print("Failed to find proper frame pair for initialization. Use default frame [1] and frame [0]")
+            return False, 1, 0, None                                # depth_init is left unset by the reference (:217-223)
+        return True, f1, f2, d_init
+
+    def findNextFrame(self, feature_track_matrix, frames_to_process, unique_3d_point_ids, next_frame: int = -1) -> int:
+        """feature_matching.cpp:231-268: among the frames still to process, the one seeing most of the already
+        triangulated tracks; the FIRST such frame on ties (strict `>` at :252); `next_frame` is returned unchanged when
+        no candidate sees any (the reference leaves its output argument untouched)."""
+        T = np.asarray(feature_track_matrix, bool)
+        ids = np.asarray(unique_3d_point_ids, np.int64)
+        best = 0
+        for i, todo in enumerate(frames_to_process):
+            if not todo:
+                continue
+            c = int(T[i, ids].sum()) if len(ids) else 0
+            if c > best:
+                best, next_frame = c, i
+        return next_frame
+
 
 # ------------------------------------------------------------------------------------------------
 @dataclass

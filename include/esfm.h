@@ -81,7 +81,8 @@ typedef enum esfm_kernel_id {
     ESFM_K_BA_SCHUR = 3,      /* ba_schur_kernel                                                */
     ESFM_K_BA_SOLVE = 4,      /* ba_chol_solve_kernel                                           */
     ESFM_K_L2_RESCAN = 5,     /* l2_exact_scan_kernel                                           */
-    ESFM_K_COUNT = 6
+    ESFM_K_SOR_KNN = 6,       /* sor_knn_mean_kernel: k-NN mean distances of the outlier filter   */
+    ESFM_K_COUNT = 7
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -324,6 +325,24 @@ double esfm_ba_line_search_next_step(double f0, double g0, double x_prev, double
  * shards so that observation counts balance (greedy over points in index
  * order), writing shard_of_point[n_pt].  Observations follow their point. */
 int esfm_ba_shard_points(int n_pt, int n_obs, const int32_t *pt_idx, int world, int32_t *shard_of_point);
+
+/* ---- sparse-cloud statistical outlier removal ------------------------
+ * CProceesing::SORFilter (cpp_code/include/cloudprocessing.hpp:24-36, called on the final cloud at
+ * cpp_code/test/sfm.cpp:333) = pcl::StatisticalOutlierRemoval with MeanK (50) and StddevMulThresh (2.0):
+ * per point the mean distance to its mean_k nearest neighbours (exact search among the finite points, float
+ * squared distances, double sum of float square roots in ascending order); then mean and standard deviation of
+ * those N numbers; a point is removed iff its mean distance > mean + std_mul * stddev.
+ *
+ * points: n rows of stride_floats floats with x, y, z first (3 = packed xyz, 8 = pcl::PointXYZRGB as
+ * rgb_pointcloud->points stores it).  keep[n]: 1 = the point survives (the order of survivors is the input
+ * order, like pcl::Filter::filter); mean_dist[n] (or NULL) receives the per-point mean distances; *threshold the
+ * cut.  mean_k in [1, 63].  Host pointers.  Fewer than mean_k + 1 finite points is undefined in PCL; here the
+ * neighbours that exist are summed and the sum is still divided by mean_k. */
+int esfm_sor_filter(esfm_ctx *ctx, const float *points, int n, int stride_floats, int mean_k, double std_mul,
+                    float *mean_dist /*n or NULL*/, uint8_t *keep /*n*/, int32_t *n_keep, double *threshold /*or NULL*/);
+/* The k-NN pass alone on device-resident points (what bench.py times); asynchronous on the context's stream. */
+int esfm_sor_mean_distances_dev(esfm_ctx *ctx, const float *points_dev, int n, int stride_floats, int mean_k,
+                                float *mean_dist_dev /*n*/);
 
 #ifdef __cplusplus
 }

@@ -79,7 +79,7 @@ class BASummary(C.Structure):
 def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     path = os.path.join(_HERE, out)
-    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
@@ -133,6 +133,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_ba_column_sqnorms.restype = C.c_int
     lib.esfm_ref_ba_column_sqnorms.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, _f64p,
                                                C.c_double, _f64p, _f64p]
+    lib.esfm_ref_sor_mean_distances.restype = C.c_int
+    lib.esfm_ref_sor_mean_distances.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p]
+    lib.esfm_ref_sor_filter.restype = C.c_int
+    lib.esfm_ref_sor_filter.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_double, _f32p, _u8p, C.POINTER(C.c_double)]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -311,3 +315,14 @@ def ba_column_sqnorms(n_cam, n_pt, cam_idx, pt_idx, uv, K4, cams, pts, cauchy_a)
 
 def iterations(summ: BASummary):
     return [summ.iterations[i] for i in range(min(summ.num_iterations + 1, BA_MAX_LOG))]
+
+
+# ----------------------------------------------------------------------------- sparse-cloud filter
+def sor_filter(points, mean_k: int = 50, std_mul: float = 2.0):
+    """pcl::StatisticalOutlierRemoval as CProceesing::SORFilter configures it (cloudprocessing.hpp:24-36).
+    points: [n, stride >= 3] float32, xyz first.  Returns (keep mask, mean distances, threshold)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    n, stride = pts.shape
+    md = np.zeros(max(n, 1), np.float32); keep = np.zeros(max(n, 1), np.uint8); thr = C.c_double(0.0)
+    load().esfm_ref_sor_filter(pts.reshape(-1), n, stride, int(mean_k), float(std_mul), md, keep, C.byref(thr))
+    return keep[:n].astype(bool), md[:n], thr.value

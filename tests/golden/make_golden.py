@@ -23,6 +23,12 @@ C oracle (oracle/*.c) is pinned by tests/test_oracle_golden.py:
                             and the Armijo line search with cubic interpolation (numpy.linalg.solve for the
                             interpolating polynomial, numpy.roots for its critical points)
 
+  sor_cases.npz             statistical outlier removal (cloudprocessing.hpp:24-36 = pcl::StatisticalOutlierRemoval, MeanK 50,
+                            StddevMulThresh 2.0): clustered clouds with planted outliers, exact duplicates, a non-finite
+                            point, a cloud smaller than MeanK + 1; expected mean distances from a full float32 distance
+                            matrix evaluated as ((dx*dx + dy*dy) + dz*dz), numpy sort, sequential float64 cumsum of float32
+                            square roots; threshold from sequential cumsums
+
     python tests/golden/make_golden.py
 """
 from __future__ import annotations
@@ -461,10 +467,59 @@ def make_ba_trace():
     np.savez_compressed(os.path.join(HERE, "ba_lm_trace.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------ cloud
+def sor_numpy(P, mean_k, std_mul):
+    P = np.asarray(P, np.float32)
+    n = len(P)
+    fin = np.isfinite(P[:, :3]).all(axis=1)
+    Q = P[fin, :3]
+    md = np.zeros(n, np.float32)
+    dx = P[:, None, 0] - Q[None, :, 0]; dy = P[:, None, 1] - Q[None, :, 1]; dz = P[:, None, 2] - Q[None, :, 2]
+    with np.errstate(invalid="ignore"):
+        D = ((dx * dx + dy * dy) + dz * dz).astype(np.float32)
+    for i in range(n):
+        if not fin[i]:
+            continue
+        row = np.sort(D[i])[1:mean_k + 1]                      # entry 0 is the point itself
+        md[i] = np.float32(np.cumsum(np.sqrt(row).astype(np.float64))[-1] / mean_k) if len(row) else np.float32(0)
+    valid = int(fin.sum())
+    s = np.cumsum(md.astype(np.float64))[-1]
+    sq = np.cumsum((md * md).astype(np.float64))[-1]
+    mean = s / valid
+    var = (sq - s * s / valid) / (valid - 1.0)
+    thr = mean + std_mul * np.sqrt(var)
+    keep = ~(md.astype(np.float64) > thr)
+    return md, thr, keep
+
+
+def make_sor():
+    rng = np.random.default_rng(4242)
+    out = {}
+    cases = {}
+    blob = np.concatenate([rng.normal(0, 1.0, (1500, 3)), rng.normal([6, 0, 0], 0.3, (500, 3)), rng.uniform(-15, 15, (40, 3))])
+    cases["blobs"] = (blob.astype(np.float32), 50, 2.0)
+    dup = rng.normal(0, 1, (300, 3)).astype(np.float32)
+    dup[50:60] = dup[0]                                        # exact duplicates: zero distances beyond entry 0
+    dup[100] = [np.nan, 0, 0]; dup[101] = [0, np.inf, 0]       # non-finite points: excluded from the search, distance 0
+    cases["dups_nonfinite"] = (dup, 50, 2.0)
+    cases["small"] = (rng.normal(0, 1, (30, 3)).astype(np.float32), 50, 2.0)    # fewer than MeanK + 1 points
+    g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0), np.arange(8.0)), -1).reshape(-1, 3).astype(np.float32)
+    cases["grid_ties"] = (g, 20, 1.0)                          # massive distance ties at the k-th place
+    xyzrgb = np.zeros((400, 8), np.float32); xyzrgb[:, :3] = rng.normal(0, 2, (400, 3)); xyzrgb[:, 3] = 1.0; xyzrgb[:, 4] = rng.random(400)
+    cases["stride8"] = (xyzrgb, 10, 1.5)                       # pcl::PointXYZRGB layout: 8 floats per point
+    for tag, (P, k, m) in cases.items():
+        md, thr, keep = sor_numpy(P, k, m)
+        out[f"{tag}.points"] = P; out[f"{tag}.mean_k"] = np.int32(k); out[f"{tag}.std_mul"] = np.float64(m)
+        out[f"{tag}.mean_dist"] = md; out[f"{tag}.threshold"] = np.float64(thr); out[f"{tag}.keep"] = keep
+        print("sor", tag, len(P), "kept", int(keep.sum()), "thr", thr)
+    np.savez_compressed(os.path.join(HERE, "sor_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     make_hamming()
     make_l2()
     make_ba_jacobians()
     make_ba_trace()
     make_ba_constrained()
+    make_sor()
     print("golden vectors written to", HERE)

@@ -129,3 +129,65 @@ def test_line_search_step_rule_matches_oracle(oracle_lib):
         assert got == pytest.approx(ref, rel=1e-9, abs=1e-12), (it, f0, g0, prev, cur)
         n_poly += 1
     assert n_poly > 300
+
+
+def _init_pair_loops(T, depth, min_track, max_ratio):
+    """feature_matching.cpp:160-229, the reference's loops verbatim."""
+    n_frames, n_unique = T.shape
+    cnt = [0] * n_unique
+    for i in range(n_frames):
+        for j in range(n_unique):
+            cnt[j] += int(T[i][j])
+    best, f1, f2 = min_track, 0, 0
+    for i in range(n_frames):
+        for j in range(i):
+            if depth[i][j] > max_ratio:
+                continue
+            s = 0
+            for k in range(n_unique):
+                if T[i][k] and T[j][k]:
+                    s += cnt[k]
+            if s >= best:
+                best, f1, f2 = s, i, j
+    return f1, f2
+
+
+def test_frame_selection_matches_reference_loops():
+    rng = np.random.default_rng(3)
+    fm = E.FeatureMatching.__new__(E.FeatureMatching)
+    for trial in range(20):
+        F, U = int(rng.integers(3, 9)), int(rng.integers(5, 60))
+        T = rng.random((F, U)) < 0.4
+        depth = rng.uniform(1, 150, (F, F))
+        frames = [None] * F
+        found, f1, f2, d = fm.findInitializeFramePair(T, frames, depth, min_track_num_init=5, max_depth_baseline_ratio_init=100.0)
+        r1, r2 = _init_pair_loops(T, depth, 5, 100.0)
+        if r1 == r2:
+            assert not found and (f1, f2) == (1, 0)
+        else:
+            assert found and (f1, f2) == (r1, r2) and d == depth[r1][r2]
+        todo = list(rng.random(F) < 0.5)
+        ids = rng.permutation(U)[:int(rng.integers(0, U))]
+        nxt = fm.findNextFrame(T, todo, ids, next_frame=-7)
+        best, ref = 0, -7
+        for i in range(F):
+            if todo[i]:
+                c = sum(1 for k in ids if T[i][k])
+                if c > best:
+                    best, ref = c, i
+        assert nxt == ref
+
+
+def test_ply_writer_layout(tmp_path):
+    """The external contract argv[5] (data_io.cpp:147-165): PCL's ASCII PLY of PointXYZRGB, camera element included."""
+    cloud = E.SparsePointCloud(xyz=np.array([[1.5, -2.25, 3.0], [0.1, 0.2, 0.3]], np.float32), rgb=np.array([[255, 0, 7], [1, 2, 3]], np.uint8))
+    path = str(tmp_path / "out.ply")
+    assert E.write_ply(path, cloud)
+    text = open(path).read().split("\n")
+    assert text[:4] == ["ply", "format ascii 1.0", "comment PCL generated", "element vertex 2"]
+    assert text[4:10] == ["property float x", "property float y", "property float z", "property uchar red", "property uchar green", "property uchar blue"]
+    assert text[10] == "element camera 1" and text[text.index("end_header") + 1] == "1.5 -2.25 3 255 0 7"
+    assert text[text.index("end_header") + 2] == "0.1 0.2 0.30000001 1 2 3"      # float printed with 8 significant digits
+    xyz, rgb, cam = E.read_ply_vertices(path)
+    assert np.array_equal(xyz, cloud.xyz) and np.array_equal(rgb, cloud.rgb)
+    assert cam == "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 1 2 0 0"                    # viewport = width 1 x height N (:151-152)

@@ -178,3 +178,15 @@ def test_ba_converged_cost_vs_scipy(oracle_lib):
     r = least_squares(fun, x0, xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=400)
     assert abs(r.cost - s.final_cost) <= 2e-3 * s.final_cost
     assert r.cost <= s.final_cost * (1 + 1e-9)     # scipy started from the oracle's answer: it can only polish it
+
+
+@pytest.mark.parametrize("tag", ["blobs", "dups_nonfinite", "small", "grid_ties", "stride8"])
+def test_sor_golden_bitexact(oracle_lib, tag):
+    """Statistical outlier removal (cloudprocessing.hpp:24-36): the C oracle == the numpy restatement, bit for bit."""
+    z = np.load(os.path.join(GOLD, "sor_cases.npz"))
+    keep, md, thr = oracle_lib.sor_filter(z[f"{tag}.points"], int(z[f"{tag}.mean_k"]), float(z[f"{tag}.std_mul"]))
+    assert np.array_equal(md, z[f"{tag}.mean_dist"])
+    assert thr == float(z[f"{tag}.threshold"])
+    assert np.array_equal(keep, z[f"{tag}.keep"])
+    if tag == "blobs":
+        assert 0 < (~keep).sum() < 200 and (~keep)[2000:].sum() >= 30      # the planted far points go
