@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -114,6 +116,58 @@ public:
         return run(cur_frame_1, cur_frame_2, matches, ratio_thre, false, "SURF");
     }
 
+    // feature_matching.cpp:160-229 (defaults feature_matching.h:26).  appro_depth[i][j] = img_match_graph[i][j].appro_depth.
+    bool findInitializeFramePair(std::vector<std::vector<bool>> &feature_track_matrix, std::vector<frame_t> &frames,
+                                 const std::vector<std::vector<double>> &appro_depth, int &initialization_frame_1,
+                                 int &initialization_frame_2, double &depth_init, int min_track_num_init = 100,
+                                 double max_depth_baseline_ratio_init = 50.0)
+    {
+        initialization_frame_1 = 0; initialization_frame_2 = 0;
+        const int frame_number = int(frames.size());
+        const int num_unique_points = int(feature_track_matrix[0].size());
+        std::vector<int> point_track_frame_num(size_t(num_unique_points), 0);
+        for (int i = 0; i < frame_number; ++i) {
+            feature_track_matrix[size_t(i)].resize(size_t(num_unique_points));
+            for (int j = 0; j < num_unique_points; ++j) point_track_frame_num[size_t(j)] += feature_track_matrix[size_t(i)][size_t(j)];
+        }
+        int max_sum_track_frame_num = min_track_num_init;
+        double depth_baseline_ratio_init = 0.0;
+        for (int i = 0; i < frame_number; ++i) {
+            for (int j = 0; j < i; ++j) {
+                const double ratio = appro_depth[size_t(i)][size_t(j)];
+                if (ratio > max_depth_baseline_ratio_init) continue;  // baseline too short (:193-194)
+                int sum = 0;
+                for (int k = 0; k < num_unique_points; ++k)
+                    if (feature_track_matrix[size_t(i)][size_t(k)] && feature_track_matrix[size_t(j)][size_t(k)]) sum += point_track_frame_num[size_t(k)];
+                if (sum >= max_sum_track_frame_num) {  // later pair wins ties (:203)
+                    max_sum_track_frame_num = sum; depth_baseline_ratio_init = ratio;
+                    initialization_frame_1 = i; initialization_frame_2 = j;
+                }
+            }
+        }
+        if (initialization_frame_1 == initialization_frame_2) {
+            if (!quiet) std::cout << "Failed to find proper frame pair for initialization. Use default frame [1] and frame [0]" << std::endl;
+            initialization_frame_1 = 1; initialization_frame_2 = 0;
+            return false;  // depth_init untouched, as in the reference (:217-223)
+        }
+        depth_init = depth_baseline_ratio_init;
+        return true;
+    }
+
+    // feature_matching.cpp:231-268
+    bool findNextFrame(std::vector<std::vector<bool>> &feature_track_matrix, std::vector<bool> &frames_to_process,
+                       std::vector<int> &unique_3d_point_ids, int &next_frame)
+    {
+        int max_common_point_num = 0;
+        for (size_t i = 0; i < frames_to_process.size(); ++i) {
+            if (!frames_to_process[i]) continue;
+            int common = 0;
+            for (int id : unique_3d_point_ids) common += feature_track_matrix[i][size_t(id)] ? 1 : 0;
+            if (common > max_common_point_num) { max_common_point_num = common; next_frame = int(i); }
+        }
+        return true;
+    }
+
     bool quiet = false;  // the reference prints timing lines (feature_matching.cpp:96-97,141-142)
 
 private:
@@ -140,6 +194,52 @@ private:
                       << " ]" << std::endl;
         }
         return true;
+    }
+};
+
+// ---- sparse-cloud post-processing (cloudprocessing.hpp:20-72, data_io.cpp:147-165) ---------------------
+// CProceesing<PointT>::SORFilter = pcl::StatisticalOutlierRemoval (MeanK 50, StddevMulThresh 2.0) -> esfm_sor_filter.
+template <typename PointT = PointXYZRGB> class CProceesing {
+public:
+    bool SORFilter(const std::vector<PointT> &incloud, std::vector<PointT> &outcloud, int MeanK = 50, double std = 2.0)
+    {
+        const int n = int(incloud.size());
+        std::vector<float> xyz(size_t(3) * size_t(std::max(n, 1)));
+        for (int i = 0; i < n; ++i) { xyz[size_t(3 * i)] = incloud[size_t(i)].x; xyz[size_t(3 * i + 1)] = incloud[size_t(i)].y; xyz[size_t(3 * i + 2)] = incloud[size_t(i)].z; }
+        std::vector<uint8_t> keep(size_t(std::max(n, 1)));
+        int32_t n_keep = 0;
+        const int rc = esfm_sor_filter(default_ctx(), xyz.data(), n, 3, MeanK, std, nullptr, keep.data(), &n_keep, nullptr);
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        outcloud.clear();
+        for (int i = 0; i < n; ++i) if (keep[size_t(i)]) outcloud.push_back(incloud[size_t(i)]);
+        std::cout << "apply SOR filter: [ " << n << " ] points before filtering, [ " << outcloud.size() << " ] points after filtering." << std::endl;
+        return true;
+    }
+};
+
+// DataIO::writePlyFile (data_io.cpp:147-165): width 1, height N, pcl::io::savePLYFile (ASCII, camera element) [upstream
+// pcl/io/ply_io.cpp, restated from memory -- the reference ships no example file].
+class DataIO {
+public:
+    bool writePlyFile(const std::string &fileName, const std::vector<PointXYZRGB> &pointCloud)
+    {
+        std::ofstream fs(fileName);
+        if (!fs) { std::cerr << "Couldn't write file " << std::endl; return false; }
+        const size_t n = pointCloud.size();
+        fs << "ply\nformat ascii 1.0\ncomment PCL generated\nelement vertex " << n
+           << "\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue"
+              "\nelement camera 1\nproperty float view_px\nproperty float view_py\nproperty float view_pz"
+              "\nproperty float x_axisx\nproperty float x_axisy\nproperty float x_axisz"
+              "\nproperty float y_axisx\nproperty float y_axisy\nproperty float y_axisz"
+              "\nproperty float z_axisx\nproperty float z_axisy\nproperty float z_axisz"
+              "\nproperty float focal\nproperty float scalex\nproperty float scaley\nproperty float centerx\nproperty float centery"
+              "\nproperty int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n";
+        fs << std::setprecision(8);
+        for (const PointXYZRGB &p : pointCloud)
+            fs << p.x << " " << p.y << " " << p.z << " " << int(p.r) << " " << int(p.g) << " " << int(p.b) << "\n";
+        fs << "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 1 " << n << " 0 0\n";
+        std::cout << "Output [ " << n << " ] points." << std::endl << "Output ply file done." << std::endl;
+        return bool(fs);
     }
 };
 

@@ -12,6 +12,7 @@ extern "C" {
 void esfm_ref_knn2_l2_f32(const float *, int, const float *, int, int, int32_t *, float *);
 void esfm_ref_knn2_hamming(const uint8_t *, int, const uint8_t *, int, int, int32_t *, float *);
 int esfm_ref_ratio_filter(const int32_t *, const float *, int, double, int32_t *, int32_t *, float *);
+int esfm_ref_sor_filter(const float *, int, int, int, double, float *, uint8_t *, double *);
 int esfm_ref_ba_solve_ex(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *, double *, double,
                          int, double, const esfm_ba_options *, esfm_ba_summary *);
 int esfm_ref_ba_solve(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *,
@@ -166,6 +167,47 @@ int main()
         CHECK(std::fabs(double(fr2[0].K_cam(0, 0)) - double(fr2_0[0].K_cam(0, 0))) <= 20.0 + 1e-3);
         std::printf("doSFMBA free calib + reference frame: cost %.6f -> %.6f, fx %.3f -> %.3f, max |dparam| vs oracle %.2e\n",
                     bc.summary_.initial_cost, bc.summary_.final_cost, double(fr2_0[0].K_cam(0, 0)), double(fr2[0].K_cam(0, 0)), worst2);
+    }
+    // ---- SORFilter + writePlyFile + frame selection (sfm.cpp:333-337, feature_matching.cpp:160-268) ----------------
+    {
+        std::normal_distribution<float> g(0.f, 1.f);
+        std::uniform_real_distribution<float> U(-25.f, 25.f);
+        std::vector<PointXYZRGB> cloud, out;
+        for (int i = 0; i < 1500; ++i) { PointXYZRGB p; p.x = g(rng); p.y = g(rng); p.z = g(rng); p.r = uint8_t(i); p.g = uint8_t(i >> 3); p.b = 9; cloud.push_back(p); }
+        for (int i = 0; i < 30; ++i) { PointXYZRGB p; p.x = U(rng); p.y = U(rng); p.z = U(rng); cloud.push_back(p); }
+        CProceesing<PointXYZRGB> cp;
+        CHECK(cp.SORFilter(cloud, out));
+        std::vector<float> xyz(3 * cloud.size()), md(cloud.size());
+        for (size_t i = 0; i < cloud.size(); ++i) { xyz[3 * i] = cloud[i].x; xyz[3 * i + 1] = cloud[i].y; xyz[3 * i + 2] = cloud[i].z; }
+        std::vector<uint8_t> keep(cloud.size());
+        double thr = 0;
+        const int kept = esfm_ref_sor_filter(xyz.data(), int(cloud.size()), 3, 50, 2.0, md.data(), keep.data(), &thr);
+        CHECK(kept == int(out.size()) && kept < int(cloud.size()) && kept > 1400);
+        size_t o = 0;
+        for (size_t i = 0; i < cloud.size(); ++i) if (keep[i]) { CHECK(out[o].x == cloud[i].x && out[o].r == cloud[i].r); ++o; }
+        DataIO io;
+        CHECK(io.writePlyFile("/tmp/esfm_host_parity.ply", out));
+        std::ifstream in("/tmp/esfm_host_parity.ply");
+        std::string line; std::getline(in, line); CHECK(line == "ply");
+        std::getline(in, line); CHECK(line == "format ascii 1.0");
+        std::getline(in, line); CHECK(line == "comment PCL generated");
+        std::getline(in, line); CHECK(line == "element vertex " + std::to_string(out.size()));
+        std::printf("SORFilter: %zu -> %d points (exact vs oracle), threshold %.6f; .ply written\n", cloud.size(), kept, thr);
+
+        FeatureMatching fm; fm.quiet = true;
+        std::vector<std::vector<bool>> T = {{1, 1, 1, 0, 0, 1}, {1, 1, 0, 1, 0, 1}, {0, 1, 1, 1, 1, 0}, {1, 0, 1, 1, 1, 1}};
+        std::vector<frame_t> fr(4);
+        std::vector<std::vector<double>> depth(4, std::vector<double>(4, 10.0));
+        depth[3][2] = 80.0;   // too short a baseline: skipped
+        int f1 = -1, f2 = -1; double d0 = -1;
+        CHECK(fm.findInitializeFramePair(T, fr, depth, f1, f2, d0, 3, 50.0));
+        // track weights: 3 3 3 3 2 3; pair scores: (1,0)=9 (2,0)=6 (2,1)=6 (3,0)=9 (3,1)=9 (3,2) skipped -> last best (3,1)
+        CHECK(f1 == 3 && f2 == 1 && d0 == 10.0);
+        std::vector<bool> todo = {false, true, true, false};
+        std::vector<int> ids = {1, 2, 4};
+        int next = -1;
+        fm.findNextFrame(T, todo, ids, next);
+        CHECK(next == 2);
     }
     std::printf("HOST PARITY OK\n");
     return 0;
