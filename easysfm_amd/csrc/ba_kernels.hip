@@ -756,17 +756,18 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const dou
 // ---------------------------------------------------------------------------------------------
 // Dense solve of the reduced camera system (DENSE_SCHUR's Cholesky):
 //   (F'F + D_c^2 + S_schur) y = F'r + rhs_corr
-// One workgroup, left-looking Cholesky on a packed lower matrix with the right-hand side carried
+// One workgroup, right-looking blocked Cholesky on a packed lower matrix in LDS with the right-hand side carried
 // as row n (so the forward substitution comes for free), then the backward substitution.
-// LDS_STORE: the packed matrix lives in LDS (n <= ~185), otherwise in d.chol (global).
 constexpr int kCholThreads = 1024;
 constexpr int kCholNB = 8;  // panel width
 
-// Blocked left-looking Cholesky, one workgroup.  Per panel of kCholNB columns:
-//   A  all waves: subtract the contribution of the already-factored columns from the panel
-//      (one dot product per panel entry, rows j0..n; row n is the right-hand side)
-//   B  wave 0 alone factors the panel column by column (wave-synchronous, no s_barrier)
-// i.e. 2 barriers per panel instead of 2 per column.  The backward substitution is blocked the same way.
+// Per panel of kCholNB columns (3 barriers):
+//   B1  wave 0 factors the nb x nb diagonal block in registers (lane r = block row r, __shfl)
+//   B2  every row below (and the rhs row) solves against the block's transpose
+//   C   all waves apply the rank-nb update to the trailing matrix in 4 x 4 register tiles: per panel column 8 LDS loads
+//       feed 16 independent FMAs (the left-looking form this replaces issued 2 dependent loads per FMA and was
+//       LDS-latency bound: 161 us at n = 150)
+// The backward substitution is blocked the same way.
 template <bool LDS_STORE>
 __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, double radius, double min_diag, double max_diag)
 {
@@ -780,6 +781,13 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
     volatile double *failp = rd + n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *failp = 0.0;
+#ifdef ESFM_CHOL_PROFILE
+    double prof[6] = {0, 0, 0, 0, 0, 0};
+    long long tprev = wall_clock64();
+#define CHOL_MARK(slot) do { const long long tn__ = wall_clock64(); prof[slot] += (double)(tn__ - tprev); tprev = tn__; } while (0)
+#else
+#define CHOL_MARK(slot) do { } while (0)
+#endif
     const double *S = d.red;
     const double *rc = d.red + (size_t)n * n;
     const double *FtF = d.camacc;
@@ -804,24 +812,11 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
         L[e] = v;
     }
     __syncthreads();
+    CHOL_MARK(0);
     auto row = [&](int i) -> double * { return L + (size_t)i * (i + 1) / 2; };
 
     for (int j0 = 0; j0 < n; j0 += kCholNB) {
         const int nb = min(kCholNB, n - j0);
-        if (j0 > 0) {
-            const int nrows = n - j0 + 1;
-            for (int e = tid; e < nrows * nb; e += kCholThreads) {
-                const int i = j0 + e / nb, col = j0 + e % nb;
-                if (col > i) continue;   // above the diagonal (row n >= every col)
-                const double *Li = row(i), *Lc = row(col);
-                double s0 = 0.0, s1 = 0.0;
-                int k = 0;
-                for (; k + 1 < j0; k += 2) { s0 += Li[k] * Lc[k]; s1 += Li[k + 1] * Lc[k + 1]; }
-                if (k < j0) s0 += Li[k] * Lc[k];
-                row(i)[col] -= s0 + s1;
-            }
-        }
-        __syncthreads();
         // B1: wave 0 factors the nb x nb diagonal block in registers (lane r = block row r)
         if (wave == 0) {
             const int r = lane;
@@ -848,6 +843,7 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
                 if (r < nb && c <= r) row(j0 + r)[j0 + c] = a[c];
         }
         __syncthreads();
+        CHOL_MARK(1);
         // B2: every row below the block (and the rhs row) solves against the block's transpose
         for (int i = j0 + nb + tid; i <= n; i += kCholThreads) {
             double *Li = row(i);
@@ -867,6 +863,54 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
             }
         }
         __syncthreads();
+        CHOL_MARK(2);
+        // C: trailing update A[i][j] -= sum_c L[i][j0+c] L[j][j0+c] over j0+nb <= j <= i <= n, j < n, in 4 x 4 tiles
+        {
+            const int base = j0 + nb;
+            const int R = (n + 1 - base + 3) / 4;           // tile rows (the rhs row n included)
+            const int ntile = R * (R + 1) / 2;
+            for (int t = tid; t < ntile; t += kCholThreads) {
+                int ta = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((ta + 1) * (ta + 2) / 2 <= t) ++ta;
+                while (ta * (ta + 1) / 2 > t) --ta;
+                const int tb = t - ta * (ta + 1) / 2;
+                const int i0 = base + 4 * ta, c0 = base + 4 * tb;
+                double acc[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+                const double *ri[4], *rj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ri[r] = row(min(i0 + r, n)) + j0;        // clamped rows are masked at the store
+                    rj[r] = row(min(c0 + r, n)) + j0;
+                }
+#pragma unroll
+                for (int c = 0; c < kCholNB; ++c) {
+                    if (c < nb) {
+                        double li[4], lj[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { li[r] = ri[r][c]; lj[r] = rj[r][c]; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[4 * r + q] += li[r] * lj[q];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r;
+                    if (i > n) continue;
+                    double *Ai = row(i);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = c0 + q;
+                        if (j <= i && j < n) Ai[j] -= acc[4 * r + q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        CHOL_MARK(3);
     }
     // backward substitution L' y = z (z = row n), panels from the bottom
     double *z = row(n);
@@ -890,9 +934,15 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
         }
         __syncthreads();
     }
+    CHOL_MARK(4);
     const bool fail = *failp != 0.0;
     for (int i = tid; i < n; i += kCholThreads) d.y_c[i] = fail ? 0.0 : z[i];
     if (tid == 0 && fail) d.scal[SC_CHOL_FAIL] = 1.0;
+#ifdef ESFM_CHOL_PROFILE
+    CHOL_MARK(5);
+    if (tid == 0) for (int q = 0; q < 6; ++q) atomicAdd(&d.chol[q], prof[q]);
+#endif
+#undef CHOL_MARK
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -56,6 +56,7 @@ struct esfm_ctx {
     // matching scratch
     esfm::DevBuf norms, pair_tab, knn_idx, knn_dist, flagged, counters, stage_a, stage_b, stage_c, stage_d, stage_e;
     esfm::DevBuf setmax;
+    esfm::DevBuf hm_exp;   // Hamming MFMA path: descriptors expanded to +-1 bytes (256 B per 256-bit row)
     // pinned host staging for small tables / counters
     void *pinned = nullptr;
     size_t pinned_cap = 0;

@@ -115,8 +115,10 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             esfm::set_error("hamming descriptors must be 16, 32 or 64 bytes (got %d)", width);
             return ESFM_ERR_UNSUPPORTED;
         }
+        if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, plan.total_rows))) return rc;
         esfm::KernelTimer tm(ctx, ESFM_K_HAMMING_KNN);
-        return esfm::launch_hamming_knn(st, width, desc_dev, dev_tab, n_pairs, plan.n_blocks, knn_idx, knn_dist);
+        return esfm::launch_hamming_knn(st, width, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, n_pairs, plan.n_blocks, knn_idx,
+                                        knn_dist);
     }
     esfm::set_error("unknown metric %d", (int)metric);
     return ESFM_ERR_INVALID_ARG;

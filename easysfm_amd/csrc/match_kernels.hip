@@ -462,6 +462,179 @@ __global__ __launch_bounds__(256) void hamming_knn_kernel(const uint32_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Hamming 2-NN for 256-bit descriptors (ORB) on the i8 matrix cores.  With every bit b stored as the byte 2b - 1,
+//   dot(q, t) = 256 - 2 hamming(q, t),
+// an exact integer identity, so `v_mfma_i32_32x32x32_i8` on the +-1 expansion computes Hamming distances
+// 32 trains x 32 queries x 32 bits at a time; starting the accumulator at 256 and negating the query operand
+// leaves 2 * hamming in the accumulator.  A = train rows (so that a lane's 16 results belong to ONE query, column
+// lane & 31, and 16 different trains), B = query columns held in registers for the whole kernel (2 sets of 32
+// queries per wave: 64 VGPRs), train tiles of 64 rows staged through LDS (row stride 272 B: conflict-free
+// ds_read_b128) and shared by the 4 waves.  K is contracted in whatever order the hardware pairs the 16 bytes a
+// lane supplies -- A and B are loaded with the same lane->byte convention, and the sum does not depend on it.
+// Top-2: running (best, second) pairs of keys 2ham << 21 | L with L = 16 * (32-train group number) + accumulator
+// register -- a wave-uniform scalar, so a result costs v_lshl_or + v_min_u32 + v_med3_u32.  Within a lane L grows
+// with the train index (row(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) is monotonic in r), so key order =
+// (distance, train index); four independent pairs per query set give the VALU chain some slack.  The train index is
+// rebuilt from L at the end, where the slots and the two lane halves are merged.
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+
+constexpr int kHmTT = 64;          // trains per LDS tile
+constexpr int kHmStride = 272;     // bytes per staged train row (256 + 16: rows land 4 banks apart)
+constexpr int kHmQB = 256;         // queries per workgroup (4 waves x 2 sets x 32)
+
+// bits -> +-1 bytes, one 32-bit word (32 output bytes) per thread
+__global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t *__restrict__ desc, long long n_words, uint32_t *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_words) return;
+    const uint32_t w = desc[i];
+    uint32_t o[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const uint32_t x = (w >> (4 * g)) & 0xFu;
+        const uint32_t bytes = (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21);   // one 0/1 byte per bit
+        o[g] = ~(bytes * 0xFEu);                                                                  // 1 -> 0x01, 0 -> 0xFF
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + i * 8);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+__device__ __forceinline__ void key_insert(uint32_t &m1, uint32_t &m2, uint32_t key)
+{
+    uint32_t med;   // second smallest of (m1 <= m2, key); operands are VALU results, no MFMA hazard to pad
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key));
+    m1 = min(m1, key);
+    m2 = med;
+}
+
+__global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned char *__restrict__ ex, const PairDesc *__restrict__ pairs,
+                                                               int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kHmTT * kHmStride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = find_pair_by_block(pairs, n_pairs, lb);
+    const PairDesc pd = pairs[pi];
+    const int nq = pd.nq, nt = pd.nt;
+    const unsigned char *__restrict__ Q = ex + (size_t)pd.q_row0 * 256;
+    const unsigned char *__restrict__ T = ex + (size_t)pd.t_row0 * 256;
+    const int qbase = (lb - pd.blk_off) * kHmQB + wave * 64;
+
+    // B operand: the negated query rows (x ^ 0xFE swaps 0x01 and 0xFF), 8 K-chunks of 32 bytes, this lane's 16
+    i32x4 bq[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool ok = qrow < nq;
+        const i32x4 *qp = reinterpret_cast<const i32x4 *>(Q + (size_t)(ok ? qrow : 0) * 256 + h * 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            i32x4 v = qp[2 * c];
+            const int neg = (int)0xFEFEFEFEu;
+            v.x ^= neg; v.y ^= neg; v.z ^= neg; v.w ^= neg;
+            if (!ok) v = i32x4{0, 0, 0, 0};
+            bq[s][c] = v;
+        }
+    }
+    uint32_t m1[2][4], m2[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m1[s][r] = 0xFFFFFFFFu; m2[s][r] = 0xFFFFFFFFu; }
+
+    const int n_tiles = (nt + kHmTT - 1) / kHmTT;
+    // staging: 256 threads x 64 B = one 64-row tile; thread t -> row t / 4, bytes [64 (t % 4), +64)
+    const int srow = tid >> 2, scol = (tid & 3) * 64;
+    auto stage_load = [&](int tile, uint4 v[4]) {
+        const int row = tile * kHmTT + srow;
+        if (row < nt) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(T + (size_t)row * 256 + scol);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = src[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf, const uint4 v[4]) {
+        uint4 *dst = reinterpret_cast<uint4 *>(&lds[buf][srow * kHmStride + scol]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = v[q];
+    };
+    if (n_tiles > 0) {
+        uint4 v[4];
+        stage_load(0, v);
+        stage_store(0, v);
+    }
+    __syncthreads();
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int buf = tile & 1;
+        uint4 nxt[4];
+        const bool more = tile + 1 < n_tiles;
+        if (more) stage_load(tile + 1, nxt);
+        const bool full = (tile + 1) * kHmTT <= nt;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            i32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 256; acc1[r] = 256; }
+            const unsigned char *arow = &lds[buf][(sub * 32 + j) * kHmStride + h * 16];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + c * 32);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], acc1, 0, 0, 0);
+            }
+            const uint32_t L0 = (uint32_t)(tile * 2 + sub) * 16u;   // wave-uniform
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    key_insert(m1[0][r & 3], m2[0][r & 3], ((uint32_t)acc0[r] << 21) | (L0 + r));
+                    key_insert(m1[1][r & 3], m2[1][r & 3], ((uint32_t)acc1[r] << 21) | (L0 + r));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (tile * 2 + sub) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool ok = idx < nt;   // zero-filled rows past the end of the set
+                    key_insert(m1[0][r & 3], m2[0][r & 3], ok ? (((uint32_t)acc0[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
+                    key_insert(m1[1][r & 3], m2[1][r & 3], ok ? (((uint32_t)acc1[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
+                }
+            }
+        }
+        if (more) stage_store(buf ^ 1, nxt);
+        __syncthreads();
+    }
+    // merge the slots, rebuild full keys (2ham << 21 | train index = ham << 22 | index), then merge the lane halves
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { key_insert(b1, b2, m1[s][r]); key_insert(b1, b2, m2[s][r]); }
+        auto full_key = [&](uint32_t k) {
+            const uint32_t L = k & 0x1FFFFFu, r = L & 15u;
+            const uint32_t idx = (L >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
+            return k == 0xFFFFFFFFu ? k : ((k & 0xFFE00000u) | idx);
+        };
+        b1 = full_key(b1); b2 = full_key(b2);
+        const uint32_t o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+        key_insert(b1, b2, o1);
+        key_insert(b1, b2, o2);
+        const int qrow = qbase + 32 * s + j;
+        if (h == 0 && qrow < nq) {
+            const size_t o = 2 * ((size_t)pd.out_off + qrow);
+            const bool h0 = nt >= 1, h1 = nt >= 2;
+            knn_idx[o] = h0 ? (int)(b1 & 0x3FFFFFu) : -1;
+            knn_idx[o + 1] = h1 ? (int)(b2 & 0x3FFFFFu) : -1;
+            knn_dist[o] = h0 ? (float)(b1 >> 22) : FLT_MAX;
+            knn_dist[o + 1] = h1 ? (float)(b2 >> 22) : FLT_MAX;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Lowe ratio test (feature_matching.cpp:88 / :133: float < double * float, i.e. in double) and an
 // order-preserving compaction: one workgroup per pair, survivors written query-ascending.
 __global__ __launch_bounds__(256) void ratio_compact_kernel(const PairDesc *__restrict__ pairs, const int32_t *__restrict__ knn_idx,
@@ -559,12 +732,20 @@ int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairD
 
 bool hamming_supported(int nbytes) { return nbytes == 16 || nbytes == 32 || nbytes == 64; }
 
-int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, const PairDesc *pairs, int n_pairs, int n_blocks,
-                       int32_t *knn_idx, float *knn_dist)
+size_t hamming_expanded_bytes(int nbytes, long long total_rows) { return nbytes == 32 ? (size_t)256 * (size_t)std::max(total_rows, 1LL) : 0; }
+
+int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs,
+                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist)
 {
     if (n_blocks <= 0) return ESFM_OK;
     const uint32_t *d = reinterpret_cast<const uint32_t *>(desc);
-    if (nbytes == 32)
+    if (nbytes == 32 && exp_scratch) {
+        const long long n_words = total_rows * 8;
+        hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d, n_words,
+                           reinterpret_cast<uint32_t *>(exp_scratch));
+        hipLaunchKernelGGL(hamming_knn_mfma_kernel, dim3(n_blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(exp_scratch),
+                           pairs, n_pairs, knn_idx, knn_dist);
+    } else if (nbytes == 32)
         hipLaunchKernelGGL(hamming_knn_kernel<8>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);
     else if (nbytes == 64)
         hipLaunchKernelGGL(hamming_knn_kernel<16>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);

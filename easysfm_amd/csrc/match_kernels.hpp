@@ -23,7 +23,11 @@ int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairD
                          const int32_t *flagged, const int32_t *counters, long long total_queries, int grid,
                          int32_t *knn_idx, float *knn_dist);
 bool hamming_supported(int nbytes);
-int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, const PairDesc *pairs, int n_pairs, int n_blocks,
+// 256-bit descriptors take the i8-MFMA path, which needs hamming_expanded_bytes(total_rows) of scratch (exp_scratch);
+// other widths run the XOR/popcount kernel and ignore it.
+size_t hamming_expanded_bytes(int nbytes, long long total_rows);
+int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch,
+                       const PairDesc *pairs, int n_pairs, int n_blocks,
                        int32_t *knn_idx, float *knn_dist);
 int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
                          double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
