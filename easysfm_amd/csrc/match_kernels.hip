@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         for (int r = 0; r < 4; ++r) { m1[s][r] = 0xFFFFFFFFu; m2[s][r] = 0xFFFFFFFFu; }
 
     const int n_tiles = (nt + kHmTT - 1) / kHmTT;
+    const int n_full = nt / kHmTT;       // tiles with all 64 rows inside the set: the software-pipelined loop
     // staging: 256 threads x 64 B = one 64-row tile; thread t -> row t / 4, bytes [64 (t % 4), +64)
     const int srow = tid >> 2, scol = (tid & 3) * 64;
     auto stage_load = [&](int tile, uint4 v[4]) {
@@ -569,17 +570,53 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         stage_store(0, v);
     }
     __syncthreads();
-    for (int tile = 0; tile < n_tiles; ++tile) {
+
+    i32x16 k256;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k256[r] = 256;
+    // One 32-train step: 16 MFMAs into (c0, c1), with the top-2 fold of the PREVIOUS step's results (p0, p1) issued
+    // in their shadow -- two inserts (6 VALU) behind each MFMA -- so the matrix pipe and the VALU run concurrently.
+    auto step = [&](const unsigned char *arow, i32x16 &c0, i32x16 &c1, const i32x16 &p0, const i32x16 &p1, uint32_t pL0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + c * 32);
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], c == 0 ? k256 : c0, 0, 0, 0);
+            key_insert(m1[0][(2 * c) & 3], m2[0][(2 * c) & 3], ((uint32_t)p0[2 * c] << 21) | (pL0 + 2 * c));
+            key_insert(m1[0][(2 * c + 1) & 3], m2[0][(2 * c + 1) & 3], ((uint32_t)p0[2 * c + 1] << 21) | (pL0 + 2 * c + 1));
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], c == 0 ? k256 : c1, 0, 0, 0);
+            key_insert(m1[1][(2 * c) & 3], m2[1][(2 * c) & 3], ((uint32_t)p1[2 * c] << 21) | (pL0 + 2 * c));
+            key_insert(m1[1][(2 * c + 1) & 3], m2[1][(2 * c + 1) & 3], ((uint32_t)p1[2 * c + 1] << 21) | (pL0 + 2 * c + 1));
+        }
+    };
+    // 2047 << 21 sorts behind every real key (2 ham <= 512): the first step folds these harmless placeholders
+    i32x16 pa0, pa1, pb0, pb1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pb0[r] = 2047; pb1[r] = 2047; }
+    uint32_t pbL = 0;
+    for (int tile = 0; tile < n_full; ++tile) {
         const int buf = tile & 1;
         uint4 nxt[4];
         const bool more = tile + 1 < n_tiles;
         if (more) stage_load(tile + 1, nxt);
-        const bool full = (tile + 1) * kHmTT <= nt;
+        const unsigned char *arow = &lds[buf][j * kHmStride + h * 16];
+        step(arow, pa0, pa1, pb0, pb1, pbL);                                   // sub 0, folding the previous tile's sub 1
+        step(arow + 32 * kHmStride, pb0, pb1, pa0, pa1, (uint32_t)(tile * 2) * 16u);   // sub 1, folding sub 0
+        pbL = (uint32_t)(tile * 2 + 1) * 16u;
+        if (more) stage_store(buf ^ 1, nxt);
+        __syncthreads();
+    }
+    // drain the pipeline
 #pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        key_insert(m1[0][r & 3], m2[0][r & 3], ((uint32_t)pb0[r] << 21) | (pbL + r));
+        key_insert(m1[1][r & 3], m2[1][r & 3], ((uint32_t)pb1[r] << 21) | (pbL + r));
+    }
+    // the partial tile at the end of the set, rows past it masked out
+    if (n_full < n_tiles) {
+        const int tile = n_full, buf = tile & 1;
+#pragma unroll 1
         for (int sub = 0; sub < 2; ++sub) {
-            i32x16 acc0, acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 256; acc1[r] = 256; }
+            i32x16 acc0 = k256, acc1 = k256;
             const unsigned char *arow = &lds[buf][(sub * 32 + j) * kHmStride + h * 16];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -587,25 +624,15 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], acc1, 0, 0, 0);
             }
-            const uint32_t L0 = (uint32_t)(tile * 2 + sub) * 16u;   // wave-uniform
-            if (full) {
+            const uint32_t L0 = (uint32_t)(tile * 2 + sub) * 16u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    key_insert(m1[0][r & 3], m2[0][r & 3], ((uint32_t)acc0[r] << 21) | (L0 + r));
-                    key_insert(m1[1][r & 3], m2[1][r & 3], ((uint32_t)acc1[r] << 21) | (L0 + r));
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int idx = (tile * 2 + sub) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bool ok = idx < nt;   // zero-filled rows past the end of the set
-                    key_insert(m1[0][r & 3], m2[0][r & 3], ok ? (((uint32_t)acc0[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
-                    key_insert(m1[1][r & 3], m2[1][r & 3], ok ? (((uint32_t)acc1[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int idx = (tile * 2 + sub) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = idx < nt;   // zero-filled rows past the end of the set
+                key_insert(m1[0][r & 3], m2[0][r & 3], ok ? (((uint32_t)acc0[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
+                key_insert(m1[1][r & 3], m2[1][r & 3], ok ? (((uint32_t)acc1[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
             }
         }
-        if (more) stage_store(buf ^ 1, nxt);
-        __syncthreads();
     }
     // merge the slots, rebuild full keys (2ham << 21 | train index = ham << 22 | index), then merge the lane halves
 #pragma unroll
@@ -618,6 +645,8 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
             const uint32_t idx = (L >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
             return k == 0xFFFFFFFFu ? k : ((k & 0xFFE00000u) | idx);
         };
+        // the pipeline's start-up placeholders (2 ham = 2047) lose to every real key; with fewer than two trains they
+        // can surface and are discarded by the nt gates below
         b1 = full_key(b1); b2 = full_key(b2);
         const uint32_t o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
         key_insert(b1, b2, o1);
