@@ -263,6 +263,44 @@ def main() -> int:
             out["ba"] = {"error": repr(e)}
         watchdog.cancel()
 
+    # ---------------------------------------------------------------- ORB leg (row a-2): M-ORB-4k, rank 0 at N = 1
+    if rank == 0 and world == 1 and not args.no_ba:
+        try:
+            osets = synth.orb_like_sets(25, N_FEATS, pool=16384, seed_base=3000)
+            opairs = synth.all_pairs(25)
+            obank = E.DescriptorBank(osets, E.ESFM_HAMMING, device=f"cuda:{local_rank}")
+            opm = E.PairMatcher(obank, opairs)
+            octx = opm.ctx
+            for _ in range(2):
+                opm.match(0.8)
+            octx.synchronize(); octx.set_kernel_timing(True); octx.kernel_time(_lib.K_HAMMING_KNN)
+            t0 = time.perf_counter()
+            n_rep = 10
+            for _ in range(n_rep):
+                opm.match(0.8)
+            octx.synchronize()
+            o_el = time.perf_counter() - t0
+            h_ms, h_n = octx.kernel_time(_lib.K_HAMMING_KNN)
+            octx.set_kernel_timing(False)
+            h_s = h_ms / max(h_n, 1) * 1e-3
+            ops = 2.0 * len(opairs) * N_FEATS * N_FEATS * 256          # i8 MAC ops of the +-1 formulation
+            out["orb"] = {"metric": "image-pairs matched/s (4096 ORB feats/img)", "value": len(opairs) * n_rep / o_el, "unit": "image-pairs/s",
+                          "config": {"workload": "M-ORB-4k all-pairs ORB-256b match (2-NN + ratio 0.8), 25 imgs x 4096 feats x 32 B, 300 pairs/step"},
+                          "kernel": "hamming_expand_kernel + hamming_knn_mfma_kernel", "avg_launch_ms": h_s * 1e3,
+                          "roofline": {"bound": "mfma", "achieved": ops / h_s / 1e12, "peak": 3944.0, "unit": "TOP/s (i8)",
+                                       "frac": ops / h_s / 1e12 / 3944.0},
+                          "valu_equivalent_lane_ops_per_s": 2.0 * len(opairs) * N_FEATS * N_FEATS * 8 / h_s}
+            if not args.no_cpu_baseline:
+                import oracle
+                res = opm.match(0.8).to_host()
+                i, j = opairs[0]
+                rq, rt, rd = oracle.match_hamming(osets[i][:512], osets[j], 0.8)
+                q, t, d = res[0]
+                m = q < 512
+                out["orb"]["verified_vs_oracle"] = bool(np.array_equal(q[m], rq) and np.array_equal(t[m], rt) and np.array_equal(d[m], rd))
+        except Exception as e:
+            out["orb"] = {"error": repr(e)}
+
     # ---------------------------------------------------------------- sparse-cloud outlier filter (row f-3; one cloud: rank 0 at N = 1)
     if rank == 0 and world == 1 and not args.no_ba:
         try:

@@ -12,7 +12,8 @@
 //   l2_exact_scan_kernel     exact brute-force scan for the (rare) queries the
 //                            certificate rejects, and for widths without an MFMA build
 // Hamming (ORB, 256-bit):
-//   hamming_knn_kernel       XOR + popcount, (distance,index) packed into one u32 key
+//   hamming_knn_mfma_kernel  256-bit descriptors: +-1 expansion on the i8 matrix cores (dot = 256 - 2 ham), fused top-2
+//   hamming_knn_kernel       other widths: XOR + popcount, (distance,index) packed into one u32 key
 // Both:
 //   ratio_compact_kernel     ratio test in double + ordered compaction per pair
 //
