@@ -19,7 +19,7 @@ ESFM_L2_F32 = 0
 ESFM_HAMMING = 1
 ESFM_REDUCE_SUM = 0
 ESFM_REDUCE_MAX = 1
-K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN, K_SOR_KNN = range(7)
+K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN, K_SOR_KNN, K_TRIANGULATE = range(8)
 BA_MAX_LOG = 256
 
 STATUS_NAMES = {
@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "esfm_ba_problem_solve", "esfm_ba_problem_get_params", "esfm_ba_problem_destroy", "esfm_ba_problem_cost",
     "esfm_ba_shard_points", "esfm_ba_problem_create_free_calib", "esfm_ba_problem_set_calib", "esfm_ba_problem_get_calib",
     "esfm_ba_problem_fix_camera", "esfm_ba_solve_ex", "esfm_ba_line_search_next_step",
-    "esfm_sor_filter", "esfm_sor_mean_distances_dev",
+    "esfm_sor_filter", "esfm_sor_mean_distances_dev", "esfm_triangulate_points", "esfm_triangulate_pairs",
 ]
 
 
@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
     L.esfm_ba_line_search_next_step.argtypes = [C.c_double] * 5 + [C.c_int] + [C.c_double] * 3 + [C.c_int]
     L.esfm_sor_filter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, i32p, f64p]
     L.esfm_sor_mean_distances_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.esfm_triangulate_points.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    L.esfm_triangulate_pairs.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.esfm_ba_problem_set_params.argtypes = [vp, vp, vp]
     L.esfm_ba_problem_solve.argtypes = [vp, C.POINTER(BAOptions), ALLREDUCE_FN, vp, C.POINTER(BASummary)]
     L.esfm_ba_problem_get_params.argtypes = [vp, vp, vp]

@@ -33,6 +33,14 @@ __device__ __forceinline__ double block_sum(double v, double *lds /*>= 4 doubles
     return s;
 }
 
+// value of lane `l` (wave-uniform index) as a scalar: two v_readlane_b32 instead of the LDS round trip of __shfl
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
 {
     // non-negative doubles order like their bit patterns
@@ -826,14 +834,14 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
 #pragma unroll
             for (int c = 0; c < kCholNB; ++c) {
                 if (c < nb) {
-                    const double piv = __shfl(a[c], c);
+                    const double piv = readlane_f64(a[c], c);
                     if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *failp = 1.0; }
                     const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
                     a[c] = (r == c) ? piv * rinv : a[c] * rinv;
                     if (lane == c) rd[j0 + c] = rinv;
 #pragma unroll
                     for (int c2 = c + 1; c2 < kCholNB; ++c2) {
-                        const double l2 = __shfl(a[c], c2);   // L[j0+c2][j0+c]
+                        const double l2 = readlane_f64(a[c], c2);   // L[j0+c2][j0+c]
                         if (r >= c2) a[c2] -= a[c] * l2;
                     }
                 }
@@ -918,13 +926,22 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
     for (int j0 = last; j0 >= 0; j0 -= kCholNB) {
         const int nb = min(kCholNB, n - j0);
         if (wave == 0) {
-            for (int i = j0 + nb - 1; i >= j0; --i) {
-                const double yi = z[i] * rd[i];
-                if (lane == 0) z[i] = yi;
-                const double *Li = row(i);
-                for (int k = j0 + lane; k < i; k += 64) z[k] -= Li[k] * yi;
-                if (!LDS_STORE) __threadfence_block();
+            // the nb x nb block in registers: lane k holds z[j0+k] and column k of the block (L[j0+i][j0+k], i > k)
+            const int kk = lane;
+            double zk = kk < nb ? z[j0 + kk] : 0.0;
+            double col[kCholNB];
+#pragma unroll
+            for (int i = 0; i < kCholNB; ++i) col[i] = (i < nb && kk < i) ? row(j0 + i)[j0 + kk] : 0.0;
+            const double rdk = kk < nb ? rd[j0 + kk] : 0.0;
+#pragma unroll
+            for (int i = kCholNB - 1; i >= 0; --i) {
+                if (i < nb) {
+                    const double yi = readlane_f64(zk * rdk, i);
+                    zk = (kk == i) ? yi : zk - col[i] * yi;
+                }
             }
+            if (kk < nb) z[j0 + kk] = zk;
+            if (!LDS_STORE) __threadfence_block();
         }
         __syncthreads();
         for (int k = tid; k < j0; k += kCholThreads) {

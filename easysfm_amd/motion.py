@@ -1,0 +1,132 @@
+"""Host-side mirror of the triangulation members of the reference's ``MotionEstimator`` over the C ABI (SURVEY.md section
+8 row f-1, triangulation part): ``getDepthFast`` (cpp_code/src/estimate_motion.cpp:234-283), ``doTriangulation``
+(:285-367) and ``outlierFilter`` (:476-505).  cv::triangulatePoints runs in libesfm_hip.so on the GPU
+(``esfm_triangulate_points``); the statistical filter is the same kernel as ``CProceesing.SORFilter``.  The RANSAC members
+(estimate2D2D_E5P_RANSAC, estimate2D3D_P3P_RANSAC: OpenCV findEssentialMat / recoverPose / solvePnPRansac) are not built."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import Context, check, default_context, lib
+from .cloud import sor_filter
+from .types import DMatch, Frame, SparsePointCloud
+
+
+def triangulate_points(P1, P2, pts1, pts2, ctx: Optional[Context] = None) -> np.ndarray:
+    """esfm_triangulate_points: cv::triangulatePoints(P1, P2, pts1, pts2) -> [n, 4] float32 homogeneous points."""
+    ctx = ctx or default_context()
+    P1 = np.ascontiguousarray(P1, np.float32).reshape(12); P2 = np.ascontiguousarray(P2, np.float32).reshape(12)
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    if a.shape != b.shape:
+        raise ValueError("point sets differ in size")
+    n = a.shape[0]
+    out = np.zeros((max(n, 1), 4), np.float32)
+    check(lib().esfm_triangulate_points(ctx.handle, C.c_void_p(P1.ctypes.data), C.c_void_p(P2.ctypes.data), C.c_void_p(a.ctypes.data),
+                                        C.c_void_p(b.ctypes.data), n, C.c_void_p(out.ctypes.data)))
+    return out[:n]
+
+
+def triangulate_pairs(P1s, P2s, point_offset, pts1, pts2, ctx: Optional[Context] = None) -> np.ndarray:
+    """esfm_triangulate_pairs: many (P1, P2, point range) jobs in one launch."""
+    ctx = ctx or default_context()
+    P1s = np.ascontiguousarray(P1s, np.float32).reshape(-1, 12); P2s = np.ascontiguousarray(P2s, np.float32).reshape(-1, 12)
+    off = np.ascontiguousarray(point_offset, np.int32)
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = a.shape[0]
+    out = np.zeros((max(n, 1), 4), np.float32)
+    check(lib().esfm_triangulate_pairs(ctx.handle, P1s.shape[0], C.c_void_p(P1s.ctypes.data), C.c_void_p(P2s.ctypes.data),
+                                       C.c_void_p(off.ctypes.data), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data),
+                                       C.c_void_p(out.ctypes.data)))
+    return out[:n]
+
+
+def pixel2cam(p: np.ndarray, K: np.ndarray) -> np.ndarray:
+    """estimate_motion.h:41-46, float arithmetic on the float K: ((u - cx) / fx, (v - cy) / fy)."""
+    p = np.asarray(p, np.float32).reshape(-1, 2); K = np.asarray(K, np.float32)
+    return np.stack([(p[:, 0] - K[0, 2]) / K[0, 0], (p[:, 1] - K[1, 2]) / K[1, 1]], axis=1).astype(np.float32)
+
+
+def _dehomogenise(h: np.ndarray) -> np.ndarray:
+    """pts_3d /= pts_3d.at<float>(3, 0) (estimate_motion.cpp:271, :341): float division."""
+    return (h[:, :3] / h[:, 3:4]).astype(np.float32)
+
+
+class MotionEstimator:
+    """Mirror of p3dv::MotionEstimator (estimate_motion.h), triangulation members only."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+
+    def getDepthFast(self, cur_frame_1: Frame, cur_frame_2: Frame, T_21: np.ndarray, matches: Sequence[DMatch],
+                     random_rate: int = 20) -> float:
+        """estimate_motion.cpp:234-283: triangulate every `random_rate`-th match between the identity camera and T_21 and
+        return the mean distance of the points from the first camera (in baseline lengths).  NaN for an empty sample, like
+        the reference's 0 / 0."""
+        T1 = np.eye(4, dtype=np.float32)[:3]
+        T2 = (np.asarray(T_21, np.float32) @ np.eye(4, dtype=np.float32))[:3]
+        sel = [m for i, m in enumerate(matches) if i % random_rate == 0]
+        if not sel:
+            return float("nan")
+        k1 = np.asarray(cur_frame_1.keypoints, np.float32).reshape(-1, 2)[[m.queryIdx for m in sel]]
+        k2 = np.asarray(cur_frame_2.keypoints, np.float32).reshape(-1, 2)[[m.trainIdx for m in sel]]
+        h = triangulate_points(T1, T2, pixel2cam(k1, cur_frame_1.K_cam), pixel2cam(k2, cur_frame_1.K_cam), self._ctx)   # K of frame 1 for both (:245)
+        p = _dehomogenise(h)
+        depth_sum = 0.0
+        for v in p:                                                     # Eigen::Vector3f::norm(), accumulated in double (:279)
+            depth_sum += float(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])))
+        return depth_sum / len(p)
+
+    def doTriangulation(self, cur_frame_1: Frame, cur_frame_2: Frame, matches: Sequence[DMatch],
+                        sparse_pointcloud: SparsePointCloud, show: bool = False, rgb_image: Optional[np.ndarray] = None) -> bool:
+        """estimate_motion.cpp:285-367: matches whose track id (of frame 1's keypoint) is not in the cloud yet are
+        triangulated from the two frames' poses and appended; colour from frame 1's image at the keypoint (BGR -> RGB,
+        :347-353) when an image is given.  As in the reference the colour lookup indexes `matches[i]` with the index of
+        the i-th NEW point (:345), which differs from the point's own match once any match was skipped."""
+        T1 = np.asarray(cur_frame_1.pose_cam, np.float32)[:3]
+        T2 = np.asarray(cur_frame_2.pose_cam, np.float32)[:3]
+        known = set(int(v) for v in np.asarray(sparse_pointcloud.unique_point_ids).tolist())
+        ids = np.asarray(cur_frame_1.unique_pixel_ids)
+        new_q, new_t, new_ids = [], [], []
+        for m in matches:
+            uid = int(ids[m.queryIdx])
+            if uid in known:
+                continue
+            known.add(uid)                                   # a repeated id inside this call is "already in world" too (:309-316)
+            new_ids.append(uid); new_q.append(m.queryIdx); new_t.append(m.trainIdx)
+        if new_ids:
+            k1 = np.asarray(cur_frame_1.keypoints, np.float32).reshape(-1, 2)
+            k2 = np.asarray(cur_frame_2.keypoints, np.float32).reshape(-1, 2)
+            h = triangulate_points(T1, T2, pixel2cam(k1[new_q], cur_frame_1.K_cam), pixel2cam(k2[new_t], cur_frame_1.K_cam), self._ctx)
+            xyz = _dehomogenise(h)
+            rgb = np.zeros((len(new_ids), 3), np.uint8)
+            if rgb_image is not None:
+                for i in range(len(new_ids)):
+                    px = k1[matches[i].queryIdx]                                  # :345, the reference's indexing
+                    b, g, r = rgb_image[int(px[1]), int(px[0])][:3]
+                    rgb[i] = (r, g, b)
+            old_xyz = np.asarray(sparse_pointcloud.xyz, np.float32).reshape(-1, 3)
+            old_rgb = np.asarray(sparse_pointcloud.rgb, np.uint8).reshape(-1, 3)
+            if len(old_rgb) != len(old_xyz):
+                old_rgb = np.zeros((len(old_xyz), 3), np.uint8)
+            sparse_pointcloud.xyz = np.concatenate([old_xyz, xyz])
+            sparse_pointcloud.rgb = np.concatenate([old_rgb, rgb])
+            sparse_pointcloud.unique_point_ids = np.concatenate([np.asarray(sparse_pointcloud.unique_point_ids, np.int64), np.array(new_ids, np.int64)])
+            sparse_pointcloud.is_inlier = np.concatenate([np.asarray(sparse_pointcloud.is_inlier, np.int32), np.ones(len(new_ids), np.int32)])
+        print(f"Triangulate [ {len(new_ids)} ] new points, [ {len(sparse_pointcloud.xyz)} ] points in total.")
+        return True
+
+    def outlierFilter(self, sparse_pointcloud: SparsePointCloud, MeanK: int = 40, std: float = 2.5) -> bool:
+        """estimate_motion.cpp:476-505: statistical outlier removal that keeps ids and inlier flags aligned."""
+        xyz = np.asarray(sparse_pointcloud.xyz, np.float32).reshape(-1, 3)
+        keep, _, _ = sor_filter(xyz, MeanK, std, self._ctx)
+        n0 = len(xyz)
+        sparse_pointcloud.xyz = xyz[keep].copy()
+        if len(sparse_pointcloud.rgb) == n0:
+            sparse_pointcloud.rgb = np.asarray(sparse_pointcloud.rgb)[keep].copy()
+        sparse_pointcloud.unique_point_ids = np.asarray(sparse_pointcloud.unique_point_ids)[keep].copy()
+        sparse_pointcloud.is_inlier = np.asarray(sparse_pointcloud.is_inlier)[keep].copy()
+        print(f"apply outlier filter: [ {n0} ] points before filtering, [ {int(keep.sum())} ] points after filtering.")
+        return True

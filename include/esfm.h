@@ -82,7 +82,8 @@ typedef enum esfm_kernel_id {
     ESFM_K_BA_SOLVE = 4,      /* ba_chol_solve_kernel                                           */
     ESFM_K_L2_RESCAN = 5,     /* l2_exact_scan_kernel                                           */
     ESFM_K_SOR_KNN = 6,       /* sor_knn_mean_kernel: k-NN mean distances of the outlier filter   */
-    ESFM_K_COUNT = 7
+    ESFM_K_TRIANGULATE = 7,   /* triangulate_dlt_kernel                                         */
+    ESFM_K_COUNT = 8
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -343,6 +344,22 @@ int esfm_sor_filter(esfm_ctx *ctx, const float *points, int n, int stride_floats
 /* The k-NN pass alone on device-resident points (what bench.py times); asynchronous on the context's stream. */
 int esfm_sor_mean_distances_dev(esfm_ctx *ctx, const float *points_dev, int n, int stride_floats, int mean_k,
                                 float *mean_dist_dev /*n*/);
+
+/* ---- two-view triangulation (triangulation part) -----------------------
+ * cv::triangulatePoints as MotionEstimator::getDepthFast (cpp_code/src/estimate_motion.cpp:263, once per image pair inside
+ * the matching loop, test/sfm.cpp:166) and doTriangulation (:333) call it: proj1 / proj2 are the 3 x 4 CV_32F projection
+ * matrices [R | t] (row-major, 12 floats), pts1 / pts2 the correspondences as normalised image points
+ * ((u - cx) / fx, (v - cy) / fy: pixel2cam, include/estimate_motion.h:41-46; 2 floats per point), and the result is the
+ * 4 x N CV_32F matrix of homogeneous points, stored here point-major: points4d[4 i + 0..3] = X, Y, Z, W.  Each point is
+ * the right singular vector of the smallest singular value of the 4 x 4 DLT system (rows x P[2] - P[0], y P[2] - P[1]),
+ * evaluated in double like cvTriangulatePoints; it is defined up to sign, which the callers' division by W removes
+ * (estimate_motion.cpp:271, :341).  Host pointers. */
+int esfm_triangulate_points(esfm_ctx *ctx, const float *proj1, const float *proj2, const float *pts1, const float *pts2, int n,
+                            float *points4d /*4*n*/);
+/* Batched form for the pair loop: pair p uses proj1[12 p..], proj2[12 p..] and the points
+ * [point_offset[p], point_offset[p+1]) of pts1 / pts2 / points4d; one launch for all pairs. */
+int esfm_triangulate_pairs(esfm_ctx *ctx, int n_pairs, const float *proj1, const float *proj2, const int32_t *point_offset /*n_pairs+1*/,
+                           const float *pts1, const float *pts2, float *points4d);
 
 #ifdef __cplusplus
 }

@@ -79,7 +79,7 @@ class BASummary(C.Structure):
 def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     path = os.path.join(_HERE, out)
-    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
@@ -137,6 +137,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_sor_mean_distances.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p]
     lib.esfm_ref_sor_filter.restype = C.c_int
     lib.esfm_ref_sor_filter.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_double, _f32p, _u8p, C.POINTER(C.c_double)]
+    lib.esfm_ref_triangulate_points.restype = None
+    lib.esfm_ref_triangulate_points.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int, _f32p]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -326,3 +328,15 @@ def sor_filter(points, mean_k: int = 50, std_mul: float = 2.0):
     md = np.zeros(max(n, 1), np.float32); keep = np.zeros(max(n, 1), np.uint8); thr = C.c_double(0.0)
     load().esfm_ref_sor_filter(pts.reshape(-1), n, stride, int(mean_k), float(std_mul), md, keep, C.byref(thr))
     return keep[:n].astype(bool), md[:n], thr.value
+
+
+# ----------------------------------------------------------------------------- two-view triangulation
+def triangulate_points(P1, P2, pts1, pts2) -> np.ndarray:
+    """cv::triangulatePoints as estimate_motion.cpp:263/:333 call it.  P: [3,4] float32; pts: [n,2] float32 normalised
+    image points.  Returns the homogeneous points [n,4] float32 (sign of each row arbitrary)."""
+    P1 = np.ascontiguousarray(P1, np.float32).reshape(12); P2 = np.ascontiguousarray(P2, np.float32).reshape(12)
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = a.shape[0]
+    out = np.zeros(max(4 * n, 1), np.float32)
+    load().esfm_ref_triangulate_points(P1, P2, a.reshape(-1), b.reshape(-1), n, out)
+    return out[:4 * n].reshape(n, 4)
