@@ -28,6 +28,8 @@ C oracle (oracle/*.c) is pinned by tests/test_oracle_golden.py:
                             point, a cloud smaller than MeanK + 1; expected mean distances from a full float32 distance
                             matrix evaluated as ((dx*dx + dy*dy) + dz*dz), numpy sort, sequential float64 cumsum of float32
                             square roots; threshold from sequential cumsums
+  triangulation_cases.npz   cv::triangulatePoints (estimate_motion.cpp:263, :333): random two-view geometries incl. a short
+                            baseline and noisy points; expected homogeneous points from numpy.linalg.svd of the f64 DLT matrix
 
     python tests/golden/make_golden.py
 """
@@ -515,6 +517,27 @@ def make_sor():
     np.savez_compressed(os.path.join(HERE, "sor_cases.npz"), **out)
 
 
+def make_triangulation():
+    rng = np.random.default_rng(606)
+    out = {}
+    for tag, n, base, noise in (("wide", 300, 1.0, 0.0), ("noisy", 300, 1.0, 2e-3), ("short_baseline", 200, 0.05, 2e-4)):
+        R = synth.aa_to_R(rng.normal(0, 0.15, 3)); t = np.array([base, 0.1 * base, -0.05 * base])
+        P1 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+        P2 = np.hstack([R, t[:, None]]).astype(np.float32)
+        X = rng.uniform(-2, 2, (n, 3)) + np.array([0, 0, 7.0])
+        x1 = (X[:, :2] / X[:, 2:3] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+        Xc = X @ R.T + t
+        x2 = (Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+        H = np.zeros((n, 4))
+        for i in range(n):
+            A = np.array([x1[i, 0].astype(np.float64) * P1[2].astype(np.float64) - P1[0], x1[i, 1].astype(np.float64) * P1[2].astype(np.float64) - P1[1],
+                          x2[i, 0].astype(np.float64) * P2[2].astype(np.float64) - P2[0], x2[i, 1].astype(np.float64) * P2[2].astype(np.float64) - P2[1]], np.float64)
+            H[i] = np.linalg.svd(A)[2][3]
+        out[f"{tag}.P1"] = P1; out[f"{tag}.P2"] = P2; out[f"{tag}.x1"] = x1; out[f"{tag}.x2"] = x2
+        out[f"{tag}.points4d"] = H.astype(np.float32); out[f"{tag}.X"] = X
+    np.savez_compressed(os.path.join(HERE, "triangulation_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     make_hamming()
     make_l2()
@@ -522,4 +545,5 @@ if __name__ == "__main__":
     make_ba_trace()
     make_ba_constrained()
     make_sor()
+    make_triangulation()
     print("golden vectors written to", HERE)

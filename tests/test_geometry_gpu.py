@@ -90,3 +90,13 @@ def test_mirror_getDepthFast_doTriangulation_outlierFilter(gpu_ctx, oracle_lib):
     n0 = len(cloud.xyz)
     me.outlierFilter(cloud)
     assert len(cloud.xyz) == len(cloud.unique_point_ids) == len(cloud.is_inlier) < n0 and 1007 not in cloud.unique_point_ids
+
+
+@pytest.mark.parametrize("tag", ["wide", "noisy", "short_baseline"])
+def test_triangulation_golden(gpu_ctx, tag):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "triangulation_cases.npz"))
+    h = E.triangulate_points(z[f"{tag}.P1"], z[f"{tag}.P2"], z[f"{tag}.x1"], z[f"{tag}.x2"], gpu_ctx)
+    g = z[f"{tag}.points4d"]
+    # short baseline: the two smallest singular values are close and the eigenvector of A'A loses digits -- 2e-5
+    assert np.allclose(h * np.sign(h[:, 3:4]), g * np.sign(g[:, 3:4]), rtol=0, atol=2e-5 if tag == "short_baseline" else 1e-6)

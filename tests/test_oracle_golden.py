@@ -190,3 +190,14 @@ def test_sor_golden_bitexact(oracle_lib, tag):
     assert np.array_equal(keep, z[f"{tag}.keep"])
     if tag == "blobs":
         assert 0 < (~keep).sum() < 200 and (~keep)[2000:].sum() >= 30      # the planted far points go
+
+
+@pytest.mark.parametrize("tag", ["wide", "noisy", "short_baseline"])
+def test_triangulation_golden(oracle_lib, tag):
+    """cv::triangulatePoints restatement (one-sided Jacobi) == numpy.linalg.svd of the same f64 DLT matrix, as floats."""
+    z = np.load(os.path.join(GOLD, "triangulation_cases.npz"))
+    h = oracle_lib.triangulate_points(z[f"{tag}.P1"], z[f"{tag}.P2"], z[f"{tag}.x1"], z[f"{tag}.x2"])
+    g = z[f"{tag}.points4d"]
+    assert np.allclose(h * np.sign(h[:, 3:4]), g * np.sign(g[:, 3:4]), rtol=0, atol=3e-7)      # unit vectors, 2 float ulps
+    if tag == "wide":
+        assert np.allclose(h[:, :3] / h[:, 3:4], z[f"{tag}.X"], atol=2e-4)
