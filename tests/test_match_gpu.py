@@ -178,3 +178,37 @@ def test_full_size_properties(gpu_ctx, oracle_lib):
     assert np.array_equal(_bits(dist2), _bits(dist))
     same = dist[:, 0] != dist[:, 1]
     assert np.array_equal(perm[idx2[same, 0]], idx[same, 0])
+
+
+def test_config4_one_rank_shard_at_full_size(gpu_ctx, oracle_lib):
+    """BASELINE config 4 (8192 SURF features per image, all pairs sharded over 8 GPUs, no collective): rank 3's share of the
+    pair list on one GPU, pairs at full size (8192 x 8192 x 64).  96 images instead of 256 keep the test short -- the image
+    count only multiplies the number of pairs (570 here, 4080 at 256 images).  Size-independent checks: the shard is a cost-balanced eighth of the (i, j < i) list;
+    per-pair output slices tile the output exactly; sampled pairs agree with the oracle bit for bit on sampled query rows;
+    every emitted match passes the ratio test against its own 2-NN record."""
+    n_img, n_feat, world, rank = 96, 8192, 8, 3
+    sets = synth.surf_like_sets(n_img, n_feat, pool=65536, seed_base=2000)
+    rows = np.full(n_img, n_feat, np.int32)
+    pairs = E.shard_pair_list(n_img, rows, rank, world)
+    assert abs(len(pairs) - n_img * (n_img - 1) // 2 / world) <= 1
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
+    pm = E.PairMatcher(bank, pairs)
+    res = pm.match(0.5)
+    host = res.to_host()
+    assert len(host) == len(pairs)
+    off = pm.offset
+    assert off[0] == 0 and np.all(np.diff(off) == n_feat) and off[-1] == len(pairs) * n_feat
+    n_q, n_rescan = pm.stats()
+    assert n_q == len(pairs) * n_feat and n_rescan < n_q // 100
+    rng = np.random.default_rng(5)
+    total = 0
+    for k in rng.choice(len(pairs), 4, replace=False):
+        i, j = pairs[k]
+        q, t, d = host[k]
+        total += len(q)
+        assert np.all(np.diff(q) > 0) and (len(q) == 0 or (q[-1] < n_feat and t.max() < n_feat))
+        sel = np.sort(rng.choice(n_feat, 96, replace=False))
+        rq, rt, rd = oracle_lib.match_l2(sets[i][sel], sets[j], 0.5)
+        m = np.isin(q, sel)
+        assert np.array_equal(np.searchsorted(sel, q[m]), rq) and np.array_equal(t[m], rt) and np.array_equal(_bits(d[m]), _bits(rd))
+    assert total > 0
