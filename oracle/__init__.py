@@ -79,7 +79,7 @@ class BASummary(C.Structure):
 def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     path = os.path.join(_HERE, out)
-    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
@@ -139,6 +139,17 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_sor_filter.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_double, _f32p, _u8p, C.POINTER(C.c_double)]
     lib.esfm_ref_triangulate_points.restype = None
     lib.esfm_ref_triangulate_points.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int, _f32p]
+    lib.esfm_ref_ransac_samples.restype = None
+    lib.esfm_ref_ransac_samples.argtypes = [C.c_int, C.c_int, _i32p]
+    lib.esfm_ref_five_point.restype = C.c_int
+    lib.esfm_ref_five_point.argtypes = [_f64p, _f64p, _f64p]
+    lib.esfm_ref_find_essential_ransac.restype = C.c_int
+    lib.esfm_ref_find_essential_ransac.argtypes = [_f32p, _f32p, C.c_int, _f32p, C.c_double, C.c_double, _f64p, _u8p,
+                                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.esfm_ref_decompose_essential.restype = None
+    lib.esfm_ref_decompose_essential.argtypes = [_f64p, _f64p, _f64p, _f64p]
+    lib.esfm_ref_recover_pose.restype = C.c_int
+    lib.esfm_ref_recover_pose.argtypes = [_f64p, _f32p, _f32p, C.c_int, _f32p, _f64p, _f64p, _u8p]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -340,3 +351,44 @@ def triangulate_points(P1, P2, pts1, pts2) -> np.ndarray:
     out = np.zeros(max(4 * n, 1), np.float32)
     load().esfm_ref_triangulate_points(P1, P2, a.reshape(-1), b.reshape(-1), n, out)
     return out[:4 * n].reshape(n, 4)
+
+
+# ----------------------------------------------------------------------------- essential matrix RANSAC + pose
+def ransac_samples(count: int, n_samples: int) -> np.ndarray:
+    """The 5-index samples RANSACPointSetRegistrator::getSubset draws from cv::RNG((uint64)-1)."""
+    idx = np.zeros(5 * max(n_samples, 1), np.int32)
+    load().esfm_ref_ransac_samples(int(count), int(n_samples), idx)
+    return idx[:5 * n_samples].reshape(n_samples, 5)
+
+
+def five_point(q1, q2) -> np.ndarray:
+    """EMEstimatorCallback::runKernel on 5 normalised correspondences: [k, 3, 3] essential matrices (k <= 10)."""
+    a = np.ascontiguousarray(q1, np.float64).reshape(10); b = np.ascontiguousarray(q2, np.float64).reshape(10)
+    out = np.zeros(90, np.float64)
+    k = load().esfm_ref_five_point(a, b, out)
+    return out[:9 * k].reshape(k, 3, 3)
+
+
+def find_essential_ransac(pts1, pts2, K4, prob: float = 0.99, threshold: float = 1.0):
+    """cv::findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold, mask).  Returns (ok, E [3,3], mask [n] bool,
+    iterations run, inlier count)."""
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = a.shape[0]
+    E = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8)
+    it = C.c_int32(0); cnt = C.c_int32(0)
+    ok = load().esfm_ref_find_essential_ransac(a.reshape(-1), b.reshape(-1), n, np.ascontiguousarray(K4, np.float32).reshape(4),
+                                               float(prob), float(threshold), E, mask, C.byref(it), C.byref(cnt))
+    return bool(ok), E.reshape(3, 3), mask[:n].astype(bool), it.value, cnt.value
+
+
+def recover_pose(E, pts1, pts2, K4, mask=None):
+    """cv::recoverPose(E, pts1, pts2, K, R, t, mask).  Returns (good, R [3,3], t [3], mask)."""
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = a.shape[0]
+    m = np.ones(max(n, 1), np.uint8) if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8)).copy()
+    if len(m) < max(n, 1):
+        m = np.ones(max(n, 1), np.uint8)
+    R = np.zeros(9, np.float64); t = np.zeros(3, np.float64)
+    g = load().esfm_ref_recover_pose(np.ascontiguousarray(E, np.float64).reshape(9), a.reshape(-1), b.reshape(-1), n,
+                                     np.ascontiguousarray(K4, np.float32).reshape(4), R, t, m)
+    return int(g), R.reshape(3, 3), t, m[:n].astype(bool)
