@@ -13,6 +13,7 @@ from .ba import (BAProblem, BundleAdjustment, ba_solve, ba_solve_ex, default_opt
                  torch_allreduce_callback)
 
 from .cloud import CProceesing, read_ply_vertices, sor_filter, write_ply  # noqa: F401
-from .motion import MotionEstimator, pixel2cam, triangulate_pairs, triangulate_points  # noqa: F401
+from .motion import (MotionEstimator, find_essential_mat, find_essential_pairs, pixel2cam, ransac_sample_stream, recover_pose,  # noqa: F401
+                     triangulate_pairs, triangulate_points)
 
 __version__ = "0.1.0"

@@ -1,0 +1,458 @@
+// Two-view geometric verification for gfx950 (MI355X): the device side of the replacement for
+// cv::findEssentialMat(..., CV_RANSAC, ...) + cv::recoverPose as MotionEstimator::estimate2D2D_E5P_RANSAC calls them
+// (reference cpp_code/src/estimate_motion.cpp:49-67; once per matched image pair, cpp_code/test/sfm.cpp:165).
+// SURVEY.md section 8 row f-1.
+//
+// RANSAC hypotheses are data-parallel: the sample stream of cv::RNG is replayed on the host (it is a 64-bit
+// multiply-with-carry recurrence, sequential by nature and a few microseconds long), every hypothesis of a chunk of
+// iterations of every pair is then solved and scored concurrently, and the host replays OpenCV's sequential
+// best-model / adaptive-iteration-count bookkeeping on the inlier counts -- the result is the one the sequential loop
+// reaches, independent of the chunk size.
+//
+//   essential_solve_kernel   one thread per (pair, iteration): 5-point kernel -> up to 10 essential matrices
+//   essential_score_kernel   one workgroup per (pair, iteration): Sampson inlier count of each of its models
+//   essential_mask_kernel    one workgroup per pair: inlier mask of the winning model
+//   pose_cheirality_kernel   one workgroup per (pair, candidate pose): f64 DLT triangulation + cheirality test per point
+//
+// All arithmetic in f64 like OpenCV; the error is rounded to float before the threshold test like
+// RANSACPointSetRegistrator::findInliers.
+#include "ransac_kernels.hpp"
+
+#include <float.h>
+#include <math.h>
+
+namespace esfm {
+
+// ---- trivariate polynomial bookkeeping -------------------------------------------------------------------------------
+// cubic monomials in the solver's column order: x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1
+// quadratic order: x2 y2 z2 xy xz yz x y z 1        linear order: x y z 1
+__constant__ signed char kLinLin[4][4] = {      // product of two linear monomials -> quadratic index
+    {0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
+__constant__ signed char kQuadLin[10][4] = {    // quadratic monomial x linear monomial -> cubic column
+    /* x2 */ {0, 2, 4, 5},   /* y2 */ {3, 1, 6, 7},   /* z2 */ {10, 13, 16, 17}, /* xy */ {2, 3, 8, 9}, /* xz */ {4, 8, 10, 11},
+    /* yz */ {8, 6, 13, 14}, /* x  */ {5, 9, 11, 12}, /* y  */ {9, 7, 14, 15},   /* z  */ {11, 14, 17, 18}, /* 1 */ {12, 15, 18, 19}};
+
+__device__ __forceinline__ void quad_mul_acc(const double *a, const double *b, double s, double *q)   // q += s * a * b (linear x linear)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[kLinLin[i][j]] += s * a[i] * b[j];
+}
+
+__device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, double s, double *c)  // c += s * q * l (quadratic x linear)
+{
+    for (int i = 0; i < 10; ++i) {
+        const double qi = s * q[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[kQuadLin[i][j]] += qi * l[j];
+    }
+}
+
+// real roots of c[0] + ... + c[10] z^10 (Durand-Kerner on all complex roots, Newton polish), ascending; returns the count
+__device__ int real_roots_deg10(const double *c, double *out)
+{
+    int n = 10;
+    while (n > 0 && c[n] == 0.0) --n;
+    if (n <= 0) return 0;
+    double re[10], im[10];
+    double bound = 0.0;
+    for (int i = 0; i < n; ++i) bound = fmax(bound, fabs(c[i] / c[n]));
+    bound = 1.0 + bound;
+    for (int i = 0; i < n; ++i) {
+        const double a = 2.0 * 3.14159265358979323846 * i / n + 0.4, r = 0.5 * bound * pow(0.9, (double)i);
+        re[i] = r * cos(a); im[i] = r * sin(a);
+    }
+    for (int it = 0; it < 2000; ++it) {
+        double move = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double pr = c[n], pi = 0.0;
+            for (int k = n - 1; k >= 0; --k) { const double t = pr * re[i] - pi * im[i] + c[k]; pi = pr * im[i] + pi * re[i]; pr = t; }
+            double dr = c[n], di = 0.0;
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                const double ar = re[i] - re[j], ai = im[i] - im[j];
+                const double t = dr * ar - di * ai; di = dr * ai + di * ar; dr = t;
+            }
+            const double den = dr * dr + di * di;
+            if (den == 0.0) continue;
+            const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
+            re[i] -= qr; im[i] -= qi;
+            move = fmax(move, fabs(qr) + fabs(qi));
+        }
+        if (move <= 1e-15 * bound) break;
+    }
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (fabs(im[i]) > 1e-10 * fmax(1.0, fabs(re[i]))) continue;
+        double z = re[i];
+        for (int it = 0; it < 3; ++it) {
+            double p = c[n], d = 0.0;
+            for (int k = n - 1; k >= 0; --k) { d = d * z + p; p = p * z + c[k]; }
+            if (d == 0.0) break;
+            z -= p / d;
+        }
+        out[m++] = z;
+    }
+    for (int i = 1; i < m; ++i) { const double v = out[i]; int j = i - 1; while (j >= 0 && out[j] > v) { out[j + 1] = out[j]; --j; } out[j + 1] = v; }
+    return m;
+}
+
+// EMEstimatorCallback::runKernel [upstream five-point.cpp]: q1, q2 = 5 normalised correspondences.  Writes up to 10 unit-norm
+// essential matrices (row-major) to E_out, each with its largest-magnitude entry positive, in ascending order of E[0][0]
+// (a basis-independent order; OpenCV's is whatever cv::solvePoly and its SVD basis produce); returns the count.
+__device__ int five_point(const double *q1, const double *q2, double *E_out)
+{
+    // null space of the 5 x 9 epipolar system by Gauss-Jordan with complete pivoting: 4 basis vectors N[k][9]
+    double Q[5][9];
+    for (int i = 0; i < 5; ++i) {
+        const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
+        Q[i][0] = x2 * x1; Q[i][1] = x2 * y1; Q[i][2] = x2; Q[i][3] = y2 * x1; Q[i][4] = y2 * y1; Q[i][5] = y2; Q[i][6] = x1; Q[i][7] = y1; Q[i][8] = 1.0;
+    }
+    int colperm[9];
+    for (int c = 0; c < 9; ++c) colperm[c] = c;
+    for (int k = 0; k < 5; ++k) {
+        int pr = k, pc = k; double best = -1.0;
+        for (int r = k; r < 5; ++r) for (int c = k; c < 9; ++c) { const double v = fabs(Q[r][c]); if (v > best) { best = v; pr = r; pc = c; } }
+        if (!(best > 1e-300)) return 0;
+        for (int c = 0; c < 9; ++c) { const double t = Q[k][c]; Q[k][c] = Q[pr][c]; Q[pr][c] = t; }
+        for (int r = 0; r < 5; ++r) { const double t = Q[r][k]; Q[r][k] = Q[r][pc]; Q[r][pc] = t; }
+        { const int t = colperm[k]; colperm[k] = colperm[pc]; colperm[pc] = t; }
+        const double inv = 1.0 / Q[k][k];
+        for (int c = 0; c < 9; ++c) Q[k][c] *= inv;
+        for (int r = 0; r < 5; ++r) {
+            if (r == k) continue;
+            const double f = Q[r][k];
+            for (int c = 0; c < 9; ++c) Q[r][c] -= f * Q[k][c];
+        }
+    }
+    double N[4][9];
+    for (int k = 0; k < 4; ++k) {
+        double nn = 1.0;
+        for (int a = 0; a < 9; ++a) N[k][a] = 0.0;
+        N[k][colperm[5 + k]] = 1.0;
+        for (int r = 0; r < 5; ++r) { const double v = -Q[r][5 + k]; N[k][colperm[r]] = v; nn += v * v; }
+        nn = 1.0 / sqrt(nn);
+        for (int a = 0; a < 9; ++a) N[k][a] *= nn;
+    }
+    // E(x, y, z) = x N0 + y N1 + z N2 + N3: entry (r, c) as the linear polynomial L[r][c][4]
+    double L[3][3][4];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) for (int k = 0; k < 4; ++k) L[r][c][k] = N[k][3 * r + c];
+    // G = E E' (6 unique quadratic entries) and its trace
+    double G[3][3][10];
+    for (int r = 0; r < 3; ++r)
+        for (int c = r; c < 3; ++c) {
+            for (int k = 0; k < 10; ++k) G[r][c][k] = 0.0;
+            for (int k = 0; k < 3; ++k) quad_mul_acc(L[r][k], L[c][k], 1.0, G[r][c]);
+            if (c != r) for (int k = 0; k < 10; ++k) G[c][r][k] = G[r][c][k];
+        }
+    double tr[10];
+    for (int k = 0; k < 10; ++k) tr[k] = G[0][0][k] + G[1][1][k] + G[2][2][k];
+    double M[10][20];
+    for (int r = 0; r < 10; ++r) for (int c = 0; c < 20; ++c) M[r][c] = 0.0;
+    // row 0: det E = sum_c E[0][c] * cofactor(0, c)
+    for (int c = 0; c < 3; ++c) {
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        double cof[10];
+        for (int k = 0; k < 10; ++k) cof[k] = 0.0;
+        quad_mul_acc(L[1][c1], L[2][c2], 1.0, cof);
+        quad_mul_acc(L[1][c2], L[2][c1], -1.0, cof);
+        cubic_mul_acc(cof, L[0][c], 1.0, M[0]);
+    }
+    // rows 1..9: 2 (E E') E - tr(E E') E
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double *row = M[1 + 3 * r + c];
+            for (int k = 0; k < 3; ++k) cubic_mul_acc(G[r][k], L[k][c], 2.0, row);
+            cubic_mul_acc(tr, L[r][c], -1.0, row);
+        }
+    // Gauss-Jordan on the first ten columns
+    for (int col = 0; col < 10; ++col) {
+        int piv = col; double best = fabs(M[col][col]);
+        for (int r = col + 1; r < 10; ++r) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
+        if (!(best > 1e-300)) return 0;
+        if (piv != col) for (int c = 0; c < 20; ++c) { const double t = M[col][c]; M[col][c] = M[piv][c]; M[piv][c] = t; }
+        const double inv = 1.0 / M[col][col];
+        for (int c = col; c < 20; ++c) M[col][c] *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            const double f = M[r][col];
+            if (f == 0.0) continue;
+            for (int c = col; c < 20; ++c) M[r][c] -= f * M[col][c];
+        }
+    }
+    // B(z): rows (4,5), (6,7), (8,9); P, Qp degree 3 and R degree 4, lowest degree first
+    double P[3][4], Qp[3][4], R[3][5];
+    for (int i = 0; i < 3; ++i) {
+        const double *a = &M[2 * i + 4][10], *b = &M[2 * i + 5][10];
+        P[i][3] = -b[0]; P[i][2] = a[0] - b[1]; P[i][1] = a[1] - b[2]; P[i][0] = a[2];
+        Qp[i][3] = -b[3]; Qp[i][2] = a[3] - b[4]; Qp[i][1] = a[4] - b[5]; Qp[i][0] = a[5];
+        R[i][4] = -b[6]; R[i][3] = a[6] - b[7]; R[i][2] = a[7] - b[8]; R[i][1] = a[8] - b[9]; R[i][0] = a[9];
+    }
+    double det[11];
+    for (int k = 0; k < 11; ++k) det[k] = 0.0;
+    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    const double sgn[6] = {1, -1, -1, 1, 1, -1};
+    for (int s = 0; s < 6; ++s) {
+        const int a = perm[s][0], b = perm[s][1], c = perm[s][2];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                const double pq = sgn[s] * P[a][i] * Qp[b][j];
+                for (int k = 0; k < 5; ++k) det[i + j + k] += pq * R[c][k];
+            }
+    }
+    double zs[10];
+    const int nz = real_roots_deg10(det, zs);
+    int count = 0;
+    for (int t = 0; t < nz && count < 10; ++t) {
+        const double z = zs[t];
+        double Bz[3][3];
+        for (int j = 0; j < 3; ++j) {
+            Bz[j][0] = ((P[j][3] * z + P[j][2]) * z + P[j][1]) * z + P[j][0];
+            Bz[j][1] = ((Qp[j][3] * z + Qp[j][2]) * z + Qp[j][1]) * z + Qp[j][0];
+            Bz[j][2] = (((R[j][4] * z + R[j][3]) * z + R[j][2]) * z + R[j][1]) * z + R[j][0];
+        }
+        // null vector of the (numerically rank-2) B(z): the largest of the three row cross products
+        double bx = 0, by = 0, bw = 0, bn = -1.0;
+        for (int a = 0; a < 3; ++a) {
+            const int b = (a + 1) % 3;
+            const double cx = Bz[a][1] * Bz[b][2] - Bz[a][2] * Bz[b][1], cy = Bz[a][2] * Bz[b][0] - Bz[a][0] * Bz[b][2],
+                         cw = Bz[a][0] * Bz[b][1] - Bz[a][1] * Bz[b][0];
+            const double nn = cx * cx + cy * cy + cw * cw;
+            if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
+        }
+        if (!(bn > 0.0) || fabs(bw) < 1e-10 * sqrt(bn)) continue;
+        const double x = bx / bw, y = by / bw;
+        double Ev[9], nrm = 0.0;
+        for (int a = 0; a < 9; ++a) { Ev[a] = x * N[0][a] + y * N[1][a] + z * N[2][a] + N[3][a]; nrm += Ev[a] * Ev[a]; }
+        nrm = 1.0 / sqrt(nrm);
+        int big = 0;
+        for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
+        if (Ev[big] < 0.0) nrm = -nrm;
+        for (int a = 0; a < 9; ++a) E_out[9 * count + a] = Ev[a] * nrm;
+        ++count;
+    }
+    for (int i = 1; i < count; ++i) {   // insertion sort by E[0][0]
+        double tmp[9];
+        for (int a = 0; a < 9; ++a) tmp[a] = E_out[9 * i + a];
+        int j = i - 1;
+        while (j >= 0 && E_out[9 * j] > tmp[0]) { for (int a = 0; a < 9; ++a) E_out[9 * (j + 1) + a] = E_out[9 * j + a]; --j; }
+        for (int a = 0; a < 9; ++a) E_out[9 * (j + 1) + a] = tmp[a];
+    }
+    return count;
+}
+
+__device__ __forceinline__ void normalise_pt(const RansacPair &pr, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int i,
+                                             double &x1, double &y1, double &x2, double &y2)
+{
+    const float2 a = p1[pr.first + i], b = p2[pr.first + i];
+    x1 = ((double)a.x - pr.cx) / pr.fx; y1 = ((double)a.y - pr.cy) / pr.fy;
+    x2 = ((double)b.x - pr.cx) / pr.fx; y2 = ((double)b.y - pr.cy) / pr.fy;
+}
+
+// one thread per (pair, iteration of this chunk)
+__global__ __launch_bounds__(64) void essential_solve_kernel(const RansacPair *__restrict__ pairs, int n_pairs, const float2 *__restrict__ p1,
+                                                             const float2 *__restrict__ p2, const int32_t *__restrict__ samples, int chunk,
+                                                             double *__restrict__ models, int32_t *__restrict__ n_models)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_pairs * chunk) return;
+    const int pi = g / chunk;
+    const RansacPair pr = pairs[pi];
+    const int32_t *id = samples + 5 * (size_t)g;
+    if (!pr.active || id[0] < 0) { n_models[g] = 0; return; }
+    double q1[10], q2[10];
+    for (int k = 0; k < 5; ++k) normalise_pt(pr, p1, p2, id[k], q1[2 * k], q1[2 * k + 1], q2[2 * k], q2[2 * k + 1]);
+    double E[90];
+    const int nm = five_point(q1, q2, E);
+    n_models[g] = nm;
+    double *dst = models + 90 * (size_t)g;
+    for (int k = 0; k < 9 * nm; ++k) dst[k] = E[k];
+}
+
+__device__ __forceinline__ bool sampson_inlier(const double *E, double x1, double y1, double x2, double y2, float t)
+{
+    const double Ex0 = E[0] * x1 + E[1] * y1 + E[2], Ex1 = E[3] * x1 + E[4] * y1 + E[5], Ex2 = E[6] * x1 + E[7] * y1 + E[8];
+    const double Et0 = E[0] * x2 + E[3] * y2 + E[6], Et1 = E[1] * x2 + E[4] * y2 + E[7];
+    const double v = x2 * Ex0 + y2 * Ex1 + Ex2;
+    const float err = (float)(v * v / (Ex0 * Ex0 + Ex1 * Ex1 + Et0 * Et0 + Et1 * Et1));
+    return err <= t;
+}
+
+// one workgroup per (pair, iteration): counts[g][m] = inliers of model m
+__global__ __launch_bounds__(256) void essential_score_kernel(const RansacPair *__restrict__ pairs, const float2 *__restrict__ p1,
+                                                              const float2 *__restrict__ p2, int chunk, const double *__restrict__ models,
+                                                              const int32_t *__restrict__ n_models, int32_t *__restrict__ counts)
+{
+    __shared__ int red[10][4];
+    __shared__ double sE[90];
+    const int g = blockIdx.x;
+    const int nm = n_models[g];
+    if (nm <= 0) return;
+    const RansacPair pr = pairs[g / chunk];
+    for (int k = threadIdx.x; k < 9 * nm; k += 256) sE[k] = models[90 * (size_t)g + k];
+    __syncthreads();
+    int cnt[10];
+#pragma unroll
+    for (int m = 0; m < 10; ++m) cnt[m] = 0;
+    for (int i = threadIdx.x; i < pr.count; i += 256) {
+        double x1, y1, x2, y2;
+        normalise_pt(pr, p1, p2, i, x1, y1, x2, y2);
+#pragma unroll
+        for (int m = 0; m < 10; ++m)
+            if (m < nm) cnt[m] += sampson_inlier(sE + 9 * m, x1, y1, x2, y2, pr.thresh_sq) ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+        int v = cnt[m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[m][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) counts[10 * (size_t)g + threadIdx.x] = threadIdx.x < nm ? red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3] : 0;
+}
+
+// one workgroup per pair: inlier mask of its best model (best[9 * pair])
+__global__ __launch_bounds__(256) void essential_mask_kernel(const RansacPair *__restrict__ pairs, const float2 *__restrict__ p1,
+                                                             const float2 *__restrict__ p2, const double *__restrict__ best,
+                                                             uint8_t *__restrict__ mask)
+{
+    const RansacPair pr = pairs[blockIdx.x];
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = best[9 * (size_t)blockIdx.x + k];
+    for (int i = threadIdx.x; i < pr.count; i += 256) {
+        double x1, y1, x2, y2;
+        normalise_pt(pr, p1, p2, i, x1, y1, x2, y2);
+        mask[pr.first + i] = sampson_inlier(E, x1, y1, x2, y2, pr.thresh_sq) ? 1 : 0;
+    }
+}
+
+// smallest right singular vector of the 4 x 4 DLT system of ([I|0], P) in double (cv::triangulatePoints on CV_64F input)
+__device__ void triangulate_f64(const double *P, double x0, double y0, double x1, double y1, double X[4])
+{
+    double A[4][4];
+    A[0][0] = -1.0; A[0][1] = 0.0; A[0][2] = x0; A[0][3] = 0.0;
+    A[1][0] = 0.0; A[1][1] = -1.0; A[1][2] = y0; A[1][3] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { A[2][k] = x1 * P[8 + k] - P[k]; A[3][k] = y1 * P[8 + k] - P[4 + k]; }
+    double M[4][4], V[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += A[r][p] * A[r][q];
+            M[p][q] = s; V[p][q] = p == q ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0, diag = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            diag += M[p][p] * M[p][p];
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) off += M[p][q] * M[p][q];
+        }
+        if (off <= 1e-34 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = M[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const double mp = M[r][p], mq = M[r][q]; M[r][p] = c * mp - s * mq; M[r][q] = s * mp + c * mq; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const double mp = M[p][r], mq = M[q][r]; M[p][r] = c * mp - s * mq; M[q][r] = s * mp + c * mq; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const double vp = V[r][p], vq = V[r][q]; V[r][p] = c * vp - s * vq; V[r][q] = s * vp + c * vq; }
+            }
+    }
+    int best = 0;
+    double bv = M[0][0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (M[k][k] < bv) { bv = M[k][k]; best = k; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = V[r][0];
+        v = best == 1 ? V[r][1] : v; v = best == 2 ? V[r][2] : v; v = best == 3 ? V[r][3] : v;
+        X[r] = v;
+    }
+}
+
+// grid (4, n_pairs): candidate pose c of pair p.  poses[p][c] = 3 x 4 [R | t].  cand_mask[c][point], good[p][c].
+__global__ __launch_bounds__(256) void pose_cheirality_kernel(const RansacPair *__restrict__ pairs, const float2 *__restrict__ p1,
+                                                              const float2 *__restrict__ p2, const double *__restrict__ poses,
+                                                              const uint8_t *__restrict__ in_mask, int n_total, uint8_t *__restrict__ cand_mask,
+                                                              int32_t *__restrict__ good)
+{
+    __shared__ int red[4];
+    const int c = blockIdx.x, pi = blockIdx.y;
+    const RansacPair pr = pairs[pi];
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = poses[12 * (4 * (size_t)pi + c) + k];
+    int cnt = 0;
+    for (int i = threadIdx.x; i < pr.count; i += 256) {
+        double x0, y0, x1, y1;
+        normalise_pt(pr, p1, p2, i, x0, y0, x1, y1);
+        double Q[4];
+        triangulate_f64(P, x0, y0, x1, y1, Q);
+        bool m = Q[2] * Q[3] > 0.0;
+        const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
+        m = m && (Z < pr.dist_thresh);
+        const double Z2 = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+        m = m && (Z2 > 0.0) && (Z2 < pr.dist_thresh);
+        if (in_mask) m = m && in_mask[pr.first + i] != 0;
+        cand_mask[(size_t)c * n_total + pr.first + i] = m ? 1 : 0;
+        cnt += m ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) good[4 * pi + c] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------
+int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const int32_t *samples,
+                           int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx)
+{
+    const int n = n_pairs * chunk;
+    if (n <= 0) return ESFM_OK;
+    KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
+    hipLaunchKernelGGL(essential_solve_kernel, dim3((n + 63) / 64), dim3(64), 0, st, pairs, n_pairs, reinterpret_cast<const float2 *>(p1),
+                       reinterpret_cast<const float2 *>(p2), samples, chunk, models, n_models);
+    ESFM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(essential_score_kernel, dim3(n), dim3(256), 0, st, pairs, reinterpret_cast<const float2 *>(p1),
+                       reinterpret_cast<const float2 *>(p2), chunk, models, n_models, counts);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_essential_mask(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *best, uint8_t *mask)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(essential_mask_kernel, dim3(n_pairs), dim3(256), 0, st, pairs, reinterpret_cast<const float2 *>(p1),
+                       reinterpret_cast<const float2 *>(p2), best, mask);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_pose_cheirality(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *poses,
+                           const uint8_t *in_mask, int n_total, uint8_t *cand_mask, int32_t *good)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(pose_cheirality_kernel, dim3(4, n_pairs), dim3(256), 0, st, pairs, reinterpret_cast<const float2 *>(p1),
+                       reinterpret_cast<const float2 *>(p2), poses, in_mask, n_total, cand_mask, good);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+}  // namespace esfm

@@ -1,0 +1,23 @@
+// Launch interface between ransac_api.cpp (cv::RNG replay, RANSAC bookkeeping, pose selection on the host) and ransac_kernels.hip.
+#pragma once
+
+#include "common.hpp"
+
+namespace esfm {
+
+struct RansacPair {       // one image pair's correspondences inside the concatenated point arrays
+    int32_t first, count;
+    int32_t active, pad;  // still iterating in this round
+    double fx, cx, fy, cy;
+    float thresh_sq;      // (float)((threshold / ((fx + fy) / 2))^2), findInliers' cut on the float error
+    float pad2;
+    double dist_thresh;   // recoverPose's distanceThresh (50)
+};
+
+int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const int32_t *samples,
+                           int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx);
+int launch_essential_mask(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *best, uint8_t *mask);
+int launch_pose_cheirality(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *poses,
+                           const uint8_t *in_mask, int n_total, uint8_t *cand_mask, int32_t *good);
+
+}  // namespace esfm

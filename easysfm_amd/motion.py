@@ -1,8 +1,9 @@
 """Host-side mirror of the triangulation members of the reference's ``MotionEstimator`` over the C ABI (SURVEY.md section
 8 row f-1, triangulation part): ``getDepthFast`` (cpp_code/src/estimate_motion.cpp:234-283), ``doTriangulation``
 (:285-367) and ``outlierFilter`` (:476-505).  cv::triangulatePoints runs in libesfm_hip.so on the GPU
-(``esfm_triangulate_points``); the statistical filter is the same kernel as ``CProceesing.SORFilter``.  The RANSAC members
-(estimate2D2D_E5P_RANSAC, estimate2D3D_P3P_RANSAC: OpenCV findEssentialMat / recoverPose / solvePnPRansac) are not built."""
+(``esfm_triangulate_points``); the statistical filter is the same kernel as ``CProceesing.SORFilter``;
+``estimate2D2D_E5P_RANSAC`` (:27-97) = cv::findEssentialMat(RANSAC) + cv::recoverPose runs through ``esfm_find_essential_mat`` /
+``esfm_recover_pose`` (hypotheses solved and scored on the GPU).  ``estimate2D3D_P3P_RANSAC`` (solvePnPRansac / EPnP) is not built."""
 from __future__ import annotations
 
 import ctypes as C
@@ -43,6 +44,69 @@ def triangulate_pairs(P1s, P2s, point_offset, pts1, pts2, ctx: Optional[Context]
     return out[:n]
 
 
+def _k4(K) -> np.ndarray:
+    K = np.asarray(K, np.float32)
+    return np.array([K[0, 0], K[0, 2], K[1, 1], K[1, 2]], np.float32) if K.shape == (3, 3) else np.ascontiguousarray(K, np.float32).reshape(4)
+
+
+def find_essential_mat(pts1, pts2, K, prob: float = 0.999, threshold: float = 1.0, ctx: Optional[Context] = None):
+    """cv::findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold, mask) -> (E [3,3] float64, mask [n] bool, iterations).
+    K: 3x3 camera matrix or (fx, cx, fy, cy).  Raises EsfmError when OpenCV would return an empty matrix."""
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    if a.shape != b.shape:
+        raise ValueError("point sets differ in size")
+    n = a.shape[0]
+    k4 = _k4(K)
+    E = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8); it = C.c_int32(0)
+    check(lib().esfm_find_essential_mat(ctx.handle, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), n, C.c_void_p(k4.ctypes.data),
+                                        float(prob), float(threshold), C.c_void_p(E.ctypes.data), C.c_void_p(mask.ctypes.data), C.byref(it)))
+    return E.reshape(3, 3), mask[:n].astype(bool), it.value
+
+
+def find_essential_pairs(point_offset, pts1, pts2, K4_per_pair, prob: float = 0.999, threshold: float = 1.0, ctx: Optional[Context] = None):
+    """esfm_find_essential_pairs: every pair's RANSAC in shared launches -> (E [p,3,3], mask [n_total] bool, status [p] bool,
+    iterations [p])."""
+    ctx = ctx or default_context()
+    off = np.ascontiguousarray(point_offset, np.int32)
+    n_pairs = len(off) - 1
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    k4 = np.ascontiguousarray(K4_per_pair, np.float32).reshape(-1, 4)
+    n = a.shape[0]
+    E = np.zeros((max(n_pairs, 1), 9), np.float64); mask = np.zeros(max(n, 1), np.uint8)
+    status = np.zeros(max(n_pairs, 1), np.int32); iters = np.zeros(max(n_pairs, 1), np.int32)
+    check(lib().esfm_find_essential_pairs(ctx.handle, n_pairs, C.c_void_p(off.ctypes.data), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data),
+                                          C.c_void_p(k4.ctypes.data), float(prob), float(threshold), C.c_void_p(E.ctypes.data),
+                                          C.c_void_p(mask.ctypes.data), C.c_void_p(status.ctypes.data), C.c_void_p(iters.ctypes.data)))
+    return E[:n_pairs].reshape(n_pairs, 3, 3), mask[:n].astype(bool), status[:n_pairs].astype(bool), iters[:n_pairs]
+
+
+def recover_pose(E, pts1, pts2, K, mask=None, ctx: Optional[Context] = None):
+    """cv::recoverPose(E, pts1, pts2, K, R, t, mask) -> (good, R [3,3], t [3], mask [n] bool or None)."""
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = a.shape[0]
+    k4 = _k4(K)
+    Ev = np.ascontiguousarray(E, np.float64).reshape(9)
+    R = np.zeros(9, np.float64); t = np.zeros(3, np.float64); good = C.c_int32(0)
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8)).copy()
+    if m is not None and len(m) != n:
+        raise ValueError("mask size")
+    if m is not None and n == 0:
+        m = np.zeros(1, np.uint8)
+    check(lib().esfm_recover_pose(ctx.handle, C.c_void_p(Ev.ctypes.data), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), n,
+                                  C.c_void_p(k4.ctypes.data), C.c_void_p(R.ctypes.data), C.c_void_p(t.ctypes.data),
+                                  None if m is None else C.c_void_p(m.ctypes.data), C.byref(good)))
+    return good.value, R.reshape(3, 3), t, (None if m is None else m[:n].astype(bool))
+
+
+def ransac_sample_stream(count: int, n_samples: int) -> np.ndarray:
+    """Host-only: the 5-index samples OpenCV's RANSAC draws for `count` points (esfm_ransac_sample_stream)."""
+    idx = np.zeros((max(n_samples, 1), 5), np.int32)
+    check(lib().esfm_ransac_sample_stream(int(count), int(n_samples), C.c_void_p(idx.ctypes.data)))
+    return idx[:n_samples]
+
+
 def pixel2cam(p: np.ndarray, K: np.ndarray) -> np.ndarray:
     """estimate_motion.h:41-46, float arithmetic on the float K: ((u - cx) / fx, (v - cy) / fy)."""
     p = np.asarray(p, np.float32).reshape(-1, 2); K = np.asarray(K, np.float32)
@@ -59,6 +123,21 @@ class MotionEstimator:
 
     def __init__(self, ctx: Optional[Context] = None):
         self._ctx = ctx
+
+    def estimate2D2D_E5P_RANSAC(self, cur_frame_1: Frame, cur_frame_2: Frame, matches: Sequence[DMatch], inlier_matches: list,
+                                ransac_thre: float = 1.0, ransac_prob: float = 0.99, show: bool = False) -> np.ndarray:
+        """estimate_motion.cpp:27-97: essential matrix by 5-point RANSAC on the matched pixels (frame 1's K for both images,
+        :43-44), inliers appended to `inlier_matches` from the RANSAC mask (:55-61), then recoverPose with that mask (:67).
+        Returns T (4 x 4 float32, [R | t; 0 0 0 1], :78-85) mapping frame 1's camera coordinates to frame 2's."""
+        k1 = np.asarray(cur_frame_1.keypoints, np.float32).reshape(-1, 2)[[m.queryIdx for m in matches]].reshape(-1, 2)
+        k2 = np.asarray(cur_frame_2.keypoints, np.float32).reshape(-1, 2)[[m.trainIdx for m in matches]].reshape(-1, 2)
+        E, mask, _ = find_essential_mat(k1, k2, cur_frame_1.K_cam, ransac_prob, ransac_thre, self._ctx)
+        inlier_matches.extend(m for m, keep in zip(matches, mask) if keep)
+        _, R, t, _ = recover_pose(E, k1, k2, cur_frame_1.K_cam, mask, self._ctx)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = R.astype(np.float32); T[:3, 3] = t.astype(np.float32)       # cv2eigen into Matrix3f / Vector3f (:76-79)
+        print(f"Find [{int(mask.sum())}] inlier matches from [{len(matches)}] total matches.")
+        return T
 
     def getDepthFast(self, cur_frame_1: Frame, cur_frame_2: Frame, T_21: np.ndarray, matches: Sequence[DMatch],
                      random_rate: int = 20) -> float:

@@ -83,7 +83,8 @@ typedef enum esfm_kernel_id {
     ESFM_K_L2_RESCAN = 5,     /* l2_exact_scan_kernel                                           */
     ESFM_K_SOR_KNN = 6,       /* sor_knn_mean_kernel: k-NN mean distances of the outlier filter   */
     ESFM_K_TRIANGULATE = 7,   /* triangulate_dlt_kernel                                         */
-    ESFM_K_COUNT = 8
+    ESFM_K_RANSAC = 8,        /* essential_solve_kernel + essential_score_kernel (one chunk)    */
+    ESFM_K_COUNT = 9
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -360,6 +361,45 @@ int esfm_triangulate_points(esfm_ctx *ctx, const float *proj1, const float *proj
  * [point_offset[p], point_offset[p+1]) of pts1 / pts2 / points4d; one launch for all pairs. */
 int esfm_triangulate_pairs(esfm_ctx *ctx, int n_pairs, const float *proj1, const float *proj2, const int32_t *point_offset /*n_pairs+1*/,
                            const float *pts1, const float *pts2, float *points4d);
+
+/* ---- essential-matrix RANSAC and pose recovery --------------------------
+ * MotionEstimator::estimate2D2D_E5P_RANSAC (cpp_code/src/estimate_motion.cpp:27-97, once per matched pair at
+ * cpp_code/test/sfm.cpp:165) = cv::findEssentialMat(pts1, pts2, K, CV_RANSAC, prob, threshold, mask) (:49) followed by
+ * cv::recoverPose(E, pts1, pts2, K, R, t, mask) (:67).
+ *
+ * esfm_find_essential_mat: pts1 / pts2 are the n matched pixel positions (2 floats each, cv::Point2f), K4 = fx, cx, fy,
+ * cy of the float camera matrix (the reference passes frame 1's K for both images, :43-44).  Points are normalised in
+ * double, threshold is divided by (fx + fy) / 2, and OpenCV's RANSAC runs with 5 model points, confidence `prob` and at
+ * most 1000 iterations on the sample stream of cv::RNG((uint64)-1): each sample goes through the 5-point kernel (up to 10
+ * models), each model is scored by the Sampson distance (float error <= (float)threshold^2), a model replaces the best
+ * iff it has more inliers (and more than 4), and the iteration count adapts (RANSACUpdateNumIters).  E[9] row-major with
+ * unit Frobenius norm, mask[n] = inliers of the winning model, *iterations = iterations the sequential loop runs.
+ * Returns ESFM_ERR_NUMERIC when no model is found (n < 5, or no model with at least 5 inliers): OpenCV returns an empty
+ * matrix there.  Every model gets a canonical sign (largest-magnitude entry positive) and the models of one sample are
+ * tried in ascending order of E[0][0] (OpenCV: cv::solvePoly's root order and its SVD basis' sign, both artefacts); this
+ * only decides ties between models of the same sample.
+ *
+ * The `_pairs` forms batch many image pairs (pair p owns points [point_offset[p], point_offset[p+1]) and K4_per_pair[4 p..]):
+ * all hypotheses of a chunk of iterations of all pairs are solved and scored in one launch; status[p] = 1 iff pair p has
+ * a model.  Results are those of the per-pair calls. */
+int esfm_find_essential_mat(esfm_ctx *ctx, const float *pts1, const float *pts2, int n, const float *K4, double prob,
+                            double threshold, double *E /*9*/, uint8_t *mask /*n*/, int32_t *iterations /*or NULL*/);
+int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_offset /*n_pairs+1*/, const float *pts1,
+                              const float *pts2, const float *K4_per_pair, double prob, double threshold,
+                              double *E /*9 per pair*/, uint8_t *mask /*per point*/, int32_t *status /*per pair*/,
+                              int32_t *iterations /*per pair or NULL*/);
+/* cv::recoverPose with distanceThresh = 50: the four poses of decomposeEssentialMat (SVD, W = [0 1 0; -1 0 0; 0 0 1]) in
+ * the order (R1, t), (R2, t), (R1, -t), (R2, -t); for each, every point is triangulated in double against [I | 0] and
+ * kept iff Z W > 0 and Z / W < 50 in the first camera and 0 < Z < 50 in the second; with `mask` (in/out, or NULL) the
+ * tests are AND-ed with it; the pose with the most points wins (first in order on ties).  R[9] row-major, t[3] unit
+ * length, *good = its point count. */
+int esfm_recover_pose(esfm_ctx *ctx, const double *E, const float *pts1, const float *pts2, int n, const float *K4,
+                      double *R, double *t, uint8_t *mask /*n, in/out, or NULL*/, int32_t *good /*or NULL*/);
+int esfm_recover_pose_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_offset, const float *pts1, const float *pts2,
+                            const float *K4_per_pair, const double *E /*9 per pair*/, uint8_t *mask /*in/out or NULL*/,
+                            double *R /*9 per pair*/, double *t /*3 per pair*/, int32_t *good /*per pair or NULL*/);
+/* Host-only (no GPU): the first n_samples 5-index samples RANSAC draws for `count` points (cv::RNG replay). */
+int esfm_ransac_sample_stream(int count, int n_samples, int32_t *idx /*5 per sample*/);
 
 #ifdef __cplusplus
 }

@@ -20,8 +20,10 @@
  *                      z2 z 1, Gauss-Jordan on the first ten columns, rows (4,5) (6,7) (8,9) combined to a 3 x 3 polynomial
  *                      matrix in z whose determinant is the degree-10 polynomial; its real roots (|imag| <= 1e-10) give z,
  *                      the null vector of B(z) gives x, y; E = x E1 + y E2 + z E3 + E4, scaled to unit Frobenius norm.
- *                      Deviations: the solutions of one sample are ordered by ascending z (cv::solvePoly's order is an
- *                      artefact of its iteration; the order only breaks ties between models of the same sample);
+ *                      Deviations: OpenCV tries the models of one sample in the order cv::solvePoly emits the roots, with
+ *                      the sign its SVD null-space basis happens to give -- artefacts of its iteration that only decide
+ *                      ties between models of the same sample.  Here every model is given a canonical sign (its
+ *                      largest-magnitude entry positive) and the models of a sample are ordered by ascending E[0][0];
  *                      the polynomial roots come from a Durand-Kerner iteration written here, not cv::solvePoly itself.
  *   recoverPose        decomposeEssentialMat (SVD, det U, det V' forced positive, W = [0 1 0; -1 0 0; 0 0 1]); the four
  *                      (R, t) candidates in OpenCV's order (R1,t) (R2,t) (R1,-t) (R2,-t); per candidate every point is
@@ -273,8 +275,18 @@ int esfm_ref_five_point(const double *q1, const double *q2, double *E_out)
         double Ev[9], nrm = 0.0;
         for (int a = 0; a < 9; ++a) { Ev[a] = x * N[0][a] + y * N[1][a] + z * N[2][a] + N[3][a]; nrm += Ev[a] * Ev[a]; }
         nrm = sqrt(nrm);
+        int big = 0;
+        for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
+        if (Ev[big] < 0) nrm = -nrm;                                   /* canonical sign */
         for (int a = 0; a < 9; ++a) E_out[9 * count + a] = Ev[a] / nrm;
         ++count;
+    }
+    /* canonical order: ascending E[0][0] */
+    for (int i = 1; i < count; ++i) {
+        double tmp[9]; memcpy(tmp, E_out + 9 * i, sizeof(tmp));
+        int j = i - 1;
+        while (j >= 0 && E_out[9 * j] > tmp[0]) { memcpy(E_out + 9 * (j + 1), E_out + 9 * j, sizeof(tmp)); --j; }
+        memcpy(E_out + 9 * (j + 1), tmp, sizeof(tmp));
     }
     return count;
 }

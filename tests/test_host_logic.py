@@ -191,3 +191,16 @@ def test_ply_writer_layout(tmp_path):
     xyz, rgb, cam = E.read_ply_vertices(path)
     assert np.array_equal(xyz, cloud.xyz) and np.array_equal(rgb, cloud.rgb)
     assert cam == "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 1 2 0 0"                    # viewport = width 1 x height N (:151-152)
+
+
+def test_ransac_sample_stream_matches_oracle(oracle_lib):
+    """cv::RNG((uint64)-1) + getSubset replayed on the host on both sides: identical 5-index samples."""
+    for count in (5, 6, 37, 1000, 4096):
+        a = E.ransac_sample_stream(count, 300)
+        b = oracle_lib.ransac_samples(count, 300)
+        assert np.array_equal(a, b)
+        assert a.min() >= 0 and a.max() < count and all(len(set(r)) == 5 for r in a.tolist())
+    # the recurrence itself: state' = lo32(state) * 4164903690 + hi32(state)
+    s = 0xFFFFFFFFFFFFFFFF
+    s = (s & 0xFFFFFFFF) * 4164903690 + (s >> 32)
+    assert E.ransac_sample_stream(1000, 1)[0, 0] == (s & 0xFFFFFFFF) % 1000

@@ -1,0 +1,102 @@
+"""Parity of the HIP essential-matrix RANSAC + pose recovery (reference cv::findEssentialMat /
+cv::recoverPose at cpp_code/src/estimate_motion.cpp:49-67) through the C ABI against the CPU oracle.
+
+Both sides replay the same cv::RNG sample stream and the same sequential bookkeeping, so the iteration counts, the winning
+sample and the inlier MASKS must agree exactly; the essential matrix comes out of two differently conditioned f64
+computations of the same 5-point kernel (null space by Gauss-Jordan on the GPU, by eigenvectors in the oracle) and agrees to
+1e-8 on the unit-norm matrix (stated floating-point tolerance); rotation / translation to 1e-7."""
+import numpy as np
+import pytest
+
+import easysfm_amd as E
+from easysfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+K4 = np.array(synth.FOUNTAIN_K4, np.float32)
+
+
+def _pair(rng, n, outlier_frac=0.3, noise=0.3, baseline=1.0):
+    R = synth.aa_to_R(rng.normal(0, 0.15, 3)); t = np.array([baseline, 0.1, -0.05]) + rng.normal(0, 0.05, 3)
+    t = t / np.linalg.norm(t)
+    X = rng.uniform(-2, 2, (n, 3)) + np.array([0, 0, 8.0])
+    x1 = X[:, :2] / X[:, 2:3]
+    Xc = X @ R.T + t
+    x2 = Xc[:, :2] / Xc[:, 2:3]
+    p1 = (x1 * [K4[0], K4[2]] + [K4[1], K4[3]]).astype(np.float32)
+    p2 = (x2 * [K4[0], K4[2]] + [K4[1], K4[3]] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    out = rng.choice(n, int(outlier_frac * n), replace=False)
+    p2[out] += rng.uniform(-60, 60, (len(out), 2)).astype(np.float32)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Egt = tx @ R
+    return p1, p2, R, t, Egt / np.linalg.norm(Egt), out
+
+
+def _same_E(a, b, tol):
+    return min(np.abs(a - b).max(), np.abs(a + b).max()) <= tol
+
+
+@pytest.mark.parametrize("n,frac,seed", [(400, 0.3, 0), (80, 0.5, 1), (2000, 0.2, 2), (30, 0.6, 3), (6, 0.0, 4)])
+def test_find_essential_and_pose_match_oracle(gpu_ctx, oracle_lib, n, frac, seed):
+    rng = np.random.default_rng(seed)
+    p1, p2, R, t, Egt, out = _pair(rng, n, frac)
+    ok, Er, mr, itr, cnt = oracle_lib.find_essential_ransac(p1, p2, K4, 0.99, 1.0)
+    assert ok
+    Eg, mg, itg = E.find_essential_mat(p1, p2, K4, 0.99, 1.0, gpu_ctx)
+    assert itg == itr
+    assert np.array_equal(mg, mr) and int(mg.sum()) == cnt
+    assert _same_E(Eg, Er, 1e-8)
+    assert abs(np.linalg.norm(Eg) - 1.0) < 1e-12
+    if n >= 80:
+        assert _same_E(Eg, Egt, 0.05) and mg[out].sum() <= 0.1 * len(out) + 2
+    good_r, Rr, tr, m2r = oracle_lib.recover_pose(Er, p1, p2, K4, mr)
+    good_g, Rg, tg, m2g = E.recover_pose(Eg, p1, p2, K4, mg, gpu_ctx)
+    assert good_g == good_r and np.array_equal(m2g, m2r)
+    assert np.allclose(Rg, Rr, atol=1e-7) and np.allclose(tg, tr, atol=1e-7)
+    if n >= 80:
+        assert np.allclose(Rg, R, atol=0.02) and np.allclose(tg, t, atol=0.05) and abs(np.linalg.det(Rg) - 1) < 1e-9
+
+
+def test_exactly_five_points_and_too_few(gpu_ctx, oracle_lib):
+    rng = np.random.default_rng(7)
+    p1, p2, *_ = _pair(rng, 5, 0.0, noise=0.0)
+    Eg, mg, it = E.find_essential_mat(p1, p2, K4, 0.99, 1.0, gpu_ctx)
+    ok, Er, mr, itr, cnt = oracle_lib.find_essential_ransac(p1, p2, K4, 0.99, 1.0)
+    assert ok and np.all(mg) and np.all(mr) and _same_E(Eg, Er, 1e-7)
+    with pytest.raises(E.EsfmError):
+        E.find_essential_mat(p1[:4], p2[:4], K4, 0.99, 1.0, gpu_ctx)
+
+
+def test_batched_pairs_equal_single_calls(gpu_ctx, oracle_lib):
+    rng = np.random.default_rng(11)
+    jobs = [_pair(rng, n, f) for n, f in ((300, 0.3), (3, 0.0), (120, 0.5), (900, 0.1), (40, 0.7))]
+    off = np.concatenate([[0], np.cumsum([len(j[0]) for j in jobs])]).astype(np.int32)
+    a = np.concatenate([j[0] for j in jobs]); b = np.concatenate([j[1] for j in jobs])
+    Ks = np.tile(K4, (len(jobs), 1)); Ks[2] *= np.float32(1.1)
+    Es, mask, status, iters = E.find_essential_pairs(off, a, b, Ks, 0.99, 1.0, gpu_ctx)
+    assert status.tolist() == [True, False, True, True, True]
+    for k, j in enumerate(jobs):
+        if not status[k]:
+            assert not mask[off[k]:off[k + 1]].any()
+            continue
+        Eg, mg, it = E.find_essential_mat(j[0], j[1], Ks[k], 0.99, 1.0, gpu_ctx)
+        assert it == iters[k] and np.array_equal(mask[off[k]:off[k + 1]], mg) and np.array_equal(Es[k], Eg)
+        ok, Er, mr, itr, cnt = oracle_lib.find_essential_ransac(j[0], j[1], Ks[k], 0.99, 1.0)
+        assert itr == it and np.array_equal(mr, mg)
+
+
+def test_mirror_estimate2D2D(gpu_ctx, oracle_lib):
+    """estimate2D2D_E5P_RANSAC -> getDepthFast, as sfm.cpp:165-166 chains them."""
+    rng = np.random.default_rng(21)
+    p1, p2, R, t, Egt, out = _pair(rng, 500, 0.25)
+    K = np.array([[K4[0], 0, K4[1]], [0, K4[2], K4[3]], [0, 0, 1]], np.float32)
+    f1 = E.Frame(frame_id=1, keypoints=p1); f1.K_cam = K
+    f2 = E.Frame(frame_id=0, keypoints=p2); f2.K_cam = K
+    matches = [E.DMatch(i, i, 0.0) for i in range(500)]
+    inl = []
+    me = E.MotionEstimator(gpu_ctx)
+    T = me.estimate2D2D_E5P_RANSAC(f1, f2, matches, inl, 1.0, 0.99)
+    assert T.dtype == np.float32 and np.allclose(T[3], [0, 0, 0, 1])
+    assert np.allclose(T[:3, :3], R, atol=0.02) and np.allclose(T[:3, 3], t, atol=0.05)
+    assert 330 <= len(inl) <= 500 and not ({m.queryIdx for m in inl} & set(out.tolist())) or len({m.queryIdx for m in inl} & set(out.tolist())) < 15
+    depth = me.getDepthFast(f1, f2, T, inl)
+    assert 6.0 < depth < 11.0      # points sit ~8 baseline lengths away
