@@ -49,46 +49,63 @@ __device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, 
     }
 }
 
-// real roots of c[0] + ... + c[10] z^10 (Durand-Kerner on all complex roots, Newton polish), ascending; returns the count
+// real roots of c[0] + ... + c[10] z^10 (Durand-Kerner on all ten complex roots, Newton polish of the near-real ones),
+// ascending; returns the count.  Fully unrolled so that the ten root estimates stay in registers; the iteration stops when
+// no estimate moves by more than 1e-13 of its own magnitude (Newton on the real axis then takes the real roots to full
+// precision) or after 300 sweeps -- clusters and multiple roots, which converge linearly, are complex pairs or double roots
+// whose exact position does not decide an inlier count.
 __device__ int real_roots_deg10(const double *c, double *out)
 {
-    int n = 10;
-    while (n > 0 && c[n] == 0.0) --n;
-    if (n <= 0) return 0;
+    if (!(fabs(c[10]) > 0.0)) return 0;
+    double cc[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) cc[k] = c[k] / c[10];
     double re[10], im[10];
     double bound = 0.0;
-    for (int i = 0; i < n; ++i) bound = fmax(bound, fabs(c[i] / c[n]));
+#pragma unroll
+    for (int i = 0; i < 10; ++i) bound = fmax(bound, fabs(cc[i]));
     bound = 1.0 + bound;
-    for (int i = 0; i < n; ++i) {
-        const double a = 2.0 * 3.14159265358979323846 * i / n + 0.4, r = 0.5 * bound * pow(0.9, (double)i);
-        re[i] = r * cos(a); im[i] = r * sin(a);
+    {
+        double r = 0.5 * bound;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            double sn, cs;
+            sincos(2.0 * 3.14159265358979323846 * i / 10.0 + 0.4, &sn, &cs);
+            re[i] = r * cs; im[i] = r * sn;
+            r *= 0.9;
+        }
     }
-    for (int it = 0; it < 2000; ++it) {
+    for (int it = 0; it < 300; ++it) {
         double move = 0.0;
-        for (int i = 0; i < n; ++i) {
-            double pr = c[n], pi = 0.0;
-            for (int k = n - 1; k >= 0; --k) { const double t = pr * re[i] - pi * im[i] + c[k]; pi = pr * im[i] + pi * re[i]; pr = t; }
-            double dr = c[n], di = 0.0;
-            for (int j = 0; j < n; ++j) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            double pr = 1.0, pi = 0.0;
+#pragma unroll
+            for (int k = 9; k >= 0; --k) { const double t = pr * re[i] - pi * im[i] + cc[k]; pi = pr * im[i] + pi * re[i]; pr = t; }
+            double dr = 1.0, di = 0.0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
                 if (j == i) continue;
                 const double ar = re[i] - re[j], ai = im[i] - im[j];
                 const double t = dr * ar - di * ai; di = dr * ai + di * ar; dr = t;
             }
             const double den = dr * dr + di * di;
-            if (den == 0.0) continue;
-            const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
+            const double inv = den > 0.0 ? 1.0 / den : 0.0;
+            const double qr = (pr * dr + pi * di) * inv, qi = (pi * dr - pr * di) * inv;
             re[i] -= qr; im[i] -= qi;
-            move = fmax(move, fabs(qr) + fabs(qi));
+            move = fmax(move, (fabs(qr) + fabs(qi)) / (fabs(re[i]) + fabs(im[i]) + 1e-300));
         }
-        if (move <= 1e-15 * bound) break;
+        if (move <= 1e-13) break;
     }
     int m = 0;
-    for (int i = 0; i < n; ++i) {
-        if (fabs(im[i]) > 1e-10 * fmax(1.0, fabs(re[i]))) continue;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        if (fabs(im[i]) > 1e-8 * fmax(1.0, fabs(re[i]))) continue;
         double z = re[i];
-        for (int it = 0; it < 3; ++it) {
-            double p = c[n], d = 0.0;
-            for (int k = n - 1; k >= 0; --k) { d = d * z + p; p = p * z + c[k]; }
+        for (int nit = 0; nit < 4; ++nit) {
+            double p = 1.0, d = 0.0;
+#pragma unroll
+            for (int k = 9; k >= 0; --k) { d = d * z + p; p = p * z + cc[k]; }
             if (d == 0.0) break;
             z -= p / d;
         }
