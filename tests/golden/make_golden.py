@@ -30,6 +30,11 @@ C oracle (oracle/*.c) is pinned by tests/test_oracle_golden.py:
                             square roots; threshold from sequential cumsums
   triangulation_cases.npz   cv::triangulatePoints (estimate_motion.cpp:263, :333): random two-view geometries incl. a short
                             baseline and noisy points; expected homogeneous points from numpy.linalg.svd of the f64 DLT matrix
+  ransac_cases.npz          two-view verification (estimate_motion.cpp:49-67): ten exact 5-point samples with their
+                            ground-truth essential matrix (known answer: it must be among the solver's models, and every
+                            model must satisfy the epipolar, determinant and trace constraints); recoverPose cases whose
+                            expected R, t, cheirality mask come from a numpy restatement (numpy.linalg.svd for the
+                            decomposition and for each point's 4 x 4 DLT system)
 
     python tests/golden/make_golden.py
 """
@@ -538,6 +543,71 @@ def make_triangulation():
     np.savez_compressed(os.path.join(HERE, "triangulation_cases.npz"), **out)
 
 
+def recover_pose_numpy(E, p1, p2, K4, mask):
+    """cv::recoverPose restated with numpy.linalg.svd (decomposeEssentialMat + cheirality with distanceThresh 50)."""
+    fx, cx, fy, cy = [float(v) for v in K4]
+    a = np.stack([(p1[:, 0].astype(np.float64) - cx) / fx, (p1[:, 1].astype(np.float64) - cy) / fy], 1)
+    b = np.stack([(p2[:, 0].astype(np.float64) - cx) / fx, (p2[:, 1].astype(np.float64) - cy) / fy], 1)
+    U, _, Vt = np.linalg.svd(E)
+    if np.linalg.det(U) < 0: U = -U
+    if np.linalg.det(Vt) < 0: Vt = -Vt
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    R1, R2, t = U @ W @ Vt, U @ W.T @ Vt, U[:, 2]
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    res = []
+    for R, tt in ((R1, t), (R2, t), (R1, -t), (R2, -t)):
+        P = np.hstack([R, tt[:, None]])
+        m = np.zeros(len(a), bool)
+        for i in range(len(a)):
+            A = np.array([a[i, 0] * P0[2] - P0[0], a[i, 1] * P0[2] - P0[1], b[i, 0] * P[2] - P[0], b[i, 1] * P[2] - P[1]])
+            Q = np.linalg.svd(A)[2][3]
+            ok = Q[2] * Q[3] > 0
+            X = Q[:3] / Q[3]
+            ok = ok and X[2] < 50
+            z2 = P[2, :3] @ X + P[2, 3]
+            m[i] = ok and z2 > 0 and z2 < 50 and mask[i]
+        res.append((int(m.sum()), R, tt, m))
+    g = [r[0] for r in res]
+    if g[0] >= g[1] and g[0] >= g[2] and g[0] >= g[3]: k = 0
+    elif g[1] >= g[0] and g[1] >= g[2] and g[1] >= g[3]: k = 1
+    elif g[2] >= g[0] and g[2] >= g[1] and g[2] >= g[3]: k = 2
+    else: k = 3
+    return res[k]
+
+
+def make_ransac():
+    rng = np.random.default_rng(515)
+    out = {}
+    K4 = np.array(synth.FOUNTAIN_K4, np.float32)
+    q1s, q2s, Es = [], [], []
+    for i in range(10):
+        R = synth.aa_to_R(rng.normal(0, 0.3, 3)); t = rng.normal(0, 1, 3); t /= np.linalg.norm(t)
+        X = rng.uniform(-2, 2, (5, 3)) + np.array([0, 0, 6.0])
+        Xc = X @ R.T + t
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Egt = tx @ R
+        q1s.append(X[:, :2] / X[:, 2:3]); q2s.append(Xc[:, :2] / Xc[:, 2:3]); Es.append(Egt / np.linalg.norm(Egt))
+    out["five.q1"] = np.array(q1s); out["five.q2"] = np.array(q2s); out["five.E"] = np.array(Es)
+    for tag, n, frac in (("pose_a", 200, 0.2), ("pose_b", 60, 0.5)):
+        R = synth.aa_to_R(rng.normal(0, 0.2, 3)); t = np.array([1.0, 0.2, -0.1]); t /= np.linalg.norm(t)
+        X = rng.uniform(-2, 2, (n, 3)) + np.array([0, 0, 8.0])
+        Xc = X @ R.T + t
+        p1 = (X[:, :2] / X[:, 2:3] * [K4[0], K4[2]] + [K4[1], K4[3]]).astype(np.float32)
+        p2 = (Xc[:, :2] / Xc[:, 2:3] * [K4[0], K4[2]] + [K4[1], K4[3]] + rng.normal(0, 0.2, (n, 2))).astype(np.float32)
+        bad = rng.choice(n, int(frac * n), replace=False)
+        p2[bad] += rng.uniform(-50, 50, (len(bad), 2)).astype(np.float32)
+        mask = np.ones(n, bool); mask[bad[: len(bad) // 2]] = False
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R; E /= np.linalg.norm(E)
+        E = E + rng.normal(0, 1e-4, (3, 3))                      # a slightly perturbed (not exactly essential) matrix, like RANSAC's
+        good, Rr, tr, m = recover_pose_numpy(E, p1, p2, K4, mask)
+        out[f"{tag}.E"] = E; out[f"{tag}.p1"] = p1; out[f"{tag}.p2"] = p2; out[f"{tag}.mask_in"] = mask
+        out[f"{tag}.R"] = Rr; out[f"{tag}.t"] = tr; out[f"{tag}.mask"] = m; out[f"{tag}.good"] = np.int32(good)
+        print("ransac", tag, "good", good, "of", n)
+    out["K4"] = K4
+    np.savez_compressed(os.path.join(HERE, "ransac_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     make_hamming()
     make_l2()
@@ -546,4 +616,5 @@ if __name__ == "__main__":
     make_ba_constrained()
     make_sor()
     make_triangulation()
+    make_ransac()
     print("golden vectors written to", HERE)

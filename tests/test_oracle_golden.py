@@ -201,3 +201,44 @@ def test_triangulation_golden(oracle_lib, tag):
     assert np.allclose(h * np.sign(h[:, 3:4]), g * np.sign(g[:, 3:4]), rtol=0, atol=3e-7)      # unit vectors, 2 float ulps
     if tag == "wide":
         assert np.allclose(h[:, :3] / h[:, 3:4], z[f"{tag}.X"], atol=2e-4)
+
+
+def test_five_point_known_answers(oracle_lib):
+    """EMEstimatorCallback::runKernel restatement: the ground-truth essential matrix is among the models of an exact
+    5-point sample, and every model satisfies the constraints the solver is built from."""
+    z = np.load(os.path.join(GOLD, "ransac_cases.npz"))
+    for q1, q2, Egt in zip(z["five.q1"], z["five.q2"], z["five.E"]):
+        Es = oracle_lib.five_point(q1, q2)
+        assert 1 <= len(Es) <= 10
+        assert min(min(np.abs(E - Egt).max(), np.abs(E + Egt).max()) for E in Es) < 1e-7      # conditioning of a 5-point sample
+        h1 = np.c_[q1, np.ones(5)]; h2 = np.c_[q2, np.ones(5)]
+        for E in Es:
+            assert abs(np.linalg.norm(E) - 1) < 1e-12 and E.ravel()[np.argmax(np.abs(E))] > 0      # unit norm, canonical sign
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, E, h1)).max() < 1e-9                        # x2' E x1 = 0 on the sample
+            assert abs(np.linalg.det(E)) < 1e-9
+            assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-8
+        assert np.all(np.diff([E[0, 0] for E in Es]) >= 0)                                          # canonical order
+
+
+@pytest.mark.parametrize("tag", ["pose_a", "pose_b"])
+def test_recover_pose_golden(oracle_lib, tag):
+    """cv::recoverPose restatement == the numpy.linalg.svd restatement of make_golden.py."""
+    z = np.load(os.path.join(GOLD, "ransac_cases.npz"))
+    good, R, t, m = oracle_lib.recover_pose(z[f"{tag}.E"], z[f"{tag}.p1"], z[f"{tag}.p2"], z["K4"], z[f"{tag}.mask_in"])
+    assert good == int(z[f"{tag}.good"]) and np.array_equal(m, z[f"{tag}.mask"])
+    assert np.allclose(R, z[f"{tag}.R"], atol=1e-9) and np.allclose(t, z[f"{tag}.t"], atol=1e-9)
+
+
+def test_essential_ransac_recovers_ground_truth(oracle_lib):
+    from easysfm_amd import synth
+    rng = np.random.default_rng(8)
+    K4 = np.array(synth.FOUNTAIN_K4, np.float32)
+    R = synth.aa_to_R(np.array([0.05, -0.2, 0.03])); t = np.array([1.0, 0.1, -0.05]); t /= np.linalg.norm(t)
+    X = rng.uniform(-2, 2, (400, 3)) + np.array([0, 0, 8.0]); Xc = X @ R.T + t
+    p1 = (X[:, :2] / X[:, 2:3] * [K4[0], K4[2]] + [K4[1], K4[3]]).astype(np.float32)
+    p2 = (Xc[:, :2] / Xc[:, 2:3] * [K4[0], K4[2]] + [K4[1], K4[3]] + rng.normal(0, 0.3, (400, 2))).astype(np.float32)
+    bad = rng.choice(400, 120, replace=False); p2[bad] += rng.uniform(-40, 40, (120, 2)).astype(np.float32)
+    ok, E, mask, iters, cnt = oracle_lib.find_essential_ransac(p1, p2, K4, 0.99, 1.0)
+    assert ok and 0 < iters < 1000 and cnt == mask.sum() >= 270 and mask[bad].sum() <= 5
+    good, Rr, tr, m2 = oracle_lib.recover_pose(E, p1, p2, K4, mask)
+    assert good >= 270 and np.allclose(Rr, R, atol=0.02) and np.allclose(tr, t, atol=0.05)

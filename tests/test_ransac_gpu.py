@@ -100,3 +100,12 @@ def test_mirror_estimate2D2D(gpu_ctx, oracle_lib):
     assert 330 <= len(inl) <= 500 and not ({m.queryIdx for m in inl} & set(out.tolist())) or len({m.queryIdx for m in inl} & set(out.tolist())) < 15
     depth = me.getDepthFast(f1, f2, T, inl)
     assert 6.0 < depth < 11.0      # points sit ~8 baseline lengths away
+
+
+@pytest.mark.parametrize("tag", ["pose_a", "pose_b"])
+def test_recover_pose_golden(gpu_ctx, tag):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ransac_cases.npz"))
+    good, R, t, m = E.recover_pose(z[f"{tag}.E"], z[f"{tag}.p1"], z[f"{tag}.p2"], z["K4"], z[f"{tag}.mask_in"], gpu_ctx)
+    assert good == int(z[f"{tag}.good"]) and np.array_equal(m, z[f"{tag}.mask"])
+    assert np.allclose(R, z[f"{tag}.R"], atol=1e-8) and np.allclose(t, z[f"{tag}.t"], atol=1e-8)
