@@ -79,7 +79,7 @@ class BASummary(C.Structure):
 def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     path = os.path.join(_HERE, out)
-    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "pnp_ref.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
@@ -150,6 +150,13 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_decompose_essential.argtypes = [_f64p, _f64p, _f64p, _f64p]
     lib.esfm_ref_recover_pose.restype = C.c_int
     lib.esfm_ref_recover_pose.argtypes = [_f64p, _f32p, _f32p, C.c_int, _f32p, _f64p, _f64p, _u8p]
+    lib.esfm_ref_epnp.restype = C.c_double
+    lib.esfm_ref_epnp.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, _f64p]
+    lib.esfm_ref_rodrigues_to_vec.restype = None
+    lib.esfm_ref_rodrigues_to_vec.argtypes = [_f64p, _f64p]
+    lib.esfm_ref_solve_pnp_ransac.restype = C.c_int
+    lib.esfm_ref_solve_pnp_ransac.argtypes = [_f32p, _f32p, C.c_int, _f32p, C.c_int, C.c_double, C.c_double, _f64p, _f64p, _f64p, _u8p,
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -392,3 +399,24 @@ def recover_pose(E, pts1, pts2, K4, mask=None):
     g = load().esfm_ref_recover_pose(np.ascontiguousarray(E, np.float64).reshape(9), a.reshape(-1), b.reshape(-1), n,
                                      np.ascontiguousarray(K4, np.float32).reshape(4), R, t, m)
     return int(g), R.reshape(3, 3), t, m[:n].astype(bool)
+
+
+# ----------------------------------------------------------------------------- PnP
+def epnp(pts3d, pix, K4):
+    """epnp::compute_pose: pts3d [n,3], pix [n,2] (pixels), K4 = fx, cx, fy, cy -> (R [3,3], t [3], mean reprojection error)."""
+    a = np.ascontiguousarray(pts3d, np.float64).reshape(-1, 3); b = np.ascontiguousarray(pix, np.float64).reshape(-1, 2)
+    R = np.zeros(9); t = np.zeros(3)
+    e = load().esfm_ref_epnp(a.reshape(-1), b.reshape(-1), a.shape[0], np.ascontiguousarray(K4, np.float64).reshape(4), R, t)
+    return R.reshape(3, 3), t, float(e)
+
+
+def solve_pnp_ransac(pts3d, pix, K4, iterations_count: int = 100, reproj_error: float = 8.0, confidence: float = 0.99):
+    """cv::solvePnPRansac(pts3d, pix, K, 0, rvec, tvec, false, iterationsCount, reprojectionError, confidence, inliers,
+    SOLVEPNP_EPNP) -> (ok, R, t, rvec, mask [n] bool, iterations run)."""
+    a = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); b = np.ascontiguousarray(pix, np.float32).reshape(-1, 2)
+    n = a.shape[0]
+    R = np.zeros(9); t = np.zeros(3); rv = np.zeros(3); mask = np.zeros(max(n, 1), np.uint8)
+    it = C.c_int32(0); ni = C.c_int32(0)
+    ok = load().esfm_ref_solve_pnp_ransac(a.reshape(-1), b.reshape(-1), n, np.ascontiguousarray(K4, np.float32).reshape(4), int(iterations_count),
+                                          float(reproj_error), float(confidence), R, t, rv, mask, C.byref(it), C.byref(ni))
+    return bool(ok), R.reshape(3, 3), t, rv, mask[:n].astype(bool), it.value
