@@ -14,6 +14,6 @@ from .ba import (BAProblem, BundleAdjustment, ba_solve, ba_solve_ex, default_opt
 
 from .cloud import CProceesing, read_ply_vertices, sor_filter, write_ply  # noqa: F401
 from .motion import (MotionEstimator, find_essential_mat, find_essential_pairs, pixel2cam, ransac_sample_stream, recover_pose,  # noqa: F401
-                     triangulate_pairs, triangulate_points)
+                     solve_pnp_ransac, triangulate_pairs, triangulate_points)
 
 __version__ = "0.1.0"

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "esfm_ba_problem_fix_camera", "esfm_ba_solve_ex", "esfm_ba_line_search_next_step",
     "esfm_sor_filter", "esfm_sor_mean_distances_dev", "esfm_triangulate_points", "esfm_triangulate_pairs",
     "esfm_find_essential_mat", "esfm_find_essential_pairs", "esfm_recover_pose", "esfm_recover_pose_pairs", "esfm_ransac_sample_stream",
+    "esfm_solve_pnp_ransac",
 ]
 
 
@@ -145,6 +146,7 @@ def lib() -> C.CDLL:
     L.esfm_recover_pose.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, i32p]
     L.esfm_recover_pose_pairs.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.esfm_ransac_sample_stream.argtypes = [C.c_int, C.c_int, vp]
+    L.esfm_solve_pnp_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, i32p, i32p]
     L.esfm_ba_problem_set_params.argtypes = [vp, vp, vp]
     L.esfm_ba_problem_solve.argtypes = [vp, C.POINTER(BAOptions), ALLREDUCE_FN, vp, C.POINTER(BASummary)]
     L.esfm_ba_problem_get_params.argtypes = [vp, vp, vp]

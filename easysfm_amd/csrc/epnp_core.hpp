@@ -1,0 +1,268 @@
+// EPnP (Lepetit, Moreno-Noguer, Fua) as cv::solvePnP(..., SOLVEPNP_EPNP) runs it [upstream opencv/modules/calib3d/src/epnp.cpp],
+// restated as small fixed-size routines that compile for the host and for gfx950: the per-hypothesis solver of
+// pnp_solve_kernel calls them on 5 points inside one thread; the refit on all RANSAC inliers calls the same routines on the
+// host between the kernels that reduce over the correspondences (pnp_kernels.hip).  Reference call site:
+// cpp_code/src/estimate_motion.cpp:161-162 (cv::solvePnPRansac, SOLVEPNP_EPNP).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define ESFM_HD __host__ __device__ inline
+
+namespace esfm {
+namespace epnp {
+
+struct Cam { double fu, fv, uc, vc; };
+
+template <int N> ESFM_HD void jacobi_sym(double *A, double *V)
+{
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) V[i * N + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < N; ++i) { diag += A[i * N + i] * A[i * N + i]; for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j]; }
+        if (off <= 1e-36 * diag || off == 0.0) break;
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                const double apq = A[p * N + q];
+                if (apq == 0.0) continue;
+                const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
+                const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int r = 0; r < N; ++r) { const double x = A[r * N + p], y = A[r * N + q]; A[r * N + p] = c * x - s * y; A[r * N + q] = s * x + c * y; }
+                for (int r = 0; r < N; ++r) { const double x = A[p * N + r], y = A[q * N + r]; A[p * N + r] = c * x - s * y; A[q * N + r] = s * x + c * y; }
+                for (int r = 0; r < N; ++r) { const double x = V[r * N + p], y = V[r * N + q]; V[r * N + p] = c * x - s * y; V[r * N + q] = s * x + c * y; }
+            }
+    }
+}
+
+// eigenvectors as ROWS of ut, eigenvalues descending (the layout cvSVD(..., CV_SVD_U_T) returns for a symmetric matrix)
+template <int N> ESFM_HD void sym_eig_desc(const double *A_in, double *ut, double *d)
+{
+    double A[N * N], V[N * N];
+    int o[N];
+    for (int i = 0; i < N * N; ++i) A[i] = A_in[i];
+    jacobi_sym<N>(A, V);
+    for (int i = 0; i < N; ++i) o[i] = i;
+    for (int i = 1; i < N; ++i) { const int v = o[i]; int j = i - 1; while (j >= 0 && A[o[j] * N + o[j]] < A[v * N + v]) { o[j + 1] = o[j]; --j; } o[j + 1] = v; }
+    for (int k = 0; k < N; ++k) { d[k] = A[o[k] * N + o[k]]; for (int a = 0; a < N; ++a) ut[k * N + a] = V[a * N + o[k]]; }
+}
+
+// minimum-norm least squares through the eigen-decomposition of A'A (what cvSolve(CV_SVD) / the QR of epnp.cpp minimise)
+template <int M, int N> ESFM_HD void lstsq(const double *A, const double *b, double *x)
+{
+    double G[N * N], V[N * N], g[N];
+    for (int i = 0; i < N; ++i) {
+        g[i] = 0.0;
+        for (int k = 0; k < M; ++k) g[i] += A[k * N + i] * b[k];
+        for (int j = 0; j < N; ++j) { double s = 0.0; for (int k = 0; k < M; ++k) s += A[k * N + i] * A[k * N + j]; G[i * N + j] = s; }
+    }
+    jacobi_sym<N>(G, V);
+    double mx = 0.0;
+    for (int i = 0; i < N; ++i) mx = fmax(mx, G[i * N + i]);
+    for (int i = 0; i < N; ++i) x[i] = 0.0;
+    for (int k = 0; k < N; ++k) {
+        const double ev = G[k * N + k];
+        if (!(ev > mx * 1e-28)) continue;
+        double c = 0.0;
+        for (int i = 0; i < N; ++i) c += V[i * N + k] * g[i];
+        c /= ev;
+        for (int i = 0; i < N; ++i) x[i] += c * V[i * N + k];
+    }
+}
+
+ESFM_HD double det3(const double *M) { return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]); }
+
+// choose_control_points + the inverse used by compute_barycentric_coordinates.  sum_pw = sum of the points, sum_pwpw = sum of
+// pw pw' (raw second moments, row-major 3 x 3).
+ESFM_HD void control_points(const double sum_pw[3], const double sum_pwpw[9], int n, double cws[4][3], double CCi[9])
+{
+    for (int j = 0; j < 3; ++j) cws[0][j] = sum_pw[j] / n;
+    double C[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = sum_pwpw[3 * a + b] - n * cws[0][a] * cws[0][b];
+    double uct[9], dc[3];
+    sym_eig_desc<3>(C, uct, dc);
+    for (int i = 1; i < 4; ++i) { const double k = sqrt(fmax(dc[i - 1], 0.0) / n); for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j]; }
+    double CC[9];
+    for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
+    const double d = det3(CC);
+    CCi[0] = (CC[4] * CC[8] - CC[5] * CC[7]) / d; CCi[1] = (CC[2] * CC[7] - CC[1] * CC[8]) / d; CCi[2] = (CC[1] * CC[5] - CC[2] * CC[4]) / d;
+    CCi[3] = (CC[5] * CC[6] - CC[3] * CC[8]) / d; CCi[4] = (CC[0] * CC[8] - CC[2] * CC[6]) / d; CCi[5] = (CC[2] * CC[3] - CC[0] * CC[5]) / d;
+    CCi[6] = (CC[3] * CC[7] - CC[4] * CC[6]) / d; CCi[7] = (CC[1] * CC[6] - CC[0] * CC[7]) / d; CCi[8] = (CC[0] * CC[4] - CC[1] * CC[3]) / d;
+}
+
+ESFM_HD void alphas_of(const double c0[3], const double CCi[9], const double pw[3], double a[4])
+{
+    const double e0 = pw[0] - c0[0], e1 = pw[1] - c0[1], e2 = pw[2] - c0[2];
+    for (int j = 0; j < 3; ++j) a[1 + j] = CCi[3 * j] * e0 + CCi[3 * j + 1] * e1 + CCi[3 * j + 2] * e2;
+    a[0] = 1.0 - a[1] - a[2] - a[3];
+}
+
+// the two rows of M this correspondence contributes (epnp::fill_M)
+ESFM_HD void m_rows(const Cam &cam, const double as[4], double u, double v, double m1[12], double m2[12])
+{
+    for (int k = 0; k < 4; ++k) {
+        m1[3 * k] = as[k] * cam.fu; m1[3 * k + 1] = 0.0; m1[3 * k + 2] = as[k] * (cam.uc - u);
+        m2[3 * k] = 0.0; m2[3 * k + 1] = as[k] * cam.fv; m2[3 * k + 2] = as[k] * (cam.vc - v);
+    }
+}
+
+// From M'M and the control points: the four null-space vectors v[k][12] and the three beta candidates (approximations 1-3, each
+// after 5 Gauss-Newton steps): compute_L_6x10, compute_rho, find_betas_approx_{1,2,3}, gauss_newton of epnp.cpp.
+ESFM_HD void betas_from_mtm(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4])
+{
+    double ut[144], d[12];
+    sym_eig_desc<12>(MtM, ut, d);
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 12; ++a) v[k][a] = ut[12 * (11 - k) + a];
+    double dv[4][6][3], L[60], rho[6];
+    for (int i = 0; i < 4; ++i) {
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; ++j) {
+            for (int k = 0; k < 3; ++k) dv[i][j][k] = v[i][3 * a + k] - v[i][3 * b + k];
+            ++b; if (b > 3) { ++a; b = a + 1; }
+        }
+    }
+    auto dot = [](const double *p, const double *q) { return p[0] * q[0] + p[1] * q[1] + p[2] * q[2]; };
+    for (int i = 0; i < 6; ++i) {
+        double *row = L + 10 * i;
+        row[0] = dot(dv[0][i], dv[0][i]); row[1] = 2.0 * dot(dv[0][i], dv[1][i]); row[2] = dot(dv[1][i], dv[1][i]);
+        row[3] = 2.0 * dot(dv[0][i], dv[2][i]); row[4] = 2.0 * dot(dv[1][i], dv[2][i]); row[5] = dot(dv[2][i], dv[2][i]);
+        row[6] = 2.0 * dot(dv[0][i], dv[3][i]); row[7] = 2.0 * dot(dv[1][i], dv[3][i]); row[8] = 2.0 * dot(dv[2][i], dv[3][i]);
+        row[9] = dot(dv[3][i], dv[3][i]);
+    }
+    {
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) { const double e = cws[a][k] - cws[b][k]; s += e * e; }
+            rho[j] = s; ++b; if (b > 3) { ++a; b = a + 1; }
+        }
+    }
+    {   // approximation 1: B11 B12 B13 B14
+        double A[24], x[4];
+        for (int i = 0; i < 6; ++i) { A[4 * i] = L[10 * i]; A[4 * i + 1] = L[10 * i + 1]; A[4 * i + 2] = L[10 * i + 3]; A[4 * i + 3] = L[10 * i + 6]; }
+        lstsq<6, 4>(A, rho, x);
+        double *b = betas[0];
+        if (x[0] < 0) { b[0] = sqrt(-x[0]); b[1] = -x[1] / b[0]; b[2] = -x[2] / b[0]; b[3] = -x[3] / b[0]; }
+        else { b[0] = sqrt(x[0]); b[1] = x[1] / b[0]; b[2] = x[2] / b[0]; b[3] = x[3] / b[0]; }
+    }
+    {   // approximation 2: B11 B12 B22
+        double A[18], x[3];
+        for (int i = 0; i < 6; ++i) { A[3 * i] = L[10 * i]; A[3 * i + 1] = L[10 * i + 1]; A[3 * i + 2] = L[10 * i + 2]; }
+        lstsq<6, 3>(A, rho, x);
+        double *b = betas[1];
+        if (x[0] < 0) { b[0] = sqrt(-x[0]); b[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
+        else { b[0] = sqrt(x[0]); b[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
+        if (x[1] < 0) b[0] = -b[0];
+        b[2] = 0.0; b[3] = 0.0;
+    }
+    {   // approximation 3: B11 B12 B22 B13 B23
+        double A[30], x[5];
+        for (int i = 0; i < 6; ++i) for (int k = 0; k < 5; ++k) A[5 * i + k] = L[10 * i + k];
+        lstsq<6, 5>(A, rho, x);
+        double *b = betas[2];
+        if (x[0] < 0) { b[0] = sqrt(-x[0]); b[1] = (x[2] < 0) ? sqrt(-x[2]) : 0.0; }
+        else { b[0] = sqrt(x[0]); b[1] = (x[2] > 0) ? sqrt(x[2]) : 0.0; }
+        if (x[1] < 0) b[0] = -b[0];
+        b[2] = x[3] / b[0]; b[3] = 0.0;
+    }
+    for (int N = 0; N < 3; ++N) {
+        double *b = betas[N];
+        for (int it = 0; it < 5; ++it) {
+            double A[24], rhs[6], x[4];
+            for (int i = 0; i < 6; ++i) {
+                const double *r = L + 10 * i;
+                A[4 * i] = 2 * r[0] * b[0] + r[1] * b[1] + r[3] * b[2] + r[6] * b[3];
+                A[4 * i + 1] = r[1] * b[0] + 2 * r[2] * b[1] + r[4] * b[2] + r[7] * b[3];
+                A[4 * i + 2] = r[3] * b[0] + r[4] * b[1] + 2 * r[5] * b[2] + r[8] * b[3];
+                A[4 * i + 3] = r[6] * b[0] + r[7] * b[1] + r[8] * b[2] + 2 * r[9] * b[3];
+                rhs[i] = rho[i] - (r[0] * b[0] * b[0] + r[1] * b[0] * b[1] + r[2] * b[1] * b[1] + r[3] * b[0] * b[2] + r[4] * b[1] * b[2] +
+                                   r[5] * b[2] * b[2] + r[6] * b[0] * b[3] + r[7] * b[1] * b[3] + r[8] * b[2] * b[3] + r[9] * b[3] * b[3]);
+            }
+            lstsq<6, 4>(A, rhs, x);
+            for (int k = 0; k < 4; ++k) b[k] += x[k];
+        }
+    }
+}
+
+// camera-frame control points for one beta vector (compute_ccs)
+ESFM_HD void ccs_of(const double b[4], const double v[4][12], double ccs[4][3])
+{
+    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) ccs[c][j] = b[0] * v[0][3 * c + j] + b[1] * v[1][3 * c + j] + b[2] * v[2][3 * c + j] + b[3] * v[3][3 * c + j];
+}
+
+// estimate_R_and_t from the raw sums over the correspondences: sum_pc, sum_pw (3), sum_pcpw = sum pc pw' (3 x 3)
+ESFM_HD void rt_from_sums(int n, const double sum_pc[3], const double sum_pw[3], const double sum_pcpw[9], double R[9], double t[3])
+{
+    double pc0[3], pw0[3], ABt[9];
+    for (int j = 0; j < 3; ++j) { pc0[j] = sum_pc[j] / n; pw0[j] = sum_pw[j] / n; }
+    for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) ABt[3 * j + k] = sum_pcpw[3 * j + k] - n * pc0[j] * pw0[k];
+    double G[9], V[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { G[3 * a + b] = 0.0; for (int k = 0; k < 3; ++k) G[3 * a + b] += ABt[3 * k + a] * ABt[3 * k + b]; }
+    jacobi_sym<3>(G, V);
+    int o[3] = {0, 1, 2};
+    for (int i = 1; i < 3; ++i) { const int vv = o[i]; int j = i - 1; while (j >= 0 && G[4 * o[j]] < G[4 * vv]) { o[j + 1] = o[j]; --j; } o[j + 1] = vv; }
+    double v[3][3], u[3][3], sig[3];
+    for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) v[k][a] = V[3 * a + o[k]];
+    for (int k = 0; k < 3; ++k) {
+        double nn = 0.0;
+        for (int a = 0; a < 3; ++a) { u[k][a] = ABt[3 * a] * v[k][0] + ABt[3 * a + 1] * v[k][1] + ABt[3 * a + 2] * v[k][2]; nn += u[k][a] * u[k][a]; }
+        sig[k] = sqrt(nn);
+        if (k < 2 || sig[2] > 1e-12 * sig[0]) for (int a = 0; a < 3; ++a) u[k][a] /= sig[k];
+    }
+    if (!(sig[2] > 1e-12 * sig[0])) {   // coplanar set: the third pair is the right-handed completion
+        u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1]; u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2]; u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+        const double w0 = v[0][1] * v[1][2] - v[0][2] * v[1][1], w1 = v[0][2] * v[1][0] - v[0][0] * v[1][2], w2 = v[0][0] * v[1][1] - v[0][1] * v[1][0];
+        v[2][0] = w0; v[2][1] = w1; v[2][2] = w2;
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = u[0][r] * v[0][c] + u[1][r] * v[1][c] + u[2][r] * v[2][c];
+    if (det3(R) < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }   // epnp.cpp negates the last row of a reflection
+    for (int j = 0; j < 3; ++j) t[j] = pc0[j] - (R[3 * j] * pw0[0] + R[3 * j + 1] * pw0[1] + R[3 * j + 2] * pw0[2]);
+}
+
+ESFM_HD double reproj_dist(const Cam &cam, const double R[9], const double t[3], const double pw[3], double u, double v)
+{
+    const double Xc = R[0] * pw[0] + R[1] * pw[1] + R[2] * pw[2] + t[0], Yc = R[3] * pw[0] + R[4] * pw[1] + R[5] * pw[2] + t[1];
+    const double inv = 1.0 / (R[6] * pw[0] + R[7] * pw[1] + R[8] * pw[2] + t[2]);
+    const double ue = cam.uc + cam.fu * Xc * inv, ve = cam.vc + cam.fv * Yc * inv;
+    return sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+}
+
+// epnp::compute_pose for K points held by one thread (the RANSAC kernel: K = 5)
+template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, const double *us, double R[9], double t[3])
+{
+    double sum_pw[3] = {0, 0, 0}, sum_pwpw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { sum_pw[a] += pws[3 * i + a]; for (int b = 0; b < 3; ++b) sum_pwpw[3 * a + b] += pws[3 * i + a] * pws[3 * i + b]; }
+    double cws[4][3], CCi[9];
+    control_points(sum_pw, sum_pwpw, K, cws, CCi);
+    double alphas[K][4], MtM[144];
+    for (int a = 0; a < 144; ++a) MtM[a] = 0.0;
+    for (int i = 0; i < K; ++i) {
+        alphas_of(cws[0], CCi, pws + 3 * i, alphas[i]);
+        double m1[12], m2[12];
+        m_rows(cam, alphas[i], us[2 * i], us[2 * i + 1], m1, m2);
+        for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) MtM[12 * a + b] += m1[a] * m1[b] + m2[a] * m2[b];
+    }
+    double v[4][12], betas[3][4];
+    betas_from_mtm(MtM, cws, v, betas);
+    double best_err = 0.0;
+    for (int N = 0; N < 3; ++N) {
+        double ccs[4][3];
+        ccs_of(betas[N], v, ccs);
+        double pcs[K][3];
+        for (int i = 0; i < K; ++i) for (int j = 0; j < 3; ++j) pcs[i][j] = alphas[i][0] * ccs[0][j] + alphas[i][1] * ccs[1][j] + alphas[i][2] * ccs[2][j] + alphas[i][3] * ccs[3][j];
+        const double sg = pcs[0][2] < 0.0 ? -1.0 : 1.0;   // solve_for_sign
+        double sum_pc[3] = {0, 0, 0}, sum_pcpw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { const double pc = sg * pcs[i][a]; sum_pc[a] += pc; for (int b = 0; b < 3; ++b) sum_pcpw[3 * a + b] += pc * pws[3 * i + b]; }
+        double Rn[9], tn[3];
+        rt_from_sums(K, sum_pc, sum_pw, sum_pcpw, Rn, tn);
+        double e = 0.0;
+        for (int i = 0; i < K; ++i) e += reproj_dist(cam, Rn, tn, pws + 3 * i, us[2 * i], us[2 * i + 1]);
+        e /= K;
+        if (N == 0 || e < best_err) { best_err = e; for (int a = 0; a < 9; ++a) R[a] = Rn[a]; for (int a = 0; a < 3; ++a) t[a] = tn[a]; }
+    }
+    return best_err;
+}
+
+}  // namespace epnp
+}  // namespace esfm

@@ -13,47 +13,19 @@
 #include <cstring>
 #include <vector>
 
+#include "ransac_host.hpp"
 #include "ransac_kernels.hpp"
 
 using esfm::RansacPair;
+using esfm::ransac::CvRng;
+using esfm::ransac::draw_subset;
+using esfm::ransac::kMaxIters;
+using esfm::ransac::kModelPoints;
+using esfm::ransac::update_num_iters;
 
 namespace {
 
-constexpr int kModelPoints = 5;
-constexpr int kMaxIters = 1000;       // RANSACPointSetRegistrator default
 constexpr int kChunk = 64;            // iterations of every active pair evaluated per round
-
-struct CvRng {                        // cv::RNG((uint64)-1) [upstream core/operations.hpp]
-    uint64_t state = 0xFFFFFFFFFFFFFFFFull;
-    unsigned next() { state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32); return (unsigned)state; }
-    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
-};
-
-// RANSACPointSetRegistrator::getSubset for a model without checkSubset: distinct indices, a repeat is redrawn
-void draw_subset(CvRng &rng, int count, int32_t idx[kModelPoints])
-{
-    for (int i = 0; i < kModelPoints;) {
-        int v;
-        for (;;) {
-            v = idx[i] = rng.uniform(0, count);
-            int j = 0;
-            for (; j < i; ++j) if (v == idx[j]) break;
-            if (j == i) break;
-        }
-        ++i;
-    }
-}
-
-int update_num_iters(double p, double ep, int model_points, int max_iters)   // cv::RANSACUpdateNumIters
-{
-    p = std::max(p, 0.0); p = std::min(p, 1.0);
-    ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
-    double num = std::max(1.0 - p, DBL_MIN);
-    double denom = 1.0 - std::pow(1.0 - ep, model_points);
-    if (denom < DBL_MIN) return 0;
-    num = std::log(num); denom = std::log(denom);
-    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
-}
 
 int fill_pairs(int n_pairs, const int32_t *off, const float *K4, double threshold, std::vector<RansacPair> &tab)
 {

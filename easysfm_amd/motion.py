@@ -3,7 +3,8 @@
 (:285-367) and ``outlierFilter`` (:476-505).  cv::triangulatePoints runs in libesfm_hip.so on the GPU
 (``esfm_triangulate_points``); the statistical filter is the same kernel as ``CProceesing.SORFilter``;
 ``estimate2D2D_E5P_RANSAC`` (:27-97) = cv::findEssentialMat(RANSAC) + cv::recoverPose runs through ``esfm_find_essential_mat`` /
-``esfm_recover_pose`` (hypotheses solved and scored on the GPU).  ``estimate2D3D_P3P_RANSAC`` (solvePnPRansac / EPnP) is not built."""
+``esfm_recover_pose`` (hypotheses solved and scored on the GPU); ``estimate2D3D_P3P_RANSAC`` (:99-232) = cv::solvePnPRansac with
+EPnP runs through ``esfm_solve_pnp_ransac``."""
 from __future__ import annotations
 
 import ctypes as C
@@ -100,6 +101,26 @@ def recover_pose(E, pts1, pts2, K, mask=None, ctx: Optional[Context] = None):
     return good.value, R.reshape(3, 3), t, (None if m is None else m[:n].astype(bool))
 
 
+def solve_pnp_ransac(pts3d, pts2d, K, iterations_count: int = 100, reprojection_error: float = 8.0, confidence: float = 0.99,
+                     ctx: Optional[Context] = None):
+    """cv::solvePnPRansac(pts3d, pts2d, K, 0, rvec, tvec, false, iterationsCount, reprojectionError, confidence, inliers,
+    SOLVEPNP_EPNP) -> (rvec [3], tvec [3], R [3,3], inlier mask [n] bool, iterations run).  Raises EsfmError where OpenCV
+    returns false."""
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); b = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+    if a.shape[0] != b.shape[0]:
+        raise ValueError("point sets differ in size")
+    n = a.shape[0]
+    k4 = _k4(K)
+    rvec = np.zeros(3); tvec = np.zeros(3); R = np.zeros(9); mask = np.zeros(max(n, 1), np.uint8)
+    ninl = C.c_int32(0); it = C.c_int32(0)
+    check(lib().esfm_solve_pnp_ransac(ctx.handle, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), n, C.c_void_p(k4.ctypes.data),
+                                      int(iterations_count), float(reprojection_error), float(confidence), C.c_void_p(rvec.ctypes.data),
+                                      C.c_void_p(tvec.ctypes.data), C.c_void_p(R.ctypes.data), C.c_void_p(mask.ctypes.data), C.byref(ninl),
+                                      C.byref(it)))
+    return rvec, tvec, R.reshape(3, 3), mask[:n].astype(bool), it.value
+
+
 def ransac_sample_stream(count: int, n_samples: int) -> np.ndarray:
     """Host-only: the 5-index samples OpenCV's RANSAC draws for `count` points (esfm_ransac_sample_stream)."""
     idx = np.zeros((max(n_samples, 1), 5), np.int32)
@@ -138,6 +159,52 @@ class MotionEstimator:
         T[:3, :3] = R.astype(np.float32); T[:3, 3] = t.astype(np.float32)       # cv2eigen into Matrix3f / Vector3f (:76-79)
         print(f"Find [{int(mask.sum())}] inlier matches from [{len(matches)}] total matches.")
         return T
+
+    def estimate2D3D_P3P_RANSAC(self, cur_frame: Frame, cur_map_3d: SparsePointCloud, ransac_thre: float = 2.5,
+                                iterationsCount: int = 50000, ransac_prob: float = 0.99, show: bool = False) -> bool:
+        """estimate_motion.cpp:99-232: 2-D/3-D correspondences by track id (every (keypoint, cloud point) pair with equal
+        ids, keypoint-major, :122-151; cloud points beyond +-300 are skipped, :114,134), solvePnPRansac with EPnP (:161-162),
+        pose written to cur_frame.pose_cam (:190-203), mean reprojection error over ALL correspondences (:207-219); returns
+        False when that error > 10 and the inlier ratio < 0.5 (:226-230).  The reference's inlier bookkeeping reads the int
+        index matrix as float (:169), so every entry addresses correspondence 0 and every other correspondence's cloud
+        point gets is_inlier = 0; reproduced."""
+        from .ba import angle_axis_to_rotation
+        K = np.asarray(cur_frame.K_cam, np.float32)
+        kp = np.asarray(cur_frame.keypoints, np.float32).reshape(-1, 2)
+        xyz = np.asarray(cur_map_3d.xyz, np.float32).reshape(-1, 3)
+        pid = np.asarray(cur_map_3d.unique_point_ids, np.int64)
+        uid = np.asarray(cur_frame.unique_pixel_ids, np.int64)
+        order = np.argsort(pid, kind="stable")                       # all cloud points with a given id, in cloud order
+        lo = np.searchsorted(pid[order], uid, "left"); hi = np.searchsorted(pid[order], uid, "right")
+        i2, j3 = [], []
+        for i in range(len(uid)):
+            for j in order[lo[i]:hi[i]]:
+                if abs(xyz[j, 0]) < 300 and abs(xyz[j, 1]) < 300 and abs(xyz[j, 2]) < 300:
+                    i2.append(i); j3.append(int(j))
+        count = len(i2)
+        print(f"{count} initial correspondences are used.")
+        p2 = kp[i2].reshape(-1, 2); p3 = xyz[j3].reshape(-1, 3)
+        rvec, tvec, R, mask, _ = solve_pnp_ransac(p3, p2, K, iterationsCount, ransac_thre, ransac_prob, self._ctx)
+        n_inl = int(mask.sum())
+        print(f"Inlier count: {n_inl}")
+        index = list(j3)
+        if n_inl > 0 and index:
+            index[0] = -1                                            # inliers.at<float>(i, 0) on a CV_32S matrix: always 0 (:169)
+        inl = np.asarray(cur_map_3d.is_inlier, np.int32).copy()
+        for j in index:
+            if j >= 0:
+                inl[j] = 0
+        cur_map_3d.is_inlier = inl
+        R32 = angle_axis_to_rotation(rvec).astype(np.float32)        # cv::Rodrigues(r_vec, R_mat) then cv2eigen into Matrix3f (:184-190)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = R32; T[:3, 3] = tvec.astype(np.float32)
+        cur_frame.pose_cam = T
+        Xc = p3.astype(np.float64) @ angle_axis_to_rotation(rvec).T + tvec
+        proj = np.stack([Xc[:, 0] / Xc[:, 2] * float(K[0, 0]) + float(K[0, 2]), Xc[:, 1] / Xc[:, 2] * float(K[1, 1]) + float(K[1, 2])], 1).astype(np.float32)
+        reproj_err = float(np.mean(np.linalg.norm((proj - p2).astype(np.float64), axis=1))) if count else float("nan")
+        inlier_ratio = n_inl / count if count else 0.0
+        print(f"Mean reprojection error: {reproj_err}")
+        return not (reproj_err > 10 and inlier_ratio < 0.5)
 
     def getDepthFast(self, cur_frame_1: Frame, cur_frame_2: Frame, T_21: np.ndarray, matches: Sequence[DMatch],
                      random_rate: int = 20) -> float:

@@ -398,6 +398,19 @@ int esfm_recover_pose(esfm_ctx *ctx, const double *E, const float *pts1, const f
 int esfm_recover_pose_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_offset, const float *pts1, const float *pts2,
                             const float *K4_per_pair, const double *E /*9 per pair*/, uint8_t *mask /*in/out or NULL*/,
                             double *R /*9 per pair*/, double *t /*3 per pair*/, int32_t *good /*per pair or NULL*/);
+/* cv::solvePnPRansac(pts3d, pts2d, K, dist = 0, rvec, tvec, false, iterationsCount, reprojectionError, confidence, inliers,
+ * cv::SOLVEPNP_EPNP) as MotionEstimator::estimate2D3D_P3P_RANSAC calls it (cpp_code/src/estimate_motion.cpp:161-162, once per
+ * newly registered frame, cpp_code/test/sfm.cpp:288).  pts3d: n x 3 floats (cv::Point3f), pts2d: n x 2 float pixels, K4 = fx,
+ * cx, fy, cy.  RANSAC with 5 model points on the cv::RNG((uint64)-1) sample stream: each sample is solved by EPnP (control
+ * points, M'M null space, three beta approximations + 5 Gauss-Newton steps each, absolute orientation, smallest mean
+ * reprojection error), scored by the squared pixel distance of the float projection (<= (float)reprojectionError^2), and the
+ * iteration count adapts from iterationsCount; then EPnP is run once more on all inliers of the best model.  rvec =
+ * cv::Rodrigues(R), tvec; R (or NULL) receives the rotation matrix, inlier_mask[n] (or NULL) the inliers of the best RANSAC
+ * model (OpenCV returns their indices), *n_inliers their number.  Fewer than 5 points is ESFM_ERR_UNSUPPORTED (OpenCV switches
+ * to P3P at 4); no model with at least 5 inliers is ESFM_ERR_NUMERIC (OpenCV returns false). */
+int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d, int n, const float *K4, int iterations_count,
+                          double reprojection_error, double confidence, double *rvec /*3*/, double *tvec /*3*/, double *R /*9 or NULL*/,
+                          uint8_t *inlier_mask /*n or NULL*/, int32_t *n_inliers /*or NULL*/, int32_t *iterations /*or NULL*/);
 /* Host-only (no GPU): the first n_samples 5-index samples RANSAC draws for `count` points (cv::RNG replay). */
 int esfm_ransac_sample_stream(int count, int n_samples, int32_t *idx /*5 per sample*/);
 

@@ -242,3 +242,30 @@ def test_essential_ransac_recovers_ground_truth(oracle_lib):
     assert ok and 0 < iters < 1000 and cnt == mask.sum() >= 270 and mask[bad].sum() <= 5
     good, Rr, tr, m2 = oracle_lib.recover_pose(E, p1, p2, K4, mask)
     assert good >= 270 and np.allclose(Rr, R, atol=0.02) and np.allclose(tr, t, atol=0.05)
+
+
+def test_epnp_and_pnp_ransac_known_answers(oracle_lib):
+    """EPnP restatement: exact observations reproduce the pose to machine precision for 5 .. 500 points (also coplanar
+    points); solvePnPRansac recovers it from 33 % gross outliers; cv::Rodrigues of the result is the rotation's angle-axis."""
+    from easysfm_amd import synth
+    from easysfm_amd.ba import rotation_to_angle_axis
+    rng = np.random.default_rng(12)
+    K4 = np.array(synth.FOUNTAIN_K4, np.float64)
+    R = synth.aa_to_R(np.array([0.3, -0.2, 0.1])); t = np.array([0.3, -0.2, 6.0])
+    for n in (5, 6, 20, 500):
+        X = rng.uniform(-2, 2, (n, 3)); Xc = X @ R.T + t
+        pix = np.stack([Xc[:, 0] / Xc[:, 2] * K4[0] + K4[1], Xc[:, 1] / Xc[:, 2] * K4[2] + K4[3]], 1)
+        Rr, tr, e = oracle_lib.epnp(X, pix, K4)
+        assert np.allclose(Rr, R, atol=1e-10) and np.allclose(tr, t, atol=1e-9) and e < 1e-9
+    Xp = rng.uniform(-2, 2, (40, 3)); Xp[:, 2] = 0.5 * Xp[:, 0] - 0.25 * Xp[:, 1] + 1.0      # a plane
+    Xc = Xp @ R.T + t
+    pix = np.stack([Xc[:, 0] / Xc[:, 2] * K4[0] + K4[1], Xc[:, 1] / Xc[:, 2] * K4[2] + K4[3]], 1)
+    Rr, tr, e = oracle_lib.epnp(Xp, pix, K4)
+    assert np.allclose(Rr, R, atol=1e-6) and e < 1e-6
+    X = rng.uniform(-2, 2, (600, 3)); Xc = X @ R.T + t
+    pix = np.stack([Xc[:, 0] / Xc[:, 2] * K4[0] + K4[1], Xc[:, 1] / Xc[:, 2] * K4[2] + K4[3]], 1) + rng.normal(0, 0.5, (600, 2))
+    bad = rng.choice(600, 200, replace=False); pix[bad] += rng.uniform(-80, 80, (200, 2))
+    ok, Rr, tr, rv, mask, it = oracle_lib.solve_pnp_ransac(X, pix, K4, 50000, 2.5, 0.99)
+    assert ok and 0 < it < 5000 and mask.sum() >= 395 and mask[bad].sum() <= 5
+    assert np.allclose(Rr, R, atol=2e-3) and np.allclose(tr, t, atol=0.02)
+    assert np.allclose(rv, rotation_to_angle_axis(Rr), atol=1e-9)
