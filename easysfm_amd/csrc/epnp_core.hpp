@@ -85,10 +85,20 @@ ESFM_HD void control_points(const double sum_pw[3], const double sum_pwpw[9], in
     for (int i = 1; i < 4; ++i) { const double k = sqrt(fmax(dc[i - 1], 0.0) / n); for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j]; }
     double CC[9];
     for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
-    const double d = det3(CC);
-    CCi[0] = (CC[4] * CC[8] - CC[5] * CC[7]) / d; CCi[1] = (CC[2] * CC[7] - CC[1] * CC[8]) / d; CCi[2] = (CC[1] * CC[5] - CC[2] * CC[4]) / d;
-    CCi[3] = (CC[5] * CC[6] - CC[3] * CC[8]) / d; CCi[4] = (CC[0] * CC[8] - CC[2] * CC[6]) / d; CCi[5] = (CC[2] * CC[3] - CC[0] * CC[5]) / d;
-    CCi[6] = (CC[3] * CC[7] - CC[4] * CC[6]) / d; CCi[7] = (CC[1] * CC[6] - CC[0] * CC[7]) / d; CCi[8] = (CC[0] * CC[4] - CC[1] * CC[3]) / d;
+    // cvInvert(&CC, &CC_inv, CV_SVD): the Moore-Penrose inverse, so that a coplanar point set (third axis of length 0) still
+    // gets finite barycentric coordinates
+    double G[9], V[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { G[3 * a + b] = 0.0; for (int k = 0; k < 3; ++k) G[3 * a + b] += CC[3 * k + a] * CC[3 * k + b]; }
+    jacobi_sym<3>(G, V);
+    const double mx = fmax(G[0], fmax(G[4], G[8]));
+    for (int i = 0; i < 9; ++i) CCi[i] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double ev = G[4 * k];
+        if (!(ev > mx * 1e-24)) continue;
+        double Av[3];
+        for (int r = 0; r < 3; ++r) Av[r] = CC[3 * r] * V[k] + CC[3 * r + 1] * V[3 + k] + CC[3 * r + 2] * V[6 + k];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) CCi[3 * i + j] += V[3 * i + k] * Av[j] / ev;
+    }
 }
 
 ESFM_HD void alphas_of(const double c0[3], const double CCi[9], const double pw[3], double a[4])

@@ -121,6 +121,23 @@ static void estimate_R_and_t(const double *pws, const double *pcs, int n, double
     for (int j = 0; j < 3; ++j) t[j] = pc0[j] - (R[3 * j] * pw0[0] + R[3 * j + 1] * pw0[1] + R[3 * j + 2] * pw0[2]);
 }
 
+/* Moore-Penrose inverse of a 3 x 3 through the eigen-decomposition of A'A (cvInvert with CV_SVD) */
+static void pinv3(const double *A, double *Ai)
+{
+    double G[9], V[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { G[3 * a + b] = 0; for (int k = 0; k < 3; ++k) G[3 * a + b] += A[3 * k + a] * A[3 * k + b]; }
+    jacobi_sym(G, 3, V);
+    double mx = fmax(G[0], fmax(G[4], G[8]));
+    for (int i = 0; i < 9; ++i) Ai[i] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double ev = G[4 * k];
+        if (!(ev > mx * 1e-24)) continue;                       /* sigma_k <= 1e-12 sigma_max: dropped */
+        double Av[3];
+        for (int r = 0; r < 3; ++r) Av[r] = A[3 * r] * V[k] + A[3 * r + 1] * V[3 + k] + A[3 * r + 2] * V[6 + k];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ai[3 * i + j] += V[3 * i + k] * Av[j] / ev;   /* v_k (A v_k)' / sigma_k^2 */
+    }
+}
+
 typedef struct { double fu, fv, uc, vc; } cam_t;
 
 /* epnp::compute_pose.  pws: n x 3 world points, us: n x 2 pixels.  Returns the mean reprojection error of the chosen pose. */
@@ -138,12 +155,7 @@ static double epnp_pose(const cam_t *cam, const double *pws, const double *us, i
     /* barycentric coordinates */
     double CC[9], CCi[9];
     for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
-    {
-        const double d = det3(CC);
-        CCi[0] = (CC[4] * CC[8] - CC[5] * CC[7]) / d; CCi[1] = (CC[2] * CC[7] - CC[1] * CC[8]) / d; CCi[2] = (CC[1] * CC[5] - CC[2] * CC[4]) / d;
-        CCi[3] = (CC[5] * CC[6] - CC[3] * CC[8]) / d; CCi[4] = (CC[0] * CC[8] - CC[2] * CC[6]) / d; CCi[5] = (CC[2] * CC[3] - CC[0] * CC[5]) / d;
-        CCi[6] = (CC[3] * CC[7] - CC[4] * CC[6]) / d; CCi[7] = (CC[1] * CC[6] - CC[0] * CC[7]) / d; CCi[8] = (CC[0] * CC[4] - CC[1] * CC[3]) / d;
-    }
+    pinv3(CC, CCi);   /* cvInvert(&CC, &CC_inv, CV_SVD): the pseudo-inverse when the points are coplanar */
     double *alphas = (double *)malloc(sizeof(double) * 4 * (size_t)n);
     for (int i = 0; i < n; ++i) {
         double *a = alphas + 4 * i;
