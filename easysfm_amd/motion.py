@@ -101,6 +101,25 @@ def recover_pose(E, pts1, pts2, K, mask=None, ctx: Optional[Context] = None):
     return good.value, R.reshape(3, 3), t, (None if m is None else m[:n].astype(bool))
 
 
+def recover_pose_pairs(point_offset, pts1, pts2, K4_per_pair, Es, mask=None, ctx: Optional[Context] = None):
+    """esfm_recover_pose_pairs -> (good [p], R [p,3,3], t [p,3], mask [n_total] bool or None)."""
+    ctx = ctx or default_context()
+    off = np.ascontiguousarray(point_offset, np.int32)
+    n_pairs = len(off) - 1
+    a = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2); b = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    k4 = np.ascontiguousarray(K4_per_pair, np.float32).reshape(-1, 4)
+    Ev = np.ascontiguousarray(Es, np.float64).reshape(-1, 9)
+    n = a.shape[0]
+    R = np.zeros((max(n_pairs, 1), 9)); t = np.zeros((max(n_pairs, 1), 3)); good = np.zeros(max(n_pairs, 1), np.int32)
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8)).copy()
+    if m is not None and len(m) == 0:
+        m = np.zeros(1, np.uint8)
+    check(lib().esfm_recover_pose_pairs(ctx.handle, n_pairs, C.c_void_p(off.ctypes.data), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data),
+                                        C.c_void_p(k4.ctypes.data), C.c_void_p(Ev.ctypes.data), None if m is None else C.c_void_p(m.ctypes.data),
+                                        C.c_void_p(R.ctypes.data), C.c_void_p(t.ctypes.data), C.c_void_p(good.ctypes.data)))
+    return good[:n_pairs], R[:n_pairs].reshape(n_pairs, 3, 3), t[:n_pairs], (None if m is None else m[:n].astype(bool))
+
+
 def solve_pnp_ransac(pts3d, pts2d, K, iterations_count: int = 100, reprojection_error: float = 8.0, confidence: float = 0.99,
                      ctx: Optional[Context] = None):
     """cv::solvePnPRansac(pts3d, pts2d, K, 0, rvec, tvec, false, iterationsCount, reprojectionError, confidence, inliers,

@@ -169,3 +169,39 @@ def in_reference_frame(sc: BAScene, ref: int) -> BAScene:
     cams_gt, pts_gt = move(sc.cams_gt, sc.pts_gt)
     return BAScene(cam_idx=sc.cam_idx, pt_idx=sc.pt_idx, uv=sc.uv, K4=sc.K4, cams0=cams0, pts0=pts0,
                    cams_gt=cams_gt, pts_gt=pts_gt)
+
+
+def sfm_scene(n_cam: int = 8, n_pt: int = 900, seed: int = 7000, pix_noise: float = 0.3, n_clutter: int = 150, desc_noise: float = 0.03):
+    """A synthetic reconstruction problem for the whole pipeline (cpp_code/test/sfm.cpp:128-339): cameras on an arc looking at
+    a point cloud with depth relief; every camera sees the points in front of it inside the 768 x 512 image; a keypoint's
+    descriptor is its point's random unit 64-vector plus noise (SURF-like, L2-normalised); clutter keypoints carry fresh
+    random descriptors.  Returns (frames as dicts of numpy arrays: keypoints, descriptors, point_id per keypoint; K [3,3];
+    camera poses world->camera [n_cam,4,4]; points [n_pt,3])."""
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    K = np.array([[FOUNTAIN_K4[0], 0, FOUNTAIN_K4[1]], [0, FOUNTAIN_K4[2], FOUNTAIN_K4[3]], [0, 0, 1]], np.float32)
+    pts = np.stack([rng.uniform(-3, 3, n_pt), rng.uniform(-2, 2, n_pt), rng.uniform(-1.5, 1.5, n_pt)], 1)
+    base = rng.standard_normal((n_pt, 64)); base /= np.linalg.norm(base, axis=1, keepdims=True)
+    poses, frames = [], []
+    for c in range(n_cam):
+        ang = (c - (n_cam - 1) / 2) * 0.16
+        C = np.array([9.0 * np.sin(ang), 0.15 * np.cos(3 * ang), -9.0 * np.cos(ang)])
+        z = -C / np.linalg.norm(C)
+        x = np.cross(np.array([0.0, 1.0, 0.0]), z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z], 0)
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = -R @ C
+        poses.append(T)
+        Xc = pts @ R.T + T[:3, 3]
+        uv = np.stack([Xc[:, 0] / Xc[:, 2] * K[0, 0] + K[0, 2], Xc[:, 1] / Xc[:, 2] * K[1, 1] + K[1, 2]], 1)
+        vis = (Xc[:, 2] > 1) & (uv[:, 0] > 5) & (uv[:, 0] < 763) & (uv[:, 1] > 5) & (uv[:, 1] < 507)
+        ids = np.nonzero(vis)[0]
+        ids = ids[rng.random(len(ids)) < 0.9]                        # detector misses
+        kp = uv[ids] + pix_noise * rng.standard_normal((len(ids), 2))
+        d = base[ids] + desc_noise * rng.standard_normal((len(ids), 64))
+        ck = np.stack([rng.uniform(5, 763, n_clutter), rng.uniform(5, 507, n_clutter)], 1)
+        cd = rng.standard_normal((n_clutter, 64))
+        kp = np.concatenate([kp, ck]); d = np.concatenate([d, cd]); pid = np.concatenate([ids, -np.ones(n_clutter, np.int64)])
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        order = rng.permutation(len(kp))
+        frames.append(dict(keypoints=kp[order].astype(np.float32), descriptors=np.ascontiguousarray(d[order], np.float32), point_id=pid[order]))
+    return frames, K, np.stack(poses), pts

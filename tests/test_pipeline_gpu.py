@@ -1,0 +1,60 @@
+"""End-to-end: the reference's main loop after feature extraction (cpp_code/test/sfm.cpp:128-339) driven through every GPU
+stage of this package on a synthetic scene with known ground truth -- all-pairs matching, 5-point RANSAC, relative depth,
+track propagation, initial-pair selection, triangulation, bundle adjustment, PnP registration of the remaining frames,
+periodic and final BA, outlier filter, .ply.  The reconstruction is compared with the truth up to the similarity transform
+an SfM result is defined by."""
+import numpy as np
+import pytest
+
+import easysfm_amd as E
+from easysfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _similarity(A, B):
+    """Least-squares s, R, t with B ~ s R A + t (Umeyama)."""
+    ma, mb = A.mean(0), B.mean(0)
+    Ac, Bc = A - ma, B - mb
+    U, S, Vt = np.linalg.svd(Bc.T @ Ac / len(A))
+    D = np.eye(3); D[2, 2] = np.sign(np.linalg.det(U @ Vt))
+    R = U @ D @ Vt
+    s = np.trace(np.diag(S) @ D) / (Ac ** 2).sum() * len(A)
+    return s, R, mb - s * R @ ma
+
+
+def test_incremental_sfm_on_synthetic_scene(gpu_ctx, tmp_path):
+    data, K, poses, pts = synth.sfm_scene(8, 900, seed=7000)
+    frames = []
+    for i, f in enumerate(data):
+        fr = E.Frame(frame_id=i, keypoints=f["keypoints"], descriptors=f["descriptors"])
+        fr.K_cam = K.copy()
+        frames.append(fr)
+    out_file = str(tmp_path / "sfm.ply")
+    cloud, filtered, graph = E.run_sfm(frames, out_file, "S", 1.0, True, 0.0, 4, gpu_ctx)
+    # every pair of neighbouring cameras was verified geometrically
+    assert all(len(graph[i][i - 1].matches) > 100 for i in range(1, 8))
+    # verified matches join keypoints of the same scene point
+    for i in range(1, 8):
+        m = graph[i][i - 1].matches
+        same = sum(data[i]["point_id"][a.queryIdx] == data[i - 1]["point_id"][a.trainIdx] and data[i]["point_id"][a.queryIdx] >= 0 for a in m)
+        assert same >= 0.98 * len(m)
+    # camera centres against the truth, up to similarity
+    C_gt = np.array([-T[:3, :3].T @ T[:3, 3] for T in poses])
+    C_est = np.array([-f.pose_cam[:3, :3].astype(np.float64).T @ f.pose_cam[:3, 3].astype(np.float64) for f in frames])
+    s, R, t = _similarity(C_est, C_gt)
+    err = np.linalg.norm((s * (R @ C_est.T).T + t) - C_gt, axis=1)
+    assert err.max() < 0.05, err                                   # camera ring radius 9: < 0.6 %
+    # structure: reconstructed points map onto their scene points
+    P = s * (R @ cloud.xyz.astype(np.float64).T).T + t
+    ids = np.asarray(cloud.unique_point_ids)
+    id_to_pt = {}
+    for f, fr in zip(data, frames):
+        for k, uid in enumerate(fr.unique_pixel_ids):
+            if f["point_id"][k] >= 0:
+                id_to_pt.setdefault(int(uid), int(f["point_id"][k]))
+    d = np.array([np.linalg.norm(P[k] - pts[id_to_pt[int(u)]]) for k, u in enumerate(ids) if int(u) in id_to_pt])
+    assert len(d) > 500 and np.median(d) < 0.03 and np.mean(d < 0.2) > 0.97
+    assert len(filtered.xyz) <= len(cloud.xyz) and len(filtered.xyz) > 0.85 * len(cloud.xyz)
+    xyz, rgb, cam = E.read_ply_vertices(out_file)
+    assert len(xyz) == len(filtered.xyz)
