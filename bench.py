@@ -340,6 +340,48 @@ def main() -> int:
         except Exception as e:
             out["cloud"] = {"error": repr(e)}
 
+    # ---------------------------------------------------------------- geometric verification (row f-1), rank 0 at N = 1
+    if rank == 0 and world == 1 and not args.no_ba:
+        try:
+            rng = np.random.default_rng(4200)
+            K4v = np.array(synth.FOUNTAIN_K4, np.float32)
+
+            def two_view(n, frac):
+                R = synth.aa_to_R(rng.normal(0, 0.15, 3)); t = np.array([1.0, 0.1, -0.05]) + rng.normal(0, 0.05, 3); t /= np.linalg.norm(t)
+                X = rng.uniform(-2, 2, (n, 3)) + np.array([0, 0, 8.0]); Xc = X @ R.T + t
+                a = (X[:, :2] / X[:, 2:3] * [K4v[0], K4v[2]] + [K4v[1], K4v[3]]).astype(np.float32)
+                b = (Xc[:, :2] / Xc[:, 2:3] * [K4v[0], K4v[2]] + [K4v[1], K4v[3]] + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+                bad = rng.choice(n, int(frac * n), replace=False); b[bad] += rng.uniform(-60, 60, (len(bad), 2)).astype(np.float32)
+                return a, b
+
+            n_pairs_g, n_m = 300, 1000
+            jobs = [two_view(n_m, 0.3) for _ in range(n_pairs_g)]
+            off = np.arange(n_pairs_g + 1, dtype=np.int32) * n_m
+            pa = np.concatenate([j[0] for j in jobs]); pb_ = np.concatenate([j[1] for j in jobs]); Ks = np.tile(K4v, (n_pairs_g, 1))
+            gctx = E.Context(local_rank, None)
+            E.find_essential_pairs(off, pa, pb_, Ks, 0.99, 1.0, gctx)
+            t0 = time.perf_counter()
+            Es_, mask_, st_, it_ = E.find_essential_pairs(off, pa, pb_, Ks, 0.99, 1.0, gctx)
+            good_, Rs_, ts_, _m = E.recover_pose_pairs(off, pa, pb_, Ks, Es_, mask_, gctx)
+            g_el = time.perf_counter() - t0
+            out["geometry"] = {"metric": "image pairs verified/s (5-point RANSAC + recoverPose, 1000 matches, 30% outliers)",
+                               "value": n_pairs_g / g_el, "unit": "image-pairs/s", "pairs": n_pairs_g, "matches_per_pair": n_m,
+                               "mean_ransac_iterations": float(it_.mean()), "batch_ms": g_el * 1e3, "includes": "host<->device copies of the batch"}
+            if not args.no_cpu_baseline:
+                import oracle
+                t0 = time.perf_counter()
+                same = True
+                for k in range(24):
+                    ok_, Er_, mr_, itr_, cnt_ = oracle.find_essential_ransac(jobs[k][0], jobs[k][1], K4v, 0.99, 1.0)
+                    oracle.recover_pose(Er_, jobs[k][0], jobs[k][1], K4v, mr_)
+                    same = same and itr_ == int(it_[k]) and np.array_equal(mr_, mask_[off[k]:off[k + 1]])
+                t1 = time.perf_counter() - t0
+                out["geometry"]["verified_vs_oracle"] = bool(same)
+                out["geometry"]["cpu_baseline"] = {"value": 24 / t1, "unit": "image-pairs/s", "cores": 1, "kind": "port",
+                                                   "sample": f"24 of the pairs in {t1:.2f}s (sequential RANSAC restatement, one core)"}
+        except Exception as e:
+            out["geometry"] = {"error": repr(e)}
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
