@@ -3,6 +3,8 @@
 // Same class and member names, argument meaning, defaults and error behaviour as
 //   p3dv::FeatureMatching::matchFeaturesORB / matchFeaturesSURF   cpp_code/include/feature_matching.h:17-21
 //   p3dv::BundleAdjustment::{initBA,setBAProblem,solveBA,doSFMBA}  cpp_code/include/ba.h:59-84
+//   p3dv::MotionEstimator::{estimate2D2D_E5P_RANSAC,getDepthFast,doTriangulation,estimate2D3D_P3P_RANSAC,outlierFilter}
+//                                                                  cpp_code/include/estimate_motion.h:17-35
 // with the OpenCV / PCL / Eigen value types of cpp_code/include/utility.h:21-102 replaced by the
 // plain structs below (the image has none of those libraries).  Header-only; link libesfm_hip.so.
 // All compute happens on the GPU behind the C ABI; there is no CPU fallback here.
@@ -240,6 +242,173 @@ public:
         fs << "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 1 " << n << " 0 0\n";
         std::cout << "Output [ " << n << " ] points." << std::endl << "Output ply file done." << std::endl;
         return bool(fs);
+    }
+};
+
+inline void angle_axis_to_rotation(const double aa[3], double R[9]);
+
+// ---- two-view / 3-D/2-D geometry (estimate_motion.h) ------------------------------------------------------
+class MotionEstimator {
+public:
+    // estimate_motion.cpp:27-97: cv::findEssentialMat(RANSAC) on the matched pixels with frame 1's K, inliers appended,
+    // cv::recoverPose with the RANSAC mask -> T = [R | t; 0 0 0 1]
+    bool estimate2D2D_E5P_RANSAC(frame_t &cur_frame_1, frame_t &cur_frame_2, std::vector<DMatch> &matches, std::vector<DMatch> &inlier_matches,
+                                 Matrix4f &T, double ransac_thre = 1.0, double ransac_prob = 0.99, bool show = false)
+    {
+        std::vector<float> p1, p2;
+        gather(cur_frame_1, cur_frame_2, matches, 1, p1, p2);
+        const int n = int(matches.size());
+        float K4[4]; k4_of(cur_frame_1.K_cam, K4);
+        std::vector<uint8_t> mask(size_t(std::max(n, 1)));
+        double E[9], R[9], t[3];
+        int rc = esfm_find_essential_mat(default_ctx(), p1.data(), p2.data(), n, K4, ransac_prob, ransac_thre, E, mask.data(), nullptr);
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        for (int i = 0; i < n; ++i) if (mask[size_t(i)]) inlier_matches.push_back(matches[size_t(i)]);   // :55-61
+        rc = esfm_recover_pose(default_ctx(), E, p1.data(), p2.data(), n, K4, R, t, mask.data(), nullptr);   // :67
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        T = Matrix4f::Identity();
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T(r, c) = float(R[3 * r + c]); T(r, 3) = float(t[r]); }   // :76-85
+        if (!quiet) std::cout << "Find [" << inlier_matches.size() << "] inlier matches from [" << matches.size() << "] total matches." << std::endl;
+        return true;
+    }
+
+    // estimate_motion.cpp:234-283: every random_rate-th match triangulated between [I|0] and T_21, mean distance from camera 1
+    bool getDepthFast(frame_t &cur_frame_1, frame_t &cur_frame_2, Matrix4f &T_21, const std::vector<DMatch> &matches, double &appro_depth,
+                      int random_rate = 20)
+    {
+        std::vector<float> a, b;
+        gather(cur_frame_1, cur_frame_2, matches, random_rate, a, b);
+        const int n = int(a.size() / 2);
+        pixel2cam(a, cur_frame_1.K_cam); pixel2cam(b, cur_frame_1.K_cam);   // frame 1's K for both (:245)
+        float P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, P2[12];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) P2[4 * r + c] = T_21(r, c);
+        std::vector<float> h(size_t(4) * size_t(std::max(n, 1)));
+        if (n > 0 && esfm_triangulate_points(default_ctx(), P1, P2, a.data(), b.data(), n, h.data()) != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        double depth_sum = 0;
+        for (int i = 0; i < n; ++i) {
+            const float x = h[size_t(4 * i)] / h[size_t(4 * i + 3)], y = h[size_t(4 * i + 1)] / h[size_t(4 * i + 3)], z = h[size_t(4 * i + 2)] / h[size_t(4 * i + 3)];
+            depth_sum += double(std::sqrt(x * x + y * y + z * z));   // Eigen::Vector3f::norm()
+        }
+        appro_depth = depth_sum / n;   // 0 / 0 for an empty sample, like the reference
+        return true;
+    }
+
+    // estimate_motion.cpp:285-367 (without the colour lookup: frame_t carries no image here)
+    bool doTriangulation(frame_t &cur_frame_1, frame_t &cur_frame_2, const std::vector<DMatch> &matches, pointcloud_sparse_t &sparse_pointcloud,
+                         bool show = false)
+    {
+        std::unordered_map<int, int> known;
+        for (int id : sparse_pointcloud.unique_point_ids) known.emplace(id, 1);
+        std::vector<float> a, b;
+        int count_new = 0;
+        for (const DMatch &m : matches) {
+            const int uid = cur_frame_1.unique_pixel_ids[size_t(m.queryIdx)];
+            if (known.count(uid)) continue;
+            known.emplace(uid, 1);
+            sparse_pointcloud.unique_point_ids.push_back(uid);
+            sparse_pointcloud.is_inlier.push_back(1);
+            a.push_back(cur_frame_1.keypoints[size_t(m.queryIdx)].pt.x); a.push_back(cur_frame_1.keypoints[size_t(m.queryIdx)].pt.y);
+            b.push_back(cur_frame_2.keypoints[size_t(m.trainIdx)].pt.x); b.push_back(cur_frame_2.keypoints[size_t(m.trainIdx)].pt.y);
+            ++count_new;
+        }
+        pixel2cam(a, cur_frame_1.K_cam); pixel2cam(b, cur_frame_1.K_cam);
+        float P1[12], P2[12];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { P1[4 * r + c] = cur_frame_1.pose_cam(r, c); P2[4 * r + c] = cur_frame_2.pose_cam(r, c); }
+        std::vector<float> h(size_t(4) * size_t(std::max(count_new, 1)));
+        if (count_new > 0 && esfm_triangulate_points(default_ctx(), P1, P2, a.data(), b.data(), count_new, h.data()) != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        for (int i = 0; i < count_new; ++i) {
+            PointXYZRGB p;
+            p.x = h[size_t(4 * i)] / h[size_t(4 * i + 3)]; p.y = h[size_t(4 * i + 1)] / h[size_t(4 * i + 3)]; p.z = h[size_t(4 * i + 2)] / h[size_t(4 * i + 3)];
+            sparse_pointcloud.points.push_back(p);
+        }
+        if (!quiet) std::cout << "Triangulate [ " << count_new << " ] new points, [ " << sparse_pointcloud.points.size() << " ] points in total." << std::endl;
+        return true;
+    }
+
+    // estimate_motion.cpp:99-232: id join (keypoint-major, +-300 gate), solvePnPRansac(EPnP), pose write-back, the reference's
+    // inlier bookkeeping (the int index matrix read as float always addresses correspondence 0)
+    bool estimate2D3D_P3P_RANSAC(frame_t &cur_frame, pointcloud_sparse_t &cur_map_3d, double ransac_thre = 2.5, int iterationsCount = 50000,
+                                 double ransac_prob = 0.99, bool show = false)
+    {
+        std::unordered_map<int, std::vector<int>> where;
+        for (size_t j = 0; j < cur_map_3d.unique_point_ids.size(); ++j) where[cur_map_3d.unique_point_ids[j]].push_back(int(j));
+        std::vector<float> p2, p3;
+        std::vector<int> index;
+        const float dist_thre = 300;
+        for (size_t i = 0; i < cur_frame.unique_pixel_ids.size(); ++i) {
+            auto it = where.find(cur_frame.unique_pixel_ids[i]);
+            if (it == where.end()) continue;
+            for (int j : it->second) {
+                const PointXYZRGB &q = cur_map_3d.points[size_t(j)];
+                if (std::abs(q.x) < dist_thre && std::abs(q.y) < dist_thre && std::abs(q.z) < dist_thre) {
+                    p2.push_back(cur_frame.keypoints[i].pt.x); p2.push_back(cur_frame.keypoints[i].pt.y);
+                    p3.push_back(q.x); p3.push_back(q.y); p3.push_back(q.z);
+                    index.push_back(j);
+                }
+            }
+        }
+        const int count = int(index.size());
+        float K4[4]; k4_of(cur_frame.K_cam, K4);
+        double rv[3], tv[3], R[9];
+        int32_t n_inl = 0;
+        std::vector<uint8_t> mask(size_t(std::max(count, 1)));
+        int rc = esfm_solve_pnp_ransac(default_ctx(), p3.data(), p2.data(), count, K4, iterationsCount, ransac_thre, ransac_prob, rv, tv, R, mask.data(),
+                                       &n_inl, nullptr);
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        if (n_inl > 0 && !index.empty()) index[0] = -1;   // inliers.at<float>(i, 0) on CV_32S (:169)
+        for (int j : index) if (j >= 0) cur_map_3d.is_inlier[size_t(j)] = 0;
+        double Rr[9];
+        angle_axis_to_rotation(rv, Rr);   // cv::Rodrigues(r_vec, R_mat) (:184)
+        cur_frame.pose_cam = Matrix4f::Identity();
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) cur_frame.pose_cam(r, c) = float(Rr[3 * r + c]); cur_frame.pose_cam(r, 3) = float(tv[r]); }
+        float reproj_err = 0.f;
+        for (int i = 0; i < count; ++i) {
+            const double X = p3[size_t(3 * i)], Y = p3[size_t(3 * i + 1)], Z = p3[size_t(3 * i + 2)];
+            const double xc = Rr[0] * X + Rr[1] * Y + Rr[2] * Z + tv[0], yc = Rr[3] * X + Rr[4] * Y + Rr[5] * Z + tv[1], zc = Rr[6] * X + Rr[7] * Y + Rr[8] * Z + tv[2];
+            const float u = float(xc / zc * double(K4[0]) + double(K4[1])), v = float(yc / zc * double(K4[2]) + double(K4[3]));
+            const float dx = u - p2[size_t(2 * i)], dy = v - p2[size_t(2 * i + 1)];
+            reproj_err += std::sqrt(dx * dx + dy * dy);
+        }
+        reproj_err /= float(count);
+        const double inlier_ratio = 1.0 * n_inl / count;
+        if (!quiet) std::cout << "Inlier count: " << n_inl << std::endl << "Mean reprojection error: " << reproj_err << std::endl;
+        return !(reproj_err > 10 && inlier_ratio < 0.5);
+    }
+
+    // estimate_motion.cpp:476-505
+    bool outlierFilter(pointcloud_sparse_t &sparse_pointcloud, int MeanK = 40, double std = 2.5)
+    {
+        const int n = int(sparse_pointcloud.points.size());
+        std::vector<float> xyz(size_t(3) * size_t(std::max(n, 1)));
+        for (int i = 0; i < n; ++i) { xyz[size_t(3 * i)] = sparse_pointcloud.points[size_t(i)].x; xyz[size_t(3 * i + 1)] = sparse_pointcloud.points[size_t(i)].y; xyz[size_t(3 * i + 2)] = sparse_pointcloud.points[size_t(i)].z; }
+        std::vector<uint8_t> keep(size_t(std::max(n, 1)));
+        if (esfm_sor_filter(default_ctx(), xyz.data(), n, 3, MeanK, std, nullptr, keep.data(), nullptr, nullptr) != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        pointcloud_sparse_t out;
+        for (int i = 0; i < n; ++i) if (keep[size_t(i)]) {
+            out.points.push_back(sparse_pointcloud.points[size_t(i)]);
+            out.unique_point_ids.push_back(sparse_pointcloud.unique_point_ids[size_t(i)]);
+            out.is_inlier.push_back(sparse_pointcloud.is_inlier[size_t(i)]);
+        }
+        sparse_pointcloud.points.swap(out.points); sparse_pointcloud.unique_point_ids.swap(out.unique_point_ids); sparse_pointcloud.is_inlier.swap(out.is_inlier);
+        return true;
+    }
+
+    bool quiet = false;
+
+private:
+    static void k4_of(const Matrix3f &K, float K4[4]) { K4[0] = K(0, 0); K4[1] = K(0, 2); K4[2] = K(1, 1); K4[3] = K(1, 2); }
+    static void gather(const frame_t &f1, const frame_t &f2, const std::vector<DMatch> &matches, int rate, std::vector<float> &a, std::vector<float> &b)
+    {
+        for (size_t i = 0; i < matches.size(); ++i) {
+            if (int(i) % rate != 0) continue;
+            a.push_back(f1.keypoints[size_t(matches[i].queryIdx)].pt.x); a.push_back(f1.keypoints[size_t(matches[i].queryIdx)].pt.y);
+            b.push_back(f2.keypoints[size_t(matches[i].trainIdx)].pt.x); b.push_back(f2.keypoints[size_t(matches[i].trainIdx)].pt.y);
+        }
+    }
+    // estimate_motion.h:41-46, float arithmetic
+    static void pixel2cam(std::vector<float> &p, const Matrix3f &K)
+    {
+        for (size_t i = 0; i + 1 < p.size(); i += 2) { p[i] = (p[i] - K(0, 2)) / K(0, 0); p[i + 1] = (p[i + 1] - K(1, 2)) / K(1, 1); }
     }
 };
 

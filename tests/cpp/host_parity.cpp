@@ -12,6 +12,9 @@ extern "C" {
 void esfm_ref_knn2_l2_f32(const float *, int, const float *, int, int, int32_t *, float *);
 void esfm_ref_knn2_hamming(const uint8_t *, int, const uint8_t *, int, int, int32_t *, float *);
 int esfm_ref_ratio_filter(const int32_t *, const float *, int, double, int32_t *, int32_t *, float *);
+int esfm_ref_find_essential_ransac(const float *, const float *, int, const float *, double, double, double *, uint8_t *, int32_t *, int32_t *);
+int esfm_ref_recover_pose(const double *, const float *, const float *, int, const float *, double *, double *, uint8_t *);
+int esfm_ref_solve_pnp_ransac(const float *, const float *, int, const float *, int, double, double, double *, double *, double *, uint8_t *, int32_t *, int32_t *);
 int esfm_ref_sor_filter(const float *, int, int, int, double, float *, uint8_t *, double *);
 int esfm_ref_ba_solve_ex(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *, double *, double,
                          int, double, const esfm_ba_options *, esfm_ba_summary *);
@@ -208,6 +211,83 @@ int main()
         int next = -1;
         fm.findNextFrame(T, todo, ids, next);
         CHECK(next == 2);
+    }
+    // ---- MotionEstimator: estimate2D2D_E5P_RANSAC -> getDepthFast -> doTriangulation; estimate2D3D_P3P_RANSAC ----------------
+    {
+        std::normal_distribution<double> g(0.0, 1.0);
+        std::uniform_real_distribution<double> U(-2.0, 2.0), O(-60.0, 60.0);
+        const int N = 400;
+        const double aa[3] = {0.05, -0.2, 0.03}; double R[9]; angle_axis_to_rotation(aa, R);
+        double t[3] = {1.0, 0.1, -0.05}; { const double nn = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]); for (double &x : t) x /= nn; }
+        frame_t f1(1, "a"), f2(0, "b");
+        for (frame_t *f : {&f1, &f2}) { f->K_cam(0, 0) = 689.87f; f->K_cam(0, 2) = 380.17f; f->K_cam(1, 1) = 691.04f; f->K_cam(1, 2) = 251.70f; f->K_cam(2, 2) = 1.f; }
+        std::vector<DMatch> matches, inl;
+        std::vector<float> p1, p2;
+        std::vector<double> X(3 * N);
+        for (int i = 0; i < N; ++i) {
+            double x[3] = {U(rng), U(rng), U(rng) + 8.0};
+            for (int k = 0; k < 3; ++k) X[size_t(3 * i + k)] = x[k];
+            double xc[3]; for (int r = 0; r < 3; ++r) xc[r] = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2] + t[r];
+            KeyPoint a, b;
+            a.pt.x = float(x[0] / x[2] * 689.87 + 380.17); a.pt.y = float(x[1] / x[2] * 691.04 + 251.70);
+            b.pt.x = float(xc[0] / xc[2] * 689.87 + 380.17 + 0.3 * g(rng)); b.pt.y = float(xc[1] / xc[2] * 691.04 + 251.70 + 0.3 * g(rng));
+            if (i % 4 == 3) { b.pt.x += float(O(rng)); b.pt.y += float(O(rng)); }   // 25 % gross outliers
+            f1.keypoints.push_back(a); f2.keypoints.push_back(b);
+            f1.unique_pixel_ids.push_back(500 + i); f2.unique_pixel_ids.push_back(500 + i);
+            matches.push_back(DMatch(i, i, 0, 0.f));
+            p1.push_back(a.pt.x); p1.push_back(a.pt.y); p2.push_back(b.pt.x); p2.push_back(b.pt.y);
+        }
+        MotionEstimator ee; ee.quiet = true;
+        Matrix4f T;
+        CHECK(ee.estimate2D2D_E5P_RANSAC(f1, f2, matches, inl, T, 1.0, 0.99));
+        const float K4[4] = {689.87f, 380.17f, 691.04f, 251.70f};
+        double Er[9], Rr[9], tr[3]; std::vector<uint8_t> mr(N); int32_t itr = 0, cnt = 0;
+        CHECK(esfm_ref_find_essential_ransac(p1.data(), p2.data(), N, K4, 0.99, 1.0, Er, mr.data(), &itr, &cnt) == 1);
+        CHECK(int(inl.size()) == cnt && cnt >= 290);
+        { size_t k = 0; for (int i = 0; i < N; ++i) if (mr[size_t(i)]) { CHECK(inl[k].queryIdx == i); ++k; } }
+        esfm_ref_recover_pose(Er, p1.data(), p2.data(), N, K4, Rr, tr, mr.data());
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) CHECK(std::fabs(double(T(r, c)) - Rr[3 * r + c]) < 1e-6); CHECK(std::fabs(double(T(r, 3)) - tr[r]) < 1e-6); }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) CHECK(std::fabs(double(T(r, c)) - R[3 * r + c]) < 0.02);
+        double depth = 0;
+        CHECK(ee.getDepthFast(f1, f2, T, inl, depth));
+        CHECK(depth > 6.0 && depth < 11.0);
+        pointcloud_sparse_t cloud;
+        f1.pose_cam = Matrix4f::Identity(); f2.pose_cam = T;
+        CHECK(ee.doTriangulation(f1, f2, inl, cloud));
+        CHECK(cloud.points.size() == inl.size() && cloud.unique_point_ids.size() == inl.size());
+        // the triangulated points reproject onto their keypoints in frame 1 (identity pose) at the scene's depth; medians, because a
+        // gross outlier displaced ALONG its epipolar line passes the Sampson test and triangulates to an arbitrary depth
+        std::vector<double> px, zz;
+        for (size_t k = 0; k < inl.size(); ++k) {
+            const PointXYZRGB &p = cloud.points[k]; const KeyPoint &kp = f1.keypoints[size_t(inl[k].queryIdx)];
+            px.push_back(std::hypot(double(p.x / p.z) * 689.87 + 380.17 - double(kp.pt.x), double(p.y / p.z) * 691.04 + 251.70 - double(kp.pt.y)));
+            zz.push_back(double(p.z));
+        }
+        std::sort(px.begin(), px.end()); std::sort(zz.begin(), zz.end());
+        CHECK(px[px.size() / 2] < 0.5 && zz[zz.size() / 2] > 6.5 && zz[zz.size() / 2] < 9.5);
+        // a third frame registered against the cloud by PnP
+        const double aa3[3] = {-0.1, 0.25, 0.02}, t3[3] = {-0.8, 0.05, 0.3}; double R3[9]; angle_axis_to_rotation(aa3, R3);
+        frame_t f3(2, "c"); f3.K_cam = f1.K_cam;
+        std::vector<float> q3, q2;
+        for (size_t k = 0; k < inl.size(); ++k) {
+            const PointXYZRGB &p = cloud.points[k];
+            double xc[3]; for (int r = 0; r < 3; ++r) xc[r] = R3[3 * r] * p.x + R3[3 * r + 1] * p.y + R3[3 * r + 2] * p.z + t3[r];
+            KeyPoint kp; kp.pt.x = float(xc[0] / xc[2] * 689.87 + 380.17 + 0.3 * g(rng)); kp.pt.y = float(xc[1] / xc[2] * 691.04 + 251.70 + 0.3 * g(rng));
+            if (k % 5 == 4) { kp.pt.x += float(O(rng)); kp.pt.y += float(O(rng)); }
+            f3.keypoints.push_back(kp); f3.unique_pixel_ids.push_back(cloud.unique_point_ids[k]);
+            q3.push_back(p.x); q3.push_back(p.y); q3.push_back(p.z); q2.push_back(kp.pt.x); q2.push_back(kp.pt.y);
+        }
+        CHECK(ee.estimate2D3D_P3P_RANSAC(f3, cloud, 2.5, 50000, 0.99));
+        double Rp[9], tp[3], rvp[3]; std::vector<uint8_t> mp(inl.size()); int32_t itp = 0, np_ = 0;
+        CHECK(esfm_ref_solve_pnp_ransac(q3.data(), q2.data(), int(inl.size()), K4, 50000, 2.5, 0.99, Rp, tp, rvp, mp.data(), &itp, &np_) == 1);
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) CHECK(std::fabs(double(f3.pose_cam(r, c)) - Rp[3 * r + c]) < 1e-5); CHECK(std::fabs(double(f3.pose_cam(r, 3)) - tp[r]) < 1e-5); }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) CHECK(std::fabs(double(f3.pose_cam(r, c)) - R3[3 * r + c]) < 0.02);
+        CHECK(cloud.is_inlier[0] == 1 && cloud.is_inlier[1] == 0);
+        const size_t before = cloud.points.size();
+        cloud.points[3].x += 400.f;
+        CHECK(ee.outlierFilter(cloud));
+        CHECK(cloud.points.size() < before && cloud.points.size() == cloud.unique_point_ids.size());
+        std::printf("MotionEstimator: %d/%d RANSAC inliers (exact vs oracle), depth %.2f, %zu points triangulated, PnP pose vs oracle < 1e-5\n", cnt, N, depth, before);
     }
     std::printf("HOST PARITY OK\n");
     return 0;
