@@ -79,7 +79,7 @@ class BASummary(C.Structure):
 def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     path = os.path.join(_HERE, out)
-    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "pnp_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "pnp_ref.c", "surf_ref.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
@@ -157,6 +157,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_solve_pnp_ransac.restype = C.c_int
     lib.esfm_ref_solve_pnp_ransac.argtypes = [_f32p, _f32p, C.c_int, _f32p, C.c_int, C.c_double, C.c_double, _f64p, _f64p, _f64p, _u8p,
                                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.esfm_ref_bgr2gray.restype = None
+    lib.esfm_ref_bgr2gray.argtypes = [_u8p, C.c_int, _u8p]
+    lib.esfm_ref_surf.restype = C.c_int
+    lib.esfm_ref_surf.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, C.c_int, _f32p, _f32p]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -420,3 +424,20 @@ def solve_pnp_ransac(pts3d, pix, K4, iterations_count: int = 100, reproj_error: 
     ok = load().esfm_ref_solve_pnp_ransac(a.reshape(-1), b.reshape(-1), n, np.ascontiguousarray(K4, np.float32).reshape(4), int(iterations_count),
                                           float(reproj_error), float(confidence), R, t, rv, mask, C.byref(it), C.byref(ni))
     return bool(ok), R.reshape(3, 3), t, rv, mask[:n].astype(bool), it.value
+
+
+# ----------------------------------------------------------------------------- SURF
+def bgr2gray(bgr) -> np.ndarray:
+    b = np.ascontiguousarray(bgr, np.uint8)
+    out = np.zeros(b.shape[:2], np.uint8)
+    load().esfm_ref_bgr2gray(b.reshape(-1), out.size, out.reshape(-1))
+    return out
+
+
+def surf(gray, hessian_threshold: float = 100.0, max_kp: int = 200000):
+    """SURF::detect + SURF::compute (feature_matching.cpp:43-58) on a gray uint8 image.
+    Returns (keypoints [n, 7] float32: x, y, size, angle, response, octave, class_id; descriptors [n, 64] float32)."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    kp = np.zeros((max_kp, 7), np.float32); desc = np.zeros((max_kp, 64), np.float32)
+    n = load().esfm_ref_surf(g.reshape(-1), g.shape[0], g.shape[1], float(hessian_threshold), int(max_kp), kp.reshape(-1), desc.reshape(-1))
+    return kp[:n].copy(), desc[:n].copy()
