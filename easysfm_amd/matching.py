@@ -99,6 +99,11 @@ class FeatureMatching:
         matches.extend(DMatch(int(a), int(b), float(c)) for a, b, c in zip(qi, ti, d))
         return True
 
+    def detectFeaturesSURF(self, cur_frame: Frame, minHessian: int = 400, show: bool = False) -> bool:
+        """feature_matching.cpp:43-69 (features.detectFeaturesSURF)."""
+        from .features import detectFeaturesSURF
+        return detectFeaturesSURF(cur_frame, minHessian, show, self._ctx)
+
     # ---- frame selection (feature_matching.cpp:160-268): integer logic on the track matrix, host side ----
     def findInitializeFramePair(self, feature_track_matrix, frames, img_match_graph, min_track_num_init: int = 100,
                                 max_depth_baseline_ratio_init: float = 50.0):

@@ -29,6 +29,7 @@ class Frame:
     unique_pixel_has_match: np.ndarray = field(default_factory=lambda: np.zeros(0, bool))
     pose_cam: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))     # Eigen::Matrix4f
     K_cam: np.ndarray = field(default_factory=lambda: np.eye(3, dtype=np.float32))        # Eigen::Matrix3f
+    rgb_image: Optional[np.ndarray] = None          # cv::Mat CV_8UC3, BGR as cv::imread delivers it (utility.h:27)
 
     def init_pixel_ids(self) -> None:
         """frame_t::init_pixel_ids (utility.h:47-54)."""

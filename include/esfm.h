@@ -84,7 +84,9 @@ typedef enum esfm_kernel_id {
     ESFM_K_SOR_KNN = 6,       /* sor_knn_mean_kernel: k-NN mean distances of the outlier filter   */
     ESFM_K_TRIANGULATE = 7,   /* triangulate_dlt_kernel                                         */
     ESFM_K_RANSAC = 8,        /* essential_solve_kernel + essential_score_kernel (one chunk)    */
-    ESFM_K_COUNT = 9
+    ESFM_K_SURF_DET = 9,      /* surf_det_trace_kernel                                          */
+    ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
+    ESFM_K_COUNT = 11
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -413,6 +415,19 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
                           uint8_t *inlier_mask /*n or NULL*/, int32_t *n_inliers /*or NULL*/, int32_t *iterations /*or NULL*/);
 /* Host-only (no GPU): the first n_samples 5-index samples RANSAC draws for `count` points (cv::RNG replay). */
 int esfm_ransac_sample_stream(int count, int n_samples, int32_t *idx /*5 per sample*/);
+
+/* ---- SURF detection + description (SURF half) ----------------------------
+ * FeatureMatching::detectFeaturesSURF (cpp_code/src/feature_matching.cpp:43-58): cv::xfeatures2d::SURF::create(minHessian)
+ * ->detect(image, keypoints) then SURF::create()->compute(image, keypoints, descriptors), OpenCV defaults (4 octaves, 3 layers
+ * per octave, 64-float descriptors, rotation-invariant).  image: rows x cols x channels uint8, row-major; channels = 3 is BGR
+ * as cv::imread delivers it (converted with cvtColor's fixed-point weights), channels = 1 is already gray.  Outputs, strongest
+ * first (OpenCV's KeypointGreater order): keypoints[7 k + 0..6] = pt.x, pt.y, size, angle (degrees), response, octave, class_id
+ * (sign of the Laplacian); descriptors[64 k ..] unit-length.  At most max_keypoints are returned (OpenCV returns all; pass
+ * rows * cols / 4 to be sure).  The box-filter Hessian pyramid, the 3 x 3 x 3 maxima with quadratic refinement, the dominant
+ * orientation (cv::fastAtan2 polynomial, 60-degree window in 5-degree steps) and the descriptor (rotated bilinear window,
+ * area shrink to 21 x 21, Gaussian-weighted 2 x 2 gradients, 4 x 4 cells) follow OpenCV's surf.cpp operation by operation. */
+int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int channels, double hessian_threshold,
+                                 int max_keypoints, float *keypoints /*7 per*/, float *descriptors /*64 per*/, int32_t *n_keypoints);
 
 #ifdef __cplusplus
 }

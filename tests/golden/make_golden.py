@@ -35,6 +35,9 @@ C oracle (oracle/*.c) is pinned by tests/test_oracle_golden.py:
                             model must satisfy the epipolar, determinant and trace constraints); recoverPose cases whose
                             expected R, t, cheirality mask come from a numpy restatement (numpy.linalg.svd for the
                             decomposition and for each point's 4 x 4 DLT system)
+  fountain_pair_half.npz    INPUT ONLY: the reference's first two test images (test_data/images_25/0000.png, 0001.png), decoded
+                            with PIL, BGR order, every second pixel (384 x 256 x 3 uint8) -- real texture for the SURF tests
+                            (written by a one-off snippet, not by this script: the PNGs live in /root/reference)
 
     python tests/golden/make_golden.py
 """
