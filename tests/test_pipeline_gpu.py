@@ -58,3 +58,49 @@ def test_incremental_sfm_on_synthetic_scene(gpu_ctx, tmp_path):
     assert len(filtered.xyz) <= len(cloud.xyz) and len(filtered.xyz) > 0.85 * len(cloud.xyz)
     xyz, rgb, cam = E.read_ply_vertices(out_file)
     assert len(xyz) == len(filtered.xyz)
+
+
+def test_fountain_from_pixels(gpu_ctx, tmp_path):
+    """The reference's own test images (test_data/images_25, the 11 shipped PNGs, gray, every second pixel) through the whole
+    chain from pixels: SURF detection + description (minHessian 100: run_fountain_small.sh uses 300 on the full-size images,
+    which at half resolution leaves too few 3-view tracks for the PnP stage), all-pairs matching, RANSAC,
+    incremental registration with BA every 4 frames (ba_frequency 4), final BA, SOR, .ply.  No ground truth ships with the
+    images, so the checks are the properties of a sound reconstruction: every frame registered, the scene in front of every
+    camera, sub-pixel mean reprojection error after the final BA, a smooth camera trajectory."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fountain11_half_gray.npz"))
+    K = np.array([[689.87 / 2, 0, 380.17 / 2], [0, 691.04 / 2, 251.70 / 2], [0, 0, 1]], np.float32)   # test_data/k_25/K.txt at half resolution
+    frames = []
+    for i, img in enumerate(z["images"]):
+        fr = E.Frame(frame_id=i, rgb_image=img)
+        fr.K_cam = K.copy()
+        E.detectFeaturesSURF(fr, 100, ctx=gpu_ctx)
+        assert len(fr.keypoints) > 500
+        frames.append(fr)
+    out_file = str(tmp_path / "fountain.ply")
+    cloud, filtered, graph = E.run_sfm(frames, out_file, "S", 1.0, True, 0.0, 4, gpu_ctx)
+    assert all(len(graph[i][i - 1].matches) >= 20 for i in range(1, len(frames)))          # neighbouring views overlap
+    n_pts = len(cloud.xyz)
+    assert n_pts > 300 and len(filtered.xyz) > 0.8 * n_pts
+    # reprojection of every cloud point into every frame that observes its track
+    ids = {int(u): k for k, u in enumerate(cloud.unique_point_ids)}
+    errs, behind = [], 0
+    for fr in frames:
+        R, t = fr.pose_cam[:3, :3].astype(np.float64), fr.pose_cam[:3, 3].astype(np.float64)
+        for kpt, uid in zip(fr.keypoints, fr.unique_pixel_ids):
+            k = ids.get(int(uid))
+            if k is None:
+                continue
+            Xc = R @ cloud.xyz[k].astype(np.float64) + t
+            behind += Xc[2] <= 0
+            errs.append(np.hypot(Xc[0] / Xc[2] * K[0, 0] + K[0, 2] - kpt[0], Xc[1] / Xc[2] * K[1, 1] + K[1, 2] - kpt[1]))
+    errs = np.array(errs)
+    print(f"fountain: {n_pts} points, {len(errs)} observations, behind {behind}, median {np.median(errs):.3f} px, < 2 px {np.mean(errs < 2.0):.3f}")
+    assert len(errs) > 1000 and behind <= 0.03 * len(errs)                                   # a few epipolar-consistent mismatches survive
+    assert np.median(errs) < 1.0 and np.mean(errs < 2.0) > 0.85                               # pixels, half-resolution image
+    C = np.array([-f.pose_cam[:3, :3].astype(np.float64).T @ f.pose_cam[:3, 3].astype(np.float64) for f in frames])
+    steps = np.linalg.norm(np.diff(C, axis=0), axis=1)
+    print("fountain: camera steps", np.round(steps / np.median(steps), 2))
+    assert steps.max() < 6.0 * np.median(steps) and steps.min() > 0                          # a walked arc, no jumps
+    xyz, rgb, cam = E.read_ply_vertices(out_file)
+    assert len(xyz) == len(filtered.xyz)
