@@ -204,3 +204,27 @@ def test_ransac_sample_stream_matches_oracle(oracle_lib):
     s = 0xFFFFFFFFFFFFFFFF
     s = (s & 0xFFFFFFFF) * 4164903690 + (s >> 32)
     assert E.ransac_sample_stream(1000, 1)[0, 0] == (s & 0xFFFFFFFF) % 1000
+
+
+def test_bin_sfm_command_line(tmp_path):
+    """./bin/sfm keeps the reference's 13 positional arguments (sfm.cpp:35-50); unsupported choices fail with a message."""
+    import os
+    import subprocess
+    import sys
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "sfm")
+    r = subprocess.run([sys.executable, exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 2 and "feature_type" in r.stdout
+    args = ["imgs", "list.txt", "K.txt", "none", str(tmp_path / "o.ply"), "O", "8000", "1.0", "1", "0", "4", "0", "0"]
+    r = subprocess.run([sys.executable, exe] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "ORB" in r.stdout
+    sys.path.insert(0, os.path.dirname(exe))
+    import importlib.machinery
+    import importlib.util
+    loader = importlib.machinery.SourceFileLoader("bin_sfm", exe)
+    mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("bin_sfm", loader))
+    loader.exec_module(mod)
+    (tmp_path / "list.txt").write_text("0000.png\r\n0001.png\n\n")
+    (tmp_path / "K.txt").write_text("689.87 0 380.17\r\n0 691.04 251.70\r\n0 0 1")
+    assert mod.import_image_filenames(str(tmp_path / "list.txt"), "dir") == [os.path.join("dir", "0000.png"), os.path.join("dir", "0001.png")]
+    K = mod.import_calib(str(tmp_path / "K.txt"))
+    assert K.shape == (3, 3) and abs(K[0, 2] - 380.17) < 1e-4 and K[2, 2] == 1

@@ -104,3 +104,28 @@ def test_fountain_from_pixels(gpu_ctx, tmp_path):
     assert steps.max() < 6.0 * np.median(steps) and steps.min() > 0                          # a walked arc, no jumps
     xyz, rgb, cam = E.read_ply_vertices(out_file)
     assert len(xyz) == len(filtered.xyz)
+
+
+def test_bin_sfm_end_to_end(tmp_path):
+    """./bin/sfm with the reference's 13 positional arguments (run_fountain_small.sh:22-24) on the fountain images written back
+    to PNG files: exit status 1 (the reference's success code, sfm.cpp:339) and a PCL-style ASCII .ply at argv[5]."""
+    import os
+    import subprocess
+    import sys
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", "fountain11_half_gray.npz"))
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    names = []
+    for i, img in enumerate(z["images"][:6]):
+        names.append(f"{i:04d}.png")
+        PIL.fromarray(np.stack([img] * 3, axis=2)).save(str(img_dir / names[-1]))
+    (tmp_path / "image_list.txt").write_text("\n".join(names) + "\n")
+    (tmp_path / "K.txt").write_text(f"{689.87 / 2} 0 {380.17 / 2}\r\n0 {691.04 / 2} {251.70 / 2}\r\n0 0 1")
+    out = tmp_path / "output" / "cloud.ply"
+    r = subprocess.run([sys.executable, os.path.join(root, "bin", "sfm"), str(img_dir), str(tmp_path / "image_list.txt"), str(tmp_path / "K.txt"), "none",
+                        str(out), "S", "100", "1.0", "1", "0", "4", "1", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 1, r.stdout[-2000:]
+    assert "Feature extraction done" in r.stdout and "Output ply file done." in r.stdout
+    xyz, rgb, cam = E.read_ply_vertices(str(out))
+    assert len(xyz) > 200 and np.all(np.isfinite(xyz))
