@@ -340,6 +340,36 @@ def main() -> int:
         except Exception as e:
             out["cloud"] = {"error": repr(e)}
 
+    # ---------------------------------------------------------------- SURF from pixels (row f-2), rank 0 at N = 1
+    if rank == 0 and world == 1 and not args.no_ba:
+        try:
+            gold = os.path.join(ROOT, "tests", "golden", "fountain11_half_gray.npz")
+            half = np.load(gold)["images"][0]
+            img = np.ascontiguousarray(np.kron(half, np.ones((2, 2), np.uint8)))               # 512 x 768 like the reference's images
+            img = np.clip(img.astype(np.int16) + np.random.default_rng(4300).integers(-6, 7, img.shape), 0, 255).astype(np.uint8)
+            fctx = E.Context(local_rank, None)
+            kp_, d_ = E.surf_detect_and_compute(img, 300.0, None, fctx)
+            fctx.set_kernel_timing(True); fctx.kernel_time(_lib.K_SURF_DET); fctx.kernel_time(_lib.K_SURF_DESC)
+            t0 = time.perf_counter()
+            n_rep = 10
+            for _ in range(n_rep):
+                kp_, d_ = E.surf_detect_and_compute(img, 300.0, None, fctx)
+            f_el = (time.perf_counter() - t0) / n_rep
+            dt_ms, dt_n = fctx.kernel_time(_lib.K_SURF_DET); ds_ms, ds_n = fctx.kernel_time(_lib.K_SURF_DESC)
+            fctx.set_kernel_timing(False)
+            out["surf"] = {"metric": "images/s, SURF detect + describe (768 x 512, minHessian 300)", "value": 1.0 / f_el, "unit": "images/s",
+                           "keypoints": int(len(kp_)), "ms_per_image": f_el * 1e3, "det_trace_kernel_ms": dt_ms / max(dt_n, 1),
+                           "describe_kernel_ms": ds_ms / max(ds_n, 1), "includes": "host<->device copies, host sort of the maxima"}
+            if not args.no_cpu_baseline:
+                import oracle
+                t0 = time.perf_counter(); rk_, rd_ = oracle.surf(img, 300.0); t1 = time.perf_counter() - t0
+                out["surf"]["verified_vs_oracle"] = bool(np.array_equal(kp_.view(np.uint32), rk_.view(np.uint32)) and
+                                                         np.array_equal(d_.view(np.uint32), rd_.view(np.uint32)))
+                out["surf"]["cpu_baseline"] = {"value": 1.0 / t1, "unit": "images/s", "cores": 1, "kind": "port",
+                                               "sample": f"the same image in {t1:.2f}s (sequential restatement, one core)"}
+        except Exception as e:
+            out["surf"] = {"error": repr(e)}
+
     # ---------------------------------------------------------------- geometric verification (row f-1), rank 0 at N = 1
     if rank == 0 and world == 1 and not args.no_ba:
         try:
