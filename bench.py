@@ -283,7 +283,7 @@ def main() -> int:
             h_ms, h_n = octx.kernel_time(_lib.K_HAMMING_KNN)
             octx.set_kernel_timing(False)
             h_s = h_ms / max(h_n, 1) * 1e-3
-            ops = 2.0 * len(opairs) * N_FEATS * N_FEATS * 256          # i8 MAC ops of the +-1 formulation
+            ops = 2.0 * len(opairs) * N_FEATS * N_FEATS * 256          # i8 MAC ops of the byte-per-bit formulation
             out["orb"] = {"metric": "image-pairs matched/s (4096 ORB feats/img)", "value": len(opairs) * n_rep / o_el, "unit": "image-pairs/s",
                           "config": {"workload": "M-ORB-4k all-pairs ORB-256b match (2-NN + ratio 0.8), 25 imgs x 4096 feats x 32 B, 300 pairs/step"},
                           "kernel": "hamming_expand_kernel + hamming_knn_mfma_kernel", "avg_launch_ms": h_s * 1e3,

@@ -11,7 +11,6 @@ using esfm::PairDesc;
 namespace {
 
 constexpr int kL2QueryBlock = 128;       // queries per workgroup in l2_knn_mfma_kernel
-constexpr int kHammingQueryBlock = 256;  // queries per workgroup in hamming_knn_kernel
 
 struct PairPlan {
     std::vector<PairDesc> tab;
@@ -37,7 +36,7 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
         PairDesc &d = plan->tab[(size_t)p];
         d.q_row0 = set_row_offset[qs]; d.nq = set_row_offset[qs + 1] - set_row_offset[qs];
         d.t_row0 = set_row_offset[ts]; d.nt = set_row_offset[ts + 1] - set_row_offset[ts];
-        ESFM_REQUIRE(d.nt < (1 << 22), "train sets are limited to 2^22-1 rows");
+        ESFM_REQUIRE(d.nt < (1 << 21), "train sets are limited to 2^21-1 rows");   // index field of the packed top-2 keys
         d.out_off = off; d.blk_off = (int32_t)blk; d.pad = 0;
         if (out_offset) out_offset[p] = off;
         off += d.nq;
@@ -154,7 +153,7 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
     const int32_t pr[2] = {1, 0};
     int64_t out_off[2];
     PairPlan plan;
-    if (int rc = make_plan(offs, 2, pr, 1, metric == ESFM_L2_F32 ? kL2QueryBlock : kHammingQueryBlock, out_off, &plan)) return rc;
+    if (int rc = make_plan(offs, 2, pr, 1, metric == ESFM_L2_F32 ? kL2QueryBlock : esfm::hamming_query_block(width), out_off, &plan)) return rc;
     const PairDesc *dev_tab = nullptr;
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
     if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)nq)) return rc;
@@ -224,7 +223,7 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
     if (int rc = check_common(ctx, metric, width)) return rc;
     ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
     PairPlan plan;
-    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : kHammingQueryBlock,
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : esfm::hamming_query_block(width),
                            out_offset, &plan))
         return rc;
     if (plan.total_queries == 0) return ESFM_OK;
@@ -241,7 +240,7 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
     if (int rc = check_common(ctx, metric, width)) return rc;
     ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
     PairPlan plan;
-    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : kHammingQueryBlock,
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : esfm::hamming_query_block(width),
                            out_offset, &plan))
         return rc;
     if (n_pairs == 0) return ESFM_OK;

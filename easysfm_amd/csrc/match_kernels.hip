@@ -463,57 +463,71 @@ __global__ __launch_bounds__(256) void hamming_knn_kernel(const uint32_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hamming 2-NN for 256-bit descriptors (ORB) on the i8 matrix cores.  With every bit b stored as the byte 2b - 1,
-//   dot(q, t) = 256 - 2 hamming(q, t),
-// an exact integer identity, so `v_mfma_i32_32x32x32_i8` on the +-1 expansion computes Hamming distances
-// 32 trains x 32 queries x 32 bits at a time; starting the accumulator at 256 and negating the query operand
-// leaves 2 * hamming in the accumulator.  A = train rows (so that a lane's 16 results belong to ONE query, column
-// lane & 31, and 16 different trains), B = query columns held in registers for the whole kernel (2 sets of 32
-// queries per wave: 64 VGPRs), train tiles of 64 rows staged through LDS (row stride 272 B: conflict-free
-// ds_read_b128) and shared by the 4 waves.  K is contracted in whatever order the hardware pairs the 16 bytes a
-// lane supplies -- A and B are loaded with the same lane->byte convention, and the sum does not depend on it.
-// Top-2: running (best, second) pairs of keys 2ham << 21 | L with L = 16 * (32-train group number) + accumulator
-// register -- a wave-uniform scalar, so a result costs v_lshl_or + v_min_u32 + v_med3_u32.  Within a lane L grows
-// with the train index (row(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) is monotonic in r), so key order =
-// (distance, train index); four independent pairs per query set give the VALU chain some slack.  The train index is
-// rebuilt from L at the end, where the slots and the two lane halves are merged.
+// Hamming 2-NN for 256-bit descriptors (ORB) on the i8 matrix cores.  Bits are stored as 0/1 bytes; the query operand
+// enters the MFMA doubled (0/2) and each train's accumulator starts at 256 - popcount(t), so that
+//   acc = 256 - popcount(t) + 2 popcount(t & q) = 256 + popcount(q) - hamming(q, t),
+// an exact integer identity: `v_mfma_i32_32x32x32_i8` ranks 32 trains x 32 queries x 32 bits at a time (larger acc =
+// closer), and the per-query constant is removed when the two winners are written.  The operand encoding is chosen for
+// the matrix pipe's power draw, which is what sets its clock here: on the symmetric +-1 expansion (dot = 256 - 2 ham, half
+// the bytes 0xFF) the same kernel is 18 % slower, and bare MFMA loops over this workload's 2.6 POP take 0.68 ms on 0/1
+// x 0/1 operands, 0.73 ms on zeros x +-1 and 0.87 ms on +-1 x +-1 -- a "peak" measured on constant operands overstates
+// what random descriptors reach, and 0/1 trains against +-1 queries gain nothing: both operands have to be sparse.
+// A = train rows (so that a lane's 16 results belong to ONE query, column lane & 31, and 16 different trains), B = query
+// columns held in registers for the whole kernel (2 sets of 32 queries per wave: 64 VGPRs), train tiles of 64 rows
+// staged through LDS (row stride 272 B: conflict-free ds_read_b128) together with their 64 start values, shared by the 4
+// waves.  K is contracted in whatever order the hardware pairs the 16 bytes a lane supplies -- A and B are loaded with
+// the same lane->byte convention, and the sum does not depend on it.
+// Top-2: running (best, second) pairs of keys acc << 21 | (2^21 - 1 - L), largest first, with L = 16 * (32-train group
+// number) + accumulator register -- a wave-uniform scalar, so a result costs v_lshl_add + v_max_u32 + v_med3_u32.  Within
+// a lane L grows with the train index (row(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) is monotonic in r), so key order =
+// (distance ascending, train index ascending); four independent pairs per query set give the VALU chain some slack.
+// The train index is rebuilt from L at the end, where the slots and the two lane halves are merged.
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 
 constexpr int kHmTT = 64;          // trains per LDS tile
 constexpr int kHmStride = 272;     // bytes per staged train row (256 + 16: rows land 4 banks apart)
 constexpr int kHmQB = 256;         // queries per workgroup (4 waves x 2 sets x 32)
+constexpr uint32_t kHmLMask = 0x1FFFFFu;
 
-// bits -> +-1 bytes, one 32-bit word (32 output bytes) per thread
-__global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t *__restrict__ desc, long long n_words, uint32_t *__restrict__ out)
+// bits -> 0/1 bytes, one 32-bit word (32 output bytes) per thread; the 8 threads of a row also leave 256 - popcount(row)
+__global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t *__restrict__ desc, long long n_words, uint32_t *__restrict__ out,
+                                                             int32_t *__restrict__ start)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t w = i < n_words ? desc[i] : 0u;
+    int pop = __popc(w);
+    pop += __shfl_xor(pop, 1);
+    pop += __shfl_xor(pop, 2);
+    pop += __shfl_xor(pop, 4);
     if (i >= n_words) return;
-    const uint32_t w = desc[i];
+    if ((i & 7) == 0) start[i >> 3] = 256 - pop;
     uint32_t o[8];
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const uint32_t x = (w >> (4 * g)) & 0xFu;
-        const uint32_t bytes = (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21);   // one 0/1 byte per bit
-        o[g] = ~(bytes * 0xFEu);                                                                  // 1 -> 0x01, 0 -> 0xFF
+        o[g] = (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21);   // one 0/1 byte per bit
     }
     uint4 *dst = reinterpret_cast<uint4 *>(out + i * 8);
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
     dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
-__device__ __forceinline__ void key_insert(uint32_t &m1, uint32_t &m2, uint32_t key)
+// keeps the two largest keys seen, m1 >= m2
+__device__ __forceinline__ void key_insert_max(uint32_t &m1, uint32_t &m2, uint32_t key)
 {
-    uint32_t med;   // second smallest of (m1 <= m2, key); operands are VALU results, no MFMA hazard to pad
+    uint32_t med;   // second largest of (m1 >= m2, key); operands are VALU results, no MFMA hazard to pad
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key));
-    m1 = min(m1, key);
+    m1 = max(m1, key);
     m2 = med;
 }
 
-__global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned char *__restrict__ ex, const PairDesc *__restrict__ pairs,
-                                                               int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+__global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned char *__restrict__ ex, const int32_t *__restrict__ start,
+                                                               const PairDesc *__restrict__ pairs, int n_pairs,
+                                                               int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][kHmTT * kHmStride];
+    __shared__ __attribute__((aligned(16))) int32_t lds_start[2][kHmTT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int pi = find_pair_by_block(pairs, n_pairs, lb);
@@ -521,35 +535,39 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
     const int nq = pd.nq, nt = pd.nt;
     const unsigned char *__restrict__ Q = ex + (size_t)pd.q_row0 * 256;
     const unsigned char *__restrict__ T = ex + (size_t)pd.t_row0 * 256;
+    const int32_t *__restrict__ TS = start + pd.t_row0;
     const int qbase = (lb - pd.blk_off) * kHmQB + wave * 64;
 
-    // B operand: the negated query rows (x ^ 0xFE swaps 0x01 and 0xFF), 8 K-chunks of 32 bytes, this lane's 16
+    // B operand: the query rows doubled (0/2 bytes), 8 K-chunks of 32 bytes, this lane's 16
     i32x4 bq[2][8];
+    int qpop[2];   // set bits of this lane's query (both lane halves hold the same query)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool ok = qrow < nq;
         const i32x4 *qp = reinterpret_cast<const i32x4 *>(Q + (size_t)(ok ? qrow : 0) * 256 + h * 16);
+        int pop = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             i32x4 v = qp[2 * c];
-            const int neg = (int)0xFEFEFEFEu;
-            v.x ^= neg; v.y ^= neg; v.z ^= neg; v.w ^= neg;
             if (!ok) v = i32x4{0, 0, 0, 0};
-            bq[s][c] = v;
+            pop += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+            bq[s][c] = i32x4{v.x << 1, v.y << 1, v.z << 1, v.w << 1};
         }
+        qpop[s] = pop + __shfl_xor(pop, 32);
     }
     uint32_t m1[2][4], m2[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { m1[s][r] = 0xFFFFFFFFu; m2[s][r] = 0xFFFFFFFFu; }
+        for (int r = 0; r < 4; ++r) { m1[s][r] = 0u; m2[s][r] = 0u; }
 
     const int n_tiles = (nt + kHmTT - 1) / kHmTT;
     const int n_full = nt / kHmTT;       // tiles with all 64 rows inside the set: the software-pipelined loop
-    // staging: 256 threads x 64 B = one 64-row tile; thread t -> row t / 4, bytes [64 (t % 4), +64)
+    // staging: 256 threads x 64 B = one 64-row tile; thread t -> row t / 4, bytes [64 (t % 4), +64); threads 0..63 also
+    // carry one start value each
     const int srow = tid >> 2, scol = (tid & 3) * 64;
-    auto stage_load = [&](int tile, uint4 v[4]) {
+    auto stage_load = [&](int tile, uint4 v[4], int32_t &sv) {
         const int row = tile * kHmTT + srow;
         if (row < nt) {
             const uint4 *src = reinterpret_cast<const uint4 *>(T + (size_t)row * 256 + scol);
@@ -559,65 +577,74 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = make_uint4(0, 0, 0, 0);
         }
+        sv = (tid < kHmTT && tile * kHmTT + tid < nt) ? TS[tile * kHmTT + tid] : 0;
     };
-    auto stage_store = [&](int buf, const uint4 v[4]) {
+    auto stage_store = [&](int buf, const uint4 v[4], int32_t sv) {
         uint4 *dst = reinterpret_cast<uint4 *>(&lds[buf][srow * kHmStride + scol]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = v[q];
+        if (tid < kHmTT) lds_start[buf][tid] = sv;
     };
     if (n_tiles > 0) {
         uint4 v[4];
-        stage_load(0, v);
-        stage_store(0, v);
+        int32_t sv;
+        stage_load(0, v, sv);
+        stage_store(0, v, sv);
     }
     __syncthreads();
 
-    i32x16 k256;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) k256[r] = 256;
+    // the accumulator start values of a 32-train step, in the C/D register order: rows 8 g + 4 h + (0..3), g = 0..3
+    auto load_start = [&](int buf, int sub) {
+        const i32x4 *sp = reinterpret_cast<const i32x4 *>(&lds_start[buf][sub * 32 + 4 * h]);
+        const i32x4 g0 = sp[0], g1 = sp[2], g2 = sp[4], g3 = sp[6];
+        return i32x16{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+    };
     // One 32-train step: 16 MFMAs into (c0, c1), with the top-2 fold of the PREVIOUS step's results (p0, p1) issued
     // in their shadow -- two inserts (6 VALU) behind each MFMA -- so the matrix pipe and the VALU run concurrently.
-    auto step = [&](const unsigned char *arow, i32x16 &c0, i32x16 &c1, const i32x16 &p0, const i32x16 &p1, uint32_t pL0) {
+    // pK = 2^21 - 1 - (16 * step number of p): key = acc << 21 + (pK - r)
+    auto step = [&](const unsigned char *arow, const i32x16 &c_init, i32x16 &c0, i32x16 &c1, const i32x16 &p0, const i32x16 &p1, uint32_t pK) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + c * 32);
-            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], c == 0 ? k256 : c0, 0, 0, 0);
-            key_insert(m1[0][(2 * c) & 3], m2[0][(2 * c) & 3], ((uint32_t)p0[2 * c] << 21) | (pL0 + 2 * c));
-            key_insert(m1[0][(2 * c + 1) & 3], m2[0][(2 * c + 1) & 3], ((uint32_t)p0[2 * c + 1] << 21) | (pL0 + 2 * c + 1));
-            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], c == 0 ? k256 : c1, 0, 0, 0);
-            key_insert(m1[1][(2 * c) & 3], m2[1][(2 * c) & 3], ((uint32_t)p1[2 * c] << 21) | (pL0 + 2 * c));
-            key_insert(m1[1][(2 * c + 1) & 3], m2[1][(2 * c + 1) & 3], ((uint32_t)p1[2 * c + 1] << 21) | (pL0 + 2 * c + 1));
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], c == 0 ? c_init : c0, 0, 0, 0);
+            key_insert_max(m1[0][(2 * c) & 3], m2[0][(2 * c) & 3], ((uint32_t)p0[2 * c] << 21) + (pK - 2 * c));
+            key_insert_max(m1[0][(2 * c + 1) & 3], m2[0][(2 * c + 1) & 3], ((uint32_t)p0[2 * c + 1] << 21) + (pK - 2 * c - 1));
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], c == 0 ? c_init : c1, 0, 0, 0);
+            key_insert_max(m1[1][(2 * c) & 3], m2[1][(2 * c) & 3], ((uint32_t)p1[2 * c] << 21) + (pK - 2 * c));
+            key_insert_max(m1[1][(2 * c + 1) & 3], m2[1][(2 * c + 1) & 3], ((uint32_t)p1[2 * c + 1] << 21) + (pK - 2 * c - 1));
         }
     };
-    // 2047 << 21 sorts behind every real key (2 ham <= 512): the first step folds these harmless placeholders
+    // start-up placeholders: acc 0 with pK = 15 gives keys 0..15, below every real key (real L < 2^21 - 16)
     i32x16 pa0, pa1, pb0, pb1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { pb0[r] = 2047; pb1[r] = 2047; }
-    uint32_t pbL = 0;
+    for (int r = 0; r < 16; ++r) { pb0[r] = 0; pb1[r] = 0; }
+    uint32_t pbK = 15u;
     for (int tile = 0; tile < n_full; ++tile) {
         const int buf = tile & 1;
         uint4 nxt[4];
+        int32_t nxt_start = 0;
         const bool more = tile + 1 < n_tiles;
-        if (more) stage_load(tile + 1, nxt);
+        if (more) stage_load(tile + 1, nxt, nxt_start);
         const unsigned char *arow = &lds[buf][j * kHmStride + h * 16];
-        step(arow, pa0, pa1, pb0, pb1, pbL);                                   // sub 0, folding the previous tile's sub 1
-        step(arow + 32 * kHmStride, pb0, pb1, pa0, pa1, (uint32_t)(tile * 2) * 16u);   // sub 1, folding sub 0
-        pbL = (uint32_t)(tile * 2 + 1) * 16u;
-        if (more) stage_store(buf ^ 1, nxt);
+        step(arow, load_start(buf, 0), pa0, pa1, pb0, pb1, pbK);                                        // sub 0, folding the previous tile's sub 1
+        step(arow + 32 * kHmStride, load_start(buf, 1), pb0, pb1, pa0, pa1, kHmLMask - (uint32_t)(tile * 2) * 16u);   // sub 1, folding sub 0
+        pbK = kHmLMask - (uint32_t)(tile * 2 + 1) * 16u;
+        if (more) stage_store(buf ^ 1, nxt, nxt_start);
         __syncthreads();
     }
     // drain the pipeline
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        key_insert(m1[0][r & 3], m2[0][r & 3], ((uint32_t)pb0[r] << 21) | (pbL + r));
-        key_insert(m1[1][r & 3], m2[1][r & 3], ((uint32_t)pb1[r] << 21) | (pbL + r));
+        key_insert_max(m1[0][r & 3], m2[0][r & 3], ((uint32_t)pb0[r] << 21) + (pbK - r));
+        key_insert_max(m1[1][r & 3], m2[1][r & 3], ((uint32_t)pb1[r] << 21) + (pbK - r));
     }
     // the partial tile at the end of the set, rows past it masked out
     if (n_full < n_tiles) {
         const int tile = n_full, buf = tile & 1;
 #pragma unroll 1
         for (int sub = 0; sub < 2; ++sub) {
-            i32x16 acc0 = k256, acc1 = k256;
+            const i32x16 c_init = load_start(buf, sub);
+            i32x16 acc0 = c_init, acc1 = c_init;
             const unsigned char *arow = &lds[buf][(sub * 32 + j) * kHmStride + h * 16];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -625,41 +652,41 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], acc1, 0, 0, 0);
             }
-            const uint32_t L0 = (uint32_t)(tile * 2 + sub) * 16u;
+            const uint32_t K0 = kHmLMask - (uint32_t)(tile * 2 + sub) * 16u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int idx = (tile * 2 + sub) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const bool ok = idx < nt;   // zero-filled rows past the end of the set
-                key_insert(m1[0][r & 3], m2[0][r & 3], ok ? (((uint32_t)acc0[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
-                key_insert(m1[1][r & 3], m2[1][r & 3], ok ? (((uint32_t)acc1[r] << 21) | (L0 + r)) : 0xFFFFFFFFu);
+                key_insert_max(m1[0][r & 3], m2[0][r & 3], ok ? (((uint32_t)acc0[r] << 21) + (K0 - r)) : 0u);
+                key_insert_max(m1[1][r & 3], m2[1][r & 3], ok ? (((uint32_t)acc1[r] << 21) + (K0 - r)) : 0u);
             }
         }
     }
-    // merge the slots, rebuild full keys (2ham << 21 | train index = ham << 22 | index), then merge the lane halves
+    // merge the slots, rebuild full keys (acc << 21 | 2^21 - 1 - train index), then merge the lane halves
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+        uint32_t b1 = 0u, b2 = 0u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { key_insert(b1, b2, m1[s][r]); key_insert(b1, b2, m2[s][r]); }
+        for (int r = 0; r < 4; ++r) { key_insert_max(b1, b2, m1[s][r]); key_insert_max(b1, b2, m2[s][r]); }
         auto full_key = [&](uint32_t k) {
-            const uint32_t L = k & 0x1FFFFFu, r = L & 15u;
+            const uint32_t L = kHmLMask - (k & kHmLMask), r = L & 15u;
             const uint32_t idx = (L >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
-            return k == 0xFFFFFFFFu ? k : ((k & 0xFFE00000u) | idx);
+            return k < 16u ? 0u : ((k & ~kHmLMask) | (kHmLMask - idx));
         };
-        // the pipeline's start-up placeholders (2 ham = 2047) lose to every real key; with fewer than two trains they
-        // can surface and are discarded by the nt gates below
+        // the pipeline's start-up placeholders and the masked rows (keys below 16) lose to every real key; with fewer
+        // than two trains they can surface and are discarded by the nt gates below
         b1 = full_key(b1); b2 = full_key(b2);
         const uint32_t o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
-        key_insert(b1, b2, o1);
-        key_insert(b1, b2, o2);
+        key_insert_max(b1, b2, o1);
+        key_insert_max(b1, b2, o2);
         const int qrow = qbase + 32 * s + j;
         if (h == 0 && qrow < nq) {
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
             const bool h0 = nt >= 1, h1 = nt >= 2;
-            knn_idx[o] = h0 ? (int)(b1 & 0x3FFFFFu) : -1;
-            knn_idx[o + 1] = h1 ? (int)(b2 & 0x3FFFFFu) : -1;
-            knn_dist[o] = h0 ? (float)(b1 >> 22) : FLT_MAX;
-            knn_dist[o + 1] = h1 ? (float)(b2 >> 22) : FLT_MAX;
+            knn_idx[o] = h0 ? (int)(kHmLMask - (b1 & kHmLMask)) : -1;
+            knn_idx[o + 1] = h1 ? (int)(kHmLMask - (b2 & kHmLMask)) : -1;
+            knn_dist[o] = h0 ? (float)(256 + qpop[s] - (int)(b1 >> 21)) : FLT_MAX;
+            knn_dist[o + 1] = h1 ? (float)(256 + qpop[s] - (int)(b2 >> 21)) : FLT_MAX;
         }
     }
 }
@@ -762,7 +789,11 @@ int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairD
 
 bool hamming_supported(int nbytes) { return nbytes == 16 || nbytes == 32 || nbytes == 64; }
 
-size_t hamming_expanded_bytes(int nbytes, long long total_rows) { return nbytes == 32 ? (size_t)256 * (size_t)std::max(total_rows, 1LL) : 0; }
+// queries per workgroup of the kernel that serves this descriptor width (the pair plan's block count depends on it)
+int hamming_query_block(int nbytes) { return 256; }
+
+// the 0/1 byte image of every descriptor followed by one start value (256 - popcount) per row
+size_t hamming_expanded_bytes(int nbytes, long long total_rows) { return nbytes == 32 ? (size_t)(256 + 4) * (size_t)std::max(total_rows, 1LL) : 0; }
 
 int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist)
@@ -771,10 +802,11 @@ int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long t
     const uint32_t *d = reinterpret_cast<const uint32_t *>(desc);
     if (nbytes == 32 && exp_scratch) {
         const long long n_words = total_rows * 8;
+        int32_t *start = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(exp_scratch) + (size_t)256 * (size_t)std::max(total_rows, 1LL));
         hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d, n_words,
-                           reinterpret_cast<uint32_t *>(exp_scratch));
+                           reinterpret_cast<uint32_t *>(exp_scratch), start);
         hipLaunchKernelGGL(hamming_knn_mfma_kernel, dim3(n_blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(exp_scratch),
-                           pairs, n_pairs, knn_idx, knn_dist);
+                           start, pairs, n_pairs, knn_idx, knn_dist);
     } else if (nbytes == 32)
         hipLaunchKernelGGL(hamming_knn_kernel<8>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);
     else if (nbytes == 64)

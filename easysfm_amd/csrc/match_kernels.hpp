@@ -23,6 +23,7 @@ int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairD
                          const int32_t *flagged, const int32_t *counters, long long total_queries, int grid,
                          int32_t *knn_idx, float *knn_dist);
 bool hamming_supported(int nbytes);
+int hamming_query_block(int nbytes);
 // 256-bit descriptors take the i8-MFMA path, which needs hamming_expanded_bytes(total_rows) of scratch (exp_scratch);
 // other widths run the XOR/popcount kernel and ignore it.
 size_t hamming_expanded_bytes(int nbytes, long long total_rows);
