@@ -1,0 +1,73 @@
+// cv::undistort (initUndistortRectifyMap in CV_16SC2 form + remap INTER_LINEAR / BORDER_CONSTANT) fused into one pass over
+// the destination image: reference cpp_code/src/estimate_motion.cpp:431-441 (MotionEstimator::doUnDistort).
+// One thread per destination pixel.  The distortion model runs in double with OpenCV's operation order (the library is built
+// with -ffp-contract=off; f64 division and sqrt are IEEE on gfx950), the source position is rounded to 1/32 pixel exactly as
+// the 16SC2 maps do, and the bilinear blend uses the 15-bit integer weights of OpenCV's table, so the result is bit-exact
+// against the CPU restatement.  The kernel is HBM-bound byte work: 3 B written and about 3 B read per pixel (the four taps
+// of neighbouring pixels share cache lines); a wave writes 192 contiguous bytes.
+#include "undistort_kernels.hpp"
+
+namespace esfm {
+
+namespace {
+
+__device__ __forceinline__ int round_sat(double v)
+{
+    // cvRound on x86 (cvtsd2si): round half to even, "integer indefinite" outside the int range and for NaN
+    if (!(v < 2147483647.5 && v >= -2147483648.5)) return (int)0x80000000;
+    return (int)__double2ll_rn(v);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void undistort_remap_kernel(UndistortParams P, const uint8_t *__restrict__ src, const double *__restrict__ xseq,
+                                                              const double *__restrict__ yrow, const double *__restrict__ wrow,
+                                                              uint8_t *__restrict__ dst)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= P.cols) return;
+    const double w = 1. / wrow[i], x = xseq[j] * w, y = yrow[i] * w;
+    const double x2 = x * x, y2 = y * y;
+    const double r2 = x2 + y2, _2xy = 2 * x * y;
+    const double kr = (1 + ((0 * r2 + P.k2) * r2 + P.k1) * r2) / (1 + ((0 * r2 + 0) * r2 + 0) * r2);
+    const double xd = (x * kr + P.p1 * _2xy + P.p2 * (r2 + 2 * x2) + 0 * r2 + 0 * r2 * r2);
+    const double yd = (y * kr + P.p1 * (r2 + 2 * y2) + P.p2 * _2xy + 0 * r2 + 0 * r2 * r2);
+    const double u = P.fx * 1. * xd + P.u0;
+    const double v = P.fy * 1. * yd + P.v0;
+    const int iu = round_sat(u * 32), iv = round_sat(v * 32);
+    const int sx = (short)(iu >> 5), sy = (short)(iv >> 5);       // the maps hold shorts
+    const int ax = iu & 31, ay = iv & 31;
+    uint8_t *D = dst + ((size_t)i * P.cols + j) * CH;
+    if (sx >= P.cols || sx + 1 < 0 || sy >= P.rows || sy + 1 < 0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) D[c] = 0;
+        return;
+    }
+    const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+    const bool x0 = sx >= 0, x1 = sx + 1 < P.cols, y0 = sy >= 0, y1 = sy + 1 < P.rows;
+    const uint8_t *S0 = src + ((ptrdiff_t)sy * P.cols + sx) * CH;
+    const uint8_t *S1 = S0 + (size_t)P.cols * CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int v00 = (x0 && y0) ? S0[c] : 0, v01 = (x1 && y0) ? S0[CH + c] : 0;
+        const int v10 = (x0 && y1) ? S1[c] : 0, v11 = (x1 && y1) ? S1[CH + c] : 0;
+        const int s = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        D[c] = (uint8_t)((s + (1 << 14)) >> 15);      // the weights sum to 32768: always within 0..255
+    }
+}
+
+}  // namespace
+
+int launch_undistort(hipStream_t st, const UndistortParams &P, const uint8_t *src, const double *xseq, const double *yrow,
+                     const double *wrow, uint8_t *dst)
+{
+    if (P.rows <= 0 || P.cols <= 0) return ESFM_OK;
+    const dim3 grid((unsigned)((P.cols + 255) / 256), (unsigned)P.rows);
+    if (P.channels == 3)
+        hipLaunchKernelGGL(undistort_remap_kernel<3>, grid, dim3(256), 0, st, P, src, xseq, yrow, wrow, dst);
+    else
+        hipLaunchKernelGGL(undistort_remap_kernel<1>, grid, dim3(256), 0, st, P, src, xseq, yrow, wrow, dst);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+}  // namespace esfm
