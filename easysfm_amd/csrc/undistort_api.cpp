@@ -60,8 +60,10 @@ int esfm_undistort(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int 
         ESFM_REQUIRE(ir[1] == 0 && ir[3] == 0 && ir[6] == 0 && ir[7] == 0, "camera matrix is not finite");
         const int sr = std::min(stripe0, rows - y0);
         for (int i = 0; i < sr; ++i) {
-            yrow[y0 + i] = i * ir[4] + ir[5];
-            wrow[y0 + i] = i * ir[7] + ir[8];
+            const double _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+            const double w = 1. / _w;
+            wrow[y0 + i] = w;
+            yrow[y0 + i] = _y * w;
         }
         if (y0 == 0) {
             double _x = 0 * ir[1] + ir[2];

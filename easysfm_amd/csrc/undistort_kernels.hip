@@ -25,10 +25,13 @@ __global__ __launch_bounds__(256) void undistort_remap_kernel(UndistortParams P,
 {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= P.cols) return;
-    const double w = 1. / wrow[i], x = xseq[j] * w, y = yrow[i] * w;
+    // w = 1 / _w and y = _y * w depend on the row only and come from the host (IEEE division there and here give the same
+    // bits).  OpenCV divides the radial numerator by 1 + ((k6 r2 + k5) r2 + k4) r2, which is exactly 1 for a 4-coefficient
+    // model and finite r2 (and NaN together with the numerator otherwise), so the division is dropped.
+    const double w = wrow[i], x = xseq[j] * w, y = yrow[i];
     const double x2 = x * x, y2 = y * y;
     const double r2 = x2 + y2, _2xy = 2 * x * y;
-    const double kr = (1 + ((0 * r2 + P.k2) * r2 + P.k1) * r2) / (1 + ((0 * r2 + 0) * r2 + 0) * r2);
+    const double kr = 1 + ((0 * r2 + P.k2) * r2 + P.k1) * r2;
     const double xd = (x * kr + P.p1 * _2xy + P.p2 * (r2 + 2 * x2) + 0 * r2 + 0 * r2 * r2);
     const double yd = (y * kr + P.p1 * (r2 + 2 * y2) + P.p2 * _2xy + 0 * r2 + 0 * r2 * r2);
     const double u = P.fx * 1. * xd + P.u0;

@@ -59,9 +59,19 @@ template <int R, int C> struct Matf {  // Eigen::Matrix<float,R,C>, (r,c) access
 using Matrix3f = Matf<3, 3>;
 using Matrix4f = Matf<4, 4>;
 
+struct ImageMat {  // cv::Mat, CV_8UC1 / CV_8UC3 (BGR, interleaved), row-major and continuous
+    int rows = 0, cols = 0, channels = 3;
+    std::vector<uint8_t> data;
+    bool empty() const { return data.empty(); }
+};
+struct DistortMat {  // the 1 x 4 CV_64FC1 matrix sfm.cpp:78 creates: zeros
+    double v[4] = {0, 0, 0, 0};
+};
+
 struct frame_t {  // utility.h:21-55
     unsigned int frame_id = 0;
     std::string image_file_path;
+    ImageMat rgb_image;
     std::vector<KeyPoint> keypoints;
     DescMat descriptors;
     std::vector<int> unique_pixel_ids;
@@ -243,6 +253,26 @@ public:
         std::cout << "Output [ " << n << " ] points." << std::endl << "Output ply file done." << std::endl;
         return bool(fs);
     }
+
+    // DataIO::importDistort (data_io.cpp:97-125): up to three groups of k1 k2 p1 p2 are extracted as floats, then stored with
+    // at<float>(0, i) into the CV_64FC1 matrix -- i.e. into its first 16 bytes.  Reproduced: cv::undistort
+    // sees v[0] = the double made of the bits of (k1, k2), v[1] = that of (p1, p2), v[2] = v[3] = 0.
+    bool importDistort(const std::string &fileName, DistortMat &distort_coeff)
+    {
+        std::ifstream in(fileName, std::ios::in);
+        if (!in) return false;
+        int i = 0;
+        float k[4] = {0.f, 0.f, 0.f, 0.f};
+        while (!in.eof() && i < 3) {       // the reference's loop spins forever on a fourth group; three are read at most
+            in >> k[0] >> k[1] >> k[2] >> k[3];
+            if (in.fail()) break;
+            ++i;
+        }
+        in.close();
+        std::memcpy(distort_coeff.v, k, sizeof(k));
+        std::cout << "Import camera distortion coefficients file done." << std::endl;
+        return true;
+    }
 };
 
 inline void angle_axis_to_rotation(const double aa[3], double R[9]);
@@ -373,6 +403,22 @@ public:
         const double inlier_ratio = 1.0 * n_inl / count;
         if (!quiet) std::cout << "Inlier count: " << n_inl << std::endl << "Mean reprojection error: " << reproj_err << std::endl;
         return !(reproj_err > 10 && inlier_ratio < 0.5);
+    }
+
+    // estimate_motion.cpp:431-441: cv::undistort(cur_frame.rgb_image, undistorted_img, K_cam, distort_coeff)
+    bool doUnDistort(frame_t &cur_frame, const DistortMat &distort_coeff)
+    {
+        ImageMat &img = cur_frame.rgb_image;
+        if (img.empty()) { std::cerr << "frame has no image" << std::endl; return false; }
+        const double K4[4] = {cur_frame.K_cam(0, 0), cur_frame.K_cam(0, 2), cur_frame.K_cam(1, 1), cur_frame.K_cam(1, 2)};
+        std::vector<uint8_t> undistorted_img(img.data.size());
+        if (esfm_undistort(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, K4, distort_coeff.v, undistorted_img.data()) != ESFM_OK) {
+            std::cerr << esfm_last_error() << std::endl;
+            return false;
+        }
+        img.data.swap(undistorted_img);
+        if (!quiet) std::cout << "Undistort the image done." << std::endl;
+        return true;
     }
 
     // estimate_motion.cpp:476-505

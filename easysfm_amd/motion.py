@@ -179,6 +179,15 @@ class MotionEstimator:
         print(f"Find [{int(mask.sum())}] inlier matches from [{len(matches)}] total matches.")
         return T
 
+    def doUnDistort(self, cur_frame: Frame, distort_coeff) -> bool:
+        """estimate_motion.cpp:431-441: cur_frame.rgb_image = cv::undistort(rgb_image, K_cam, distort_coeff)."""
+        from .features import undistort
+        if cur_frame.rgb_image is None:
+            raise ValueError("frame has no image")
+        cur_frame.rgb_image = undistort(cur_frame.rgb_image, np.asarray(cur_frame.K_cam, np.float32), distort_coeff, self._ctx)
+        print("Undistort the image done.")
+        return True
+
     def estimate2D3D_P3P_RANSAC(self, cur_frame: Frame, cur_map_3d: SparsePointCloud, ransac_thre: float = 2.5,
                                 iterationsCount: int = 50000, ransac_prob: float = 0.99, show: bool = False) -> bool:
         """estimate_motion.cpp:99-232: 2-D/3-D correspondences by track id (every (keypoint, cloud point) pair with equal

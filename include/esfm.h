@@ -86,7 +86,8 @@ typedef enum esfm_kernel_id {
     ESFM_K_RANSAC = 8,        /* essential_solve_kernel + essential_score_kernel (one chunk)    */
     ESFM_K_SURF_DET = 9,      /* surf_det_trace_kernel                                          */
     ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
-    ESFM_K_COUNT = 11
+    ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
+    ESFM_K_COUNT = 12
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -428,6 +429,20 @@ int esfm_ransac_sample_stream(int count, int n_samples, int32_t *idx /*5 per sam
  * area shrink to 21 x 21, Gaussian-weighted 2 x 2 gradients, 4 x 4 cells) follow OpenCV's surf.cpp operation by operation. */
 int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int channels, double hessian_threshold,
                                  int max_keypoints, float *keypoints /*7 per*/, float *descriptors /*64 per*/, int32_t *n_keypoints);
+
+/* ---- Image undistortion (undistort part) -------------------------------
+ * MotionEstimator::doUnDistort (cpp_code/src/estimate_motion.cpp:431-441): cv::undistort(rgb_image, out, K, distort_coeff), run
+ * once per imported frame before feature detection (cpp_code/test/sfm.cpp:97-98).  image / out: rows x cols x channels uint8
+ * (1 or 3 interleaved channels), distinct buffers; K4 = fx, cx, fy, cy (no skew; it is also the new camera matrix); dist4 =
+ * k1, k2, p1, p2 as DOUBLES -- the values cv::undistort actually sees.  (The reference fills its CV_64F coefficient matrix
+ * through at<float>, cpp_code/src/data_io.cpp:118-121, so a distortion file reaches OpenCV as two doubles whose bit patterns
+ * are the float pairs (k1, k2) and (p1, p2); the host mirrors reproduce that, this entry point takes whatever doubles result.)
+ * Follows OpenCV's algorithm operation by operation: stripes of min(max(1, 4096 / cols), rows) rows with their own new camera
+ * matrix (cy - y0) and closed-form 3 x 3 inverse, the normalised x accumulated along the row, the distortion model in double,
+ * source coordinates rounded to 1/32 pixel (CV_16SC2 maps), 8-bit bilinear taps with 15-bit fixed-point weights, zero outside
+ * the image (INTER_LINEAR, BORDER_CONSTANT). */
+int esfm_undistort(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int channels, const double *K4, const double *dist4,
+                   uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
                                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.esfm_ref_bgr2gray.restype = None
     lib.esfm_ref_bgr2gray.argtypes = [_u8p, C.c_int, _u8p]
+    lib.esfm_ref_undistort.restype = C.c_int
+    lib.esfm_ref_undistort.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _u8p]
     lib.esfm_ref_surf.restype = C.c_int
     lib.esfm_ref_surf.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, C.c_int, _f32p, _f32p]
     _LIB, _LIB_PATH = lib, path
@@ -441,3 +443,17 @@ def surf(gray, hessian_threshold: float = 100.0, max_kp: int = 200000):
     kp = np.zeros((max_kp, 7), np.float32); desc = np.zeros((max_kp, 64), np.float32)
     n = load().esfm_ref_surf(g.reshape(-1), g.shape[0], g.shape[1], float(hessian_threshold), int(max_kp), kp.reshape(-1), desc.reshape(-1))
     return kp[:n].copy(), desc[:n].copy()
+
+
+def undistort(image, K4, dist4):
+    """cv::undistort(image, out, K, dist) as MotionEstimator::doUnDistort calls it (estimate_motion.cpp:431-441).
+    image: [rows, cols] or [rows, cols, 3] uint8; K4 = fx, cx, fy, cy; dist4 = k1, k2, p1, p2 (doubles)."""
+    img = np.ascontiguousarray(image, np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    k = np.ascontiguousarray(K4, np.float64).reshape(4)
+    d = np.ascontiguousarray(dist4, np.float64).reshape(4)
+    rc = load().esfm_ref_undistort(img.reshape(-1), img.shape[0], img.shape[1], ch, k, d, out.reshape(-1))
+    if rc != 0:
+        raise MemoryError("esfm_ref_undistort")
+    return out

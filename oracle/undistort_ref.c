@@ -38,8 +38,9 @@ static void invert3(const double *S, double *t)
 
 static int sat_int(double v)
 {
-    if (!(v > -2147483648.0)) return INT32_MIN;   /* also NaN, as cvRound's cvtsd2si does */
-    if (!(v < 2147483647.0)) return v != v ? INT32_MIN : INT32_MAX;
+    /* saturate_cast<int>(double) = cvRound = cvtsd2si on x86: round half to even; NaN and anything that rounds outside the
+     * int range give the "integer indefinite" value 0x80000000 */
+    if (!(v < 2147483647.5 && v >= -2147483648.5)) return INT32_MIN;
     return (int)lrint(v);
 }
 

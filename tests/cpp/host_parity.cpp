@@ -16,6 +16,7 @@ int esfm_ref_find_essential_ransac(const float *, const float *, int, const floa
 int esfm_ref_recover_pose(const double *, const float *, const float *, int, const float *, double *, double *, uint8_t *);
 int esfm_ref_solve_pnp_ransac(const float *, const float *, int, const float *, int, double, double, double *, double *, double *, uint8_t *, int32_t *, int32_t *);
 int esfm_ref_sor_filter(const float *, int, int, int, double, float *, uint8_t *, double *);
+int esfm_ref_undistort(const uint8_t *, int, int, int, const double *, const double *, uint8_t *);
 int esfm_ref_ba_solve_ex(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *, double *, double,
                          int, double, const esfm_ba_options *, esfm_ba_summary *);
 int esfm_ref_ba_solve(int, int, int, const int32_t *, const int32_t *, const float *, const float *, double *, double *,
@@ -288,6 +289,35 @@ int main()
         CHECK(ee.outlierFilter(cloud));
         CHECK(cloud.points.size() < before && cloud.points.size() == cloud.unique_point_ids.size());
         std::printf("MotionEstimator: %d/%d RANSAC inliers (exact vs oracle), depth %.2f, %zu points triangulated, PnP pose vs oracle < 1e-5\n", cnt, N, depth, before);
+    }
+    // ---- DataIO::importDistort + MotionEstimator::doUnDistort ---------------------------------------
+    {
+        const char *path = "/tmp/esfm_host_parity_distort.txt";
+        { std::ofstream f(path); f << "-0.2 1.5 0.001 0.002\n"; }
+        DataIO io;
+        DistortMat dc;
+        CHECK(io.importDistort(path, dc));
+        const float kf[4] = {-0.2f, 1.5f, 0.001f, 0.002f};
+        double expect[4] = {0, 0, 0, 0};
+        std::memcpy(expect, kf, sizeof(kf));                       // floats stored into the CV_64F buffer
+        CHECK(std::memcmp(dc.v, expect, sizeof(expect)) == 0 && dc.v[2] == 0 && dc.v[3] == 0 && dc.v[0] > 0.1);
+        DistortMat none;
+        CHECK(!io.importDistort("/tmp/esfm_no_such_file", none) && none.v[0] == 0);
+        frame_t fr(0, "img");
+        fr.K_cam(0, 0) = 150.25f; fr.K_cam(0, 2) = 80.5f; fr.K_cam(1, 1) = 149.75f; fr.K_cam(1, 2) = 60.25f;
+        fr.rgb_image.rows = 120; fr.rgb_image.cols = 160; fr.rgb_image.channels = 3;
+        fr.rgb_image.data.resize(size_t(120) * 160 * 3);
+        for (auto &b : fr.rgb_image.data) b = uint8_t(rng());
+        const std::vector<uint8_t> src = fr.rgb_image.data;
+        MotionEstimator ee; ee.quiet = true;
+        CHECK(ee.doUnDistort(fr, dc));
+        std::vector<uint8_t> ref(src.size());
+        const double K4[4] = {150.25, 80.5, 149.75, 60.25};
+        CHECK(esfm_ref_undistort(src.data(), 120, 160, 3, K4, dc.v, ref.data()) == 0);
+        CHECK(fr.rgb_image.data == ref && fr.rgb_image.data != src);
+        frame_t same(1, "img2"); same.K_cam = fr.K_cam; same.rgb_image = fr.rgb_image; same.rgb_image.data = src;
+        CHECK(ee.doUnDistort(same, none) && same.rgb_image.data == src);     // zero coefficients: identity
+        std::printf("doUnDistort: bit-exact vs oracle with the imported (scrambled) coefficients, identity with zeros\n");
     }
     std::printf("HOST PARITY OK\n");
     return 0;

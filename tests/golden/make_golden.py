@@ -611,6 +611,78 @@ def make_ransac():
     np.savez_compressed(os.path.join(HERE, "ransac_cases.npz"), **out)
 
 
+def undistort_numpy(img, K4, dist):
+    """cv::undistort (estimate_motion.cpp:436) restated with whole-array numpy operations, independently of oracle/undistort_ref.c:
+    per stripe the inverse of the shifted camera matrix by cofactors, x numerators by a running sum along the row, the k1 k2 p1
+    p2 model in float64, positions rounded (half to even) to 1/32 pixel, integer bilinear weights, zero border."""
+    img = np.asarray(img, np.uint8)
+    rows, cols = img.shape[:2]
+    src = img.reshape(rows, cols, -1).astype(np.int64)
+    fx, u0, fy, v0 = [float(v) for v in K4]
+    k1, k2, p1, p2 = [float(v) for v in dist]
+    stripe0 = min(max(1, 4096 // cols), rows)
+    out = np.zeros_like(src)
+    padded = np.zeros((rows + 2, cols + 2, src.shape[2]), np.int64)      # zero border, index shifted by one
+    padded[1:-1, 1:-1] = src
+    for y0 in range(0, rows, stripe0):
+        sr = min(stripe0, rows - y0)
+        S = np.array([[fx, 0.0, u0], [0.0, fy, v0 - y0], [0.0, 0.0, 1.0]])
+        det = S[0, 0] * (S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) - S[0, 1] * (S[1, 0] * S[2, 2] - S[1, 2] * S[2, 0]) \
+            + S[0, 2] * (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0])
+        d = 1.0 / det
+        cof = lambda a, b, c, e: (S[a] * S[b] - S[c] * S[e]) * d
+        ir = np.array([cof((1, 1), (2, 2), (1, 2), (2, 1)), cof((0, 2), (2, 1), (0, 1), (2, 2)), cof((0, 1), (1, 2), (0, 2), (1, 1)),
+                       cof((1, 2), (2, 0), (1, 0), (2, 2)), cof((0, 0), (2, 2), (0, 2), (2, 0)), cof((0, 2), (1, 0), (0, 0), (1, 2)),
+                       cof((1, 0), (2, 1), (1, 1), (2, 0)), cof((0, 1), (2, 0), (0, 0), (2, 1)), cof((0, 0), (1, 1), (0, 1), (1, 0))])
+        i = np.arange(sr, dtype=np.float64)[:, None]
+        run = lambda first, inc: np.cumsum(np.concatenate([first, np.broadcast_to(inc, (sr, cols - 1))], axis=1), axis=1)
+        X = run(i * ir[1] + ir[2], ir[0]); Y = run(i * ir[4] + ir[5], ir[3]); W = run(i * ir[7] + ir[8], ir[6])
+        w = 1.0 / W; x = X * w; y = Y * w
+        x2 = x * x; y2 = y * y; r2 = x2 + y2; xy2 = 2 * x * y
+        kr = (1 + (k2 * r2 + k1) * r2) / 1.0
+        xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2)
+        yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2
+        iu = np.rint((fx * xd + u0) * 32).astype(np.int64); iv = np.rint((fy * yd + v0) * 32).astype(np.int64)
+        sx = iu >> 5; sy = iv >> 5; ax = iu & 31; ay = iv & 31
+        outside = (sx >= cols) | (sx + 1 < 0) | (sy >= rows) | (sy + 1 < 0)
+        cx = np.clip(sx, -1, cols - 1) + 1; cy = np.clip(sy, -1, rows - 1) + 1      # into the padded image
+        acc = np.zeros((sr, cols, src.shape[2]), np.int64)
+        for dy, dx, wgt in ((0, 0, (32 - ax) * (32 - ay)), (0, 1, ax * (32 - ay)), (1, 0, (32 - ax) * ay), (1, 1, ax * ay)):
+            acc += padded[cy + dy, cx + dx] * (wgt * 32)[..., None]
+        res = (acc + 16384) >> 15
+        res[outside] = 0
+        out[y0:y0 + sr] = res
+    return out.reshape(img.shape).astype(np.uint8)
+
+
+def make_undistort():
+    """Golden undistortion cases: a colour and a gray image, mild and strong coefficients, a wide image (one-row stripes) and
+    the coefficients the reference's importDistort quirk produces from a typical file (float pairs read as doubles)."""
+    rng = np.random.default_rng(np.random.PCG64(97))
+    out = {}
+    yy, xx = np.mgrid[0:96, 0:160]
+    smooth = (127 + 80 * np.sin(xx / 7.0) * np.cos(yy / 5.0)).astype(np.uint8)
+    color = np.stack([smooth, np.roll(smooth, 5, 1), 255 - smooth], axis=2) ^ rng.integers(0, 8, (96, 160, 3), dtype=np.uint8)
+    wide = rng.integers(0, 256, (6, 4500), dtype=np.uint8)
+    quirk = np.zeros(4, np.float64)
+    quirk.view(np.float32)[:4] = np.array([-0.28, 1.35, 0.0007, -0.0004], np.float32)     # k1 k2 p1 p2 written through at<float>
+    cases = [
+        ("color_mild", color, [140.0, 79.4, 138.0, 47.6], [-0.12, 0.03, 0.001, -0.0005]),
+        ("color_strong", color, [90.0, 81.0, 92.0, 50.0], [0.45, -0.2, 0.01, 0.02]),
+        ("gray_barrel", smooth, [120.0, 80.0, 120.0, 48.0], [-0.35, 0.12, 0.0, 0.0]),
+        ("gray_zero", smooth, [131.7, 77.77, 129.3, 45.21], [0.0, 0.0, 0.0, 0.0]),
+        ("wide_rows", wide, [2200.0, 2250.5, 2200.0, 2.5], [-0.08, 0.01, 0.0, 0.0]),
+        ("quirk_coeffs", color, [140.0, 79.4, 138.0, 47.6], quirk),
+    ]
+    for name, img, K4, dist in cases:
+        out[name + "_image"] = img
+        out[name + "_K4"] = np.asarray(K4, np.float64)
+        out[name + "_dist"] = np.asarray(dist, np.float64)
+        out[name + "_out"] = undistort_numpy(img, K4, dist)
+    out["names"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "undistort_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     make_hamming()
     make_l2()
@@ -620,4 +692,5 @@ if __name__ == "__main__":
     make_sor()
     make_triangulation()
     make_ransac()
+    make_undistort()
     print("golden vectors written to", HERE)

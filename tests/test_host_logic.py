@@ -228,3 +228,22 @@ def test_bin_sfm_command_line(tmp_path):
     assert mod.import_image_filenames(str(tmp_path / "list.txt"), "dir") == [os.path.join("dir", "0000.png"), os.path.join("dir", "0001.png")]
     K = mod.import_calib(str(tmp_path / "K.txt"))
     assert K.shape == (3, 3) and abs(K[0, 2] - 380.17) < 1e-4 and K[2, 2] == 1
+
+
+def test_import_distort_reproduces_the_float_into_double_storage(tmp_path):
+    """DataIO::importDistort (data_io.cpp:97-125) writes floats into a CV_64F matrix (SURVEY section 9.10): the doubles OpenCV
+    sees are the float pairs reinterpreted; a missing file leaves the default zeros to the caller."""
+    import struct
+    import easysfm_amd as E
+    p = tmp_path / "dist.txt"
+    p.write_text("-0.28 1.35 0.0007 -0.0004\n")
+    c = E.import_distort(str(p))
+    assert c.dtype == np.float64 and c.shape == (4,)
+    k1p = struct.unpack("<d", struct.pack("<ff", np.float32(-0.28), np.float32(1.35)))[0]
+    k2p = struct.unpack("<d", struct.pack("<ff", np.float32(0.0007), np.float32(-0.0004)))[0]
+    assert c[0] == k1p and c[1] == k2p and c[2] == 0 and c[3] == 0
+    assert abs(c[0] - 0.05625) < 1e-6                      # k2 = 1.35 lands in the exponent: a visible k1'
+    p.write_text("1 2 3 4\n5 6")                          # a second, partial group overwrites k1 k2 only
+    c = E.import_distort(str(p))
+    assert np.array_equal(c.view(np.float32)[:4], np.array([5, 6, 3, 4], np.float32))
+    assert E.import_distort(str(tmp_path / "none")) is None

@@ -269,3 +269,13 @@ def test_epnp_and_pnp_ransac_known_answers(oracle_lib):
     assert ok and 0 < it < 5000 and mask.sum() >= 395 and mask[bad].sum() <= 5
     assert np.allclose(Rr, R, atol=2e-3) and np.allclose(tr, t, atol=0.02)
     assert np.allclose(rv, rotation_to_angle_axis(Rr), atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["color_mild", "color_strong", "gray_barrel", "gray_zero", "wide_rows", "quirk_coeffs"])
+def test_undistort_golden_bitexact(oracle_lib, tag):
+    """oracle/undistort_ref.c against the independent numpy restatement of cv::undistort (make_golden.undistort_numpy)."""
+    z = np.load(os.path.join(GOLD, "undistort_cases.npz"))
+    out = oracle_lib.undistort(z[tag + "_image"], z[tag + "_K4"], z[tag + "_dist"])
+    assert np.array_equal(out, z[tag + "_out"])
+    if tag == "gray_zero":
+        assert np.array_equal(out, z[tag + "_image"])          # zero coefficients: exact identity
