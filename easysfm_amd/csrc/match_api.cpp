@@ -10,7 +10,6 @@ using esfm::PairDesc;
 
 namespace {
 
-constexpr int kL2QueryBlock = 128;       // queries per workgroup in l2_knn_mfma_kernel
 
 struct PairPlan {
     std::vector<PairDesc> tab;
@@ -88,7 +87,15 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
             if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
-            {
+            if (esfm::l2_bf16_pass(width)) {
+                if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
+                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr)) return rc;
+                esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
+                if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, ctx->norms.as<float>(), dev_tab, n_pairs,
+                                                      plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
+                                                      ctx->counters.as<int32_t>(), (int)cap64))
+                    return rc;
+            } else {
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                 if (int rc = esfm::launch_l2_knn_mfma(st, width, desc, ctx->norms.as<float>(), dev_tab, n_pairs, plan.n_blocks, knn_idx,
                                                       knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))
@@ -153,7 +160,7 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
     const int32_t pr[2] = {1, 0};
     int64_t out_off[2];
     PairPlan plan;
-    if (int rc = make_plan(offs, 2, pr, 1, metric == ESFM_L2_F32 ? kL2QueryBlock : esfm::hamming_query_block(width), out_off, &plan)) return rc;
+    if (int rc = make_plan(offs, 2, pr, 1, metric == ESFM_L2_F32 ? esfm::l2_query_block(width) : esfm::hamming_query_block(width), out_off, &plan)) return rc;
     const PairDesc *dev_tab = nullptr;
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
     if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)nq)) return rc;
@@ -223,7 +230,7 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
     if (int rc = check_common(ctx, metric, width)) return rc;
     ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
     PairPlan plan;
-    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : esfm::hamming_query_block(width),
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? esfm::l2_query_block(width) : esfm::hamming_query_block(width),
                            out_offset, &plan))
         return rc;
     if (plan.total_queries == 0) return ESFM_OK;
@@ -240,7 +247,7 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
     if (int rc = check_common(ctx, metric, width)) return rc;
     ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
     PairPlan plan;
-    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? kL2QueryBlock : esfm::hamming_query_block(width),
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? esfm::l2_query_block(width) : esfm::hamming_query_block(width),
                            out_offset, &plan))
         return rc;
     if (n_pairs == 0) return ESFM_OK;

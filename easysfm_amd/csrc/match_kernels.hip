@@ -21,6 +21,8 @@
 #include "match_kernels.hpp"
 
 #include <float.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace esfm {
 
@@ -367,6 +369,349 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         if (!certified) {
             const int slot = atomicAdd(&counters[0], 1);
             if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 distance pass (64-float descriptors): the same kernel shape as l2_knn_mfma_kernel, with the f32 MFMA (157 TFLOP/s,
+// no VALU co-execution) replaced by three bf16 MFMAs (2.5 PFLOP/s, VALU runs beside them).  Every float a is split into
+// hi = bf16(a) and lo = bf16(a - hi) (round to nearest even; a = hi + lo + e, |e| <= 2^-18 |a|), and
+//   q.t ~ sum hi_q hi_t + hi_q lo_t + lo_q hi_t          (the dropped terms are <= 3.01 * 2^-18 sum |q_i t_i|)
+// is accumulated by v_mfma_f32_32x32x16_bf16 on top of |t|^2, with -2 folded into the query operand.  bf16 products are exact
+// in f32; the accumulation error and the split error go into the certificate's eps (2^-15 instead of 2^-16 of |q|^2 + max|t|^2,
+// DESIGN.md), so the exact re-rank and the rescan of uncertified queries keep the result bit-identical to the oracle's.
+// The split image (l2_split_bf16_kernel) has the f32 rows' size: per 16 features 32 B of hi then 32 B of lo, so a lane's A
+// fragment of K-step ks is the 16-B slot 4 ks + h (hi) or 4 ks + 2 + h (lo) of its train row -- the staging code, the XOR
+// swizzle and the conflict-free ds_read_b128 of the f32 kernel carry over unchanged.
+// Each wave owns TWO sets of 32 queries (B operands: 64 VGPRs), so an A fragment feeds two MFMAs and a workgroup covers 256
+// queries (half the L2 -> LDS traffic of the f32 kernel).  The fold of step n runs in the shadow of step n+1's MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float a)
+{
+    const uint32_t u = __float_as_uint(a);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// hi / lo halves of 2 consecutive floats packed into one dword each (element 0 in the low half)
+__device__ __forceinline__ void bf16_split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
+{
+    const uint32_t h0 = bf16_rne_bits(a0), h1 = bf16_rne_bits(a1);
+    const float r0 = __fsub_rn(a0, __uint_as_float(h0 << 16)), r1 = __fsub_rn(a1, __uint_as_float(h1 << 16));   // exact
+    hi = h0 | (h1 << 16);
+    lo = bf16_rne_bits(r0) | (bf16_rne_bits(r1) << 16);
+}
+
+// 8 consecutive floats, scaled by `scale` (a power of two: exact), as 8 hi and 8 lo bf16 values
+__device__ __forceinline__ void bf16_split8(float4 a, float4 b, float scale, u32x4 &hi, u32x4 &lo)
+{
+    uint32_t hv[4], lv[4];
+    bf16_split2(scale * a.x, scale * a.y, hv[0], lv[0]); bf16_split2(scale * a.z, scale * a.w, hv[1], lv[1]);
+    bf16_split2(scale * b.x, scale * b.y, hv[2], lv[2]); bf16_split2(scale * b.z, scale * b.w, hv[3], lv[3]);
+    hi = u32x4{hv[0], hv[1], hv[2], hv[3]};
+    lo = u32x4{lv[0], lv[1], lv[2], lv[3]};
+}
+
+// one thread per (row, 16-feature group): 64 B in, 32 B of hi + 32 B of lo out
+__global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_groups, u32x4 *__restrict__ out)
+{
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    const float4 v0 = desc[4 * g], v1 = desc[4 * g + 1], v2 = desc[4 * g + 2], v3 = desc[4 * g + 3];
+    u32x4 h0, h1, l0, l1;
+    bf16_split8(v0, v1, 1.f, h0, l0);
+    bf16_split8(v2, v3, 1.f, h1, l1);
+    out[4 * g] = h0; out[4 * g + 1] = h1; out[4 * g + 2] = l0; out[4 * g + 3] = l1;
+}
+
+template <int TT>
+__global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
+                                                             const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
+                                                             int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
+                                                             int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap)
+{
+    constexpr int DIM = 64, QB = 256, SLOTS = 16, KS = 4;
+    constexpr int NDMA = TT / 16;             // LDS-DMA instructions per wave per tile (4 rows = 1 KiB each)
+    static_assert(TT == 64 || TT == 128, "an even number of 32-row steps per tile: the accumulator pairs alternate");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef L2B_SHIFT
+#define L2B_SHIFT 0
+#endif
+    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem + L2B_SHIFT);                         // [2][TT*SLOTS]
+    float *lds_norm = reinterpret_cast<float *>(smem + L2B_SHIFT + 2 * TT * SLOTS * 16);   // [2][TT]
+    float *lds_red = lds_norm + 2 * TT;                                        // [4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = find_pair_by_block(pairs, n_pairs, lb);
+    const PairDesc pd = pairs[pi];
+    const int nq = pd.nq, nt = pd.nt;
+    const float *__restrict__ Q = desc + (size_t)pd.q_row0 * DIM;
+    const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
+    const float *__restrict__ tn = norms + pd.t_row0;
+    const int qbase = (lb - pd.blk_off) * QB + wave * 64;
+
+    // B operands: -2 q split into hi and lo, this lane's 8 features of every K-step (scaling by -2 commutes with the split)
+    bf16x8 bhi[2][KS], blo[2][KS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool ok = qrow < nq;
+        const float4 *qp = reinterpret_cast<const float4 *>(Q + (size_t)(ok ? qrow : 0) * DIM + 8 * h);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float4 a = qp[4 * ks], b = qp[4 * ks + 1];
+            if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+            u32x4 hi, lo;
+            bf16_split8(a, b, -2.f, hi, lo);
+            bhi[s][ks] = __builtin_bit_cast(bf16x8, hi);
+            blo[s][ks] = __builtin_bit_cast(bf16x8, lo);
+        }
+    }
+
+    // running top-3 per query set: segment keys (8-bit position code in the low mantissa bits) and master (key, row)
+    constexpr float kBig = 3.0e38f;
+    constexpr int kSegSub = 16;
+    float k0[2] = {kBig, kBig}, k1[2] = {kBig, kBig}, k2[2] = {kBig, kBig};
+    float v0[2] = {kBig, kBig}, v1[2] = {kBig, kBig}, v2[2] = {kBig, kBig};
+    int c0[2] = {-1, -1}, c1[2] = {-1, -1}, c2[2] = {-1, -1};
+    float tmax;
+    unsigned kmask = 0xFFFFFF00u;
+    asm volatile("" : "+v"(kmask));
+    auto fold = [&](int s, float val, int code0 /* wave-uniform, multiple of 16 */, int r) {
+#ifdef L2B_NOFOLD
+        if (r != 0) return;
+#endif
+        // plain C so that hipcc sees an MFMA result feeding a VALU instruction and keeps the required wait states (an inline-asm
+        // reader is not hazard-checked: scheduled right behind the last MFMA of a step it read stale accumulators, rarely);
+        // with the mask pinned in a VGPR this is still one v_and_or_b32 with the code as its SGPR operand
+        const float key = __uint_as_float((__float_as_uint(val) & kmask) | (unsigned)(code0 + r));
+        k2[s] = __builtin_amdgcn_fmed3f(k1[s], k2[s], key);
+        k1[s] = __builtin_amdgcn_fmed3f(k0[s], k1[s], key);
+        k0[s] = __builtin_amdgcn_fmed3f(k0[s], key, -kBig);
+    };
+    auto master_insert = [&](int s, float key, int seg_sub0) {
+        const int code = (int)(__float_as_uint(key) & 0xFFu);
+        const int r = code & 15;
+        const int t = (seg_sub0 + (code >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool live = key < 1.0e38f;
+        const bool l2 = live && key < v2[s], l1 = live && key < v1[s], l0 = live && key < v0[s];
+        const int t2 = l2 ? t : c2[s];
+        const int t1 = l1 ? t : c1[s];
+        c2[s] = l1 ? c1[s] : t2;
+        c1[s] = l0 ? c0[s] : t1;
+        c0[s] = l0 ? t : c0[s];
+        const float n2 = l2 ? key : v2[s];
+        const float n1 = l1 ? key : v1[s];
+        v2[s] = l1 ? v1[s] : n2;
+        v1[s] = l0 ? v0[s] : n1;
+        v0[s] = l0 ? key : v0[s];
+    };
+    auto flush = [&](int seg_sub0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            master_insert(s, k0[s], seg_sub0); master_insert(s, k1[s], seg_sub0); master_insert(s, k2[s], seg_sub0);
+            k0[s] = k1[s] = k2[s] = kBig;
+        }
+    };
+
+    const int ntiles = (nt + TT - 1) / TT;
+    // Staging is LDS-DMA (buffer_load_dwordx4 ... lds): a wave instruction moves 4 train rows (1 KiB) straight into LDS, lane l
+    // to byte 16 l of the destination, so the XOR swizzle is applied on the SOURCE side (lane l fetches slot (l & 15) ^ (row & 15)
+    // of its row) -- no staging VGPRs, no ds_write pass.  Rows past nt read as zeros through the buffer descriptor; their norm
+    // is kBig.  The per-lane byte offsets are loop-invariant, the tile offset is scalar.
+    // The DMA is issued from inline asm: through the builtin hipcc orders every later LDS read behind vmcnt(0) (it cannot tell
+    // the two LDS buffers apart), which would serialise each tile's transfer with its MFMAs.  The asm is invisible to the
+    // waitcnt pass, so the wait is explicit: s_waitcnt vmcnt(0) in front of the barrier that publishes the tile.
+    u32x4 trsrc;
+    {
+        const uint64_t base = reinterpret_cast<uint64_t>(split + (size_t)pd.t_row0 * SLOTS);
+        trsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        trsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xFFFFu);      // stride 0: raw buffer
+        trsrc[2] = __builtin_amdgcn_readfirstlane((uint32_t)nt * (DIM * 4));               // bytes; reads past it return 0
+        trsrc[3] = 0x00020000u;
+    }
+    const uint32_t lds_tile_addr = (uint32_t)(uintptr_t)lds_tile;   // LDS byte address (the low 32 bits of the flat pointer's offset)
+    const int wrow0 = __builtin_amdgcn_readfirstlane(wave * (TT / 4));      // this wave stages rows [wrow0, wrow0 + TT / 4) of a tile
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wrow0 + 4 * i + (lane >> 4);
+        voff[i] = row * (DIM * 4) + (((lane & 15) ^ (row & 15)) * 16);       // rows 16 apart share the swizzle: i and i + 4
+    }
+    auto dma_tile = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const uint32_t dst = lds_tile_addr + (uint32_t)((buf * TT * SLOTS + (wrow0 + 4 * i) * SLOTS) * 16);
+            const int soff = (tile * TT + (i >= 4 ? 16 : 0)) * (DIM * 4);    // wave-uniform
+#ifdef L2B_BUILTIN_DMA
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(split + (size_t)pd.t_row0 * SLOTS), 0, nt * DIM * 4, 0x00020000),
+                                                     &lds_tile[buf * TT * SLOTS + (wrow0 + 4 * i) * SLOTS], 16, voff[i & 3], soff, 0, 0);
+            (void)dst;
+#else
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(voff[i & 3]), "s"(trsrc), "s"(soff) : "memory");
+#endif
+        }
+    };
+    // |t|^2 of the tile's rows (the accumulators' start values) go through a register: an ordinary load whose consumer sits
+    // behind an LDS-DMA makes hipcc wait for vmcnt(0), so the load is issued BEFORE the tile's DMA and stored at the end of
+    // the iteration, where the DMA has to have landed anyway
+    auto norm_load = [&](int tile) {
+        const int t = tile * TT + tid;
+        return (tid < TT && t < nt) ? tn[t] : kBig;
+    };
+    auto norm_store = [&](int buf, float nv) { if (tid < TT) lds_norm[buf * TT + tid] = nv; };
+
+    // rows past nt of the last tile are not transferred (their norm kBig keeps them out of every top-3): what they hold must
+    // at least be finite, so the buffers start out zeroed (NaN keys would corrupt the v_med3 network)
+    if (ntiles * TT != nt) {
+        for (int i = tid; i < 2 * TT * SLOTS; i += 256) lds_tile[i] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+    if (ntiles > 0) {
+        const float nv = norm_load(0);
+        norm_store(0, nv);
+        dma_tile(0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // One 32-train step: 24 MFMAs into (n0, n1) with the fold of the PREVIOUS step's results (p0, p1) between them.
+    auto step = [&](int buf, int base, floatx16 &n0, floatx16 &n1, const floatx16 &p0, const floatx16 &p1, int pcode) {
+        floatx16 cinit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 nv = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + base + 8 * g + 4 * h]);
+            cinit[4 * g + 0] = nv.x; cinit[4 * g + 1] = nv.y; cinit[4 * g + 2] = nv.z; cinit[4 * g + 3] = nv.w;
+        }
+        const u32x4 *rowp = &lds_tile[buf * TT * SLOTS + (base + j) * SLOTS];
+        const int sw = j & 15;       // (base + j) & 15: base is a multiple of 32
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#ifdef L2B_NOLDS
+            const bf16x8 ahi = bhi[1][(ks + 1) & 3], alo = blo[1][(ks + 2) & 3];
+#else
+            const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[(4 * ks + h) ^ sw]);
+            const bf16x8 alo = __builtin_bit_cast(bf16x8, rowp[(4 * ks + 2 + h) ^ sw]);
+#endif
+            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[0][ks], ks == 0 ? cinit : n0, 0, 0, 0);
+            fold(0, p0[4 * ks + 0], pcode, 4 * ks + 0);
+            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[1][ks], ks == 0 ? cinit : n1, 0, 0, 0);
+            fold(1, p1[4 * ks + 0], pcode, 4 * ks + 0);
+            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[0][ks], n0, 0, 0, 0);
+            fold(0, p0[4 * ks + 1], pcode, 4 * ks + 1);
+            fold(1, p1[4 * ks + 1], pcode, 4 * ks + 1);
+            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[1][ks], n1, 0, 0, 0);
+            fold(0, p0[4 * ks + 2], pcode, 4 * ks + 2);
+            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[0][ks], n0, 0, 0, 0);
+            fold(1, p1[4 * ks + 2], pcode, 4 * ks + 2);
+            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[1][ks], n1, 0, 0, 0);
+            fold(0, p0[4 * ks + 3], pcode, 4 * ks + 3);
+            fold(1, p1[4 * ks + 3], pcode, 4 * ks + 3);
+        }
+    };
+    floatx16 ra0, ra1, rb0, rb1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rb0[r] = kBig; rb1[r] = kBig; }     // start-up placeholders: never "live"
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+#ifndef L2B_NOSTAGE
+        const bool more = tile + 1 < ntiles;
+        float next_norm = kBig;
+        if (more) {
+            next_norm = norm_load(tile + 1);
+            dma_tile(tile + 1, buf ^ 1);                                       // lands under this tile's MFMAs
+        }
+#endif
+#pragma unroll
+        for (int sp = 0; sp < TT / 64; ++sp) {
+            const int sub = (TT / 32) * tile + 2 * sp;                         // global 32-row step index of the first step
+            // step `sub` folds step sub - 1 (codes of its position inside its segment)
+            step(buf, 64 * sp, ra0, ra1, rb0, rb1, __builtin_amdgcn_readfirstlane(((sub + kSegSub - 1) % kSegSub) * 16));
+            if (sub > 0 && sub % kSegSub == 0) flush(sub - kSegSub);           // step sub - 1 closed a segment
+            step(buf, 64 * sp + 32, rb0, rb1, ra0, ra1, __builtin_amdgcn_readfirstlane((sub % kSegSub) * 16));
+        }
+#ifndef L2B_NOSTAGE
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) norm_store(buf ^ 1, next_norm);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the DMA issued above has landed
+        __syncthreads();
+#endif
+    }
+    {
+        const int nsub = (TT / 32) * ntiles;
+        if (nsub > 0) {
+            // the drain reads the last MFMAs' results from inline asm, which hipcc does not hazard-pad
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(rb0), "+v"(rb1));
+            const int pcode = ((nsub - 1) % kSegSub) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { fold(0, rb0[r], pcode, r); fold(1, rb1[r], pcode, r); }
+            flush(((nsub - 1) / kSegSub) * kSegSub);
+        }
+    }
+
+    // max |t|^2 over the train set (for the certificate's error bound): one pass over the norms, once per workgroup
+    {
+        float m = 0.f;
+        for (int t = tid; t < nt; t += 256) m = fmaxf(m, tn[t]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) lds_red[wave] = m;
+        __syncthreads();
+        tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
+    }
+
+    // ---- exact re-rank of this lane's 3 candidates per set in the oracle's order, certificate ----
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool qvalid = qrow < nq;
+        Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
+        float ed[3], ed2[3];
+        int ei[3];
+        {
+            const int cc[3] = {c0[s], c1[s], c2[s]};
+            const float *qp = Q + (size_t)(qvalid ? qrow : 0) * DIM;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                ei[m] = -1; ed[m] = FLT_MAX; ed2[m] = 0.f;
+                if (cc[m] >= 0 && qvalid) {
+                    const int t = cc[m];
+                    const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
+                    ei[m] = t; ed2[m] = d2; ed[m] = sqrt_rn_f32(d2);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) best2_insert(b0, b1, ed[m], ei[m], ed2[m]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const float pd_ = __shfl_xor(ed[m], 32), pd2 = __shfl_xor(ed2[m], 32);
+            const int pi_ = __shfl_xor(ei[m], 32);
+            best2_insert(b0, b1, pd_, pi_, pd2);
+        }
+        const float tau = fminf(v2[s], __shfl_xor(v2[s], 32));  // every train outside the 6 candidates has key >= tau
+        if (qvalid && h == 0) {
+            const size_t o = 2 * ((size_t)pd.out_off + qrow);
+            knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
+            knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
+            // Certificate: |(|q|^2 + s(t)) - D(t)| <= 2^-15 (|q|^2 + max|t|^2) for every train t -- split 193 u,
+            // bf16-MFMA accumulation 36 u (3 u per MFMA; measured 0.75 u, profiles/r01_ubench_bf16_acc.txt), norms and the
+            // canonical distance 96 u, of |q|^2 + 2 |t|^2 at most; keys are s with 8 mantissa bits replaced (< 2^-14 |tau|).
+            bool certified = !(tau < 1.0e38f);
+            if (!certified && b1.i >= 0) {
+                const double qn = (double)norms[pd.q_row0 + qrow];
+                const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0 / 16384.0);
+                certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
+            }
+            if (!certified) {
+                const int slot = atomicAdd(&counters[0], 1);
+                if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
+            }
         }
     }
 }
@@ -748,6 +1093,44 @@ int launch_l2_norms(hipStream_t st, const float *desc, int dim, long long n_rows
 }
 
 bool l2_mfma_supported(int dim) { return dim == 64 || dim == 128; }
+
+// 64-float descriptors take the split-bf16 pass (256 queries per workgroup); ESFM_L2_PASS=f32 in the environment keeps them on
+// the f32-MFMA kernel (measurement only: bench.py reports both)
+bool l2_bf16_pass(int dim)
+{
+    static const bool forced_f32 = [] { const char *e = getenv("ESFM_L2_PASS"); return e && strcmp(e, "f32") == 0; }();
+    return dim == 64 && !forced_f32;
+}
+int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 256 : 128; }
+size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)256 * (size_t)std::max(total_rows, 1LL) : 0; }
+
+int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split)
+{
+    const long long n_groups = total_rows * 4;
+    if (n_groups <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(desc), n_groups, reinterpret_cast<u32x4 *>(split));
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, const float *norms, const PairDesc *pairs,
+                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)
+{
+    if (n_blocks <= 0) return ESFM_OK;
+#ifndef L2B_TT
+#define L2B_TT 128
+#endif
+#ifndef L2B_SHIFT
+#define L2B_SHIFT 0
+#endif
+    constexpr int TT = L2B_TT;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
+    constexpr size_t lds = L2B_SHIFT + 2 * TT * 16 * 16 + 2 * TT * 4 + 16;
+    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split), norms, pairs,
+                       n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
 
 int launch_l2_knn_mfma(hipStream_t st, int dim, const float *desc, const float *norms, const PairDesc *pairs, int n_pairs,
                        int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)

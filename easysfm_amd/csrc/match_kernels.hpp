@@ -19,6 +19,13 @@ int launch_l2_norms(hipStream_t st, const float *desc, int dim, long long n_rows
 bool l2_mfma_supported(int dim);
 int launch_l2_knn_mfma(hipStream_t st, int dim, const float *desc, const float *norms, const PairDesc *pairs, int n_pairs,
                        int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap);
+// 64-float descriptors: split-bf16 distance pass (needs l2_split_bytes(total_rows) of scratch; 256 queries per workgroup)
+bool l2_bf16_pass(int dim);
+int l2_query_block(int dim);
+size_t l2_split_bytes(int dim, long long total_rows);
+int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split);
+int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, const float *norms, const PairDesc *pairs,
+                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap);
 int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairDesc *pairs, int n_pairs,
                          const int32_t *flagged, const int32_t *counters, long long total_queries, int grid,
                          int32_t *knn_idx, float *knn_dist);
