@@ -86,16 +86,16 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
             const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
-            if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
             if (esfm::l2_bf16_pass(width)) {
                 if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
-                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr)) return rc;
+                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>())) return rc;
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                 if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, ctx->norms.as<float>(), dev_tab, n_pairs,
                                                       plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
                                                       ctx->counters.as<int32_t>(), (int)cap64))
                     return rc;
             } else {
+                if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                 if (int rc = esfm::launch_l2_knn_mfma(st, width, desc, ctx->norms.as<float>(), dev_tab, n_pairs, plan.n_blocks, knn_idx,
                                                       knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))

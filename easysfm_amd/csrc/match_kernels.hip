@@ -413,34 +413,43 @@ __device__ __forceinline__ void bf16_split8(float4 a, float4 b, float scale, u32
     lo = u32x4{lv[0], lv[1], lv[2], lv[3]};
 }
 
-// one thread per (row, 16-feature group): 64 B in, 32 B of hi + 32 B of lo out
-__global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_groups, u32x4 *__restrict__ out)
+// one thread per (row, 16-feature group): 64 B in, 32 B of hi + 32 B of lo out; the 4 threads of a row also leave |row|^2
+// (the approximate pass and the certificate only need it to 64 u: the summation order is free)
+__global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_groups, u32x4 *__restrict__ out,
+                                                            float *__restrict__ norms)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_groups) return;
-    const float4 v0 = desc[4 * g], v1 = desc[4 * g + 1], v2 = desc[4 * g + 2], v3 = desc[4 * g + 3];
+    const bool ok = g < n_groups;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v0 = ok ? desc[4 * g] : z, v1 = ok ? desc[4 * g + 1] : z, v2 = ok ? desc[4 * g + 2] : z, v3 = ok ? desc[4 * g + 3] : z;
+    float s = 0.f;
+    s = fmaf(v0.x, v0.x, s); s = fmaf(v0.y, v0.y, s); s = fmaf(v0.z, v0.z, s); s = fmaf(v0.w, v0.w, s);
+    s = fmaf(v1.x, v1.x, s); s = fmaf(v1.y, v1.y, s); s = fmaf(v1.z, v1.z, s); s = fmaf(v1.w, v1.w, s);
+    s = fmaf(v2.x, v2.x, s); s = fmaf(v2.y, v2.y, s); s = fmaf(v2.z, v2.z, s); s = fmaf(v2.w, v2.w, s);
+    s = fmaf(v3.x, v3.x, s); s = fmaf(v3.y, v3.y, s); s = fmaf(v3.z, v3.z, s); s = fmaf(v3.w, v3.w, s);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (!ok) return;
+    if ((g & 3) == 0) norms[g >> 2] = s;
     u32x4 h0, h1, l0, l1;
     bf16_split8(v0, v1, 1.f, h0, l0);
     bf16_split8(v2, v3, 1.f, h1, l1);
     out[4 * g] = h0; out[4 * g + 1] = h1; out[4 * g + 2] = l0; out[4 * g + 3] = l1;
 }
 
-template <int TT>
-__global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
+template <int TT, int NS>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
                                                              const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                              int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap)
 {
-    constexpr int DIM = 64, QB = 256, SLOTS = 16, KS = 4;
+    constexpr int DIM = 64, QB = 128 * NS, SLOTS = 16, KS = 4;   // NS sets of 32 queries per wave
     constexpr int NDMA = TT / 16;             // LDS-DMA instructions per wave per tile (4 rows = 1 KiB each)
     static_assert(TT == 64 || TT == 128, "an even number of 32-row steps per tile: the accumulator pairs alternate");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifndef L2B_SHIFT
-#define L2B_SHIFT 0
-#endif
-    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem + L2B_SHIFT);                         // [2][TT*SLOTS]
-    float *lds_norm = reinterpret_cast<float *>(smem + L2B_SHIFT + 2 * TT * SLOTS * 16);   // [2][TT]
+    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [2][TT*SLOTS]
+    float *lds_norm = reinterpret_cast<float *>(smem + 2 * TT * SLOTS * 16);   // [2][TT]
     float *lds_red = lds_norm + 2 * TT;                                        // [4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -451,12 +460,12 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     const float *__restrict__ Q = desc + (size_t)pd.q_row0 * DIM;
     const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
     const float *__restrict__ tn = norms + pd.t_row0;
-    const int qbase = (lb - pd.blk_off) * QB + wave * 64;
+    const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
 
     // B operands: -2 q split into hi and lo, this lane's 8 features of every K-step (scaling by -2 commutes with the split)
-    bf16x8 bhi[2][KS], blo[2][KS];
+    bf16x8 bhi[NS][KS], blo[NS][KS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool ok = qrow < nq;
         const float4 *qp = reinterpret_cast<const float4 *>(Q + (size_t)(ok ? qrow : 0) * DIM + 8 * h);
@@ -474,16 +483,14 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     // running top-3 per query set: segment keys (8-bit position code in the low mantissa bits) and master (key, row)
     constexpr float kBig = 3.0e38f;
     constexpr int kSegSub = 16;
-    float k0[2] = {kBig, kBig}, k1[2] = {kBig, kBig}, k2[2] = {kBig, kBig};
-    float v0[2] = {kBig, kBig}, v1[2] = {kBig, kBig}, v2[2] = {kBig, kBig};
-    int c0[2] = {-1, -1}, c1[2] = {-1, -1}, c2[2] = {-1, -1};
+    float k0[NS], k1[NS], k2[NS], v0[NS], v1[NS], v2[NS];
+    int c0[NS], c1[NS], c2[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { k0[s] = k1[s] = k2[s] = v0[s] = v1[s] = v2[s] = kBig; c0[s] = c1[s] = c2[s] = -1; }
     float tmax;
     unsigned kmask = 0xFFFFFF00u;
     asm volatile("" : "+v"(kmask));
     auto fold = [&](int s, float val, int code0 /* wave-uniform, multiple of 16 */, int r) {
-#ifdef L2B_NOFOLD
-        if (r != 0) return;
-#endif
         // plain C so that hipcc sees an MFMA result feeding a VALU instruction and keeps the required wait states (an inline-asm
         // reader is not hazard-checked: scheduled right behind the last MFMA of a step it read stale accumulators, rarely);
         // with the mask pinned in a VGPR this is still one v_and_or_b32 with the code as its SGPR operand
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     };
     auto flush = [&](int seg_sub0) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             master_insert(s, k0[s], seg_sub0); master_insert(s, k1[s], seg_sub0); master_insert(s, k2[s], seg_sub0);
             k0[s] = k1[s] = k2[s] = kBig;
         }
@@ -546,15 +553,9 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
         for (int i = 0; i < NDMA; ++i) {
             const uint32_t dst = lds_tile_addr + (uint32_t)((buf * TT * SLOTS + (wrow0 + 4 * i) * SLOTS) * 16);
             const int soff = (tile * TT + (i >= 4 ? 16 : 0)) * (DIM * 4);    // wave-uniform
-#ifdef L2B_BUILTIN_DMA
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(split + (size_t)pd.t_row0 * SLOTS), 0, nt * DIM * 4, 0x00020000),
-                                                     &lds_tile[buf * TT * SLOTS + (wrow0 + 4 * i) * SLOTS], 16, voff[i & 3], soff, 0, 0);
-            (void)dst;
-#else
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "s"(dst), "v"(voff[i & 3]), "s"(trsrc), "s"(soff) : "memory");
-#endif
         }
     };
     // |t|^2 of the tile's rows (the accumulators' start values) go through a register: an ordinary load whose consumer sits
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     __syncthreads();
 
     // One 32-train step: 24 MFMAs into (n0, n1) with the fold of the PREVIOUS step's results (p0, p1) between them.
-    auto step = [&](int buf, int base, floatx16 &n0, floatx16 &n1, const floatx16 &p0, const floatx16 &p1, int pcode) {
+    auto step = [&](int buf, int base, floatx16 (&n)[NS], const floatx16 (&p)[NS], int pcode) {
         floatx16 cinit;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -592,64 +593,60 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
         const int sw = j & 15;       // (base + j) & 15: base is a multiple of 32
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-#ifdef L2B_NOLDS
-            const bf16x8 ahi = bhi[1][(ks + 1) & 3], alo = blo[1][(ks + 2) & 3];
-#else
             const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[(4 * ks + h) ^ sw]);
             const bf16x8 alo = __builtin_bit_cast(bf16x8, rowp[(4 * ks + 2 + h) ^ sw]);
-#endif
-            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[0][ks], ks == 0 ? cinit : n0, 0, 0, 0);
-            fold(0, p0[4 * ks + 0], pcode, 4 * ks + 0);
-            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[1][ks], ks == 0 ? cinit : n1, 0, 0, 0);
-            fold(1, p1[4 * ks + 0], pcode, 4 * ks + 0);
-            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[0][ks], n0, 0, 0, 0);
-            fold(0, p0[4 * ks + 1], pcode, 4 * ks + 1);
-            fold(1, p1[4 * ks + 1], pcode, 4 * ks + 1);
-            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[1][ks], n1, 0, 0, 0);
-            fold(0, p0[4 * ks + 2], pcode, 4 * ks + 2);
-            n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[0][ks], n0, 0, 0, 0);
-            fold(1, p1[4 * ks + 2], pcode, 4 * ks + 2);
-            n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[1][ks], n1, 0, 0, 0);
-            fold(0, p0[4 * ks + 3], pcode, 4 * ks + 3);
-            fold(1, p1[4 * ks + 3], pcode, 4 * ks + 3);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[s][ks], ks == 0 ? cinit : n[s], 0, 0, 0);
+                fold(s, p[s][4 * ks + 0], pcode, 4 * ks + 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[s][ks], n[s], 0, 0, 0);
+                fold(s, p[s][4 * ks + 1], pcode, 4 * ks + 1);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[s][ks], n[s], 0, 0, 0);
+                fold(s, p[s][4 * ks + 2], pcode, 4 * ks + 2);
+                fold(s, p[s][4 * ks + 3], pcode, 4 * ks + 3);
+            }
         }
     };
-    floatx16 ra0, ra1, rb0, rb1;
+    floatx16 ra[NS], rb[NS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { rb0[r] = kBig; rb1[r] = kBig; }     // start-up placeholders: never "live"
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rb[s][r] = kBig;                  // start-up placeholders: never "live"
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-#ifndef L2B_NOSTAGE
         const bool more = tile + 1 < ntiles;
         float next_norm = kBig;
         if (more) {
             next_norm = norm_load(tile + 1);
             dma_tile(tile + 1, buf ^ 1);                                       // lands under this tile's MFMAs
         }
-#endif
 #pragma unroll
         for (int sp = 0; sp < TT / 64; ++sp) {
             const int sub = (TT / 32) * tile + 2 * sp;                         // global 32-row step index of the first step
             // step `sub` folds step sub - 1 (codes of its position inside its segment)
-            step(buf, 64 * sp, ra0, ra1, rb0, rb1, __builtin_amdgcn_readfirstlane(((sub + kSegSub - 1) % kSegSub) * 16));
+            step(buf, 64 * sp, ra, rb, __builtin_amdgcn_readfirstlane(((sub + kSegSub - 1) % kSegSub) * 16));
             if (sub > 0 && sub % kSegSub == 0) flush(sub - kSegSub);           // step sub - 1 closed a segment
-            step(buf, 64 * sp + 32, rb0, rb1, ra0, ra1, __builtin_amdgcn_readfirstlane((sub % kSegSub) * 16));
+            step(buf, 64 * sp + 32, rb, ra, __builtin_amdgcn_readfirstlane((sub % kSegSub) * 16));
         }
-#ifndef L2B_NOSTAGE
         __builtin_amdgcn_sched_barrier(0);
         if (more) norm_store(buf ^ 1, next_norm);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the DMA issued above has landed
         __syncthreads();
-#endif
     }
     {
         const int nsub = (TT / 32) * ntiles;
         if (nsub > 0) {
-            // the drain reads the last MFMAs' results from inline asm, which hipcc does not hazard-pad
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(rb0), "+v"(rb1));
             const int pcode = ((nsub - 1) % kSegSub) * 16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { fold(0, rb0[r], pcode, r); fold(1, rb1[r], pcode, r); }
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) fold(s, rb[s][r], pcode, r);
             flush(((nsub - 1) / kSegSub) * kSegSub);
         }
     }
@@ -667,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
 
     // ---- exact re-rank of this lane's 3 candidates per set in the oracle's order, certificate ----
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
         Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
@@ -1101,15 +1098,16 @@ bool l2_bf16_pass(int dim)
     static const bool forced_f32 = [] { const char *e = getenv("ESFM_L2_PASS"); return e && strcmp(e, "f32") == 0; }();
     return dim == 64 && !forced_f32;
 }
-int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 256 : 128; }
+constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_kernel (1: 3 waves per SIMD, measured 7-15 % slower)
+int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)256 * (size_t)std::max(total_rows, 1LL) : 0; }
 
-int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split)
+int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms)
 {
     const long long n_groups = total_rows * 4;
     if (n_groups <= 0) return ESFM_OK;
     hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float4 *>(desc), n_groups, reinterpret_cast<u32x4 *>(split));
+                       reinterpret_cast<const float4 *>(desc), n_groups, reinterpret_cast<u32x4 *>(split), norms);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
@@ -1118,15 +1116,9 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, con
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)
 {
     if (n_blocks <= 0) return ESFM_OK;
-#ifndef L2B_TT
-#define L2B_TT 128
-#endif
-#ifndef L2B_SHIFT
-#define L2B_SHIFT 0
-#endif
-    constexpr int TT = L2B_TT;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
-    constexpr size_t lds = L2B_SHIFT + 2 * TT * 16 * 16 + 2 * TT * 4 + 16;
-    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split), norms, pairs,
+    constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
+    constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16;
+    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT, kL2BfSets>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split), norms, pairs,
                        n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
