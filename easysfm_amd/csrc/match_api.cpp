@@ -90,7 +90,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                 if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
                 if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>())) return rc;
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
-                if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, ctx->norms.as<float>(), dev_tab, n_pairs,
+                if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
                                                       plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
                                                       ctx->counters.as<int32_t>(), (int)cap64))
                     return rc;

@@ -4,15 +4,18 @@
 // the pair loop of cpp_code/test/sfm.cpp:140-161.
 //
 // L2 (SURF, float):
-//   l2_row_norms_kernel      |t|^2 per descriptor row
-//   l2_knn_mfma_kernel       distance GEMM on v_mfma_f32_32x32x2_f32 with a fused
+//   l2_split_bf16_kernel     64-float rows as bf16 hi + lo halves (train image, query image = -2 x) and |row|^2
+//   l2_knn_bf16_kernel       64-float rows: distance GEMM as three bf16 MFMAs per product with a fused per-lane top-3,
+//                            the exact re-rank and the rounding-error certificate of l2_knn_mfma_kernel (eps 2^-15)
+//   l2_row_norms_kernel      |t|^2 per descriptor row (other widths)
+//   l2_knn_mfma_kernel       128-float rows: distance GEMM on v_mfma_f32_32x32x2_f32 with a fused
 //                            per-lane top-3 epilogue, then an exact re-rank of the
 //                            6 candidates per query in the oracle's summation
 //                            order and a rounding-error certificate
 //   l2_exact_scan_kernel     exact brute-force scan for the (rare) queries the
 //                            certificate rejects, and for widths without an MFMA build
 // Hamming (ORB, 256-bit):
-//   hamming_knn_mfma_kernel  256-bit descriptors: +-1 expansion on the i8 matrix cores (dot = 256 - 2 ham), fused top-2
+//   hamming_knn_mfma_kernel  256-bit descriptors: 0/1 byte expansion on the i8 matrix cores, fused top-2
 //   hamming_knn_kernel       other widths: XOR + popcount, (distance,index) packed into one u32 key
 // Both:
 //   ratio_compact_kernel     ratio test in double + ordered compaction per pair
@@ -413,10 +416,11 @@ __device__ __forceinline__ void bf16_split8(float4 a, float4 b, float scale, u32
     lo = u32x4{lv[0], lv[1], lv[2], lv[3]};
 }
 
-// one thread per (row, 16-feature group): 64 B in, 32 B of hi + 32 B of lo out; the 4 threads of a row also leave |row|^2
+// one thread per (row, 16-feature group): 64 B in, 32 B of hi + 32 B of lo out, twice (train image, query image = -2 x);
+// the 4 threads of a row also leave |row|^2
 // (the approximate pass and the certificate only need it to 64 u: the summation order is free)
 __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_groups, u32x4 *__restrict__ out,
-                                                            float *__restrict__ norms)
+                                                            u32x4 *__restrict__ out_q, float *__restrict__ norms)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool ok = g < n_groups;
@@ -435,11 +439,15 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
     bf16_split8(v0, v1, 1.f, h0, l0);
     bf16_split8(v2, v3, 1.f, h1, l1);
     out[4 * g] = h0; out[4 * g + 1] = h1; out[4 * g + 2] = l0; out[4 * g + 3] = l1;
+    // the same rows as the matcher's QUERY operand: -2 q, split the same way (scaling by -2 commutes with the split)
+    bf16_split8(v0, v1, -2.f, h0, l0);
+    bf16_split8(v2, v3, -2.f, h1, l1);
+    out_q[4 * g] = h0; out_q[4 * g + 1] = h1; out_q[4 * g + 2] = l0; out_q[4 * g + 3] = l1;
 }
 
 template <int TT, int NS>
 __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
-                                                             const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
+                                                             const u32x4 *__restrict__ split_q, const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                              int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap)
 {
@@ -462,19 +470,17 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     const float *__restrict__ tn = norms + pd.t_row0;
     const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
 
-    // B operands: -2 q split into hi and lo, this lane's 8 features of every K-step (scaling by -2 commutes with the split)
+    // B operands: -2 q split into hi and lo (the query image of l2_split_bf16_kernel), this lane's 8 features of every K-step
     bf16x8 bhi[NS][KS], blo[NS][KS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool ok = qrow < nq;
-        const float4 *qp = reinterpret_cast<const float4 *>(Q + (size_t)(ok ? qrow : 0) * DIM + 8 * h);
+        const u32x4 *qp = split_q + ((size_t)pd.q_row0 + (ok ? qrow : 0)) * SLOTS + h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            float4 a = qp[4 * ks], b = qp[4 * ks + 1];
-            if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
-            u32x4 hi, lo;
-            bf16_split8(a, b, -2.f, hi, lo);
+            u32x4 hi = qp[4 * ks], lo = qp[4 * ks + 2];
+            if (!ok) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
             bhi[s][ks] = __builtin_bit_cast(bf16x8, hi);
             blo[s][ks] = __builtin_bit_cast(bf16x8, lo);
         }
@@ -1100,25 +1106,28 @@ bool l2_bf16_pass(int dim)
 }
 constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_kernel (1: 3 waves per SIMD, measured 7-15 % slower)
 int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
-size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)256 * (size_t)std::max(total_rows, 1LL) : 0; }
+size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
 
 int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms)
 {
+    // `split` holds two images of 256 B per row: the train operand, then the query operand (-2 x)
     const long long n_groups = total_rows * 4;
     if (n_groups <= 0) return ESFM_OK;
     hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float4 *>(desc), n_groups, reinterpret_cast<u32x4 *>(split), norms);
+                       reinterpret_cast<const float4 *>(desc), n_groups, reinterpret_cast<u32x4 *>(split),
+                       reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
 
-int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, const float *norms, const PairDesc *pairs,
+int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
     constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16;
-    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT, kL2BfSets>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split), norms, pairs,
+    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT, kL2BfSets>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
+                       reinterpret_cast<const u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, pairs,
                        n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
