@@ -78,6 +78,43 @@ def test_l2_unnormalised_and_dim128(gpu_ctx, oracle_lib):
     _check_knn_l2(gpu_ctx, oracle_lib, q, t)     # odd width: scalar tail of the canonical sum
 
 
+@pytest.mark.parametrize("case", ["cluster", "dynamic_range", "tiny", "huge_norms", "equal_rows", "sparse", "segment_edges"])
+def test_l2_split_bf16_pass_adversarial(gpu_ctx, oracle_lib, case):
+    """64-float descriptors go through the split-bf16 distance pass, whose scores carry ~2^-16 relative error: inputs built to
+    sit inside that error (near-equal distances, cancellation, extreme magnitudes) must still come out bit-identical to the
+    oracle, through the certificate's rescan if need be."""
+    rng = np.random.default_rng({"cluster": 1, "dynamic_range": 2, "tiny": 3, "huge_norms": 4, "equal_rows": 5, "sparse": 6,
+                                 "segment_edges": 7}[case])
+    nq, nt = 300, 1500
+    q = rng.standard_normal((nq, 64)).astype(np.float32)
+    t = rng.standard_normal((nt, 64)).astype(np.float32)
+    if case == "cluster":                   # every train within 1e-5 relative of one centre: all distances nearly equal
+        c = rng.standard_normal(64).astype(np.float32)
+        t = (c[None, :] * (1 + 1e-5 * rng.standard_normal((nt, 64)))).astype(np.float32)
+        q[:150] = (c[None, :] * (1 + 1e-5 * rng.standard_normal((150, 64)))).astype(np.float32)
+    elif case == "dynamic_range":           # components spread over 12 decades inside a row
+        q = (q * np.exp(rng.uniform(-14, 14, q.shape))).astype(np.float32)
+        t = (t * np.exp(rng.uniform(-14, 14, t.shape))).astype(np.float32)
+    elif case == "tiny":                    # magnitudes near the bottom of the normal range
+        q = (q * 1e-18).astype(np.float32); t = (t * 1e-18).astype(np.float32)
+    elif case == "huge_norms":              # large common offset: d^2 << |q|^2 + |t|^2 (catastrophic cancellation in the GEMM form)
+        q = (q + 300.0).astype(np.float32); t = (t + 300.0).astype(np.float32)
+    elif case == "equal_rows":              # many identical trains and queries equal to trains
+        t[100:400] = t[7]; t[900:] = t[13]; q[:50] = t[7]; q[50:100] = t[13]
+    elif case == "sparse":
+        q[rng.random(q.shape) < 0.9] = 0; t[rng.random(t.shape) < 0.9] = 0
+    elif case == "segment_edges":           # the two nearest trains at the seams of the 32-row steps / 512-row segments / 128-row tiles
+        nt = 2100
+        t = rng.standard_normal((nt, 64)).astype(np.float32)
+        for k, pos in enumerate([0, 31, 32, 127, 128, 511, 512, 1023, 1024, 2047, 2048, 2099]):
+            q[k] = t[pos] * np.float32(1 + 1e-4)
+            q[k + 20] = t[pos]; t[(pos + 1) % nt] = t[pos] * np.float32(1 + 3e-7)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)
+    qi, ti, d = E.match_l2(q, t, 0.8, gpu_ctx)
+    rq, rt, rd = oracle_lib.match_l2(q, t, 0.8)
+    assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(_bits(d), _bits(rd))
+
+
 @pytest.mark.parametrize("ratio", [0.5, 0.7, 0.8, 1.0])
 def test_l2_match_surf_like(gpu_ctx, oracle_lib, ratio):
     s = synth.surf_like_sets(2, 1500, pool=2048, seed_base=100)
