@@ -768,6 +768,84 @@ __global__ __launch_bounds__(256) void l2_exact_scan_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// The rescan of the queries the certificate rejects, 64-float rows: same result as l2_exact_scan_kernel, but latency-aware --
+// the handful of flagged queries (0.06 % on M-SURF-4k) leaves the chip nearly empty, so a thread keeps its query row in
+// registers and has the loads of two train rows in flight at a time, and the (distance, index) reduction runs on wave
+// shuffles.  l2sqr64_canonical_regs is l2sqr_canonical on register operands: the same 8 chains, the same final order.
+__device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], const float4 (&b)[16])
+{
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float av[8] = {a[2 * j].x, a[2 * j].y, a[2 * j].z, a[2 * j].w, a[2 * j + 1].x, a[2 * j + 1].y, a[2 * j + 1].z, a[2 * j + 1].w};
+        const float bv[8] = {b[2 * j].x, b[2 * j].y, b[2 * j].z, b[2 * j].w, b[2 * j + 1].x, b[2 * j + 1].y, b[2 * j + 1].z, b[2 * j + 1].w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = __fsub_rn(av[c], bv[c]);
+            acc[c] = __fadd_rn(acc[c], __fmul_rn(t, t));
+        }
+    }
+    const float s0 = __fadd_rn(acc[0], acc[4]);
+    const float s1 = __fadd_rn(acc[1], acc[5]);
+    const float s2 = __fadd_rn(acc[2], acc[6]);
+    const float s3 = __fadd_rn(acc[3], acc[7]);
+    float d = __fadd_rn(s0, s1);
+    d = __fadd_rn(d, s2);
+    return __fadd_rn(d, s3);
+}
+
+__global__ __launch_bounds__(256) void l2_rescan64_kernel(const float *__restrict__ desc, const PairDesc *__restrict__ pairs,
+                                                          const int32_t *__restrict__ flagged, const int32_t *__restrict__ counters,
+                                                          int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+{
+    __shared__ float s_d[2][4];
+    __shared__ int s_i[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_entries = counters[0];
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const int pi = flagged[2 * e], qrow = flagged[2 * e + 1];
+        const PairDesc pd = pairs[pi];
+        const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + qrow) * 64);
+        const float4 *T = reinterpret_cast<const float4 *>(desc + (size_t)pd.t_row0 * 64);
+        float4 qv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) qv[c] = qp[c];
+        Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
+        for (int t = tid; t < pd.nt; t += 512) {
+            const int t2 = t + 256;
+            const bool two = t2 < pd.nt;
+            float4 ta[16], tb[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) ta[c] = T[(size_t)t * 16 + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) tb[c] = T[(size_t)(two ? t2 : t) * 16 + c];
+            const float da = l2sqr64_canonical_regs(qv, ta), db = l2sqr64_canonical_regs(qv, tb);
+            best2_insert(b0, b1, sqrt_rn_f32(da), t, da);
+            if (two) best2_insert(b0, b1, sqrt_rn_f32(db), t2, db);
+        }
+        // (distance, index) is a total order: the merge order does not matter
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float d0 = __shfl_xor(b0.d, o), d1 = __shfl_xor(b1.d, o);
+            const int i0 = __shfl_xor(b0.i, o), i1 = __shfl_xor(b1.i, o);
+            best2_insert(b0, b1, d0, i0, 0.f);
+            best2_insert(b0, b1, d1, i1, 0.f);
+        }
+        if (lane == 0) { s_d[0][wave] = b0.d; s_i[0][wave] = b0.i; s_d[1][wave] = b1.d; s_i[1][wave] = b1.i; }
+        __syncthreads();
+        if (tid == 0) {
+            Cand a0 = {FLT_MAX, -1, 0.f}, a1 = {FLT_MAX, -1, 0.f};
+            for (int w = 0; w < 4; ++w) { best2_insert(a0, a1, s_d[0][w], s_i[0][w], 0.f); best2_insert(a0, a1, s_d[1][w], s_i[1][w], 0.f); }
+            const size_t o = 2 * ((size_t)pd.out_off + qrow);
+            knn_idx[o] = a0.i; knn_idx[o + 1] = a1.i;
+            knn_dist[o] = a0.i >= 0 ? a0.d : FLT_MAX;
+            knn_dist[o + 1] = a1.i >= 0 ? a1.d : FLT_MAX;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Hamming 2-NN (ORB).  One thread per query row, descriptor words in VGPRs; the train row is
 // wave-uniform, so it is fetched through the scalar cache (s_load) and XOR'd against the VGPRs.
 // key = distance << 22 | train index: one u32 min orders by (distance, index) exactly.
@@ -1161,7 +1239,9 @@ int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairD
                          int32_t *knn_idx, float *knn_dist)
 {
     if (grid <= 0) return ESFM_OK;
-    if (dim % 4 == 0)
+    if (dim == 64 && flagged)
+        hipLaunchKernelGGL(l2_rescan64_kernel, dim3(grid), dim3(256), 0, st, desc, pairs, flagged, counters, knn_idx, knn_dist);
+    else if (dim % 4 == 0)
         hipLaunchKernelGGL(l2_exact_scan_kernel<true>, dim3(grid), dim3(256), 0, st, desc, dim, pairs, n_pairs, flagged, counters,
                            total_queries, knn_idx, knn_dist);
     else
