@@ -75,8 +75,8 @@ void *esfm_ctx_stream(esfm_ctx *ctx);
  * elapsed times of all launches since the last call for that kernel to
  * *total_ms / *launches (caller zero-initialises) and recycles the events. */
 typedef enum esfm_kernel_id {
-    ESFM_K_L2_KNN = 0,        /* l2_knn_mfma_kernel: MFMA distance pass + fused top-k + re-rank */
-    ESFM_K_HAMMING_KNN = 1,   /* hamming_knn_kernel                                             */
+    ESFM_K_L2_KNN = 0,        /* l2_knn_bf16_kernel (dim 64) / l2_knn_mfma_kernel: MFMA distance pass + fused top-k + re-rank */
+    ESFM_K_HAMMING_KNN = 1,   /* hamming_expand_kernel + hamming_knn_mfma_kernel / hamming_knn_kernel */
     ESFM_K_BA_LINEARIZE = 2,  /* ba_linearize_kernel: the Jacobian sweep                        */
     ESFM_K_BA_SCHUR = 3,      /* ba_schur_kernel                                                */
     ESFM_K_BA_SOLVE = 4,      /* ba_chol_solve_kernel                                           */
