@@ -9,7 +9,7 @@
 //   surf_integral_*_kernel    32-bit integral image, one row / column larger than the image (row scan, then column scan)
 //   surf_det_trace_kernel     box-filter Hessian determinant and trace of every pyramid layer (one thread per sample)
 //   surf_maxima_kernel        3 x 3 x 3 non-maximum suppression + quadratic refinement on the middle layers
-//   surf_describe_kernel      one wave per keypoint: dominant orientation, rotated window, area shrink to 21 x 21,
+//   surf_describe_kernel      one workgroup per keypoint: dominant orientation, rotated window, area shrink to 21 x 21,
 //                             weighted gradients, 4 x 4 x 4 sums, normalisation
 #include "surf_kernels.hpp"
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void surf_maxima_kernel(const SurfParams *__re
 }
 
 // One wave per keypoint (SURFInvoker::operator()).
-__global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
+__global__ __launch_bounds__(256) void surf_describe_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
                                                            const uint8_t *__restrict__ gray, const int32_t *__restrict__ sum,
                                                            SurfKeypoint *__restrict__ kps, const int64_t *__restrict__ win_offset,
                                                            uint8_t *__restrict__ win_scratch, float *__restrict__ desc)
@@ -180,12 +180,12 @@ __global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__r
     __shared__ float sVec[64];
     __shared__ float sDir;
     __shared__ int sN;
-    const int k = blockIdx.x, lane = threadIdx.x;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SurfKeypoint kp = kps[k];
     const int rows = P->rows, cols = P->cols, sr = rows + 1, sc = cols + 1;
     const float s = kp.size * 1.2f / 9.0f;
     const int grad_wav_size = 2 * cv_round_f(2 * s);
-    if (sr < grad_wav_size || sc < grad_wav_size) { if (lane == 0) kps[k].valid = 0; return; }
+    if (sr < grad_wav_size || sc < grad_wav_size) { if (tid == 0) kps[k].valid = 0; return; }
     // ---- dominant orientation
     SurfHF dx_t[2], dy_t[2];
     {
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__r
         }
     }
     int nangle = 0;
-    for (int base = 0; base < T->n_ori; base += 64) {   // sample order is preserved: the window sums below add in this order
+    if (wave == 0) {   // one wave: the ballot compaction keeps the sample order, in which the window sums below add
+    for (int base = 0; base < T->n_ori; base += 64) {
         const int kk = base + lane;
         bool ok = false;
         float vx = 0.f, vy = 0.f;
@@ -218,9 +219,12 @@ __global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__r
         if (ok) { sX[pos] = vx; sY[pos] = vy; sAng[pos] = fast_atan2(vy, vx); }
         nangle += __popcll(m);
     }
+    if (lane == 0) sN = nangle;
+    }
     __syncthreads();
-    if (nangle == 0) { if (lane == 0) kps[k].valid = 0; return; }
-    for (int w = lane; w < 72; w += 64) {
+    nangle = sN;
+    if (nangle == 0) { if (tid == 0) kps[k].valid = 0; return; }
+    for (int w = tid; w < 72; w += 256) {
         const int i = 5 * w;
         float sumx = 0.f, sumy = 0.f;
         for (int j = 0; j < nangle; ++j) {
@@ -230,38 +234,47 @@ __global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__r
         sSumX[w] = sumx; sSumY[w] = sumy; sMod[w] = sumx * sumx + sumy * sumy;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         float bestx = 0.f, besty = 0.f, best = 0.f;
         for (int w = 0; w < 72; ++w) if (sMod[w] > best) { best = sMod[w]; bestx = sSumX[w]; besty = sSumY[w]; }
         sDir = fast_atan2(-besty, bestx);
         kps[k].angle = sDir;
     }
     __syncthreads();
-    // ---- rotated window of (int)(21 s) pixels, bilinear; one lane per row so that the position accumulators are OpenCV's
+    // ---- rotated window of (int)(21 s) pixels, bilinear.  OpenCV walks each row with double accumulators (pixel_x += cos, pixel_y
+    // -= sin); a row is cut into chunks and the thread of a chunk first replays the additions up to its start, so every position
+    // is the same sum of the same terms in the same order, and a keypoint's 256 threads share its (up to 600 x 600) window
     const int win_size = (int)((kSurfPatch + 1) * s);
     uint8_t *win = win_scratch + win_offset[k];
     const float ddir = sDir * (float)(3.14159265358979323846 / 180);
     const float sin_dir = -(float)sin((double)ddir), cos_dir = (float)cos((double)ddir);
-    if (lane == 0) {
+    if (tid == 0) {
         const float win_off = -(float)(win_size - 1) / 2;
         float sx = kp.x + win_off * cos_dir + win_off * sin_dir, sy = kp.y - win_off * sin_dir + win_off * cos_dir;
         for (int i = 0; i < win_size; ++i, sx += sin_dir, sy += cos_dir) { sStartX[i] = sx; sStartY[i] = sy; }
     }
     __syncthreads();
     const int ncols1 = cols - 1, nrows1 = rows - 1;
-    for (int i = lane; i < win_size; i += 64) {
-        double pixel_x = sStartX[i], pixel_y = sStartY[i];
-        uint8_t *wrow = win + (size_t)i * win_size;
-        for (int j = 0; j < win_size; ++j, pixel_x += cos_dir, pixel_y -= sin_dir) {
-            const int ix = (int)floor(pixel_x), iy = (int)floor(pixel_y);
-            if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
-                const float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
-                const uint8_t *p = gray + (size_t)iy * cols + ix;
-                wrow[j] = (uint8_t)cv_round_f(p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) + p[cols] * (1.f - a) * b + p[cols + 1] * a * b);
-            } else {
-                int x = (int)rint(pixel_x), y = (int)rint(pixel_y);
-                x = x < 0 ? 0 : (x > ncols1 ? ncols1 : x); y = y < 0 ? 0 : (y > nrows1 ? nrows1 : y);
-                wrow[j] = gray[(size_t)y * cols + x];
+    {
+        int nch = (1024 + win_size / 2) / win_size;                       // about 1024 work items per keypoint
+        nch = nch < 1 ? 1 : (nch > 16 ? 16 : nch);
+        const int clen = (win_size + nch - 1) / nch;
+        for (int item = tid; item < win_size * nch; item += 256) {
+            const int i = item / nch, j0 = (item % nch) * clen, j1 = j0 + clen < win_size ? j0 + clen : win_size;
+            double pixel_x = sStartX[i], pixel_y = sStartY[i];
+            for (int j = 0; j < j0; ++j) { pixel_x += cos_dir; pixel_y -= sin_dir; }
+            uint8_t *wrow = win + (size_t)i * win_size;
+            for (int j = j0; j < j1; ++j, pixel_x += cos_dir, pixel_y -= sin_dir) {
+                const int ix = (int)floor(pixel_x), iy = (int)floor(pixel_y);
+                if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+                    const float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
+                    const uint8_t *p = gray + (size_t)iy * cols + ix;
+                    wrow[j] = (uint8_t)cv_round_f(p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) + p[cols] * (1.f - a) * b + p[cols + 1] * a * b);
+                } else {
+                    int x = (int)rint(pixel_x), y = (int)rint(pixel_y);
+                    x = x < 0 ? 0 : (x > ncols1 ? ncols1 : x); y = y < 0 ? 0 : (y > nrows1 ? nrows1 : y);
+                    wrow[j] = gray[(size_t)y * cols + x];
+                }
             }
         }
     }
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__r
             has_first = s1 - f1 > 1e-3; has_last = f2 - s2 > 1e-3;
             a_first = (float)((s1 - f1) / cell); a_mid = (float)(1.0 / cell); a_last = (float)(fmin(fmin(f2 - s2, 1.), cell) / cell);
         };
-        for (int o = lane; o < D * D; o += 64) {
+        for (int o = tid; o < D * D; o += 256) {
             const int dy = o / D, dx = o % D;
             int x1, x2, y1, y2; float axf, axm, axl, ayf, aym, ayl; bool hxf, hxl, hyf, hyl;
             cell_of(dx, x1, x2, axf, axm, axl, hxf, hxl);
@@ -300,29 +313,28 @@ __global__ __launch_bounds__(64) void surf_describe_kernel(const SurfParams *__r
         }
     }
     __syncthreads();
-    for (int o = lane; o < kSurfPatch * kSurfPatch; o += 64) {
+    for (int o = tid; o < kSurfPatch * kSurfPatch; o += 256) {
         const int i = o / kSurfPatch, j = o % kSurfPatch;
         const float dw = T->DW[o];
         sDX[i][j] = (sPatch[i][j + 1] - sPatch[i][j] + sPatch[i + 1][j + 1] - sPatch[i + 1][j]) * dw;
         sDY[i][j] = (sPatch[i + 1][j] - sPatch[i][j] + sPatch[i + 1][j + 1] - sPatch[i][j + 1]) * dw;
     }
     __syncthreads();
-    if (lane < 16) {
-        const int i = lane / 4, j = lane % 4;
+    if (tid < 16) {
+        const int i = tid / 4, j = tid % 4;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         for (int y = i * 5; y < i * 5 + 5; ++y)
             for (int x = j * 5; x < j * 5 + 5; ++x) { const float tx = sDX[y][x], ty = sDY[y][x]; v0 += tx; v1 += ty; v2 += fabsf(tx); v3 += fabsf(ty); }
-        sVec[4 * lane] = v0; sVec[4 * lane + 1] = v1; sVec[4 * lane + 2] = v2; sVec[4 * lane + 3] = v3;
+        sVec[4 * tid] = v0; sVec[4 * tid + 1] = v1; sVec[4 * tid + 2] = v2; sVec[4 * tid + 3] = v3;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         double square_mag = 0.0;
         for (int q = 0; q < 64; ++q) square_mag += sVec[q] * sVec[q];
         sDir = (float)(1. / (sqrt(square_mag) + DBL_EPSILON));
-        (void)sN;
     }
     __syncthreads();
-    desc[64 * (size_t)k + lane] = sVec[lane] * sDir;
+    if (tid < 64) desc[64 * (size_t)k + tid] = sVec[tid] * sDir;
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
@@ -370,7 +382,7 @@ int launch_surf_describe(hipStream_t st, const SurfParams *params_dev, const Sur
 {
     if (n_kp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_SURF_DESC);
-    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(64), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, win_scratch, desc);
+    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(256), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, win_scratch, desc);
     LAUNCH_OK();
     return ESFM_OK;
 }
