@@ -44,6 +44,53 @@ __global__ __launch_bounds__(256) void k(const u32x4 *in, float *out, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// phased variant: all 24 MFMAs of a step back to back, then the whole fold of the previous step's results
+template <int NE>
+__global__ __launch_bounds__(256) void kphase(const u32x4 *in, float *out, int iters)
+{
+    u32x4 av[4], bv[4];
+    for (int i = 0; i < 4; ++i) { av[i] = in[(threadIdx.x * 8 + i) & 4095]; bv[i] = in[(threadIdx.x * 8 + 4 + i) & 4095]; }
+    floatx16 acc0, acc1, p0, p1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = r; acc1[r] = r + 1; p0[r] = 1e30f; p1[r] = 1e30f; }
+    float k0 = 3e38f, k1 = 3e38f, k2 = 3e38f, j0 = 3e38f, j1 = 3e38f, j2 = 3e38f;
+    unsigned kmask = 0xFFFFFF00u;
+    asm volatile("" : "+v"(kmask));
+    for (int it = 0; it < iters; ++it) {
+        const int code = __builtin_amdgcn_readfirstlane((it & 15) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[m & 3]), __builtin_bit_cast(bf16x8, bv[(m + 1) & 3]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[(m + 2) & 3]), __builtin_bit_cast(bf16x8, bv[m & 3]), acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 12 * NE; ++e) {
+            const float key = __uint_as_float((__float_as_uint(p0[e & 15]) & kmask) | (unsigned)(code + (e & 15)));
+            k2 = __builtin_amdgcn_fmed3f(k1, k2, key); k1 = __builtin_amdgcn_fmed3f(k0, k1, key); k0 = __builtin_amdgcn_fmed3f(k0, key, -3e38f);
+            const float key1 = __uint_as_float((__float_as_uint(p1[e & 15]) & kmask) | (unsigned)(code + (e & 15)));
+            j2 = __builtin_amdgcn_fmed3f(j1, j2, key1); j1 = __builtin_amdgcn_fmed3f(j0, j1, key1); j0 = __builtin_amdgcn_fmed3f(j0, key1, -3e38f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        floatx16 t0 = p0, t1 = p1; p0 = acc0; p1 = acc1; acc0 = t0; acc1 = t1;
+    }
+    float s = k0 + k1 + k2 + j0 + j1 + j2;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r] + p0[r] + p1[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NE> void runphase(const u32x4 *in, float *d, int waves_per_simd, const char *data)
+{
+    const int iters = 2000, grid = 256 * waves_per_simd;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kphase<NE>), dim3(grid), dim3(256), 0, 0, in, d, 500);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kphase<NE>), dim3(grid), dim3(256), 0, 0, in, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double cyc = ms * 1e-3 * 2.4e9 / (double(iters) * 24 * waves_per_simd);
+    printf("%-8s PHASED: 24 MFMAs then fold of %d elements per MFMA (VALU per MFMA %2d)  waves/SIMD %d : %7.3f ms  %6.1f cycles@2.4GHz per MFMA per SIMD\n", data, NE, 4 * NE, waves_per_simd, ms, cyc);
+}
+
 template <int NACC>
 __global__ __launch_bounds__(256) void kacc(const u32x4 *in, float *out, int iters)
 {
@@ -76,9 +123,9 @@ template <int NACC> void runacc(const u32x4 *in, float *d, int waves_per_simd, c
 
 template <int NE> void run(const u32x4 *in, float *d, int waves_per_simd, const char *data)
 {
-    const int iters = 400, grid = 256 * waves_per_simd;
+    const int iters = 2000, grid = 256 * waves_per_simd;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<NE>), dim3(grid), dim3(256), 0, 0, in, d, 20);
+    hipLaunchKernelGGL((k<NE>), dim3(grid), dim3(256), 0, 0, in, d, 500);
     hipEventRecord(e0);
     hipLaunchKernelGGL((k<NE>), dim3(grid), dim3(256), 0, 0, in, d, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
@@ -102,6 +149,7 @@ int main()
         const char *name = pass ? "random" : "const";
         for (int w = 1; w <= 2; ++w) { run<0>(in, d, w, name); run<1>(in, d, w, name); run<2>(in, d, w, name); }
         run<1>(in, d, 3, name); run<1>(in, d, 4, name);
+        for (int w = 1; w <= 4; w *= 2) { runphase<1>(in, d, w, name); runphase<2>(in, d, w, name); }
         for (int w = 1; w <= 4; w *= 2) { runacc<1>(in, d, w, name); runacc<2>(in, d, w, name); runacc<4>(in, d, w, name); }
     }
     return 0;
