@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -24,6 +25,7 @@
 #include <vector>
 
 #include "../../include/esfm.h"
+#include "esfm_png.hpp"
 
 namespace p3dv {
 
@@ -36,7 +38,11 @@ struct DMatch {  // cv::DMatch
 };
 
 struct Point2f { float x = 0.f, y = 0.f; };
-struct KeyPoint { Point2f pt; };  // cv::KeyPoint (only .pt is read on this path, ba.cpp:37)
+struct KeyPoint {  // cv::KeyPoint (only .pt is read downstream, ba.cpp:37)
+    Point2f pt;
+    float size = 0.f, angle = -1.f, response = 0.f;
+    int octave = 0, class_id = -1;
+};
 
 // cv::Mat restricted to what descriptors need: CV_32F (SURF, N x 64) or CV_8U (ORB, N x 32), continuous
 struct DescMat {
@@ -116,6 +122,32 @@ inline esfm_ctx *default_ctx()
 // ---- matching (feature_matching.h:17-21) ----------------------------------------------------------
 class FeatureMatching {
 public:
+    // feature_matching.cpp:43-69: SURF::create(minHessian)->detect + SURF::create()->compute on cur_frame.rgb_image (BGR)
+    bool detectFeaturesSURF(frame_t &cur_frame, int minHessian = 400, bool show = false)
+    {
+        (void)show;
+        const ImageMat &img = cur_frame.rgb_image;
+        if (img.empty()) { std::cerr << "frame has no image" << std::endl; return false; }
+        const int cap = img.rows * img.cols / 4 + 1024;
+        std::vector<float> kp(size_t(7) * size_t(cap)), desc(size_t(64) * size_t(cap));
+        int32_t n = 0;
+        if (esfm_surf_detect_and_compute(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, double(minHessian), cap, kp.data(),
+                                         desc.data(), &n) != ESFM_OK) {
+            std::cerr << esfm_last_error() << std::endl;
+            return false;
+        }
+        cur_frame.keypoints.resize(size_t(n));
+        for (int k = 0; k < n; ++k) {
+            KeyPoint &q = cur_frame.keypoints[size_t(k)];
+            const float *v = &kp[size_t(7) * size_t(k)];
+            q.pt.x = v[0]; q.pt.y = v[1]; q.size = v[2]; q.angle = v[3]; q.response = v[4]; q.octave = int(v[5]); q.class_id = int(v[6]);
+        }
+        cur_frame.descriptors.create(n, 64, DescMat::F32);
+        if (n) std::memcpy(cur_frame.descriptors.ptr<float>(), desc.data(), sizeof(float) * size_t(64) * size_t(n));
+        if (!quiet) std::cout << "Found " << n << " features." << std::endl;
+        return true;
+    }
+
     bool matchFeaturesORB(frame_t &cur_frame_1, frame_t &cur_frame_2, std::vector<DMatch> &matches, double ratio_thre = 0.8,
                           bool show = false)
     {
@@ -233,6 +265,47 @@ public:
 // pcl/io/ply_io.cpp, restated from memory -- the reference ships no example file].
 class DataIO {
 public:
+    // data_io.cpp:17-46: whitespace-separated file names, each joined with the folder; frame ids count up from 0
+    bool importImageFilenames(const std::string image_list_path, const std::string image_data_path, std::vector<frame_t> &frames)
+    {
+        std::ifstream image_list_file(image_list_path.c_str(), std::ios::in);
+        if (!image_list_file.is_open()) { std::cout << "open image_list_file failed, file is: " << image_list_path << std::endl; return 0; }
+        int count = 0;
+        std::string cur_file;
+        while (image_list_file >> cur_file) {
+            frames.push_back(frame_t(unsigned(count), image_data_path + "/" + cur_file));
+            std::cout << count << ": " << frames.back().image_file_path << std::endl;
+            ++count;
+        }
+        std::cout << "Frame number is " << frames.size() << std::endl;
+        return 1;
+    }
+
+    // data_io.cpp:48-72: cv::imread(path, CV_LOAD_IMAGE_COLOR) -> 8-bit BGR (PNG files; esfm_png.hpp)
+    bool importImages(frame_t &cur_frame, bool show = false)
+    {
+        (void)show;
+        ImageMat &img = cur_frame.rgb_image;
+        img.channels = 3;
+        const std::string err = png::read_bgr(cur_frame.image_file_path, img.rows, img.cols, img.data);
+        if (!err.empty()) { img = ImageMat(); std::cout << "No more images" << " (" << err << ")" << std::endl; return false; }
+        return true;
+    }
+
+    // data_io.cpp:74-95: up to three rows of three numbers into K (later rows of a longer file are ignored)
+    bool importCalib(const std::string &fileName, Matrix3f &K_mat)
+    {
+        std::ifstream in(fileName, std::ios::in);
+        if (!in) return false;
+        for (int i = 0; i < 3; ++i) {
+            float a, b, c;
+            if (!(in >> a >> b >> c)) break;
+            K_mat(i, 0) = a; K_mat(i, 1) = b; K_mat(i, 2) = c;
+        }
+        std::cout << "Import camera calibration file done." << std::endl;
+        return true;
+    }
+
     bool writePlyFile(const std::string &fileName, const std::vector<PointXYZRGB> &pointCloud)
     {
         std::ofstream fs(fileName);
@@ -346,9 +419,20 @@ public:
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { P1[4 * r + c] = cur_frame_1.pose_cam(r, c); P2[4 * r + c] = cur_frame_2.pose_cam(r, c); }
         std::vector<float> h(size_t(4) * size_t(std::max(count_new, 1)));
         if (count_new > 0 && esfm_triangulate_points(default_ctx(), P1, P2, a.data(), b.data(), count_new, h.data()) != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        const ImageMat &img = cur_frame_1.rgb_image;
         for (int i = 0; i < count_new; ++i) {
             PointXYZRGB p;
             p.x = h[size_t(4 * i)] / h[size_t(4 * i + 3)]; p.y = h[size_t(4 * i + 1)] / h[size_t(4 * i + 3)]; p.z = h[size_t(4 * i + 2)] / h[size_t(4 * i + 3)];
+            if (!img.empty() && img.channels == 3) {
+                // colour from frame 1's image at the keypoint of matches[i] -- the reference indexes the match list with the
+                // index of the i-th NEW point (estimate_motion.cpp:345), which is another match once any was skipped
+                const Point2f &px = cur_frame_1.keypoints[size_t(matches[size_t(i)].queryIdx)].pt;
+                const int y = int(px.y), x = int(px.x);
+                if (y >= 0 && y < img.rows && x >= 0 && x < img.cols) {
+                    const uint8_t *bgr = &img.data[(size_t(y) * size_t(img.cols) + size_t(x)) * 3];
+                    p.b = bgr[0]; p.g = bgr[1]; p.r = bgr[2];
+                }
+            }
             sparse_pointcloud.points.push_back(p);
         }
         if (!quiet) std::cout << "Triangulate [ " << count_new << " ] new points, [ " << sparse_pointcloud.points.size() << " ] points in total." << std::endl;

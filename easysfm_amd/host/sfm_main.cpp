@@ -1,0 +1,206 @@
+// ./bin/sfm_native -- the reference executable's command line (cpp_code/test/sfm.cpp:32-50, cpp_code/script/run_fountain_small.sh:22-24)
+// as a native C++ program over the C ABI of libesfm_hip.so, through the host mirror of the reference's classes
+// (esfm_host.hpp).  Same thirteen positional arguments in the same order, same ASCII .ply of PointXYZRGB at argv[5], exit
+// status 1 on success like the reference (sfm.cpp:339).  The control flow is the one of
+// easysfm_amd/pipeline.py (the Python twin of this file), pair by pair as the reference runs it:
+//   import -> undistort -> SURF -> all-pairs match + 5-point RANSAC + depth -> track ids -> initial pair -> triangulate -> BA
+//   -> (next frame by PnP -> triangulate against every registered frame -> periodic BA)* -> final BA -> SOR -> .ply
+// Differences from the reference, printed at run time: feature type O (ORB) is not built (cv::ORB's learned sampling pattern
+// ships only inside OpenCV); the viewer arguments are accepted and ignored (no display); only PNG images are read.
+//   bin/sfm_native --dump-image in.png out.raw   writes rows, cols (int32) and the BGR bytes: the decoder's test hook
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "esfm_host.hpp"
+
+using namespace p3dv;
+
+namespace {
+
+struct frame_pair_t {  // utility.h:57-78
+    std::vector<DMatch> matches;
+    Matrix4f T_21 = Matrix4f::Identity();
+    double appro_depth = 1.0;
+};
+
+Matrix4f mul(const Matrix4f &a, const Matrix4f &b)
+{
+    Matrix4f c;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s += a(i, k) * b(k, j);
+            c(i, j) = s;
+        }
+    return c;
+}
+
+int dump_image(const char *in, const char *out)
+{
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> bgr;
+    const std::string err = png::read_bgr(in, rows, cols, bgr);
+    if (!err.empty()) { std::cerr << err << std::endl; return 3; }
+    std::ofstream f(out, std::ios::binary);
+    const int32_t hdr[2] = {rows, cols};
+    f.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
+    f.write(reinterpret_cast<const char *>(bgr.data()), std::streamsize(bgr.size()));
+    return f ? 0 : 3;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc == 4 && std::string(argv[1]) == "--dump-image") return dump_image(argv[2], argv[3]);
+    if (argc != 14) {
+        std::cerr << "usage: sfm_native image_folder image_list calib_K_file calib_distort_file output.ply feature_type(S) feature_parameter "
+                     "repro_dis_ransac find_init_frames ba_calib_change_tolerance ba_frequency launch_viewer view_sphere" << std::endl;
+        return 2;
+    }
+    const std::string image_data_path = argv[1], image_list_path = argv[2], calib_file_path = argv[3], distort_file_path = argv[4],
+                      output_file_path = argv[5];
+    char using_feature = argv[6][0];
+    const int feature_extract_parameter = std::atoi(argv[7]);
+    const double ransac_reproj_distance = std::atof(argv[8]);
+    const bool use_track_frames_as_init = std::atoi(argv[9]) != 0;
+    const double fix_calib_tolerance_BA = std::atof(argv[10]);
+    const int frequency_BA = std::max(1, std::atoi(argv[11]));
+    if (using_feature == 'O') { std::cerr << "feature type O (ORB) is not built: cv::ORB's learned sampling pattern ships only inside OpenCV; use S" << std::endl; return 3; }
+    if (using_feature != 'S') { std::cout << "Wrong feature input. Use SURF as default feature." << std::endl; using_feature = 'S'; }
+
+    try {
+        DataIO io;
+        FeatureMatching fm;
+        MotionEstimator ee;
+        std::vector<frame_t> frames;
+        if (!io.importImageFilenames(image_list_path, image_data_path, frames) || frames.size() < 2) { std::cerr << "need at least two images" << std::endl; return 3; }
+        const int frame_number = int(frames.size());
+        Matrix3f K_mat = Matrix3f::Identity();
+        if (!io.importCalib(calib_file_path, K_mat)) { std::cerr << "cannot read the calibration file " << calib_file_path << std::endl; return 3; }
+        DistortMat distort_coeff;
+        if (!io.importDistort(distort_file_path, distort_coeff)) std::cout << "No distortion coefficients imported. Use defualt one (0)." << std::endl;
+
+        // ---- per frame: import, undistort, SURF (sfm.cpp:84-126)
+        std::cout << "Begin feature extraction" << std::endl;
+        for (int i = 0; i < frame_number; ++i) {
+            if (!io.importImages(frames[size_t(i)], false)) return 3;
+            frames[size_t(i)].K_cam = K_mat;
+            if (!ee.doUnDistort(frames[size_t(i)], distort_coeff)) return 3;
+            std::cout << "Feature extraction of Frame [ " << i << " ]" << std::endl;
+            if (!fm.detectFeaturesSURF(frames[size_t(i)], feature_extract_parameter)) return 3;
+            frames[size_t(i)].init_pixel_ids();
+        }
+        std::cout << "Feature extraction done" << std::endl;
+
+        // ---- all pairs (i, j < i): match, verify, relative depth (sfm.cpp:140-167)
+        const int num_min_pair = 20;
+        const size_t nf = size_t(frame_number);
+        std::vector<std::vector<frame_pair_t>> graph(nf, std::vector<frame_pair_t>(nf));
+        for (int i = 0; i < frame_number; ++i)
+            for (int j = 0; j < i; ++j) {
+                frame_pair_t &g = graph[size_t(i)][size_t(j)];
+                std::vector<DMatch> temp_matches, inlier_matches;
+                fm.matchFeaturesSURF(frames[size_t(i)], frames[size_t(j)], temp_matches);
+                if (int(temp_matches.size()) > num_min_pair) {
+                    Matrix4f T = Matrix4f::Identity();
+                    if (ee.estimate2D2D_E5P_RANSAC(frames[size_t(i)], frames[size_t(j)], temp_matches, inlier_matches, T, ransac_reproj_distance)) {
+                        g.T_21 = T;
+                        double depth = 1.0;
+                        if (ee.getDepthFast(frames[size_t(i)], frames[size_t(j)], T, inlier_matches, depth)) g.appro_depth = depth;
+                        g.matches.swap(inlier_matches);
+                        if (!g.matches.empty()) std::cout << "Pair ( " << i << " , " << j << " ): [" << g.matches.size() << "] verified matches." << std::endl;
+                    }
+                }
+            }
+
+        // ---- track ids (sfm.cpp:173-216): a keypoint takes the id of its verified match in an earlier frame unless the frame
+        // already uses that id; the rest get fresh ids
+        size_t total_kp = 0;
+        for (const frame_t &f : frames) total_kp += f.keypoints.size();
+        std::vector<std::vector<bool>> track(nf, std::vector<bool>(std::max<size_t>(total_kp, 1), false));
+        int cur_id = 0;
+        for (int i = 0; i < frame_number; ++i) {
+            frame_t &fi = frames[size_t(i)];
+            for (int j = 0; j < i; ++j) {
+                const frame_t &fj = frames[size_t(j)];
+                for (const DMatch &m : graph[size_t(i)][size_t(j)].matches) {
+                    const int tid = fj.unique_pixel_ids[size_t(m.trainIdx)];
+                    int &mine = fi.unique_pixel_ids[size_t(m.queryIdx)];
+                    if (mine >= 0 && mine == tid) continue;
+                    bool is_duplicated = false;
+                    for (int v : fi.unique_pixel_ids) if (v == tid) { is_duplicated = true; break; }
+                    if (!is_duplicated) { mine = tid; fi.unique_pixel_has_match[size_t(m.queryIdx)] = true; }
+                }
+            }
+            int fresh = 0;
+            for (size_t k = 0; k < fi.unique_pixel_ids.size(); ++k) {
+                if (fi.unique_pixel_ids[k] < 0) fi.unique_pixel_ids[k] = cur_id + fresh++;
+                track[size_t(i)][size_t(fi.unique_pixel_ids[k])] = true;
+            }
+            cur_id += fresh;
+        }
+        std::cout << "The total unique feature point number is " << cur_id << std::endl;
+
+        // ---- initial pair (sfm.cpp:218-247)
+        int init_1 = 1, init_2 = 0;
+        double depth_init = 10.0;
+        if (use_track_frames_as_init) {
+            std::vector<std::vector<double>> depth(nf, std::vector<double>(nf, 0.0));
+            for (int i = 0; i < frame_number; ++i) for (int j = 0; j < i; ++j) depth[size_t(i)][size_t(j)] = graph[size_t(i)][size_t(j)].appro_depth;
+            fm.findInitializeFramePair(track, frames, depth, init_1, init_2, depth_init);
+        }
+        std::cout << "Initialization frames: [ " << init_1 << " ] and [ " << init_2 << " ]" << std::endl;
+        pointcloud_sparse_t cloud;
+        frames[size_t(init_1)].pose_cam = Matrix4f::Identity();
+        frames[size_t(init_2)].pose_cam = mul(graph[size_t(init_1)][size_t(init_2)].T_21, frames[size_t(init_1)].pose_cam);
+        ee.doTriangulation(frames[size_t(init_1)], frames[size_t(init_2)], graph[size_t(init_1)][size_t(init_2)].matches, cloud);
+        std::vector<bool> todo(nf, true);
+        todo[size_t(init_1)] = todo[size_t(init_2)] = false;
+        BundleAdjustment ba;
+        ba.doSFMBA(frames, todo, cloud, fix_calib_tolerance_BA);
+
+        // ---- register the remaining frames (sfm.cpp:262-321)
+        int remaining = frame_number - 2;
+        double reproj = ransac_reproj_distance;
+        while (remaining > 0) {
+            int nxt = -1;
+            fm.findNextFrame(track, todo, cloud.unique_point_ids, nxt);
+            if (nxt < 0) break;                      // no unregistered frame sees the map (the reference would index with an uninitialised value)
+            const bool ok = ee.estimate2D3D_P3P_RANSAC(frames[size_t(nxt)], cloud, reproj);
+            reproj += 1.0;
+            for (int i = 0; i < frame_number; ++i) {
+                if (todo[size_t(i)]) continue;
+                if (nxt > i) ee.doTriangulation(frames[size_t(nxt)], frames[size_t(i)], graph[size_t(nxt)][size_t(i)].matches, cloud);
+                else ee.doTriangulation(frames[size_t(i)], frames[size_t(nxt)], graph[size_t(i)][size_t(nxt)].matches, cloud);
+            }
+            if (!ok) ee.outlierFilter(cloud);
+            todo[size_t(nxt)] = false;
+            --remaining;
+            if (remaining % frequency_BA == 0) {
+                ba.initBA();
+                ba.doSFMBA(frames, todo, cloud, fix_calib_tolerance_BA);
+                reproj = ransac_reproj_distance;
+            }
+            std::cout << "Progress: [ " << frame_number - remaining << " / " << frame_number << " ]" << std::endl;
+        }
+        ba.doSFMBA(frames, todo, cloud);
+
+        // ---- final cloud: SOR filter, .ply (sfm.cpp:329-337)
+        std::vector<PointXYZRGB> filtered;
+        CProceesing<PointXYZRGB> cp;
+        if (!cp.SORFilter(cloud.points, filtered)) return 3;
+        const std::filesystem::path out_dir = std::filesystem::path(output_file_path).parent_path();
+        if (!out_dir.empty()) std::filesystem::create_directories(out_dir);
+        if (!io.writePlyFile(output_file_path, filtered)) return 3;
+    } catch (const std::exception &e) {       // 1 is the reference's SUCCESS status: a failure must not look like one
+        std::cerr << "sfm_native: " << e.what() << std::endl;
+        return 3;
+    }
+    return 1;
+}

@@ -279,7 +279,8 @@ class MotionEstimator:
             if rgb_image is not None:
                 for i in range(len(new_ids)):
                     px = k1[matches[i].queryIdx]                                  # :345, the reference's indexing
-                    b, g, r = rgb_image[int(px[1]), int(px[0])][:3]
+                    v = np.asarray(rgb_image)[int(px[1]), int(px[0])]
+                    b, g, r = (v, v, v) if np.ndim(v) == 0 else v[:3]                # a gray image colours its points gray
                     rgb[i] = (r, g, b)
             old_xyz = np.asarray(sparse_pointcloud.xyz, np.float32).reshape(-1, 3)
             old_rgb = np.asarray(sparse_pointcloud.rgb, np.uint8).reshape(-1, 3)

@@ -129,17 +129,25 @@ def run_sfm(frames: List[Frame], output_file: Optional[str] = None, use_feature:
     for f in frames:
         f.init_pixel_ids()
     graph = match_and_verify_all_pairs(frames, use_feature, ransac_reproj_distance, 20, ctx)
-    track, _ = propagate_track_ids(frames, graph)
+    track, n_unique = propagate_track_ids(frames, graph)
+    if verbose:
+        for i in range(len(frames)):
+            for j in range(i):
+                if graph[i][j].matches:
+                    print(f"Pair ( {i} , {j} ): [{len(graph[i][j].matches)}] verified matches.")
+        print(f"The total unique feature point number is {n_unique}")
     init_1, init_2, depth_init = 1, 0, 10.0
     if use_track_frames_as_init:
         found, a, b, d = fm.findInitializeFramePair(track, frames, [[p.appro_depth for p in row] + [0.0] * (len(frames) - len(row)) for row in graph])
         init_1, init_2 = a, b
         if found:
             depth_init = d
+    if verbose:
+        print(f"Initialization frames: [ {init_1} ] and [ {init_2} ]")
     cloud = SparsePointCloud()
     frames[init_1].pose_cam = np.eye(4, dtype=np.float32)
     frames[init_2].pose_cam = (graph[init_1][init_2].T_21 @ frames[init_1].pose_cam).astype(np.float32)
-    ee.doTriangulation(frames[init_1], frames[init_2], graph[init_1][init_2].matches, cloud)
+    ee.doTriangulation(frames[init_1], frames[init_2], graph[init_1][init_2].matches, cloud, rgb_image=frames[init_1].rgb_image)
     todo = [True] * len(frames)
     todo[init_1] = todo[init_2] = False
     ba = BundleAdjustment(ctx)
@@ -155,9 +163,9 @@ def run_sfm(frames: List[Frame], output_file: Optional[str] = None, use_feature:
         for i in range(len(frames)):
             if not todo[i]:
                 if nxt > i:
-                    ee.doTriangulation(frames[nxt], frames[i], graph[nxt][i].matches, cloud)
+                    ee.doTriangulation(frames[nxt], frames[i], graph[nxt][i].matches, cloud, rgb_image=frames[nxt].rgb_image)
                 else:
-                    ee.doTriangulation(frames[i], frames[nxt], graph[i][nxt].matches, cloud)
+                    ee.doTriangulation(frames[i], frames[nxt], graph[i][nxt].matches, cloud, rgb_image=frames[i].rgb_image)
         if not ok:
             ee.outlierFilter(cloud)
         todo[nxt] = False

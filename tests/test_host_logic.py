@@ -1,10 +1,14 @@
 """Host-side logic above the C ABI that needs no GPU: pair-list / point sharding and the reference's
 observation derivation (setBAProblem, ba.cpp:22-56).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
 import easysfm_amd as E
 from easysfm_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_pair_list_is_the_reference_loop():
@@ -247,3 +251,50 @@ def test_import_distort_reproduces_the_float_into_double_storage(tmp_path):
     c = E.import_distort(str(p))
     assert np.array_equal(c.view(np.float32)[:4], np.array([5, 6, 3, 4], np.float32))
     assert E.import_distort(str(tmp_path / "none")) is None
+
+
+def _build_native(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "sfm_native")
+    cmd = ["g++", "-O2", "-std=c++17", os.path.join(ROOT, "easysfm_amd", "host", "sfm_main.cpp"), "-o", exe,
+           os.path.join(ROOT, "easysfm_amd", "libesfm_hip.so"), "-lz", "-Wl,-rpath," + os.path.join(ROOT, "easysfm_amd"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return exe
+
+
+def test_native_png_reader_matches_pil(tmp_path):
+    """The C++ executable's PNG reader (easysfm_amd/host/esfm_png.hpp, cv::imread(..., COLOR) for the reference's inputs): RGB,
+    gray, RGBA, palette and 16-bit files come out as the same 8-bit BGR pixels PIL decodes; a non-PNG is refused."""
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    exe = _build_native(tmp_path)
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    rgb[5:20, 10:40] = (rgb[5:20, 10:40] // 32) * 32                 # smooth areas: exercises the sub / up / average / Paeth filters
+    cases = {
+        "rgb.png": (PIL.fromarray(rgb), rgb[:, :, ::-1]),
+        "gray.png": (PIL.fromarray(rgb[:, :, 0]), np.stack([rgb[:, :, 0]] * 3, axis=2)),
+        "rgba.png": (PIL.fromarray(np.dstack([rgb, rng.integers(0, 256, (37, 53), dtype=np.uint8)]), "RGBA"), rgb[:, :, ::-1]),
+    }
+    pal = PIL.fromarray(rgb).quantize(16)
+    cases["palette.png"] = (pal, np.asarray(pal.convert("RGB"))[:, :, ::-1])
+    bw = PIL.fromarray(rgb[:, :, 1]).convert("1")
+    cases["bilevel.png"] = (bw, np.stack([np.asarray(bw.convert("L"))] * 3, axis=2))
+    g16 = (rng.integers(0, 65536, (21, 34))).astype(np.uint16)
+    cases["gray16.png"] = (PIL.fromarray(g16), np.stack([(g16 >> 8).astype(np.uint8)] * 3, axis=2))
+    for name, (im, want) in cases.items():
+        path = str(tmp_path / name)
+        im.save(path)
+        out = str(tmp_path / (name + ".raw"))
+        r = subprocess.run([exe, "--dump-image", path, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, (name, r.stdout)
+        raw = np.fromfile(out, np.uint8)
+        rows, cols = np.frombuffer(raw[:8].tobytes(), np.int32)
+        got = raw[8:].reshape(rows, cols, 3)
+        assert np.array_equal(got, np.ascontiguousarray(want)), name
+    bad = tmp_path / "not.png"
+    bad.write_bytes(b"JFIF" * 10)
+    r = subprocess.run([exe, "--dump-image", str(bad), str(tmp_path / "x.raw")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 3 and "not a PNG" in r.stdout
