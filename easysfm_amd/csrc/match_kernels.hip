@@ -505,22 +505,25 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         k1[s] = __builtin_amdgcn_fmed3f(k0[s], k1[s], key);
         k0[s] = __builtin_amdgcn_fmed3f(k0[s], key, -kBig);
     };
-    auto master_insert = [&](int s, float key, int seg_sub0) {
-        const int code = (int)(__float_as_uint(key) & 0xFFu);
-        const int r = code & 15;
-        const int t = (seg_sub0 + (code >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    // the master keeps (key, first step of the key's segment); the train row is decoded from the two once, at the end
+    auto master_insert = [&](int s, float key, int seg_sub0 /* wave-uniform */) {
         const bool live = key < 1.0e38f;
         const bool l2 = live && key < v2[s], l1 = live && key < v1[s], l0 = live && key < v0[s];
-        const int t2 = l2 ? t : c2[s];
-        const int t1 = l1 ? t : c1[s];
+        const int t2 = l2 ? seg_sub0 : c2[s];
+        const int t1 = l1 ? seg_sub0 : c1[s];
         c2[s] = l1 ? c1[s] : t2;
         c1[s] = l0 ? c0[s] : t1;
-        c0[s] = l0 ? t : c0[s];
+        c0[s] = l0 ? seg_sub0 : c0[s];
         const float n2 = l2 ? key : v2[s];
         const float n1 = l1 ? key : v1[s];
         v2[s] = l1 ? v1[s] : n2;
         v1[s] = l0 ? v0[s] : n1;
         v0[s] = l0 ? key : v0[s];
+    };
+    auto train_row_of = [&](float key, int seg_sub0) {
+        const int code = (int)(__float_as_uint(key) & 0xFFu);
+        const int r = code & 15;
+        return key < 1.0e38f ? (seg_sub0 + (code >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h : -1;
     };
     auto flush = [&](int seg_sub0) {
 #pragma unroll
@@ -677,12 +680,23 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         float ed[3], ed2[3];
         int ei[3];
         {
-            const int cc[3] = {c0[s], c1[s], c2[s]};
+            const float vk[3] = {v0[s], v1[s], v2[s]};
+            const int cc[3] = {train_row_of(v0[s], c0[s]), train_row_of(v1[s], c1[s]), train_row_of(v2[s], c2[s])};
+            // Only candidates that can be among the two nearest are re-ranked.  With ka <= kb the two smallest of the query's six
+            // keys, both of their exact d^2 are <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-14 |k| being the
+            // certificate's bound on |(|q|^2 + key) - d^2|; a candidate with |q|^2 + k - E(k) > U (1 + 2^-20) is farther than
+            // both even after sqrtf's rounding.  Typically one candidate per lane survives instead of three.
+            const float p0 = __shfl_xor(vk[0], 32), p1 = __shfl_xor(vk[1], 32);
+            const float kb = fminf(fmaxf(vk[0], p0), fminf(vk[1], p1));
+            const double qn = (double)norms[pd.q_row0 + (qvalid ? qrow : 0)];
+            const double e1 = (qn + (double)tmax) * (1.0 / 32768.0);
+            const double U = (qn + (double)kb + e1 + fabs((double)kb) * (1.0 / 16384.0)) * (1.0 + 1.0 / 1048576.0);
             const float *qp = Q + (size_t)(qvalid ? qrow : 0) * DIM;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 ei[m] = -1; ed[m] = FLT_MAX; ed2[m] = 0.f;
-                if (cc[m] >= 0 && qvalid) {
+                const bool cannot = (qn + (double)vk[m] - e1 - fabs((double)vk[m]) * (1.0 / 16384.0)) > U;   // false on NaN: re-rank
+                if (cc[m] >= 0 && qvalid && !cannot) {
                     const int t = cc[m];
                     const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
                     ei[m] = t; ed2[m] = d2; ed[m] = sqrt_rn_f32(d2);
