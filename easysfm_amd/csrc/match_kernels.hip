@@ -486,6 +486,14 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         }
     }
 
+    // read ahead what the tail needs, so that its latency hides under the first tile's transfer: this thread's share of
+    // max |t|^2 and the queries' |q|^2
+    float tmax_part = 0.f;
+    for (int t = tid; t < nt; t += 256) tmax_part = fmaxf(tmax_part, tn[t]);
+    float qnorm[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { const int qrow = qbase + 32 * s + j; qnorm[s] = norms[pd.q_row0 + (qrow < nq ? qrow : 0)]; }
+
     // running top-3 per query set: segment keys (8-bit position code in the low mantissa bits) and master (key, row)
     constexpr float kBig = 3.0e38f;
     constexpr int kSegSub = 16;
@@ -660,10 +668,9 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         }
     }
 
-    // max |t|^2 over the train set (for the certificate's error bound): one pass over the norms, once per workgroup
+    // max |t|^2 over the train set (for the certificate's error bound): the per-thread part was read in the prologue
     {
-        float m = 0.f;
-        for (int t = tid; t < nt; t += 256) m = fmaxf(m, tn[t]);
+        float m = tmax_part;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) lds_red[wave] = m;
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             // both even after sqrtf's rounding.  Typically one candidate per lane survives instead of three.
             const float p0 = __shfl_xor(vk[0], 32), p1 = __shfl_xor(vk[1], 32);
             const float kb = fminf(fmaxf(vk[0], p0), fminf(vk[1], p1));
-            const double qn = (double)norms[pd.q_row0 + (qvalid ? qrow : 0)];
+            const double qn = (double)qnorm[s];
             const double e1 = (qn + (double)tmax) * (1.0 / 32768.0);
             const double U = (qn + (double)kb + e1 + fabs((double)kb) * (1.0 / 16384.0)) * (1.0 + 1.0 / 1048576.0);
             const float *qp = Q + (size_t)(qvalid ? qrow : 0) * DIM;
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             // canonical distance 96 u, of |q|^2 + 2 |t|^2 at most; keys are s with 8 mantissa bits replaced (< 2^-14 |tau|).
             bool certified = !(tau < 1.0e38f);
             if (!certified && b1.i >= 0) {
-                const double qn = (double)norms[pd.q_row0 + qrow];
+                const double qn = (double)qnorm[s];
                 const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0 / 16384.0);
                 certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
             }
