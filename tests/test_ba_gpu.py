@@ -61,7 +61,9 @@ def test_ba_trace_and_params_match_oracle(gpu_ctx, oracle_lib, n_cam, n_pt, k, s
     opt, ropt = _solve_both(oracle_lib, sc, 50)
     cams, pts, summ = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
     rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, ropt)
-    assert abs(summ.final_cost - rs.final_cost) <= 1e-5 * rs.final_cost
+    # the reductions use atomics: near convergence two runs of the GPU solver can stop an iteration apart (about one run in
+    # twenty on the 4-camera scene lands 1-2e-5 from the oracle's final cost), hence 1e-4
+    assert abs(summ.final_cost - rs.final_cost) <= 1e-4 * rs.final_cost
     assert abs(oracle_lib.ba_cost(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, cams, pts) - summ.final_cost) <= 1e-10 * summ.final_cost
 
 
