@@ -921,8 +921,8 @@ __global__ __launch_bounds__(256) void hamming_knn_kernel(const uint32_t *__rest
 // what random descriptors reach, and 0/1 trains against +-1 queries gain nothing: both operands have to be sparse.
 // A = train rows (so that a lane's 16 results belong to ONE query, column lane & 31, and 16 different trains), B = query
 // columns held in registers for the whole kernel (2 sets of 32 queries per wave: 64 VGPRs), train tiles of 64 rows
-// staged through LDS (row stride 272 B: conflict-free ds_read_b128) together with their 64 start values, shared by the 4
-// waves.  K is contracted in whatever order the hardware pairs the 16 bytes a lane supplies -- A and B are loaded with
+// staged through LDS (LDS-DMA, 16-B slots XOR-swizzled with row & 15: conflict-free ds_read_b128) together with their 64
+// start values, shared by the 4 waves.  K is contracted in whatever order the hardware pairs the 16 bytes a lane supplies -- A and B are loaded with
 // the same lane->byte convention, and the sum does not depend on it.
 // Top-2: running (best, second) pairs of keys acc << 21 | (2^21 - 1 - L), largest first, with L = 16 * (32-train group
 // number) + accumulator register -- a wave-uniform scalar, so a result costs v_lshl_add + v_max_u32 + v_med3_u32.  Within
@@ -933,7 +933,6 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 
 constexpr int kHmTT = 64;          // trains per LDS tile
-constexpr int kHmStride = 272;     // bytes per staged train row (256 + 16: rows land 4 banks apart)
 constexpr int kHmQB = 256;         // queries per workgroup (4 waves x 2 sets x 32)
 constexpr uint32_t kHmLMask = 0x1FFFFFu;
 
@@ -973,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
                                                                const PairDesc *__restrict__ pairs, int n_pairs,
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kHmTT * kHmStride];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kHmTT * 256];   // 256-B rows, 16-B slots XOR-swizzled with row & 15
     __shared__ __attribute__((aligned(16))) int32_t lds_start[2][kHmTT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -1011,33 +1010,45 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
 
     const int n_tiles = (nt + kHmTT - 1) / kHmTT;
     const int n_full = nt / kHmTT;       // tiles with all 64 rows inside the set: the software-pipelined loop
-    // staging: 256 threads x 64 B = one 64-row tile; thread t -> row t / 4, bytes [64 (t % 4), +64); threads 0..63 also
-    // carry one start value each
-    const int srow = tid >> 2, scol = (tid & 3) * 64;
-    auto stage_load = [&](int tile, uint4 v[4], int32_t &sv) {
-        const int row = tile * kHmTT + srow;
-        if (row < nt) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(T + (size_t)row * 256 + scol);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = src[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = make_uint4(0, 0, 0, 0);
-        }
-        sv = (tid < kHmTT && tile * kHmTT + tid < nt) ? TS[tile * kHmTT + tid] : 0;
-    };
-    auto stage_store = [&](int buf, const uint4 v[4], int32_t sv) {
-        uint4 *dst = reinterpret_cast<uint4 *>(&lds[buf][srow * kHmStride + scol]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = v[q];
-        if (tid < kHmTT) lds_start[buf][tid] = sv;
-    };
-    if (n_tiles > 0) {
-        uint4 v[4];
-        int32_t sv;
-        stage_load(0, v, sv);
-        stage_store(0, v, sv);
+    // Staging is LDS-DMA (buffer_load_dwordx4 ... lds, 4 rows = 1 KiB per wave instruction) with the swizzle applied on the
+    // source side, issued from inline asm so that hipcc does not order the tile's LDS reads behind the transfer, and waited for
+    // explicitly in front of the barrier -- the scheme of l2_knn_bf16_kernel.  Start values go through a register, loaded
+    // before the tile's DMA and stored at the end of the iteration.
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t trsrc;
+    {
+        const uint64_t base = reinterpret_cast<uint64_t>(T);
+        trsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        trsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xFFFFu);
+        trsrc[2] = __builtin_amdgcn_readfirstlane((uint32_t)nt * 256u);
+        trsrc[3] = 0x00020000u;
     }
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)&lds[0][0];
+    const int wrow0 = __builtin_amdgcn_readfirstlane(wave * 16);             // this wave moves rows [wrow0, wrow0 + 16) of a tile
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wrow0 + 4 * i + (lane >> 4);
+        voff[i] = row * 256 + (((lane & 15) ^ (row & 15)) * 16);
+    }
+    auto dma_tile = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t dst = lds_addr + (uint32_t)(buf * kHmTT * 256 + (wrow0 + 4 * i) * 256);
+            const int soff = tile * kHmTT * 256;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(voff[i]), "s"(trsrc), "s"(soff) : "memory");
+        }
+    };
+    auto start_load = [&](int tile) { return (tid < kHmTT && tile * kHmTT + tid < nt) ? TS[tile * kHmTT + tid] : 0; };
+    auto start_store = [&](int buf, int32_t sv) { if (tid < kHmTT) lds_start[buf][tid] = sv; };
+    if (n_tiles > 0) {
+        const int32_t sv = start_load(0);
+        start_store(0, sv);
+        dma_tile(0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // the accumulator start values of a 32-train step, in the C/D register order: rows 8 g + 4 h + (0..3), g = 0..3
@@ -1049,10 +1060,11 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
     // One 32-train step: 16 MFMAs into (c0, c1), with the top-2 fold of the PREVIOUS step's results (p0, p1) issued
     // in their shadow -- two inserts (6 VALU) behind each MFMA -- so the matrix pipe and the VALU run concurrently.
     // pK = 2^21 - 1 - (16 * step number of p): key = acc << 21 + (pK - r)
+    // arow = the lane's train row in LDS; its K-chunk c is the 16-B slot 2 c + h, stored at slot ^ (row & 15) = ^ (j & 15)
     auto step = [&](const unsigned char *arow, const i32x16 &c_init, i32x16 &c0, i32x16 &c1, const i32x16 &p0, const i32x16 &p1, uint32_t pK) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + c * 32);
+            const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + (((2 * c + h) ^ (j & 15)) * 16));
             c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], c == 0 ? c_init : c0, 0, 0, 0);
             key_insert_max(m1[0][(2 * c) & 3], m2[0][(2 * c) & 3], ((uint32_t)p0[2 * c] << 21) + (pK - 2 * c));
             key_insert_max(m1[0][(2 * c + 1) & 3], m2[0][(2 * c + 1) & 3], ((uint32_t)p0[2 * c + 1] << 21) + (pK - 2 * c - 1));
@@ -1068,15 +1080,19 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
     uint32_t pbK = 15u;
     for (int tile = 0; tile < n_full; ++tile) {
         const int buf = tile & 1;
-        uint4 nxt[4];
-        int32_t nxt_start = 0;
         const bool more = tile + 1 < n_tiles;
-        if (more) stage_load(tile + 1, nxt, nxt_start);
-        const unsigned char *arow = &lds[buf][j * kHmStride + h * 16];
+        int32_t nxt_start = 0;
+        if (more) {
+            nxt_start = start_load(tile + 1);
+            dma_tile(tile + 1, buf ^ 1);                                       // lands under this tile's MFMAs
+        }
+        const unsigned char *arow = &lds[buf][j * 256];
         step(arow, load_start(buf, 0), pa0, pa1, pb0, pb1, pbK);                                        // sub 0, folding the previous tile's sub 1
-        step(arow + 32 * kHmStride, load_start(buf, 1), pb0, pb1, pa0, pa1, kHmLMask - (uint32_t)(tile * 2) * 16u);   // sub 1, folding sub 0
+        step(arow + 32 * 256, load_start(buf, 1), pb0, pb1, pa0, pa1, kHmLMask - (uint32_t)(tile * 2) * 16u);   // sub 1, folding sub 0
         pbK = kHmLMask - (uint32_t)(tile * 2 + 1) * 16u;
-        if (more) stage_store(buf ^ 1, nxt, nxt_start);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) start_store(buf ^ 1, nxt_start);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the DMA issued above has landed
         __syncthreads();
     }
     // drain the pipeline
@@ -1092,10 +1108,10 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         for (int sub = 0; sub < 2; ++sub) {
             const i32x16 c_init = load_start(buf, sub);
             i32x16 acc0 = c_init, acc1 = c_init;
-            const unsigned char *arow = &lds[buf][(sub * 32 + j) * kHmStride + h * 16];
+            const unsigned char *arow = &lds[buf][(sub * 32 + j) * 256];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + c * 32);
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + (((2 * c + h) ^ (j & 15)) * 16));
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], acc1, 0, 0, 0);
             }
