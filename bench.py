@@ -23,6 +23,12 @@ import sys
 import threading
 import time
 
+# The CPU oracle (checker / cpu_baseline legs) is OpenMP code: after a parallel region libgomp's workers spin for a while by
+# default, which on a 256-core host starves the HIP runtime's threads of the GPU legs that follow (seen: the SURF leg at 10 ms
+# per image instead of 1.5).  Passive waiting costs the long CPU regions nothing.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
