@@ -26,6 +26,8 @@ struct esfm_ba_problem {
     int ref_cam = -1;
     double ref_threshold = 0.0;
     double calib_center[4] = {0, 0, 0, 0}, calib_tol = 0.0;
+    double *h_scal = nullptr;   // pinned host copy of the scalar slots: the LM loop reads them back twice per iteration
+    unsigned long long seq = 0; // sequence number of the last publication (the flag sits behind the scalars)
 };
 
 namespace {
@@ -68,7 +70,7 @@ struct Solver {
     esfm_allreduce_fn ar;
     void *ar_user;
     hipStream_t st;
-    double h[esfm::SC_COUNT];
+    double *h = nullptr;        // P->h_scal
 
     int allreduce(double *buf, int64_t count, int op)
     {
@@ -85,8 +87,23 @@ struct Solver {
     {
         if (int rc = allreduce(P->d.scal, esfm::SC_SUM_COUNT, ESFM_REDUCE_SUM)) return rc;
         if (int rc = allreduce(P->d.scal + esfm::SC_GMAX, esfm::SC_MAX_COUNT, ESFM_REDUCE_MAX)) return rc;
-        ESFM_HIP_TRY(hipMemcpyAsync(h, P->d.scal, sizeof(double) * esfm::SC_COUNT, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipStreamSynchronize(st));
+        // The device publishes the slots into pinned memory and then a sequence number; the host spins on that instead of
+        // paying a stream synchronisation (two read-backs per LM iteration of ~0.4 ms: the wake-up latency is a tenth of it).
+        unsigned long long *flag = reinterpret_cast<unsigned long long *>(h + esfm::SC_COUNT);
+        const unsigned long long seq = ++P->seq;
+        if (int rc = esfm::ba_publish_scalars(st, P->d, h, flag, seq)) return rc;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+            if ((spins & 0xFFF) == 0xFFF) {
+                if (hipStreamQuery(st) != hipErrorNotReady) {           // finished (or failed) without the store being seen: settle by sync
+                    ESFM_HIP_TRY(hipStreamSynchronize(st));
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                    esfm::set_error("BA scalar publication was not observed");
+                    return ESFM_ERR_HIP;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { esfm::set_error("BA scalar read-back timed out"); return ESFM_ERR_HIP; }
+            }
+        }
         return ESFM_OK;
     }
     // residuals + Jacobian at x, per-camera sums, per-point blocks; leaves cost/gmax in h[].
@@ -319,6 +336,7 @@ int esfm_ba_problem_destroy(esfm_ba_problem *P)
     if (!P) return ESFM_OK;
     if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
     for (void *p : P->allocs) (void)hipFree(p);
+    if (P->h_scal) (void)hipHostFree(P->h_scal);
     delete P;
     return ESFM_OK;
 }
@@ -347,6 +365,12 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     memset(sum, 0, sizeof(*sum));
     Solver S;
     S.P = P; S.ar = allreduce; S.ar_user = allreduce_user; S.st = P->ctx->stream;
+    if (!P->h_scal) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&P->h_scal), sizeof(double) * (esfm::SC_COUNT + 2), hipHostMallocDefault);
+        if (e == hipSuccess) memset(P->h_scal, 0, sizeof(double) * (esfm::SC_COUNT + 2));
+        if (e != hipSuccess) { esfm::set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return ESFM_ERR_HIP; }
+    }
+    S.h = P->h_scal;
     if (options) S.opt = *options; else options_default(&S.opt);
     const esfm_ba_options &opt = S.opt;
     ESFM_REQUIRE(opt.initial_trust_region_radius > 0.0 && opt.max_num_iterations >= 0, "bad options");

@@ -1393,6 +1393,25 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
     return ESFM_OK;
 }
 
+// Scalar read-back without a stream synchronisation: one wave copies the scalar slots into pinned host memory, fences to system
+// scope and then stores the sequence number the host is spinning on.
+__global__ __launch_bounds__(64) void ba_publish_scalars_kernel(const double *__restrict__ scal, double *host, unsigned long long *flag,
+                                                                unsigned long long seq)
+{
+    const int i = threadIdx.x;
+    if (i < SC_COUNT) host[i] = scal[i];
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(64), 0, st, d.scal, host, flag, seq);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
 int ba_camera_step(hipStream_t st, const BADev &d)
 {
     hipLaunchKernelGGL(ba_camera_step_kernel, dim3(1), dim3(256), 0, st, d);

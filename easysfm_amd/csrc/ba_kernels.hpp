@@ -97,6 +97,7 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
 size_t ba_chol_large_doubles(int n_cam);
 // intrinsics row/column block of the reduced system (has_calib): runs after ba_schur, adds into d.red
 int ba_schur_calib(hipStream_t st, const BADev &d);
+int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq);
 int ba_camera_step(hipStream_t st, const BADev &d);
 int ba_backsub(hipStream_t st, const BADev &d);
 // with_slope: also the derivative of the cost along (delta_c, delta_p) at (cams, pts) into SC_LS_GRAD
