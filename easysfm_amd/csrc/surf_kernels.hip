@@ -65,14 +65,23 @@ __global__ __launch_bounds__(64) void surf_integral_rows_kernel(const uint8_t *_
 }
 
 // column pass: running sum down each column (row 0 of the integral image is zero)
-__global__ __launch_bounds__(256) void surf_integral_cols_kernel(int rows, int cols, int32_t *__restrict__ sum)
+__global__ __launch_bounds__(64) void surf_integral_cols_kernel(int rows, int cols, int32_t *__restrict__ sum)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     const int sc = cols + 1;
     if (x > cols) return;
     int acc = 0;
     sum[x] = 0;
-    for (int y = 1; y <= rows; ++y) { acc += sum[(size_t)y * sc + x]; sum[(size_t)y * sc + x] = acc; }
+    // the loads do not depend on the running sum: 16 rows are fetched at a time so that their latencies overlap
+    int y = 1;
+    for (; y + 15 <= rows; y += 16) {
+        int v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = sum[(size_t)(y + k) * sc + x];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc += v[k]; sum[(size_t)(y + k) * sc + x] = acc; }
+    }
+    for (; y <= rows; ++y) { acc += sum[(size_t)y * sc + x]; sum[(size_t)y * sc + x] = acc; }
 }
 
 // grid.y = layer; one thread per written sample of the layer (calcLayerDetAndTrace)
@@ -352,7 +361,7 @@ int launch_surf_integral(hipStream_t st, const uint8_t *gray, int rows, int cols
 {
     hipLaunchKernelGGL(surf_integral_rows_kernel, dim3(rows), dim3(64), 0, st, gray, rows, cols, sum);
     LAUNCH_OK();
-    hipLaunchKernelGGL(surf_integral_cols_kernel, dim3((cols + 1 + 255) / 256), dim3(256), 0, st, rows, cols, sum);
+    hipLaunchKernelGGL(surf_integral_cols_kernel, dim3((cols + 1 + 63) / 64), dim3(64), 0, st, rows, cols, sum);   // one wave per CU: more of them stream
     LAUNCH_OK();
     return ESFM_OK;
 }
