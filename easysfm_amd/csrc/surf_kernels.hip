@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void surf_maxima_kernel(const SurfParams *__re
 }
 
 // One wave per keypoint (SURFInvoker::operator()).
-__global__ __launch_bounds__(256) void surf_describe_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
+constexpr int kSurfDescThreads = 1024;   // a keypoint's window holds up to 633 x 633 samples: the widest workgroup
+__global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
                                                            const uint8_t *__restrict__ gray, const int32_t *__restrict__ sum,
                                                            SurfKeypoint *__restrict__ kps, const int64_t *__restrict__ win_offset,
                                                            uint8_t *__restrict__ win_scratch, float *__restrict__ desc)
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void surf_describe_kernel(const SurfParams *__
     __syncthreads();
     nangle = sN;
     if (nangle == 0) { if (tid == 0) kps[k].valid = 0; return; }
-    for (int w = tid; w < 72; w += 256) {
+    for (int w = tid; w < 72; w += kSurfDescThreads) {
         const int i = 5 * w;
         float sumx = 0.f, sumy = 0.f;
         for (int j = 0; j < nangle; ++j) {
@@ -265,10 +266,10 @@ __global__ __launch_bounds__(256) void surf_describe_kernel(const SurfParams *__
     __syncthreads();
     const int ncols1 = cols - 1, nrows1 = rows - 1;
     {
-        int nch = (1024 + win_size / 2) / win_size;                       // about 1024 work items per keypoint
+        int nch = (4 * kSurfDescThreads + win_size / 2) / win_size;           // about four work items per thread
         nch = nch < 1 ? 1 : (nch > 16 ? 16 : nch);
         const int clen = (win_size + nch - 1) / nch;
-        for (int item = tid; item < win_size * nch; item += 256) {
+        for (int item = tid; item < win_size * nch; item += kSurfDescThreads) {
             const int i = item / nch, j0 = (item % nch) * clen, j1 = j0 + clen < win_size ? j0 + clen : win_size;
             double pixel_x = sStartX[i], pixel_y = sStartY[i];
             for (int j = 0; j < j0; ++j) { pixel_x += cos_dir; pixel_y -= sin_dir; }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void surf_describe_kernel(const SurfParams *__
             has_first = s1 - f1 > 1e-3; has_last = f2 - s2 > 1e-3;
             a_first = (float)((s1 - f1) / cell); a_mid = (float)(1.0 / cell); a_last = (float)(fmin(fmin(f2 - s2, 1.), cell) / cell);
         };
-        for (int o = tid; o < D * D; o += 256) {
+        for (int o = tid; o < D * D; o += kSurfDescThreads) {
             const int dy = o / D, dx = o % D;
             int x1, x2, y1, y2; float axf, axm, axl, ayf, aym, ayl; bool hxf, hxl, hyf, hyl;
             cell_of(dx, x1, x2, axf, axm, axl, hxf, hxl);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void surf_describe_kernel(const SurfParams *__
         }
     }
     __syncthreads();
-    for (int o = tid; o < kSurfPatch * kSurfPatch; o += 256) {
+    for (int o = tid; o < kSurfPatch * kSurfPatch; o += kSurfDescThreads) {
         const int i = o / kSurfPatch, j = o % kSurfPatch;
         const float dw = T->DW[o];
         sDX[i][j] = (sPatch[i][j + 1] - sPatch[i][j] + sPatch[i + 1][j + 1] - sPatch[i + 1][j]) * dw;
@@ -391,7 +392,7 @@ int launch_surf_describe(hipStream_t st, const SurfParams *params_dev, const Sur
 {
     if (n_kp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_SURF_DESC);
-    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(256), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, win_scratch, desc);
+    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(kSurfDescThreads), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, win_scratch, desc);
     LAUNCH_OK();
     return ESFM_OK;
 }
