@@ -158,15 +158,24 @@ int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, 
         ESFM_REQUIRE(w < 1024, "keypoint scale beyond the descriptor window the kernel is built for");
         win_off[(size_t)k + 1] = win_off[(size_t)k] + ((w * w + 15) / 16) * 16;
     }
+    // launch order: widest windows first (a window of 600 x 600 samples takes a workgroup a hundred times longer than one of 42 x 42)
+    std::vector<int32_t> order((size_t)n_kp);
+    for (int k = 0; k < n_kp; ++k) order[(size_t)k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return win_off[(size_t)a + 1] - win_off[(size_t)a] > win_off[(size_t)b + 1] - win_off[(size_t)b];
+    });
     const size_t off_bytes = sizeof(int64_t) * ((size_t)n_kp + 1), desc_bytes = sizeof(float) * 64 * (size_t)n_kp;
-    if (int rc = b_win.reserve((size_t)win_off[(size_t)n_kp] + off_bytes + desc_bytes + 64)) return rc;
+    const size_t order_bytes = ((sizeof(int32_t) * (size_t)n_kp + 15) / 16) * 16;
+    if (int rc = b_win.reserve((size_t)win_off[(size_t)n_kp] + off_bytes + desc_bytes + order_bytes + 128)) return rc;
     uint8_t *d_win = b_win.as<uint8_t>();
     int64_t *d_off = reinterpret_cast<int64_t *>(d_win + ((win_off[(size_t)n_kp] + 15) / 16) * 16);
     float *d_desc = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(d_off) + off_bytes);
+    int32_t *d_order = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(d_desc) + ((desc_bytes + 15) / 16) * 16);
     ESFM_HIP_TRY(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
     ESFM_HIP_TRY(hipMemcpyAsync(d_cand, kps.data(), sizeof(SurfKeypoint) * (size_t)n_kp, hipMemcpyHostToDevice, st));
     ESFM_HIP_TRY(hipMemcpyAsync(d_off, win_off.data(), off_bytes, hipMemcpyHostToDevice, st));
-    if (int rc = esfm::launch_surf_describe(st, d_P, d_T, d_gray, d_sum, d_cand, n_kp, d_off, d_win, d_desc, ctx)) return rc;
+    ESFM_HIP_TRY(hipMemcpyAsync(d_order, order.data(), sizeof(int32_t) * (size_t)n_kp, hipMemcpyHostToDevice, st));
+    if (int rc = esfm::launch_surf_describe(st, d_P, d_T, d_gray, d_sum, d_cand, n_kp, d_off, d_order, d_win, d_desc, ctx)) return rc;
     std::vector<float> desc(64 * (size_t)n_kp);
     ESFM_HIP_TRY(hipMemcpyAsync(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_kp, hipMemcpyDeviceToHost, st));
     ESFM_HIP_TRY(hipMemcpyAsync(desc.data(), d_desc, desc_bytes, hipMemcpyDeviceToHost, st));

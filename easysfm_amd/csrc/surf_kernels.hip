@@ -180,7 +180,8 @@ constexpr int kSurfDescThreads = 1024;   // a keypoint's window holds up to 633 
 __global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
                                                            const uint8_t *__restrict__ gray, const int32_t *__restrict__ sum,
                                                            SurfKeypoint *__restrict__ kps, const int64_t *__restrict__ win_offset,
-                                                           uint8_t *__restrict__ win_scratch, float *__restrict__ desc)
+                                                           const int32_t *__restrict__ order, uint8_t *__restrict__ win_scratch,
+                                                           float *__restrict__ desc)
 {
     __shared__ float sX[kSurfOriSamples], sY[kSurfOriSamples], sAng[kSurfOriSamples];
     __shared__ float sMod[72], sSumX[72], sSumY[72];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const S
     __shared__ float sVec[64];
     __shared__ float sDir;
     __shared__ int sN;
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = order[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // largest windows first: they set the kernel's length
     SurfKeypoint kp = kps[k];
     const int rows = P->rows, cols = P->cols, sr = rows + 1, sc = cols + 1;
     const float s = kp.size * 1.2f / 9.0f;
@@ -388,11 +389,12 @@ int launch_surf_maxima(hipStream_t st, const SurfParams *params_dev, const SurfP
 }
 
 int launch_surf_describe(hipStream_t st, const SurfParams *params_dev, const SurfDescTables *tables_dev, const uint8_t *gray, const int32_t *sum,
-                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, uint8_t *win_scratch, float *desc, esfm_ctx *timing_ctx)
+                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, const int32_t *order, uint8_t *win_scratch, float *desc,
+                         esfm_ctx *timing_ctx)
 {
     if (n_kp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_SURF_DESC);
-    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(kSurfDescThreads), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, win_scratch, desc);
+    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(kSurfDescThreads), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, order, win_scratch, desc);
     LAUNCH_OK();
     return ESFM_OK;
 }

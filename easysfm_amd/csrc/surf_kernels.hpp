@@ -41,6 +41,6 @@ int launch_surf_det_trace(hipStream_t st, const SurfParams *params_dev, const Su
 int launch_surf_maxima(hipStream_t st, const SurfParams *params_dev, const SurfParams &params_host, const float *det, const float *trace,
                        SurfKeypoint *cand, int32_t *n_cand);
 int launch_surf_describe(hipStream_t st, const SurfParams *params_dev, const SurfDescTables *tables_dev, const uint8_t *gray, const int32_t *sum,
-                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, uint8_t *win_scratch, float *desc, esfm_ctx *timing_ctx);
+                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, const int32_t *order, uint8_t *win_scratch, float *desc, esfm_ctx *timing_ctx);
 
 }  // namespace esfm
