@@ -294,6 +294,11 @@ def test_native_png_reader_matches_pil(tmp_path):
         rows, cols = np.frombuffer(raw[:8].tobytes(), np.int32)
         got = raw[8:].reshape(rows, cols, 3)
         assert np.array_equal(got, np.ascontiguousarray(want)), name
+    good = (tmp_path / "rgb.png").read_bytes()
+    for name, data, msg in (("trunc.png", good[:len(good) // 2], "truncated"), ("crc.png", good[:60] + bytes([good[60] ^ 0xFF]) + good[61:], "CRC")):
+        (tmp_path / name).write_bytes(data)
+        r = subprocess.run([exe, "--dump-image", str(tmp_path / name), str(tmp_path / "x.raw")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 3 and (msg in r.stdout or "inflate" in r.stdout or "header" in r.stdout), (name, r.stdout)
     bad = tmp_path / "not.png"
     bad.write_bytes(b"JFIF" * 10)
     r = subprocess.run([exe, "--dump-image", str(bad), str(tmp_path / "x.raw")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -199,3 +199,38 @@ def test_native_sfm_matches_the_python_driver(tmp_path):
     d, _ = tree.query(sc * (R @ a_all.T).T + t)
     extent = np.linalg.norm(b_all - b_all.mean(0), axis=1).mean()
     assert abs(sc - 1) < 0.15 and np.median(d) < 0.1 * extent
+
+
+def test_native_sfm_with_a_distortion_file(tmp_path):
+    """argv[4] names a distortion file: both drivers read it the way the reference does (floats stored into a CV_64F matrix,
+    SURVEY section 9.10 -- k2 = 1.2 turns into k1' ~ 0.025), undistort every frame on the GPU before detection and still
+    reconstruct; the features found differ from the undistorted run's."""
+    import os
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "sfm_native")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(root, "easysfm_amd", "csrc"), "../../bin/sfm_native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+    z = np.load(os.path.join(root, "tests", "golden", "fountain11_half_gray.npz"))
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    names = []
+    for i, img in enumerate(z["images"][:6]):
+        names.append(f"{i:04d}.png")
+        PIL.fromarray(np.stack([img] * 3, axis=2)).save(str(img_dir / names[-1]))
+    (tmp_path / "image_list.txt").write_text("\n".join(names) + "\n")
+    (tmp_path / "K.txt").write_text(f"{689.87 / 2} 0 {380.17 / 2}\n0 {691.04 / 2} {251.70 / 2}\n0 0 1\n")
+    (tmp_path / "dist.txt").write_text("0.1 1.2 0.0 0.0\n")
+    outs = {}
+    for tag, dist in (("none", "none"), ("dist", str(tmp_path / "dist.txt"))):
+        out = tmp_path / tag / "cloud.ply"
+        r = subprocess.run([exe, str(img_dir), str(tmp_path / "image_list.txt"), str(tmp_path / "K.txt"), dist, str(out), "S", "100", "1.0", "1", "0",
+                            "4", "1", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 1, r.stdout[-3000:]
+        assert r.stdout.count("Undistort the image done.") == 6
+        assert ("Import camera distortion coefficients file done." in r.stdout) == (tag == "dist")
+        xyz, _, _ = E.read_ply_vertices(str(out))
+        assert len(xyz) > 150 and np.all(np.isfinite(xyz))
+        outs[tag] = [l for l in r.stdout.splitlines() if l.startswith("Found ")]
+    assert outs["none"] != outs["dist"]                      # the undistortion moved pixels: other keypoint counts
