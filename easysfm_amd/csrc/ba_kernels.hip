@@ -1011,6 +1011,10 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
         double xp[3] = {d.x_p[3 * (size_t)p], d.x_p[3 * (size_t)p + 1], d.x_p[3 * (size_t)p + 2]};
         if (e > b) {
             double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
+            // F_i y_c of the first kKeep observations stays in registers: the second pass below needs its negative
+            // (-(a + b) == (-a) + (-b) exactly), which saves re-reading the camera Jacobian
+            constexpr int kKeep = 8;
+            double keep0[kKeep], keep1[kKeep];
             for (int k = b; k < e; ++k) {
                 const int c = d.obs_cam[k];
                 double f0 = 0.0, f1 = 0.0;
@@ -1024,6 +1028,8 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
                     f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
                 }
 #pragma unroll
+                for (int q = 0; q < kKeep; ++q) if (k - b == q) { keep0[q] = f0; keep1[q] = f1; }
+#pragma unroll
                 for (int a = 0; a < 3; ++a) g[a] -= d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
             }
             const double *Mi = d.Minv + 6 * (size_t)p;
@@ -1031,16 +1037,21 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
                                   -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
                                   -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
             for (int k = b; k < e; ++k) {
-                const int c = d.obs_cam[k];
                 double m0 = 0.0, m1 = 0.0;
+                if (k - b < kKeep) {
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double sc = -d.y_c[6 * c + a];
-                    m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
-                }
-                if (d.has_calib) {
-                    m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
-                    m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+                    for (int q = 0; q < kKeep; ++q) if (k - b == q) { m0 = -keep0[q]; m1 = -keep1[q]; }
+                } else {
+                    const int c = d.obs_cam[k];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        const double sc = -d.y_c[6 * c + a];
+                        m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
+                    }
+                    if (d.has_calib) {
+                        m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+                        m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+                    }
                 }
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
