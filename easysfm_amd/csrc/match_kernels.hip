@@ -690,19 +690,20 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             const float vk[3] = {v0[s], v1[s], v2[s]};
             const int cc[3] = {train_row_of(v0[s], c0[s]), train_row_of(v1[s], c1[s]), train_row_of(v2[s], c2[s])};
             // Only candidates that can be among the two nearest are re-ranked.  With ka <= kb the two smallest of the query's six
-            // keys, both of their exact d^2 are <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-14 |k| being the
+            // keys, both of their exact d^2 are <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-15 |k| being the
             // certificate's bound on |(|q|^2 + key) - d^2|; a candidate with |q|^2 + k - E(k) > U (1 + 2^-20) is farther than
             // both even after sqrtf's rounding.  Typically one candidate per lane survives instead of three.
             const float p0 = __shfl_xor(vk[0], 32), p1 = __shfl_xor(vk[1], 32);
             const float kb = fminf(fmaxf(vk[0], p0), fminf(vk[1], p1));
             const double qn = (double)qnorm[s];
             const double e1 = (qn + (double)tmax) * (1.0 / 32768.0);
-            const double U = (qn + (double)kb + e1 + fabs((double)kb) * (1.0 / 16384.0)) * (1.0 + 1.0 / 1048576.0);
+            constexpr double kTrunc = 1.0001 / 32768.0;   // |key - s| < 2^8 ulp(s) <= 2^-15 |s|: 8 mantissa bits hold the position code
+            const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
             const float *qp = Q + (size_t)(qvalid ? qrow : 0) * DIM;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 ei[m] = -1; ed[m] = FLT_MAX; ed2[m] = 0.f;
-                const bool cannot = (qn + (double)vk[m] - e1 - fabs((double)vk[m]) * (1.0 / 16384.0)) > U;   // false on NaN: re-rank
+                const bool cannot = (qn + (double)vk[m] - e1 - fabs((double)vk[m]) * kTrunc) > U;   // false on NaN: re-rank
                 if (cc[m] >= 0 && qvalid && !cannot) {
                     const int t = cc[m];
                     const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
@@ -725,11 +726,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
             // Certificate: |(|q|^2 + s(t)) - D(t)| <= 2^-15 (|q|^2 + max|t|^2) for every train t -- split 193 u,
             // bf16-MFMA accumulation 36 u (3 u per MFMA; measured 0.75 u, profiles/r01_ubench_bf16_acc.txt), norms and the
-            // canonical distance 96 u, of |q|^2 + 2 |t|^2 at most; keys are s with 8 mantissa bits replaced (< 2^-14 |tau|).
+            // canonical distance 96 u, of |q|^2 + 2 |t|^2 at most; keys are s with 8 mantissa bits replaced (< 2^-15 |s|).
             bool certified = !(tau < 1.0e38f);
             if (!certified && b1.i >= 0) {
                 const double qn = (double)qnorm[s];
-                const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0 / 16384.0);
+                const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0001 / 32768.0);
                 certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
             }
             if (!certified) {
