@@ -30,6 +30,31 @@
 namespace esfm {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA staging (buffer_load_dwordx4 ... lds): lane l of the wave writes its 16 bytes to lds_dst + 16 l, from byte
+// voff (per lane) + soff (wave-uniform) of the buffer.  Issued from inline asm on purpose: through the builtin hipcc orders
+// every later LDS read behind vmcnt(0) (it cannot tell a double buffer's halves apart) and the transfer would serialise with the
+// compute it is meant to hide under.  The asm is invisible to the waitcnt pass, so the CALLER waits: lds_dma_wait() in front of
+// the barrier that publishes the tile.  M0 (the LDS base of the transfer) is saved and restored around the instruction.
+__device__ __forceinline__ u32x4 raw_buffer_rsrc(const void *base, uint32_t bytes)
+{
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu);   // stride 0: raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);                            // the per-lane offset is range-checked against it
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void lds_dma_b128(uint32_t lds_dst /* wave-uniform */, int voff, u32x4 rsrc, int soff /* wave-uniform */)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------
 // helpers
@@ -390,7 +415,6 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
 // Each wave owns TWO sets of 32 queries (B operands: 64 VGPRs), so an A fragment feeds two MFMAs and a workgroup covers 256
 // queries (half the L2 -> LDS traffic of the f32 kernel).  The fold of step n runs in the shadow of step n+1's MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t bf16_rne_bits(float a)
 {
@@ -546,17 +570,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     // to byte 16 l of the destination, so the XOR swizzle is applied on the SOURCE side (lane l fetches slot (l & 15) ^ (row & 15)
     // of its row) -- no staging VGPRs, no ds_write pass.  Rows past nt read as zeros through the buffer descriptor; their norm
     // is kBig.  The per-lane byte offsets are loop-invariant, the tile offset is scalar.
-    // The DMA is issued from inline asm: through the builtin hipcc orders every later LDS read behind vmcnt(0) (it cannot tell
-    // the two LDS buffers apart), which would serialise each tile's transfer with its MFMAs.  The asm is invisible to the
-    // waitcnt pass, so the wait is explicit: s_waitcnt vmcnt(0) in front of the barrier that publishes the tile.
-    u32x4 trsrc;
-    {
-        const uint64_t base = reinterpret_cast<uint64_t>(split + (size_t)pd.t_row0 * SLOTS);
-        trsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        trsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xFFFFu);      // stride 0: raw buffer
-        trsrc[2] = __builtin_amdgcn_readfirstlane((uint32_t)nt * (DIM * 4));               // bytes; reads past it return 0
-        trsrc[3] = 0x00020000u;
-    }
+    const u32x4 trsrc = raw_buffer_rsrc(split + (size_t)pd.t_row0 * SLOTS, (uint32_t)nt * (DIM * 4));   // reads past it return 0
     const uint32_t lds_tile_addr = (uint32_t)(uintptr_t)lds_tile;   // LDS byte address (the low 32 bits of the flat pointer's offset)
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave * (TT / 4));      // this wave stages rows [wrow0, wrow0 + TT / 4) of a tile
     int voff[4];
@@ -570,9 +584,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         for (int i = 0; i < NDMA; ++i) {
             const uint32_t dst = lds_tile_addr + (uint32_t)((buf * TT * SLOTS + (wrow0 + 4 * i) * SLOTS) * 16);
             const int soff = (tile * TT + (i >= 4 ? 16 : 0)) * (DIM * 4);    // wave-uniform
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(dst), "v"(voff[i & 3]), "s"(trsrc), "s"(soff) : "memory");
+            lds_dma_b128(dst, voff[i & 3], trsrc, soff);
         }
     };
     // |t|^2 of the tile's rows (the accumulators' start values) go through a register: an ordinary load whose consumer sits
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         norm_store(0, nv);
         dma_tile(0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_dma_wait();
     __syncthreads();
 
     // One 32-train step: 24 MFMAs into (n0, n1) with the fold of the PREVIOUS step's results (p0, p1) between them.
@@ -653,7 +665,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) norm_store(buf ^ 1, next_norm);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the DMA issued above has landed
+        lds_dma_wait();                                                        // the DMA issued above has landed
         __syncthreads();
     }
     {
@@ -1015,15 +1027,7 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
     // source side, issued from inline asm so that hipcc does not order the tile's LDS reads behind the transfer, and waited for
     // explicitly in front of the barrier -- the scheme of l2_knn_bf16_kernel.  Start values go through a register, loaded
     // before the tile's DMA and stored at the end of the iteration.
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t trsrc;
-    {
-        const uint64_t base = reinterpret_cast<uint64_t>(T);
-        trsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        trsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xFFFFu);
-        trsrc[2] = __builtin_amdgcn_readfirstlane((uint32_t)nt * 256u);
-        trsrc[3] = 0x00020000u;
-    }
+    const u32x4 trsrc = raw_buffer_rsrc(T, (uint32_t)nt * 256u);
     const uint32_t lds_addr = (uint32_t)(uintptr_t)&lds[0][0];
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave * 16);             // this wave moves rows [wrow0, wrow0 + 16) of a tile
     int voff[4];
@@ -1037,9 +1041,7 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         for (int i = 0; i < 4; ++i) {
             const uint32_t dst = lds_addr + (uint32_t)(buf * kHmTT * 256 + (wrow0 + 4 * i) * 256);
             const int soff = tile * kHmTT * 256;
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(dst), "v"(voff[i]), "s"(trsrc), "s"(soff) : "memory");
+            lds_dma_b128(dst, voff[i], trsrc, soff);
         }
     };
     auto start_load = [&](int tile) { return (tid < kHmTT && tile * kHmTT + tid < nt) ? TS[tile * kHmTT + tid] : 0; };
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         start_store(0, sv);
         dma_tile(0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_dma_wait();
     __syncthreads();
 
     // the accumulator start values of a 32-train step, in the C/D register order: rows 8 g + 4 h + (0..3), g = 0..3
@@ -1093,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         pbK = kHmLMask - (uint32_t)(tile * 2 + 1) * 16u;
         __builtin_amdgcn_sched_barrier(0);
         if (more) start_store(buf ^ 1, nxt_start);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the DMA issued above has landed
+        lds_dma_wait();                                                        // the DMA issued above has landed
         __syncthreads();
     }
     // drain the pipeline
