@@ -47,6 +47,11 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
 // products, (B1) wave 0 factors the 8 x 8 diagonal block in registers with __shfl, (B2) the rows below solve
 // against it.  rd[] receives the reciprocal diagonal.  *fail is raised on a non-positive pivot.
 constexpr int FB = 8;
+// value of lane `l` (wave-uniform index): two v_readlane_b32 instead of the LDS round trip of __shfl
+__device__ __forceinline__ double lane_value_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 // rows: CB for the diagonal tile alone, 2*CB when a panel tile is stacked below it (rows CB..2CB-1 then come out as
 // X = A L^-T, the triangular solve, at no extra barriers).
 __device__ __forceinline__ void factor_tile_lds(double *L, double *rd, volatile int *fail, int rows)
@@ -59,9 +64,11 @@ __device__ __forceinline__ void factor_tile_lds(double *L, double *rd, volatile 
                 const int i = j0 + e / FB, col = j0 + e % FB;
                 if (col > i) continue;
                 const double *Li = L + i * CLD, *Lc = L + col * CLD;
-                double s0 = 0.0, s1 = 0.0;
-                for (int k = 0; k < j0; k += 2) { s0 += Li[k] * Lc[k]; s1 += Li[k + 1] * Lc[k + 1]; }   // j0 is a multiple of 8
-                L[i * CLD + col] -= s0 + s1;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four chains: the dot product is latency-bound
+                for (int k = 0; k < j0; k += 4) {                // j0 is a multiple of 8
+                    s0 += Li[k] * Lc[k]; s1 += Li[k + 1] * Lc[k + 1]; s2 += Li[k + 2] * Lc[k + 2]; s3 += Li[k + 3] * Lc[k + 3];
+                }
+                L[i * CLD + col] -= (s0 + s1) + (s2 + s3);
             }
         }
         __syncthreads();
@@ -72,14 +79,14 @@ __device__ __forceinline__ void factor_tile_lds(double *L, double *rd, volatile 
             for (int c = 0; c < FB; ++c) a[c] = (r < FB && c <= r) ? L[(j0 + r) * CLD + j0 + c] : 0.0;
 #pragma unroll
             for (int c = 0; c < FB; ++c) {
-                const double piv = __shfl(a[c], c);
+                const double piv = lane_value_f64(a[c], c);
                 if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *fail = 1; }
                 const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
                 a[c] = (r == c) ? piv * rinv : a[c] * rinv;
                 if (lane == c) rd[j0 + c] = rinv;
 #pragma unroll
                 for (int c2 = c + 1; c2 < FB; ++c2) {
-                    const double l2 = __shfl(a[c], c2);
+                    const double l2 = lane_value_f64(a[c], c2);
                     if (r >= c2) a[c2] -= a[c] * l2;
                 }
             }
