@@ -7,6 +7,7 @@ here is the reference's own host-side packing (Rodrigues conversion, float trunc
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
@@ -38,15 +39,19 @@ class _DevArray:
 
 def torch_allreduce_callback(group=None):
     """esfm_allreduce_fn backed by torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
-    The solver's context must have been created on torch's current stream, so that the collective
-    is ordered after the kernels that produced the buffer and before the ones that consume it."""
+    The collective is enqueued on the hipStream_t the library passes (the solver's stream), wrapped as a
+    torch ExternalStream, so it is ordered after the kernels that produced the buffer and before the ones that
+    consume it whatever torch's current stream is.  The library's own RCCL path (esfm_comm_*, include/esfm.h)
+    needs no callback at all; this one serves torch-managed process groups (and gloo in the CPU tests)."""
     import torch
     import torch.distributed as dist
 
     def _cb(user, buf, count, op, stream):
         try:
-            t = torch.as_tensor(_DevArray(buf, count), device=torch.device("cuda", torch.cuda.current_device()))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == ESFM_REDUCE_SUM else dist.ReduceOp.MAX, group=group)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)) if stream else contextlib.nullcontext():
+                t = torch.as_tensor(_DevArray(buf, count), device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == ESFM_REDUCE_SUM else dist.ReduceOp.MAX, group=group)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print(f"[easysfm_amd] all-reduce callback failed: {e!r}", flush=True)

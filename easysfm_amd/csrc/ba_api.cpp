@@ -6,6 +6,7 @@
 // back a handful of scalars per iteration and takes the accept/reject decision.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cfloat>
@@ -101,7 +102,9 @@ struct Solver {
                     esfm::set_error("BA scalar publication was not observed");
                     return ESFM_ERR_HIP;
                 }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { esfm::set_error("BA scalar read-back timed out"); return ESFM_ERR_HIP; }
+                // no wall-clock limit: a large reduced system (6 n_cam up to 46 000) legitimately keeps the stream busy for
+                // seconds; hipStreamQuery above is what detects completion and failure.  After a while stop burning a core.
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(200));
             }
         }
         return ESFM_OK;
@@ -366,7 +369,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     Solver S;
     S.P = P; S.ar = allreduce; S.ar_user = allreduce_user; S.st = P->ctx->stream;
     if (!P->h_scal) {
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&P->h_scal), sizeof(double) * (esfm::SC_COUNT + 2), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&P->h_scal), sizeof(double) * (esfm::SC_COUNT + 2), hipHostMallocCoherent);   // explicit: the host spins on a device-written flag
         if (e == hipSuccess) memset(P->h_scal, 0, sizeof(double) * (esfm::SC_COUNT + 2));
         if (e != hipSuccess) { esfm::set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return ESFM_ERR_HIP; }
     }
@@ -378,6 +381,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     hipStream_t st = S.st;
     const bool multi = allreduce != nullptr;
     double *h = S.h;
+    if (multi && !d.red_packed) { if (int rc = dev_alloc(P, &d.red_packed, esfm::ba_red_packed_doubles(d.n_cam))) return rc; }
 
     // camera observation counts over all shards; Jacobi scaling starts at 1
     if (d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(d.cam_nobs, P->cam_nobs_local.data(), sizeof(double) * (size_t)d.n_cam, hipMemcpyHostToDevice, st));
@@ -484,7 +488,12 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap)) return finish(rc);
             if (int rc = esfm::ba_schur_calib(st, d)) return finish(rc);
         }
-        if (int rc = S.allreduce(d.red, (int64_t)esfm::ba_red_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
+        if (multi) {
+            // one exchange per LM iteration: the block-lower-triangular S and the right-hand side, packed
+            if (int rc = esfm::ba_red_pack(st, d, d.red_packed, false)) return finish(rc);
+            if (int rc = S.allreduce(d.red_packed, (int64_t)esfm::ba_red_packed_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
+            if (int rc = esfm::ba_red_pack(st, d, d.red_packed, true)) return finish(rc);
+        }
         {
             esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SOLVE);
             if (int rc = esfm::ba_solve_reduced(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal)) return finish(rc);

@@ -1304,9 +1304,41 @@ __global__ void ba_points_delta_kernel(BADev d, int to_delta)
     else d.x_p[i] = d.x0_p[i] + d.x_p[i];
 }
 
+// Multi-GPU exchange buffer of the reduced system ("packed-upper S + rhs"): only the blocks the Schur kernels
+// write (row camera >= column camera) travel, row by row -- row i of block row bi holds 6 (bi + 1) doubles at
+// 36 bi (bi + 1) / 2 + (i % 6) 6 (bi + 1) -- followed by the n right-hand-side entries: 36 Nc (Nc + 1) / 2 + 6 Nc doubles
+// instead of (6 Nc)^2 + 6 Nc.  One workgroup per row (coalesced both ways), the last one moves the right-hand side.
+__global__ __launch_bounds__(256) void ba_red_pack_kernel(BADev d, double *__restrict__ packed, int unpack)
+{
+    const int n = 6 * d.n_cam;
+    const int i = blockIdx.x;
+    const double *src; double *dst; int cnt;
+    if (i < n) {
+        const int bi = i / 6, r = i - 6 * bi;
+        cnt = 6 * (bi + 1);
+        double *full = d.red + (size_t)i * n;
+        double *pk = packed + (size_t)18 * bi * (bi + 1) + (size_t)r * cnt;
+        src = unpack ? pk : full; dst = unpack ? full : pk;
+    } else {
+        cnt = n;
+        double *full = d.red + (size_t)n * n;
+        double *pk = packed + (size_t)18 * d.n_cam * (d.n_cam + 1);
+        src = unpack ? pk : full; dst = unpack ? full : pk;
+    }
+    for (int k = threadIdx.x; k < cnt; k += 256) dst[k] = src[k];
+}
+
 // ---------------------------------------------------------------------------------------------
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 #define LAUNCH_CHECK() ESFM_HIP_TRY(hipGetLastError())
+
+int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack)
+{
+    if (d.n_cam <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(ba_red_pack_kernel, dim3(6 * d.n_cam + 1), dim3(256), 0, st, d, packed, unpack ? 1 : 0);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
 
 int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx)
 {

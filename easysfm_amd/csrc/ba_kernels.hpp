@@ -62,6 +62,7 @@ struct BADev {
     // Schur part of the reduced system, one contiguous SUM all-reduce buffer:
     //   red = S_schur (n*n, only blocks with row camera >= column camera are written) | rhs_corr (n)
     double *red = nullptr;
+    double *red_packed = nullptr;   // [ba_red_packed_doubles] exchange buffer (allocated on the first sharded solve)
     double *y_c = nullptr;   // [6 n_cam] solution of the reduced system
     double *scal = nullptr;  // [SC_COUNT]
     double *chol = nullptr;  // [(n+1)(n+2)/2] packed-lower work matrix for large n
@@ -78,6 +79,9 @@ struct BADev {
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
 inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
+// what travels between GPUs: the block-lower-triangular part of S row by row, then the right-hand side
+inline size_t ba_red_packed_doubles(int n_cam) { return (size_t)18 * (size_t)n_cam * ((size_t)n_cam + 1) + 6 * (size_t)n_cam; }
+int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack);
 
 int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx);
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian);

@@ -1,0 +1,124 @@
+// Native multi-GPU exchange of the BA path: RCCL (librccl, "nccl" API) over xGMI, one communicator per rank = per GPU.
+// per LM iteration ONE all-reduce(sum) of the reduced camera system (packed block-lower S + rhs),
+// one of the per-camera F'F / F'r blocks on accepted steps, and SUM / MAX over a dozen scalars.  esfm_comm_allreduce has the
+// esfm_allreduce_fn signature, so `esfm_ba_problem_solve(p, opt, esfm_comm_allreduce, comm, &summary)` needs no callback
+// into the host language (round 1 went through a ctypes -> Python -> torch.distributed trampoline on every call).
+//
+// librccl is bound at run time (dlopen): the library stays loadable on a box without RCCL, and inside a PyTorch process the
+// same librccl.so.1 torch already mapped is reused (one RCCL, one HIP runtime per process).
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "common.hpp"
+
+namespace {
+
+// the slice of rccl.h this file uses (ABI of RCCL 2.x / ROCm 7: ncclUniqueId is 128 opaque bytes, ncclComm_t a pointer)
+typedef struct { char internal[ESFM_COMM_ID_BYTES]; } rcclUniqueId;
+typedef void *rcclComm_t;
+enum { rcclSuccess = 0 };
+enum { rcclSum = 0, rcclMax = 2 };
+enum { rcclFloat64 = 8 };
+
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(rcclUniqueId *) = nullptr;
+    int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+
+Rccl &rccl()
+{
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            R.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (R.handle) break;
+        }
+        if (!R.handle) { R.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+        auto sym = [&](const char *s) { void *p = dlsym(R.handle, s); if (!p && R.error.empty()) R.error = std::string("librccl lacks ") + s; return p; };
+        R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+        R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+        R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(sym("ncclAllReduce"));
+        R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return R;
+}
+
+int rccl_ready()
+{
+    Rccl &R = rccl();
+    if (!R.error.empty() || !R.handle) { esfm::set_error("%s", R.error.empty() ? "librccl not loaded" : R.error.c_str()); return ESFM_ERR_COMM; }
+    return ESFM_OK;
+}
+
+}  // namespace
+
+struct esfm_comm {
+    esfm_ctx *ctx = nullptr;
+    rcclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int esfm_comm_get_unique_id(void *id_out)
+{
+    if (!id_out) { esfm::set_error("id_out is NULL"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = rccl_ready()) return rc;
+    rcclUniqueId id;
+    const int r = rccl().GetUniqueId(&id);
+    if (r != rcclSuccess) { esfm::set_error("ncclGetUniqueId: %s", rccl().GetErrorString(r)); return ESFM_ERR_COMM; }
+    memcpy(id_out, id.internal, ESFM_COMM_ID_BYTES);
+    return ESFM_OK;
+}
+
+int esfm_comm_create(esfm_ctx *ctx, const void *id, int rank, int world, esfm_comm **out)
+{
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) { esfm::set_error("esfm_comm_create: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (int rc = rccl_ready()) return rc;
+    if (int rc = esfm::set_device(ctx)) return rc;
+    rcclUniqueId uid;
+    memcpy(uid.internal, id, ESFM_COMM_ID_BYTES);
+    rcclComm_t c = nullptr;
+    const int r = rccl().CommInitRank(&c, world, uid, rank);
+    if (r != rcclSuccess) { esfm::set_error("ncclCommInitRank(rank %d of %d): %s", rank, world, rccl().GetErrorString(r)); return ESFM_ERR_COMM; }
+    auto *C = new esfm_comm();
+    C->ctx = ctx; C->comm = c; C->rank = rank; C->world = world;
+    *out = C;
+    return ESFM_OK;
+}
+
+int esfm_comm_destroy(esfm_comm *c)
+{
+    if (!c) return ESFM_OK;
+    if (c->ctx) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+    if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+    delete c;
+    return ESFM_OK;
+}
+
+int esfm_comm_rank(const esfm_comm *c) { return c ? c->rank : -1; }
+int esfm_comm_world(const esfm_comm *c) { return c ? c->world : 0; }
+
+// esfm_allreduce_fn: user = esfm_comm*
+int esfm_comm_allreduce(void *user, double *buf_dev, int64_t count, int op, void *hip_stream)
+{
+    esfm_comm *c = static_cast<esfm_comm *>(user);
+    if (!c || !c->comm || (count > 0 && !buf_dev) || count < 0) { esfm::set_error("esfm_comm_allreduce: bad arguments"); return 1; }
+    if (count == 0 || c->world == 1) return 0;
+    const int r = rccl().AllReduce(buf_dev, buf_dev, (size_t)count, rcclFloat64, op == ESFM_REDUCE_MAX ? rcclMax : rcclSum, c->comm,
+                                   static_cast<hipStream_t>(hip_stream));
+    if (r != rcclSuccess) { esfm::set_error("ncclAllReduce(%lld doubles): %s", (long long)count, rccl().GetErrorString(r)); return 1; }
+    return 0;
+}
+
+}  // extern "C"

@@ -62,6 +62,7 @@ struct esfm_ctx {
     size_t pinned_cap = 0;
     int64_t last_n_queries = 0;
     size_t last_pair_bytes = 0;
+    int l2_audit = 0;   // esfm_ctx_set_l2_audit: 0 product path, 1 no re-scan, 2 exact scan of every query
     int pin(size_t bytes);
     // optional per-kernel hipEvent timing (esfm_ctx_set_kernel_timing)
     bool timing = false;

@@ -60,12 +60,13 @@ int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
         return ESFM_OK;
     }
     // the pinned buffer may still be the source of an in-flight copy: drain before rewriting it
+    ctx->last_pair_bytes = 0;   // the cache is valid only once the new table's copy has been enqueued
     ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int rc = ctx->pin(bytes)) return rc;
     if (int rc = ctx->pair_tab.reserve(bytes)) return rc;
     memcpy(ctx->pinned, plan.tab.data(), bytes);
-    ctx->last_pair_bytes = bytes;
     ESFM_HIP_TRY(hipMemcpyAsync(ctx->pair_tab.ptr, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->last_pair_bytes = bytes;
     *dev_tab = ctx->pair_tab.as<PairDesc>();
     return ESFM_OK;
 }
@@ -82,7 +83,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
         if (int rc = ctx->counters.reserve(64)) return rc;
         ESFM_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 64, st));
         ctx->last_n_queries = plan.total_queries;
-        if (esfm::l2_mfma_supported(width)) {
+        if (esfm::l2_mfma_supported(width) && ctx->l2_audit != 2) {
             if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
             const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
@@ -101,6 +102,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                                                       knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))
                     return rc;
             }
+            if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the pass's own answer in place
             // certificate failures: exact scan, grid-stride over the device-side count (no host sync)
             const int grid = (int)std::min<int64_t>(plan.total_queries, 8 * (int64_t)ctx->num_cu);
             esfm::KernelTimer tm(ctx, ESFM_K_L2_RESCAN);
@@ -273,6 +275,31 @@ int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanne
     }
     if (n_queries) *n_queries = ctx->last_n_queries;
     if (n_rescanned) *n_rescanned = c;
+    return ESFM_OK;
+}
+
+int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) { esfm::set_error("esfm_ctx_set_l2_audit: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    ctx->l2_audit = mode;
+    return ESFM_OK;
+}
+
+int esfm_match_last_flagged(esfm_ctx *ctx, int32_t *out, int64_t cap, int64_t *n)
+{
+    if (!ctx || !n || cap < 0 || (cap > 0 && !out)) { esfm::set_error("esfm_match_last_flagged: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+    int32_t c = 0;
+    if (ctx->counters.ptr) {
+        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *n = c;
+    const int64_t k = std::min<int64_t>(std::min<int64_t>(c, cap), (int64_t)(ctx->flagged.cap / (2 * sizeof(int32_t))));
+    if (k > 0) {
+        ESFM_HIP_TRY(hipMemcpyAsync(out, ctx->flagged.ptr, sizeof(int32_t) * 2 * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return ESFM_OK;
 }
 

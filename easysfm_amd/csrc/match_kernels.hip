@@ -24,6 +24,7 @@
 #include "match_kernels.hpp"
 
 #include <float.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -125,6 +126,29 @@ __device__ __forceinline__ float l2sqr_canonical(const float *__restrict__ a, co
         d = __fadd_rn(d, __fmul_rn(t, t));
     }
     return d;
+}
+
+// l2sqr_canonical for 64-float rows held in registers: the same 8 chains, the same final order.
+__device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], const float4 (&b)[16])
+{
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float av[8] = {a[2 * j].x, a[2 * j].y, a[2 * j].z, a[2 * j].w, a[2 * j + 1].x, a[2 * j + 1].y, a[2 * j + 1].z, a[2 * j + 1].w};
+        const float bv[8] = {b[2 * j].x, b[2 * j].y, b[2 * j].z, b[2 * j].w, b[2 * j + 1].x, b[2 * j + 1].y, b[2 * j + 1].z, b[2 * j + 1].w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = __fsub_rn(av[c], bv[c]);
+            acc[c] = __fadd_rn(acc[c], __fmul_rn(t, t));
+        }
+    }
+    const float s0 = __fadd_rn(acc[0], acc[4]);
+    const float s1 = __fadd_rn(acc[1], acc[5]);
+    const float s2 = __fadd_rn(acc[2], acc[6]);
+    const float s3 = __fadd_rn(acc[3], acc[7]);
+    float d = __fadd_rn(s0, s1);
+    d = __fadd_rn(d, s2);
+    return __fadd_rn(d, s3);
 }
 
 // Correctly rounded f32 square root.  NOT __fsqrt_rn: in this toolchain that maps to
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
     out_q[4 * g] = h0; out_q[4 * g + 1] = h1; out_q[4 * g + 2] = l0; out_q[4 * g + 3] = l1;
 }
 
-template <int TT, int NS>
+template <int TT, int NS, int GRP>
 __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
                                                              const u32x4 *__restrict__ split_q, const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
@@ -483,6 +507,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [2][TT*SLOTS]
     float *lds_norm = reinterpret_cast<float *>(smem + 2 * TT * SLOTS * 16);   // [2][TT]
     float *lds_red = lds_norm + 2 * TT;                                        // [4]
+    float *lds_master = lds_red + 4;                                           // [NS][6][256]: per-thread master top-3 (keys, segments)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -514,53 +539,85 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     // max |t|^2 and the queries' |q|^2
     float tmax_part = 0.f;
     for (int t = tid; t < nt; t += 256) tmax_part = fmaxf(tmax_part, tn[t]);
-    float qnorm[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { const int qrow = qbase + 32 * s + j; qnorm[s] = norms[pd.q_row0 + (qrow < nq ? qrow : 0)]; }
 
-    // running top-3 per query set: segment keys (8-bit position code in the low mantissa bits) and master (key, row)
+    // Running top-3 per query set, TWO levels deep in the hot loop.  A lane's 16 results of a 32-train step are four groups of
+    // four consecutive train rows (accumulator registers 4g .. 4g+3 = rows 8g + 4h + 0..3).  Per group: the minimum of the four raw
+    // scores (two v_min3_f32), the 8-bit position code (6 bits step in segment, 2 bits group) into the low mantissa bits of that
+    // minimum (one v_and_or_b32), and the three-smallest network on the group key (three v_med3_f32): 6 VALU per 4 results
+    // instead of 16.  The two nearest trains of a query lie in the (at most two) groups with the smallest minima; the third
+    // group key bounds every row outside the kept groups, which is what the certificate needs.  The tail re-ranks the kept groups'
+    // rows exactly -- four consecutive 256-B rows per group.
+    // (Measured on MI355X, scratch/ubench/mfma_issue: in SHADER CYCLES up to six VALU instructions hide behind every bf16 MFMA --
+    // the shipped 5.33-per-MFMA fold included; what they cost is POWER: the chip is clock-limited on random operands, 1660 TFLOP/s
+    // with the 4-per-result fold beside the MFMAs against 1805 with this one and 1690-1940 with none.)
     constexpr float kBig = 3.0e38f;
-    constexpr int kSegSub = 16;
-    float k0[NS], k1[NS], k2[NS], v0[NS], v1[NS], v2[NS];
-    int c0[NS], c1[NS], c2[NS];
+    static_assert(GRP == 2 || GRP == 4, "group = 2 or 4 consecutive train rows");
+    constexpr int NG = 16 / GRP;              // groups per lane per 32-train step
+    constexpr int kSegSub = 256 / NG;         // steps per segment: the 8-bit code is (step in segment) * NG + group
+    // The master top-3 (key, first step of the key's segment) is touched once per segment (2048 trains): it lives in LDS, a
+    // private column per thread, so that the main loop's registers go to the pipeline.
+    float k0[NS], k1[NS], k2[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { k0[s] = k1[s] = k2[s] = v0[s] = v1[s] = v2[s] = kBig; c0[s] = c1[s] = c2[s] = -1; }
+    for (int s = 0; s < NS; ++s) {
+        k0[s] = k1[s] = k2[s] = kBig;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { lds_master[(6 * s + m) * 256 + tid] = kBig; lds_master[(6 * s + 3 + m) * 256 + tid] = __int_as_float(-1); }
+    }
     float tmax;
     unsigned kmask = 0xFFFFFF00u;
     asm volatile("" : "+v"(kmask));
-    auto fold = [&](int s, float val, int code0 /* wave-uniform, multiple of 16 */, int r) {
-        // plain C so that hipcc sees an MFMA result feeding a VALU instruction and keeps the required wait states (an inline-asm
-        // reader is not hazard-checked: scheduled right behind the last MFMA of a step it read stale accumulators, rarely);
-        // with the mask pinned in a VGPR this is still one v_and_or_b32 with the code as its SGPR operand
-        const float key = __uint_as_float((__float_as_uint(val) & kmask) | (unsigned)(code0 + r));
+    auto fold_group = [&](int s, const floatx16 &p, int g, int code0 /* wave-uniform */) {
+        // plain C (an inline-asm reader of MFMA results is not hazard-checked by hipcc).  Seeding the chain with the constant keeps
+        // hipcc from canonicalising the operands (v_max x, x): exactly GRP / 2 v_min3_f32; a NaN score loses every minimum.
+        float gm = __builtin_fminf(__builtin_fminf(kBig, p[GRP * g]), p[GRP * g + 1]);
+        if (GRP == 4) gm = __builtin_fminf(__builtin_fminf(gm, p[GRP * g + 2]), p[GRP * g + 3]);
+        const int code = code0 + g;
+        const float key = __uint_as_float((__float_as_uint(gm) & kmask) | (unsigned)code);
         k2[s] = __builtin_amdgcn_fmed3f(k1[s], k2[s], key);
         k1[s] = __builtin_amdgcn_fmed3f(k0[s], k1[s], key);
         k0[s] = __builtin_amdgcn_fmed3f(k0[s], key, -kBig);
     };
-    // the master keeps (key, first step of the key's segment); the train row is decoded from the two once, at the end
-    auto master_insert = [&](int s, float key, int seg_sub0 /* wave-uniform */) {
-        const bool live = key < 1.0e38f;
-        const bool l2 = live && key < v2[s], l1 = live && key < v1[s], l0 = live && key < v0[s];
-        const int t2 = l2 ? seg_sub0 : c2[s];
-        const int t1 = l1 ? seg_sub0 : c1[s];
-        c2[s] = l1 ? c1[s] : t2;
-        c1[s] = l0 ? c0[s] : t1;
-        c0[s] = l0 ? seg_sub0 : c0[s];
-        const float n2 = l2 ? key : v2[s];
-        const float n1 = l1 ? key : v1[s];
-        v2[s] = l1 ? v1[s] : n2;
-        v1[s] = l0 ? v0[s] : n1;
-        v0[s] = l0 ? key : v0[s];
+    // the master keeps (key, first step of the key's segment); the group's rows are decoded from the two once, at the end
+    struct Master { float v0, v1, v2; int c0, c1, c2; };
+    auto master_load = [&](int s) {
+        Master m;
+        m.v0 = lds_master[(6 * s + 0) * 256 + tid]; m.v1 = lds_master[(6 * s + 1) * 256 + tid]; m.v2 = lds_master[(6 * s + 2) * 256 + tid];
+        m.c0 = __float_as_int(lds_master[(6 * s + 3) * 256 + tid]); m.c1 = __float_as_int(lds_master[(6 * s + 4) * 256 + tid]);
+        m.c2 = __float_as_int(lds_master[(6 * s + 5) * 256 + tid]);
+        return m;
     };
-    auto train_row_of = [&](float key, int seg_sub0) {
+    auto master_store = [&](int s, const Master &m) {
+        lds_master[(6 * s + 0) * 256 + tid] = m.v0; lds_master[(6 * s + 1) * 256 + tid] = m.v1; lds_master[(6 * s + 2) * 256 + tid] = m.v2;
+        lds_master[(6 * s + 3) * 256 + tid] = __int_as_float(m.c0); lds_master[(6 * s + 4) * 256 + tid] = __int_as_float(m.c1);
+        lds_master[(6 * s + 5) * 256 + tid] = __int_as_float(m.c2);
+    };
+    auto master_insert = [&](Master &m, float key, int seg_sub0 /* wave-uniform */) {
+        const bool live = key < 1.0e38f;
+        const bool l2 = live && key < m.v2, l1 = live && key < m.v1, l0 = live && key < m.v0;
+        const int t2 = l2 ? seg_sub0 : m.c2;
+        const int t1 = l1 ? seg_sub0 : m.c1;
+        m.c2 = l1 ? m.c1 : t2;
+        m.c1 = l0 ? m.c0 : t1;
+        m.c0 = l0 ? seg_sub0 : m.c0;
+        const float n2 = l2 ? key : m.v2;
+        const float n1 = l1 ? key : m.v1;
+        m.v2 = l1 ? m.v1 : n2;
+        m.v1 = l0 ? m.v0 : n1;
+        m.v0 = l0 ? key : m.v0;
+    };
+    // first of the GRP consecutive train rows of the group a key names (-1: empty slot): accumulator register r holds row
+    // (r & 3) + 8 (r >> 2) + 4 h of its step
+    auto group_row0_of = [&](float key, int seg_sub0) {
         const int code = (int)(__float_as_uint(key) & 0xFFu);
-        const int r = code & 15;
-        return key < 1.0e38f ? (seg_sub0 + (code >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h : -1;
+        const int r0 = GRP * (code % NG);
+        return key < 1.0e38f ? (seg_sub0 + code / NG) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h : -1;
     };
     auto flush = [&](int seg_sub0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            master_insert(s, k0[s], seg_sub0); master_insert(s, k1[s], seg_sub0); master_insert(s, k2[s], seg_sub0);
+            Master m = master_load(s);
+            master_insert(m, k0[s], seg_sub0); master_insert(m, k1[s], seg_sub0); master_insert(m, k2[s], seg_sub0);
+            master_store(s, m);
             k0[s] = k1[s] = k2[s] = kBig;
         }
     };
@@ -573,13 +630,13 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     const u32x4 trsrc = raw_buffer_rsrc(split + (size_t)pd.t_row0 * SLOTS, (uint32_t)nt * (DIM * 4));   // reads past it return 0
     const uint32_t lds_tile_addr = (uint32_t)(uintptr_t)lds_tile;   // LDS byte address (the low 32 bits of the flat pointer's offset)
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave * (TT / 4));      // this wave stages rows [wrow0, wrow0 + TT / 4) of a tile
-    int voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wrow0 + 4 * i + (lane >> 4);
-        voff[i] = row * (DIM * 4) + (((lane & 15) ^ (row & 15)) * 16);       // rows 16 apart share the swizzle: i and i + 4
-    }
     auto dma_tile = [&](int tile, int buf) {
+        int voff[4];                                                          // recomputed per tile: a few VALU against 4 registers
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wrow0 + 4 * i + (lane >> 4);
+            voff[i] = row * (DIM * 4) + (((lane & 15) ^ (row & 15)) * 16);   // rows 16 apart share the swizzle: i and i + 4
+        }
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const uint32_t dst = lds_tile_addr + (uint32_t)((buf * TT * SLOTS + (wrow0 + 4 * i) * SLOTS) * 16);
@@ -610,8 +667,9 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     lds_dma_wait();
     __syncthreads();
 
-    // One 32-train step: 24 MFMAs into (n0, n1) with the fold of the PREVIOUS step's results (p0, p1) between them.
-    auto step = [&](int buf, int base, floatx16 (&n)[NS], const floatx16 (&p)[NS], int pcode) {
+    // One 32-train step: 24 MFMAs into (n0, n1) with the fold of the PREVIOUS step's results (p0, p1) between them: K-step ks
+    // carries group ks of both query sets (2 x 6 VALU beside 6 MFMAs).
+    auto step = [&](int buf, int base, floatx16 (&n)[NS], const floatx16 (&p)[NS], int pcode /* NG x (step in segment), wave-uniform */) {
         floatx16 cinit;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -625,21 +683,17 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[(4 * ks + h) ^ sw]);
             const bf16x8 alo = __builtin_bit_cast(bf16x8, rowp[(4 * ks + 2 + h) ^ sw]);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[s][ks], ks == 0 ? cinit : n[s], 0, 0, 0);
-                fold(s, p[s][4 * ks + 0], pcode, 4 * ks + 0);
+            for (int s = 0; s < NS; ++s) n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[s][ks], ks == 0 ? cinit : n[s], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG / 4; ++g) fold_group(0, p[0], (NG / 4) * ks + g, pcode);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[s][ks], n[s], 0, 0, 0);
+            if (NS > 1) {
+#pragma unroll
+                for (int g = 0; g < NG / 4; ++g) fold_group(NS - 1, p[NS - 1], (NG / 4) * ks + g, pcode);
             }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[s][ks], n[s], 0, 0, 0);
-                fold(s, p[s][4 * ks + 1], pcode, 4 * ks + 1);
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[s][ks], n[s], 0, 0, 0);
-                fold(s, p[s][4 * ks + 2], pcode, 4 * ks + 2);
-                fold(s, p[s][4 * ks + 3], pcode, 4 * ks + 3);
-            }
+            for (int s = 0; s < NS; ++s) n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[s][ks], n[s], 0, 0, 0);
         }
     };
     floatx16 ra[NS], rb[NS];
@@ -659,9 +713,9 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         for (int sp = 0; sp < TT / 64; ++sp) {
             const int sub = (TT / 32) * tile + 2 * sp;                         // global 32-row step index of the first step
             // step `sub` folds step sub - 1 (codes of its position inside its segment)
-            step(buf, 64 * sp, ra, rb, __builtin_amdgcn_readfirstlane(((sub + kSegSub - 1) % kSegSub) * 16));
+            step(buf, 64 * sp, ra, rb, __builtin_amdgcn_readfirstlane(((sub + kSegSub - 1) % kSegSub) * NG));
             if (sub > 0 && sub % kSegSub == 0) flush(sub - kSegSub);           // step sub - 1 closed a segment
-            step(buf, 64 * sp + 32, rb, ra, __builtin_amdgcn_readfirstlane((sub % kSegSub) * 16));
+            step(buf, 64 * sp + 32, rb, ra, __builtin_amdgcn_readfirstlane((sub % kSegSub) * NG));
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) norm_store(buf ^ 1, next_norm);
@@ -671,11 +725,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     {
         const int nsub = (TT / 32) * ntiles;
         if (nsub > 0) {
-            const int pcode = ((nsub - 1) % kSegSub) * 16;
+            const int pcode = ((nsub - 1) % kSegSub) * NG;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int s = 0; s < NS; ++s) fold(s, rb[s][r], pcode, r);
+                for (int s = 0; s < NS; ++s) fold_group(s, rb[s], g, pcode);
             flush(((nsub - 1) / kSegSub) * kSegSub);
         }
     }
@@ -690,48 +744,88 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     }
 
-    // ---- exact re-rank of this lane's 3 candidates per set in the oracle's order, certificate ----
+    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate ----
+    // A query's six kept groups (three per half-wave lane) are ranked by key across the two lanes and dealt out alternately --
+    // global rank 2 r + h goes to lane half h in round r -- so the two groups that usually matter cost ONE round of four rows
+    // whichever lanes found them.  A group is skipped when it provably cannot hold one of the two nearest: with ka <= kb the two
+    // smallest of the six keys (two groups, hence two different rows: the groups' minima), both of those rows' exact d^2 are
+    // <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-15 |k| being the certificate's bound on |(|q|^2 + key) - d^2|;
+    // every row of a group with |q|^2 + k - E(k) > U (1 + 2^-20) -- k its minimum -- is farther than both even after sqrtf's
+    // rounding.  Keys only grow with the rank, so the rounds stop at the first one no lane of the wave needs.
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
         Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
-        float ed[3], ed2[3];
-        int ei[3];
+        const Master mst = master_load(s);
+        const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
         {
-            const float vk[3] = {v0[s], v1[s], v2[s]};
-            const int cc[3] = {train_row_of(v0[s], c0[s]), train_row_of(v1[s], c1[s]), train_row_of(v2[s], c2[s])};
-            // Only candidates that can be among the two nearest are re-ranked.  With ka <= kb the two smallest of the query's six
-            // keys, both of their exact d^2 are <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-15 |k| being the
-            // certificate's bound on |(|q|^2 + key) - d^2|; a candidate with |q|^2 + k - E(k) > U (1 + 2^-20) is farther than
-            // both even after sqrtf's rounding.  Typically one candidate per lane survives instead of three.
-            const float p0 = __shfl_xor(vk[0], 32), p1 = __shfl_xor(vk[1], 32);
-            const float kb = fminf(fmaxf(vk[0], p0), fminf(vk[1], p1));
-            const double qn = (double)qnorm[s];
+            const float vk[3] = {mst.v0, mst.v1, mst.v2};
+            const int g0[3] = {group_row0_of(mst.v0, mst.c0), group_row0_of(mst.v1, mst.c1), group_row0_of(mst.v2, mst.c2)};
+            float pk[3]; int pg[3], rank_own[3], rank_par[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
+                rank_own[i] = i; rank_par[i] = i;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    rank_own[i] += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
+                    rank_par[i] += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
+                }
+            }
+            const float kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));
+            const double qn = (double)qnorm_s;
             const double e1 = (qn + (double)tmax) * (1.0 / 32768.0);
             constexpr double kTrunc = 1.0001 / 32768.0;   // |key - s| < 2^8 ulp(s) <= 2^-15 |s|: 8 mantissa bits hold the position code
             const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
-            const float *qp = Q + (size_t)(qvalid ? qrow : 0) * DIM;
+            const float4 *qp = reinterpret_cast<const float4 *>(Q + (size_t)(qvalid ? qrow : 0) * DIM);
+            float4 qv[16];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                ei[m] = -1; ed[m] = FLT_MAX; ed2[m] = 0.f;
-                const bool cannot = (qn + (double)vk[m] - e1 - fabs((double)vk[m]) * kTrunc) > U;   // false on NaN: re-rank
-                if (cc[m] >= 0 && qvalid && !cannot) {
-                    const int t = cc[m];
-                    const float d2 = l2sqr_canonical<true>(qp, T + (size_t)t * DIM, DIM);
-                    ei[m] = t; ed2[m] = d2; ed[m] = sqrt_rn_f32(d2);
+            for (int c = 0; c < 16; ++c) qv[c] = qp[c];
+            for (int r = 0; r < 3; ++r) {
+                const int want = 2 * r + h;
+                float key = kBig; int row0 = -1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
+                    if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
+                }
+                const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
+#ifdef ESFM_DIAG_NOTAIL
+                const bool need = row0 == -12345;
+#else
+                const bool need = row0 >= 0 && qvalid && !cannot;
+#endif
+                if (__ballot(need) == 0ull) break;
+                if (need) {
+                    // four consecutive 256-B rows, two at a time (their 32 loads in flight together); a group at the end of the
+                    // train set may reach into the padding: clamped address, result dropped
+#pragma unroll
+                    for (int u = 0; u < GRP; u += 2) {
+                        const int ta_ = row0 + u, tb_ = row0 + u + 1;
+                        const float4 *pa = reinterpret_cast<const float4 *>(T + (size_t)min(ta_, nt - 1) * DIM);
+                        const float4 *pb = reinterpret_cast<const float4 *>(T + (size_t)min(tb_, nt - 1) * DIM);
+                        float4 ra_[16], rb_[16];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) ra_[c] = pa[c];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) rb_[c] = pb[c];
+                        const float da = l2sqr64_canonical_regs(qv, ra_), db = l2sqr64_canonical_regs(qv, rb_);
+                        if (ta_ < nt) best2_insert(b0, b1, sqrt_rn_f32(da), ta_, da);
+                        if (tb_ < nt) best2_insert(b0, b1, sqrt_rn_f32(db), tb_, db);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int m = 0; m < 3; ++m) best2_insert(b0, b1, ed[m], ei[m], ed2[m]);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const float pd_ = __shfl_xor(ed[m], 32), pd2 = __shfl_xor(ed2[m], 32);
-            const int pi_ = __shfl_xor(ei[m], 32);
-            best2_insert(b0, b1, pd_, pi_, pd2);
+        {
+            // the other half-wave evaluated the other groups of this query: merge its two best ((distance, index) is a total order)
+            const float pd0 = __shfl_xor(b0.d, 32), pq0 = __shfl_xor(b0.d2, 32), pd1 = __shfl_xor(b1.d, 32), pq1 = __shfl_xor(b1.d2, 32);
+            const int pi0 = __shfl_xor(b0.i, 32), pi1 = __shfl_xor(b1.i, 32);
+            best2_insert(b0, b1, pd0, pi0, pq0);
+            best2_insert(b0, b1, pd1, pi1, pq1);
         }
-        const float tau = fminf(v2[s], __shfl_xor(v2[s], 32));  // every train outside the 6 candidates has key >= tau
+        const float tau = fminf(mst.v2, __shfl_xor(mst.v2, 32));  // every train outside the 6 kept groups has key >= its group's key >= tau
         if (qvalid && h == 0) {
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
             knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
@@ -741,7 +835,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             // canonical distance 96 u, of |q|^2 + 2 |t|^2 at most; keys are s with 8 mantissa bits replaced (< 2^-15 |s|).
             bool certified = !(tau < 1.0e38f);
             if (!certified && b1.i >= 0) {
-                const double qn = (double)qnorm[s];
+                const double qn = (double)qnorm_s;
                 const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0001 / 32768.0);
                 certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
             }
@@ -806,28 +900,6 @@ __global__ __launch_bounds__(256) void l2_exact_scan_kernel(const float *__restr
 // the handful of flagged queries (0.06 % on M-SURF-4k) leaves the chip nearly empty, so a thread keeps its query row in
 // registers and has the loads of two train rows in flight at a time, and the (distance, index) reduction runs on wave
 // shuffles.  l2sqr64_canonical_regs is l2sqr_canonical on register operands: the same 8 chains, the same final order.
-__device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], const float4 (&b)[16])
-{
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float av[8] = {a[2 * j].x, a[2 * j].y, a[2 * j].z, a[2 * j].w, a[2 * j + 1].x, a[2 * j + 1].y, a[2 * j + 1].z, a[2 * j + 1].w};
-        const float bv[8] = {b[2 * j].x, b[2 * j].y, b[2 * j].z, b[2 * j].w, b[2 * j + 1].x, b[2 * j + 1].y, b[2 * j + 1].z, b[2 * j + 1].w};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float t = __fsub_rn(av[c], bv[c]);
-            acc[c] = __fadd_rn(acc[c], __fmul_rn(t, t));
-        }
-    }
-    const float s0 = __fadd_rn(acc[0], acc[4]);
-    const float s1 = __fadd_rn(acc[1], acc[5]);
-    const float s2 = __fadd_rn(acc[2], acc[6]);
-    const float s3 = __fadd_rn(acc[3], acc[7]);
-    float d = __fadd_rn(s0, s1);
-    d = __fadd_rn(d, s2);
-    return __fadd_rn(d, s3);
-}
-
 __global__ __launch_bounds__(256) void l2_rescan64_kernel(const float *__restrict__ desc, const PairDesc *__restrict__ pairs,
                                                           const int32_t *__restrict__ flagged, const int32_t *__restrict__ counters,
                                                           int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
@@ -1222,6 +1294,10 @@ bool l2_bf16_pass(int dim)
     static const bool forced_f32 = [] { const char *e = getenv("ESFM_L2_PASS"); return e && strcmp(e, "f32") == 0; }();
     return dim == 64 && !forced_f32;
 }
+#ifndef ESFM_L2_GROUP
+#define ESFM_L2_GROUP 4
+#endif
+constexpr int kL2BfGroup = ESFM_L2_GROUP;   // consecutive train rows folded as one group in l2_knn_bf16_kernel (2 or 4)
 constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_kernel (1: 3 waves per SIMD, measured 7-15 % slower)
 int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
@@ -1243,8 +1319,9 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
-    constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16;
-    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT, kL2BfSets>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
+    constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16 + kL2BfSets * 6 * 256 * 4;   // two tiles, their norms, the master top-3
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT, kL2BfSets, kL2BfGroup>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
                        reinterpret_cast<const u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, pairs,
                        n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap);
     ESFM_HIP_TRY(hipGetLastError());

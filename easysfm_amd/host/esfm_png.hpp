@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,10 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
         pos += 12 + (size_t)len;
     }
     if (color < 0 || width == 0 || height == 0) return path + ": no image header";
+    // bound the header before anything is sized from it: (stride + 1) * height must not overflow and a crafted IHDR must come back
+    // as an error string, not as std::length_error / bad_alloc (65 536 x 65 536 at most, 2^28 pixels = 1 GiB of RGBA8 at most)
+    if (width > (1u << 16) || height > (1u << 16) || (uint64_t)width * (uint64_t)height > ((uint64_t)1 << 28))
+        return path + ": image dimensions out of range";
     if (interlace != 0) return path + ": Adam7-interlaced PNGs are not supported";
     int channels;
     switch (color) {
@@ -76,7 +81,8 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
     // filters work on whole bytes: the "pixel" distance is one byte for sub-byte samples
     const size_t bps = sub_byte ? 1 : (size_t)depth / 8, bpp = bps * (size_t)channels;
     const size_t stride = sub_byte ? ((size_t)width * (size_t)depth + 7) / 8 : bpp * width;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)height);
+    std::vector<uint8_t> raw;
+    try { raw.resize((stride + 1) * (size_t)height); } catch (const std::exception &) { return path + ": out of memory"; }
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return path + ": inflate failed";
     // undo the scanline filters in place (filter byte + stride bytes per row)
@@ -101,16 +107,22 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
         std::memcpy(prev.data(), cur, stride);
     }
     rows = (int)height; cols = (int)width;
-    bgr.resize((size_t)rows * cols * 3);
+    try { bgr.resize((size_t)rows * cols * 3); } catch (const std::exception &) { return path + ": out of memory"; }
     for (int y = 0; y < rows; ++y) {
         const uint8_t *cur = &raw[(stride + 1) * (size_t)y + 1];
         uint8_t *dst = &bgr[(size_t)y * cols * 3];
         for (int x = 0; x < cols; ++x) {
-            const uint8_t *p = cur + (size_t)x * bpp;   // 16-bit samples: big endian, the high byte comes first
-            uint8_t sample = p[0];
-            if (sub_byte) {                             // leftmost pixel in the high-order bits
+            // whole-byte samples: pixel x starts at byte x * bpp (16-bit: big endian, the high byte comes first);
+            // sub-byte samples are addressed by bit, leftmost pixel in the high-order bits -- p must not be formed from x * bpp there
+            // (it would run up to width - stride bytes past the row)
+            const uint8_t *p = cur;
+            uint8_t sample;
+            if (sub_byte) {
                 const size_t bit = (size_t)x * (size_t)depth;
                 sample = (uint8_t)((cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1 << depth) - 1));
+            } else {
+                p = cur + (size_t)x * bpp;
+                sample = p[0];
             }
             uint8_t r, g, b;
             if (color == 0 || color == 4) { r = g = b = sub_byte ? (uint8_t)(sample * (255 / ((1 << depth) - 1))) : sample; }

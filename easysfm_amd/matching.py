@@ -250,6 +250,18 @@ class PairMatcher:
             _ptr(self.offset)))
         return self.knn_idx, self.knn_dist
 
+    def set_l2_audit(self, mode: int) -> None:
+        """Certificate audit (tests): 0 product path, 1 skip the exact re-scan, 2 brute-force every query (esfm.h)."""
+        check(lib().esfm_ctx_set_l2_audit(self.ctx.handle, int(mode)))
+
+    def flagged(self) -> np.ndarray:
+        """(pair index, query row) of the queries the last L2 call could not certify; synchronises."""
+        n = C.c_int64(0)
+        check(lib().esfm_match_last_flagged(self.ctx.handle, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 2), np.int32)
+        check(lib().esfm_match_last_flagged(self.ctx.handle, _ptr(out), n.value, C.byref(n)))
+        return out[:n.value].copy()
+
     def stats(self) -> Tuple[int, int]:
         """(queries, queries re-scanned exactly) of the last L2 call; synchronises."""
         a = C.c_int64(0); b = C.c_int64(0)

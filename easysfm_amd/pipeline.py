@@ -2,8 +2,8 @@
 stages of this package: all-pairs matching -> 5-point RANSAC + relative depth per pair -> track ids -> initial pair ->
 triangulation -> BA -> (next frame by PnP -> triangulation -> periodic BA)* -> final BA -> SOR filter -> .ply.
 
-Feature extraction (detectFeaturesSURF / ORB from pixels, sfm.cpp:84-126) is SURVEY.md section 8 row f-2 and is not built:
-``run_sfm`` starts from frames that already carry keypoints and descriptors.  The stages that the reference runs pair by
+Feature extraction (detectFeaturesSURF / detectFeaturesORB from pixels, sfm.cpp:84-126) lives in
+``features.py``; ``run_sfm`` starts from frames that already carry keypoints and descriptors.  The stages that the reference runs pair by
 pair but whose results do not depend on the loop state (matching, RANSAC, pose recovery, depth) are batched over all pairs;
 the track bookkeeping that does depend on it runs in the reference's order."""
 from __future__ import annotations
@@ -44,8 +44,8 @@ def match_and_verify_all_pairs(frames: Sequence[Frame], use_feature: str = "S", 
     graph: List[List[FramePair]] = [[FramePair(i, j) for j in range(i)] for i in range(n)]
     if len(pairs) == 0:
         return graph
-    bank = DescriptorBank([f.descriptors for f in frames], metric)
-    res = PairMatcher(bank, pairs).match(ratio).to_host()
+    bank = DescriptorBank([f.descriptors for f in frames], metric, device=f"cuda:{ctx.device}")
+    res = PairMatcher(bank, pairs, ctx).match(ratio).to_host()      # PairMatcher drains torch's upload stream before its first launch
     # RANSAC + pose for every pair with enough matches, in shared launches
     sel = [k for k in range(len(pairs)) if len(res[k][0]) > num_min_pair]
     if sel:

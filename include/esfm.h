@@ -162,6 +162,17 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
  * exactly (see DESIGN.md "certified re-rank").  For tests and profiling. */
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned);
 
+/* Audit of the L2 certificate (tests only; the default mode 0 is the product path).
+ *   mode 1: the MFMA pass runs but the exact re-scan of uncertified queries is SKIPPED, so the
+ *           2-NN table holds the pass's own answer for every query;
+ *   mode 2: every query is brute-forced by l2_exact_scan_kernel (no MFMA pass).
+ * Diffing the two tables row by row and removing the rows esfm_match_last_flagged() lists gives
+ * the number of queries the certificate accepted with a wrong answer; it must be 0. */
+int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode);
+/* The (pair, query row) entries the last L2 batched call flagged as uncertified: writes
+ * min(*n, cap) entries of 2 x int32 to `out` (host) and the count to *n.  Synchronises. */
+int esfm_match_last_flagged(esfm_ctx *ctx, int32_t *out, int64_t cap, int64_t *n);
+
 /* Host-only helper (no GPU needed): the (i, j<i) pair list of sfm.cpp:140-143
  * for n_frames frames, restricted to shard `rank` of `world` by a cost-balanced
  * partition (cost = nq*nt when rows_per_frame is given, else 1).  Writes pairs
@@ -233,13 +244,31 @@ void esfm_ba_options_default(esfm_ba_options *opt);
  * on `hip_stream`; op = ESFM_REDUCE_SUM or ESFM_REDUCE_MAX.  Return 0 on success.
  * Used only when the caller shards observations over several GPUs (one rank per
  * GPU); NULL = single GPU.  A torch.distributed (RCCL) implementation is in
- * easysfm_amd/ba.py.  Per LM iteration the solver issues one SUM over the
- * reduced camera system ((6 n_cam)^2 + 6 n_cam doubles), one SUM over the
+ * easysfm_amd/ba.py; the library's own RCCL one is esfm_comm_allreduce below.
+ * Per LM iteration the solver issues one SUM over the reduced camera system,
+ * packed block-lower-triangular (36 n_cam (n_cam + 1) / 2 + 6 n_cam doubles:
+ * 11.8 k at 25 cameras, 4.73 M = 37.8 MB at 512), one SUM over the
  * per-camera F'F / F'r blocks (42 n_cam doubles, accepted steps only), and SUM /
  * MAX over a handful of scalars. */
 #define ESFM_REDUCE_SUM 0
 #define ESFM_REDUCE_MAX 1
 typedef int (*esfm_allreduce_fn)(void *user, double *buf_dev, int64_t count, int op, void *hip_stream);
+
+/* The library's own exchange: RCCL over xGMI, one communicator per rank (= per GPU, per esfm_ctx).
+ * Rank 0 calls esfm_comm_get_unique_id and hands the ESFM_COMM_ID_BYTES bytes to the other ranks by whatever the
+ * host program has (a file, MPI, a torch.distributed store); every rank then calls esfm_comm_create with the same
+ * id (collective: returns once all `world` ranks have joined).  esfm_comm_allreduce IS an esfm_allreduce_fn whose
+ * `user` is the esfm_comm*, so a sharded solve is
+ *     esfm_ba_problem_solve(p, opt, esfm_comm_allreduce, comm, &summary);
+ * with no callback into the host language.  librccl is bound at run time; without it these return ESFM_ERR_COMM. */
+#define ESFM_COMM_ID_BYTES 128
+typedef struct esfm_comm esfm_comm;
+int esfm_comm_get_unique_id(void *id_out /*ESFM_COMM_ID_BYTES*/);
+int esfm_comm_create(esfm_ctx *ctx, const void *id /*ESFM_COMM_ID_BYTES*/, int rank, int world, esfm_comm **out);
+int esfm_comm_destroy(esfm_comm *comm);
+int esfm_comm_rank(const esfm_comm *comm);
+int esfm_comm_world(const esfm_comm *comm);
+int esfm_comm_allreduce(void *comm, double *buf_dev, int64_t count, int op, void *hip_stream);
 
 /*
  * The replacement for setBAProblem's parameter packing + solveBA's

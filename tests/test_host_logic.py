@@ -303,3 +303,50 @@ def test_native_png_reader_matches_pil(tmp_path):
     bad.write_bytes(b"JFIF" * 10)
     r = subprocess.run([exe, "--dump-image", str(bad), str(tmp_path / "x.raw")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 3 and "not a PNG" in r.stdout
+
+
+def test_native_png_reader_under_asan(tmp_path):
+    """the reader, built with AddressSanitizer + UBSan on the CPU, on the inputs that used to go wrong -- sub-byte gray
+    and palette images wider than their byte stride (the per-pixel pointer ran past the row), a header that claims
+    0xFFFFFFFF x 0xFFFFFFFF RGBA16 (allocation size overflow / uncaught std::length_error), and a header whose pixel count is
+    merely absurd.  Every case must either decode to PIL's pixels or come back as an error string; the sanitizers abort otherwise."""
+    import struct
+    import subprocess
+    import zlib
+    PIL = pytest.importorskip("PIL.Image")
+    exe = str(tmp_path / "png_asan")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        os.path.join(ROOT, "tests", "cpp", "png_reader_main.cpp"), "-o", exe, "-lz"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 256, (2, 64), dtype=np.uint8)
+    cases = {"bw_64x2.png": PIL.fromarray(g).convert("1"), "bw_61x7.png": PIL.fromarray(rng.integers(0, 256, (7, 61), dtype=np.uint8)).convert("1"),
+             "pal4_33x5.png": PIL.fromarray(rng.integers(0, 256, (5, 33, 3), dtype=np.uint8)).quantize(16),
+             "pal2_19x3.png": PIL.fromarray(rng.integers(0, 256, (3, 19, 3), dtype=np.uint8)).quantize(4),
+             "pal1_70x2.png": PIL.fromarray(rng.integers(0, 256, (2, 70, 3), dtype=np.uint8)).quantize(2)}
+    for name, im in cases.items():
+        path = str(tmp_path / name)
+        im.save(path, bits={"pal4_33x5.png": 4, "pal2_19x3.png": 2, "pal1_70x2.png": 1}.get(name, 1)) if name.startswith("pal") else im.save(path)
+        out = str(tmp_path / (name + ".raw"))
+        r = subprocess.run([exe, path, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, (name, r.stdout)
+        rows, cols = map(int, r.stdout.split())
+        want = np.asarray(PIL.open(path).convert("RGB"))[:, :, ::-1]
+        assert np.array_equal(np.fromfile(out, np.uint8).reshape(rows, cols, 3), want), name
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    sig = bytes([0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A])
+    for name, (w, h, depth, color) in {"huge.png": (0xFFFFFFFF, 0xFFFFFFFF, 16, 6), "wide.png": (70000, 2, 8, 2),
+                                       "many.png": (60000, 60000, 8, 0), "zero.png": (0, 5, 8, 0)}.items():
+        data = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+        (tmp_path / name).write_bytes(data)
+        r = subprocess.run([exe, str(tmp_path / name)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 3 and r.stdout.startswith("error:") and ("out of range" in r.stdout or "no image header" in r.stdout), (name, r.stdout)
+    # a consistent header whose data is too short for it
+    data = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 64, 64, 1, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 10)) + chunk(b"IEND", b"")
+    (tmp_path / "short.png").write_bytes(data)
+    r = subprocess.run([exe, str(tmp_path / "short.png")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 3 and "inflate" in r.stdout, r.stdout
