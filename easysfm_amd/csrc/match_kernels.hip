@@ -22,6 +22,7 @@
 //
 // DESIGN.md "Matching" explains the data layout and the certificate.
 #include "match_kernels.hpp"
+#include "l2_segment_gfx950.inc"   // ESFM_L2_SEGMENT_ASM: the matcher's hand-scheduled main loop (gen_l2_segment_asm.py)
 
 #include <float.h>
 #include <type_traits>
@@ -493,19 +494,18 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
     out_q[4 * g] = h0; out_q[4 * g + 1] = h1; out_q[4 * g + 2] = l0; out_q[4 * g + 3] = l1;
 }
 
-template <int TT, int NS, int GRP>
-__global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
+__global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
                                                              const u32x4 *__restrict__ split_q, const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                              int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap)
 {
-    constexpr int DIM = 64, QB = 128 * NS, SLOTS = 16, KS = 4;   // NS sets of 32 queries per wave
+    constexpr int TT = 128, NS = 2, GRP = 4;                     // train rows per LDS tile, query sets of 32 per wave, rows per fold group
+    constexpr int DIM = 64, QB = 128 * NS, SLOTS = 16, KS = 4;
     constexpr int NDMA = TT / 16;             // LDS-DMA instructions per wave per tile (4 rows = 1 KiB each)
-    static_assert(TT == 64 || TT == 128, "an even number of 32-row steps per tile: the accumulator pairs alternate");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [2][TT*SLOTS]
-    float *lds_norm = reinterpret_cast<float *>(smem + 2 * TT * SLOTS * 16);   // [2][TT]
+    float *lds_norm = reinterpret_cast<float *>(smem + 2 * TT * SLOTS * 16);   // [2][TT]   (the asm segment assumes norms right behind the tiles)
     float *lds_red = lds_norm + 2 * TT;                                        // [4]
     float *lds_master = lds_red + 4;                                           // [NS][6][256]: per-thread master top-3 (keys, segments)
 
@@ -519,64 +519,29 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
     const float *__restrict__ tn = norms + pd.t_row0;
     const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
 
-    // B operands: -2 q split into hi and lo (the query image of l2_split_bf16_kernel), this lane's 8 features of every K-step
-    bf16x8 bhi[NS][KS], blo[NS][KS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int qrow = qbase + 32 * s + j;
-        const bool ok = qrow < nq;
-        const u32x4 *qp = split_q + ((size_t)pd.q_row0 + (ok ? qrow : 0)) * SLOTS + h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 hi = qp[4 * ks], lo = qp[4 * ks + 2];
-            if (!ok) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
-            bhi[s][ks] = __builtin_bit_cast(bf16x8, hi);
-            blo[s][ks] = __builtin_bit_cast(bf16x8, lo);
-        }
-    }
-
-    // read ahead what the tail needs, so that its latency hides under the first tile's transfer: this thread's share of
-    // max |t|^2 and the queries' |q|^2
-    float tmax_part = 0.f;
-    for (int t = tid; t < nt; t += 256) tmax_part = fmaxf(tmax_part, tn[t]);
-
-    // Running top-3 per query set, TWO levels deep in the hot loop.  A lane's 16 results of a 32-train step are four groups of
-    // four consecutive train rows (accumulator registers 4g .. 4g+3 = rows 8g + 4h + 0..3).  Per group: the minimum of the four raw
-    // scores (two v_min3_f32), the 8-bit position code (6 bits step in segment, 2 bits group) into the low mantissa bits of that
-    // minimum (one v_and_or_b32), and the three-smallest network on the group key (three v_med3_f32): 6 VALU per 4 results
-    // instead of 16.  The two nearest trains of a query lie in the (at most two) groups with the smallest minima; the third
-    // group key bounds every row outside the kept groups, which is what the certificate needs.  The tail re-ranks the kept groups'
-    // rows exactly -- four consecutive 256-B rows per group.
+    // Running top-3 per query set, TWO levels deep in the hot loop (l2_segment_gfx950.inc).  A lane's 16 results of a 32-train
+    // step are four groups of four consecutive train rows (accumulator registers 4g .. 4g+3 = rows 8g + 4h + 0..3).  Per group:
+    // the minimum of the four raw scores (two v_min3_f32 seeded with kBig: a NaN score loses every minimum), the 8-bit position
+    // code (6 bits step in segment, 2 bits group) into the low mantissa bits of that minimum (one v_and_or_b32), and the
+    // three-smallest network on the group key (three v_med3_f32): 6 VALU per 4 results instead of 16.  The two nearest trains of a
+    // query lie in the (at most two) groups with the smallest minima; the third group key bounds every row outside the kept
+    // groups, which is what the certificate needs.  The tail re-ranks the kept groups' rows exactly -- four consecutive 256-B rows
+    // per group.
     // (Measured on MI355X, scratch/ubench/mfma_issue: in SHADER CYCLES up to six VALU instructions hide behind every bf16 MFMA --
-    // the shipped 5.33-per-MFMA fold included; what they cost is POWER: the chip is clock-limited on random operands, 1660 TFLOP/s
+    // the 5.33-per-MFMA fold of round 1 included; what they cost is POWER: the chip is clock-limited on random operands, 1660 TFLOP/s
     // with the 4-per-result fold beside the MFMAs against 1805 with this one and 1690-1940 with none.)
     constexpr float kBig = 3.0e38f;
-    static_assert(GRP == 2 || GRP == 4, "group = 2 or 4 consecutive train rows");
     constexpr int NG = 16 / GRP;              // groups per lane per 32-train step
     constexpr int kSegSub = 256 / NG;         // steps per segment: the 8-bit code is (step in segment) * NG + group
+    constexpr int kSegTiles = kSegSub / (TT / 32);
     // The master top-3 (key, first step of the key's segment) is touched once per segment (2048 trains): it lives in LDS, a
     // private column per thread, so that the main loop's registers go to the pipeline.
-    float k0[NS], k1[NS], k2[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        k0[s] = k1[s] = k2[s] = kBig;
 #pragma unroll
         for (int m = 0; m < 3; ++m) { lds_master[(6 * s + m) * 256 + tid] = kBig; lds_master[(6 * s + 3 + m) * 256 + tid] = __int_as_float(-1); }
     }
     float tmax;
-    unsigned kmask = 0xFFFFFF00u;
-    asm volatile("" : "+v"(kmask));
-    auto fold_group = [&](int s, const floatx16 &p, int g, int code0 /* wave-uniform */) {
-        // plain C (an inline-asm reader of MFMA results is not hazard-checked by hipcc).  Seeding the chain with the constant keeps
-        // hipcc from canonicalising the operands (v_max x, x): exactly GRP / 2 v_min3_f32; a NaN score loses every minimum.
-        float gm = __builtin_fminf(__builtin_fminf(kBig, p[GRP * g]), p[GRP * g + 1]);
-        if (GRP == 4) gm = __builtin_fminf(__builtin_fminf(gm, p[GRP * g + 2]), p[GRP * g + 3]);
-        const int code = code0 + g;
-        const float key = __uint_as_float((__float_as_uint(gm) & kmask) | (unsigned)code);
-        k2[s] = __builtin_amdgcn_fmed3f(k1[s], k2[s], key);
-        k1[s] = __builtin_amdgcn_fmed3f(k0[s], k1[s], key);
-        k0[s] = __builtin_amdgcn_fmed3f(k0[s], key, -kBig);
-    };
     // the master keeps (key, first step of the key's segment); the group's rows are decoded from the two once, at the end
     struct Master { float v0, v1, v2; int c0, c1, c2; };
     auto master_load = [&](int s) {
@@ -612,26 +577,19 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         const int r0 = GRP * (code % NG);
         return key < 1.0e38f ? (seg_sub0 + code / NG) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h : -1;
     };
-    auto flush = [&](int seg_sub0) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            Master m = master_load(s);
-            master_insert(m, k0[s], seg_sub0); master_insert(m, k1[s], seg_sub0); master_insert(m, k2[s], seg_sub0);
-            master_store(s, m);
-            k0[s] = k1[s] = k2[s] = kBig;
-        }
-    };
 
     const int ntiles = (nt + TT - 1) / TT;
     // Staging is LDS-DMA (buffer_load_dwordx4 ... lds): a wave instruction moves 4 train rows (1 KiB) straight into LDS, lane l
     // to byte 16 l of the destination, so the XOR swizzle is applied on the SOURCE side (lane l fetches slot (l & 15) ^ (row & 15)
     // of its row) -- no staging VGPRs, no ds_write pass.  Rows past nt read as zeros through the buffer descriptor; their norm
-    // is kBig.  The per-lane byte offsets are loop-invariant, the tile offset is scalar.
+    // is kBig.  Tiles 0 and 1 are issued here, tile t + 2 by the segment code when tile t hands its buffer over.
     const u32x4 trsrc = raw_buffer_rsrc(split + (size_t)pd.t_row0 * SLOTS, (uint32_t)nt * (DIM * 4));   // reads past it return 0
-    const uint32_t lds_tile_addr = (uint32_t)(uintptr_t)lds_tile;   // LDS byte address (the low 32 bits of the flat pointer's offset)
-    const int wrow0 = __builtin_amdgcn_readfirstlane(wave * (TT / 4));      // this wave stages rows [wrow0, wrow0 + TT / 4) of a tile
+    const u32x4 nrsrc = raw_buffer_rsrc(tn, (uint32_t)nt * 4u);
+    const uint32_t lds_tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_tile);   // LDS byte address
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wrow0 = wave_s * (TT / 4);                                   // this wave stages rows [wrow0, wrow0 + TT / 4) of a tile
     auto dma_tile = [&](int tile, int buf) {
-        int voff[4];                                                          // recomputed per tile: a few VALU against 4 registers
+        int voff[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wrow0 + 4 * i + (lane >> 4);
@@ -644,9 +602,6 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
             lds_dma_b128(dst, voff[i & 3], trsrc, soff);
         }
     };
-    // |t|^2 of the tile's rows (the accumulators' start values) go through a register: an ordinary load whose consumer sits
-    // behind an LDS-DMA makes hipcc wait for vmcnt(0), so the load is issued BEFORE the tile's DMA and stored at the end of
-    // the iteration, where the DMA has to have landed anyway
     auto norm_load = [&](int tile) {
         const int t = tile * TT + tid;
         return (tid < TT && t < nt) ? tn[t] : kBig;
@@ -660,89 +615,61 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void l2_knn_bf16_kernel(const
         __syncthreads();
     }
     if (ntiles > 0) {
-        const float nv = norm_load(0);
-        norm_store(0, nv);
+        norm_store(0, norm_load(0));
         dma_tile(0, 0);
+        if (ntiles > 1) { norm_store(1, norm_load(1)); dma_tile(1, 1); }
     }
-    lds_dma_wait();
-    __syncthreads();
 
-    // One 32-train step: 24 MFMAs into (n0, n1) with the fold of the PREVIOUS step's results (p0, p1) between them: K-step ks
-    // carries group ks of both query sets (2 x 6 VALU beside 6 MFMAs).
-    auto step = [&](int buf, int base, floatx16 (&n)[NS], const floatx16 (&p)[NS], int pcode /* NG x (step in segment), wave-uniform */) {
-        floatx16 cinit;
+    // (issued after the first two tiles' DMA so that their latencies overlap)
+    // B operands: -2 q split into hi and lo (the query image of l2_split_bf16_kernel), this lane's 8 features of every K-step
+    u32x4 bhi[NS][KS], blo[NS][KS];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 nv = *reinterpret_cast<const float4 *>(&lds_norm[buf * TT + base + 8 * g + 4 * h]);
-            cinit[4 * g + 0] = nv.x; cinit[4 * g + 1] = nv.y; cinit[4 * g + 2] = nv.z; cinit[4 * g + 3] = nv.w;
-        }
-        const u32x4 *rowp = &lds_tile[buf * TT * SLOTS + (base + j) * SLOTS];
-        const int sw = j & 15;       // (base + j) & 15: base is a multiple of 32
+    for (int s = 0; s < NS; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool ok = qrow < nq;
+        const u32x4 *qp = split_q + ((size_t)pd.q_row0 + (ok ? qrow : 0)) * SLOTS + h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[(4 * ks + h) ^ sw]);
-            const bf16x8 alo = __builtin_bit_cast(bf16x8, rowp[(4 * ks + 2 + h) ^ sw]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[s][ks], ks == 0 ? cinit : n[s], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NG / 4; ++g) fold_group(0, p[0], (NG / 4) * ks + g, pcode);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[s][ks], n[s], 0, 0, 0);
-            if (NS > 1) {
-#pragma unroll
-                for (int g = 0; g < NG / 4; ++g) fold_group(NS - 1, p[NS - 1], (NG / 4) * ks + g, pcode);
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) n[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[s][ks], n[s], 0, 0, 0);
-        }
-    };
-    floatx16 ra[NS], rb[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rb[s][r] = kBig;                  // start-up placeholders: never "live"
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        const bool more = tile + 1 < ntiles;
-        float next_norm = kBig;
-        if (more) {
-            next_norm = norm_load(tile + 1);
-            dma_tile(tile + 1, buf ^ 1);                                       // lands under this tile's MFMAs
-        }
-#pragma unroll
-        for (int sp = 0; sp < TT / 64; ++sp) {
-            const int sub = (TT / 32) * tile + 2 * sp;                         // global 32-row step index of the first step
-            // step `sub` folds step sub - 1 (codes of its position inside its segment)
-            step(buf, 64 * sp, ra, rb, __builtin_amdgcn_readfirstlane(((sub + kSegSub - 1) % kSegSub) * NG));
-            if (sub > 0 && sub % kSegSub == 0) flush(sub - kSegSub);           // step sub - 1 closed a segment
-            step(buf, 64 * sp + 32, rb, ra, __builtin_amdgcn_readfirstlane((sub % kSegSub) * NG));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) norm_store(buf ^ 1, next_norm);
-        lds_dma_wait();                                                        // the DMA issued above has landed
-        __syncthreads();
-    }
-    {
-        const int nsub = (TT / 32) * ntiles;
-        if (nsub > 0) {
-            const int pcode = ((nsub - 1) % kSegSub) * NG;
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) fold_group(s, rb[s], g, pcode);
-            flush(((nsub - 1) / kSegSub) * kSegSub);
+            u32x4 hi = qp[4 * ks], lo = qp[4 * ks + 2];
+            if (!ok) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
+            bhi[s][ks] = hi;
+            blo[s][ks] = lo;
         }
     }
 
-    // max |t|^2 over the train set (for the certificate's error bound): the per-thread part was read in the prologue
+    // max |t|^2 over the train set (the certificate's error bound needs it in the tail): reduced here, while the first tiles are
+    // on their way, and published through LDS -- the segment code's first barrier orders it for the whole workgroup
     {
-        float m = tmax_part;
+        float m = 0.f;
+        for (int t = tid; t < nt; t += 256) m = fmaxf(m, tn[t]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) lds_red[wave] = m;
-        __syncthreads();
-        tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     }
+
+    // Main loop: one hand-scheduled asm block per segment of <= 16 tiles (gen_l2_segment_asm.py has the schedule: software-pipelined
+    // by two K-steps, LDS-DMA of tile t + 2 issued when tile t hands its buffer over, one barrier per tile).  It returns the
+    // segment's three smallest group keys per query set; they go into the master top-3 between segments.
+    for (int t0 = 0; t0 < ntiles; t0 += kSegTiles) {
+        const int t1 = min(t0 + kSegTiles, ntiles);
+        float k0[NS], k1[NS], k2[NS];
+        asm volatile(ESFM_L2_SEGMENT_ASM
+                     : "=&v"(k0[0]), "=&v"(k1[0]), "=&v"(k2[0]), "=&v"(k0[1]), "=&v"(k1[1]), "=&v"(k2[1])
+                     : "v"(bhi[0][0]), "v"(bhi[0][1]), "v"(bhi[0][2]), "v"(bhi[0][3]), "v"(bhi[1][0]), "v"(bhi[1][1]), "v"(bhi[1][2]), "v"(bhi[1][3]),
+                       "v"(blo[0][0]), "v"(blo[0][1]), "v"(blo[0][2]), "v"(blo[0][3]), "v"(blo[1][0]), "v"(blo[1][1]), "v"(blo[1][2]), "v"(blo[1][3]),
+                       "s"(t0), "s"(t1), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
+                     : ESFM_L2_SEGMENT_CLOBBERS);
+        const int seg_sub0 = t0 * (TT / 32);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            Master m = master_load(s);
+            master_insert(m, k0[s], seg_sub0); master_insert(m, k1[s], seg_sub0); master_insert(m, k2[s], seg_sub0);
+            master_store(s, m);
+        }
+    }
+
+    if (ntiles == 0) __syncthreads();   // no segment ran, so no barrier has published lds_red yet
+    tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
 
     // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate ----
     // A query's six kept groups (three per half-wave lane) are ranked by key across the two lanes and dealt out alternately --
@@ -1294,10 +1221,6 @@ bool l2_bf16_pass(int dim)
     static const bool forced_f32 = [] { const char *e = getenv("ESFM_L2_PASS"); return e && strcmp(e, "f32") == 0; }();
     return dim == 64 && !forced_f32;
 }
-#ifndef ESFM_L2_GROUP
-#define ESFM_L2_GROUP 4
-#endif
-constexpr int kL2BfGroup = ESFM_L2_GROUP;   // consecutive train rows folded as one group in l2_knn_bf16_kernel (2 or 4)
 constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_kernel (1: 3 waves per SIMD, measured 7-15 % slower)
 int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
@@ -1321,7 +1244,7 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
     constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
     constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16 + kL2BfSets * 6 * 256 * 4;   // two tiles, their norms, the master top-3
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    hipLaunchKernelGGL((l2_knn_bf16_kernel<TT, kL2BfSets, kL2BfGroup>), dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
+    hipLaunchKernelGGL(l2_knn_bf16_kernel, dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
                        reinterpret_cast<const u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, pairs,
                        n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap);
     ESFM_HIP_TRY(hipGetLastError());
