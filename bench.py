@@ -12,6 +12,13 @@ F images with F(F-1)/2 >= 300 N pairs, pair list partitioned over ranks, no data
 The second half of the metric, bundle-adjustment LM iterations/s on 25 cameras x 30k points
 (240k observations, workload "BA-25"), is measured in the same process and reported under "ba".
 
+At every N the same process also runs BASELINE.json's two multi-GPU configurations and reports them as extra objects of the
+one JSON line (strong scaling: the total work is fixed, N = 1 is the single-GPU point of the curve):
+  "config4"  256 images x 8192 SURF features, all 32 640 pairs, pair list partitioned over the ranks, no collective
+  "config5"  BA-512: 512 cams x 300k pts x 3M obs, points sharded, one RCCL all-reduce (esfm_comm_allreduce, the library's own
+             communicator) of the packed reduced camera system per LM iteration
+
+`python bench.py --gpus N` with WORLD_SIZE unset starts its N ranks itself (child processes, before anything touches a GPU).
 Rank 0 prints ONE JSON line.  `value` = image pairs matched per second over all ranks.
 """
 from __future__ import annotations
@@ -70,7 +77,7 @@ def cpu_baseline_match(sets, budget_s: float = 12.0):
             "sample": f"{n} pairs of 4096x4096x64 (M-SURF-4k) in {el:.1f}s, OpenMP over query rows"}
 
 
-def cpu_baseline_ba(scene, iters: int = 3):
+def cpu_baseline_ba(scene, iters: int = 25):
     import oracle
     threads = min(4, os.cpu_count() or 1)   # ceres_options_->num_threads = 4 (reference ba.cpp:203)
     oracle.set_num_threads(threads)
@@ -90,7 +97,24 @@ def main() -> int:
     ap.add_argument("--ba-iters", type=int, default=50, help="LM iterations timed for the BA half of the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-config45", action="store_true", help="skip the config-4 / config-5 strong-scaling legs")
+    ap.add_argument("--config4-steps", type=int, default=2)
+    ap.add_argument("--ba512-iters", type=int, default=20)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without a launcher: become the launcher.  Children are ordinary processes started BEFORE this one has
+        # touched a GPU (no torch import, no HIP call so far); rank 0 inherits stdout and prints the JSON line.
+        import socket
+        import subprocess
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rcs = [p.wait() for p in procs]
+        return max(rcs, key=abs)
 
     import torch
     import torch.distributed as dist
@@ -98,7 +122,7 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         print("[bench] no GPU visible: easysfm_amd has no CPU fallback", file=sys.stderr)
@@ -214,65 +238,153 @@ def main() -> int:
             printed.set()
             print(json.dumps(out), flush=True)
 
+    # the library's own RCCL communicator for the sharded BA legs (esfm_comm_*: no callback into Python per all-reduce);
+    # the 128-byte id travels through torch.distributed's store
+    bctx = E.Context.on_torch_stream(local_rank)
+    comm = None
+    if world > 1:
+        box = [E.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = E.Comm(bctx, box[0], rank, world)
+
+    def ba_leg(scene, iters, name, workload):
+        """LM iterations/s on `scene`, points (hence observations) sharded over the ranks; returns the leg's JSON object."""
+        if world > 1:
+            shard = E.shard_points(scene.n_pt, scene.pt_idx, world)
+            keep = shard[scene.pt_idx] == rank
+            ci, pi, uv = scene.cam_idx[keep], scene.pt_idx[keep], scene.uv[keep]
+        else:
+            ci, pi, uv = scene.cam_idx, scene.pt_idx, scene.uv
+        with torch.cuda.stream(bctx.torch_stream):
+            prob = E.BAProblem(ci, pi, uv, scene.K4, scene.cams0, scene.pts0, bctx)
+            opt = E.default_options()
+            opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
+            opt.max_num_iterations = 3
+            prob.solve(opt, comm)                   # warm-up (allocations, code objects, RCCL channels)
+            prob.set_params(scene.cams0, scene.pts0)
+            opt.max_num_iterations = iters
+            barrier()
+            bctx.set_kernel_timing(True)
+            bctx.kernel_time(_lib.K_BA_LINEARIZE); bctx.kernel_time(_lib.K_BA_SCHUR); bctx.kernel_time(_lib.K_BA_SOLVE)
+            tb = time.perf_counter()
+            summ = prob.solve(opt, comm)
+            bctx.synchronize()
+            if world > 1:
+                dist.barrier()
+            ba_el = time.perf_counter() - tb
+            l_ms, l_n = bctx.kernel_time(_lib.K_BA_LINEARIZE)
+            s_ms, s_n = bctx.kernel_time(_lib.K_BA_SCHUR)
+            c_ms, c_n = bctx.kernel_time(_lib.K_BA_SOLVE)
+            bctx.set_kernel_timing(False)
+            cams_out, pts_out = prob.get_params()
+            prob.close()
+        tt2 = torch.tensor([ba_el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+        ba_el = float(tt2.item())
+        sweep_bytes = 176.0 * len(ci) + 48.0 * scene.n_cam + 24.0 * scene.n_pt   # SURVEY 8d compulsory bytes of the Jacobian sweep
+        lin_s = (l_ms / max(l_n, 1)) * 1e-3
+        n_red = 6 * scene.n_cam
+        leg = {
+            "metric": "BA LM iters/s", "value": summ.num_iterations / ba_el, "unit": "LM iters/s",
+            "lm_iterations": summ.num_iterations, "seconds": ba_el, "ms_per_iteration": ba_el / max(summ.num_iterations, 1) * 1e3,
+            "n_gpus": world, "scaling": "strong",
+            "config": {"workload": workload, "obs_sharded_by_point": world > 1,
+                       "allreduce": (f"RCCL (esfm_comm_allreduce) sum of the packed reduced camera system, "
+                                     f"{(18 * scene.n_cam * (scene.n_cam + 1) + n_red) * 8 / 1e6:.2f} MB per LM iteration") if world > 1 else None},
+            "initial_cost": summ.initial_cost, "final_cost": summ.final_cost,
+            "successful_steps": summ.num_successful_steps, "unsuccessful_steps": summ.num_unsuccessful_steps,
+            "roofline": {"bound": "hbm", "kernel": "ba_linearize_kernel", "achieved": sweep_bytes / lin_s / 1e9 if lin_s > 0 else 0.0,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0,
+                         "traffic": traffic_ba if name == "ba" else None,
+                         "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes},
+            "schur_kernel_avg_ms": s_ms / max(s_n, 1), "solve_kernel_avg_ms": c_ms / max(c_n, 1),
+            "solve_gflops_f64": (n_red ** 3 / 3.0) / (c_ms / max(c_n, 1) * 1e-3) / 1e9 if c_n else None,
+        }
+        return leg, summ
+
     if not args.no_ba:
-        watchdog = threading.Timer(240.0, lambda: (out.setdefault("ba", {"error": "BA leg timed out"}), emit(), os._exit(0)))
+        watchdog = threading.Timer(400.0, lambda: (out.setdefault("ba", {"error": "BA leg timed out"}), emit(), os._exit(0)))
         watchdog.daemon = True
         watchdog.start()
         try:
             scene = synth.ba_scene(25, 30000, 8, radius=10.0, extent=2.0, seed=4000)
-            if world > 1:
-                shard = E.shard_points(scene.n_pt, scene.pt_idx, world)
-                keep = shard[scene.pt_idx] == rank
-                ci, pi, uv = scene.cam_idx[keep], scene.pt_idx[keep], scene.uv[keep]
-                cb = E.torch_allreduce_callback()
-            else:
-                ci, pi, uv, cb = scene.cam_idx, scene.pt_idx, scene.uv, None
-            bctx = E.Context.on_torch_stream(local_rank)
-            with torch.cuda.stream(bctx.torch_stream):
-                prob = E.BAProblem(ci, pi, uv, scene.K4, scene.cams0, scene.pts0, bctx)
-                opt = E.default_options()
-                opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
-                opt.max_num_iterations = 3
-                prob.solve(opt, cb)                     # warm-up (allocations, code objects, RCCL channels)
-                prob.set_params(scene.cams0, scene.pts0)
-                opt.max_num_iterations = args.ba_iters
-                barrier()
-                bctx.set_kernel_timing(True)
-                bctx.kernel_time(_lib.K_BA_LINEARIZE); bctx.kernel_time(_lib.K_BA_SCHUR); bctx.kernel_time(_lib.K_BA_SOLVE)
-                tb = time.perf_counter()
-                summ = prob.solve(opt, cb)
-                bctx.synchronize()
-                if world > 1:
-                    dist.barrier()
-                ba_el = time.perf_counter() - tb
-                l_ms, l_n = bctx.kernel_time(_lib.K_BA_LINEARIZE)
-                s_ms, s_n = bctx.kernel_time(_lib.K_BA_SCHUR)
-                c_ms, c_n = bctx.kernel_time(_lib.K_BA_SOLVE)
-                bctx.set_kernel_timing(False)
-            tt2 = torch.tensor([ba_el], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-            ba_el = float(tt2.item())
-            n_obs_local = len(ci)
-            sweep_bytes = 176.0 * n_obs_local + 48.0 * scene.n_cam + 24.0 * scene.n_pt   # SURVEY 8d compulsory bytes
-            lin_s = (l_ms / max(l_n, 1)) * 1e-3
-            out["ba"] = {
-                "metric": "BA LM iters/s", "value": summ.num_iterations / ba_el, "unit": "LM iters/s",
-                "lm_iterations": summ.num_iterations, "seconds": ba_el, "n_gpus": world,
-                "scaling": "strong" if world > 1 else "n/a",
-                "config": {"workload": "BA-25: 25 cams x 30000 pts x 240000 obs (8 obs/pt), Cauchy(0.5), DENSE_SCHUR-style LM",
-                           "obs_sharded_by_point": world > 1, "allreduce": "RCCL sum of reduced camera system" if world > 1 else None},
-                "initial_cost": summ.initial_cost, "final_cost": summ.final_cost,
-                "successful_steps": summ.num_successful_steps, "unsuccessful_steps": summ.num_unsuccessful_steps,
-                "roofline": {"bound": "hbm", "kernel": "ba_linearize_kernel", "achieved": sweep_bytes / lin_s / 1e9 if lin_s > 0 else 0.0,
-                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0, "traffic": traffic_ba,
-                             "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes},
-                "schur_kernel_avg_ms": s_ms / max(s_n, 1), "solve_kernel_avg_ms": c_ms / max(c_n, 1),
-            }
-            prob.close()
+            out["ba"], _ = ba_leg(scene, args.ba_iters, "ba",
+                                  "BA-25: 25 cams x 30000 pts x 240000 obs (8 obs/pt), Cauchy(0.5), DENSE_SCHUR-style LM")
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # parity at the metric's size: the first LM iterations against the oracle (cost 1e-9, accept pattern exact)
+                try:
+                    import oracle
+                    o5 = E.default_options(); o5.max_num_iterations = 5
+                    _c, _p, g5 = E.ba_solve(scene.cam_idx, scene.pt_idx, scene.uv, scene.K4, scene.cams0, scene.pts0, o5, bctx)
+                    r5 = oracle.ba_default_options(); r5.max_num_iterations = 5
+                    oracle.set_num_threads(min(16, os.cpu_count() or 1))
+                    _rc, _rp, rs5 = oracle.ba_solve(scene.cam_idx, scene.pt_idx, scene.uv, scene.K4, scene.cams0, scene.pts0, r5)
+                    oracle.set_num_threads(os.cpu_count() or 1)
+                    ok = g5.num_iterations == rs5.num_iterations
+                    for a_, b_ in zip(g5.log(), oracle.iterations(rs5)):
+                        ok = ok and a_.step_is_successful == b_.step_is_successful and abs(a_.cost - b_.cost) <= 1e-9 * max(1.0, abs(b_.cost))
+                    out["ba"]["verified_vs_oracle"] = bool(ok and np.allclose(_c, _rc, rtol=1e-6, atol=1e-6) and np.allclose(_p, _rp, rtol=1e-6, atol=1e-6))
+                except Exception as e:
+                    out["ba"]["verified_vs_oracle"] = f"check failed to run: {e!r}"
         except Exception as e:
             out["ba"] = {"error": repr(e)}
+        watchdog.cancel()
+
+    # ---------------------------------------------------------------- BASELINE configs 4 and 5 (strong scaling over the ranks)
+    if not args.no_config45 and not args.no_ba:
+        watchdog = threading.Timer(900.0, lambda: (out.setdefault("config4", {"error": "config 4/5 legs timed out"}), emit(), os._exit(0)))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            n_img4, n_feat4 = 256, 8192
+            sets4 = synth.surf_like_sets(n_img4, n_feat4, pool=65536, seed_base=2000)
+            pairs4 = E.shard_pair_list(n_img4, np.full(n_img4, n_feat4, np.int32), rank, world)
+            bank4 = E.DescriptorBank(sets4, E.ESFM_L2_F32, device=f"cuda:{local_rank}")
+            pm4 = E.PairMatcher(bank4, pairs4)
+            pm4.match(ratio)
+            pm4.ctx.synchronize(); torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            pm4.ctx.set_kernel_timing(True); pm4.ctx.kernel_time(_lib.K_L2_KNN)
+            t0 = time.perf_counter()
+            for _ in range(args.config4_steps):
+                res4 = pm4.match(ratio)
+            pm4.ctx.synchronize(); torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            el4 = time.perf_counter() - t0
+            k4_ms, k4_n = pm4.ctx.kernel_time(_lib.K_L2_KNN)
+            pm4.ctx.set_kernel_timing(False)
+            tt4 = torch.tensor([el4], dtype=torch.float64, device=dev)
+            nm4 = torch.tensor([float(res4.n_out.sum().item()), float(len(pairs4)), float(pm4.stats()[1])], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt4, op=dist.ReduceOp.MAX); dist.all_reduce(nm4, op=dist.ReduceOp.SUM)
+            el4 = float(tt4.item())
+            n_pairs4 = n_img4 * (n_img4 - 1) // 2
+            fl4 = 2.0 * len(pairs4) * n_feat4 * n_feat4 * DIM
+            k4_s = k4_ms / max(k4_n, 1) * 1e-3
+            out["config4"] = {
+                "metric": "image-pairs matched/s (8192 SURF feats/img)", "value": n_pairs4 * args.config4_steps / el4, "unit": "image-pairs/s",
+                "n_gpus": world, "scaling": "strong", "steps": args.config4_steps, "s_per_step": el4 / args.config4_steps,
+                "config": {"workload": f"M-SURF-8k: {n_img4} imgs x {n_feat4} feats x {DIM} f32, all {n_pairs4} pairs per step, "
+                                       "pair list partitioned over ranks (cost-balanced), no collective"},
+                "pairs_covered": int(nm4[1].item()), "matches_per_step": int(nm4[0].item()), "rescanned_queries_per_step": int(nm4[2].item()),
+                "roofline_rank0": {"bound": "mfma", "kernel": "l2_knn_bf16_kernel", "achieved": fl4 / k4_s / 1e12 if k4_s > 0 else 0.0,
+                                   "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl4 / k4_s / 1e12 / PEAK_BF16_MFMA_TFLOPS if k4_s > 0 else 0.0,
+                                   "avg_launch_ms": k4_s * 1e3, "pairs_this_rank": len(pairs4)},
+            }
+            del pm4, bank4, sets4, res4
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["config4"] = {"error": repr(e)}
+        try:
+            scene5 = synth.ba_scene(512, 300000, 10, radius=40.0, extent=8.0, seed=5000)
+            out["config5"], _ = ba_leg(scene5, args.ba512_iters, "config5",
+                                       "BA-512: 512 cams x 300000 pts x 3000000 obs (10 obs/pt), Cauchy(0.5), DENSE_SCHUR-style LM")
+        except Exception as e:
+            out["config5"] = {"error": repr(e)}
         watchdog.cancel()
 
     # ---------------------------------------------------------------- ORB leg (row a-2): M-ORB-4k, rank 0 at N = 1
@@ -465,6 +577,8 @@ def main() -> int:
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     emit()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -60,6 +60,44 @@ def torch_allreduce_callback(group=None):
     return ALLREDUCE_FN(_cb)
 
 
+class Comm:
+    """esfm_comm: the library's own RCCL communicator (one rank per GPU / esfm_ctx).  Pass an instance as ``allreduce=`` to
+    BAProblem.solve / ba_solve / ba_solve_ex: the solver then calls esfm_comm_allreduce (ncclAllReduce on the context's stream)
+    itself, with no callback into Python.  ``unique_id()`` runs on rank 0; the 128 bytes reach the other ranks by whatever the
+    host program has (bench.py broadcasts them through its torch.distributed store)."""
+
+    def __init__(self, ctx: Context, uid: bytes, rank: int, world: int):
+        if len(uid) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), 128)
+        check(lib().esfm_comm_create(ctx.handle, buf, self.rank, self.world, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib().esfm_comm_get_unique_id(buf))
+        return buf.raw
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def allreduce_(self, dev_ptr: int, count: int, op: int = ESFM_REDUCE_SUM) -> None:
+        """In-place all-reduce of `count` doubles at a device pointer on the context's stream (tests)."""
+        rc = lib().esfm_comm_allreduce(self._h, C.c_void_p(dev_ptr), int(count), int(op), C.c_void_p(self.ctx.stream))
+        if rc != 0:
+            raise RuntimeError("esfm_comm_allreduce failed: " + lib().esfm_last_error().decode("utf-8", "replace"))
+
+    def close(self) -> None:
+        """Collective teardown (ncclCommDestroy).  Call it explicitly: a communicator that is only garbage-collected at
+        interpreter exit is left to the process teardown, because RCCL aborts when destroyed after the HIP runtime has gone."""
+        if self._h:
+            lib().esfm_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class BAProblem:
     """Resident problem (esfm_ba_problem): upload once, solve/iterate many times.
 
@@ -114,8 +152,12 @@ class BAProblem:
     def solve(self, options: Optional[BAOptions] = None, allreduce=None) -> BASummary:
         summ = BASummary()
         opt = options if options is not None else default_options()
-        cb = allreduce if allreduce is not None else _NULL_ALLREDUCE
-        check(lib().esfm_ba_problem_solve(self._h, C.byref(opt), cb, None, C.byref(summ)))
+        user = None
+        if isinstance(allreduce, Comm):         # the library's own RCCL path: a C function pointer and its communicator
+            cb, user = C.cast(lib().esfm_comm_allreduce, ALLREDUCE_FN), allreduce.handle
+        else:
+            cb = allreduce if allreduce is not None else _NULL_ALLREDUCE
+        check(lib().esfm_ba_problem_solve(self._h, C.byref(opt), cb, user, C.byref(summ)))
         return summ
 
     def get_params(self) -> Tuple[np.ndarray, np.ndarray]:

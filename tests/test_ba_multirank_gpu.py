@@ -129,3 +129,26 @@ def test_sharded_constrained_ba_two_ranks_matches_single(gpu_ctx):
         assert np.allclose(c, cams, rtol=1e-6, atol=1e-6) and np.allclose(p, pts, rtol=1e-6, atol=1e-6)
         assert np.all(np.abs(c[0]) <= 1e-10)
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][6], res[1][6])
+
+
+def test_native_rccl_communicator_single_rank(gpu_ctx):
+    """The library's own exchange (esfm_comm_*: librccl bound at run time, ncclAllReduce on the context's stream, no callback
+    into Python): a one-rank communicator -- RCCL refuses two ranks on one device, and the box has one -- must leave the
+    solve equal to the single-GPU one (to the trace tolerance), through the same packed reduced-system exchange the 8-GPU run uses; and
+    esfm_comm_allreduce on a device buffer is the identity."""
+    import torch
+    import easysfm_amd as E
+    from easysfm_amd import synth
+    sc, (cams, pts, summ) = _single()
+    ctx = E.Context.on_torch_stream(0)
+    comm = E.Comm(ctx, E.Comm.unique_id(), 0, 1)
+    with torch.cuda.stream(ctx.torch_stream):
+        x = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+        comm.allreduce_(x.data_ptr(), x.numel())
+        ctx.synchronize()
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+        opt = E.default_options(); opt.max_num_iterations = 6
+        c, p, s2 = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, ctx, allreduce=comm)
+    comm.close()
+    assert np.allclose([it.cost for it in s2.log()], [it.cost for it in summ.log()], rtol=1e-9)
+    assert np.allclose(c, cams, rtol=1e-6, atol=1e-6) and np.allclose(p, pts, rtol=1e-6, atol=1e-6)

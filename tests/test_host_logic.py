@@ -1,6 +1,7 @@
 """Host-side logic above the C ABI that needs no GPU: pair-list / point sharding and the reference's
 observation derivation (setBAProblem, ba.cpp:22-56).  CPU only."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -350,3 +351,16 @@ def test_native_png_reader_under_asan(tmp_path):
     (tmp_path / "short.png").write_bytes(data)
     r = subprocess.run([exe, str(tmp_path / "short.png")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 3 and "inflate" in r.stdout, r.stdout
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself, as child processes, before it touches a GPU
+    (it silently measured one rank).  Without a GPU every rank reports that and exits 2; the parent passes it on."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+        assert r.stderr.count("no GPU visible") == 2, r.stderr[-500:]
