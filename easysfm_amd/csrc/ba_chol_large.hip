@@ -5,16 +5,17 @@
 // Ceres' Eigen LLT [upstream]) for large camera counts.
 //
 //   chol_assemble_kernel   W = F'F + D_c^2 + S_schur (lower), rhs row = F'r + rhs_corr, identity padding
-//   chol_panel_kernel(k)   every workgroup factors the diagonal tile (k,k) redundantly in LDS, then solves its
-//                          own 64-row tile (i,k) against it; workgroup 0 stores L_kk
-//   chol_update_kernel(k)  trailing update C_ij -= A_ik A_jk' for k < j <= i (rhs block row included)
+//   chol_potrf0_kernel     factor of the first diagonal tile (one wave)
+//   chol_trsm_kernel(k)    X_ik = A_ik L_kk^-T for the tiles below the diagonal one (one wave per tile, rhs block row included)
+//   chol_update_kernel(k)  trailing update C_ij -= X_ik X_jk' for k < j <= i on v_mfma_f64_16x16x4_f64; the workgroup that
+//                          finishes tile (k+1, k+1) factors it in the same launch (one wave, no barrier in the factorisation)
 //   chol_back_kernel(k)    y_k = L_kk^-T z_k (redundantly per workgroup), z_b -= L_kb' y_k for b < k
 #include "ba_kernels.hpp"
 
 namespace esfm {
 
 constexpr int CB = 64;          // tile edge
-constexpr int CLD = CB + 1;     // LDS leading dimension (f64, odd: conflict-free column access)
+constexpr int CLD = CB + 1;     // LDS leading dimension of the back-substitution's tile (f64, odd: conflict-free column access)
 
 __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__restrict__ W, int ld, int nb, double radius,
                                                             double min_diag, double max_diag)
@@ -42,111 +43,217 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
     W[(size_t)i * ld + j] = v;
 }
 
-// In-LDS Cholesky of a 64 x 64 tile (lower), 256 threads, blocked by 8 columns (2 barriers + 1 per panel
-// instead of 3 per column): (A) all threads subtract the already-factored columns from the panel by dot
-// products, (B1) wave 0 factors the 8 x 8 diagonal block in registers with __shfl, (B2) the rows below solve
-// against it.  rd[] receives the reciprocal diagonal.  *fail is raised on a non-positive pivot.
-constexpr int FB = 8;
-// value of lane `l` (wave-uniform index): two v_readlane_b32 instead of the LDS round trip of __shfl
+// ---------------------------------------------------------------------------------------------
+// 64 x 64 tile kernels built from 16 x 16 sub-blocks on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
+// A[l & 15][l >> 4] and B[l >> 4][l & 15]; its four results are D[(l >> 4) + 4 g][l & 15]).  Everything is a short loop:
+// round 1 ran the tile factorisation with 256 threads between barriers out of LDS (45 us per block column); two one-wave
+// rewrites measured this round were no better -- tile in LDS: 40 us (36 dependent ds_read_b64 per 32 FMAs); tile in
+// registers, fully unrolled: 78 us (25 KB of straight-line code executed once per launch: instruction fetch).
+//   P Q^T accumulate:  acc += sign * P (16 x 16, row-major in LDS) * Q^T (Q 16 x 16 row-major in LDS)  -- 4 MFMAs
+//   potrf16_inv:       one wave factors a 16 x 16 diagonal sub-block in registers (lane = row, v_readlane broadcasts) and
+//                      inverts the factor (lane = column of the inverse), ~500 instructions
+//   tile_potrf64:      4 sub-block steps: potrf16_inv, panel X = A Linv^T (MFMA), trailing update (MFMA); 3 barriers each
+//   strip_trsm64:      one wave solves its 16-row strip of X = A L^-T: per sub-block  acc = A_b - sum X_b' L_bb'^T,
+//                      X_b = acc Linv_bb^T, all MFMA, re-laid out through the wave's own LDS rows (no workgroup barrier)
+constexpr int SB = 16;                  // sub-block edge
+constexpr int ULD = CB + 2;             // LDS leading dimension of MFMA operand tiles: 32 lanes, 32 distinct 8-byte bank pairs
+constexpr int VLD = SB + 2;             // the same for a 16 x 16 block
+constexpr int LSLOT = CB * CB + CB + 4 * SB * SB;   // per diagonal tile in Ldiag: L, 1 / diag(L), inverses of its four sub-blocks
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double lane_value_f64(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-// rows: CB for the diagonal tile alone, 2*CB when a panel tile is stacked below it (rows CB..2CB-1 then come out as
-// X = A L^-T, the triangular solve, at no extra barriers).
-__device__ __forceinline__ void factor_tile_lds(double *L, double *rd, volatile int *fail, int rows)
+
+// 1 / sqrt(x) for the pivots: the hardware seed (v_rsq_f64, ~2^-26) and two Newton steps in f64 -- a short dependent chain; the
+// library rsqrt's longer one sits on the critical path of every one of the n pivots (dependent f64 operations cost ~16 cycles each)
+__device__ __forceinline__ double rsqrt_pivot(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h, y * y, 1.5);
+    y = y * fma(-h, y * y, 1.5);
+    return y;
+}
+
+__device__ __forceinline__ doublex4 pqt16(doublex4 acc, const double *P, int ldp, const double *Q, int ldq, double sign, int lane)
+{
+    const double *pp = P + (lane & 15) * ldp + (lane >> 4), *qp = Q + (lane & 15) * ldq + (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * pp[4 * kk], qp[4 * kk], acc, 0, 0, 0);
+    return acc;
+}
+// D-layout <-> row-major 16 x 16 block in LDS
+__device__ __forceinline__ doublex4 load_d16(const double *B, int ld, int lane)
+{
+    doublex4 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = B[((lane >> 4) + 4 * g) * ld + (lane & 15)];
+    return v;
+}
+__device__ __forceinline__ void store_d16(double *B, int ld, doublex4 v, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) B[((lane >> 4) + 4 * g) * ld + (lane & 15)] = v[g];
+}
+
+// One wave: Cholesky factor of the 16 x 16 block D (LDS, row-major ldd) written back in place (upper part zeroed), the
+// inverse of the factor to Vi (row-major VLD) and the reciprocal diagonal to rd[0..16).  A 16-step LOOP, not unrolled code
+// (a fully unrolled register version spent its time fetching instructions: the one workgroup per launch that runs it finds
+// its CU's instruction cache cold).  Lane l holds the four elements ((l >> 4) + 4 g, l & 15) -- the MFMA result layout -- of
+// the trailing matrix a[] and of the matrix y[] that starts as the identity and ends as the inverse; step c publishes column
+// c of a and row c of y through LDS (buf: 32 doubles), everybody scales them by 1 / sqrt(pivot) and eliminates.
+__device__ __forceinline__ void potrf16_inv(double *D, int ldd, double *Vi, double *rd, double *buf, int *fail, int lane)
+{
+    const int j = lane & 15, i0 = lane >> 4;
+    double a[4], y[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { a[g] = D[(i0 + 4 * g) * ldd + j]; y[g] = (i0 + 4 * g == j) ? 1.0 : 0.0; }
+    double *colbuf = buf, *rowbuf = buf + SB;
+    for (int c = 0; c < SB; ++c) {
+        if (j == c) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) colbuf[i0 + 4 * g] = a[g];
+        }
+        if (i0 == (c & 3)) {
+            const int gc = c >> 2;
+            rowbuf[j] = gc == 0 ? y[0] : gc == 1 ? y[1] : gc == 2 ? y[2] : y[3];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double piv = colbuf[c];
+        if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *fail = 1; }
+        const double rinv = rsqrt_pivot(piv > 0.0 ? piv : 1.0);
+        const double lj = colbuf[j] * rinv;            // L[j][c]
+        const double yc = rowbuf[j] * rinv;            // row c of the inverse, final
+        if (lane == c) rd[c] = rinv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = i0 + 4 * g;
+            const double li = (i == c) ? piv * rinv : colbuf[i] * rinv;     // L[i][c]
+            if (j == c) a[g] = (i >= c) ? li : 0.0;                         // column c is final
+            else if (j > c && i > c) a[g] -= li * lj;
+            if (i == c) y[g] = yc;
+            else if (i > c) y[g] -= li * yc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int i = i0 + 4 * g;
+        D[i * ldd + j] = (j <= i) ? a[g] : 0.0;
+        Vi[i * VLD + j] = (j <= i) ? y[g] : 0.0;
+    }
+}
+
+// 256 threads: in-place Cholesky of the 64 x 64 tile T (LDS, row-major ULD; upper part must be zero).  Vi: 4 blocks of
+// 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.
+__device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, double *buf, int *fail)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __syncthreads();
-    for (int j0 = 0; j0 < CB; j0 += FB) {
-        if (j0 > 0) {
-            for (int e = tid; e < (rows - j0) * FB; e += 256) {
-                const int i = j0 + e / FB, col = j0 + e % FB;
-                if (col > i) continue;
-                const double *Li = L + i * CLD, *Lc = L + col * CLD;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four chains: the dot product is latency-bound
-                for (int k = 0; k < j0; k += 4) {                // j0 is a multiple of 8
-                    s0 += Li[k] * Lc[k]; s1 += Li[k + 1] * Lc[k + 1]; s2 += Li[k + 2] * Lc[k + 2]; s3 += Li[k + 3] * Lc[k + 3];
-                }
-                L[i * CLD + col] -= (s0 + s1) + (s2 + s3);
-            }
+    for (int b = 0; b < 4; ++b) {
+        if (wave == 0) potrf16_inv(T + (SB * b) * ULD + SB * b, ULD, Vi + b * SB * VLD, rd + SB * b, buf, fail, lane);
+        __syncthreads();
+        // panel: strips i = b+1 .. 3:  X_i = A_i Linv_bb^T   (A_i is read whole before it is overwritten: one wave per strip)
+        if (wave > b) {
+            const int i = wave;
+            doublex4 acc = pqt16(doublex4{0.0, 0.0, 0.0, 0.0}, T + (SB * i) * ULD + SB * b, ULD, Vi + b * SB * VLD, VLD, 1.0, lane);
+            __builtin_amdgcn_wave_barrier();
+            store_d16(T + (SB * i) * ULD + SB * b, ULD, acc, lane);
         }
         __syncthreads();
-        if (wave == 0) {
-            const int r = lane;
-            double a[FB];
-#pragma unroll
-            for (int c = 0; c < FB; ++c) a[c] = (r < FB && c <= r) ? L[(j0 + r) * CLD + j0 + c] : 0.0;
-#pragma unroll
-            for (int c = 0; c < FB; ++c) {
-                const double piv = lane_value_f64(a[c], c);
-                if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *fail = 1; }
-                const double rinv = rsqrt(piv > 0.0 ? piv : 1.0);
-                a[c] = (r == c) ? piv * rinv : a[c] * rinv;
-                if (lane == c) rd[j0 + c] = rinv;
-#pragma unroll
-                for (int c2 = c + 1; c2 < FB; ++c2) {
-                    const double l2 = lane_value_f64(a[c], c2);
-                    if (r >= c2) a[c2] -= a[c] * l2;
+        // trailing update: blocks (i, j), b < j <= i <= 3, one per wave and round
+        int idx = 0;
+        for (int i = b + 1; i < 4; ++i)
+            for (int j = b + 1; j <= i; ++j, ++idx)
+                if ((idx & 3) == wave) {
+                    doublex4 acc = load_d16(T + (SB * i) * ULD + SB * j, ULD, lane);
+                    acc = pqt16(acc, T + (SB * i) * ULD + SB * b, ULD, T + (SB * j) * ULD + SB * b, ULD, -1.0, lane);
+                    store_d16(T + (SB * i) * ULD + SB * j, ULD, acc, lane);
                 }
-            }
-#pragma unroll
-            for (int c = 0; c < FB; ++c)
-                if (r < FB && c <= r) L[(j0 + r) * CLD + j0 + c] = a[c];
-        }
-        __syncthreads();
-        for (int i = j0 + FB + tid; i < rows; i += 256) {
-            double *Li = L + i * CLD;
-            double x[FB];
-#pragma unroll
-            for (int c = 0; c < FB; ++c) x[c] = Li[j0 + c];
-#pragma unroll
-            for (int c = 0; c < FB; ++c) {
-                const double *Lc = L + (j0 + c) * CLD + j0;
-                double v = x[c];
-#pragma unroll
-                for (int c1 = 0; c1 < c; ++c1) v -= x[c1] * Lc[c1];
-                x[c] = v * rd[j0 + c];
-                Li[j0 + c] = x[c];
-            }
-        }
         __syncthreads();
     }
 }
 
-// Ldiag: factored diagonal tiles, kept OUT of W: other workgroups of the same launch still read the unfactored (k,k) tile
-__global__ __launch_bounds__(256) void chol_panel_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, int nb, int k,
-                                                         double *__restrict__ scal)
+// One wave: X = A L^-T for its 16-row strip S (LDS, 16 x 64, row-major ULD, in place).  L: the factored 64 x 64 tile (LDS,
+// ULD), Vi: the inverses of its diagonal sub-blocks.  scratch: 16 x VLD doubles private to the wave.
+__device__ __forceinline__ void strip_trsm64(double *S, const double *L, const double *Vi, double *scratch, int lane)
 {
-    __shared__ double T[2 * CB * CLD];   // rows 0..63: diagonal tile (k,k); rows 64..127: this workgroup's tile (i,k)
+    for (int b = 0; b < 4; ++b) {
+        doublex4 acc = load_d16(S + SB * b, ULD, lane);
+        for (int bp = 0; bp < b; ++bp) acc = pqt16(acc, S + SB * bp, ULD, L + (SB * b) * ULD + SB * bp, ULD, -1.0, lane);
+        store_d16(scratch, VLD, acc, lane);
+        __builtin_amdgcn_wave_barrier();
+        acc = pqt16(doublex4{0.0, 0.0, 0.0, 0.0}, scratch, VLD, Vi + b * SB * VLD, VLD, 1.0, lane);
+        __builtin_amdgcn_wave_barrier();
+        store_d16(S + SB * b, ULD, acc, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// publish a factored tile: L (row-major 64 x 64, upper part zero), reciprocal diagonal, sub-block inverses
+__device__ __forceinline__ void publish_diag(double *__restrict__ Ld, const double *T, const double *Vi, const double *rd)
+{
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CB * CB; e += 256) Ld[e] = T[(e / CB) * ULD + (e % CB)];
+    if (tid < CB) Ld[CB * CB + tid] = rd[tid];
+    for (int e = tid; e < 4 * SB * SB; e += 256) Ld[CB * CB + CB + e] = Vi[(e / SB) * VLD + (e % SB)];
+}
+
+// Factor of the FIRST diagonal tile (the others are factored by the trailing update that finishes them).
+// Ldiag: LSLOT doubles per diagonal tile, read by the TRSM and back-substitution launches.
+__global__ __launch_bounds__(256) void chol_potrf0_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, double *__restrict__ scal)
+{
+    __shared__ double T[CB * ULD];
+    __shared__ double Vi[4 * SB * VLD];
     __shared__ double rd[CB];
+    __shared__ double pbuf[2 * SB];
     __shared__ int fail;
     const int tid = threadIdx.x;
-    const int bi = k + blockIdx.x;  // block row handled by this workgroup (k .. nb, nb = rhs block)
     if (tid == 0) fail = 0;
-    for (int e = tid; e < CB * CB; e += 256) {
-        const int r = e / CB, c = e % CB;
-        T[r * CLD + c] = (c <= r) ? W[(size_t)(k * CB + r) * ld + k * CB + c] : 0.0;
-        if (bi != k) T[(CB + r) * CLD + c] = W[(size_t)(bi * CB + r) * ld + k * CB + c];
-    }
-    factor_tile_lds(T, rd, &fail, bi == k ? CB : 2 * CB);
-    if (bi == k) {
-        for (int e = tid; e < CB * CB; e += 256) {
-            const int r = e / CB, c = e % CB;
-            Ldiag[(size_t)k * (CB * CB + CB) + e] = (c <= r) ? T[r * CLD + c] : 0.0;
-        }
-        if (tid < CB) Ldiag[(size_t)k * (CB * CB + CB) + CB * CB + tid] = rd[tid];   // reciprocal diagonal for the back-substitution
-        if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
-        return;
-    }
-    for (int e = tid; e < CB * CB; e += 256) W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)] = T[(CB + e / CB) * CLD + (e % CB)];
+    for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; T[r * ULD + c] = (c <= r) ? W[(size_t)r * ld + c] : 0.0; }
+    __syncthreads();
+    tile_potrf64(T, Vi, rd, pbuf, &fail);
+    publish_diag(Ldiag, T, Vi, rd);
+    if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
 }
 
-// C_ij -= A_ik A_jk'  for the tiles k < j <= i <= nb (j <= nb-1).  256 threads, 4 x 4 outputs per thread.
-__global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W, int ld, int nb, int k)
+// X_ik = A_ik L_kk^-T for the block rows i = k + 1 .. nb (nb = right-hand-side block row): one workgroup per tile, one wave
+// per 16-row strip.
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ W, const double *__restrict__ Ldiag, int ld, int k)
 {
-    __shared__ double Ai[CB * CLD];
-    __shared__ double Aj[CB * CLD];
+    __shared__ double L[CB * ULD];
+    __shared__ double T[CB * ULD];
+    __shared__ double Vi[4 * SB * VLD];
+    __shared__ double scratch[4][SB * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bi = k + 1 + blockIdx.x;
+    const double *__restrict__ Lk = Ldiag + (size_t)k * LSLOT;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        L[r * ULD + c] = Lk[e];
+        T[r * ULD + c] = W[(size_t)(bi * CB + r) * ld + k * CB + c];
+    }
+    for (int e = tid; e < 4 * SB * SB; e += 256) Vi[(e / SB) * VLD + (e % SB)] = Lk[CB * CB + CB + e];
+    __syncthreads();
+    strip_trsm64(T + (SB * wave) * ULD, L, Vi, scratch[wave], lane);
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += 256) W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)] = T[(e / CB) * ULD + (e % CB)];
+}
+
+// Trailing update C_ij -= X_ik X_jk' for the tiles k < j <= i <= nb (j <= nb - 1) on the f64 matrix cores: wave w of the
+// workgroup owns rows [16 w, 16 w + 16) of the tile, four 16 x 16 outputs, K = 64 in 16 steps.  The workgroup that finishes the
+// NEXT diagonal tile (k + 1, k + 1) factors it on the spot (tile_potrf64) and publishes it, so the factorisation never costs a
+// launch of its own.
+__global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, int nb, int k,
+                                                          double *__restrict__ scal)
+{
+    __shared__ double Ai[CB * ULD];
+    __shared__ double Aj[CB * ULD];
+    __shared__ double Vi[4 * SB * VLD];
+    __shared__ double rd[CB];
+    __shared__ double pbuf[2 * SB];
+    __shared__ int fail;
     // linear tile id -> (i, j): tiles of block row i (k+1 .. nb) are j = k+1 .. min(i, nb-1)
     const int m = nb - k - 1;  // square trailing block rows
     int t = blockIdx.x, i, j;
@@ -159,31 +266,51 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W
     } else {
         i = nb; j = k + 1 + (t - tri);
     }
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < CB * CB; e += 256) {
         const int r = e / CB, c = e % CB;
-        Ai[r * CLD + c] = W[(size_t)(i * CB + r) * ld + k * CB + c];
-        Aj[r * CLD + c] = W[(size_t)(j * CB + r) * ld + k * CB + c];
+        Ai[r * ULD + c] = W[(size_t)(i * CB + r) * ld + k * CB + c];
+        Aj[r * ULD + c] = W[(size_t)(j * CB + r) * ld + k * CB + c];
     }
+    if (tid == 0) fail = 0;
     __syncthreads();
-    const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
-    double acc[4][4] = {{0}};
-    for (int kk = 0; kk < CB; ++kk) {
-        double a[4], b[4];
+    doublex4 acc[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = Ai[(tr + u) * CLD + kk]; b[u] = Aj[(tc + u) * CLD + kk]; }
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = doublex4{0.0, 0.0, 0.0, 0.0};
+    const double *ap = Ai + (16 * wave + (lane & 15)) * ULD + (lane >> 4);
+    const double *bp = Aj + (lane & 15) * ULD + (lane >> 4);
+#pragma unroll 4
+    for (int kk = 0; kk < CB / 4; ++kk) {
+        const double a = ap[4 * kk];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[16 * cb * ULD + 4 * kk], acc[cb], 0, 0, 0);
     }
+    const bool next_diag = (i == k + 1 && j == k + 1);
+    if (!next_diag) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int r = tr + u, c = tc + v;
-            if (i != j || c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] -= acc[u][v];
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+                if (i != j || c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] -= acc[cb][g];
+            }
+        return;
+    }
+    // the next diagonal tile: finish it in LDS (Ai is free once every wave is past its MFMAs), factor, publish
+    __syncthreads();
+    double *T = Ai;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+            T[r * ULD + c] = (c <= r) ? W[(size_t)(i * CB + r) * ld + j * CB + c] - acc[cb][g] : 0.0;
         }
+    __syncthreads();
+    tile_potrf64(T, Vi, rd, pbuf, &fail);
+    publish_diag(Ldiag + (size_t)(k + 1) * LSLOT, T, Vi, rd);
+    for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; if (c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] = T[r * ULD + c]; }
+    if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
 }
 
 // Backward substitution step k: z = rhs row (row nb*CB of W).  Every workgroup solves L_kk' y_k = z_k (one wave),
@@ -197,9 +324,9 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, 
     double *z = W + (size_t)nb * CB * ld;
     for (int e = tid; e < CB * CB; e += 256) {
         const int r = e / CB, c = e % CB;
-        Lkk[r * CLD + c] = Ldiag[(size_t)k * (CB * CB + CB) + e];
+        Lkk[r * CLD + c] = Ldiag[(size_t)k * LSLOT + e];
     }
-    if (tid < CB) rd[tid] = Ldiag[(size_t)k * (CB * CB + CB) + CB * CB + tid];
+    if (tid < CB) rd[tid] = Ldiag[(size_t)k * LSLOT + CB * CB + tid];
     __syncthreads();
     if (tid < CB) {  // one wave; lane = row index, its y value lives in a register
         double yl = z[k * CB + tid];
@@ -235,7 +362,7 @@ __global__ void chol_extract_kernel(BADev d, const double *__restrict__ W, int l
 size_t ba_chol_large_doubles(int n_cam)
 {
     const int n = 6 * n_cam, nb = (n + CB - 1) / CB;
-    return (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * (CB * CB + CB);
+    return (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT;
 }
 
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
@@ -246,11 +373,14 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
     const long long tot = (long long)(nb + 1) * CB * ld;
     hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag);
     ESFM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(chol_potrf0_kernel, dim3(1), dim3(256), 0, st, W, Ldiag, ld, d.scal);
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(nb - k + 1), dim3(256), 0, st, W, Ldiag, ld, nb, k, d.scal);
+        // block column k: X = A L_kk^-T for the tiles below the diagonal one (right-hand-side row included), then the trailing
+        // update, whose (k + 1, k + 1) workgroup also factors the next diagonal tile
+        hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb - k), dim3(256), 0, st, W, Ldiag, ld, k);
         const int m = nb - k - 1;
         const int tiles = m * (m + 1) / 2 + m;
-        if (tiles > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tiles), dim3(256), 0, st, W, ld, nb, k);
+        if (tiles > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tiles), dim3(256), 0, st, W, Ldiag, ld, nb, k, d.scal);
     }
     ESFM_HIP_TRY(hipGetLastError());
     for (int k = nb - 1; k >= 0; --k) hipLaunchKernelGGL(chol_back_kernel, dim3(k + 1), dim3(256), 0, st, W, Ldiag, ld, nb, k);

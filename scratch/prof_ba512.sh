@@ -1,8 +1,19 @@
 #!/bin/bash
+# rocprofv3 kernel trace of a BA-512 solve (scratch/ba512.py): per-kernel calls / avg / total
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ba512prof
-rocprofv3 --kernel-trace --stats -d gpurun_out/ba512prof -- python3 scratch/ba512.py > gpurun_out/ba512prof/run.log 2>&1
-db=$(find gpurun_out/ba512prof -name "*.db" | head -1)
-[ -n "$db" ] && python tools/rocprof_summary.py $db | head -24 | cut -c1-175
-find gpurun_out/ba512prof -name "*.db" -delete
+out=gpurun_out/${1:-ba512prof}
+mkdir -p $out
+rocprofv3 --kernel-trace --output-format csv -d $out -o ba512 -- python3 scratch/ba512.py > $out/run.log 2>&1
+tail -4 $out/run.log
+python3 - $out <<'PY'
+import csv, glob, collections, sys
+f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True))[-1]
+d = collections.defaultdict(list)
+for row in csv.DictReader(open(f)):
+    d[row['Kernel_Name'].split('(')[0][:60]].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
+tot = sum(sum(v) for v in d.values())
+print(f'# {f}: kernel | calls | total_us | avg_us | min | max | pct')
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    print(f'{k:60s} {len(v):6d} {sum(v):12.1f} {sum(v)/len(v):9.2f} {min(v):9.2f} {max(v):9.2f} {100*sum(v)/tot:6.2f}')
+PY
