@@ -99,60 +99,58 @@ __device__ __forceinline__ void store_d16(double *B, int ld, doublex4 v, int lan
 }
 
 // One wave: Cholesky factor of the 16 x 16 block D (LDS, row-major ldd) written back in place (upper part zeroed), the
-// inverse of the factor to Vi (row-major VLD) and the reciprocal diagonal to rd[0..16).  A 16-step LOOP, not unrolled code
-// (a fully unrolled register version spent its time fetching instructions: the one workgroup per launch that runs it finds
-// its CU's instruction cache cold).  Lane l holds the four elements ((l >> 4) + 4 g, l & 15) -- the MFMA result layout -- of
-// the trailing matrix a[] and of the matrix y[] that starts as the identity and ends as the inverse; step c publishes column
-// c of a and row c of y through LDS (buf: 32 doubles), everybody scales them by 1 / sqrt(pivot) and eliminates.
-__device__ __forceinline__ void potrf16_inv(double *D, int ldd, double *Vi, double *rd, double *buf, int *fail, int lane)
+// inverse of the factor to Vi (row-major VLD) and the reciprocal diagonal to rd[0..16).  Lane r (and r + 16, r + 32, r + 48,
+// redundantly) holds row r in registers; the pivot and the column below it reach the other lanes through v_readlane -- per
+// pivot: readlane, 1 / sqrt, scale, readlane, FMA, ~200 dependent cycles.  (A version that kept the block in LDS and published
+// column and row through it measured 675 cycles per pivot, 10.0k per block against 5.0k for this one:
+// scratch/ubench/potrf_bench.hip.)  The inverse is formed right-looking too (lane = column of the inverse): no serial FMA chain.
+template <bool WRITE_L = true>
+__device__ __forceinline__ void potrf16_inv(double *D, int ldd, double *Vi, double *rd, int *fail, int lane)
 {
-    const int j = lane & 15, i0 = lane >> 4;
-    double a[4], y[4];
+    const int r = lane & 15;
+    double x[SB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { a[g] = D[(i0 + 4 * g) * ldd + j]; y[g] = (i0 + 4 * g == j) ? 1.0 : 0.0; }
-    double *colbuf = buf, *rowbuf = buf + SB;
+    for (int c = 0; c < SB; ++c) x[c] = D[r * ldd + c];
+    double my_rd = 1.0;
+#pragma unroll
     for (int c = 0; c < SB; ++c) {
-        if (j == c) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) colbuf[i0 + 4 * g] = a[g];
-        }
-        if (i0 == (c & 3)) {
-            const int gc = c >> 2;
-            rowbuf[j] = gc == 0 ? y[0] : gc == 1 ? y[1] : gc == 2 ? y[2] : y[3];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const double piv = colbuf[c];
+        const double piv = lane_value_f64(x[c], c);
         if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *fail = 1; }
         const double rinv = rsqrt_pivot(piv > 0.0 ? piv : 1.0);
-        const double lj = colbuf[j] * rinv;            // L[j][c]
-        const double yc = rowbuf[j] * rinv;            // row c of the inverse, final
-        if (lane == c) rd[c] = rinv;
+        x[c] = (r == c) ? piv * rinv : x[c] * rinv;
+        if (r == c) my_rd = rinv;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i = i0 + 4 * g;
-            const double li = (i == c) ? piv * rinv : colbuf[i] * rinv;     // L[i][c]
-            if (j == c) a[g] = (i >= c) ? li : 0.0;                         // column c is final
-            else if (j > c && i > c) a[g] -= li * lj;
-            if (i == c) y[g] = yc;
-            else if (i > c) y[g] -= li * yc;
-        }
-        __builtin_amdgcn_wave_barrier();
+        for (int c2 = c + 1; c2 < SB; ++c2) x[c2] -= x[c] * lane_value_f64(x[c], c2);   // rows above the diagonal: garbage, never read
     }
+    // inverse: lane r solves L y = e_r.  t starts as e_r; step k fixes y_k = t_k / L_kk and eliminates it from the rows below.
+    double t[SB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int i = i0 + 4 * g;
-        D[i * ldd + j] = (j <= i) ? a[g] : 0.0;
-        Vi[i * VLD + j] = (j <= i) ? y[g] : 0.0;
+    for (int i = 0; i < SB; ++i) t[i] = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        t[k] *= lane_value_f64(my_rd, k);
+#pragma unroll
+        for (int i = k + 1; i < SB; ++i) t[i] -= lane_value_f64(x[k], i) * t[k];      // L[i][k] = row i's x[k]
+    }
+    if (lane < SB) {
+        if (WRITE_L) {
+#pragma unroll
+            for (int c = 0; c < SB; ++c) D[r * ldd + c] = (c <= r) ? x[c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) Vi[i * VLD + r] = (i >= r) ? t[i] : 0.0;       // (WRITE_L false: Vi may be D itself)
+        rd[r] = my_rd;
     }
 }
 
 // 256 threads: in-place Cholesky of the 64 x 64 tile T (LDS, row-major ULD; upper part must be zero).  Vi: 4 blocks of
 // 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.
-__device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, double *buf, int *fail)
+__device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, int *fail)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
     for (int b = 0; b < 4; ++b) {
-        if (wave == 0) potrf16_inv(T + (SB * b) * ULD + SB * b, ULD, Vi + b * SB * VLD, rd + SB * b, buf, fail, lane);
+        if (wave == 0) potrf16_inv(T + (SB * b) * ULD + SB * b, ULD, Vi + b * SB * VLD, rd + SB * b, fail, lane);
         __syncthreads();
         // panel: strips i = b+1 .. 3:  X_i = A_i Linv_bb^T   (A_i is read whole before it is overwritten: one wave per strip)
         if (wave > b) {
@@ -207,13 +205,12 @@ __global__ __launch_bounds__(256) void chol_potrf0_kernel(double *__restrict__ W
     __shared__ double T[CB * ULD];
     __shared__ double Vi[4 * SB * VLD];
     __shared__ double rd[CB];
-    __shared__ double pbuf[2 * SB];
     __shared__ int fail;
     const int tid = threadIdx.x;
     if (tid == 0) fail = 0;
     for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; T[r * ULD + c] = (c <= r) ? W[(size_t)r * ld + c] : 0.0; }
     __syncthreads();
-    tile_potrf64(T, Vi, rd, pbuf, &fail);
+    tile_potrf64(T, Vi, rd, &fail);
     publish_diag(Ldiag, T, Vi, rd);
     if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
 }
@@ -252,7 +249,6 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W
     __shared__ double Aj[CB * ULD];
     __shared__ double Vi[4 * SB * VLD];
     __shared__ double rd[CB];
-    __shared__ double pbuf[2 * SB];
     __shared__ int fail;
     // linear tile id -> (i, j): tiles of block row i (k+1 .. nb) are j = k+1 .. min(i, nb-1)
     const int m = nb - k - 1;  // square trailing block rows
@@ -307,7 +303,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W
             T[r * ULD + c] = (c <= r) ? W[(size_t)(i * CB + r) * ld + j * CB + c] - acc[cb][g] : 0.0;
         }
     __syncthreads();
-    tile_potrf64(T, Vi, rd, pbuf, &fail);
+    tile_potrf64(T, Vi, rd, &fail);
     publish_diag(Ldiag + (size_t)(k + 1) * LSLOT, T, Vi, rd);
     for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; if (c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] = T[r * ULD + c]; }
     if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
@@ -348,6 +344,131 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, 
     part[g][t] = s;
     __syncthreads();
     if (tid < CB) z[b * CB + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduced systems that fit ONE workgroup's LDS (n = 6 n_cam <= 176, i.e. up to 29 cameras: BASELINE's BA-25 has n = 150): the
+// whole solve in one launch on the same 16 x 16 building blocks.  The lower block triangle lives in LDS (block (i, j) at
+// i (i + 1) / 2 + j, 16 x VLD doubles each), the right-hand side is carried along as a row vector z (forward substitution for
+// free).  Per block column b: wave 0 factors and inverts the diagonal block (potrf16_inv), then all 16 waves do the panel
+// X_i = A_i Linv^T and the trailing update A_ij -= X_i X_j^T as MFMA products, one block per wave and round; 3 barriers.  Then
+// the backward substitution through the block inverses.  Round 1's kernel (ba_chol_solve_kernel: 8-column panels, dot products
+// from packed rows, 19 panels x 3 barriers) took 127 us at n = 150.
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallMaxNb = 11;
+__device__ __forceinline__ int blk_off(int i, int j) { return (i * (i + 1) / 2 + j) * (SB * VLD); }
+
+__global__ __launch_bounds__(kSmallThreads) void ba_chol_small_kernel(BADev d, double radius, double min_diag, double max_diag)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = 6 * d.n_cam, nb = (n + SB - 1) / SB, np = nb * SB;
+    double *A = sm;                                     // nb (nb + 1) / 2 blocks; a factored diagonal block is replaced by its INVERSE
+    double *z = A + (size_t)(nb * (nb + 1) / 2) * (SB * VLD);    // np: right-hand side, then the solution
+    double *rd = z + np;                                // np
+    __shared__ int fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) fail = 0;
+    const double *S = d.red, *rc = d.red + (size_t)n * n, *FtF = d.camacc, *Ftr = d.camacc + 36 * (size_t)d.n_cam;
+    // assemble W = F'F + D_c^2 + S_schur (lower block triangle, full diagonal blocks), identity padding, z = F'r + rhs_corr
+    for (int e = tid; e < (nb * (nb + 1) / 2) * SB * SB; e += kSmallThreads) {
+        const int blk = e / (SB * SB), w = e % (SB * SB), r = w / SB, c = w % SB;
+        int bi = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+        while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+        while (bi * (bi + 1) / 2 > blk) --bi;
+        const int bj = blk - bi * (bi + 1) / 2;
+        int i = SB * bi + r, k = SB * bj + c;
+        const bool upper = k > i;                       // only inside diagonal blocks: mirror (the factorisation reads the lower part)
+        if (upper) { const int t = i; i = k; k = t; }
+        double v = 0.0;
+        if (i < n) {
+            v = S[(size_t)i * n + k];
+            if (i / 6 == k / 6) {
+                const int cc = i / 6;
+                v += FtF[36 * (size_t)cc + 6 * (i % 6) + (k % 6)];
+                if (i == k) v += fmin(fmax(FtF[36 * (size_t)cc + 7 * (i % 6)], min_diag), max_diag) / radius;
+            }
+        } else if (i == k) v = 1.0;
+        A[blk * (SB * VLD) + r * VLD + c] = v;
+    }
+    for (int i = tid; i < np; i += kSmallThreads) z[i] = i < n ? Ftr[i] + rc[i] : 0.0;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        if (wave == 0) {
+            potrf16_inv<false>(A + blk_off(b, b), VLD, A + blk_off(b, b), rd + SB * b, &fail, lane);
+            // the right-hand side's block: z_b <- z_b Linv^T (lanes 0..15: entry j = sum_k z_b[k] Linv[j][k])
+            __builtin_amdgcn_wave_barrier();
+            double acc = 0.0;
+            if (lane < SB) {
+#pragma unroll
+                for (int k = 0; k < SB; ++k) acc += z[SB * b + k] * A[blk_off(b, b) + lane * VLD + k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < SB) z[SB * b + lane] = acc;
+        }
+        __syncthreads();
+        // panel: X_i = A_i Linv^T for the blocks below the diagonal one
+        for (int i = b + 1 + wave; i < nb; i += kSmallThreads / 64) {
+            doublex4 acc = pqt16(doublex4{0.0, 0.0, 0.0, 0.0}, A + blk_off(i, b), VLD, A + blk_off(b, b), VLD, 1.0, lane);
+            __builtin_amdgcn_wave_barrier();
+            store_d16(A + blk_off(i, b), VLD, acc, lane);
+        }
+        __syncthreads();
+        // trailing update A_ij -= X_i X_j^T (b < j <= i), and z_j -= z_b X_j^T
+        const int m = nb - 1 - b;
+        for (int t = wave; t < m * (m + 1) / 2; t += kSmallThreads / 64) {
+            int ri = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
+            while (ri * (ri + 1) / 2 > t) --ri;
+            const int i = b + 1 + ri, j = b + 1 + (t - ri * (ri + 1) / 2);
+            doublex4 acc = load_d16(A + blk_off(i, j), VLD, lane);
+            acc = pqt16(acc, A + blk_off(i, b), VLD, A + blk_off(j, b), VLD, -1.0, lane);
+            store_d16(A + blk_off(i, j), VLD, acc, lane);
+        }
+        for (int e = tid; e < m * SB; e += kSmallThreads) {
+            const int j = b + 1 + e / SB, c = e % SB;
+            const double *Xj = A + blk_off(j, b) + c * VLD;
+            double s0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < SB; ++k) s0 += z[SB * b + k] * Xj[k];
+            z[SB * j + c] -= s0;
+        }
+        __syncthreads();
+    }
+    // backward substitution L' y = z through the block inverses: y_b = Linv_bb' (z_b - sum_{i > b} L_ib' y_i)
+    for (int b = nb - 1; b >= 0; --b) {
+        if (tid < SB) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < SB; ++k) acc += A[blk_off(b, b) + k * VLD + tid] * z[SB * b + k];
+            rd[SB * b + tid] = acc;          // y_b (rd is free after the factorisation)
+        }
+        __syncthreads();
+        for (int e = tid; e < b * SB; e += kSmallThreads) {
+            const int j = e / SB, c = e % SB;
+            const double *Lbj = A + blk_off(b, j);
+            double s0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < SB; ++k) s0 += Lbj[k * VLD + c] * rd[SB * b + k];
+            z[SB * j + c] -= s0;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += kSmallThreads) d.y_c[i] = fail ? 0.0 : rd[i];
+    if (tid == 0 && fail) d.scal[SC_CHOL_FAIL] = 1.0;
+}
+
+bool ba_chol_small_fits(int n_cam) { return (6 * n_cam + SB - 1) / SB <= kSmallMaxNb; }
+
+int ba_solve_reduced_small(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
+{
+    const int n = 6 * d.n_cam, nb = (n + SB - 1) / SB;
+    const size_t bytes = sizeof(double) * ((size_t)(nb * (nb + 1) / 2) * (SB * VLD) + 2 * (size_t)nb * SB);
+    ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_chol_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(kSmallThreads), bytes, st, d, radius, min_diag, max_diag);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
 }
 
 __global__ void chol_extract_kernel(BADev d, const double *__restrict__ W, int ld, int nb)

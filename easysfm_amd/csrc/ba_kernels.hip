@@ -1425,6 +1425,7 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
     if (d.n_cam <= 0) return ESFM_OK;
     const int n = 6 * d.n_cam;
     const size_t bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + n + 2);
+    if (ba_chol_small_fits(d.n_cam)) return ba_solve_reduced_small(st, d, radius, min_diag, max_diag);
     if (bytes <= 150 * 1024) {
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_chol_solve_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

@@ -99,6 +99,9 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
 // ba_chol_large_doubles(n_cam) doubles
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
 size_t ba_chol_large_doubles(int n_cam);
+// one-workgroup MFMA solve for n = 6 n_cam <= 176 (ba_chol_large.hip)
+bool ba_chol_small_fits(int n_cam);
+int ba_solve_reduced_small(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
 // intrinsics row/column block of the reduced system (has_calib): runs after ba_schur, adds into d.red
 int ba_schur_calib(hipStream_t st, const BADev &d);
 int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq);

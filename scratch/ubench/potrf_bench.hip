@@ -6,6 +6,27 @@
 namespace esfm { void set_error(const char *, ...) {} }
 using namespace esfm;
 
+__global__ __launch_bounds__(256) void bench_p16(const double *A, long long *cyc, int reps, int variant)
+{
+    __shared__ double T[CB * ULD];
+    __shared__ double Vi[4 * SB * VLD];
+    __shared__ double rd[CB];
+    __shared__ double pbuf[2 * SB];
+    __shared__ int fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long tot = 0, first = 0;
+    for (int it = 0; it < reps; ++it) {
+        for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; T[r * ULD + c] = A[r * CB + c]; }
+        __syncthreads();
+        long long t0 = clock64();
+        if (wave == 0) potrf16_inv(T, ULD, Vi, rd, &fail, lane);
+        long long t1 = clock64();
+        __syncthreads();
+        if (it == 0) first = t1 - t0; else tot += t1 - t0;
+    }
+    if (tid == 0) { cyc[0] = first; cyc[1] = reps > 1 ? tot / (reps - 1) : 0; }
+}
+
 __global__ __launch_bounds__(256) void bench_potrf(const double *A, double *out, long long *cyc, int reps)
 {
     __shared__ double T[CB * ULD];
@@ -23,9 +44,10 @@ __global__ __launch_bounds__(256) void bench_potrf(const double *A, double *out,
         long long t1 = clock64();
         {   // tile_potrf64 with a clock per phase
             const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
             for (int b = 0; b < 4; ++b) {
                 long long c0 = clock64();
-                if (wave == 0) potrf16_inv(T + (SB * b) * ULD + SB * b, ULD, Vi + b * SB * VLD, rd + SB * b, pbuf, &fail, lane);
+                if (wave == 0) potrf16_inv(T + (SB * b) * ULD + SB * b, ULD, Vi + b * SB * VLD, rd + SB * b, &fail, lane);
                 long long c1 = clock64();
                 __syncthreads();
                 if (wave > b) {
@@ -75,6 +97,11 @@ int main()
         long long c[20]; hipMemcpy(c, cyc, 160, hipMemcpyDeviceToHost);
         printf("grid %3d reps %2d: wall %8.2f us per rep; clock64 ticks per rep: load %lld, tile_potrf64 %lld\n", grid, reps, ms * 1e3 / reps, c[0], c[1]);
         if (grid == 1) for (int b = 0; b < 4; ++b) printf("    sub-block %d: potrf16_inv %lld, panel %lld, trailing %lld\n", b, c[8 + 3 * b], c[9 + 3 * b], c[10 + 3 * b]);
+    }
+    for (int variant : {0}) {
+        bench_p16<<<1, 256>>>(A, cyc, 20, variant); hipDeviceSynchronize();
+        long long c[2]; hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);
+        printf("potrf16_inv %s: first call %lld cycles, warm %lld cycles\n", "(registers + v_readlane)", c[0], c[1]);
     }
     // correctness: L L' == A
     std::vector<double> L(CB * CB);
