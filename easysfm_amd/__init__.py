@@ -16,7 +16,7 @@ from .cloud import CProceesing, read_ply_vertices, sor_filter, write_ply  # noqa
 from .motion import (MotionEstimator, find_essential_mat, find_essential_pairs, pixel2cam, ransac_sample_stream, recover_pose,  # noqa: F401
                      recover_pose_pairs, solve_pnp_ransac, triangulate_pairs, triangulate_points)
 
-from .features import detectFeaturesSURF, import_distort, surf_detect_and_compute, undistort  # noqa: F401
+from .features import detectFeaturesORB, detectFeaturesSURF, import_distort, orb_detect_and_compute, surf_detect_and_compute, undistort  # noqa: F401
 from .pipeline import FramePair, match_and_verify_all_pairs, propagate_track_ids, run_sfm  # noqa: F401
 
 __version__ = "0.1.0"

@@ -19,7 +19,7 @@ ESFM_L2_F32 = 0
 ESFM_HAMMING = 1
 ESFM_REDUCE_SUM = 0
 ESFM_REDUCE_MAX = 1
-K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN, K_SOR_KNN, K_TRIANGULATE, K_RANSAC, K_SURF_DET, K_SURF_DESC, K_UNDISTORT = range(12)
+K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN, K_SOR_KNN, K_TRIANGULATE, K_RANSAC, K_SURF_DET, K_SURF_DESC, K_UNDISTORT, K_ORB_FAST = range(13)
 BA_MAX_LOG = 256
 
 STATUS_NAMES = {
@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "esfm_ba_problem_fix_camera", "esfm_ba_solve_ex", "esfm_ba_line_search_next_step",
     "esfm_sor_filter", "esfm_sor_mean_distances_dev", "esfm_triangulate_points", "esfm_triangulate_pairs",
     "esfm_find_essential_mat", "esfm_find_essential_pairs", "esfm_recover_pose", "esfm_recover_pose_pairs", "esfm_ransac_sample_stream",
-    "esfm_solve_pnp_ransac", "esfm_surf_detect_and_compute", "esfm_undistort",
+    "esfm_solve_pnp_ransac", "esfm_surf_detect_and_compute", "esfm_orb_detect_and_compute", "esfm_undistort",
 ]
 
 
@@ -157,6 +157,7 @@ def lib() -> C.CDLL:
     L.esfm_recover_pose_pairs.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.esfm_ransac_sample_stream.argtypes = [C.c_int, C.c_int, vp]
     L.esfm_surf_detect_and_compute.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, i32p]
+    L.esfm_orb_detect_and_compute.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i32p]
     L.esfm_undistort.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.esfm_solve_pnp_ransac.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, i32p, i32p]
     L.esfm_ba_problem_set_params.argtypes = [vp, vp, vp]

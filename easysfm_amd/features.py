@@ -1,7 +1,8 @@
-"""Host-side mirror of the reference's feature extraction over the C ABI (SURF half):
-``FeatureMatching::detectFeaturesSURF`` (cpp_code/src/feature_matching.cpp:43-69).  The Hessian pyramid, the maxima, the
-orientation and the 64-float descriptors are computed in libesfm_hip.so on the GPU.  ``detectFeaturesORB`` (:14-41) is not
-built: cv::ORB's descriptor depends on a 256 x 4 learned sampling pattern that ships only inside OpenCV.  Also here: the image
+"""Host-side mirror of the reference's feature extraction over the C ABI:
+``FeatureMatching::detectFeaturesSURF`` (cpp_code/src/feature_matching.cpp:43-69) and ``detectFeaturesORB`` (:14-41).  The
+Hessian pyramid / FAST + Harris pyramid, the orientations and the descriptors are computed in libesfm_hip.so on the GPU.
+ORB's 256 intensity tests use this library's own seeded point pairs: cv::ORB's learned table ships only inside OpenCV, so the
+descriptors are ORB descriptors in kind, not bit-compatible with OpenCV's (esfm.h, oracle/orb_ref.c).  Also here: the image
 undistortion that precedes detection (``MotionEstimator::doUnDistort``, cpp_code/src/estimate_motion.cpp:431-441) and
 ``DataIO::importDistort`` (cpp_code/src/data_io.cpp:97-125)."""
 from __future__ import annotations
@@ -45,6 +46,38 @@ def detectFeaturesSURF(cur_frame: Frame, minHessian: int = 400, show: bool = Fal
     cur_frame.keypoints_full = kp
     cur_frame.descriptors = desc
     print(f"Found {len(kp)} features.")
+    return True
+
+
+def orb_detect_and_compute(image, nfeatures: int = 500, max_keypoints: Optional[int] = None,
+                           ctx: Optional[Context] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """esfm_orb_detect_and_compute.  image: [rows, cols] gray or [rows, cols, 3] BGR uint8.
+    Returns (keypoints [n, 7] float32: x, y, size, angle, response, octave, class_id; descriptors [n, 32] uint8)."""
+    ctx = ctx or default_context()
+    img = np.ascontiguousarray(image, np.uint8)
+    if img.ndim == 2:
+        rows, cols, ch = img.shape[0], img.shape[1], 1
+    elif img.ndim == 3 and img.shape[2] == 3:
+        rows, cols, ch = img.shape[0], img.shape[1], 3
+    else:
+        raise ValueError("image must be [rows, cols] or [rows, cols, 3] uint8")
+    cap = int(max_keypoints) if max_keypoints is not None else 2 * int(nfeatures) + 4096      # retainBest keeps ties
+    kp = np.zeros((max(cap, 1), 7), np.float32); desc = np.zeros((max(cap, 1), 32), np.uint8)
+    n = C.c_int32(0)
+    check(lib().esfm_orb_detect_and_compute(ctx.handle, C.c_void_p(img.ctypes.data), rows, cols, ch, int(nfeatures), cap,
+                                            C.c_void_p(kp.ctypes.data), C.c_void_p(desc.ctypes.data), C.byref(n)))
+    return kp[:n.value].copy(), desc[:n.value].copy()
+
+
+def detectFeaturesORB(cur_frame: Frame, max_num: int = 5000, show: bool = False, ctx: Optional[Context] = None) -> bool:
+    """feature_matching.cpp:14-41: cv::ORB::create(max_num) detect + compute on cur_frame.rgb_image (BGR)."""
+    if cur_frame.rgb_image is None:
+        raise ValueError("frame has no image")
+    kp, desc = orb_detect_and_compute(cur_frame.rgb_image, int(max_num), None, ctx)
+    cur_frame.keypoints = np.ascontiguousarray(kp[:, :2], np.float32)
+    cur_frame.keypoints_full = kp
+    cur_frame.descriptors = desc
+    print(f"Found {len(kp)} features")
     return True
 
 

@@ -148,6 +148,33 @@ public:
         return true;
     }
 
+    // feature_matching.cpp:14-41: ORB::create(max_num)->detect + ->compute on cur_frame.rgb_image (BGR)
+    bool detectFeaturesORB(frame_t &cur_frame, int max_num = 5000, bool show = false)
+    {
+        (void)show;
+        const ImageMat &img = cur_frame.rgb_image;
+        if (img.empty()) { std::cerr << "frame has no image" << std::endl; return false; }
+        const int cap = 2 * max_num + 4096;       // retainBest keeps ties
+        std::vector<float> kp(size_t(7) * size_t(cap));
+        std::vector<uint8_t> desc(size_t(32) * size_t(cap));
+        int32_t n = 0;
+        if (esfm_orb_detect_and_compute(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, max_num, cap, kp.data(), desc.data(),
+                                        &n) != ESFM_OK) {
+            std::cerr << esfm_last_error() << std::endl;
+            return false;
+        }
+        cur_frame.keypoints.resize(size_t(n));
+        for (int k = 0; k < n; ++k) {
+            KeyPoint &q = cur_frame.keypoints[size_t(k)];
+            const float *v = &kp[size_t(7) * size_t(k)];
+            q.pt.x = v[0]; q.pt.y = v[1]; q.size = v[2]; q.angle = v[3]; q.response = v[4]; q.octave = int(v[5]); q.class_id = int(v[6]);
+        }
+        cur_frame.descriptors.create(n, 32, DescMat::U8);
+        if (n) std::memcpy(cur_frame.descriptors.ptr<uint8_t>(), desc.data(), size_t(32) * size_t(n));
+        if (!quiet) std::cout << "Found " << n << " features" << std::endl;
+        return true;
+    }
+
     bool matchFeaturesORB(frame_t &cur_frame_1, frame_t &cur_frame_2, std::vector<DMatch> &matches, double ratio_thre = 0.8,
                           bool show = false)
     {

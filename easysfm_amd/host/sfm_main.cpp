@@ -3,10 +3,10 @@
 // (esfm_host.hpp).  Same thirteen positional arguments in the same order, same ASCII .ply of PointXYZRGB at argv[5], exit
 // status 1 on success like the reference (sfm.cpp:339).  The control flow is the one of
 // easysfm_amd/pipeline.py (the Python twin of this file), pair by pair as the reference runs it:
-//   import -> undistort -> SURF -> all-pairs match + 5-point RANSAC + depth -> track ids -> initial pair -> triangulate -> BA
+//   import -> undistort -> SURF or ORB -> all-pairs match + 5-point RANSAC + depth -> track ids -> initial pair -> triangulate -> BA
 //   -> (next frame by PnP -> triangulate against every registered frame -> periodic BA)* -> final BA -> SOR -> .ply
-// Differences from the reference, printed at run time: feature type O (ORB) is not built (cv::ORB's learned sampling pattern
-// ships only inside OpenCV); the viewer arguments are accepted and ignored (no display); only PNG images are read.
+// Differences from the reference: ORB's intensity tests use this library's own point pairs (cv::ORB's learned table ships only
+// inside OpenCV); the viewer arguments are accepted and ignored (no display); PNG and baseline JPEG images are read.
 //   bin/sfm_native --dump-image in.png out.raw   writes rows, cols (int32) and the BGR bytes: the decoder's test hook
 #include <cstdio>
 #include <cstdlib>
@@ -71,8 +71,7 @@ int main(int argc, char **argv)
     const bool use_track_frames_as_init = std::atoi(argv[9]) != 0;
     const double fix_calib_tolerance_BA = std::atof(argv[10]);
     const int frequency_BA = std::max(1, std::atoi(argv[11]));
-    if (using_feature == 'O') { std::cerr << "feature type O (ORB) is not built: cv::ORB's learned sampling pattern ships only inside OpenCV; use S" << std::endl; return 3; }
-    if (using_feature != 'S') { std::cout << "Wrong feature input. Use SURF as default feature." << std::endl; using_feature = 'S'; }
+    if (using_feature != 'S' && using_feature != 'O') { std::cout << "Wrong feature input. Use SURF as default feature." << std::endl; using_feature = 'S'; }
 
     try {
         DataIO io;
@@ -93,7 +92,8 @@ int main(int argc, char **argv)
             frames[size_t(i)].K_cam = K_mat;
             if (!ee.doUnDistort(frames[size_t(i)], distort_coeff)) return 3;
             std::cout << "Feature extraction of Frame [ " << i << " ]" << std::endl;
-            if (!fm.detectFeaturesSURF(frames[size_t(i)], feature_extract_parameter)) return 3;
+            if (using_feature == 'O' ? !fm.detectFeaturesORB(frames[size_t(i)], feature_extract_parameter)          // sfm.cpp:112-117
+                                     : !fm.detectFeaturesSURF(frames[size_t(i)], feature_extract_parameter)) return 3;
             frames[size_t(i)].init_pixel_ids();
         }
         std::cout << "Feature extraction done" << std::endl;
@@ -106,7 +106,8 @@ int main(int argc, char **argv)
             for (int j = 0; j < i; ++j) {
                 frame_pair_t &g = graph[size_t(i)][size_t(j)];
                 std::vector<DMatch> temp_matches, inlier_matches;
-                fm.matchFeaturesSURF(frames[size_t(i)], frames[size_t(j)], temp_matches);
+                if (using_feature == 'O') fm.matchFeaturesORB(frames[size_t(i)], frames[size_t(j)], temp_matches);   // sfm.cpp:153-160
+                else fm.matchFeaturesSURF(frames[size_t(i)], frames[size_t(j)], temp_matches);
                 if (int(temp_matches.size()) > num_min_pair) {
                     Matrix4f T = Matrix4f::Identity();
                     if (ee.estimate2D2D_E5P_RANSAC(frames[size_t(i)], frames[size_t(j)], temp_matches, inlier_matches, T, ransac_reproj_distance)) {

@@ -104,6 +104,11 @@ class FeatureMatching:
         from .features import detectFeaturesSURF
         return detectFeaturesSURF(cur_frame, minHessian, show, self._ctx)
 
+    def detectFeaturesORB(self, cur_frame: Frame, max_num: int = 5000, show: bool = False) -> bool:
+        """feature_matching.cpp:14-41 (features.detectFeaturesORB)."""
+        from .features import detectFeaturesORB
+        return detectFeaturesORB(cur_frame, max_num, show, self._ctx)
+
     # ---- frame selection (feature_matching.cpp:160-268): integer logic on the track matrix, host side ----
     def findInitializeFramePair(self, feature_track_matrix, frames, img_match_graph, min_track_num_init: int = 100,
                                 max_depth_baseline_ratio_init: float = 50.0):

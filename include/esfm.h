@@ -87,7 +87,8 @@ typedef enum esfm_kernel_id {
     ESFM_K_SURF_DET = 9,      /* surf_det_trace_kernel                                          */
     ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
     ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
-    ESFM_K_COUNT = 12
+    ESFM_K_ORB_FAST = 12,     /* orb_fast_kernel: FAST-9/16 score of every pyramid pixel          */
+    ESFM_K_COUNT = 13
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -458,6 +459,19 @@ int esfm_ransac_sample_stream(int count, int n_samples, int32_t *idx /*5 per sam
  * area shrink to 21 x 21, Gaussian-weighted 2 x 2 gradients, 4 x 4 cells) follow OpenCV's surf.cpp operation by operation. */
 int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int channels, double hessian_threshold,
                                  int max_keypoints, float *keypoints /*7 per*/, float *descriptors /*64 per*/, int32_t *n_keypoints);
+
+/*
+ * FeatureMatching::detectFeaturesORB (cpp_code/src/feature_matching.cpp:14-41; feature type 'O', sfm.cpp:116):
+ * cv::ORB::create(nfeatures)->detect + ->compute with OpenCV's defaults (scale factor 1.2, 8 levels, edge threshold 31,
+ * HARRIS_SCORE, patch 31, FAST threshold 20).  image: rows x cols x channels (1 = gray, 3 = BGR) bytes, host.
+ * keypoints: 7 floats each -- x, y (level-0 pixels), size, angle (degrees), response (Harris), octave, class_id (-1);
+ * descriptors: 32 bytes each (cv::Mat CV_8U, what esfm_match_hamming takes).  Level by level, ordered inside a level by
+ * (response descending, y, x); at most max_keypoints are written.  Documented deviation: the 256 intensity tests use this
+ * library's own seeded point pairs, not OpenCV's learned rBRIEF table (which ships only inside OpenCV).
+ */
+int esfm_orb_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int channels, int nfeatures,
+                                int max_keypoints, float *keypoints /*7 each*/, uint8_t *descriptors /*32 each*/,
+                                int32_t *n_keypoints);
 
 /* ---- Image undistortion (undistort part) -------------------------------
  * MotionEstimator::doUnDistort (cpp_code/src/estimate_motion.cpp:431-441): cv::undistort(rgb_image, out, K, distort_coeff), run

@@ -79,7 +79,7 @@ class BASummary(C.Structure):
 def build(arch: str = "x86-64-v3", out: str = "libesfm_oracle.so", force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
     path = os.path.join(_HERE, out)
-    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "pnp_ref.c", "surf_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.c", "ba_ref.c", "cloud_ref.c", "geometry_ref.c", "ransac_ref.c", "pnp_ref.c", "surf_ref.c", "orb_ref.c", "undistort_ref.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "esfm.h"))
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.run(["make", "-B", "-C", _HERE, f"ARCH={arch}", f"OUT={out}"], check=True,
@@ -161,6 +161,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_bgr2gray.argtypes = [_u8p, C.c_int, _u8p]
     lib.esfm_ref_undistort.restype = C.c_int
     lib.esfm_ref_undistort.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _u8p]
+    lib.esfm_ref_orb.restype = C.c_int
+    lib.esfm_ref_orb.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _u8p]
+    lib.esfm_ref_orb_pattern.restype = None
+    lib.esfm_ref_orb_pattern.argtypes = [C.POINTER(C.c_int8)]
     lib.esfm_ref_surf.restype = C.c_int
     lib.esfm_ref_surf.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, C.c_int, _f32p, _f32p]
     _LIB, _LIB_PATH = lib, path
@@ -443,6 +447,22 @@ def surf(gray, hessian_threshold: float = 100.0, max_kp: int = 200000):
     kp = np.zeros((max_kp, 7), np.float32); desc = np.zeros((max_kp, 64), np.float32)
     n = load().esfm_ref_surf(g.reshape(-1), g.shape[0], g.shape[1], float(hessian_threshold), int(max_kp), kp.reshape(-1), desc.reshape(-1))
     return kp[:n].copy(), desc[:n].copy()
+
+
+def orb(gray, nfeatures: int = 500, max_kp: int = 200000):
+    """cv::ORB::create(nfeatures) detect + compute on a gray image: (keypoints[n, 7], descriptors[n, 32] uint8)."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    cap = min(int(max_kp), 2 * int(nfeatures) + 4096)
+    kp = np.zeros((cap, 7), np.float32); desc = np.zeros((cap, 32), np.uint8)
+    n = load().esfm_ref_orb(g.reshape(-1), g.shape[0], g.shape[1], int(nfeatures), cap, kp.reshape(-1), desc.reshape(-1))
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def orb_pattern() -> np.ndarray:
+    """The 256 test point pairs (x0, y0, x1, y1) of the descriptor."""
+    out = np.zeros(1024, np.int8)
+    load().esfm_ref_orb_pattern(out.ctypes.data_as(C.POINTER(C.c_int8)))
+    return out.reshape(256, 4)
 
 
 def undistort(image, K4, dist4):
