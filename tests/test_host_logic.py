@@ -365,3 +365,27 @@ def test_bench_starts_its_own_ranks():
     if not torch.cuda.is_available():
         assert r.returncode == 2, (r.returncode, r.stderr[-500:])
         assert r.stderr.count("no GPU visible") == 2, r.stderr[-500:]
+
+
+def test_run_scripts_keep_the_reference_parameters():
+    """script/run_*.sh: one launcher per reference script (cpp_code/script/), same 13 parameter VALUES in the order of sfm.cpp:35-50.
+    A stub in place of the driver records what it is called with."""
+    import subprocess
+    import tempfile
+    want = {   # feature, parameter, ransac px, find init pair, calib tolerance, BA every (the reference scripts' values)
+        "run_fountain_small.sh": ("S", "300", "1.0", "1", "0", "4"), "run_fountain_large.sh": ("S", "300", "1.0", "1", "0", "4"),
+        "run_gerrardhall.sh": ("S", "500", "1.0", "1", "0", "5"), "run_personhall.sh": ("S", "600", "1.0", "1", "0", "5"),
+        "run_southbuilding.sh": ("S", "500", "1.0", "1", "0", "5"), "run_zurich.sh": ("S", "300", "2.0", "0", "20.0", "4"),
+    }
+    with tempfile.TemporaryDirectory() as td:
+        stub = os.path.join(td, "stub.sh")
+        with open(stub, "w") as f:
+            f.write('#!/bin/bash\necho "$#" "$@"\nexit 1\n')
+        os.chmod(stub, 0o755)
+        for name, vals in want.items():
+            env = dict(os.environ, SFM_BIN=stub, SFM_DATA="/data/x", SFM_OUT=os.path.join(td, "o", "c.ply"))
+            r = subprocess.run(["bash", os.path.join(ROOT, "script", name)], env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+            a = r.stdout.splitlines()[0].split()
+            assert r.returncode == 1 and a[0] == "13", (name, r.stdout)
+            assert tuple(a[6:12]) == vals and a[1].startswith("/data/x/") and a[5].endswith("c.ply"), (name, a)
+            assert (a[4] == "none") == (name in ("run_fountain_small.sh", "run_fountain_large.sh", "run_zurich.sh"))
