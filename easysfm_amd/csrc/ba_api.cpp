@@ -27,6 +27,7 @@ struct esfm_ba_problem {
     int ref_cam = -1;
     double ref_threshold = 0.0;
     double calib_center[4] = {0, 0, 0, 0}, calib_tol = 0.0;
+    esfm::ScalParts parts{};    // per-workgroup scalar partials pending on the device (BADev::parts points here)
     double *h_scal = nullptr;   // pinned host copy of the scalar slots: the LM loop reads them back twice per iteration
     unsigned long long seq = 0; // sequence number of the last publication (the flag sits behind the scalars)
 };
@@ -82,10 +83,11 @@ struct Solver {
         }
         return ESFM_OK;
     }
-    int zero_scal() { ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st)); return ESFM_OK; }
+    int zero_scal() { ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st)); esfm::ba_scal_discard(P->d, 0, esfm::SC_SUM_COUNT); return ESFM_OK; }
     // SUM the partial-sum slots and MAX the gradient slot across ranks, then fetch all scalars.
     int fetch_scal()
     {
+        if (ar) { if (int rc = esfm::ba_scal_reduce(st, P->d)) return rc; }   // this rank's partials -> d.scal before the exchange
         if (int rc = allreduce(P->d.scal, esfm::SC_SUM_COUNT, ESFM_REDUCE_SUM)) return rc;
         if (int rc = allreduce(P->d.scal + esfm::SC_GMAX, esfm::SC_MAX_COUNT, ESFM_REDUCE_MAX)) return rc;
         // The device publishes the slots into pinned memory and then a sequence number; the host spins on that instead of
@@ -188,16 +190,41 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     A(&d.x_c, nc6); A(&d.x_p, np3); A(&d.cand_c, nc6); A(&d.cand_p, np3); A(&d.x0_p, np3);
     A(&d.Jc, 12 * no); A(&d.Jp, 6 * no); A(&d.res, 2 * no);
     A(&d.scale_c, nc6); A(&d.scale_p, np3);
-    A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3); A(&d.gE, np3);
+    A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3);
     A(&d.camacc, esfm::ba_camacc_doubles(n_cam)); A(&d.red, esfm::ba_red_doubles(n_cam));
     A(&d.y_c, nc6); A(&d.scal, (size_t)esfm::SC_COUNT);
     A(&d.chol, std::max((nc6 + 1) * (nc6 + 2) / 2 + 2, esfm::ba_chol_large_doubles(n_cam)));
     d.slab_cap = esfm::ba_schur_slab_doubles(n_cam, ctx->num_cu);
     if (d.slab_cap) A(&d.slabs, d.slab_cap);
-    if ((size_t)n_cam * 27 * sizeof(double) <= 149 * 1024) {
+    if ((size_t)n_real * 304 + 144 <= 150 * 1024) {   // kLinLdsPerCam: the sweep keeps the camera sums in LDS
         d.lin_slab_cap = (size_t)n_cam * 27 * 2 * (size_t)ctx->num_cu;
         A(&d.lin_slabs, d.lin_slab_cap);
     }
+    // camera CSR of the (point-sorted) observations, cut into chunks, for the atomic-free per-camera sums
+    std::vector<int32_t> cam_obs((size_t)n_obs), cchunk_cam, cchunk_beg, cchunk_end, cam_chunk0((size_t)n_real + 1, 0);
+    {
+        std::vector<int32_t> cstart((size_t)n_real + 1, 0);
+        for (int t = 0; t < n_obs; ++t) cstart[(size_t)s_cam[(size_t)t] + 1]++;
+        for (int c = 0; c < n_real; ++c) cstart[(size_t)c + 1] += cstart[(size_t)c];
+        std::vector<int32_t> fill(cstart.begin(), cstart.end() - 1);
+        for (int t = 0; t < n_obs; ++t) cam_obs[(size_t)fill[(size_t)s_cam[(size_t)t]]++] = t;
+        for (int c = 0; c < n_real; ++c) {
+            cam_chunk0[(size_t)c] = (int32_t)cchunk_cam.size();
+            for (int b0 = cstart[(size_t)c]; b0 < cstart[(size_t)c + 1]; b0 += esfm::kCamChunk) {
+                cchunk_cam.push_back(c); cchunk_beg.push_back(b0); cchunk_end.push_back(std::min(b0 + esfm::kCamChunk, cstart[(size_t)c + 1]));
+            }
+        }
+        cam_chunk0[(size_t)n_real] = (int32_t)cchunk_cam.size();
+    }
+    d.n_cchunks = (int)cchunk_cam.size();
+    A(&d.cam_obs, no); A(&d.cchunk_cam, cchunk_cam.size()); A(&d.cchunk_beg, cchunk_cam.size()); A(&d.cchunk_end, cchunk_cam.size());
+    A(&d.cam_chunk0, (size_t)n_real + 1); A(&d.cam_part, cchunk_cam.size() * (size_t)esfm::kCamPart);
+    // room for a few launches' partials per slot between two read-backs (a full slot is flushed by an extra reduce launch)
+    d.scal_cap = std::max(1 << 12, 4 * std::max((n_pt + 63) / 64, (n_obs + 255) / 256));
+    A(&d.scal_part, (size_t)esfm::SC_SUM_COUNT * (size_t)d.scal_cap);
+    d.parts = &P->parts;
+    A(&d.qexp, nc6);
+    if (n_obs >= esfm::kBacksubPointMaxObs) A(&d.tE, 3 * no);
     // Windowed Schur for large camera counts: order points by their lowest camera, cut the observation stream into
     // ~2 chunks per CU.  (Structure only; built once per problem.)
     std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0;
@@ -238,6 +265,9 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         up(d.chunk_slot, chunk_slot.data(), sizeof(int32_t) * chunk_slot.size());
         up(d.chunk_cam0, chunk_cam0.data(), sizeof(int32_t) * chunk_cam0.size());
     }
+    up(d.cam_obs, cam_obs.data(), sizeof(int32_t) * no);
+    up(d.cchunk_cam, cchunk_cam.data(), sizeof(int32_t) * cchunk_cam.size()); up(d.cchunk_beg, cchunk_beg.data(), sizeof(int32_t) * cchunk_beg.size());
+    up(d.cchunk_end, cchunk_end.data(), sizeof(int32_t) * cchunk_end.size()); up(d.cam_chunk0, cam_chunk0.data(), sizeof(int32_t) * cam_chunk0.size());
     up(d.x_c, cams, sizeof(double) * 6 * (size_t)n_real); up(d.x_p, pts, sizeof(double) * np3);
     if (rc == ESFM_OK && hipStreamSynchronize(st) != hipSuccess) { esfm::set_error("stream sync failed"); rc = ESFM_ERR_HIP; }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
@@ -350,7 +380,9 @@ int esfm_ba_problem_cost(esfm_ba_problem *P, double cauchy_a, double *cost)
     if (int rc = esfm::set_device(P->ctx)) return rc;
     hipStream_t st = P->ctx->stream;
     ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
+    esfm::ba_scal_discard(P->d, 0, esfm::SC_SUM_COUNT);
     if (int rc = esfm::ba_cost(st, P->d, P->ctx->num_cu, P->d.x_c, P->d.x_p, cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD)) return rc;
+    if (int rc = esfm::ba_scal_reduce(st, P->d)) return rc;
     double h[esfm::SC_COUNT];
     ESFM_HIP_TRY(hipMemcpyAsync(h, P->d.scal, sizeof(h), hipMemcpyDeviceToHost, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
@@ -437,6 +469,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         // keep |x|^2, restart the other accumulators, and linearise again with scaled columns
         ESFM_HIP_TRY(hipMemsetAsync(d.scal, 0, sizeof(double) * esfm::SC_XNORM_SQ_PT, st));
         ESFM_HIP_TRY(hipMemsetAsync(d.scal + esfm::SC_LIN_BAD, 0, sizeof(double) * (esfm::SC_SUM_COUNT - esfm::SC_LIN_BAD), st));
+        esfm::ba_scal_discard(d, 0, esfm::SC_XNORM_SQ_PT); esfm::ba_scal_discard(d, esfm::SC_LIN_BAD, esfm::SC_SUM_COUNT);
         ESFM_HIP_TRY(hipMemsetAsync(d.scal + esfm::SC_GMAX, 0, sizeof(double), st));
         if (int rc = S.linearize(true, radius)) return finish(rc);
     }
@@ -451,6 +484,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     double gmax = h[esfm::SC_GMAX];
     double x_norm = std::sqrt(h[esfm::SC_XNORM_SQ_PT] + h[esfm::SC_XNORM_SQ_CAM]);
     double prep_radius = radius;  // radius the per-point inverses were built with
+    bool prep_singular = h[esfm::SC_PT_SINGULAR] > 0.0;   // ... and whether one of them could not be inverted (any rank)
     bool reuse_diagonal = false;  // the LM diagonal is a function of J only; kept for parity with the strategy's state
     int n_invalid = 0;
     sum->initial_cost = x_cost;
@@ -478,15 +512,17 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         memset(&cur, 0, sizeof(cur));
         cur.iteration = iter; cur.gradient_max_norm = last_gmax;
         // LevenbergMarquardtStrategy::ComputeStep: D^2 = clamp(diag(J'J)) / radius, then the Schur solve
+        if (int rc = S.zero_scal()) return finish(rc);
+        bool reprepped = false;
         if (prep_radius != radius) {
             if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false)) return finish(rc);
-            prep_radius = radius;
+            prep_radius = radius; reprepped = true;
         }
-        ESFM_HIP_TRY(hipMemsetAsync(d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
         {
             esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SCHUR);
-            if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap)) return finish(rc);
-            if (int rc = esfm::ba_schur_calib(st, d)) return finish(rc);
+            const double rhs_bound = std::sqrt(2.0 * std::max(x_cost, 0.0));   // |robustified residual vector| over all ranks
+            if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap, rhs_bound)) return finish(rc);
+            if (int rc = esfm::ba_schur_calib(st, d, rhs_bound)) return finish(rc);
         }
         if (multi) {
             // one exchange per LM iteration: the block-lower-triangular S and the right-hand side, packed
@@ -507,7 +543,8 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         const double model_cost_change = h[esfm::SC_MODEL_CHANGE];
         double step_norm = std::sqrt(h[esfm::SC_STEP_SQ_PT] + h[esfm::SC_STEP_SQ_CAM]);
         double cand_norm = std::sqrt(h[esfm::SC_CAND_SQ_PT] + h[esfm::SC_CAND_SQ_CAM]);
-        const bool lin_ok = h[esfm::SC_CHOL_FAIL] == 0.0 && h[esfm::SC_PT_SINGULAR] == 0.0 && std::isfinite(model_cost_change) &&
+        if (reprepped) prep_singular = h[esfm::SC_PT_SINGULAR] > 0.0;
+        const bool lin_ok = h[esfm::SC_CHOL_FAIL] == 0.0 && !prep_singular && std::isfinite(model_cost_change) &&
                             std::isfinite(step_norm);
         cur.model_cost_change = model_cost_change;
         cur.step_is_valid = lin_ok && (model_cost_change > 0.0);
@@ -589,6 +626,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
                 sum->termination = ESFM_BA_FAILURE; rc_final = ESFM_ERR_NUMERIC; terminated = true;
             }
             x_cost = h[esfm::SC_COST];
+            prep_singular = h[esfm::SC_PT_SINGULAR] > 0.0;
             gmax = h[esfm::SC_GMAX]; last_gmax = gmax;
             cur.step_is_successful = 1; cur.cost = x_cost; cur.gradient_max_norm = gmax;
             sum->num_successful_steps++;

@@ -47,29 +47,63 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
     atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
 }
 
-// Sum of entry e over n_slabs per-workgroup slabs, computed by a 32 x 8 thread tile: thread (ent, grp)
-// adds slabs grp, grp+8, ... (independent loads, coalesced across ent), then the 8 partial sums are
-// combined in a fixed order through LDS.  Deterministic; returns the total to the grp == 0 threads.
+// ba_schur_reduce_kernel sums entry e over the per-workgroup slabs with a 32 x 8 thread tile: thread (ent, grp) adds slabs grp,
+// grp + 8, ... (independent loads, coalesced across ent), then the 8 partial sums are combined through LDS.
 constexpr int kRedEnt = 32, kRedGrp = 8;
-__device__ __forceinline__ double slab_sum(const double *__restrict__ slabs, int per, int n_slabs, int e, double *lds /*[256]*/)
+
+// Scalar sums across workgroups without f64 atomics (whose order of arrival differs from run to run): every workgroup leaves its
+// block sums in d.scal_part[slot][base + blockIdx.x]; the next read-back (ba_publish_scalars / ba_scal_reduce, one workgroup) adds
+// the pending partials of each slot in index order -- thread t takes entries t, t + 256, ..., then the fixed tree of block_sum --
+// and adds the total to d.scal[slot].  The result is a function of the launch geometry only.  The host keeps the number of
+// pending partials per slot (BADev::parts); `base` is where this launch's go.  vals are per-THREAD partials.
+// (A first version let the last workgroup to take a ticket do the sum inside the producing kernel: the fence + ticket + tail cost
+// ~10 us per kernel on the 25-camera problem, a tenth of the LM iteration.)
+template <int N>
+__device__ __forceinline__ void scal_commit(const BADev &d, const ScalBase &base, const int (&slots)[N], const double (&vals)[N], double *lds /* >= 8 */)
 {
-    const int grp = threadIdx.x / kRedEnt;
-    double v0 = 0.0, v1 = 0.0;
-    if (e < per) {
-        int b = grp;
-        for (; b + kRedGrp < n_slabs; b += 2 * kRedGrp) {
-            v0 += slabs[(size_t)b * per + e];
-            v1 += slabs[(size_t)(b + kRedGrp) * per + e];
-        }
-        if (b < n_slabs) v0 += slabs[(size_t)b * per + e];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const double t = block_sum(vals[q], lds);
+        if (threadIdx.x == 0) d.scal_part[(size_t)slots[q] * d.scal_cap + base.b[q] + blockIdx.x] = t;
     }
-    lds[threadIdx.x] = v0 + v1;
-    __syncthreads();
-    double t = 0.0;
-    if (grp == 0)
-        for (int g = 0; g < kRedGrp; ++g) t += lds[g * kRedEnt + (threadIdx.x % kRedEnt)];
-    return t;
 }
+
+__device__ __forceinline__ void scal_reduce_pending(const double *scal_part, int scal_cap, double *scal, const ScalCounts &c, double *lds /* >= 4, 256 threads */)
+{
+#pragma unroll 1
+    for (int slot = 0; slot < SC_SUM_COUNT; ++slot) {
+        const int n = c.n[slot];
+        if (n == 0) continue;
+        double v = 0.0;
+        for (int b = threadIdx.x; b < n; b += 256) v += scal_part[(size_t)slot * scal_cap + b];
+        const double t = block_sum(v, lds);
+        if (threadIdx.x == 0) scal[slot] += t;
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_scal_reduce_kernel(const double *__restrict__ scal_part, int scal_cap, double *scal, ScalCounts c)
+{
+    __shared__ double lds[8];
+    scal_reduce_pending(scal_part, scal_cap, scal, c, lds);
+}
+
+// host side: where the partials of a launch of `grid` workgroups go, for each of its slots
+template <int N>
+static int scal_reserve(hipStream_t st, const BADev &d, const int (&slots)[N], int grid, ScalBase &base)
+{
+    if (grid > d.scal_cap) { set_error("BA: %d workgroups exceed the scalar partial capacity %d", grid, d.scal_cap); return ESFM_ERR_INVALID_ARG; }
+    bool full = false;
+    for (int q = 0; q < N; ++q) full = full || d.parts->n[slots[q]] + grid > d.scal_cap;
+    if (full) { if (int rc = ba_scal_reduce(st, d)) return rc; }
+    for (int q = 0; q < N; ++q) { base.b[q] = d.parts->n[slots[q]]; d.parts->n[slots[q]] += grid; }
+    return ESFM_OK;
+}
+
+// Exact accumulation of the Schur complement in 64-bit fixed point (BADev::qexp): fx64(v, sh) = round(v 2^sh) as an integer.
+__device__ __forceinline__ unsigned long long fx64(double v, int sh) { return (unsigned long long)__double2ll_rn(ldexp(v, sh)); }
+__device__ __forceinline__ double fx64_to_double(unsigned long long q, int sh) { return ldexp((double)(long long)q, -sh); }
+__device__ __forceinline__ void fx_add(double *slot, double v, int sh) { atomicAdd(reinterpret_cast<unsigned long long *>(slot), fx64(v, sh)); }
+constexpr int kFxBits = 60;   // |v| <= B < 2^e  ->  |v 2^(kFxBits - e)| < 2^60: three bits of head-room in an int64
 
 // ceres::CauchyLoss::Evaluate [upstream]; a <= 0 selects the trivial (squared) loss.
 __device__ __forceinline__ void loss_eval(double a, double s, double &rho0, double &rho1)
@@ -178,21 +212,43 @@ __device__ __forceinline__ void reproject_jac(const double cam[6], const double 
     xn = x; yn = y;
 }
 
+// e with sqrt(diag(F'F)_i) < 2^e (BADev::qexp)
+__device__ __forceinline__ int qexp_of(double diag)
+{
+    const double sd = sqrt(fabs(diag));
+    return (sd > 1e-120 && sd < 1e120) ? ilogb(sd) + 1 : -400;   // a zero column only ever contributes zeros
+}
+
 // ---------------------------------------------------------------------------------------------
-// Jacobian sweep.  PRIV: per-camera sums go through an LDS-private copy first (n_cam * 27 doubles),
-// so global f64 atomics are one per camera entry per workgroup instead of 27 per observation.
+// Jacobian sweep: 16 B in, 160 B out per observation (+ 32 B with free intrinsics), and the per-camera sums F'F / F'r.
+//
+// PRIV (the 27 sums of every camera fit in LDS): each workgroup accumulates its observations' contributions in LDS as 64-bit
+// FIXED-POINT integers -- integer adds are associative, so the order in which waves reach the LDS does not matter (round 1 used
+// ds_add_f64 here and was not reproducible) -- and stores its private copy as one coalesced slab of doubles;
+// ba_camacc_reduce_kernel adds the slabs in a fixed order.  The fixed-point scale is per workgroup, per camera and per column:
+// pass 1 streams the Jacobian out and leaves  m[c][a] = max_k (J_k[a]^2 + J_k[6+a]^2)  (and max |r_k|^2) and the number of
+// observations n_c of each camera in LDS (u64 max of non-negative doubles and integer adds: order-independent);
+// then  sum_k f_a f_b <= sqrt(n_c m[c][a]) sqrt(n_c m[c][b]) < 2^(ex[c][a] + ex[c][b])  bounds every partial sum and pass 2 re-reads
+// the workgroup's own Jacobian rows (L2) and adds round(v 2^(60 - ex[c][a] - ex[c][b])).
+// !PRIV: the sweep only; ba_camacc_chunk_kernel then forms the sums by gathering each camera's observations in order.
 constexpr int kLinThreads = 512;
+constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
 
 template <bool PRIV, bool CALIB>
-__global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, double *__restrict__ slabs)
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, ScalBase sbase, double *__restrict__ slabs)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [8] reduction scratch, then PRIV: [n_cam*27]
-    double *red = lds;
-    double *priv = lds + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *red = reinterpret_cast<double *>(lds_raw);                                  // [8] reduction scratch, [10] intrinsics-block sums
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds_raw) + 18;     // PRIV: [n_real_cam * 27]
+    unsigned long long *mx = acc + (size_t)d.n_real_cam * 27;                           //       [n_real_cam * 7]
+    int *cnt = reinterpret_cast<int *>(mx + (size_t)d.n_real_cam * 7);                  //       [n_real_cam]
+    int *ex = cnt + d.n_real_cam;                                                       //       [n_real_cam * 7]
     const int tid = threadIdx.x;
     const int n_obs = d.n_obs;
     if (PRIV) {
-        for (int e = tid; e < d.n_cam * 27; e += kLinThreads) priv[e] = 0.0;
+        for (int e = tid; e < d.n_real_cam * 27; e += kLinThreads) acc[e] = 0ull;
+        for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) mx[e] = 0ull;
+        for (int e = tid; e < d.n_real_cam; e += kLinThreads) cnt[e] = 0;
         __syncthreads();
     }
     double cost = 0.0, bad = 0.0;
@@ -250,71 +306,109 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
         if (CALIB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) d.Jk[(size_t)i * n_obs + k] = Jk[i];
-            // G'G (upper triangle of the 4x4: rows fx, cx | fy, cy never mix) and G'r, kept in registers over the sweep
-            kacc[0] += Jk[0] * Jk[0]; kacc[1] += Jk[0] * Jk[1]; kacc[2] += Jk[1] * Jk[1];
-            kacc[3] += Jk[2] * Jk[2]; kacc[4] += Jk[2] * Jk[3]; kacc[5] += Jk[3] * Jk[3];
-            kacc[6] += Jk[0] * r0; kacc[7] += Jk[1] * r0; kacc[8] += Jk[2] * r1; kacc[9] += Jk[3] * r1;
+            if (PRIV) {
+                // G'G (upper triangle of the 4x4: rows fx, cx | fy, cy never mix) and G'r, kept in registers over the sweep
+                kacc[0] += Jk[0] * Jk[0]; kacc[1] += Jk[0] * Jk[1]; kacc[2] += Jk[1] * Jk[1];
+                kacc[3] += Jk[2] * Jk[2]; kacc[4] += Jk[2] * Jk[3]; kacc[5] += Jk[3] * Jk[3];
+                kacc[6] += Jk[0] * r0; kacc[7] += Jk[1] * r0; kacc[8] += Jk[2] * r1; kacc[9] += Jk[3] * r1;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) d.Jc[(size_t)i * n_obs + k] = Jc[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.Jp[(size_t)i * n_obs + k] = Jp[i];
         d.res[k] = r0; d.res[(size_t)n_obs + k] = r1;
-        // per-camera sums: F'F upper triangle (21) and F'r (6)
+        if (PRIV) {
+            atomicAdd(&cnt[c], 1);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) atomicMax(&mx[c * 7 + a], (unsigned long long)__double_as_longlong(Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]));
+            atomicMax(&mx[c * 7 + 6], (unsigned long long)__double_as_longlong(r0 * r0 + r1 * r1));
+        }
+    }
+    {
+        const int slots[2] = {SC_COST, SC_LIN_BAD};
+        const double vals[2] = {cost, bad};
+        scal_commit<2>(d, sbase, slots, vals, red);
+    }
+    if (!PRIV) return;
+    if (CALIB) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const double v = block_sum(kacc[q], red);     // a fixed tree
+            if (tid == 0) red[8 + q] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) {
+        const double b = sqrt((double)cnt[e / 7] * __longlong_as_double((long long)mx[e]));   // > sqrt(sum): every term is <= the maximum
+        ex[e] = (b > 1e-120 && b < 1e120) ? ilogb(b) + 1 : -400;
+    }
+    __syncthreads();
+    for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
+        const int c = d.obs_cam[k];
+        double J[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) J[i] = d.Jc[(size_t)i * n_obs + k];    // this thread's own stores
+        const double r0 = d.res[k], r1 = d.res[(size_t)n_obs + k];
+        int ea[7];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) ea[a] = ex[c * 7 + a];
         int e = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
             for (int b = a; b < 6; ++b) {
-                const double v = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
-                if (PRIV) atomicAdd(&priv[c * 27 + e], v);
-                else { atomicAdd(&d.camacc[36 * (size_t)c + 6 * a + b], v); if (a != b) atomicAdd(&d.camacc[36 * (size_t)c + 6 * b + a], v); }
+                atomicAdd(&acc[c * 27 + e], fx64(J[a] * J[b] + J[6 + a] * J[6 + b], kFxBits - ea[a] - ea[b]));
                 ++e;
             }
         }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double v = Jc[a] * r0 + Jc[6 + a] * r1;
-            if (PRIV) atomicAdd(&priv[c * 27 + 21 + a], v);
-            else atomicAdd(&d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + a], v);
-        }
+        for (int a = 0; a < 6; ++a) atomicAdd(&acc[c * 27 + 21 + a], fx64(J[a] * r0 + J[6 + a] * r1, kFxBits - ea[a] - ea[6]));
     }
-    const double cs = block_sum(cost, red);
-    const double bs = block_sum(bad, red);
-    if (tid == 0) { atomicAdd(&d.scal[SC_COST], cs); if (bs > 0.0) atomicAdd(&d.scal[SC_LIN_BAD], bs); }
+    __syncthreads();
+    // one coalesced slab of doubles per workgroup; ba_camacc_reduce_kernel sums them in a fixed order
+    double *out = slabs + (size_t)blockIdx.x * d.n_cam * 27;
+    for (int e = tid; e < d.n_real_cam * 27; e += kLinThreads) {
+        const int c = e / 27, q = e % 27;
+        int a = 0, b2 = 6;                      // q >= 21: column a = q - 21 against the residual
+        if (q >= 21) a = q - 21;
+        else { int rem = q; while (rem >= 6 - a) { rem -= 6 - a; ++a; } b2 = a + rem; }
+        out[e] = fx64_to_double(acc[e], kFxBits - ex[c * 7 + a] - ex[c * 7 + b2]);
+    }
     if (CALIB) {
-        // the intrinsics block's F'F / F'r entries: every observation hits the same 10 sums, so they are reduced
-        // over the workgroup instead of through atomics.  Packed index of (a, b), a <= b: a*6 - a(a-1)/2 + b - a.
-        const int kc = d.n_real_cam;
+        // the intrinsics block rides as camera-side block n_real_cam.  Packed index of (a, b), a <= b: a*6 - a(a-1)/2 + b - a.
         const int slot[10] = {0, 1, 6, 11, 12, 15, 21, 22, 23, 24};
-        const int ra[10] = {0, 0, 1, 2, 2, 3, 0, 1, 2, 3}, rb[10] = {0, 1, 1, 2, 3, 3, 0, 0, 0, 0};
+        if (tid < 27) {
+            double v = 0.0;
 #pragma unroll
-        for (int q = 0; q < 10; ++q) {
-            const double v = block_sum(kacc[q], red);
-            if (tid != 0) continue;
-            if (PRIV) priv[kc * 27 + slot[q]] += v;
-            else if (q < 6) {
-                atomicAdd(&d.camacc[36 * (size_t)kc + 6 * ra[q] + rb[q]], v);
-                if (ra[q] != rb[q]) atomicAdd(&d.camacc[36 * (size_t)kc + 6 * rb[q] + ra[q]], v);
-            } else atomicAdd(&d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)kc + ra[q]], v);
+            for (int q = 0; q < 10; ++q) if (slot[q] == tid) v = red[8 + q];
+            out[(size_t)d.n_real_cam * 27 + tid] = v;
         }
-    }
-    if (PRIV) {
-        // one coalesced slab per workgroup; ba_camacc_reduce_kernel sums them in a fixed order
-        __syncthreads();
-        double *out = slabs + (size_t)blockIdx.x * d.n_cam * 27;
-        for (int e = tid; e < d.n_cam * 27; e += kLinThreads) out[e] = priv[e];
     }
 }
 
-// camacc = sum over slabs, unpacked: F'F (36 per camera, both triangles) | F'r (6 per camera)
+// Sum of entry e over n_slabs per-workgroup slabs, computed by a 32 x 8 thread tile: thread (ent, grp) adds slabs grp, grp + 8, ...
+// (independent loads, coalesced across ent), then the 8 partial sums are combined in a fixed order through LDS.  Deterministic.
 __global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const double *__restrict__ slabs, int n_slabs)
 {
     __shared__ double lds[256];
     const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
     const int per = d.n_cam * 27;
-    const double v = slab_sum(slabs, per, n_slabs, e, lds);
+    const int grp = threadIdx.x / kRedEnt;
+    double v0 = 0.0, v1 = 0.0;
+    if (e < per) {
+        int b = grp;
+        for (; b + kRedGrp < n_slabs; b += 2 * kRedGrp) {
+            v0 += slabs[(size_t)b * per + e];
+            v1 += slabs[(size_t)(b + kRedGrp) * per + e];
+        }
+        if (b < n_slabs) v0 += slabs[(size_t)b * per + e];
+    }
+    lds[threadIdx.x] = v0 + v1;
+    __syncthreads();
     if (threadIdx.x >= kRedEnt || e >= per) return;
+    double v = 0.0;
+    for (int g = 0; g < kRedGrp; ++g) v += lds[g * kRedEnt + threadIdx.x];
     const int c = e / 27, q = e % 27;
     if (q >= 21) { d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)] = v; return; }
     int a = 0, rem = q;
@@ -322,12 +416,113 @@ __global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const do
     const int b2 = a + rem;
     d.camacc[36 * (size_t)c + 6 * a + b2] = v;
     d.camacc[36 * (size_t)c + 6 * b2 + a] = v;
+    if (a == b2) d.qexp[6 * c + a] = qexp_of(v);
+}
+
+// Per-camera sums from the stored Jacobian, chunk by chunk: ONE WAVE per chunk adds F'F (upper triangle, 21), F'r (6) -- and with
+// free intrinsics the 10 sums of the shared block, G'G (6) and G'r (4) -- over the (up to kCamChunk = 256) observations
+// cam_obs[beg, end) of ONE camera.  Lane l takes observations l, l + 64, l + 128, l + 192 in that order (all four index loads,
+// then all Jacobian loads, are issued before the first use: the kernel is two memory round trips deep, not eight); the 37 sums
+// then go through the wave shuffle tree.  A fixed association: bit-reproducible.
+template <bool CALIB>
+__global__ __launch_bounds__(64) void ba_camacc_chunk_kernel(BADev d)
+{
+    const int lane = threadIdx.x;
+    const int beg = d.cchunk_beg[blockIdx.x], end = d.cchunk_end[blockIdx.x];
+    const size_t n = d.n_obs;
+    constexpr int U = kCamChunk / 64;
+    int k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int idx = beg + lane + 64 * u; k[u] = idx < end ? d.cam_obs[idx] : -1; }
+    double J[U][12], r0[U], r1[U], K[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int kk = k[u] < 0 ? 0 : k[u];
+#pragma unroll
+        for (int a = 0; a < 12; ++a) J[u][a] = d.Jc[a * n + kk];
+        r0[u] = d.res[kk]; r1[u] = d.res[n + kk];
+        if (CALIB) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) K[u][a] = d.Jk[a * n + kk];
+        }
+    }
+    double acc[kCamPart];
+#pragma unroll
+    for (int q = 0; q < kCamPart; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (k[u] < 0) continue;
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[e++] += J[u][a] * J[u][b] + J[u][6 + a] * J[u][6 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += J[u][a] * r0[u] + J[u][6 + a] * r1[u];
+        if (CALIB) {
+            const double k0 = K[u][0], k1 = K[u][1], k2 = K[u][2], k3 = K[u][3];
+            acc[27] += k0 * k0; acc[28] += k0 * k1; acc[29] += k1 * k1; acc[30] += k2 * k2; acc[31] += k2 * k3; acc[32] += k3 * k3;
+            acc[33] += k0 * r0[u]; acc[34] += k1 * r0[u]; acc[35] += k2 * r1[u]; acc[36] += k3 * r1[u];
+        }
+    }
+    constexpr int NQ = CALIB ? kCamPart : 27;
+    double mine = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == q) mine = v;
+    }
+    if (lane < NQ) d.cam_part[(size_t)blockIdx.x * kCamPart + lane] = mine;
+}
+
+// camacc = F'F (36 per camera, both triangles) | F'r (6 per camera): a camera's chunk sums added in chunk order; the
+// intrinsics block (free calibration) adds ALL chunks in order.  Every entry of camacc is written (cameras without observations get
+// zeros), and the diagonal entries also leave their fixed-point exponent in qexp.
+__global__ __launch_bounds__(256) void ba_camacc_final_kernel(BADev d)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int nr = d.n_real_cam;
+    if (e < nr * 27) {
+        const int c = e / 27, q = e % 27;
+        double v = 0.0;
+        for (int b = d.cam_chunk0[c]; b < d.cam_chunk0[c + 1]; ++b) v += d.cam_part[(size_t)b * kCamPart + q];
+        if (q >= 21) { d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)] = v; return; }
+        int a = 0, rem = q;
+        while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+        const int b2 = a + rem;
+        d.camacc[36 * (size_t)c + 6 * a + b2] = v;
+        d.camacc[36 * (size_t)c + 6 * b2 + a] = v;
+        if (a == b2) d.qexp[6 * c + a] = qexp_of(v);
+        return;
+    }
+    const int q = e - nr * 27;
+    if (!d.has_calib || q >= 42) return;
+    // the shared intrinsics block rides as camera-side block nr: 6 x 6 with the 4 x 4 part G'G (fx, cx | fy, cy never mix), then G'r
+    const int kc = nr;
+    if (q < 36) {
+        const int a = q / 6, b2 = q % 6;
+        const int lo = a < b2 ? a : b2, hi = a < b2 ? b2 : a;
+        int src = -1;
+        if (lo == 0 && hi == 0) src = 27; else if (lo == 0 && hi == 1) src = 28; else if (lo == 1 && hi == 1) src = 29;
+        else if (lo == 2 && hi == 2) src = 30; else if (lo == 2 && hi == 3) src = 31; else if (lo == 3 && hi == 3) src = 32;
+        double v = 0.0;
+        if (src >= 0) for (int b = 0; b < d.n_cchunks; ++b) v += d.cam_part[(size_t)b * kCamPart + src];
+        d.camacc[36 * (size_t)kc + q] = v;
+        if (a == b2) d.qexp[6 * kc + a] = qexp_of(v);
+    } else {
+        const int a = q - 36;
+        double v = 0.0;
+        if (a < 4) for (int b = 0; b < d.n_cchunks; ++b) v += d.cam_part[(size_t)b * kCamPart + 33 + a];
+        d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)kc + a] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Per point: E'E, E'r (only when the Jacobian is fresh), then M^-1 = (E'E + clamp(diag)/radius)^-1
 // via a 3x3 Cholesky (ceres InvertPSDMatrix), M^-1 E'r, and the point part of max|gradient|.
-__global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh)
+__global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh, ScalBase sbase)
 {
     __shared__ double red[8];
     const int p = blockIdx.x * 64 + threadIdx.x;
@@ -404,8 +599,9 @@ __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radiu
         for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
         if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], gmax);
     }
-    const double ss = block_sum(sing, red);
-    if (threadIdx.x == 0 && ss > 0.0) atomicAdd(&d.scal[SC_PT_SINGULAR], ss);
+    const int slots[1] = {SC_PT_SINGULAR};
+    const double vals[1] = {sing};
+    scal_commit<1>(d, sbase, slots, vals, red);
 }
 
 // Jacobi scaling 1/(1 + sqrt(squared column norm)) from the unscaled linearisation
@@ -449,7 +645,7 @@ __global__ void ba_camera_gradient_kernel(BADev d)
 // point p: W_i = F_i'E_i, Y_i = W_i M^-1; rhs_corr[c_i] -= W_i M^-1 E'r; and for every observation j of
 // the same point with camera(j) <= camera(i):  S[c_i][c_j] -= Y_i W_j'.  Only blocks on or below the
 // block diagonal are produced (the factorisation reads the lower triangle).
-__global__ __launch_bounds__(256) void ba_schur_kernel(BADev d)
+__global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.n_obs) return;
@@ -465,12 +661,15 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d)
     const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
     const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
     double Y[18];
+    int ei[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) ei[a] = kFxBits - d.qexp[6 * ci + a];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
         const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
         const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
-        atomicAdd(&d.red[(size_t)n * n + 6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2));
+        fx_add(&d.red[(size_t)n * n + 6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
         Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
         Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
         Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
@@ -490,9 +689,10 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d)
             const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
             const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
             const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
+            const int ej = d.qexp[6 * cj + c2];
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                atomicAdd(&Sb[(size_t)a * n + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
+                fx_add(&Sb[(size_t)a * n + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2), ei[a] - ej);
         }
     }
 }
@@ -502,7 +702,7 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d)
 // each workgroup accumulates its observations' contributions with LDS f64 atomics (ds_add_f64) and
 // then stores its private copy as one coalesced slab; ba_schur_reduce_kernel sums the slabs in a fixed
 // order and unpacks them into the n x n layout.  No global atomics.
-__global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__restrict__ slabs, int slab_doubles)
+__global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__restrict__ slabs, int slab_doubles, int rhs_exp)
 {
     extern __shared__ __attribute__((aligned(16))) double sl[];   // [nblk*36] blocks, then [n] rhs_corr
     const int tid = threadIdx.x;
@@ -523,12 +723,15 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
         const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
         double Y[18];
+        int ei[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ei[a] = kFxBits - d.qexp[6 * ci + a];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
             const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
             const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
-            atomicAdd(&srhs[6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2));
+            fx_add(&srhs[6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
             Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
             Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
             Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
@@ -548,9 +751,10 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
                 const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
                 const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
                 const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
+                const int ej = d.qexp[6 * cj + c2];
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
-                    atomicAdd(&Sb[a * 6 + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
+                    fx_add(&Sb[a * 6 + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2), ei[a] - ej);
             }
         }
     }
@@ -568,7 +772,7 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
 constexpr int kWinCams = 28;
 constexpr int kWinBlocks = kWinCams * (kWinCams + 1) / 2;
 
-__global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d)
+__global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_exp)
 {
     extern __shared__ __attribute__((aligned(16))) double sl[];   // [kWinBlocks*36] blocks, then [6*kWinCams] rhs_corr
     const int tid = threadIdx.x;
@@ -595,13 +799,16 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d)
         const int wi = ci - cw;
         const bool in_i = wi >= 0 && wi < kWinCams;
         double Y[18];
+        int ei[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ei[a] = kFxBits - d.qexp[6 * ci + a];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
             const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
             const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
-            const double rv = -(w0 * ag0 + w1 * ag1 + w2 * ag2);
-            if (in_i) atomicAdd(&srhs[6 * wi + a], rv); else atomicAdd(&d.red[(size_t)n * n + 6 * ci + a], rv);
+            const unsigned long long rv = fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
+            atomicAdd(reinterpret_cast<unsigned long long *>(in_i ? &srhs[6 * wi + a] : &d.red[(size_t)n * n + 6 * ci + a]), rv);
             Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
             Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
             Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
@@ -624,30 +831,32 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d)
                 const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
                 const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
                 const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
+                const int ej = d.qexp[6 * cj + c2];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
-                    const double v = -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2);
-                    if (in_w) atomicAdd(&Sl[a * 6 + c2], v); else atomicAdd(&Sg[(size_t)a * n + c2], v);
+                    const unsigned long long v = fx64(-(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2), ei[a] - ej);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(in_w ? &Sl[a * 6 + c2] : &Sg[(size_t)a * n + c2]), v);
                 }
             }
         }
     }
     __syncthreads();
     // flush the window
+    const unsigned long long *sq = reinterpret_cast<const unsigned long long *>(sl);   // same grid per entry as d.red: integer adds
     for (int e = tid; e < kWinBlocks * 36; e += 1024) {
-        const double v = sl[e];
-        if (v == 0.0) continue;
+        const unsigned long long v = sq[e];
+        if (v == 0ull) continue;
         const int blk = e / 36, r = e % 36;
         int wi = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
         while ((wi + 1) * (wi + 2) / 2 <= blk) ++wi;
         while (wi * (wi + 1) / 2 > blk) --wi;
         const int wj = blk - wi * (wi + 1) / 2;
         const int ci = cw + wi, cj = cw + wj;
-        if (ci < d.n_cam) atomicAdd(&d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6], v);
+        if (ci < d.n_cam) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6]), v);
     }
     for (int e = tid; e < 6 * kWinCams; e += 1024) {
-        const double v = srhs[e];
-        if (v != 0.0 && cw + e / 6 < d.n_cam) atomicAdd(&d.red[(size_t)n * n + 6 * cw + e], v);
+        const unsigned long long v = sq[kWinBlocks * 36 + e];
+        if (v != 0ull && cw + e / 6 < d.n_cam) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)n * n + 6 * cw + e]), v);
     }
 }
 
@@ -658,7 +867,7 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d)
 //   S[k][c_j] -= Yk W_j'  + G_j'F_j  for every observation j of p  (the second term is the F'F cross block)
 // The camera-indexed part goes through an LDS copy of the block row (4 x 6 n_real_cam) when it fits, the 14 sums
 // every point shares through a workgroup reduction; both are then added into d.red.  Runs after ba_schur.
-__global__ __launch_bounds__(256) void ba_schur_calib_kernel(BADev d, int use_lds)
+__global__ __launch_bounds__(256) void ba_schur_calib_kernel(BADev d, int use_lds, int rhs_exp)
 {
     extern __shared__ __attribute__((aligned(16))) double sl[];   // [8] reduction scratch, then use_lds: [4 * 6 n_real_cam]
     double *red = sl;
@@ -715,11 +924,11 @@ __global__ __launch_bounds__(256) void ba_schur_calib_kernel(BADev d, int use_ld
                 for (int c2 = 0; c2 < 6; ++c2) {
                     const double f0 = d.Jc[c2 * no + k], f1 = d.Jc[(6 + c2) * no + k];
                     const double w0 = f0 * Ej[0] + f1 * Ej[3], w1 = f0 * Ej[1] + f1 * Ej[4], w2 = f0 * Ej[2] + f1 * Ej[5];
+                    const int ej = d.qexp[6 * c + c2];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const double v = (a < 2 ? kk[a] * f0 : kk[a] * f1) - (Yk[a][0] * w0 + Yk[a][1] * w1 + Yk[a][2] * w2);
-                        if (use_lds) atomicAdd(&rowblk[a * roww + 6 * c + c2], v);
-                        else atomicAdd(&d.red[(size_t)(kap + a) * n + 6 * c + c2], v);
+                        fx_add(use_lds ? &rowblk[a * roww + 6 * c + c2] : &d.red[(size_t)(kap + a) * n + 6 * c + c2], v, kFxBits - d.qexp[kap + a] - ej);
                     }
                 }
             }
@@ -727,38 +936,78 @@ __global__ __launch_bounds__(256) void ba_schur_calib_kernel(BADev d, int use_ld
     }
 #pragma unroll
     for (int q = 0; q < 14; ++q) {
-        const double v = block_sum(acc[q], red);
-        if (tid != 0 || v == 0.0) continue;
-        if (q >= 10) { atomicAdd(&d.red[(size_t)n * n + kap + (q - 10)], v); continue; }
+        const double t = block_sum(acc[q], red);   // the workgroup's sum (fixed tree), rounded to the entry's grid, then exact adds
+        if (tid != 0 || t == 0.0) continue;
+        if (q >= 10) { fx_add(&d.red[(size_t)n * n + kap + (q - 10)], t, kFxBits - d.qexp[kap + (q - 10)] - rhs_exp); continue; }
         int a = 0, rem = q;
         while (rem > a) { rem -= a + 1; ++a; }
-        atomicAdd(&d.red[(size_t)(kap + a) * n + kap + rem], v);
+        fx_add(&d.red[(size_t)(kap + a) * n + kap + rem], t, kFxBits - d.qexp[kap + a] - d.qexp[kap + rem]);
     }
     if (use_lds) {
         __syncthreads();
         for (int e = tid; e < 4 * roww; e += 256) {
-            const double v = rowblk[e];
-            if (v != 0.0) atomicAdd(&d.red[(size_t)(kap + e / roww) * n + (e % roww)], v);
+            const unsigned long long v = reinterpret_cast<const unsigned long long *>(rowblk)[e];
+            if (v != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)(kap + e / roww) * n + (e % roww)]), v);
         }
     }
 }
 
-// Sum the per-workgroup slabs (fixed order) and scatter into red = S_schur (n x n) | rhs_corr (n).
-__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const double *__restrict__ slabs, int slab_doubles, int n_slabs)
+// Sum the per-workgroup slabs (fixed-point integers: exact in any order) and scatter into red = S_schur (n x n) | rhs_corr (n);
+// TO_DOUBLE: converted to f64 on the way (no free intrinsics), else left in fixed point for ba_schur_calib_kernel to add to.
+template <bool TO_DOUBLE>
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const double *__restrict__ slabs_f, int slab_doubles, int n_slabs, int rhs_exp)
 {
-    __shared__ double lds[256];
+    __shared__ unsigned long long lds[256];
+    const unsigned long long *slabs = reinterpret_cast<const unsigned long long *>(slabs_f);
     const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
-    const double s = slab_sum(slabs, slab_doubles, n_slabs, e, lds);
+    const int grp = threadIdx.x / kRedEnt;
+    unsigned long long v0 = 0, v1 = 0;
+    if (e < slab_doubles) {
+        int b = grp;
+        for (; b + kRedGrp < n_slabs; b += 2 * kRedGrp) {
+            v0 += slabs[(size_t)b * slab_doubles + e];
+            v1 += slabs[(size_t)(b + kRedGrp) * slab_doubles + e];
+        }
+        if (b < n_slabs) v0 += slabs[(size_t)b * slab_doubles + e];
+    }
+    lds[threadIdx.x] = v0 + v1;
+    __syncthreads();
     if (threadIdx.x >= kRedEnt || e >= slab_doubles) return;
+    unsigned long long t = 0;
+    for (int g = 0; g < kRedGrp; ++g) t += lds[g * kRedEnt + threadIdx.x];
     const int n = 6 * d.n_cam;
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
-    if (e >= nblk * 36) { d.red[(size_t)n * n + (e - nblk * 36)] = s; return; }
-    const int blk = e / 36, r = e % 36;
-    int ci = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
-    while ((ci + 1) * (ci + 2) / 2 <= blk) ++ci;
-    while (ci * (ci + 1) / 2 > blk) --ci;
-    const int cj = blk - ci * (ci + 1) / 2;
-    d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6] = s;
+    size_t dst; int sh;
+    if (e >= nblk * 36) {
+        const int r = e - nblk * 36;
+        dst = (size_t)n * n + r; sh = kFxBits - d.qexp[r] - rhs_exp;
+    } else {
+        const int blk = e / 36, r = e % 36;
+        int ci = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+        while ((ci + 1) * (ci + 2) / 2 <= blk) ++ci;
+        while (ci * (ci + 1) / 2 > blk) --ci;
+        const int cj = blk - ci * (ci + 1) / 2;
+        const int row = 6 * ci + r / 6, col = 6 * cj + r % 6;
+        dst = (size_t)row * n + col; sh = kFxBits - d.qexp[row] - d.qexp[col];
+    }
+    if (TO_DOUBLE) d.red[dst] = fx64_to_double(t, sh);
+    else reinterpret_cast<unsigned long long *>(d.red)[dst] = t;
+}
+
+// red: fixed point -> f64 in place, block-lower triangle and right-hand side (everything else is zero in both encodings).
+__global__ __launch_bounds__(256) void ba_schur_to_double_kernel(BADev d, int rhs_exp)
+{
+    const int n = 6 * d.n_cam;
+    const int row = blockIdx.y;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (row == n) {
+        if (col < n) d.red[(size_t)n * n + col] = fx64_to_double(reinterpret_cast<const unsigned long long *>(d.red)[(size_t)n * n + col], kFxBits - d.qexp[col] - rhs_exp);
+        return;
+    }
+    if (col >= 6 * (row / 6 + 1)) return;
+    const size_t at = (size_t)row * n + col;
+    const unsigned long long q = reinterpret_cast<const unsigned long long *>(d.red)[at];
+    if (q != 0ull) d.red[at] = fx64_to_double(q, kFxBits - d.qexp[row] - d.qexp[col]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -995,7 +1244,7 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
 // Back-substitution, point-parallel variant (one thread per point; fewer, fatter threads: faster below ~1M
 // observations, where the observation-parallel passes are launch/atomic bound): y_p = M^-1 (E'r - sum_i E_i'F_i y_c), step = -y, candidate point,
 // and this point's share of model_cost_change = -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).
-__global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
+__global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d, ScalBase sbase)
 {
     __shared__ double red[8];
     const int p = blockIdx.x * 64 + threadIdx.x;
@@ -1076,17 +1325,10 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
             }
         }
     }
-    const double s0 = block_sum(mc, red);
-    const double s1 = block_sum(ssq, red);
-    const double s2 = block_sum(csq, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(&d.scal[SC_MODEL_CHANGE], s0);
-        atomicAdd(&d.scal[SC_STEP_SQ_PT], s1);
-        atomicAdd(&d.scal[SC_CAND_SQ_PT], s2);
-    }
+    const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
+    const double vals[4] = {mc, ssq, csq, d.constrained ? gd : 0.0};
+    scal_commit<4>(d, sbase, slots, vals, red);
     if (d.constrained) {
-        const double s3 = block_sum(gd, red);
-        if (threadIdx.x == 0) atomicAdd(&d.scal[SC_GDOTD], s3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
         if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
@@ -1094,8 +1336,9 @@ __global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d)
 }
 
 // Back-substitution, observation-parallel so that every J access is a coalesced SoA stream:
-//   pass 1 (ba_backsub_accum_kernel)  gE[p] += E_k' (F_k y_c)           3 f64 atomics per observation
-//   pass 2 (ba_backsub_apply_kernel)  s_p = -M^-1 (E'r - gE[p]) (recomputed per observation, 12 cached loads),
+//   pass 1 (ba_backsub_accum_kernel)  tE[k] = E_k' (F_k y_c)            3 coalesced stores per observation, no atomics
+//   pass 2 (ba_backsub_apply_kernel)  gE[p] = sum of tE over the point's (contiguous) observations, in order;
+//                                     s_p = -M^-1 (E'r - gE[p]) (recomputed per observation, cached loads),
 //                                     model_cost_change -= (J s).(r + J s / 2)  (trust_region_minimizer.cc),
 //                                     and the first observation of each point writes the candidate point.
 __global__ __launch_bounds__(256) void ba_backsub_accum_kernel(BADev d)
@@ -1103,7 +1346,7 @@ __global__ __launch_bounds__(256) void ba_backsub_accum_kernel(BADev d)
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= d.n_obs) return;
     const size_t n = d.n_obs;
-    const int c = d.obs_cam[k], p = d.obs_pt[k];
+    const int c = d.obs_cam[k];
     double f0 = 0.0, f1 = 0.0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -1116,10 +1359,10 @@ __global__ __launch_bounds__(256) void ba_backsub_accum_kernel(BADev d)
         f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) atomicAdd(&d.gE[3 * (size_t)p + a], d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1);
+    for (int a = 0; a < 3; ++a) d.tE[a * n + k] = d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
 }
 
-__global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
+__global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d, ScalBase sbase)
 {
     __shared__ double red[8];
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1127,8 +1370,9 @@ __global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
     if (k < d.n_obs) {
         const size_t n = d.n_obs;
         const int c = d.obs_cam[k], p = d.obs_pt[k];
-        const double g0 = d.Etr[3 * (size_t)p] - d.gE[3 * (size_t)p], g1 = d.Etr[3 * (size_t)p + 1] - d.gE[3 * (size_t)p + 1],
-                     g2 = d.Etr[3 * (size_t)p + 2] - d.gE[3 * (size_t)p + 2];
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int j = d.pt_start[p]; j < d.pt_start[p + 1]; ++j) { t0 += d.tE[j]; t1 += d.tE[n + j]; t2 += d.tE[2 * n + j]; }
+        const double g0 = d.Etr[3 * (size_t)p] - t0, g1 = d.Etr[3 * (size_t)p + 1] - t1, g2 = d.Etr[3 * (size_t)p + 2] - t2;
         const double *Mi = d.Minv + 6 * (size_t)p;
         const double sp[3] = {-(Mi[0] * g0 + Mi[1] * g1 + Mi[2] * g2), -(Mi[1] * g0 + Mi[3] * g1 + Mi[4] * g2),
                               -(Mi[2] * g0 + Mi[4] * g1 + Mi[5] * g2)};
@@ -1161,17 +1405,10 @@ __global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
             }
         }
     }
-    const double s0 = block_sum(mc, red);
-    const double s1 = block_sum(ssq, red);
-    const double s2 = block_sum(csq, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(&d.scal[SC_MODEL_CHANGE], s0);
-        atomicAdd(&d.scal[SC_STEP_SQ_PT], s1);
-        atomicAdd(&d.scal[SC_CAND_SQ_PT], s2);
-    }
+    const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
+    const double vals[4] = {mc, ssq, csq, d.constrained ? gd : 0.0};
+    scal_commit<4>(d, sbase, slots, vals, red);
     if (d.constrained) {
-        const double s3 = block_sum(gd, red);
-        if (threadIdx.x == 0) atomicAdd(&d.scal[SC_GDOTD], s3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
         if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
@@ -1183,7 +1420,7 @@ __global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d)
 // the Armijo search's cubic interpolation uses [upstream line_search.cc LineSearchFunction::Evaluate].
 template <bool SLOPE>
 __global__ __launch_bounds__(256) void ba_cost_kernel(BADev d, const double *__restrict__ cams, const double *__restrict__ pts,
-                                                      double cauchy_a, int slot, int bad_slot)
+                                                      double cauchy_a, int slot, int bad_slot, ScalBase sbase)
 {
     __shared__ double red[8];
     double cost = 0.0, bad = 0.0, slope = 0.0;
@@ -1224,17 +1461,19 @@ __global__ __launch_bounds__(256) void ba_cost_kernel(BADev d, const double *__r
         cost += 0.5 * rho0;
         if (SLOPE) slope += rho1 * (r0 * m0 + r1 * m1);
     }
-    const double cs = block_sum(cost, red);
-    const double bs = block_sum(bad, red);
-    if (threadIdx.x == 0) { atomicAdd(&d.scal[slot], cs); if (bs > 0.0) atomicAdd(&d.scal[bad_slot], bs); }
     if (SLOPE) {
-        const double ss = block_sum(slope, red);
-        if (threadIdx.x == 0) atomicAdd(&d.scal[SC_LS_GRAD], ss);
+        const int slots[3] = {slot, bad_slot, SC_LS_GRAD};
+        const double vals[3] = {cost, bad, slope};
+        scal_commit<3>(d, sbase, slots, vals, red);
+    } else {
+        const int slots[2] = {slot, bad_slot};
+        const double vals[2] = {cost, bad};
+        scal_commit<2>(d, sbase, slots, vals, red);
     }
 }
 
 // candidate = Plus(x, t delta): cameras (projected onto the box) by workgroup 0, points by all; step / candidate norms.
-__global__ __launch_bounds__(256) void ba_take_step_kernel(BADev d, double t)
+__global__ __launch_bounds__(256) void ba_take_step_kernel(BADev d, double t, ScalBase sbase)
 {
     __shared__ double red[8];
     double ssq = 0.0, csq = 0.0, ssc = 0.0, csc = 0.0;
@@ -1258,14 +1497,12 @@ __global__ __launch_bounds__(256) void ba_take_step_kernel(BADev d, double t)
                 d.cand_c[i] = cnd;
             } else d.cand_c[i] = x;
         }
-    const double a = block_sum(ssq, red);
-    const double b = block_sum(csq, red);
     const double c = block_sum(ssc, red);
     const double e = block_sum(csc, red);
-    if (threadIdx.x == 0) {
-        atomicAdd(&d.scal[SC_STEP_SQ_PT], a); atomicAdd(&d.scal[SC_CAND_SQ_PT], b);
-        if (blockIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = c; d.scal[SC_CAND_SQ_CAM] = e; }
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = c; d.scal[SC_CAND_SQ_CAM] = e; }
+    const int slots[2] = {SC_STEP_SQ_PT, SC_CAND_SQ_PT};
+    const double vals[2] = {ssq, csq};
+    scal_commit<2>(d, sbase, slots, vals, red);
 }
 
 // x_c <- projection onto the box (TrustRegionMinimizer::IterationZero: Plus(x, 0))
@@ -1276,7 +1513,7 @@ __global__ void ba_project_cameras_kernel(BADev d)
 }
 
 // |x|^2 over the parameter blocks that take part in the problem (Ceres drops unused blocks).
-__global__ __launch_bounds__(256) void ba_param_sqnorm_kernel(BADev d)
+__global__ __launch_bounds__(256) void ba_param_sqnorm_kernel(BADev d, ScalBase sbase)
 {
     __shared__ double red[8];
     double sp = 0.0, sc = 0.0;
@@ -1287,9 +1524,11 @@ __global__ __launch_bounds__(256) void ba_param_sqnorm_kernel(BADev d)
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 6 * d.n_cam; i += 256)
             if (d.cam_nobs[i / 6] > 0.0) sc += d.x_c[i] * d.x_c[i];
-    const double a = block_sum(sp, red);
     const double b = block_sum(sc, red);
-    if (threadIdx.x == 0) { atomicAdd(&d.scal[SC_XNORM_SQ_PT], a); if (blockIdx.x == 0) d.scal[SC_XNORM_SQ_CAM] = b; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) d.scal[SC_XNORM_SQ_CAM] = b;
+    const int slots[1] = {SC_XNORM_SQ_PT};
+    const double vals[1] = {sp};
+    scal_commit<1>(d, sbase, slots, vals, red);
 }
 
 // Multi-GPU merge of the point blocks: each rank owns the points it has observations for.
@@ -1342,25 +1581,37 @@ int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack)
 
 int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx)
 {
-    if (d.n_obs <= 0) { ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st)); return ESFM_OK; }
-    const size_t priv_bytes = sizeof(double) * (8 + (size_t)d.n_cam * 27);
+    if (d.n_obs <= 0 || d.n_cchunks <= 0) {
+        ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
+        ESFM_HIP_TRY(hipMemsetAsync(d.qexp, 0, sizeof(int32_t) * 6 * (size_t)d.n_cam, st));
+        return ESFM_OK;
+    }
+    const size_t priv_bytes = 18 * sizeof(double) + (size_t)d.n_real_cam * kLinLdsPerCam;
     const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
     const bool priv = priv_bytes <= 150 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
+    ScalBase sbase;
+    { const int slots[2] = {SC_COST, SC_LIN_BAD}; if (int rc = scal_reserve<2>(st, d, slots, grid, sbase)) return rc; }
     if (priv) {
         auto kern = d.has_calib ? &ba_linearize_kernel<true, true> : &ba_linearize_kernel<true, false>;
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv_bytes));
         {
-            KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone (not the slab reduction)
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, d.lin_slabs);
+            KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep with its in-LDS camera sums (not the slab reduction)
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, sbase, d.lin_slabs);
         }
         LAUNCH_CHECK();
         hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid);
-    } else {
-        ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
-        KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);
-        auto kern = d.has_calib ? &ba_linearize_kernel<false, true> : &ba_linearize_kernel<false, false>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), sizeof(double) * 8, st, d, cauchy_a, use_scaling ? 1 : 0, (double *)nullptr);
+        LAUNCH_CHECK();
+        return ESFM_OK;
     }
+    {
+        KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone
+        auto kern = d.has_calib ? &ba_linearize_kernel<false, true> : &ba_linearize_kernel<false, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), 18 * sizeof(double), st, d, cauchy_a, use_scaling ? 1 : 0, sbase, (double *)nullptr);
+    }
+    LAUNCH_CHECK();
+    if (d.has_calib) hipLaunchKernelGGL(ba_camacc_chunk_kernel<true>, dim3(d.n_cchunks), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(ba_camacc_chunk_kernel<false>, dim3(d.n_cchunks), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(ba_camacc_final_kernel, dim3(div_up(d.n_real_cam * 27 + 42, 256)), dim3(256), 0, st, d);
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1368,7 +1619,9 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh)
 {
     if (d.n_pt <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0);
+    ScalBase sbase;
+    { const int slots[1] = {SC_PT_SINGULAR}; if (int rc = scal_reserve<1>(st, d, slots, div_up(d.n_pt, 64), sbase)) return rc; }
+    hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0, sbase);
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1390,10 +1643,28 @@ int ba_camera_gradient(hipStream_t st, const BADev &d)
     return ESFM_OK;
 }
 
-int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles)
+// e with |x| < 2^e (the exponent the right-hand side's fixed point is scaled by)
+static int bound_exponent(double x)
+{
+    if (!(x > 1e-120)) return -400;
+    if (!(x < 1e120)) return 400;
+    return std::ilogb(x) + 1;
+}
+
+static int schur_to_double(hipStream_t st, const BADev &d, int rhs_exp)
+{
+    const int n = 6 * d.n_cam;
+    hipLaunchKernelGGL(ba_schur_to_double_kernel, dim3(div_up(n, 256), n + 1), dim3(256), 0, st, d, rhs_exp);
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles, double rhs_bound)
 {
     ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
     if (d.n_obs <= 0) return ESFM_OK;
+    const int rhs_exp = bound_exponent(rhs_bound);
+    const bool finish = !d.has_calib;    // with free intrinsics ba_schur_calib adds its block row first, then converts
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
     const int slab_doubles = nblk * 36 + 6 * d.n_cam;
     const size_t lds_bytes = sizeof(double) * (size_t)slab_doubles;
@@ -1401,9 +1672,10 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
     if (lds_bytes <= 156 * 1024 && slabs && (size_t)n_slabs * slab_doubles <= slab_capacity_doubles) {
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_lds_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(1024), lds_bytes, st, d, slabs, slab_doubles);
+        hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(1024), lds_bytes, st, d, slabs, slab_doubles, rhs_exp);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs);
+        if (finish) hipLaunchKernelGGL(ba_schur_reduce_kernel<true>, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs, rhs_exp);
+        else hipLaunchKernelGGL(ba_schur_reduce_kernel<false>, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs, rhs_exp);
         LAUNCH_CHECK();
         return ESFM_OK;
     }
@@ -1411,13 +1683,13 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * 36 + 6 * kWinCams);
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_window_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-        hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d);
+        hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d, rhs_exp);
         LAUNCH_CHECK();
-        return ESFM_OK;
+    } else {
+        hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, rhs_exp);
+        LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
-    LAUNCH_CHECK();
-    return ESFM_OK;
+    return finish ? schur_to_double(st, d, rhs_exp) : ESFM_OK;
 }
 
 int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
@@ -1437,11 +1709,15 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
     return ESFM_OK;
 }
 
-// Scalar read-back without a stream synchronisation: one wave copies the scalar slots into pinned host memory, fences to system
-// scope and then stores the sequence number the host is spinning on.
-__global__ __launch_bounds__(64) void ba_publish_scalars_kernel(const double *__restrict__ scal, double *host, unsigned long long *flag,
-                                                                unsigned long long seq)
+// Scalar read-back without a stream synchronisation: one workgroup adds the pending per-workgroup partials to the sum slots (see
+// scal_commit), copies the scalar slots into pinned host memory, fences to system scope and then stores the sequence number the
+// host is spinning on.
+__global__ __launch_bounds__(256) void ba_publish_scalars_kernel(const double *__restrict__ scal_part, int scal_cap, double *scal, ScalCounts c,
+                                                                 double *host, unsigned long long *flag, unsigned long long seq)
 {
+    __shared__ double lds[8];
+    scal_reduce_pending(scal_part, scal_cap, scal, c, lds);
+    __syncthreads();
     const int i = threadIdx.x;
     if (i < SC_COUNT) host[i] = scal[i];
     __threadfence_system();
@@ -1449,11 +1725,33 @@ __global__ __launch_bounds__(64) void ba_publish_scalars_kernel(const double *__
     if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+static ScalCounts take_counts(const BADev &d)
+{
+    ScalCounts c;
+    for (int q = 0; q < SC_SUM_COUNT; ++q) { c.n[q] = d.parts->n[q]; d.parts->n[q] = 0; }
+    return c;
+}
+
 int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq)
 {
-    hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(64), 0, st, d.scal, host, flag, seq);
+    hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(256), 0, st, d.scal_part, d.scal_cap, d.scal, take_counts(d), host, flag, seq);
     LAUNCH_CHECK();
     return ESFM_OK;
+}
+
+int ba_scal_reduce(hipStream_t st, const BADev &d)
+{
+    bool any = false;
+    for (int q = 0; q < SC_SUM_COUNT; ++q) any = any || d.parts->n[q] > 0;
+    if (!any) return ESFM_OK;
+    hipLaunchKernelGGL(ba_scal_reduce_kernel, dim3(1), dim3(256), 0, st, d.scal_part, d.scal_cap, d.scal, take_counts(d));
+    LAUNCH_CHECK();
+    return ESFM_OK;
+}
+
+void ba_scal_discard(const BADev &d, int first_slot, int end_slot)
+{
+    for (int q = std::max(0, first_slot); q < std::min<int>(SC_SUM_COUNT, end_slot); ++q) d.parts->n[q] = 0;
 }
 
 int ba_camera_step(hipStream_t st, const BADev &d)
@@ -1466,18 +1764,21 @@ int ba_camera_step(hipStream_t st, const BADev &d)
 int ba_backsub(hipStream_t st, const BADev &d)
 {
     if (d.n_pt <= 0) return ESFM_OK;
-    if (d.n_obs < (1 << 20)) {
-        hipLaunchKernelGGL(ba_backsub_point_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d);
+    ScalBase sbase;
+    const int bs_slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
+    if (d.n_obs < kBacksubPointMaxObs || !d.tE) {
+        if (int rc = scal_reserve<4>(st, d, bs_slots, div_up(d.n_pt, 64), sbase)) return rc;
+        hipLaunchKernelGGL(ba_backsub_point_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, sbase);
         LAUNCH_CHECK();
         return ESFM_OK;
     }
     // points without observations keep their value; observed ones are overwritten by pass 2
     ESFM_HIP_TRY(hipMemcpyAsync(d.cand_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
-    ESFM_HIP_TRY(hipMemsetAsync(d.gE, 0, sizeof(double) * 3 * (size_t)d.n_pt, st));
     if (d.n_obs <= 0) return ESFM_OK;
     hipLaunchKernelGGL(ba_backsub_accum_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(ba_backsub_apply_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
+    if (int rc = scal_reserve<4>(st, d, bs_slots, div_up(d.n_obs, 256), sbase)) return rc;
+    hipLaunchKernelGGL(ba_backsub_apply_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, sbase);
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1487,8 +1788,16 @@ int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, cons
 {
     if (d.n_obs <= 0) return ESFM_OK;
     const int grid = std::min(div_up(d.n_obs, 256), std::max(1, num_cu) * 8);
-    if (with_slope) hipLaunchKernelGGL(ba_cost_kernel<true>, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot);
-    else hipLaunchKernelGGL(ba_cost_kernel<false>, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot);
+    ScalBase sbase;
+    if (with_slope) {
+        const int slots[3] = {slot, bad_slot, SC_LS_GRAD};
+        if (int rc = scal_reserve<3>(st, d, slots, grid, sbase)) return rc;
+        hipLaunchKernelGGL(ba_cost_kernel<true>, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot, sbase);
+    } else {
+        const int slots[2] = {slot, bad_slot};
+        if (int rc = scal_reserve<2>(st, d, slots, grid, sbase)) return rc;
+        hipLaunchKernelGGL(ba_cost_kernel<false>, dim3(grid), dim3(256), 0, st, d, cams, pts, cauchy_a, slot, bad_slot, sbase);
+    }
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1496,7 +1805,9 @@ int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, cons
 int ba_take_step(hipStream_t st, const BADev &d, double t)
 {
     const int grid = std::max(1, std::min(div_up(3LL * d.n_pt, 256), 1024));
-    hipLaunchKernelGGL(ba_take_step_kernel, dim3(grid), dim3(256), 0, st, d, t);
+    ScalBase sbase;
+    { const int slots[2] = {SC_STEP_SQ_PT, SC_CAND_SQ_PT}; if (int rc = scal_reserve<2>(st, d, slots, grid, sbase)) return rc; }
+    hipLaunchKernelGGL(ba_take_step_kernel, dim3(grid), dim3(256), 0, st, d, t, sbase);
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1509,21 +1820,24 @@ int ba_project_cameras(hipStream_t st, const BADev &d)
     return ESFM_OK;
 }
 
-int ba_schur_calib(hipStream_t st, const BADev &d)
+int ba_schur_calib(hipStream_t st, const BADev &d, double rhs_bound)
 {
     if (!d.has_calib || d.n_pt <= 0 || d.n_obs <= 0) return ESFM_OK;
     const size_t row_bytes = sizeof(double) * (8 + (size_t)4 * 6 * d.n_real_cam);
     const bool use_lds = row_bytes <= 64 * 1024;
     const size_t lds = use_lds ? row_bytes : sizeof(double) * 8;
-    hipLaunchKernelGGL(ba_schur_calib_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), lds, st, d, use_lds ? 1 : 0);
+    const int rhs_exp = bound_exponent(rhs_bound);
+    hipLaunchKernelGGL(ba_schur_calib_kernel, dim3(div_up(d.n_pt, 256)), dim3(256), lds, st, d, use_lds ? 1 : 0, rhs_exp);
     LAUNCH_CHECK();
-    return ESFM_OK;
+    return schur_to_double(st, d, rhs_exp);
 }
 
 int ba_param_sqnorm(hipStream_t st, const BADev &d)
 {
     const int grid = std::max(1, std::min(div_up(3LL * d.n_pt, 256), 1024));
-    hipLaunchKernelGGL(ba_param_sqnorm_kernel, dim3(grid), dim3(256), 0, st, d);
+    ScalBase sbase;
+    { const int slots[1] = {SC_XNORM_SQ_PT}; if (int rc = scal_reserve<1>(st, d, slots, grid, sbase)) return rc; }
+    hipLaunchKernelGGL(ba_param_sqnorm_kernel, dim3(grid), dim3(256), 0, st, d, sbase);
     LAUNCH_CHECK();
     return ESFM_OK;
 }

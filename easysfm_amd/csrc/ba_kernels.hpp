@@ -28,6 +28,10 @@ enum BAScalar {
 // one more 6-wide camera-side block (two padding unknowns with zero Jacobian columns) behind the real cameras, so
 // n_cam = n_real_cam + has_calib is the number of 6-wide blocks of the reduced system and every per-block array
 // (x_c, scale_c, camacc, red, y_c ...) simply has one more block; observations only ever name real cameras.
+struct ScalParts { int n[SC_SUM_COUNT]; };    // host-side bookkeeping
+struct ScalCounts { int n[SC_SUM_COUNT]; };   // kernel argument: how many partials each slot has pending
+struct ScalBase { int b[4]; };                // kernel argument: first partial index of this launch, per slot it commits
+
 struct BADev {
     int n_cam = 0, n_pt = 0, n_obs = 0;
     int n_real_cam = 0, has_calib = 0;
@@ -55,7 +59,6 @@ struct BADev {
     double *Etr = nullptr;   // [3 n_pt]
     double *Minv = nullptr;  // [6 n_pt] (E'E + D_p^2)^-1
     double *Aig = nullptr;   // [3 n_pt] Minv * Etr
-    double *gE = nullptr;    // [3 n_pt] sum_k E_k' F_k y_c (back-substitution scratch)
     // per-camera normal-equation pieces, one contiguous SUM all-reduce buffer:
     //   camacc = FtF (36 per camera, full symmetric) | Ftr (6 per camera)
     double *camacc = nullptr;
@@ -73,9 +76,33 @@ struct BADev {
     int32_t *slot_obs = nullptr;    // [n_obs] observation indices in chunk order
     int32_t *chunk_slot = nullptr;  // [n_chunks+1] first slot of each chunk
     int32_t *chunk_cam0 = nullptr;  // [n_chunks] lowest camera of the chunk = window base
-    double *lin_slabs = nullptr;  // per-workgroup F'F / F'r slabs of the Jacobian sweep (27 n_cam each)
+    // per-camera sums F'F / F'r of LARGE camera counts (the small ones are summed inside the sweep, see ba_linearize_kernel): the observations of every camera in ascending order (cam_obs, a CSR over
+    // cameras built once per problem), cut into chunks of kCamChunk; one wave sums a chunk in a fixed order, a second
+    // launch adds a camera's chunk sums in order.  Bit-reproducible whatever the launch timing.
+    double *lin_slabs = nullptr;        // per-workgroup F'F / F'r slabs of the Jacobian sweep (27 n_cam doubles each), small camera counts
     size_t lin_slab_cap = 0;
+    int32_t *cam_obs = nullptr;         // [n_obs]
+    int32_t *cchunk_cam = nullptr, *cchunk_beg = nullptr, *cchunk_end = nullptr;   // [n_cchunks]
+    int32_t *cam_chunk0 = nullptr;      // [n_real_cam + 1] first chunk of each camera
+    int n_cchunks = 0;
+    double *cam_part = nullptr;         // [n_cchunks][kCamPart]: 27 camera sums + 10 intrinsics-block sums per chunk
+    // scalar sums across workgroups: per-workgroup partials, added in index order at the next read-back (scal_commit)
+    double *scal_part = nullptr;        // [SC_SUM_COUNT][scal_cap]
+    int scal_cap = 0;
+    ScalParts *parts = nullptr;         // HOST memory (esfm_ba_problem): partials pending per slot; never dereferenced on the device
+    // Exact, hence order-independent, accumulation of the Schur complement: d.red is accumulated as 64-bit FIXED-POINT integers
+    // (LDS / global u64 atomics, slab sums: integer addition is associative) and converted to f64 once, before the solve.  Entry
+    // (r, c) is scaled by 2^(60 - qexp[r] - qexp[c]) with sqrt(diag(F'F)_i) < 2^qexp[i]:  Cauchy-Schwarz with E M^-1 E' <= I bounds
+    // every partial sum  |sum_p f_r' E M^-1 E' f_c| <= sqrt(diag(F'F)_r diag(F'F)_c) < 2^(qexp[r] + qexp[c]),  so the integers stay
+    // below 2^60; the right-hand side uses |residual| <= sqrt(2 cost) < 2^rhs_exp in place of the column factor.  The grid is 2^-60
+    // of the entry's natural scale -- 7 bits finer than f64 -- so nothing is lost against f64 atomics (a common f64 grid, i.e.
+    // (v + 1.5 2^k) - 1.5 2^k, was tried first: it costs 3 digits of the parameters).  Refreshed by ba_linearize from
+    // this rank's observations.
+    int32_t *qexp = nullptr;            // [6 n_cam]
+    double *tE = nullptr;               // [3][n_obs] E_k'(F_k y_c) per observation (back-substitution of problems >= 2^20 observations)
 };
+constexpr int kCamChunk = 256, kCamPart = 37;
+constexpr int kBacksubPointMaxObs = 1 << 20;   // below: one thread per point; from here on: observation-parallel two-pass
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
 inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
@@ -88,7 +115,7 @@ int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag
 int ba_jacobi_scaling(hipStream_t st, const BADev &d);
 int ba_camera_gradient(hipStream_t st, const BADev &d);
 // slabs: scratch for the LDS-privatised variant (n_cam small), >= ba_schur_slab_doubles(n_cam, num_cu) doubles, or NULL
-int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles);
+int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles, double rhs_bound);
 inline size_t ba_schur_slab_doubles(int n_cam, int num_cu)
 {
     const size_t per = (size_t)n_cam * (n_cam + 1) / 2 * 36 + 6 * (size_t)n_cam;
@@ -103,7 +130,11 @@ size_t ba_chol_large_doubles(int n_cam);
 bool ba_chol_small_fits(int n_cam);
 int ba_solve_reduced_small(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag);
 // intrinsics row/column block of the reduced system (has_calib): runs after ba_schur, adds into d.red
-int ba_schur_calib(hipStream_t st, const BADev &d);
+int ba_schur_calib(hipStream_t st, const BADev &d, double rhs_bound);
+// the pending per-workgroup partials -> d.scal (ba_publish_scalars does it itself; needed before an all-reduce of d.scal)
+int ba_scal_reduce(hipStream_t st, const BADev &d);
+// forget the pending partials of slots [first, end): the companion of a memset of those d.scal slots
+void ba_scal_discard(const BADev &d, int first_slot, int end_slot);
 int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq);
 int ba_camera_step(hipStream_t st, const BADev &d);
 int ba_backsub(hipStream_t st, const BADev &d);

@@ -61,8 +61,19 @@ def test_ba_trace_and_params_match_oracle(gpu_ctx, oracle_lib, n_cam, n_pt, k, s
     opt, ropt = _solve_both(oracle_lib, sc, 50)
     cams, pts, summ = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
     rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, ropt)
-    # the reductions use atomics: near convergence two runs of the GPU solver can stop an iteration apart (about one run in
-    # twenty on the 4-camera scene lands 1-2e-5 from the oracle's final cost), hence 1e-4
+    # Every reduction of the GPU solver has a fixed association or is exact (tests/test_ba_determinism_gpu.py), so this run is one
+    # reproducible outcome, not a distribution (round 1 needed 1e-4 here because of f64 atomics).  What remains is the gauge:
+    # once the radius passes ~1e10 the damping D^2 = diag(J'J) / radius of the 7 unconstrained directions is below the round-off
+    # of the reduced matrix, and ANY two f64 factorisations (Ceres + Eigen included) take different steps from there on (on this
+    # 4-camera scene the cost traces agree to 2e-12 at iteration 10 and split at iteration ~20, radius 3e13).  So: the trace to
+    # 1e-9 for as long as the problem is numerically determined, then both runs must have converged to the same basin.
+    n_checked = 0
+    for a, b in zip(summ.log(), oracle_lib.iterations(rs)):
+        if b.trust_region_radius > 1e10:
+            break
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= RTOL_TRACE * b.cost, a.iteration
+        n_checked += 1
+    assert n_checked >= min(10, rs.num_iterations)
     assert abs(summ.final_cost - rs.final_cost) <= 1e-4 * rs.final_cost
     assert abs(oracle_lib.ba_cost(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, cams, pts) - summ.final_cost) <= 1e-10 * summ.final_cost
 
