@@ -348,101 +348,179 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, 
 
 // ---------------------------------------------------------------------------------------------
 // Reduced systems that fit ONE workgroup's LDS (n = 6 n_cam <= 176, i.e. up to 29 cameras: BASELINE's BA-25 has n = 150): the
-// whole solve in one launch on the same 16 x 16 building blocks.  The lower block triangle lives in LDS (block (i, j) at
+// whole solve -- and the camera step that follows it -- in one launch.  The lower block triangle lives in LDS (block (i, j) at
 // i (i + 1) / 2 + j, 16 x VLD doubles each), the right-hand side is carried along as a row vector z (forward substitution for
-// free).  Per block column b: wave 0 factors and inverts the diagonal block (potrf16_inv), then all 16 waves do the panel
-// X_i = A_i Linv^T and the trailing update A_ij -= X_i X_j^T as MFMA products, one block per wave and round; 3 barriers.  Then
-// the backward substitution through the block inverses.  Round 1's kernel (ba_chol_solve_kernel: 8-column panels, dot products
-// from packed rows, 19 panels x 3 barriers) took 127 us at n = 150.
+// free).  The n pivots are a serial chain, so everything that is not the chain is kept off it.  Per block column b:
+//   1. wave 0 factors the diagonal block in registers and inverts the factor in the same pass (potrf16_fused_inv: lane = row,
+//      v_readlane broadcasts shared by both recurrences);
+//   2. the panel X_i = A_i Linv' and 3. the trailing update A_ij -= X_i X_j' run on the f64 matrix cores, one 16 x 16 block per
+//      wave and round.
+// The backward substitution then runs through the block inverses as matrix-vector products, and the workgroup writes y and the
+// candidate cameras (ba_camera_step).  (Measured alternative: factor only + one thread per panel row solving by substitution +
+// the inverses side by side at the end: 82 us against 90 us for the unfused factor-then-invert; substitution is 16 dependent
+// LDS-fed steps per block column, 1.45 us.)
+// Round 1's kernel (ba_chol_solve_kernel: 8-column panels, dot products from packed rows, 19 panels x 3 barriers): 127 us.
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallMaxNb = 11;
 __device__ __forceinline__ int blk_off(int i, int j) { return (i * (i + 1) / 2 + j) * (SB * VLD); }
+
+// 1 / sqrt(x) from the hardware seed (v_rsq_f64, relative error <= 2^-26) and ONE Newton step: relative error <= 1.5 * 2^-52.
+// The factor only has to be backward stable (the iteration log is compared with the oracle at 1e-9), and the second step is 30
+// cycles on the critical path of each of the n pivots.
+__device__ __forceinline__ double rsqrt_pivot1(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    return y * fma(-0.5 * x, y * y, 1.5);
+}
+
+// One wave: the 16 x 16 block D (LDS, row-major VLD) is replaced by the INVERSE of its Cholesky factor (above the diagonal: +-0).
+// Lane r (and r + 16, ... redundantly) holds row r of the block in x and solves L y = e_r in t.  Factorisation and inversion are
+// both right-looking and share every broadcast: once column c is final, lane i's L[i][c] (DPP row_newbcast) updates column i of
+// the block (x[i] -= L[r][c] L[i][c]) AND row i of the inverse (t[i] -= L[i][c] t[c]).  The whole thing is one generated asm
+// block (gen_potrf16_asm.py -> potrf16_gfx950.inc, ~740 instructions): the pivots are a serial chain (broadcast, v_rsq_f64, one
+// Newton step, scale) and the updates have to be issued in the shadow of its latencies, which hipcc does not do -- measured per
+// 16 x 16 block at n = 150: factor then invert, v_readlane broadcasts: 9.7k cycles; fused, v_readlane: 8.4k (the compiler parks
+// 30 scalars per pivot in VGPR lanes, v_writelane + s_nop); fused, DPP from C++: spills to scratch; this one: see DESIGN.md.
+#include "potrf16_gfx950.inc"
+__device__ __forceinline__ void potrf16_fused_inv(double *D, int *fail, int lane)
+{
+    const int r = lane & 15;
+    const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * VLD), col_addr = (uint32_t)(uintptr_t)(D + r);
+    int bad;
+    asm volatile(ESFM_POTRF16_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr), "v"(lane) : ESFM_POTRF16_CLOBBERS);
+    if (__any(bad) && lane == 0) *fail = 1;
+}
 
 __global__ __launch_bounds__(kSmallThreads) void ba_chol_small_kernel(BADev d, double radius, double min_diag, double max_diag)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = 6 * d.n_cam, nb = (n + SB - 1) / SB, np = nb * SB;
-    double *A = sm;                                     // nb (nb + 1) / 2 blocks; a factored diagonal block is replaced by its INVERSE
+    double *A = sm;                                     // nb (nb + 1) / 2 blocks; after the factorisation a diagonal block holds the INVERSE of its factor
     double *z = A + (size_t)(nb * (nb + 1) / 2) * (SB * VLD);    // np: right-hand side, then the solution
     double *rd = z + np;                                // np
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) fail = 0;
+#ifdef ESFM_CHOL_PROFILE
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = wall_clock64();
+#define CHOL_MARK(q) do { const long long tm1 = wall_clock64(); prof[q] += tm1 - tm0; tm0 = tm1; } while (0)
+#else
+#define CHOL_MARK(q) do { } while (0)
+#endif
     const double *S = d.red, *rc = d.red + (size_t)n * n, *FtF = d.camacc, *Ftr = d.camacc + 36 * (size_t)d.n_cam;
-    // assemble W = F'F + D_c^2 + S_schur (lower block triangle, full diagonal blocks), identity padding, z = F'r + rhs_corr
-    for (int e = tid; e < (nb * (nb + 1) / 2) * SB * SB; e += kSmallThreads) {
-        const int blk = e / (SB * SB), w = e % (SB * SB), r = w / SB, c = w % SB;
-        int bi = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
-        while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
-        while (bi * (bi + 1) / 2 > blk) --bi;
-        const int bj = blk - bi * (bi + 1) / 2;
-        int i = SB * bi + r, k = SB * bj + c;
-        const bool upper = k > i;                       // only inside diagonal blocks: mirror (the factorisation reads the lower part)
-        if (upper) { const int t = i; i = k; k = t; }
-        double v = 0.0;
-        if (i < n) {
-            v = S[(size_t)i * n + k];
-            if (i / 6 == k / 6) {
-                const int cc = i / 6;
-                v += FtF[36 * (size_t)cc + 6 * (i % 6) + (k % 6)];
-                if (i == k) v += fmin(fmax(FtF[36 * (size_t)cc + 7 * (i % 6)], min_diag), max_diag) / radius;
+    // assemble W = F'F + D_c^2 + S_schur (lower block triangle, full diagonal blocks), identity padding, z = F'r + rhs_corr.
+    // Pass 1: S -> LDS, one block per wave and round, lane = (row, 4 consecutive columns), every round's loads in flight at
+    // once (the rounds used to wait for each other's memory round trip: 7.7 us).  Pass 2: the 6 x 6 camera blocks of F'F + D^2.
+    {
+        constexpr int kRounds = (kSmallMaxNb * (kSmallMaxNb + 1) / 2 + kSmallThreads / 64 - 1) / (kSmallThreads / 64);
+        const int nblk = nb * (nb + 1) / 2;
+        const int r = lane >> 2, c0 = (lane & 3) * 4;
+        double v[kRounds][4];
+        int bi = 0, bj = 0;
+        for (int q = 0; q < wave; ++q) { if (++bj > bi) { ++bi; bj = 0; } }
+#pragma unroll
+        for (int q = 0; q < kRounds; ++q) {
+            const bool live = wave + q * (kSmallThreads / 64) < nblk;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                int i = SB * bi + r, k = SB * bj + c0 + cc;
+                if (k > i) { const int t = i; i = k; k = t; }   // only inside diagonal blocks: mirror (the factorisation reads the lower part)
+                v[q][cc] = (live && i < n) ? S[(size_t)i * n + k] : ((live && i == k) ? 1.0 : 0.0);
             }
-        } else if (i == k) v = 1.0;
-        A[blk * (SB * VLD) + r * VLD + c] = v;
+            for (int w = 0; w < kSmallThreads / 64; ++w) { if (++bj > bi) { ++bi; bj = 0; } }
+        }
+#pragma unroll
+        for (int q = 0; q < kRounds; ++q) {
+            const int blk = wave + q * (kSmallThreads / 64);
+            if (blk < nblk) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) A[blk * (SB * VLD) + r * VLD + c0 + cc] = v[q][cc];
+            }
+        }
     }
-    for (int i = tid; i < np; i += kSmallThreads) z[i] = i < n ? Ftr[i] + rc[i] : 0.0;
+    double ftf = 0.0;
+    if (tid < 36 * d.n_cam) ftf = FtF[tid];                 // (n_cam <= 29: one entry per thread)
+    const double zr = tid < n ? Ftr[tid] + rc[tid] : 0.0;
     __syncthreads();
+    if (tid < 36 * d.n_cam) {
+        const int cam = tid / 36, a = (tid % 36) / 6, b2 = tid % 6;
+        if (b2 <= a) {
+            const int i = 6 * cam + a, k = 6 * cam + b2;
+            double add = ftf;
+            if (a == b2) add += fmin(fmax(ftf, min_diag), max_diag) / radius;
+            double *B = A + blk_off(i / SB, k / SB);
+            B[(i % SB) * VLD + (k % SB)] += add;
+            if (i / SB == k / SB && i != k) B[(k % SB) * VLD + (i % SB)] += add;
+        }
+    }
+    if (tid < np) z[tid] = zr;
+    __syncthreads();
+    CHOL_MARK(0);
 
+    // Block column b: panel X_i = A_i Linv_b' (MFMA), then the trailing update A_ij -= X_i X_j' (MFMA) -- during which wave 0
+    // updates block (b+1, b+1) FIRST and factors / inverts it (look-ahead: the serial pivot chain of the next block column runs
+    // in the shadow of this one's update).  The right-hand side rides along off that critical path: z_b <- z_b Linv_b' by the
+    // last wave during the panel, z_j -= z_b X_j' by the last threads during the update.
+    if (wave == 0) potrf16_fused_inv(A + blk_off(0, 0), &fail, lane);
+    __syncthreads();
+    CHOL_MARK(1);
 #pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-        if (wave == 0) {
-            potrf16_inv<false>(A + blk_off(b, b), VLD, A + blk_off(b, b), rd + SB * b, &fail, lane);
-            // the right-hand side's block: z_b <- z_b Linv^T (lanes 0..15: entry j = sum_k z_b[k] Linv[j][k])
-            __builtin_amdgcn_wave_barrier();
+        if (wave == kSmallThreads / 64 - 1) {
             double acc = 0.0;
             if (lane < SB) {
 #pragma unroll
-                for (int k = 0; k < SB; ++k) acc += z[SB * b + k] * A[blk_off(b, b) + lane * VLD + k];
+                for (int k = 0; k < SB; ++k) acc = fma(z[SB * b + k], A[blk_off(b, b) + lane * VLD + k], acc);
             }
             __builtin_amdgcn_wave_barrier();
             if (lane < SB) z[SB * b + lane] = acc;
         }
-        __syncthreads();
-        // panel: X_i = A_i Linv^T for the blocks below the diagonal one
         for (int i = b + 1 + wave; i < nb; i += kSmallThreads / 64) {
             doublex4 acc = pqt16(doublex4{0.0, 0.0, 0.0, 0.0}, A + blk_off(i, b), VLD, A + blk_off(b, b), VLD, 1.0, lane);
             __builtin_amdgcn_wave_barrier();
             store_d16(A + blk_off(i, b), VLD, acc, lane);
         }
         __syncthreads();
-        // trailing update A_ij -= X_i X_j^T (b < j <= i), and z_j -= z_b X_j^T
+        CHOL_MARK(2);
         const int m = nb - 1 - b;
-        for (int t = wave; t < m * (m + 1) / 2; t += kSmallThreads / 64) {
-            int ri = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
-            while (ri * (ri + 1) / 2 > t) --ri;
-            const int i = b + 1 + ri, j = b + 1 + (t - ri * (ri + 1) / 2);
-            doublex4 acc = load_d16(A + blk_off(i, j), VLD, lane);
-            acc = pqt16(acc, A + blk_off(i, b), VLD, A + blk_off(j, b), VLD, -1.0, lane);
-            store_d16(A + blk_off(i, j), VLD, acc, lane);
-        }
-        for (int e = tid; e < m * SB; e += kSmallThreads) {
-            const int j = b + 1 + e / SB, c = e % SB;
-            const double *Xj = A + blk_off(j, b) + c * VLD;
-            double s0 = 0.0;
+        if (wave == 0) {
+            if (m > 0) {
+                doublex4 acc = load_d16(A + blk_off(b + 1, b + 1), VLD, lane);
+                acc = pqt16(acc, A + blk_off(b + 1, b), VLD, A + blk_off(b + 1, b), VLD, -1.0, lane);
+                store_d16(A + blk_off(b + 1, b + 1), VLD, acc, lane);
+                __builtin_amdgcn_wave_barrier();
+                potrf16_fused_inv(A + blk_off(b + 1, b + 1), &fail, lane);
+            }
+        } else {
+            // the other trailing blocks (b + 1 < i, j <= i) over waves 1..15, and z_j -= z_b X_j' for j > b
+            for (int t = wave; t < m * (m + 1) / 2; t += kSmallThreads / 64 - 1) {
+                int ri = 0, rj = t;
+                while (rj > ri) { rj -= ri + 1; ++ri; }
+                const int i = b + 1 + ri, j = b + 1 + rj;
+                doublex4 acc = load_d16(A + blk_off(i, j), VLD, lane);
+                acc = pqt16(acc, A + blk_off(i, b), VLD, A + blk_off(j, b), VLD, -1.0, lane);
+                store_d16(A + blk_off(i, j), VLD, acc, lane);
+            }
+            for (int e = kSmallThreads - 1 - tid; e < m * SB; e += kSmallThreads - 64) {     // (the last waves have the fewest blocks)
+                const int j = b + 1 + e / SB, c = e % SB;
+                const double *Xj = A + blk_off(j, b) + c * VLD;
+                double s0 = 0.0;
 #pragma unroll
-            for (int k = 0; k < SB; ++k) s0 += z[SB * b + k] * Xj[k];
-            z[SB * j + c] -= s0;
+                for (int k = 0; k < SB; ++k) s0 = fma(z[SB * b + k], Xj[k], s0);
+                z[SB * j + c] -= s0;
+            }
         }
         __syncthreads();
+        CHOL_MARK(3);
     }
+    CHOL_MARK(4);
     // backward substitution L' y = z through the block inverses: y_b = Linv_bb' (z_b - sum_{i > b} L_ib' y_i)
     for (int b = nb - 1; b >= 0; --b) {
         if (tid < SB) {
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < SB; ++k) acc += A[blk_off(b, b) + k * VLD + tid] * z[SB * b + k];
-            rd[SB * b + tid] = acc;          // y_b (rd is free after the factorisation)
+            rd[SB * b + tid] = acc;          // y_b (rd is free after the inversions)
         }
         __syncthreads();
         for (int e = tid; e < b * SB; e += kSmallThreads) {
@@ -455,8 +533,16 @@ __global__ __launch_bounds__(kSmallThreads) void ba_chol_small_kernel(BADev d, d
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += kSmallThreads) d.y_c[i] = fail ? 0.0 : rd[i];
+    CHOL_MARK(5);
+    for (int i = tid; i < n; i += kSmallThreads) { const double y = fail ? 0.0 : rd[i]; rd[i] = y; d.y_c[i] = y; }
     if (tid == 0 && fail) d.scal[SC_CHOL_FAIL] = 1.0;
+    __syncthreads();
+    ba_camera_step_body(d, rd, z);       // candidate cameras from y (z: reduction scratch from here on)
+#ifdef ESFM_CHOL_PROFILE
+    CHOL_MARK(6);
+    if (tid == 0) printf("chol_small [10 ns]: assemble %lld potrf %lld panel %lld update %lld inverse %lld back %lld tail %lld\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6]);
+#endif
+#undef CHOL_MARK
 }
 
 bool ba_chol_small_fits(int n_cam) { return (6 * n_cam + SB - 1) / SB <= kSmallMaxNb; }

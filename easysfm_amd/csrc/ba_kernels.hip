@@ -1212,33 +1212,12 @@ __global__ __launch_bounds__(kCholThreads) void ba_chol_solve_kernel(BADev d, do
 }
 
 // ---------------------------------------------------------------------------------------------
-// Candidate cameras: x + (-y) .* scaling for cameras that have observations; step/candidate norms.
+// Candidate cameras: x + (-y) .* scaling for cameras that have observations; step/candidate norms (ba_camera_step_body in
+// ba_kernels.hpp; the one-workgroup reduced solve calls it at its end instead of this launch).
 __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
 {
-    __shared__ double red[8];
-    double ssq = 0.0, csq = 0.0, dmax = 0.0;
-    for (int i = threadIdx.x; i < 6 * d.n_cam; i += 256) {
-        const bool active = d.cam_nobs[i / 6] > 0.0;
-        const double x = d.x_c[i];
-        const double dl = active ? (-d.y_c[i]) * d.scale_c[i] : 0.0;
-        double cnd = active ? x + dl : x;
-        if (d.constrained) {
-            // ParameterBlock::Plus projects onto the box (lower bound first) [upstream parameter_block.h]
-            if (active) cnd = fmin(fmax(cnd, d.lo_c[i]), d.up_c[i]);
-            d.delta_c[i] = dl;
-            dmax = fmax(dmax, fabs(dl));
-        }
-        d.cand_c[i] = cnd;
-        if (active) { const double df = x - cnd; ssq += df * df; csq += cnd * cnd; }
-    }
-    const double a = block_sum(ssq, red);
-    const double b = block_sum(csq, red);
-    if (threadIdx.x == 0) { d.scal[SC_STEP_SQ_CAM] = a; d.scal[SC_CAND_SQ_CAM] = b; }
-    if (d.constrained) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
-        if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
-    }
+    __shared__ double red[48];
+    ba_camera_step_body(d, d.y_c, red);
 }
 
 // Back-substitution, point-parallel variant (one thread per point; fewer, fatter threads: faster below ~1M
@@ -1756,6 +1735,7 @@ void ba_scal_discard(const BADev &d, int first_slot, int end_slot)
 
 int ba_camera_step(hipStream_t st, const BADev &d)
 {
+    if (ba_chol_small_fits(d.n_cam)) return ESFM_OK;     // the one-workgroup reduced solve has done it
     hipLaunchKernelGGL(ba_camera_step_kernel, dim3(1), dim3(256), 0, st, d);
     LAUNCH_CHECK();
     return ESFM_OK;

@@ -136,6 +136,42 @@ int ba_scal_reduce(hipStream_t st, const BADev &d);
 // forget the pending partials of slots [first, end): the companion of a memset of those d.scal slots
 void ba_scal_discard(const BADev &d, int first_slot, int end_slot);
 int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq);
+#ifdef __HIPCC__
+// Candidate cameras from the reduced solve's y (one workgroup of up to 1024 threads; lds: >= 48 doubles): x + (-y) .* scaling for cameras that
+// have observations, projected onto the box when the problem is bounded; step / candidate norms and max |delta|.
+__device__ inline void ba_camera_step_body(const BADev &d, const double *y, double *lds)
+{
+    double ssq = 0.0, csq = 0.0, dmax = 0.0;
+    for (int i = threadIdx.x; i < 6 * d.n_cam; i += blockDim.x) {
+        const bool active = d.cam_nobs[i / 6] > 0.0;
+        const double x = d.x_c[i];
+        const double dl = active ? (-y[i]) * d.scale_c[i] : 0.0;
+        double cnd = active ? x + dl : x;
+        if (d.constrained) {
+            // ParameterBlock::Plus projects onto the box (lower bound first) [upstream parameter_block.h]
+            if (active) cnd = fmin(fmax(cnd, d.lo_c[i]), d.up_c[i]);
+            d.delta_c[i] = dl;
+            dmax = fmax(dmax, fabs(dl));
+        }
+        d.cand_c[i] = cnd;
+        if (active) { const double df = x - cnd; ssq += df * df; csq += cnd * cnd; }
+    }
+    // 6 n_cam entries only: every thread past them holds zeros, so the sums are those of the first ceil(6 n_cam / 64) waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ssq += __shfl_xor(ssq, o); csq += __shfl_xor(csq, o); dmax = fmax(dmax, __shfl_xor(dmax, o)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { lds[wave] = ssq; lds[16 + wave] = csq; lds[32 + wave] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, m = 0.0;
+        for (int w = 0; w < nw; ++w) { a += lds[w]; b += lds[16 + w]; m = fmax(m, lds[32 + w]); }
+        d.scal[SC_STEP_SQ_CAM] = a; d.scal[SC_CAND_SQ_CAM] = b;
+        if (d.constrained && m > 0.0) atomicMax(reinterpret_cast<unsigned long long *>(&d.scal[SC_DMAX]), (unsigned long long)__double_as_longlong(m));
+    }
+}
+#endif
+
 int ba_camera_step(hipStream_t st, const BADev &d);
 int ba_backsub(hipStream_t st, const BADev &d);
 // with_slope: also the derivative of the cost along (delta_c, delta_p) at (cams, pts) into SC_LS_GRAD
