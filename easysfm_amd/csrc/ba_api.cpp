@@ -220,11 +220,10 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     A(&d.cam_obs, no); A(&d.cchunk_cam, cchunk_cam.size()); A(&d.cchunk_beg, cchunk_cam.size()); A(&d.cchunk_end, cchunk_cam.size());
     A(&d.cam_chunk0, (size_t)n_real + 1); A(&d.cam_part, cchunk_cam.size() * (size_t)esfm::kCamPart);
     // room for a few launches' partials per slot between two read-backs (a full slot is flushed by an extra reduce launch)
-    d.scal_cap = std::max(1 << 12, 4 * std::max((n_pt + 63) / 64, (n_obs + 255) / 256));
+    d.scal_cap = std::max(1 << 12, 4 * (std::max((n_pt + 63) / 64, (n_obs + 255) / 256) + n_pt / 256 + 2));
     A(&d.scal_part, (size_t)esfm::SC_SUM_COUNT * (size_t)d.scal_cap);
     d.parts = &P->parts;
     A(&d.qexp, nc6);
-    if (n_obs >= esfm::kBacksubPointMaxObs) A(&d.tE, 3 * no);
     // Windowed Schur for large camera counts: order points by their lowest camera, cut the observation stream into
     // ~2 chunks per CU.  (Structure only; built once per problem.)
     std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0;
@@ -247,6 +246,24 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         d.n_chunks = (int)chunk_cam0.size();
         A(&d.slot_obs, slot_obs.size()); A(&d.chunk_slot, chunk_slot.size()); A(&d.chunk_cam0, chunk_cam0.size());
     }
+    // point chunks: consecutive points with at most 256 observations (and 256 points) per chunk; a longer track stands alone
+    std::vector<int32_t> pchunk_pt0;
+    {
+        int p = 0;
+        while (p < n_pt) {
+            pchunk_pt0.push_back(p);
+            int obs = 0, pts_in = 0;
+            while (p < n_pt && pts_in < 256) {
+                const int t = pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+                if (pts_in > 0 && obs + t > 256) break;
+                obs += t; ++pts_in; ++p;
+                if (obs > 256) break;       // a single long track
+            }
+        }
+        pchunk_pt0.push_back(n_pt);
+        d.n_pchunks = (int)pchunk_pt0.size() - 1;
+        A(&d.pchunk_pt0, pchunk_pt0.size());
+    }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     hipStream_t st = ctx->stream;
     auto up = [&](void *dst, const void *src, size_t bytes) {
@@ -265,6 +282,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         up(d.chunk_slot, chunk_slot.data(), sizeof(int32_t) * chunk_slot.size());
         up(d.chunk_cam0, chunk_cam0.data(), sizeof(int32_t) * chunk_cam0.size());
     }
+    up(d.pchunk_pt0, pchunk_pt0.data(), sizeof(int32_t) * pchunk_pt0.size());
     up(d.cam_obs, cam_obs.data(), sizeof(int32_t) * no);
     up(d.cchunk_cam, cchunk_cam.data(), sizeof(int32_t) * cchunk_cam.size()); up(d.cchunk_beg, cchunk_beg.data(), sizeof(int32_t) * cchunk_beg.size());
     up(d.cchunk_end, cchunk_end.data(), sizeof(int32_t) * cchunk_end.size()); up(d.cam_chunk0, cam_chunk0.data(), sizeof(int32_t) * cam_chunk0.size());

@@ -13,6 +13,8 @@
 //   ba_cost_kernel         robustified cost of a parameter vector (candidate evaluation)
 //
 // The LM control flow (accept/reject, radius) lives in ba_api.cpp.  DESIGN.md "Bundle adjustment".
+#include <array>
+
 #include "ba_kernels.hpp"
 
 #include <float.h>
@@ -53,7 +55,7 @@ constexpr int kRedEnt = 32, kRedGrp = 8;
 
 // Scalar sums across workgroups without f64 atomics (whose order of arrival differs from run to run): every workgroup leaves its
 // block sums in d.scal_part[slot][base + blockIdx.x]; the next read-back (ba_publish_scalars / ba_scal_reduce, one workgroup) adds
-// the pending partials of each slot in index order -- thread t takes entries t, t + 256, ..., then the fixed tree of block_sum --
+// the pending partials of each slot in a fixed order -- one wave per slot, lane l takes entries l, l + 64, ..., then the shuffle tree --
 // and adds the total to d.scal[slot].  The result is a function of the launch geometry only.  The host keeps the number of
 // pending partials per slot (BADev::parts); `base` is where this launch's go.  vals are per-THREAD partials.
 // (A first version let the last workgroup to take a ticket do the sum inside the producing kernel: the fence + ticket + tail cost
@@ -68,23 +70,31 @@ __device__ __forceinline__ void scal_commit(const BADev &d, const ScalBase &base
     }
 }
 
-__device__ __forceinline__ void scal_reduce_pending(const double *scal_part, int scal_cap, double *scal, const ScalCounts &c, double *lds /* >= 4, 256 threads */)
+// 1024 threads: wave w adds the pending partials of slot w (SC_SUM_COUNT <= 16) -- lane l takes entries l, l + 64, ... in order,
+// eight loads in flight, then the fixed shuffle tree -- so all slots cost one memory round trip together.
+__device__ __forceinline__ void scal_reduce_pending(const double *scal_part, int scal_cap, double *scal, const ScalCounts &c)
 {
-#pragma unroll 1
-    for (int slot = 0; slot < SC_SUM_COUNT; ++slot) {
-        const int n = c.n[slot];
-        if (n == 0) continue;
-        double v = 0.0;
-        for (int b = threadIdx.x; b < n; b += 256) v += scal_part[(size_t)slot * scal_cap + b];
-        const double t = block_sum(v, lds);
-        if (threadIdx.x == 0) scal[slot] += t;
+    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (slot >= SC_SUM_COUNT) return;
+    const int n = c.n[slot];
+    if (n == 0) return;
+    const double *part = scal_part + (size_t)slot * scal_cap;
+    double v = 0.0;
+    for (int b = lane; b < n; b += 8 * 64) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (b + 64 * u < n) ? part[b + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) scal[slot] += v;
 }
 
-__global__ __launch_bounds__(256) void ba_scal_reduce_kernel(const double *__restrict__ scal_part, int scal_cap, double *scal, ScalCounts c)
+__global__ __launch_bounds__(1024) void ba_scal_reduce_kernel(const double *__restrict__ scal_part, int scal_cap, double *scal, ScalCounts c)
 {
-    __shared__ double lds[8];
-    scal_reduce_pending(scal_part, scal_cap, scal, c, lds);
+    scal_reduce_pending(scal_part, scal_cap, scal, c);
 }
 
 // host side: where the partials of a launch of `grid` workgroups go, for each of its slots
@@ -100,9 +110,23 @@ static int scal_reserve(hipStream_t st, const BADev &d, const int (&slots)[N], i
 }
 
 // Exact accumulation of the Schur complement in 64-bit fixed point (BADev::qexp): fx64(v, sh) = round(v 2^sh) as an integer.
-__device__ __forceinline__ unsigned long long fx64(double v, int sh) { return (unsigned long long)__double2ll_rn(ldexp(v, sh)); }
+// fx64_scaled: round-to-nearest-even of an already scaled x, |x| < 2^62, to int64 WITHOUT the compiler's f64 -> i64 lowering (which,
+// with the ldexp, came to ~110 VALU instructions per entry: the Schur kernel was VALU bound on it).  Two magic-number additions:
+// A = x + 1.5 2^84 rounds x to a multiple of 2^32, whose quotient sits in A's low mantissa dword; xl = x - (A - 1.5 2^84) is exact,
+// |xl| <= 2^31, and B = xl + 1.5 2^52 holds round(xl) as a 64-bit two's complement offset of bits(1.5 2^52).  5 f64 + 1 int op.
+__device__ __forceinline__ unsigned long long fx64_scaled(double x)
+{
+    const double M1 = 0x1.8p84, M2 = 0x1.8p52;
+    const double A = __dadd_rn(x, M1);
+    const double xl = __dsub_rn(x, __dsub_rn(A, M1));
+    const double B = __dadd_rn(xl, M2);
+    const unsigned int hi = (unsigned int)__double2loint(A) + ((unsigned int)__double2hiint(B) - 0x43380000u);
+    return ((unsigned long long)hi << 32) | (unsigned int)__double2loint(B);
+}
+__device__ __forceinline__ unsigned long long fx64(double v, int sh) { return fx64_scaled(ldexp(v, sh)); }
 __device__ __forceinline__ double fx64_to_double(unsigned long long q, int sh) { return ldexp((double)(long long)q, -sh); }
 __device__ __forceinline__ void fx_add(double *slot, double v, int sh) { atomicAdd(reinterpret_cast<unsigned long long *>(slot), fx64(v, sh)); }
+__device__ __forceinline__ void fx_add_scaled(double *slot, double x) { atomicAdd(reinterpret_cast<unsigned long long *>(slot), fx64_scaled(x)); }
 constexpr int kFxBits = 60;   // |v| <= B < 2^e  ->  |v 2^(kFxBits - e)| < 2^60: three bits of head-room in an int64
 
 // ceres::CauchyLoss::Evaluate [upstream]; a <= 0 selects the trivial (squared) loss.
@@ -350,20 +374,22 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
 #pragma unroll
         for (int i = 0; i < 12; ++i) J[i] = d.Jc[(size_t)i * n_obs + k];    // this thread's own stores
         const double r0 = d.res[k], r1 = d.res[(size_t)n_obs + k];
-        int ea[7];
+        // every factor carries 2^(30 - exponent of its column): the products are scaled by 2^(60 - ex[a] - ex[b]) exactly
 #pragma unroll
-        for (int a = 0; a < 7; ++a) ea[a] = ex[c * 7 + a];
+        for (int a = 0; a < 6; ++a) { const int sh = kFxBits / 2 - ex[c * 7 + a]; J[a] = ldexp(J[a], sh); J[6 + a] = ldexp(J[6 + a], sh); }
+        const int shr = kFxBits / 2 - ex[c * 7 + 6];
+        const double q0 = ldexp(r0, shr), q1 = ldexp(r1, shr);
         int e = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
             for (int b = a; b < 6; ++b) {
-                atomicAdd(&acc[c * 27 + e], fx64(J[a] * J[b] + J[6 + a] * J[6 + b], kFxBits - ea[a] - ea[b]));
+                atomicAdd(&acc[c * 27 + e], fx64_scaled(J[a] * J[b] + J[6 + a] * J[6 + b]));
                 ++e;
             }
         }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) atomicAdd(&acc[c * 27 + 21 + a], fx64(J[a] * r0 + J[6 + a] * r1, kFxBits - ea[a] - ea[6]));
+        for (int a = 0; a < 6; ++a) atomicAdd(&acc[c * 27 + 21 + a], fx64_scaled(J[a] * q0 + J[6 + a] * q1));
     }
     __syncthreads();
     // one coalesced slab of doubles per workgroup; ba_camacc_reduce_kernel sums them in a fixed order
@@ -395,16 +421,19 @@ __global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const do
     const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
     const int per = d.n_cam * 27;
     const int grp = threadIdx.x / kRedEnt;
-    double v0 = 0.0, v1 = 0.0;
+    // thread (ent, grp) adds slabs grp, grp + 8, ... in that order; eight loads in flight per round (the loop used to wait for
+    // every load: ~1 us each)
+    double v0 = 0.0;
     if (e < per) {
-        int b = grp;
-        for (; b + kRedGrp < n_slabs; b += 2 * kRedGrp) {
-            v0 += slabs[(size_t)b * per + e];
-            v1 += slabs[(size_t)(b + kRedGrp) * per + e];
+        for (int b = grp; b < n_slabs; b += 8 * kRedGrp) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (b + u * kRedGrp < n_slabs) ? slabs[(size_t)(b + u * kRedGrp) * per + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v0 += t[u];
         }
-        if (b < n_slabs) v0 += slabs[(size_t)b * per + e];
     }
-    lds[threadIdx.x] = v0 + v1;
+    lds[threadIdx.x] = v0;
     __syncthreads();
     if (threadIdx.x >= kRedEnt || e >= per) return;
     double v = 0.0;
@@ -670,9 +699,9 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
         const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
         const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
         fx_add(&d.red[(size_t)n * n + 6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
-        Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
-        Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
-        Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+        Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei[a]);      // rows carry 2^(60 - qexp[row]), columns 2^-qexp[col] below
+        Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei[a]);
+        Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei[a]);
     }
     const int b = d.pt_start[p], e = d.pt_start[p + 1];
     for (int j = b; j < e; ++j) {
@@ -686,13 +715,13 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
         double *Sb = d.red + (size_t)(6 * ci) * n + 6 * cj;
 #pragma unroll
         for (int c2 = 0; c2 < 6; ++c2) {
-            const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
-            const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
-            const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
-            const int ej = d.qexp[6 * cj + c2];
+            const int ej = -d.qexp[6 * cj + c2];
+            const double w0 = ldexp(Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3], ej);
+            const double w1 = ldexp(Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4], ej);
+            const double w2 = ldexp(Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5], ej);
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                fx_add(&Sb[(size_t)a * n + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2), ei[a] - ej);
+                fx_add_scaled(&Sb[(size_t)a * n + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
         }
     }
 }
@@ -702,17 +731,22 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
 // each workgroup accumulates its observations' contributions with LDS f64 atomics (ds_add_f64) and
 // then stores its private copy as one coalesced slab; ba_schur_reduce_kernel sums the slabs in a fixed
 // order and unpacks them into the n x n layout.  No global atomics.
+// LDS pitch of a 6 x 6 block: 37 doubles, not 36.  The lanes of a wave add the same entry of DIFFERENT blocks; at pitch 36 (288 B)
+// those addresses fall on 8 of the 64 banks (SQ_LDS_BANK_CONFLICT was two thirds of SQ_LDS_IDX_ACTIVE), at 37 on all of them.
+constexpr int kSchurPitch = 37;
+
 __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__restrict__ slabs, int slab_doubles, int rhs_exp)
 {
-    extern __shared__ __attribute__((aligned(16))) double sl[];   // [nblk*36] blocks, then [n] rhs_corr
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // [nblk * kSchurPitch] blocks, then [n] rhs_corr
     const int tid = threadIdx.x;
     const int n = 6 * d.n_cam;
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
-    for (int e = tid; e < slab_doubles; e += 1024) sl[e] = 0.0;
+    const int lds_doubles = nblk * kSchurPitch + 6 * d.n_cam;
+    for (int e = tid; e < lds_doubles; e += blockDim.x) sl[e] = 0.0;
     __syncthreads();
-    double *srhs = sl + (size_t)nblk * 36;
+    double *srhs = sl + (size_t)nblk * kSchurPitch;
     const size_t n_obs = d.n_obs;
-    for (int i = blockIdx.x * 1024 + tid; i < d.n_obs; i += gridDim.x * 1024) {
+    for (int i = blockIdx.x * blockDim.x + tid; i < d.n_obs; i += gridDim.x * blockDim.x) {
         const int p = d.obs_pt[i], ci = d.obs_cam[i];
         double Jc[12], Jp[6];
 #pragma unroll
@@ -732,9 +766,9 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
             const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
             const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
             fx_add(&srhs[6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
-            Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
-            Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
-            Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+            Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei[a]);      // rows carry 2^(60 - qexp[row]), columns 2^-qexp[col] below
+            Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei[a]);
+            Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei[a]);
         }
         const int b = d.pt_start[p], e = d.pt_start[p + 1];
         for (int j = b; j < e; ++j) {
@@ -745,22 +779,22 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
             for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
 #pragma unroll
             for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
-            double *Sb = sl + (size_t)(ci * (ci + 1) / 2 + cj) * 36;
+            double *Sb = sl + (size_t)(ci * (ci + 1) / 2 + cj) * kSchurPitch;
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2) {
-                const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
-                const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
-                const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
-                const int ej = d.qexp[6 * cj + c2];
+                const int ej = -d.qexp[6 * cj + c2];
+                const double w0 = ldexp(Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3], ej);
+                const double w1 = ldexp(Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4], ej);
+                const double w2 = ldexp(Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5], ej);
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
-                    fx_add(&Sb[a * 6 + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2), ei[a] - ej);
+                    fx_add_scaled(&Sb[a * 6 + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
             }
         }
     }
     __syncthreads();
     double *out = slabs + (size_t)blockIdx.x * slab_doubles;
-    for (int e = tid; e < slab_doubles; e += 1024) out[e] = sl[e];
+    for (int e = tid; e < slab_doubles; e += blockDim.x) out[e] = e < nblk * 36 ? sl[(e / 36) * kSchurPitch + e % 36] : sl[e + nblk * (kSchurPitch - 36)];
     (void)n;
 }
 
@@ -780,10 +814,10 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
     const int chunk = blockIdx.x;
     const int s0 = d.chunk_slot[chunk], s1 = d.chunk_slot[chunk + 1];
     const int cw = d.chunk_cam0[chunk];
-    constexpr int kWinDoubles = kWinBlocks * 36 + 6 * kWinCams;
+    constexpr int kWinDoubles = kWinBlocks * kSchurPitch + 6 * kWinCams;
     for (int e = tid; e < kWinDoubles; e += 1024) sl[e] = 0.0;
     __syncthreads();
-    double *srhs = sl + kWinBlocks * 36;
+    double *srhs = sl + kWinBlocks * kSchurPitch;
     const size_t n_obs = d.n_obs;
     for (int s = s0 + tid; s < s1; s += 1024) {
         const int i = d.slot_obs[s];
@@ -809,9 +843,9 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
             const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
             const unsigned long long rv = fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
             atomicAdd(reinterpret_cast<unsigned long long *>(in_i ? &srhs[6 * wi + a] : &d.red[(size_t)n * n + 6 * ci + a]), rv);
-            Y[3 * a + 0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
-            Y[3 * a + 1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
-            Y[3 * a + 2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+            Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei[a]);      // rows carry 2^(60 - qexp[row]), columns 2^-qexp[col] below
+            Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei[a]);
+            Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei[a]);
         }
         const int b = d.pt_start[p], e = d.pt_start[p + 1];
         for (int j = b; j < e; ++j) {
@@ -824,17 +858,17 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
             for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
             const int wj = cj - cw;
             const bool in_w = in_i && wj >= 0;   // cj <= ci < cw + kWinCams
-            double *Sl = sl + (size_t)(wi * (wi + 1) / 2 + wj) * 36;
+            double *Sl = sl + (size_t)(wi * (wi + 1) / 2 + wj) * kSchurPitch;
             double *Sg = d.red + (size_t)(6 * ci) * n + 6 * cj;
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2) {
-                const double w0 = Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3];
-                const double w1 = Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4];
-                const double w2 = Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5];
-                const int ej = d.qexp[6 * cj + c2];
+                const int ej = -d.qexp[6 * cj + c2];
+                const double w0 = ldexp(Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3], ej);
+                const double w1 = ldexp(Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4], ej);
+                const double w2 = ldexp(Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5], ej);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
-                    const unsigned long long v = fx64(-(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2), ei[a] - ej);
+                    const unsigned long long v = fx64_scaled(-(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
                     atomicAdd(reinterpret_cast<unsigned long long *>(in_w ? &Sl[a * 6 + c2] : &Sg[(size_t)a * n + c2]), v);
                 }
             }
@@ -844,9 +878,9 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
     // flush the window
     const unsigned long long *sq = reinterpret_cast<const unsigned long long *>(sl);   // same grid per entry as d.red: integer adds
     for (int e = tid; e < kWinBlocks * 36; e += 1024) {
-        const unsigned long long v = sq[e];
-        if (v == 0ull) continue;
         const int blk = e / 36, r = e % 36;
+        const unsigned long long v = sq[blk * kSchurPitch + r];
+        if (v == 0ull) continue;
         int wi = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
         while ((wi + 1) * (wi + 2) / 2 <= blk) ++wi;
         while (wi * (wi + 1) / 2 > blk) --wi;
@@ -855,7 +889,7 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
         if (ci < d.n_cam) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6]), v);
     }
     for (int e = tid; e < 6 * kWinCams; e += 1024) {
-        const unsigned long long v = sq[kWinBlocks * 36 + e];
+        const unsigned long long v = sq[kWinBlocks * kSchurPitch + e];
         if (v != 0ull && cw + e / 6 < d.n_cam) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)n * n + 6 * cw + e]), v);
     }
 }
@@ -961,16 +995,17 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BADev d, const dou
     const unsigned long long *slabs = reinterpret_cast<const unsigned long long *>(slabs_f);
     const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
     const int grp = threadIdx.x / kRedEnt;
-    unsigned long long v0 = 0, v1 = 0;
+    unsigned long long v0 = 0;
     if (e < slab_doubles) {
-        int b = grp;
-        for (; b + kRedGrp < n_slabs; b += 2 * kRedGrp) {
-            v0 += slabs[(size_t)b * slab_doubles + e];
-            v1 += slabs[(size_t)(b + kRedGrp) * slab_doubles + e];
+        for (int b = grp; b < n_slabs; b += 8 * kRedGrp) {      // eight loads in flight per round
+            unsigned long long t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (b + u * kRedGrp < n_slabs) ? slabs[(size_t)(b + u * kRedGrp) * slab_doubles + e] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v0 += t[u];
         }
-        if (b < n_slabs) v0 += slabs[(size_t)b * slab_doubles + e];
     }
-    lds[threadIdx.x] = v0 + v1;
+    lds[threadIdx.x] = v0;
     __syncthreads();
     if (threadIdx.x >= kRedEnt || e >= slab_doubles) return;
     unsigned long long t = 0;
@@ -1220,168 +1255,135 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
     ba_camera_step_body(d, d.y_c, red);
 }
 
-// Back-substitution, point-parallel variant (one thread per point; fewer, fatter threads: faster below ~1M
-// observations, where the observation-parallel passes are launch/atomic bound): y_p = M^-1 (E'r - sum_i E_i'F_i y_c), step = -y, candidate point,
-// and this point's share of model_cost_change = -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).
-__global__ __launch_bounds__(64) void ba_backsub_point_kernel(BADev d, ScalBase sbase)
+// Back-substitution: y_p = M^-1 (E'r - sum_k E_k'F_k y_c), step = -y, candidate point, and the model cost change
+// -sum (J s).(r + J s / 2)  (trust_region_minimizer.cc).  One workgroup per point chunk (pchunk_pt0: consecutive points whose
+// observations -- contiguous in the point-sorted order -- number at most kPtChunkObs = 256, built once per problem):
+//   1. thread = observation: one coalesced read of its Jacobian rows (kept in registers), f = F_k y_c, t_k = E_k' f -> LDS;
+//   2. thread = point: adds its t_k in observation order, s_p = -M^-1 (E'r - sum t_k), candidate point, s_p -> LDS;
+//   3. thread = observation again: J s = -f + E_k s_p  (-(a + b) == (-a) + (-b) exactly), its share of the scalars.
+// No atomics, every sum in a fixed order.  (Round 1 had one thread per point walking its observations: 16 dependent memory round
+// trips on an 8-observation track, 43 us on the 25-camera problem; and, from 2^20 observations, two observation-parallel passes
+// joined by f64 atomics.)  A single point with more observations than a chunk holds gets a chunk of its own and loops.
+constexpr int kPtChunkObs = 256;
+
+__global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, ScalBase sbase)
 {
     __shared__ double red[8];
-    const int p = blockIdx.x * 64 + threadIdx.x;
+    __shared__ double tE[kPtChunkObs][3];
+    __shared__ double sps[kPtChunkObs][3];
+    const int tid = threadIdx.x;
+    const int p0 = d.pchunk_pt0[blockIdx.x], p1 = d.pchunk_pt0[blockIdx.x + 1];
+    const int k0 = d.pt_start[p0], k1 = d.pt_start[p1];
+    const int nobs = k1 - k0;
+    const size_t n = d.n_obs;
     double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0;
     double yk[4] = {0.0, 0.0, 0.0, 0.0};
     if (d.has_calib) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) yk[a] = d.y_c[6 * d.n_real_cam + a];
     }
-    if (p < d.n_pt) {
-        const int b = d.pt_start[p], e = d.pt_start[p + 1];
-        const size_t n = d.n_obs;
-        double xp[3] = {d.x_p[3 * (size_t)p], d.x_p[3 * (size_t)p + 1], d.x_p[3 * (size_t)p + 2]};
-        if (e > b) {
-            double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
-            // F_i y_c of the first kKeep observations stays in registers: the second pass below needs its negative
-            // (-(a + b) == (-a) + (-b) exactly), which saves re-reading the camera Jacobian
-            constexpr int kKeep = 8;
-            double keep0[kKeep], keep1[kKeep];
-            for (int k = b; k < e; ++k) {
-                const int c = d.obs_cam[k];
-                double f0 = 0.0, f1 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const double yc = d.y_c[6 * c + a];
-                    f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
-                }
-                if (d.has_calib) {
-                    f0 += d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
-                    f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
-                }
-#pragma unroll
-                for (int q = 0; q < kKeep; ++q) if (k - b == q) { keep0[q] = f0; keep1[q] = f1; }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) g[a] -= d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
-            }
-            const double *Mi = d.Minv + 6 * (size_t)p;
-            const double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]),
-                                  -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
-                                  -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
-            for (int k = b; k < e; ++k) {
-                double m0 = 0.0, m1 = 0.0;
-                if (k - b < kKeep) {
-#pragma unroll
-                    for (int q = 0; q < kKeep; ++q) if (k - b == q) { m0 = -keep0[q]; m1 = -keep1[q]; }
-                } else {
-                    const int c = d.obs_cam[k];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        const double sc = -d.y_c[6 * c + a];
-                        m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
-                    }
-                    if (d.has_calib) {
-                        m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
-                        m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
-                const double r0 = d.res[k], r1 = d.res[n + k];
-                mc -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
-                gd += m0 * r0 + m1 * r1;
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double dl = sp[a] * d.scale_p[3 * (size_t)p + a];
-                const double cnd = xp[a] + dl;
-                const double df = xp[a] - cnd;
-                ssq += df * df; csq += cnd * cnd;
-                d.cand_p[3 * (size_t)p + a] = cnd;
-                if (d.constrained) { d.delta_p[3 * (size_t)p + a] = dl; dmax = fmax(dmax, fabs(dl)); }
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                d.cand_p[3 * (size_t)p + a] = xp[a];
-                if (d.constrained) d.delta_p[3 * (size_t)p + a] = 0.0;
-            }
-        }
-    }
-    const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
-    const double vals[4] = {mc, ssq, csq, d.constrained ? gd : 0.0};
-    scal_commit<4>(d, sbase, slots, vals, red);
-    if (d.constrained) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
-        if ((threadIdx.x & 63) == 0 && dmax > 0.0) atomic_max_nonneg(&d.scal[SC_DMAX], dmax);
-    }
-}
-
-// Back-substitution, observation-parallel so that every J access is a coalesced SoA stream:
-//   pass 1 (ba_backsub_accum_kernel)  tE[k] = E_k' (F_k y_c)            3 coalesced stores per observation, no atomics
-//   pass 2 (ba_backsub_apply_kernel)  gE[p] = sum of tE over the point's (contiguous) observations, in order;
-//                                     s_p = -M^-1 (E'r - gE[p]) (recomputed per observation, cached loads),
-//                                     model_cost_change -= (J s).(r + J s / 2)  (trust_region_minimizer.cc),
-//                                     and the first observation of each point writes the candidate point.
-__global__ __launch_bounds__(256) void ba_backsub_accum_kernel(BADev d)
-{
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= d.n_obs) return;
-    const size_t n = d.n_obs;
-    const int c = d.obs_cam[k];
-    double f0 = 0.0, f1 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const double yc = d.y_c[6 * c + a];
-        f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc;
-    }
-    if (d.has_calib) {
-        const double *yk = d.y_c + 6 * d.n_real_cam;
-        f0 += d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
-        f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) d.tE[a * n + k] = d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
-}
-
-__global__ __launch_bounds__(256) void ba_backsub_apply_kernel(BADev d, ScalBase sbase)
-{
-    __shared__ double red[8];
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0;
-    if (k < d.n_obs) {
-        const size_t n = d.n_obs;
-        const int c = d.obs_cam[k], p = d.obs_pt[k];
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-        for (int j = d.pt_start[p]; j < d.pt_start[p + 1]; ++j) { t0 += d.tE[j]; t1 += d.tE[n + j]; t2 += d.tE[2 * n + j]; }
-        const double g0 = d.Etr[3 * (size_t)p] - t0, g1 = d.Etr[3 * (size_t)p + 1] - t1, g2 = d.Etr[3 * (size_t)p + 2] - t2;
+    auto point_step = [&](int p, const double g[3]) {       // s_p, candidate point, norms
         const double *Mi = d.Minv + 6 * (size_t)p;
-        const double sp[3] = {-(Mi[0] * g0 + Mi[1] * g1 + Mi[2] * g2), -(Mi[1] * g0 + Mi[3] * g1 + Mi[4] * g2),
-                              -(Mi[2] * g0 + Mi[4] * g1 + Mi[5] * g2)};
-        double m0 = 0.0, m1 = 0.0;
+        double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]), -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
+                        -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double sc = -d.y_c[6 * c + a];
-            m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc;
+        for (int a = 0; a < 3; ++a) {
+            const double xp = d.x_p[3 * (size_t)p + a];
+            const double dl = sp[a] * d.scale_p[3 * (size_t)p + a];
+            const double cnd = xp + dl;
+            const double df = xp - cnd;
+            ssq += df * df; csq += cnd * cnd;
+            d.cand_p[3 * (size_t)p + a] = cnd;
+            if (d.constrained) { d.delta_p[3 * (size_t)p + a] = dl; dmax = fmax(dmax, fabs(dl)); }
         }
-        if (d.has_calib) {
-            const double *yk = d.y_c + 6 * d.n_real_cam;
-            m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
-            m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
-        }
+        return std::array<double, 3>{sp[0], sp[1], sp[2]};
+    };
+    if (nobs <= kPtChunkObs) {
+        const bool has = tid < nobs;
+        const int k = k0 + (has ? tid : 0);
+        double Jp[6], f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
+        int pl = 0;
+        if (has) {
+            const int c = d.obs_cam[k];
+            pl = d.obs_pt[k] - p0;
+            double Jc[12], yc[6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sp[a]; m1 += d.Jp[(3 + a) * n + k] * sp[a]; }
-        const double r0 = d.res[k], r1 = d.res[n + k];
-        mc = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
-        gd = m0 * r0 + m1 * r1;
-        if (k == d.pt_start[p]) {   // one writer per point
+            for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n + k];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double xp = d.x_p[3 * (size_t)p + a];
-                const double dl = sp[a] * d.scale_p[3 * (size_t)p + a];
-                const double cnd = xp + dl;
-                const double df = xp - cnd;
-                ssq += df * df; csq += cnd * cnd;
-                d.cand_p[3 * (size_t)p + a] = cnd;
-                if (d.constrained) { d.delta_p[3 * (size_t)p + a] = dl; dmax = fmax(dmax, fabs(dl)); }
+            for (int a = 0; a < 6; ++a) { Jp[a] = d.Jp[a * n + k]; yc[a] = d.y_c[6 * c + a]; }
+            r0 = d.res[k]; r1 = d.res[n + k];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { f0 += Jc[a] * yc[a]; f1 += Jc[6 + a] * yc[a]; }
+            if (d.has_calib) {
+                f0 += d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+                f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
             }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) tE[tid][a] = Jp[a] * f0 + Jp[3 + a] * f1;
+        }
+        __syncthreads();
+        if (tid < p1 - p0) {
+            const int p = p0 + tid;
+            const int b = d.pt_start[p] - k0, e = d.pt_start[p + 1] - k0;
+            if (e > b) {
+                double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
+                for (int o = b; o < e; ++o) { g[0] -= tE[o][0]; g[1] -= tE[o][1]; g[2] -= tE[o][2]; }
+                const auto sp = point_step(p, g);
+                sps[tid][0] = sp[0]; sps[tid][1] = sp[1]; sps[tid][2] = sp[2];
+            } else {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    d.cand_p[3 * (size_t)p + a] = d.x_p[3 * (size_t)p + a];
+                    if (d.constrained) d.delta_p[3 * (size_t)p + a] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (has) {
+            double m0 = -f0, m1 = -f1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { m0 += Jp[a] * sps[pl][a]; m1 += Jp[3 + a] * sps[pl][a]; }
+            mc = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
+            gd = m0 * r0 + m1 * r1;
+        }
+    } else {
+        // one point, more observations than threads: strided passes, block-wide sums in a fixed tree
+        const int p = p0;
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int k = k0 + tid; k < k1; k += kPtChunkObs) {
+            const int c = d.obs_cam[k];
+            double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { const double yc = d.y_c[6 * c + a]; f0 += d.Jc[a * n + k] * yc; f1 += d.Jc[(6 + a) * n + k] * yc; }
+            if (d.has_calib) {
+                f0 += d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+                f1 += d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) t[a] += d.Jp[a * n + k] * f0 + d.Jp[(3 + a) * n + k] * f1;
+        }
+        double g[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] = d.Etr[3 * (size_t)p + a] - block_sum(t[a], red);
+        if (tid == 0) {
+            const auto sp = point_step(p, g);
+            sps[0][0] = sp[0]; sps[0][1] = sp[1]; sps[0][2] = sp[2];
+        }
+        __syncthreads();
+        for (int k = k0 + tid; k < k1; k += kPtChunkObs) {
+            const int c = d.obs_cam[k];
+            double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { const double sc = -d.y_c[6 * c + a]; m0 += d.Jc[a * n + k] * sc; m1 += d.Jc[(6 + a) * n + k] * sc; }
+            if (d.has_calib) {
+                m0 -= d.Jk[k] * yk[0] + d.Jk[n + k] * yk[1];
+                m1 -= d.Jk[2 * n + k] * yk[2] + d.Jk[3 * n + k] * yk[3];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { m0 += d.Jp[a * n + k] * sps[0][a]; m1 += d.Jp[(3 + a) * n + k] * sps[0][a]; }
+            const double r0 = d.res[k], r1 = d.res[n + k];
+            mc -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
+            gd += m0 * r0 + m1 * r1;
         }
     }
     const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
@@ -1646,12 +1648,13 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
     const bool finish = !d.has_calib;    // with free intrinsics ba_schur_calib adds its block row first, then converts
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
     const int slab_doubles = nblk * 36 + 6 * d.n_cam;
-    const size_t lds_bytes = sizeof(double) * (size_t)slab_doubles;
-    const int n_slabs = std::max(1, std::min(num_cu, div_up(d.n_obs, 1024)));
+    const size_t lds_bytes = sizeof(double) * ((size_t)nblk * kSchurPitch + 6 * (size_t)d.n_cam);
+    static const int schur_threads = [] { const char *e = getenv("ESFM_SCHUR_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
+    const int n_slabs = std::max(1, std::min(num_cu, div_up(d.n_obs, schur_threads)));
     if (lds_bytes <= 156 * 1024 && slabs && (size_t)n_slabs * slab_doubles <= slab_capacity_doubles) {
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_lds_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(1024), lds_bytes, st, d, slabs, slab_doubles, rhs_exp);
+        hipLaunchKernelGGL(ba_schur_lds_kernel, dim3(n_slabs), dim3(schur_threads), lds_bytes, st, d, slabs, slab_doubles, rhs_exp);
         LAUNCH_CHECK();
         if (finish) hipLaunchKernelGGL(ba_schur_reduce_kernel<true>, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs, rhs_exp);
         else hipLaunchKernelGGL(ba_schur_reduce_kernel<false>, dim3(div_up(slab_doubles, kRedEnt)), dim3(256), 0, st, d, slabs, slab_doubles, n_slabs, rhs_exp);
@@ -1659,7 +1662,7 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         return ESFM_OK;
     }
     if (d.n_chunks > 0 && d.slot_obs) {
-        constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * 36 + 6 * kWinCams);
+        constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * kSchurPitch + 6 * kWinCams);
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_window_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
         hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d, rhs_exp);
@@ -1691,11 +1694,10 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
 // Scalar read-back without a stream synchronisation: one workgroup adds the pending per-workgroup partials to the sum slots (see
 // scal_commit), copies the scalar slots into pinned host memory, fences to system scope and then stores the sequence number the
 // host is spinning on.
-__global__ __launch_bounds__(256) void ba_publish_scalars_kernel(const double *__restrict__ scal_part, int scal_cap, double *scal, ScalCounts c,
-                                                                 double *host, unsigned long long *flag, unsigned long long seq)
+__global__ __launch_bounds__(1024) void ba_publish_scalars_kernel(const double *__restrict__ scal_part, int scal_cap, double *scal, ScalCounts c,
+                                                                  double *host, unsigned long long *flag, unsigned long long seq)
 {
-    __shared__ double lds[8];
-    scal_reduce_pending(scal_part, scal_cap, scal, c, lds);
+    scal_reduce_pending(scal_part, scal_cap, scal, c);
     __syncthreads();
     const int i = threadIdx.x;
     if (i < SC_COUNT) host[i] = scal[i];
@@ -1713,7 +1715,7 @@ static ScalCounts take_counts(const BADev &d)
 
 int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq)
 {
-    hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(256), 0, st, d.scal_part, d.scal_cap, d.scal, take_counts(d), host, flag, seq);
+    hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(1024), 0, st, d.scal_part, d.scal_cap, d.scal, take_counts(d), host, flag, seq);
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1723,7 +1725,7 @@ int ba_scal_reduce(hipStream_t st, const BADev &d)
     bool any = false;
     for (int q = 0; q < SC_SUM_COUNT; ++q) any = any || d.parts->n[q] > 0;
     if (!any) return ESFM_OK;
-    hipLaunchKernelGGL(ba_scal_reduce_kernel, dim3(1), dim3(256), 0, st, d.scal_part, d.scal_cap, d.scal, take_counts(d));
+    hipLaunchKernelGGL(ba_scal_reduce_kernel, dim3(1), dim3(1024), 0, st, d.scal_part, d.scal_cap, d.scal, take_counts(d));
     LAUNCH_CHECK();
     return ESFM_OK;
 }
@@ -1743,22 +1745,11 @@ int ba_camera_step(hipStream_t st, const BADev &d)
 
 int ba_backsub(hipStream_t st, const BADev &d)
 {
-    if (d.n_pt <= 0) return ESFM_OK;
+    if (d.n_pt <= 0 || d.n_pchunks <= 0) return ESFM_OK;
     ScalBase sbase;
     const int bs_slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
-    if (d.n_obs < kBacksubPointMaxObs || !d.tE) {
-        if (int rc = scal_reserve<4>(st, d, bs_slots, div_up(d.n_pt, 64), sbase)) return rc;
-        hipLaunchKernelGGL(ba_backsub_point_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, sbase);
-        LAUNCH_CHECK();
-        return ESFM_OK;
-    }
-    // points without observations keep their value; observed ones are overwritten by pass 2
-    ESFM_HIP_TRY(hipMemcpyAsync(d.cand_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
-    if (d.n_obs <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(ba_backsub_accum_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d);
-    LAUNCH_CHECK();
-    if (int rc = scal_reserve<4>(st, d, bs_slots, div_up(d.n_obs, 256), sbase)) return rc;
-    hipLaunchKernelGGL(ba_backsub_apply_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, sbase);
+    if (int rc = scal_reserve<4>(st, d, bs_slots, d.n_pchunks, sbase)) return rc;
+    hipLaunchKernelGGL(ba_backsub_chunk_kernel, dim3(d.n_pchunks), dim3(kPtChunkObs), 0, st, d, sbase);
     LAUNCH_CHECK();
     return ESFM_OK;
 }

@@ -99,10 +99,11 @@ struct BADev {
     // (v + 1.5 2^k) - 1.5 2^k, was tried first: it costs 3 digits of the parameters).  Refreshed by ba_linearize from
     // this rank's observations.
     int32_t *qexp = nullptr;            // [6 n_cam]
-    double *tE = nullptr;               // [3][n_obs] E_k'(F_k y_c) per observation (back-substitution of problems >= 2^20 observations)
+    // point chunks of the back-substitution (and of the per-point normal blocks): consecutive points, <= 256 observations each
+    int32_t *pchunk_pt0 = nullptr;      // [n_pchunks + 1]
+    int n_pchunks = 0;
 };
 constexpr int kCamChunk = 256, kCamPart = 37;
-constexpr int kBacksubPointMaxObs = 1 << 20;   // below: one thread per point; from here on: observation-parallel two-pass
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
 inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
