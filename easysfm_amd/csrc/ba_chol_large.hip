@@ -1,21 +1,20 @@
-// Dense solve of the reduced camera system when it does not fit one workgroup's LDS (n = 6 n_cam > ~185;
-// BASELINE config 5: 512 cameras, n = 3072).  Blocked right-looking Cholesky on 64 x 64 f64 tiles across the
-// whole chip, the right-hand side carried as an extra block row (forward substitution for free), then a
-// blocked backward substitution.  This is DENSE_SCHUR's factorisation step (reference cpp_code/src/ba.cpp:201,
-// Ceres' Eigen LLT [upstream]) for large camera counts.
+// Dense solve of the reduced camera system: DENSE_SCHUR's factorisation step (reference cpp_code/src/ba.cpp:201, Ceres' Eigen
+// LLT [upstream]).
 //
+// n = 6 n_cam > 176 (BASELINE config 5: 512 cameras, n = 3072): blocked right-looking Cholesky on 64 x 64 f64 tiles across the
+// whole chip, the right-hand side carried as an extra block row (forward substitution for free), then the backward substitution.
 //   chol_assemble_kernel   W = F'F + D_c^2 + S_schur (lower), rhs row = F'r + rhs_corr, identity padding
-//   chol_potrf0_kernel     factor of the first diagonal tile (one wave)
-//   chol_trsm_kernel(k)    X_ik = A_ik L_kk^-T for the tiles below the diagonal one (one wave per tile, rhs block row included)
-//   chol_update_kernel(k)  trailing update C_ij -= X_ik X_jk' for k < j <= i on v_mfma_f64_16x16x4_f64; the workgroup that
-//                          finishes tile (k+1, k+1) factors it in the same launch (one wave, no barrier in the factorisation)
-//   chol_back_kernel(k)    y_k = L_kk^-T z_k (redundantly per workgroup), z_b -= L_kb' y_k for b < k
+//   chol2_step_kernel(k)   ONE launch per block column: trailing update C_ij -= X_ik X_jk' on v_mfma_f64_16x16x4_f64; its first
+//                          workgroup factors the next diagonal tile (tile_potrf64) and inverts the factor (inv64); the workgroups
+//                          of the next block column wait for that inverse and turn their tiles into factor tiles X_i,k+1
+//   chol2_back_kernel      the whole backward substitution in one launch, solution blocks handed on through flags in memory
+// n <= 176 (BASELINE's BA-25: n = 150): ba_chol_small_kernel, the whole solve and the camera step in one workgroup.
+// Both sit on potrf16_fused_*: one wave factors a 16 x 16 block and inverts the factor in one pass of generated, scheduled asm.
 #include "ba_kernels.hpp"
 
 namespace esfm {
 
 constexpr int CB = 64;          // tile edge
-constexpr int CLD = CB + 1;     // LDS leading dimension of the back-substitution's tile (f64, odd: conflict-free column access)
 
 __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__restrict__ W, int ld, int nb, double radius,
                                                             double min_diag, double max_diag)
@@ -45,37 +44,18 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
 
 // ---------------------------------------------------------------------------------------------
 // 64 x 64 tile kernels built from 16 x 16 sub-blocks on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
-// A[l & 15][l >> 4] and B[l >> 4][l & 15]; its four results are D[(l >> 4) + 4 g][l & 15]).  Everything is a short loop:
-// round 1 ran the tile factorisation with 256 threads between barriers out of LDS (45 us per block column); two one-wave
-// rewrites measured this round were no better -- tile in LDS: 40 us (36 dependent ds_read_b64 per 32 FMAs); tile in
-// registers, fully unrolled: 78 us (25 KB of straight-line code executed once per launch: instruction fetch).
-//   P Q^T accumulate:  acc += sign * P (16 x 16, row-major in LDS) * Q^T (Q 16 x 16 row-major in LDS)  -- 4 MFMAs
-//   potrf16_inv:       one wave factors a 16 x 16 diagonal sub-block in registers (lane = row, v_readlane broadcasts) and
-//                      inverts the factor (lane = column of the inverse), ~500 instructions
-//   tile_potrf64:      4 sub-block steps: potrf16_inv, panel X = A Linv^T (MFMA), trailing update (MFMA); 3 barriers each
-//   strip_trsm64:      one wave solves its 16-row strip of X = A L^-T: per sub-block  acc = A_b - sum X_b' L_bb'^T,
-//                      X_b = acc Linv_bb^T, all MFMA, re-laid out through the wave's own LDS rows (no workgroup barrier)
+// A[l & 15][l >> 4] and B[l >> 4][l & 15]; its four results are D[(l >> 4) + 4 g][l & 15]).
+//   pqt16 / pq16:      acc += sign * P Q' / P Q  for 16 x 16 row-major blocks in LDS  -- 4 MFMAs
+//   tile_potrf64:      4 sub-block steps: potrf16_fused_full, panel X = A Linv' (MFMA), trailing update (MFMA)
+//   inv64:             the inverse of the factored tile from its sub-block inverses
+// History of the diagonal-block factorisation, per 16 x 16 block: 256 threads out of LDS between barriers (round 1): 11 us; one
+// wave, block in registers, v_readlane broadcasts, factor then invert: 4 us; one pass of scheduled asm with DPP broadcasts: 1.5 us.
 constexpr int SB = 16;                  // sub-block edge
 constexpr int ULD = CB + 2;             // LDS leading dimension of MFMA operand tiles: 32 lanes, 32 distinct 8-byte bank pairs
 constexpr int VLD = SB + 2;             // the same for a 16 x 16 block
-constexpr int LSLOT = CB * CB + CB + 4 * SB * SB;   // per diagonal tile in Ldiag: L, 1 / diag(L), inverses of its four sub-blocks
+constexpr int LSLOT = CB * CB;          // per diagonal tile in Ldiag: the inverse of its factor (64 x 64, row-major)
+constexpr int LINV_OFF = 0;
 typedef double doublex4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double lane_value_f64(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
-// 1 / sqrt(x) for the pivots: the hardware seed (v_rsq_f64, ~2^-26) and two Newton steps in f64 -- a short dependent chain; the
-// library rsqrt's longer one sits on the critical path of every one of the n pivots (dependent f64 operations cost ~16 cycles each)
-__device__ __forceinline__ double rsqrt_pivot(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = y * fma(-h, y * y, 1.5);
-    y = y * fma(-h, y * y, 1.5);
-    return y;
-}
 
 __device__ __forceinline__ doublex4 pqt16(doublex4 acc, const double *P, int ldp, const double *Q, int ldq, double sign, int lane)
 {
@@ -98,60 +78,46 @@ __device__ __forceinline__ void store_d16(double *B, int ld, doublex4 v, int lan
     for (int g = 0; g < 4; ++g) B[((lane >> 4) + 4 * g) * ld + (lane & 15)] = v[g];
 }
 
-// One wave: Cholesky factor of the 16 x 16 block D (LDS, row-major ldd) written back in place (upper part zeroed), the
-// inverse of the factor to Vi (row-major VLD) and the reciprocal diagonal to rd[0..16).  Lane r (and r + 16, r + 32, r + 48,
-// redundantly) holds row r in registers; the pivot and the column below it reach the other lanes through v_readlane -- per
-// pivot: readlane, 1 / sqrt, scale, readlane, FMA, ~200 dependent cycles.  (A version that kept the block in LDS and published
-// column and row through it measured 675 cycles per pivot, 10.0k per block against 5.0k for this one:
-// scratch/ubench/potrf_bench.hip.)  The inverse is formed right-looking too (lane = column of the inverse): no serial FMA chain.
-template <bool WRITE_L = true>
-__device__ __forceinline__ void potrf16_inv(double *D, int ldd, double *Vi, double *rd, int *fail, int lane)
+// One wave: the 16 x 16 block D (LDS, row-major VLD) is replaced by the INVERSE of its Cholesky factor (above the diagonal: +-0).
+// Lane r (and r + 16, ... redundantly) holds row r of the block in x and solves L y = e_r in t.  Factorisation and inversion are
+// both right-looking and share every broadcast: once column c is final, lane i's L[i][c] (DPP row_newbcast) updates column i of
+// the block (x[i] -= L[r][c] L[i][c]) AND row i of the inverse (t[i] -= L[i][c] t[c]).  The whole thing is one generated asm
+// block (gen_potrf16_asm.py -> potrf16_gfx950.inc, ~740 instructions): the pivots are a serial chain (broadcast, v_rsq_f64, one
+// Newton step, scale) and the updates have to be issued in the shadow of its latencies, which hipcc does not do -- measured per
+// 16 x 16 block at n = 150: factor then invert, v_readlane broadcasts: 9.7k cycles; fused, v_readlane: 8.4k (the compiler parks
+// 30 scalars per pivot in VGPR lanes, v_writelane + s_nop); fused, DPP from C++: spills to scratch; this one: see DESIGN.md.
+#include "potrf16_gfx950.inc"
+__device__ __forceinline__ void potrf16_fused_inv(double *D, int *fail, int lane)
 {
     const int r = lane & 15;
-    double x[SB];
-#pragma unroll
-    for (int c = 0; c < SB; ++c) x[c] = D[r * ldd + c];
-    double my_rd = 1.0;
-#pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        const double piv = lane_value_f64(x[c], c);
-        if (!(piv > 0.0) || !isfinite(piv)) { if (lane == 0) *fail = 1; }
-        const double rinv = rsqrt_pivot(piv > 0.0 ? piv : 1.0);
-        x[c] = (r == c) ? piv * rinv : x[c] * rinv;
-        if (r == c) my_rd = rinv;
-#pragma unroll
-        for (int c2 = c + 1; c2 < SB; ++c2) x[c2] -= x[c] * lane_value_f64(x[c], c2);   // rows above the diagonal: garbage, never read
-    }
-    // inverse: lane r solves L y = e_r.  t starts as e_r; step k fixes y_k = t_k / L_kk and eliminates it from the rows below.
-    double t[SB];
-#pragma unroll
-    for (int i = 0; i < SB; ++i) t[i] = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < SB; ++k) {
-        t[k] *= lane_value_f64(my_rd, k);
-#pragma unroll
-        for (int i = k + 1; i < SB; ++i) t[i] -= lane_value_f64(x[k], i) * t[k];      // L[i][k] = row i's x[k]
-    }
-    if (lane < SB) {
-        if (WRITE_L) {
-#pragma unroll
-            for (int c = 0; c < SB; ++c) D[r * ldd + c] = (c <= r) ? x[c] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < SB; ++i) Vi[i * VLD + r] = (i >= r) ? t[i] : 0.0;       // (WRITE_L false: Vi may be D itself)
-        rd[r] = my_rd;
-    }
+    const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * VLD), col_addr = (uint32_t)(uintptr_t)(D + r);
+    int bad;
+    asm volatile(ESFM_POTRF16_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr), "v"(lane) : ESFM_POTRF16_CLOBBERS);
+    if (__any(bad) && lane == 0) *fail = 1;
+}
+
+// The same for the 64 x 64 tile factorisation: D (row pitch ldd doubles) keeps the factor (upper part zeroed), the inverse goes
+// to Vi (row-major VLD) and the reciprocal diagonal to rd[0..16).
+__device__ __forceinline__ void potrf16_fused_full(double *D, int ldd, double *Vi, double *rd, int *fail, int lane)
+{
+    const int r = lane & 15;
+    const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * ldd), col_addr = (uint32_t)(uintptr_t)(Vi + r), rd_addr = (uint32_t)(uintptr_t)rd;
+    int bad;
+    asm volatile(ESFM_POTRF16_FULL_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr), "v"(lane), "v"(rd_addr) : ESFM_POTRF16_CLOBBERS);
+    if (__any(bad) && lane == 0) *fail = 1;
 }
 
 // 256 threads: in-place Cholesky of the 64 x 64 tile T (LDS, row-major ULD; upper part must be zero).  Vi: 4 blocks of
-// 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.
+// 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.  Sub-block column b: panel X_i = A_i Linv_bb'
+// (waves b+1 .. 3), then the trailing update -- during which wave 0 updates sub-block (b+1, b+1) first and factors it at once
+// (look-ahead: the next pivot chain runs while the other waves finish the update); two barriers per sub-block column.
 __device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, int *fail)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) potrf16_fused_full(T, ULD, Vi, rd, fail, lane);
+    __syncthreads();
 #pragma unroll 1
-    for (int b = 0; b < 4; ++b) {
-        if (wave == 0) potrf16_inv(T + (SB * b) * ULD + SB * b, ULD, Vi + b * SB * VLD, rd + SB * b, fail, lane);
-        __syncthreads();
+    for (int b = 0; b < 3; ++b) {
         // panel: strips i = b+1 .. 3:  X_i = A_i Linv_bb^T   (A_i is read whole before it is overwritten: one wave per strip)
         if (wave > b) {
             const int i = wave;
@@ -160,190 +126,266 @@ __device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, 
             store_d16(T + (SB * i) * ULD + SB * b, ULD, acc, lane);
         }
         __syncthreads();
-        // trailing update: blocks (i, j), b < j <= i <= 3, one per wave and round
-        int idx = 0;
-        for (int i = b + 1; i < 4; ++i)
-            for (int j = b + 1; j <= i; ++j, ++idx)
-                if ((idx & 3) == wave) {
-                    doublex4 acc = load_d16(T + (SB * i) * ULD + SB * j, ULD, lane);
-                    acc = pqt16(acc, T + (SB * i) * ULD + SB * b, ULD, T + (SB * j) * ULD + SB * b, ULD, -1.0, lane);
-                    store_d16(T + (SB * i) * ULD + SB * j, ULD, acc, lane);
+        // trailing update: blocks (i, j), b < j <= i <= 3; wave 0 takes (b+1, b+1) and goes on to factor it
+        if (wave == 0) {
+            const int i = b + 1;
+            doublex4 acc = load_d16(T + (SB * i) * ULD + SB * i, ULD, lane);
+            acc = pqt16(acc, T + (SB * i) * ULD + SB * b, ULD, T + (SB * i) * ULD + SB * b, ULD, -1.0, lane);
+            store_d16(T + (SB * i) * ULD + SB * i, ULD, acc, lane);
+            __builtin_amdgcn_wave_barrier();
+            potrf16_fused_full(T + (SB * i) * ULD + SB * i, ULD, Vi + i * SB * VLD, rd + SB * i, fail, lane);
+        } else {
+            int idx = 0;
+            for (int i = b + 1; i < 4; ++i)
+                for (int j = b + 1; j <= i; ++j) {
+                    if (i == b + 1 && j == b + 1) continue;
+                    if (idx++ % 3 == wave - 1) {
+                        doublex4 acc = load_d16(T + (SB * i) * ULD + SB * j, ULD, lane);
+                        acc = pqt16(acc, T + (SB * i) * ULD + SB * b, ULD, T + (SB * j) * ULD + SB * b, ULD, -1.0, lane);
+                        store_d16(T + (SB * i) * ULD + SB * j, ULD, acc, lane);
+                    }
                 }
+        }
         __syncthreads();
     }
 }
 
-// One wave: X = A L^-T for its 16-row strip S (LDS, 16 x 64, row-major ULD, in place).  L: the factored 64 x 64 tile (LDS,
-// ULD), Vi: the inverses of its diagonal sub-blocks.  scratch: 16 x VLD doubles private to the wave.
-__device__ __forceinline__ void strip_trsm64(double *S, const double *L, const double *Vi, double *scratch, int lane)
+// ---------------------------------------------------------------------------------------------
+// Second generation of the large solve (this round): ONE launch per block column and ONE for the whole backward substitution.
+//   * the workgroup that factors a diagonal tile also inverts the factor (inv64: the four 16 x 16 sub-block inverses are there
+//     already; the six blocks below them are products), so "X_ik = A_ik L_kk^-T" is a dense product with L_kk^-1 and needs no
+//     triangular sweep -- every trailing-update workgroup forms the X_ik, X_jk it needs itself (3 tile products instead of 1:
+//     the matrix cores are idle anyway, the launch and the sweep were what cost 11 us per block column);
+//   * the factor tiles X_ik go to a second matrix W2 (the update workgroups of the same launch still read A_ik from W);
+//   * the backward substitution is one launch of nb workgroups that hand the solution blocks on through flags in memory:
+//     workgroup b folds  z_b -= L_ib' y_i  for i = nb-1 .. b+1 as the y_i appear, then publishes  y_b = L_bb^-T z_b.
+//     Workgroup b has blockIdx nb-1-b: it only ever waits for workgroups dispatched before it, so the chain cannot deadlock
+//     whatever part of the grid is resident.  (48 launches of 16 us before.)
+__device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp, const double *Q, int ldq, double sign, int lane)
 {
-    for (int b = 0; b < 4; ++b) {
-        doublex4 acc = load_d16(S + SB * b, ULD, lane);
-        for (int bp = 0; bp < b; ++bp) acc = pqt16(acc, S + SB * bp, ULD, L + (SB * b) * ULD + SB * bp, ULD, -1.0, lane);
-        store_d16(scratch, VLD, acc, lane);
-        __builtin_amdgcn_wave_barrier();
-        acc = pqt16(doublex4{0.0, 0.0, 0.0, 0.0}, scratch, VLD, Vi + b * SB * VLD, VLD, 1.0, lane);
-        __builtin_amdgcn_wave_barrier();
-        store_d16(S + SB * b, ULD, acc, lane);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// publish a factored tile: L (row-major 64 x 64, upper part zero), reciprocal diagonal, sub-block inverses
-__device__ __forceinline__ void publish_diag(double *__restrict__ Ld, const double *T, const double *Vi, const double *rd)
-{
-    const int tid = threadIdx.x;
-    for (int e = tid; e < CB * CB; e += 256) Ld[e] = T[(e / CB) * ULD + (e % CB)];
-    if (tid < CB) Ld[CB * CB + tid] = rd[tid];
-    for (int e = tid; e < 4 * SB * SB; e += 256) Ld[CB * CB + CB + e] = Vi[(e / SB) * VLD + (e % SB)];
-}
-
-// Factor of the FIRST diagonal tile (the others are factored by the trailing update that finishes them).
-// Ldiag: LSLOT doubles per diagonal tile, read by the TRSM and back-substitution launches.
-__global__ __launch_bounds__(256) void chol_potrf0_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, double *__restrict__ scal)
-{
-    __shared__ double T[CB * ULD];
-    __shared__ double Vi[4 * SB * VLD];
-    __shared__ double rd[CB];
-    __shared__ int fail;
-    const int tid = threadIdx.x;
-    if (tid == 0) fail = 0;
-    for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; T[r * ULD + c] = (c <= r) ? W[(size_t)r * ld + c] : 0.0; }
-    __syncthreads();
-    tile_potrf64(T, Vi, rd, &fail);
-    publish_diag(Ldiag, T, Vi, rd);
-    if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
-}
-
-// X_ik = A_ik L_kk^-T for the block rows i = k + 1 .. nb (nb = right-hand-side block row): one workgroup per tile, one wave
-// per 16-row strip.
-__global__ __launch_bounds__(256) void chol_trsm_kernel(double *__restrict__ W, const double *__restrict__ Ldiag, int ld, int k)
-{
-    __shared__ double L[CB * ULD];
-    __shared__ double T[CB * ULD];
-    __shared__ double Vi[4 * SB * VLD];
-    __shared__ double scratch[4][SB * VLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bi = k + 1 + blockIdx.x;
-    const double *__restrict__ Lk = Ldiag + (size_t)k * LSLOT;
-    for (int e = tid; e < CB * CB; e += 256) {
-        const int r = e / CB, c = e % CB;
-        L[r * ULD + c] = Lk[e];
-        T[r * ULD + c] = W[(size_t)(bi * CB + r) * ld + k * CB + c];
-    }
-    for (int e = tid; e < 4 * SB * SB; e += 256) Vi[(e / SB) * VLD + (e % SB)] = Lk[CB * CB + CB + e];
-    __syncthreads();
-    strip_trsm64(T + (SB * wave) * ULD, L, Vi, scratch[wave], lane);
-    __syncthreads();
-    for (int e = tid; e < CB * CB; e += 256) W[(size_t)(bi * CB + e / CB) * ld + k * CB + (e % CB)] = T[(e / CB) * ULD + (e % CB)];
-}
-
-// Trailing update C_ij -= X_ik X_jk' for the tiles k < j <= i <= nb (j <= nb - 1) on the f64 matrix cores: wave w of the
-// workgroup owns rows [16 w, 16 w + 16) of the tile, four 16 x 16 outputs, K = 64 in 16 steps.  The workgroup that finishes the
-// NEXT diagonal tile (k + 1, k + 1) factors it on the spot (tile_potrf64) and publishes it, so the factorisation never costs a
-// launch of its own.
-__global__ __launch_bounds__(256) void chol_update_kernel(double *__restrict__ W, double *__restrict__ Ldiag, int ld, int nb, int k,
-                                                          double *__restrict__ scal)
-{
-    __shared__ double Ai[CB * ULD];
-    __shared__ double Aj[CB * ULD];
-    __shared__ double Vi[4 * SB * VLD];
-    __shared__ double rd[CB];
-    __shared__ int fail;
-    // linear tile id -> (i, j): tiles of block row i (k+1 .. nb) are j = k+1 .. min(i, nb-1)
-    const int m = nb - k - 1;  // square trailing block rows
-    int t = blockIdx.x, i, j;
-    const int tri = m * (m + 1) / 2;
-    if (t < tri) {
-        int ri = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((ri + 1) * (ri + 2) / 2 <= t) ++ri;
-        while (ri * (ri + 1) / 2 > t) --ri;
-        i = k + 1 + ri; j = k + 1 + (t - ri * (ri + 1) / 2);
-    } else {
-        i = nb; j = k + 1 + (t - tri);
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < CB * CB; e += 256) {
-        const int r = e / CB, c = e % CB;
-        Ai[r * ULD + c] = W[(size_t)(i * CB + r) * ld + k * CB + c];
-        Aj[r * ULD + c] = W[(size_t)(j * CB + r) * ld + k * CB + c];
-    }
-    if (tid == 0) fail = 0;
-    __syncthreads();
-    doublex4 acc[4];
+    // acc += sign * P (16 x 16 row-major) * Q (16 x 16 row-major)
+    const double *pp = P + (lane & 15) * ldp + (lane >> 4), *qp = Q + (lane >> 4) * ldq + (lane & 15);
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) acc[cb] = doublex4{0.0, 0.0, 0.0, 0.0};
-    const double *ap = Ai + (16 * wave + (lane & 15)) * ULD + (lane >> 4);
-    const double *bp = Aj + (lane & 15) * ULD + (lane >> 4);
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * pp[4 * kk], qp[4 * kk * ldq], acc, 0, 0, 0);
+    return acc;
+}
+
+// 256 threads: O (LDS, 64 x 64, row-major ULD) = inverse of the lower-triangular factor T (LDS, ULD) whose diagonal sub-block
+// inverses are in Vi.  Wave j computes block column j:  O_jj = Vi_j,  O_ij = -Vi_i (sum_{m=j}^{i-1} T_im O_mj)  for i > j.
+__device__ __forceinline__ void inv64(double *O, const double *T, const double *Vi, double (*scratch)[SB * VLD])
+{
+    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
+    for (int e = lane; e < SB * CB; e += 64) {          // this wave's block column: zero above the diagonal block, Vi_j on it
+        const int r = e / SB, c = e % SB;
+        O[r * ULD + SB * j + c] = (r >= SB * j && r < SB * (j + 1)) ? Vi[j * SB * VLD + (r - SB * j) * VLD + c] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = j + 1; i < 4; ++i) {
+        doublex4 acc = doublex4{0.0, 0.0, 0.0, 0.0};
+        for (int m = j; m < i; ++m) acc = pq16(acc, T + (SB * i) * ULD + SB * m, ULD, O + (SB * m) * ULD + SB * j, ULD, 1.0, lane);
+        store_d16(scratch[j], VLD, acc, lane);
+        __builtin_amdgcn_wave_barrier();
+        acc = pq16(doublex4{0.0, 0.0, 0.0, 0.0}, Vi + i * SB * VLD, VLD, scratch[j], VLD, -1.0, lane);
+        __builtin_amdgcn_wave_barrier();
+        store_d16(O + (SB * i) * ULD + SB * j, ULD, acc, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// (only the inverse of the factor is read again -- by the next block column's workgroups and by the backward substitution)
+__device__ __forceinline__ void publish_diag2(double *__restrict__ Ld, const double *O)
+{
+    for (int e = threadIdx.x; e < CB * CB; e += 256) Ld[LINV_OFF + e] = O[(e / CB) * ULD + (e % CB)];
+}
+
+// this wave's 16-row strip of  P (64 x 64, LDS ULD) * Q' (Q 64 x 64, LDS ULD): four 16 x 16 outputs, K = 64
+template <bool NEGATE = false>
+__device__ __forceinline__ void strip_pqt64(doublex4 (&acc)[4], const double *P, const double *Q, int wave, int lane)
+{
+    const double *ap = P + (16 * wave + (lane & 15)) * ULD + (lane >> 4);
+    const double *bp = Q + (lane & 15) * ULD + (lane >> 4);
 #pragma unroll 4
     for (int kk = 0; kk < CB / 4; ++kk) {
-        const double a = ap[4 * kk];
+        const double a = NEGATE ? -ap[4 * kk] : ap[4 * kk];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[16 * cb * ULD + 4 * kk], acc[cb], 0, 0, 0);
     }
-    const bool next_diag = (i == k + 1 && j == k + 1);
-    if (!next_diag) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-                if (i != j || c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] -= acc[cb][g];
-            }
-        return;
+}
+
+// Block column k in one launch (k = -1: the first one, nothing to subtract yet).  Workgroup (i, j), k < j <= i <= nb (block row
+// nb = the right-hand side; j <= nb - 1), reads the factor tiles X_ik, X_jk from W2 and forms  C_ij - X_ik X_jk'.  Then
+//   (k+1, k+1), blockIdx 0:  finishes the next diagonal tile in LDS, factors it, inverts the factor, publishes both, raises
+//                            ready[k+1];
+//   (i, k+1), i > k+1:       its tile is the final A_i,k+1: it waits for ready[k+1] (blockIdx 0 was dispatched before it, so the
+//                            wait cannot deadlock), multiplies by L_k+1,k+1^-T and stores the factor tile X_i,k+1 to W2 -- the
+//                            "triangular solve" of the next block column rides in the tail of this launch;
+//   everything else:         writes C_ij back to W.
+__global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W, double *__restrict__ W2, double *__restrict__ Ldiag, int ld, int nb,
+                                                         int k, int *__restrict__ ready, double *__restrict__ scal)
+{
+    __shared__ double Xi[CB * ULD];
+    __shared__ double Xj[CB * ULD];
+    __shared__ double Vi[4 * SB * VLD];
+    __shared__ double scratch[4][SB * VLD];
+    __shared__ double rd[CB];
+    __shared__ int fail;
+    const int m = nb - k - 1;  // square trailing block rows
+    int t = blockIdx.x, i, j;
+    // tile order: block column k + 1 first (its workgroups end with a wait and a second product: they must not be dispatched in the
+    // last round), i = k+1 .. nb; then the rest of the trailing triangle row by row, then the rest of the right-hand side's row
+    if (k < 0) { i = t; j = 0; }                        // the first launch only has block column 0 to do
+    else if (t <= m) { i = k + 1 + t; j = k + 1; }
+    else {
+        t -= m + 1;
+        const int tri = (m - 1) * m / 2;                // tiles (i, j), k + 2 <= j <= i <= nb - 1
+        if (t < tri) {
+            int ri = 0, rj = t;
+            while (rj > ri) { rj -= ri + 1; ++ri; }
+            i = k + 2 + ri; j = k + 2 + rj;
+        } else {
+            i = nb; j = k + 2 + (t - tri);
+        }
     }
-    // the next diagonal tile: finish it in LDS (Ai is free once every wave is past its MFMAs), factor, publish
-    __syncthreads();
-    double *T = Ai;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // C = A_ij - X_i X_j' in the D layout (this wave: rows 16 wave + (lane >> 4) + 4 g, columns 16 cb + (lane & 15)): the
+    // accumulators start from A_ij -- its loads are in flight together with the X tiles' -- and the product is subtracted
+    doublex4 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-            T[r * ULD + c] = (c <= r) ? W[(size_t)(i * CB + r) * ld + j * CB + c] - acc[cb][g] : 0.0;
+            acc[cb][g] = (i != j || c <= r) ? W[(size_t)(i * CB + r) * ld + j * CB + c] : 0.0;
         }
+    if (tid == 0) fail = 0;
+    if (k >= 0) {
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e / CB, c = e % CB;
+            Xi[r * ULD + c] = W2[(size_t)(i * CB + r) * ld + k * CB + c];
+            if (j != i) Xj[r * ULD + c] = W2[(size_t)(j * CB + r) * ld + k * CB + c];
+        }
+        __syncthreads();
+        strip_pqt64<true>(acc, Xi, (j != i) ? Xj : Xi, wave, lane);
+        if (i == j) {                // (the part above the diagonal of a diagonal tile is not stored)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+                    if (c > r) acc[cb][g] = 0.0;
+                }
+        }
+    }
+    if (j != k + 1) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+                if (i != j || c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] = acc[cb][g];
+            }
+        return;
+    }
+    __syncthreads();                 // every wave is past its reads of Xi / Xj
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
+    if (i == k + 1) {
+        // the next diagonal tile: factor, invert, publish
+        __syncthreads();
+        tile_potrf64(Xi, Vi, rd, &fail);
+        inv64(Xj, Xi, Vi, scratch);
+        __syncthreads();
+        publish_diag2(Ldiag + (size_t)(k + 1) * LSLOT, Xj);
+        if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&ready[k + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // a tile of the next block column: X_i,k+1 = C L_k+1,k+1^-T once the inverse is there
+    if (tid == 0) {
+        long spins = 0;
+        // relaxed polls (an acquire per poll invalidates caches the other workgroups are working from), one acquire at the end
+        while (__hip_atomic_load(&ready[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1L << 22)) { scal[SC_CHOL_FAIL] = 1.0; break; }     // never seen; keeps a broken launch from hanging the device
+        }
+    }
     __syncthreads();
-    tile_potrf64(T, Vi, rd, &fail);
-    publish_diag(Ldiag + (size_t)(k + 1) * LSLOT, T, Vi, rd);
-    for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; if (c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] = T[r * ULD + c]; }
-    if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    {
+        const double *Lk = Ldiag + (size_t)(k + 1) * LSLOT + LINV_OFF;
+        for (int e = tid; e < CB * CB; e += 256) Xj[(e / CB) * ULD + (e % CB)] = Lk[e];
+    }
+    __syncthreads();
+    doublex4 x[4] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
+    strip_pqt64<false>(x, Xi, Xj, wave, lane);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+            W2[(size_t)(i * CB + r) * ld + (k + 1) * CB + c] = x[cb][g];
+        }
 }
 
-// Backward substitution step k: z = rhs row (row nb*CB of W).  Every workgroup solves L_kk' y_k = z_k (one wave),
-// workgroup b < k then applies z_b -= L_kb' y_k; workgroup k stores y_k.
-__global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, const double *__restrict__ Ldiag, int ld, int nb, int k)
+// The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles; flags: nb ints,
+// zeroed before the launch.
+__global__ __launch_bounds__(256) void chol2_back_kernel(BADev d, const double *__restrict__ W2, const double *__restrict__ Ldiag, int ld, int nb,
+                                                         double *__restrict__ ybuf, int *__restrict__ flags)
 {
-    __shared__ double Lkk[CB * CLD];
+    __shared__ double z[CB];
     __shared__ double y[CB];
-    __shared__ double rd[CB];
-    const int tid = threadIdx.x;
-    double *z = W + (size_t)nb * CB * ld;
-    for (int e = tid; e < CB * CB; e += 256) {
-        const int r = e / CB, c = e % CB;
-        Lkk[r * CLD + c] = Ldiag[(size_t)k * LSLOT + e];
-    }
-    if (tid < CB) rd[tid] = Ldiag[(size_t)k * LSLOT + CB * CB + tid];
-    __syncthreads();
-    if (tid < CB) {  // one wave; lane = row index, its y value lives in a register
-        double yl = z[k * CB + tid];
-        for (int c = CB - 1; c >= 0; --c) {
-            const double yc = __shfl(yl, c) * rd[c];
-            if (tid == c) yl = yc;
-            if (tid < c) yl -= Lkk[c * CLD + tid] * yc;
-        }
-        y[tid] = yl;
-    }
-    __syncthreads();
-    const int b = blockIdx.x;
-    if (b == k) { if (tid < CB) z[k * CB + tid] = y[tid]; return; }
-    // z_b[t] -= sum_r L[k*CB + r][b*CB + t] * y[r]; 4 row-groups per column, reduced through LDS
     __shared__ double part[4][CB];
-    const int t = tid & 63, g = tid >> 6;
-    double s = 0.0;
-    for (int r = g; r < CB; r += 4) s += W[(size_t)(k * CB + r) * ld + b * CB + t] * y[r];
-    part[g][t] = s;
+    __shared__ int gave_up;
+    const int tid = threadIdx.x, t = tid & 63, g = tid >> 6;
+    const int b = nb - 1 - (int)blockIdx.x;
+    if (tid < CB) z[tid] = W2[(size_t)nb * CB * ld + b * CB + tid];
+    if (tid == 0) gave_up = 0;
     __syncthreads();
-    if (tid < CB) z[b * CB + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    for (int i = nb - 1; i > b; --i) {
+        // the tile's loads are in flight while the workgroup waits for y_i
+        double l[CB / 4];
+#pragma unroll
+        for (int q = 0; q < CB / 4; ++q) l[q] = W2[(size_t)(i * CB + g + 4 * q) * ld + b * CB + t];
+        if (tid == 0) {
+            long spins = 0;
+            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1L << 24)) { gave_up = 1; break; }        // never seen; keeps a broken launch from hanging the device
+            }
+        }
+        __syncthreads();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (tid < CB) y[tid] = ybuf[i * CB + tid];
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < CB / 4; ++q) s = fma(l[q], y[g + 4 * q], s);
+        part[g][t] = s;
+        __syncthreads();
+        if (tid < CB) z[tid] -= ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+        __syncthreads();
+    }
+    // y_b = Linv_bb' z_b
+    {
+        const double *Lb = Ldiag + (size_t)b * LSLOT + LINV_OFF;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < CB / 4; ++q) { const int r = g + 4 * q; s = fma(Lb[r * CB + t], z[r], s); }
+        part[g][t] = s;
+        __syncthreads();
+        if (tid < CB) {
+            const double yb = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+            ybuf[b * CB + tid] = yb;
+            const bool fail = d.scal[SC_CHOL_FAIL] != 0.0 || gave_up;
+            if (b * CB + tid < 6 * d.n_cam) d.y_c[b * CB + tid] = fail ? 0.0 : yb;
+            if (gave_up && tid == 0) d.scal[SC_CHOL_FAIL] = 1.0;
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&flags[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -363,33 +405,6 @@ __global__ __launch_bounds__(256) void chol_back_kernel(double *__restrict__ W, 
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallMaxNb = 11;
 __device__ __forceinline__ int blk_off(int i, int j) { return (i * (i + 1) / 2 + j) * (SB * VLD); }
-
-// 1 / sqrt(x) from the hardware seed (v_rsq_f64, relative error <= 2^-26) and ONE Newton step: relative error <= 1.5 * 2^-52.
-// The factor only has to be backward stable (the iteration log is compared with the oracle at 1e-9), and the second step is 30
-// cycles on the critical path of each of the n pivots.
-__device__ __forceinline__ double rsqrt_pivot1(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    return y * fma(-0.5 * x, y * y, 1.5);
-}
-
-// One wave: the 16 x 16 block D (LDS, row-major VLD) is replaced by the INVERSE of its Cholesky factor (above the diagonal: +-0).
-// Lane r (and r + 16, ... redundantly) holds row r of the block in x and solves L y = e_r in t.  Factorisation and inversion are
-// both right-looking and share every broadcast: once column c is final, lane i's L[i][c] (DPP row_newbcast) updates column i of
-// the block (x[i] -= L[r][c] L[i][c]) AND row i of the inverse (t[i] -= L[i][c] t[c]).  The whole thing is one generated asm
-// block (gen_potrf16_asm.py -> potrf16_gfx950.inc, ~740 instructions): the pivots are a serial chain (broadcast, v_rsq_f64, one
-// Newton step, scale) and the updates have to be issued in the shadow of its latencies, which hipcc does not do -- measured per
-// 16 x 16 block at n = 150: factor then invert, v_readlane broadcasts: 9.7k cycles; fused, v_readlane: 8.4k (the compiler parks
-// 30 scalars per pivot in VGPR lanes, v_writelane + s_nop); fused, DPP from C++: spills to scratch; this one: see DESIGN.md.
-#include "potrf16_gfx950.inc"
-__device__ __forceinline__ void potrf16_fused_inv(double *D, int *fail, int lane)
-{
-    const int r = lane & 15;
-    const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * VLD), col_addr = (uint32_t)(uintptr_t)(D + r);
-    int bad;
-    asm volatile(ESFM_POTRF16_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr), "v"(lane) : ESFM_POTRF16_CLOBBERS);
-    if (__any(bad) && lane == 0) *fail = 1;
-}
 
 __global__ __launch_bounds__(kSmallThreads) void ba_chol_small_kernel(BADev d, double radius, double min_diag, double max_diag)
 {
@@ -557,41 +572,33 @@ int ba_solve_reduced_small(hipStream_t st, const BADev &d, double radius, double
     return ESFM_OK;
 }
 
-__global__ void chol_extract_kernel(BADev d, const double *__restrict__ W, int ld, int nb)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = 6 * d.n_cam;
-    if (i >= n) return;
-    const bool fail = d.scal[SC_CHOL_FAIL] != 0.0;
-    d.y_c[i] = fail ? 0.0 : W[(size_t)nb * CB * ld + i];
-}
-
 size_t ba_chol_large_doubles(int n_cam)
 {
     const int n = 6 * n_cam, nb = (n + CB - 1) / CB;
-    return (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT;
+    // W, W2 (the factor), the diagonal slots, y, flags
+    return 2 * (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT + (size_t)nb * CB + (size_t)nb + 1;
 }
 
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
 {
     const int n = 6 * d.n_cam, nb = (n + CB - 1) / CB, ld = nb * CB;
-    double *W = d.chol;
-    double *Ldiag = W + (size_t)(nb + 1) * CB * ld;
-    const long long tot = (long long)(nb + 1) * CB * ld;
+    const size_t wsz = (size_t)(nb + 1) * CB * ld;
+    double *W = d.chol, *W2 = W + wsz;
+    double *Ldiag = W2 + wsz;
+    double *ybuf = Ldiag + (size_t)nb * LSLOT;
+    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);
+    const long long tot = (long long)wsz;
     hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag);
     ESFM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(chol_potrf0_kernel, dim3(1), dim3(256), 0, st, W, Ldiag, ld, d.scal);
-    for (int k = 0; k < nb; ++k) {
-        // block column k: X = A L_kk^-T for the tiles below the diagonal one (right-hand-side row included), then the trailing
-        // update, whose (k + 1, k + 1) workgroup also factors the next diagonal tile
-        hipLaunchKernelGGL(chol_trsm_kernel, dim3(nb - k), dim3(256), 0, st, W, Ldiag, ld, k);
+    ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * 2 * (size_t)nb, st));     // y-ready and factor-ready
+    for (int k = -1; k < nb - 1; ++k) {
+        // block column k's trailing update; its first workgroup factors and inverts the next diagonal tile, the workgroups of the
+        // next block column turn their tiles into factor tiles (see chol2_step_kernel).  k = -1 starts the chain.
         const int m = nb - k - 1;
-        const int tiles = m * (m + 1) / 2 + m;
-        if (tiles > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(tiles), dim3(256), 0, st, W, Ldiag, ld, nb, k, d.scal);
+        hipLaunchKernelGGL(chol2_step_kernel, dim3(k < 0 ? nb + 1 : m * (m + 1) / 2 + m), dim3(256), 0, st, W, W2, Ldiag, ld, nb, k, flags + nb, d.scal);
     }
     ESFM_HIP_TRY(hipGetLastError());
-    for (int k = nb - 1; k >= 0; --k) hipLaunchKernelGGL(chol_back_kernel, dim3(k + 1), dim3(256), 0, st, W, Ldiag, ld, nb, k);
-    hipLaunchKernelGGL(chol_extract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, W, ld, nb);
+    hipLaunchKernelGGL(chol2_back_kernel, dim3(nb), dim3(256), 0, st, d, W2, Ldiag, ld, nb, ybuf, flags);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -342,6 +342,11 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.Jp[(size_t)i * n_obs + k] = Jp[i];
         d.res[k] = r0; d.res[(size_t)n_obs + k] = r1;
+        // W_k = F_k'E_k (6 x 3): what the Schur complement needs of this observation -- W_i M^-1 W_j' per pair of a point's observations
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) d.W[(size_t)(3 * a + m) * n_obs + k] = Jc[a] * Jp[m] + Jc[6 + a] * Jp[3 + m];
         if (PRIV) {
             atomicAdd(&cnt[c], 1);
 #pragma unroll
@@ -674,6 +679,27 @@ __global__ void ba_camera_gradient_kernel(BADev d)
 // point p: W_i = F_i'E_i, Y_i = W_i M^-1; rhs_corr[c_i] -= W_i M^-1 E'r; and for every observation j of
 // the same point with camera(j) <= camera(i):  S[c_i][c_j] -= Y_i W_j'.  Only blocks on or below the
 // block diagonal are produced (the factorisation reads the lower triangle).
+// One pair of observations (i, j) of a point: block (c_i, c_j) of the Schur complement gets -Y_i W_j' (Y_i = W_i M^-1, rows scaled
+// by 2^(60 - qexp[row]); W_j's columns by 2^-qexp[col] here), as fixed-point adds.  Entry (a, c2) goes to Sb[a * ra + c2 * rc]:
+// (ra, rc) = (6, 1) normally, (1, 6) when the pair was met with c_j > c_i and the contribution belongs to the stored block
+// (c_j, c_i) as its transpose -- run-time strides, so that a wave whose lanes disagree does not execute the loop twice.
+// BOTH: a camera that sees the point twice -- the diagonal block is stored in full and takes the product and its transpose.
+template <bool BOTH>
+__device__ __forceinline__ void schur_pair(double *Sb, int ra, int rc, const double (&Y)[18], const double (&Wj)[18], const int *qe_j)
+{
+#pragma unroll
+    for (int c2 = 0; c2 < 6; ++c2) {
+        const int ej = -qe_j[c2];
+        const double w0 = ldexp(Wj[3 * c2], ej), w1 = ldexp(Wj[3 * c2 + 1], ej), w2 = ldexp(Wj[3 * c2 + 2], ej);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const unsigned long long v = fx64_scaled(-fma(Y[3 * a + 2], w2, fma(Y[3 * a + 1], w1, Y[3 * a] * w0)));   // (explicit fma: the file is built with -ffp-contract=off)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&Sb[a * ra + c2 * rc]), v);
+            if (BOTH) atomicAdd(reinterpret_cast<unsigned long long *>(&Sb[a * rc + c2 * ra]), v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -681,121 +707,96 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
     const size_t n_obs = d.n_obs;
     const int n = 6 * d.n_cam;
     const int p = d.obs_pt[i], ci = d.obs_cam[i];
-    double Jc[12], Jp[6];
+    double W[18];
 #pragma unroll
-    for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n_obs + i];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) Jp[a] = d.Jp[a * n_obs + i];
+    for (int q = 0; q < 18; ++q) W[q] = d.W[q * n_obs + i];
     const double *Mi = d.Minv + 6 * (size_t)p;
     const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
     const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+    const int b = d.pt_start[p], T = d.pt_start[p + 1] - b, t = i - b;
     double Y[18];
-    int ei[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) ei[a] = kFxBits - d.qexp[6 * ci + a];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
-        const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
-        const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
-        fx_add(&d.red[(size_t)n * n + 6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
-        Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei[a]);      // rows carry 2^(60 - qexp[row]), columns 2^-qexp[col] below
-        Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei[a]);
-        Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei[a]);
+        const double w0 = W[3 * a], w1 = W[3 * a + 1], w2 = W[3 * a + 2];
+        const int ei = kFxBits - d.qexp[6 * ci + a];
+        fx_add(&d.red[(size_t)n * n + 6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei - rhs_exp);
+        Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei);
+        Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei);
+        Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei);
     }
-    const int b = d.pt_start[p], e = d.pt_start[p + 1];
-    for (int j = b; j < e; ++j) {
+    schur_pair<false>(d.red + (size_t)(6 * ci) * n + 6 * ci, n, 1, Y, W, d.qexp + 6 * ci);
+    for (int s2 = 1; 2 * s2 <= T; ++s2) {
+        if (2 * s2 == T && t < s2) continue;
+        int q = t - s2; if (q < 0) q += T;
+        const int j = b + q;
         const int cj = d.obs_cam[j];
-        if (cj > ci) continue;
-        double Fj[12], Ej[6];
+        double Wj[18];
 #pragma unroll
-        for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
-        double *Sb = d.red + (size_t)(6 * ci) * n + 6 * cj;
-#pragma unroll
-        for (int c2 = 0; c2 < 6; ++c2) {
-            const int ej = -d.qexp[6 * cj + c2];
-            const double w0 = ldexp(Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3], ej);
-            const double w1 = ldexp(Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4], ej);
-            const double w2 = ldexp(Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5], ej);
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-                fx_add_scaled(&Sb[(size_t)a * n + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
-        }
+        for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
+        const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
+        double *Sb = d.red + (size_t)(6 * hi) * n + 6 * lo;
+        if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : n, cj > ci ? n : 1, Y, Wj, d.qexp + 6 * cj);
+        else schur_pair<true>(Sb, n, 1, Y, Wj, d.qexp + 6 * cj);
     }
 }
 
-// Small-camera-count variant (the metric configuration: 25 cameras): the whole lower-block-triangular
-// Schur matrix fits in LDS (n_cam (n_cam+1)/2 blocks of 36 doubles + the 6 n_cam right-hand side), so
-// each workgroup accumulates its observations' contributions with LDS f64 atomics (ds_add_f64) and
-// then stores its private copy as one coalesced slab; ba_schur_reduce_kernel sums the slabs in a fixed
-// order and unpacks them into the n x n layout.  No global atomics.
 // LDS pitch of a 6 x 6 block: 37 doubles, not 36.  The lanes of a wave add the same entry of DIFFERENT blocks; at pitch 36 (288 B)
 // those addresses fall on 8 of the 64 banks (SQ_LDS_BANK_CONFLICT was two thirds of SQ_LDS_IDX_ACTIVE), at 37 on all of them.
 constexpr int kSchurPitch = 37;
 
 __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__restrict__ slabs, int slab_doubles, int rhs_exp)
 {
-    extern __shared__ __attribute__((aligned(16))) double sl[];   // [nblk * kSchurPitch] blocks, then [n] rhs_corr
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // [nblk * kSchurPitch] blocks, [n] rhs_corr, then [n] ints: qexp
     const int tid = threadIdx.x;
     const int n = 6 * d.n_cam;
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
-    const int lds_doubles = nblk * kSchurPitch + 6 * d.n_cam;
+    const int lds_doubles = nblk * kSchurPitch + n;
     for (int e = tid; e < lds_doubles; e += blockDim.x) sl[e] = 0.0;
-    __syncthreads();
     double *srhs = sl + (size_t)nblk * kSchurPitch;
+    int *qe = reinterpret_cast<int *>(sl + lds_doubles);
+    for (int e = tid; e < n; e += blockDim.x) qe[e] = d.qexp[e];
+    __syncthreads();
     const size_t n_obs = d.n_obs;
     for (int i = blockIdx.x * blockDim.x + tid; i < d.n_obs; i += gridDim.x * blockDim.x) {
         const int p = d.obs_pt[i], ci = d.obs_cam[i];
-        double Jc[12], Jp[6];
+        double W[18];
 #pragma unroll
-        for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n_obs + i];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) Jp[a] = d.Jp[a * n_obs + i];
+        for (int q = 0; q < 18; ++q) W[q] = d.W[q * n_obs + i];
         const double *Mi = d.Minv + 6 * (size_t)p;
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
         const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+        const int b = d.pt_start[p], T = d.pt_start[p + 1] - b, t = i - b;
         double Y[18];
-        int ei[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) ei[a] = kFxBits - d.qexp[6 * ci + a];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
-            const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
-            const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
-            fx_add(&srhs[6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
-            Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei[a]);      // rows carry 2^(60 - qexp[row]), columns 2^-qexp[col] below
-            Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei[a]);
-            Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei[a]);
+            const double w0 = W[3 * a], w1 = W[3 * a + 1], w2 = W[3 * a + 2];
+            const int ei = kFxBits - qe[6 * ci + a];
+            fx_add(&srhs[6 * ci + a], -(w0 * ag0 + w1 * ag1 + w2 * ag2), ei - rhs_exp);
+            Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei);
+            Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei);
+            Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei);
         }
-        const int b = d.pt_start[p], e = d.pt_start[p + 1];
-        for (int j = b; j < e; ++j) {
+        // its own block, then the partners at distance s = 1 .. T/2 around the track (cyclically): every unordered pair of the
+        // point's observations is met exactly once and every observation does the same number of pairs (walking j over the
+        // whole track and keeping c_j <= c_i did 8 iterations for 4.5 pairs on an 8-observation track)
+        schur_pair<false>(sl + (size_t)(ci * (ci + 1) / 2 + ci) * kSchurPitch, 6, 1, Y, W, qe + 6 * ci);
+        for (int s2 = 1; 2 * s2 <= T; ++s2) {
+            if (2 * s2 == T && t < s2) continue;              // the half-way partners meet once
+            int q = t - s2; if (q < 0) q += T;
+            const int j = b + q;
             const int cj = d.obs_cam[j];
-            if (cj > ci) continue;
-            double Fj[12], Ej[6];
+            double Wj[18];
 #pragma unroll
-            for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
-            double *Sb = sl + (size_t)(ci * (ci + 1) / 2 + cj) * kSchurPitch;
-#pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) {
-                const int ej = -d.qexp[6 * cj + c2];
-                const double w0 = ldexp(Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3], ej);
-                const double w1 = ldexp(Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4], ej);
-                const double w2 = ldexp(Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5], ej);
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-                    fx_add_scaled(&Sb[a * 6 + c2], -(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
-            }
+            for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
+            const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
+            double *Sb = sl + (size_t)(hi * (hi + 1) / 2 + lo) * kSchurPitch;
+            if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : 6, cj > ci ? 6 : 1, Y, Wj, qe + 6 * cj);
+            else schur_pair<true>(Sb, 6, 1, Y, Wj, qe + 6 * cj);
         }
     }
     __syncthreads();
     double *out = slabs + (size_t)blockIdx.x * slab_doubles;
     for (int e = tid; e < slab_doubles; e += blockDim.x) out[e] = e < nblk * 36 ? sl[(e / 36) * kSchurPitch + e % 36] : sl[e + nblk * (kSchurPitch - 36)];
-    (void)n;
 }
 
 // Large camera counts: the Schur matrix does not fit LDS, but a workgroup that walks points ordered by their
@@ -808,7 +809,7 @@ constexpr int kWinBlocks = kWinCams * (kWinCams + 1) / 2;
 
 __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_exp)
 {
-    extern __shared__ __attribute__((aligned(16))) double sl[];   // [kWinBlocks*36] blocks, then [6*kWinCams] rhs_corr
+    extern __shared__ __attribute__((aligned(16))) double sl[];   // [kWinBlocks * kSchurPitch] blocks, then [6*kWinCams] rhs_corr
     const int tid = threadIdx.x;
     const int n = 6 * d.n_cam;
     const int chunk = blockIdx.x;
@@ -822,55 +823,51 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
     for (int s = s0 + tid; s < s1; s += 1024) {
         const int i = d.slot_obs[s];
         const int p = d.obs_pt[i], ci = d.obs_cam[i];
-        double Jc[12], Jp[6];
+        double W[18];
 #pragma unroll
-        for (int a = 0; a < 12; ++a) Jc[a] = d.Jc[a * n_obs + i];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) Jp[a] = d.Jp[a * n_obs + i];
+        for (int q = 0; q < 18; ++q) W[q] = d.W[q * n_obs + i];
         const double *Mi = d.Minv + 6 * (size_t)p;
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
         const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+        const int b = d.pt_start[p], T = d.pt_start[p + 1] - b, t = i - b;
         const int wi = ci - cw;
         const bool in_i = wi >= 0 && wi < kWinCams;
         double Y[18];
-        int ei[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) ei[a] = kFxBits - d.qexp[6 * ci + a];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            const double w0 = Jc[a] * Jp[0] + Jc[6 + a] * Jp[3];
-            const double w1 = Jc[a] * Jp[1] + Jc[6 + a] * Jp[4];
-            const double w2 = Jc[a] * Jp[2] + Jc[6 + a] * Jp[5];
-            const unsigned long long rv = fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei[a] - rhs_exp);
+            const double w0 = W[3 * a], w1 = W[3 * a + 1], w2 = W[3 * a + 2];
+            const int ei = kFxBits - d.qexp[6 * ci + a];
+            const unsigned long long rv = fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei - rhs_exp);
             atomicAdd(reinterpret_cast<unsigned long long *>(in_i ? &srhs[6 * wi + a] : &d.red[(size_t)n * n + 6 * ci + a]), rv);
-            Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei[a]);      // rows carry 2^(60 - qexp[row]), columns 2^-qexp[col] below
-            Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei[a]);
-            Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei[a]);
+            Y[3 * a + 0] = ldexp(w0 * M[0] + w1 * M[3] + w2 * M[6], ei);
+            Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei);
+            Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei);
         }
-        const int b = d.pt_start[p], e = d.pt_start[p + 1];
-        for (int j = b; j < e; ++j) {
+        // its own block, then the partners at distance 1 .. T/2 around the track (see ba_schur_lds_kernel).  Block (hi, lo) of the
+        // pair sits in the LDS window when hi does (lo >= cw: the chunk's points are ordered by their lowest camera).
+        if (in_i) schur_pair<false>(sl + (size_t)(wi * (wi + 1) / 2 + wi) * kSchurPitch, 6, 1, Y, W, d.qexp + 6 * ci);
+        else schur_pair<false>(d.red + (size_t)(6 * ci) * n + 6 * ci, n, 1, Y, W, d.qexp + 6 * ci);
+        for (int s2 = 1; 2 * s2 <= T; ++s2) {
+            if (2 * s2 == T && t < s2) continue;              // the half-way partners meet once
+            int q = t - s2; if (q < 0) q += T;
+            const int j = b + q;
             const int cj = d.obs_cam[j];
-            if (cj > ci) continue;
-            double Fj[12], Ej[6];
+            double Wj[18];
 #pragma unroll
-            for (int a = 0; a < 12; ++a) Fj[a] = d.Jc[a * n_obs + j];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) Ej[a] = d.Jp[a * n_obs + j];
-            const int wj = cj - cw;
-            const bool in_w = in_i && wj >= 0;   // cj <= ci < cw + kWinCams
-            double *Sl = sl + (size_t)(wi * (wi + 1) / 2 + wj) * kSchurPitch;
-            double *Sg = d.red + (size_t)(6 * ci) * n + 6 * cj;
-#pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) {
-                const int ej = -d.qexp[6 * cj + c2];
-                const double w0 = ldexp(Fj[c2] * Ej[0] + Fj[6 + c2] * Ej[3], ej);
-                const double w1 = ldexp(Fj[c2] * Ej[1] + Fj[6 + c2] * Ej[4], ej);
-                const double w2 = ldexp(Fj[c2] * Ej[2] + Fj[6 + c2] * Ej[5], ej);
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const unsigned long long v = fx64_scaled(-(Y[3 * a] * w0 + Y[3 * a + 1] * w1 + Y[3 * a + 2] * w2));
-                    atomicAdd(reinterpret_cast<unsigned long long *>(in_w ? &Sl[a * 6 + c2] : &Sg[(size_t)a * n + c2]), v);
-                }
+            for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
+            const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
+            const int wh = hi - cw, wl = lo - cw;
+            const bool in_w = wh < kWinCams && wl >= 0;
+            // (two call sites on purpose: with the address space known the window gets ds_add_u64; one merged pointer made every
+            // add a flat atomic, 5x slower per entry than the all-LDS kernel)
+            if (in_w) {
+                double *Sb = sl + (size_t)(wh * (wh + 1) / 2 + wl) * kSchurPitch;
+                if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : 6, cj > ci ? 6 : 1, Y, Wj, d.qexp + 6 * cj);
+                else schur_pair<true>(Sb, 6, 1, Y, Wj, d.qexp + 6 * cj);
+            } else {
+                double *Sb = d.red + (size_t)(6 * hi) * n + 6 * lo;
+                if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : n, cj > ci ? n : 1, Y, Wj, d.qexp + 6 * cj);
+                else schur_pair<true>(Sb, n, 1, Y, Wj, d.qexp + 6 * cj);
             }
         }
     }
@@ -1569,7 +1566,7 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     }
     const size_t priv_bytes = 18 * sizeof(double) + (size_t)d.n_real_cam * kLinLdsPerCam;
     const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
-    const bool priv = priv_bytes <= 150 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
+    const bool priv = priv_bytes <= 160 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
     ScalBase sbase;
     { const int slots[2] = {SC_COST, SC_LIN_BAD}; if (int rc = scal_reserve<2>(st, d, slots, grid, sbase)) return rc; }
     if (priv) {
@@ -1648,7 +1645,7 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
     const bool finish = !d.has_calib;    // with free intrinsics ba_schur_calib adds its block row first, then converts
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
     const int slab_doubles = nblk * 36 + 6 * d.n_cam;
-    const size_t lds_bytes = sizeof(double) * ((size_t)nblk * kSchurPitch + 6 * (size_t)d.n_cam);
+    const size_t lds_bytes = sizeof(double) * ((size_t)nblk * kSchurPitch + 6 * (size_t)d.n_cam) + sizeof(int) * 6 * (size_t)d.n_cam;
     static const int schur_threads = [] { const char *e = getenv("ESFM_SCHUR_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
     const int n_slabs = std::max(1, std::min(num_cu, div_up(d.n_obs, schur_threads)));
     if (lds_bytes <= 156 * 1024 && slabs && (size_t)n_slabs * slab_doubles <= slab_capacity_doubles) {

@@ -13,7 +13,9 @@ L y = e_r in t[0..15].  Once column c is final, L[i][c] -- row_newbcast:i of x[c
 t[i] -= L[i][c] t[c].  1 / sqrt(pivot): v_rsq_f64 + one Newton step (relative error <= 1.5 * 2^-52).
 
 Operands:  %0 (out, v) bad-pivot flag;  %1 (in, v) LDS byte address of row r of the block;  %2 (in, v) LDS byte address of
-column r of the block (the inverse is written column-wise: lane r holds column r);  row pitch = PITCH bytes.
+column r of the inverse (written column-wise: lane r holds column r; row pitch PITCH bytes);  %3 (in, v) lane id.
+The FULL variant (the 64 x 64 tile factorisation of the large solve) also writes the factor back over the block's rows (upper part
+zeroed) and the reciprocal diagonal:  %4 (in, v) LDS byte address of rd[0].
 """
 import os
 import sys
@@ -28,7 +30,8 @@ def T(c): return 32 + 2 * c
 PIV, Y, H, W, RINV = 64, 66, 68, 70, 72
 BC0, NBC = 74, 6
 C15 = 86                # 1.5
-NV = 88                 # v0..v87
+RREG = 88               # lane & 15 (FULL variant)
+NV = 89                 # v0..v88
 S_MASK, S_CMP, S_BAD = 4, 6, 8
 
 def pair(v): return "v[%d:%d]" % (v, v + 1)
@@ -53,7 +56,8 @@ def dpp_bcast(dst, src, lane):
     emit("v_mov_b32_dpp v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (dst, src, lane), [src], [dst], "dpp")
     emit("v_mov_b32_dpp v%d, v%d row_newbcast:%d row_mask:0xf bank_mask:0xf bound_ctrl:1" % (dst + 1, src + 1, lane), [src + 1], [dst + 1], "dpp")
 
-def build():
+def build(full):
+    del prog[:]
     bc_next = [0]
     def new_bc():
         v = BC0 + 2 * (bc_next[0] % NBC); bc_next[0] += 1; return v
@@ -67,6 +71,8 @@ def build():
         emit("v_mul_f64 %s, %s, %s" % (pair(W), pair(Y), pair(Y)), regs(Y), regs(W))
         emit("v_fma_f64 %s, %s, %s, %s" % (pair(W), pair(H), pair(W), pair(C15)), regs(H) + regs(W) + regs(C15), regs(W))
         emit("v_mul_f64 %s, %s, %s" % (pair(RINV), pair(Y), pair(W)), regs(Y) + regs(W), regs(RINV))
+        if full:
+            emit("ds_write_b64 %%4, %s offset:%d" % (pair(RINV), 8 * c), regs(RINV), [], "lds")
         emit("v_mul_f64 %s, %s, %s" % (pair(X(c)), pair(X(c)), pair(RINV)), regs(X(c)) + regs(RINV), regs(X(c)))
         emit("v_mul_f64 %s, %s, %s" % (pair(T(c)), pair(T(c)), pair(RINV)), regs(T(c)) + regs(RINV), regs(T(c)))
         for i in range(c + 1, SB):
@@ -77,8 +83,8 @@ def build():
                 dpp_bcast(PIV, X(i), i)
             emit("v_fma_f64 %s, -%s, %s, %s" % (pair(T(i)), pair(bc), pair(T(c)), pair(T(i))), regs(bc) + regs(T(c)) + regs(T(i)), regs(T(i)))
 
-LAT = {"dp": 10, "trans": 20, "dpp": 6, "cmp": 8, "salu": 2}     # issue-to-use estimates (cycles); only the ORDER depends on them
-ISSUE = {"dp": 4, "trans": 8, "dpp": 4, "cmp": 4, "salu": 1}
+LAT = {"dp": 10, "trans": 20, "dpp": 6, "cmp": 8, "salu": 2, "lds": 4}     # issue-to-use estimates (cycles); only the ORDER depends on them
+ISSUE = {"dp": 4, "trans": 8, "dpp": 4, "cmp": 4, "salu": 1, "lds": 4}
 
 def schedule():
     n = len(prog)
@@ -140,20 +146,20 @@ def hazards(order):
         recent.append((set(x for x in ins.writes if isinstance(x, int)), ins.kind))
     return out
 
-def main(path):
-    build()
+def generate(full):
+    build(full)
     order, cycles = schedule()
     body = hazards(order)
     pre = []
-    # rows in: 8 x ds_read_b128 (row pitch 144 B: 16-byte aligned)
+    # rows in: 8 x ds_read_b128 (row pitch a multiple of 16 B)
     for c in range(0, SB, 2):
         pre.append("ds_read_b128 v[%d:%d], %%1 offset:%d" % (X(c), X(c) + 3, 8 * c))
-    pre.append("v_and_b32 v%d, 15, %%3" % W)                        # r
+    pre.append("v_mov_b32 v%d, 0x3ff00000" % H)                      # H holds the high word of 1.0 until the first pivot
+    pre.append("v_and_b32 v%d, 15, %%3" % RREG)                      # r
     for c in range(SB):
         pre.append("v_mov_b32 v%d, 0" % T(c))
-        pre.append("v_cmp_eq_u32 vcc, %d, v%d" % (c, W))
-        pre.append("v_cndmask_b32 v%d, 0, v%d, vcc" % (T(c) + 1, H))   # H holds 0x3ff00000 until the first pivot
-    pre.insert(8, "v_mov_b32 v%d, 0x3ff00000" % H)
+        pre.append("v_cmp_eq_u32 vcc, %d, v%d" % (c, RREG))
+        pre.append("v_cndmask_b32 v%d, 0, v%d, vcc" % (T(c) + 1, H))
     pre.append("v_mov_b32 v%d, 0" % C15)
     pre.append("v_mov_b32 v%d, 0x3ff80000" % (C15 + 1))
     pre.append("s_movk_i32 s%d, 0x27f" % S_MASK)                     # v_cmp_class mask: NaN, -anything, +-0, +inf
@@ -162,18 +168,30 @@ def main(path):
     post = []
     for i in range(SB):
         post.append("ds_write_b64 %%2, %s offset:%d" % (pair(T(i)), PITCH * i))   # column r of the inverse: exactly +-0 above the diagonal
+    if full:
+        for c in range(1, SB):                                        # L[r][c] = 0 for c > r
+            post.append("v_cmp_le_u32 vcc, %d, v%d" % (c, RREG))
+            post.append("v_cndmask_b32 v%d, 0, v%d, vcc" % (X(c), X(c)))
+            post.append("v_cndmask_b32 v%d, 0, v%d, vcc" % (X(c) + 1, X(c) + 1))
+        for c in range(0, SB, 2):
+            post.append("ds_write_b128 %%1, v[%d:%d] offset:%d" % (X(c), X(c) + 3, 8 * c))
     post.append("v_cndmask_b32_e64 %%0, 0, 1, s[%d:%d]" % (S_BAD, S_BAD + 1))
     post.append("s_waitcnt lgkmcnt(0)")
-    lines = pre + body + post
+    return pre + body + post, cycles
+
+def main(path):
     with open(path, "w") as f:
-        f.write("// GENERATED by gen_potrf16_asm.py -- do not edit.  %d instructions, scheduler estimate %d cycles.\n" % (len(lines), cycles))
-        f.write("#define ESFM_POTRF16_ASM \\\n")
-        for ln in lines:
-            f.write('    "%s\\n\\t" \\\n' % ln)
-        f.write('    ""\n')
+        f.write("// GENERATED by gen_potrf16_asm.py -- do not edit.\n")
+        for name, full in (("ESFM_POTRF16_ASM", False), ("ESFM_POTRF16_FULL_ASM", True)):
+            lines, cycles = generate(full)
+            f.write("// %s: %d instructions, scheduler estimate %d cycles\n" % (name, len(lines), cycles))
+            f.write("#define %s \\\n" % name)
+            for ln in lines:
+                f.write('    "%s\\n\\t" \\\n' % ln)
+            f.write('    ""\n')
+            print("%s: %d instructions, estimated %d cycles" % (name, len(lines), cycles))
         clob = ['"v%d"' % v for v in range(NV)] + ['"s%d"' % s for s in (S_MASK, S_CMP, S_CMP + 1, S_BAD, S_BAD + 1)] + ['"vcc"', '"memory"']
         f.write("#define ESFM_POTRF16_CLOBBERS " + ", ".join(clob) + "\n")
-    print("potrf16: %d instructions, estimated %d cycles" % (len(lines), cycles))
 
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "potrf16_gfx950.inc")
