@@ -679,6 +679,8 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     // <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-15 |k| being the certificate's bound on |(|q|^2 + key) - d^2|;
     // every row of a group with |q|^2 + k - E(k) > U (1 + 2^-20) -- k its minimum -- is farther than both even after sqrtf's
     // rounding.  Keys only grow with the rank, so the rounds stop at the first one no lane of the wave needs.
+    // (The tail is ~6 memory round trips per workgroup and bound by L1 requests -- a load instruction of 64 lanes touches 64
+    // different lines; fetching both sets' query rows together would save one trip but needs 128 more VGPRs than there are.)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
@@ -719,12 +721,8 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
                     if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
                 }
                 const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-#ifdef ESFM_DIAG_NOTAIL
-                const bool need = row0 == -12345;
-#else
                 const bool need = row0 >= 0 && qvalid && !cannot;
-#endif
-                if (__ballot(need) == 0ull) break;
+                if (__ballot(need) == 0ull) break;      // (measured on M-SURF-4k: round 0 in every workgroup, round 1 in one of ten)
                 if (need) {
                     // four consecutive 256-B rows, two at a time (their 32 loads in flight together); a group at the end of the
                     // train set may reach into the padding: clamped address, result dropped
