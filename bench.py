@@ -287,7 +287,8 @@ def main() -> int:
         if world > 1:
             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
         ba_el = float(tt2.item())
-        sweep_bytes = 176.0 * len(ci) + 48.0 * scene.n_cam + 24.0 * scene.n_pt   # SURVEY 8d compulsory bytes of the Jacobian sweep
+        # compulsory bytes of the Jacobian sweep: 16 B in, 304 B out per observation (Jc 96 + Jp 48 + res 16 + W = F'E 144), DESIGN 4
+        sweep_bytes = 320.0 * len(ci) + 48.0 * scene.n_cam + 24.0 * scene.n_pt
         lin_s = (l_ms / max(l_n, 1)) * 1e-3
         n_red = 6 * scene.n_cam
         leg = {
