@@ -225,26 +225,51 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     d.parts = &P->parts;
     A(&d.qexp, nc6);
     // Windowed Schur for large camera counts: order points by their lowest camera, cut the observation stream into
-    // ~2 chunks per CU.  (Structure only; built once per problem.)
-    std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0;
+    // ~2 chunks per CU.  (Structure only; built once per problem.)  A second table, on camera indices rotated by half the
+    // camera count, takes the tracks that are only narrow there (the seam of a closed camera loop); what is wide in both
+    // index spaces goes to the plain kernel.
+    std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0, slot_obs_b, chunk_slot_b, chunk_cam0_b, wide_obs;
     if (d.slab_cap == 0 && n_obs > 0) {
-        std::vector<int32_t> min_cam((size_t)n_pt, INT32_MAX), perm;
-        for (int t = 0; t < n_obs; ++t) min_cam[(size_t)s_pt[(size_t)t]] = std::min(min_cam[(size_t)s_pt[(size_t)t]], s_cam[(size_t)t]);
-        perm.reserve((size_t)n_pt);
-        for (int p = 0; p < n_pt; ++p) if (pt_start[(size_t)p + 1] > pt_start[(size_t)p]) perm.push_back(p);
-        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return min_cam[(size_t)a] < min_cam[(size_t)b]; });
-        const int want_chunks = std::max(1, 2 * ctx->num_cu);
-        const int64_t per = std::max<int64_t>(1024, ((int64_t)n_obs + want_chunks - 1) / want_chunks);
-        slot_obs.reserve((size_t)n_obs);
-        int64_t in_chunk = 0;
-        for (int p : perm) {
-            if (chunk_slot.empty() || in_chunk >= per) { chunk_slot.push_back((int32_t)slot_obs.size()); chunk_cam0.push_back(min_cam[(size_t)p]); in_chunk = 0; }
-            for (int t = pt_start[(size_t)p]; t < pt_start[(size_t)p + 1]; ++t) slot_obs.push_back(t);
-            in_chunk += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+        const int rot = n_real / 2;
+        auto rotated = [&](int c) { const int r = c + rot; return r >= n_real ? r - n_real : r; };
+        std::vector<int32_t> lo_a((size_t)n_pt, INT32_MAX), hi_a((size_t)n_pt, -1), lo_b((size_t)n_pt, INT32_MAX), hi_b((size_t)n_pt, -1);
+        for (int t = 0; t < n_obs; ++t) {
+            const size_t p = (size_t)s_pt[(size_t)t];
+            const int c = s_cam[(size_t)t], cr = rotated(c);
+            lo_a[p] = std::min(lo_a[p], c); hi_a[p] = std::max(hi_a[p], c);
+            lo_b[p] = std::min(lo_b[p], cr); hi_b[p] = std::max(hi_b[p], cr);
         }
-        chunk_slot.push_back((int32_t)slot_obs.size());
-        d.n_chunks = (int)chunk_cam0.size();
+        std::vector<int32_t> perm_a, perm_b;
+        for (int p = 0; p < n_pt; ++p) {
+            if (pt_start[(size_t)p + 1] <= pt_start[(size_t)p]) continue;
+            if (hi_a[(size_t)p] - lo_a[(size_t)p] < esfm::kSchurWinCams) perm_a.push_back(p);
+            else if (hi_b[(size_t)p] - lo_b[(size_t)p] < esfm::kSchurWinCams) perm_b.push_back(p);
+            else for (int t = pt_start[(size_t)p]; t < pt_start[(size_t)p + 1]; ++t) wide_obs.push_back(t);
+        }
+        auto build = [&](std::vector<int32_t> &perm, const std::vector<int32_t> &lo, std::vector<int32_t> &slots, std::vector<int32_t> &cslot,
+                         std::vector<int32_t> &ccam0) {
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lo[(size_t)a] < lo[(size_t)b]; });
+            int64_t total = 0;
+            for (int p : perm) total += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+            static const int chunks_per_cu = [] { const char *e = getenv("ESFM_SCHUR_CHUNKS_PER_CU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? v : 2; }();
+            const int want_chunks = std::max(1, chunks_per_cu * ctx->num_cu);
+            const int64_t per = std::max<int64_t>(1024, (total + want_chunks - 1) / want_chunks);
+            slots.reserve((size_t)total);
+            int64_t in_chunk = 0;
+            for (int p : perm) {
+                if (cslot.empty() || in_chunk >= per) { cslot.push_back((int32_t)slots.size()); ccam0.push_back(lo[(size_t)p]); in_chunk = 0; }
+                for (int t = pt_start[(size_t)p]; t < pt_start[(size_t)p + 1]; ++t) slots.push_back(t);
+                in_chunk += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+            }
+            cslot.push_back((int32_t)slots.size());
+        };
+        build(perm_a, lo_a, slot_obs, chunk_slot, chunk_cam0);
+        build(perm_b, lo_b, slot_obs_b, chunk_slot_b, chunk_cam0_b);
+        d.n_chunks = (int)chunk_cam0.size(); d.n_chunks_b = (int)chunk_cam0_b.size();
+        d.n_wide_obs = (int)wide_obs.size();
         A(&d.slot_obs, slot_obs.size()); A(&d.chunk_slot, chunk_slot.size()); A(&d.chunk_cam0, chunk_cam0.size());
+        A(&d.slot_obs_b, slot_obs_b.size()); A(&d.chunk_slot_b, chunk_slot_b.size()); A(&d.chunk_cam0_b, chunk_cam0_b.size());
+        A(&d.wide_obs, wide_obs.size());
     }
     // point chunks: consecutive points with at most 256 observations (and 256 points) per chunk; a longer track stands alone
     std::vector<int32_t> pchunk_pt0;
@@ -281,12 +306,20 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         up(d.slot_obs, slot_obs.data(), sizeof(int32_t) * slot_obs.size());
         up(d.chunk_slot, chunk_slot.data(), sizeof(int32_t) * chunk_slot.size());
         up(d.chunk_cam0, chunk_cam0.data(), sizeof(int32_t) * chunk_cam0.size());
+        up(d.wide_obs, wide_obs.data(), sizeof(int32_t) * wide_obs.size());
+    }
+    if (d.n_chunks_b) {
+        up(d.slot_obs_b, slot_obs_b.data(), sizeof(int32_t) * slot_obs_b.size());
+        up(d.chunk_slot_b, chunk_slot_b.data(), sizeof(int32_t) * chunk_slot_b.size());
+        up(d.chunk_cam0_b, chunk_cam0_b.data(), sizeof(int32_t) * chunk_cam0_b.size());
     }
     up(d.pchunk_pt0, pchunk_pt0.data(), sizeof(int32_t) * pchunk_pt0.size());
     up(d.cam_obs, cam_obs.data(), sizeof(int32_t) * no);
     up(d.cchunk_cam, cchunk_cam.data(), sizeof(int32_t) * cchunk_cam.size()); up(d.cchunk_beg, cchunk_beg.data(), sizeof(int32_t) * cchunk_beg.size());
     up(d.cchunk_end, cchunk_end.data(), sizeof(int32_t) * cchunk_end.size()); up(d.cam_chunk0, cam_chunk0.data(), sizeof(int32_t) * cam_chunk0.size());
     up(d.x_c, cams, sizeof(double) * 6 * (size_t)n_real); up(d.x_p, pts, sizeof(double) * np3);
+    // red: the entries no kernel ever writes (blocks above the diagonal) must read as zero
+    if (rc == ESFM_OK && hipMemsetAsync(d.red, 0, sizeof(double) * esfm::ba_red_doubles(n_cam), st) != hipSuccess) { esfm::set_error("memset failed"); rc = ESFM_ERR_HIP; }
     if (rc == ESFM_OK && hipStreamSynchronize(st) != hipSuccess) { esfm::set_error("stream sync failed"); rc = ESFM_ERR_HIP; }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     *out = P;
@@ -430,6 +463,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     BADev &d = P->d;
     hipStream_t st = S.st;
     const bool multi = allreduce != nullptr;
+    P->parts.single_rank = !multi; P->parts.grad_done = false;
     double *h = S.h;
     if (multi && !d.red_packed) { if (int rc = dev_alloc(P, &d.red_packed, esfm::ba_red_packed_doubles(d.n_cam))) return rc; }
 

@@ -286,20 +286,34 @@ __global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W,
             }
         return;
     }
+#ifdef ESFM_CHOL_PROFILE
+    long long tq[8]; int nq = 0;
+#define STEP_MARK() do { if (k == 40) tq[nq++] = wall_clock64(); } while (0)
+#else
+#define STEP_MARK() do { } while (0)
+#endif
+    STEP_MARK();
     __syncthreads();                 // every wave is past its reads of Xi / Xj
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
     if (i == k + 1) {
         // the next diagonal tile: factor, invert, publish
         __syncthreads();
+        STEP_MARK();
         tile_potrf64(Xi, Vi, rd, &fail);
+        STEP_MARK();
         inv64(Xj, Xi, Vi, scratch);
         __syncthreads();
+        STEP_MARK();
         publish_diag2(Ldiag + (size_t)(k + 1) * LSLOT, Xj);
         if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
         __threadfence();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&ready[k + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        STEP_MARK();
+#ifdef ESFM_CHOL_PROFILE
+        if (k == 40 && tid == 0) printf("step40 wg0 [10ns]: start..update %lld potrf %lld inv %lld publish %lld (abs end %lld)\n", tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[4]);
+#endif
         return;
     }
     // a tile of the next block column: X_i,k+1 = C L_k+1,k+1^-T once the inverse is there
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W,
         }
     }
     __syncthreads();
+    STEP_MARK();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     {
         const double *Lk = Ldiag + (size_t)(k + 1) * LSLOT + LINV_OFF;
@@ -327,6 +342,11 @@ __global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W,
             const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
             W2[(size_t)(i * CB + r) * ld + (k + 1) * CB + c] = x[cb][g];
         }
+#ifdef ESFM_CHOL_PROFILE
+    STEP_MARK();
+    if (k == 40 && tid == 0 && blockIdx.x == 1) printf("step40 wg1 [10ns]: update-done..flag seen %lld, tail %lld (abs flag seen %lld, end %lld)\n", tq[1] - tq[0], tq[2] - tq[1], tq[1], tq[2]);
+#endif
+#undef STEP_MARK
 }
 
 // The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles; flags: nb ints,

@@ -418,9 +418,21 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
     }
 }
 
+// Camera part of max|gradient| (needs the all-reduced F'r): |F'r_i / scale_i|, or for bounded problems the norm of
+// x - Plus(x, -gradient)  (trust_region_minimizer.cc, projected gradient step).
+__device__ __forceinline__ double camera_gradient_entry(const BADev &d, int i, double ftr)
+{
+    double g = ftr / d.scale_c[i];
+    if (d.constrained) {
+        const double x = d.x_c[i];
+        g = x - fmin(fmax(x - g, d.lo_c[i]), d.up_c[i]);
+    }
+    return fabs(g);
+}
+
 // Sum of entry e over n_slabs per-workgroup slabs, computed by a 32 x 8 thread tile: thread (ent, grp) adds slabs grp, grp + 8, ...
 // (independent loads, coalesced across ent), then the 8 partial sums are combined in a fixed order through LDS.  Deterministic.
-__global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const double *__restrict__ slabs, int n_slabs)
+__global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const double *__restrict__ slabs, int n_slabs, int with_gradient)
 {
     __shared__ double lds[256];
     const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
@@ -444,7 +456,12 @@ __global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const do
     double v = 0.0;
     for (int g = 0; g < kRedGrp; ++g) v += lds[g * kRedEnt + threadIdx.x];
     const int c = e / 27, q = e % 27;
-    if (q >= 21) { d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)] = v; return; }
+    if (q >= 21) {
+        d.camacc[36 * (size_t)d.n_cam + 6 * (size_t)c + (q - 21)] = v;
+        // one rank: this IS the gradient's camera part, max-reduced here instead of in a launch of its own
+        if (with_gradient) { const double g = camera_gradient_entry(d, 6 * c + (q - 21), v); if (g > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], g); }
+        return;
+    }
     int a = 0, rem = q;
     while (rem >= 6 - a) { rem -= 6 - a; ++a; }
     const int b2 = a + rem;
@@ -556,6 +573,49 @@ __global__ __launch_bounds__(256) void ba_camacc_final_kernel(BADev d)
 // ---------------------------------------------------------------------------------------------
 // Per point: E'E, E'r (only when the Jacobian is fresh), then M^-1 = (E'E + clamp(diag)/radius)^-1
 // via a 3x3 Cholesky (ceres InvertPSDMatrix), M^-1 E'r, and the point part of max|gradient|.
+// M = E'E + D^2 of one point, its inverse (closed-form 3 x 3 Cholesky) and M^-1 E'r; returns 1.0 when M is not positive definite
+__device__ __forceinline__ double point_block_invert(const BADev &d, int p, const double (&A)[6], const double (&g)[3], double radius, double min_diag,
+                                                     double max_diag)
+{
+    double sing = 0.0;
+    // M = E'E + D^2, D^2 = clamp(diag(E'E)) / radius  (levenberg_marquardt_strategy.cc)
+    const double m00 = A[0] + fmin(fmax(A[0], min_diag), max_diag) / radius;
+    const double m11 = A[3] + fmin(fmax(A[3], min_diag), max_diag) / radius;
+    const double m22 = A[5] + fmin(fmax(A[5], min_diag), max_diag) / radius;
+    const double m10 = A[1], m20 = A[2], m21 = A[4];
+    double Mi[6] = {0, 0, 0, 0, 0, 0};
+    bool ok = m00 > 0.0;
+    const double l00 = sqrt(m00);
+    const double l10 = m10 / l00, l20 = m20 / l00;
+    const double t11 = m11 - l10 * l10;
+    ok = ok && (t11 > 0.0);
+    const double l11 = sqrt(t11);
+    const double l21 = (m21 - l20 * l10) / l11;
+    const double t22 = m22 - l20 * l20 - l21 * l21;
+    ok = ok && (t22 > 0.0);
+    const double l22 = sqrt(t22);
+    if (ok) {
+        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+        const double i10 = -l10 * i00 * i11;
+        const double i21 = -l21 * i11 * i22;
+        const double i20 = -(l20 * i00 + l21 * i10) * i22;
+        Mi[0] = i00 * i00 + i10 * i10 + i20 * i20;  // xx
+        Mi[1] = i10 * i11 + i20 * i21;              // xy
+        Mi[2] = i20 * i22;                          // xz
+        Mi[3] = i11 * i11 + i21 * i21;              // yy
+        Mi[4] = i21 * i22;                          // yz
+        Mi[5] = i22 * i22;                          // zz
+    } else {
+        sing = 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d.Minv[6 * (size_t)p + i] = Mi[i];
+    d.Aig[3 * (size_t)p + 0] = Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2];
+    d.Aig[3 * (size_t)p + 1] = Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2];
+    d.Aig[3 * (size_t)p + 2] = Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2];
+    return sing;
+}
+
 __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh, ScalBase sbase)
 {
     __shared__ double red[8];
@@ -591,41 +651,7 @@ __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radiu
 #pragma unroll
                 for (int i = 0; i < 3; ++i) g[i] = d.Etr[3 * (size_t)p + i];
             }
-            // M = E'E + D^2, D^2 = clamp(diag(E'E)) / radius  (levenberg_marquardt_strategy.cc)
-            const double m00 = A[0] + fmin(fmax(A[0], min_diag), max_diag) / radius;
-            const double m11 = A[3] + fmin(fmax(A[3], min_diag), max_diag) / radius;
-            const double m22 = A[5] + fmin(fmax(A[5], min_diag), max_diag) / radius;
-            const double m10 = A[1], m20 = A[2], m21 = A[4];
-            double Mi[6] = {0, 0, 0, 0, 0, 0};
-            bool ok = m00 > 0.0;
-            const double l00 = sqrt(m00);
-            const double l10 = m10 / l00, l20 = m20 / l00;
-            const double t11 = m11 - l10 * l10;
-            ok = ok && (t11 > 0.0);
-            const double l11 = sqrt(t11);
-            const double l21 = (m21 - l20 * l10) / l11;
-            const double t22 = m22 - l20 * l20 - l21 * l21;
-            ok = ok && (t22 > 0.0);
-            const double l22 = sqrt(t22);
-            if (ok) {
-                const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
-                const double i10 = -l10 * i00 * i11;
-                const double i21 = -l21 * i11 * i22;
-                const double i20 = -(l20 * i00 + l21 * i10) * i22;
-                Mi[0] = i00 * i00 + i10 * i10 + i20 * i20;  // xx
-                Mi[1] = i10 * i11 + i20 * i21;              // xy
-                Mi[2] = i20 * i22;                          // xz
-                Mi[3] = i11 * i11 + i21 * i21;              // yy
-                Mi[4] = i21 * i22;                          // yz
-                Mi[5] = i22 * i22;                          // zz
-            } else {
-                sing = 1.0;
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) d.Minv[6 * (size_t)p + i] = Mi[i];
-            d.Aig[3 * (size_t)p + 0] = Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2];
-            d.Aig[3 * (size_t)p + 1] = Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2];
-            d.Aig[3 * (size_t)p + 2] = Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2];
+            sing = point_block_invert(d, p, A, g, radius, min_diag, max_diag);
         }
     }
     if (fresh) {
@@ -655,20 +681,11 @@ __global__ void ba_jacobi_scaling_kernel(BADev d)
     }
 }
 
-// Camera part of max|gradient| (needs the all-reduced F'r).
 __global__ void ba_camera_gradient_kernel(BADev d)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double g = 0.0;
-    if (i < 6 * d.n_cam) {
-        g = d.camacc[36 * (size_t)d.n_cam + i] / d.scale_c[i];
-        if (d.constrained) {
-            // bounded problems: norm of x - Plus(x, -gradient)  (trust_region_minimizer.cc, projected gradient step)
-            const double x = d.x_c[i];
-            g = x - fmin(fmax(x - g, d.lo_c[i]), d.up_c[i]);
-        }
-        g = fabs(g);
-    }
+    if (i < 6 * d.n_cam) g = camera_gradient_entry(d, i, d.camacc[36 * (size_t)d.n_cam + i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
     if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], g);
@@ -700,10 +717,12 @@ __device__ __forceinline__ void schur_pair(double *Sb, int ra, int rc, const dou
     }
 }
 
-__global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp)
+// list != NULL: the observations list[0 .. n_list) only (the wide tracks the windowed kernel leaves out)
+__global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ list, int n_list)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.n_obs) return;
+    const int li = blockIdx.x * 256 + threadIdx.x;
+    if (li >= (list ? n_list : d.n_obs)) return;
+    const int i = list ? list[li] : li;
     const size_t n_obs = d.n_obs;
     const int n = 6 * d.n_cam;
     const int p = d.obs_pt[i], ci = d.obs_cam[i];
@@ -804,24 +823,29 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
 // LDS window of kWinCams consecutive cameras starting at the chunk's lowest one: contributions whose two
 // cameras fall inside the window are accumulated with LDS f64 atomics, the few that do not (wide baselines,
 // ring wrap-around) go straight to global f64 atomics; the window is flushed once at the end.
-constexpr int kWinCams = 28;
+constexpr int kWinCams = kSchurWinCams;
 constexpr int kWinBlocks = kWinCams * (kWinCams + 1) / 2;
 
-__global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_exp)
+// rot: camera indices are rotated by rot (mod n_real_cam) before the window test -- the second pass, rot = n_real_cam / 2, takes
+// the tracks that straddle the seam of a closed camera loop (cameras 508 .. 511, 0 .. 5 of a ring of 512): in true indices they
+// are 500 cameras wide and would all go to same-address global atomics (measured: 2.1 ms for 2 % of BA-512's observations).
+__global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs,
+                                                               const int32_t *__restrict__ chunk_slot, const int32_t *__restrict__ chunk_cam0, int rot)
 {
     extern __shared__ __attribute__((aligned(16))) double sl[];   // [kWinBlocks * kSchurPitch] blocks, then [6*kWinCams] rhs_corr
     const int tid = threadIdx.x;
-    const int n = 6 * d.n_cam;
+    const int n = 6 * d.n_cam, nrc = d.n_real_cam;
     const int chunk = blockIdx.x;
-    const int s0 = d.chunk_slot[chunk], s1 = d.chunk_slot[chunk + 1];
-    const int cw = d.chunk_cam0[chunk];
+    const int s0 = chunk_slot[chunk], s1 = chunk_slot[chunk + 1];
+    const int cw = chunk_cam0[chunk];                               // window base, in ROTATED camera indices
+    auto rotated = [&](int c) { const int r = c + rot; return r >= nrc ? r - nrc : r; };
     constexpr int kWinDoubles = kWinBlocks * kSchurPitch + 6 * kWinCams;
     for (int e = tid; e < kWinDoubles; e += 1024) sl[e] = 0.0;
     __syncthreads();
     double *srhs = sl + kWinBlocks * kSchurPitch;
     const size_t n_obs = d.n_obs;
     for (int s = s0 + tid; s < s1; s += 1024) {
-        const int i = d.slot_obs[s];
+        const int i = slot_obs[s];
         const int p = d.obs_pt[i], ci = d.obs_cam[i];
         double W[18];
 #pragma unroll
@@ -830,7 +854,7 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
         const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
         const int b = d.pt_start[p], T = d.pt_start[p + 1] - b, t = i - b;
-        const int wi = ci - cw;
+        const int wi = rotated(ci) - cw;
         const bool in_i = wi >= 0 && wi < kWinCams;
         double Y[18];
 #pragma unroll
@@ -843,8 +867,9 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
             Y[3 * a + 1] = ldexp(w0 * M[1] + w1 * M[4] + w2 * M[7], ei);
             Y[3 * a + 2] = ldexp(w0 * M[2] + w1 * M[5] + w2 * M[8], ei);
         }
-        // its own block, then the partners at distance 1 .. T/2 around the track (see ba_schur_lds_kernel).  Block (hi, lo) of the
-        // pair sits in the LDS window when hi does (lo >= cw: the chunk's points are ordered by their lowest camera).
+        // its own block, then the partners at distance 1 .. T/2 around the track (see ba_schur_lds_kernel).  A pair's block sits
+        // in the LDS window when both cameras do; there it is oriented by the ROTATED indices (row = the larger one) and turned
+        // the right way round when the window is flushed.
         if (in_i) schur_pair<false>(sl + (size_t)(wi * (wi + 1) / 2 + wi) * kSchurPitch, 6, 1, Y, W, d.qexp + 6 * ci);
         else schur_pair<false>(d.red + (size_t)(6 * ci) * n + 6 * ci, n, 1, Y, W, d.qexp + 6 * ci);
         for (int s2 = 1; 2 * s2 <= T; ++s2) {
@@ -855,16 +880,17 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
             double Wj[18];
 #pragma unroll
             for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
-            const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
-            const int wh = hi - cw, wl = lo - cw;
-            const bool in_w = wh < kWinCams && wl >= 0;
+            const int wj = rotated(cj) - cw;
+            const bool in_w = in_i && wj >= 0 && wj < kWinCams;
             // (two call sites on purpose: with the address space known the window gets ds_add_u64; one merged pointer made every
-            // add a flat atomic, 5x slower per entry than the all-LDS kernel)
+            // add a flat atomic)
             if (in_w) {
+                const int wh = wj > wi ? wj : wi, wl = wj > wi ? wi : wj;
                 double *Sb = sl + (size_t)(wh * (wh + 1) / 2 + wl) * kSchurPitch;
-                if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : 6, cj > ci ? 6 : 1, Y, Wj, d.qexp + 6 * cj);
+                if (wj != wi) schur_pair<false>(Sb, wj > wi ? 1 : 6, wj > wi ? 6 : 1, Y, Wj, d.qexp + 6 * cj);
                 else schur_pair<true>(Sb, 6, 1, Y, Wj, d.qexp + 6 * cj);
             } else {
+                const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
                 double *Sb = d.red + (size_t)(6 * hi) * n + 6 * lo;
                 if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : n, cj > ci ? n : 1, Y, Wj, d.qexp + 6 * cj);
                 else schur_pair<true>(Sb, n, 1, Y, Wj, d.qexp + 6 * cj);
@@ -872,22 +898,25 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
         }
     }
     __syncthreads();
-    // flush the window
+    // flush the window: rotated-local (wi >= wj) -> true cameras; the stored triangle wants row camera >= column camera
     const unsigned long long *sq = reinterpret_cast<const unsigned long long *>(sl);   // same grid per entry as d.red: integer adds
+    auto true_cam = [&](int w) { int c = cw + w - rot; if (c < 0) c += nrc; return c; };
     for (int e = tid; e < kWinBlocks * 36; e += 1024) {
         const int blk = e / 36, r = e % 36;
         const unsigned long long v = sq[blk * kSchurPitch + r];
         if (v == 0ull) continue;
-        int wi = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
-        while ((wi + 1) * (wi + 2) / 2 <= blk) ++wi;
-        while (wi * (wi + 1) / 2 > blk) --wi;
-        const int wj = blk - wi * (wi + 1) / 2;
-        const int ci = cw + wi, cj = cw + wj;
-        if (ci < d.n_cam) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6]), v);
+        int wi = 0, wj = blk;
+        while (wj > wi) { wj -= wi + 1; ++wi; }
+        const int ci = true_cam(wi), cj = true_cam(wj);
+        if (ci >= nrc || cj >= nrc) continue;
+        const size_t at = ci >= cj ? (size_t)(6 * ci + r / 6) * n + 6 * cj + r % 6 : (size_t)(6 * cj + r % 6) * n + 6 * ci + r / 6;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[at]), v);
     }
     for (int e = tid; e < 6 * kWinCams; e += 1024) {
         const unsigned long long v = sq[kWinBlocks * kSchurPitch + e];
-        if (v != 0ull && cw + e / 6 < d.n_cam) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)n * n + 6 * cw + e]), v);
+        if (v == 0ull) continue;
+        const int c = true_cam(e / 6);
+        if (c < nrc) atomicAdd(reinterpret_cast<unsigned long long *>(&d.red[(size_t)n * n + 6 * c + e % 6]), v);
     }
 }
 
@@ -1261,7 +1290,6 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
 // No atomics, every sum in a fixed order.  (Round 1 had one thread per point walking its observations: 16 dependent memory round
 // trips on an 8-observation track, 43 us on the 25-camera problem; and, from 2^20 observations, two observation-parallel passes
 // joined by f64 atomics.)  A single point with more observations than a chunk holds gets a chunk of its own and loops.
-constexpr int kPtChunkObs = 256;
 
 __global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, ScalBase sbase)
 {
@@ -1577,7 +1605,8 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, sbase, d.lin_slabs);
         }
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid);
+        hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid, d.parts->single_rank ? 1 : 0);
+        d.parts->grad_done = d.parts->single_rank;
         LAUNCH_CHECK();
         return ESFM_OK;
     }
@@ -1597,8 +1626,12 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh)
 {
     if (d.n_pt <= 0) return ESFM_OK;
+    // (a chunked variant -- thread = observation forms the nine products from one coalesced read, thread = point adds them from LDS
+    // -- measured 17.6 us against this kernel's 12 us on the 25-camera problem: the 3 x 3 inverse's sqrt / divide chain then runs
+    // in one half-filled wave per chunk)
     ScalBase sbase;
-    { const int slots[1] = {SC_PT_SINGULAR}; if (int rc = scal_reserve<1>(st, d, slots, div_up(d.n_pt, 64), sbase)) return rc; }
+    const int slots[1] = {SC_PT_SINGULAR};
+    if (int rc = scal_reserve<1>(st, d, slots, div_up(d.n_pt, 64), sbase)) return rc;
     hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0, sbase);
     LAUNCH_CHECK();
     return ESFM_OK;
@@ -1615,6 +1648,7 @@ int ba_jacobi_scaling(hipStream_t st, const BADev &d)
 
 int ba_camera_gradient(hipStream_t st, const BADev &d)
 {
+    if (d.parts->grad_done) { d.parts->grad_done = false; return ESFM_OK; }    // ba_camacc_reduce_kernel has done it (one rank)
     if (d.n_cam <= 0) return ESFM_OK;
     hipLaunchKernelGGL(ba_camera_gradient_kernel, dim3(div_up(6 * d.n_cam, 256)), dim3(256), 0, st, d);
     LAUNCH_CHECK();
@@ -1639,7 +1673,11 @@ static int schur_to_double(hipStream_t st, const BADev &d, int rhs_exp)
 
 int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t slab_capacity_doubles, double rhs_bound)
 {
-    ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
+    // (the slab path writes every entry of red anything reads -- lower blocks and right-hand side -- in its reduce kernel; the other
+    // paths and the free-intrinsics kernel accumulate into it)
+    const bool slab_path = d.n_obs > 0 && !d.has_calib && slabs &&
+                           sizeof(double) * ((size_t)(d.n_cam * (d.n_cam + 1) / 2) * kSchurPitch + 6 * (size_t)d.n_cam) + sizeof(int) * 6 * (size_t)d.n_cam <= 156 * 1024;
+    if (!slab_path) ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
     if (d.n_obs <= 0) return ESFM_OK;
     const int rhs_exp = bound_exponent(rhs_bound);
     const bool finish = !d.has_calib;    // with free intrinsics ba_schur_calib adds its block row first, then converts
@@ -1662,10 +1700,21 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * kSchurPitch + 6 * kWinCams);
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_window_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-        hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d, rhs_exp);
+        hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d, rhs_exp, d.slot_obs, d.chunk_slot, d.chunk_cam0, 0);
         LAUNCH_CHECK();
+        if (d.n_chunks_b > 0) {        // the tracks that are narrow once the camera indices are rotated by half the loop
+            hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks_b), dim3(1024), win_bytes, st, d, rhs_exp, d.slot_obs_b, d.chunk_slot_b, d.chunk_cam0_b,
+                               d.n_real_cam / 2);
+            LAUNCH_CHECK();
+        }
+        // tracks wider than the window in both index spaces go through the plain kernel, spread over the chip (inside the window
+        // kernel they would all land in the chunks of the lowest cameras and the whole launch would wait for those workgroups)
+        if (d.n_wide_obs > 0) {
+            hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_wide_obs, 256)), dim3(256), 0, st, d, rhs_exp, d.wide_obs, d.n_wide_obs);
+            LAUNCH_CHECK();
+        }
     } else {
-        hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, rhs_exp);
+        hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, rhs_exp, (const int32_t *)nullptr, 0);
         LAUNCH_CHECK();
     }
     return finish ? schur_to_double(st, d, rhs_exp) : ESFM_OK;

@@ -28,7 +28,11 @@ enum BAScalar {
 // one more 6-wide camera-side block (two padding unknowns with zero Jacobian columns) behind the real cameras, so
 // n_cam = n_real_cam + has_calib is the number of 6-wide blocks of the reduced system and every per-block array
 // (x_c, scale_c, camacc, red, y_c ...) simply has one more block; observations only ever name real cameras.
-struct ScalParts { int n[SC_SUM_COUNT]; };    // host-side bookkeeping
+struct ScalParts {                             // host-side bookkeeping of one problem
+    int n[SC_SUM_COUNT];                       // per-workgroup scalar partials pending on the device, per slot
+    bool single_rank = true;                   // no all-reduce callback in the running solve
+    bool grad_done = false;                    // the camera part of max|gradient| came with the last linearisation
+};
 struct ScalCounts { int n[SC_SUM_COUNT]; };   // kernel argument: how many partials each slot has pending
 struct ScalBase { int b[4]; };                // kernel argument: first partial index of this launch, per slot it commits
 
@@ -77,6 +81,10 @@ struct BADev {
     int32_t *slot_obs = nullptr;    // [n_obs] observation indices in chunk order
     int32_t *chunk_slot = nullptr;  // [n_chunks+1] first slot of each chunk
     int32_t *chunk_cam0 = nullptr;  // [n_chunks] lowest camera of the chunk = window base
+    int32_t *slot_obs_b = nullptr, *chunk_slot_b = nullptr, *chunk_cam0_b = nullptr;   // the same for the pass on rotated camera indices
+    int n_chunks_b = 0;
+    int32_t *wide_obs = nullptr;    // [n_wide_obs] observations of the points whose cameras span kSchurWinCams or more (not in slot_obs)
+    int n_wide_obs = 0;
     // per-camera sums F'F / F'r of LARGE camera counts (the small ones are summed inside the sweep, see ba_linearize_kernel): the observations of every camera in ascending order (cam_obs, a CSR over
     // cameras built once per problem), cut into chunks of kCamChunk; one wave sums a chunk in a fixed order, a second
     // launch adds a camera's chunk sums in order.  Bit-reproducible whatever the launch timing.
@@ -105,6 +113,8 @@ struct BADev {
     int n_pchunks = 0;
 };
 constexpr int kCamChunk = 256, kCamPart = 37;
+constexpr int kPtChunkObs = 256;               // observations per point chunk (back-substitution, per-point normal blocks)
+constexpr int kSchurWinCams = 28;              // cameras in the windowed Schur kernel's LDS window
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
 inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
