@@ -25,7 +25,7 @@
 #include <vector>
 
 #include "../../include/esfm.h"
-#include "esfm_png.hpp"
+#include "esfm_jpeg.hpp"   // (pulls in esfm_png.hpp and read_image_bgr)
 
 namespace p3dv {
 
@@ -314,7 +314,7 @@ public:
         (void)show;
         ImageMat &img = cur_frame.rgb_image;
         img.channels = 3;
-        const std::string err = png::read_bgr(cur_frame.image_file_path, img.rows, img.cols, img.data);
+        const std::string err = read_image_bgr(cur_frame.image_file_path, img.rows, img.cols, img.data);
         if (!err.empty()) { img = ImageMat(); std::cout << "No more images" << " (" << err << ")" << std::endl; return false; }
         return true;
     }

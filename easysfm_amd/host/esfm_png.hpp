@@ -1,7 +1,7 @@
 // Minimal PNG reader for the native host layer: what cv::imread(path, CV_LOAD_IMAGE_COLOR) delivers for the reference's inputs
 // (reference cpp_code/src/data_io.cpp:48-72, DataIO::importImages) -- an 8-bit, 3-channel, BGR, row-major image.
 // Supported: gray (1, 2, 4, 8, 16 bit), gray + alpha, RGB, RGBA and palette (1, 2, 4, 8 bit) PNGs, 16-bit samples reduced to
-// their high byte (as libpng's strip-16 does for imread), sub-byte gray expanded by bit replication, non-interlaced.  Adam7 files, and JPEGs, are reported as unsupported -- image decoding is host
+// their high byte (as libpng's strip-16 does for imread), sub-byte gray expanded by bit replication, non-interlaced.  Adam7 files are reported as unsupported (JPEG: esfm_jpeg.hpp) -- image decoding is host
 // I/O outside the hot path, this reader exists so that the C++ executable needs no Python.
 // Needs zlib (-lz) for the inflate step; everything else (chunk walk, CRC check, the five scanline filters) is here.
 #pragma once

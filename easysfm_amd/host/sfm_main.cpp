@@ -44,7 +44,7 @@ int dump_image(const char *in, const char *out)
 {
     int rows = 0, cols = 0;
     std::vector<uint8_t> bgr;
-    const std::string err = png::read_bgr(in, rows, cols, bgr);
+    const std::string err = read_image_bgr(in, rows, cols, bgr);
     if (!err.empty()) { std::cerr << err << std::endl; return 3; }
     std::ofstream f(out, std::ios::binary);
     const int32_t hdr[2] = {rows, cols};

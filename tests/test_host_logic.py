@@ -389,3 +389,59 @@ def test_run_scripts_keep_the_reference_parameters():
             assert r.returncode == 1 and a[0] == "13", (name, r.stdout)
             assert tuple(a[6:12]) == vals and a[1].startswith("/data/x/") and a[5].endswith("c.ply"), (name, a)
             assert (a[4] == "none") == (name in ("run_fountain_small.sh", "run_fountain_large.sh", "run_zurich.sh"))
+
+
+def test_native_jpeg_reader(tmp_path):
+    """the native driver reads baseline JPEG (the COLMAP data sets of script/run_*hall.sh, run_southbuilding.sh).
+    Files written by tests/jpeg_util.encode (own baseline encoder: no imaging library in the image) in 4:4:4 / 4:2:2 / 4:2:0 /
+    gray, odd sizes, with and without restart intervals; the decoded BGR must equal, bit for bit, the numpy restatement of
+    libjpeg's pipeline (islow IDCT, fancy upsampling, 16-bit colour tables) applied to the coefficients the encoder wrote, and
+    be close to the source image.  Progressive files and truncated ones come back as error strings.  (Parity unpinned: neither
+    side has been compared with libjpeg itself.)"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import jpeg_util
+    exe = os.path.join(ROOT, "bin", "sfm_native")
+    if not os.path.exists(exe):
+        pytest.skip("bin/sfm_native not built")
+    rng = np.random.default_rng(5)
+
+    def picture(h, w):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        base = np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 60 + 1.5 * xx + 0.5 * yy, 200 - 1.2 * yy + 20 * np.sin((xx + yy) / 5.0)], axis=2)
+        return np.clip(base + rng.normal(0, 4, (h, w, 3)), 0, 255).astype(np.uint8)
+
+    def dump(path):
+        out = path + ".raw"
+        r = subprocess.run([exe, "--dump-image", path, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            return r.returncode, r.stdout
+        raw = np.fromfile(out, np.uint8)
+        rows, cols = np.frombuffer(raw[:8].tobytes(), np.int32)
+        return 0, raw[8:].reshape(rows, cols, 3)
+
+    cases = [("444", 40, 56, 0, 92), ("420", 37, 53, 0, 90), ("420", 64, 48, 3, 75), ("422", 33, 70, 5, 85), ("420", 17, 9, 1, 95), ("gray", 29, 41, 0, 88),
+             ("420", 8, 8, 0, 90), ("444", 1, 1, 0, 90), ("420", 2, 3, 0, 90)]
+    for sub, h, w, rst, q in cases:
+        img = picture(h, w)
+        src = img[:, :, 1] if sub == "gray" else img
+        data, info = jpeg_util.encode(src, subsampling="444" if sub == "gray" else sub, quality=q, restart=rst)
+        path = str(tmp_path / f"{sub}_{h}x{w}_{rst}.jpg")
+        with open(path, "wb") as f:
+            f.write(data)
+        rc, got = dump(path)
+        assert rc == 0, (sub, h, w, got)
+        want = jpeg_util.reference_decode(info)
+        assert got.shape == want.shape and np.array_equal(got, want), (sub, h, w, rst, int(np.abs(got.astype(int) - want).max()))
+        ref = np.stack([src] * 3, axis=2) if sub == "gray" else img[:, :, ::-1]
+        if h >= 16 and w >= 16:
+            mse = np.mean((got.astype(np.float64) - ref) ** 2)
+            assert 10 * np.log10(255.0 ** 2 / mse) > 28.0, (sub, h, w, mse)
+    data, _ = jpeg_util.encode(picture(32, 32), "420", 90)
+    prog = data.replace(b"\xFF\xC0", b"\xFF\xC2", 1)
+    for name, blob, msg in (("prog.jpg", prog, "progressive"), ("trunc.jpg", data[:len(data) // 3], ""), ("hdr.jpg", data[:30], "")):
+        (tmp_path / name).write_bytes(blob)
+        rc, out = dump(str(tmp_path / name))
+        assert rc == 3 or (rc == 0 and name == "trunc.jpg"), (name, rc, out)      # a cut entropy stream decodes to padding, as libjpeg's does
+        if msg:
+            assert msg in out
