@@ -192,10 +192,24 @@ __device__ __forceinline__ void inv64(double *O, const double *T, const double *
     }
 }
 
+// Data handed from one workgroup to another INSIDE a launch (factor tiles, tile inverses, solution blocks) is written and read
+// with agent-scope relaxed atomics -- plain stores / loads with the coherence bits set, write-through and L2-bypassing -- and
+// ordered against the flag by a WORKGROUP-scope fence (s_waitcnt) plus a barrier.  An agent-scope release (__threadfence) is a
+// write-back of the XCD's whole L2, with megabytes of other workgroups' dirty tiles in it: two of those per block column were
+// ~15 us of the 31 us step.
+__device__ __forceinline__ void st_coh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_coh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_flag(int *f, int value = 1)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have been acknowledged
+    __syncthreads();                                            // ... and everybody else's
+    if (threadIdx.x == 0) __hip_atomic_store(f, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // (only the inverse of the factor is read again -- by the next block column's workgroups and by the backward substitution)
 __device__ __forceinline__ void publish_diag2(double *__restrict__ Ld, const double *O)
 {
-    for (int e = threadIdx.x; e < CB * CB; e += 256) Ld[LINV_OFF + e] = O[(e / CB) * ULD + (e % CB)];
+    for (int e = threadIdx.x; e < CB * CB; e += 256) st_coh(&Ld[LINV_OFF + e], O[(e / CB) * ULD + (e % CB)]);
 }
 
 // this wave's 16-row strip of  P (64 x 64, LDS ULD) * Q' (Q 64 x 64, LDS ULD): four 16 x 16 outputs, K = 64
@@ -212,16 +226,21 @@ __device__ __forceinline__ void strip_pqt64(doublex4 (&acc)[4], const double *P,
     }
 }
 
-// Block column k in one launch (k = -1: the first one, nothing to subtract yet).  Workgroup (i, j), k < j <= i <= nb (block row
-// nb = the right-hand side; j <= nb - 1), reads the factor tiles X_ik, X_jk from W2 and forms  C_ij - X_ik X_jk'.  Then
-//   (k+1, k+1), blockIdx 0:  finishes the next diagonal tile in LDS, factors it, inverts the factor, publishes both, raises
-//                            ready[k+1];
-//   (i, k+1), i > k+1:       its tile is the final A_i,k+1: it waits for ready[k+1] (blockIdx 0 was dispatched before it, so the
-//                            wait cannot deadlock), multiplies by L_k+1,k+1^-T and stores the factor tile X_i,k+1 to W2 -- the
-//                            "triangular solve" of the next block column rides in the tail of this launch;
-//   everything else:         writes C_ij back to W.
-__global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W, double *__restrict__ W2, double *__restrict__ Ldiag, int ld, int nb,
-                                                         int k, int *__restrict__ ready, double *__restrict__ scal)
+// The factorisation as ONE launch, a dataflow over tiles.  Workgroup = tile (i, j), 0 <= j <= i <= nb (block row nb = the
+// right-hand side), dispatched column by column (diagonal tile first):
+//   * its tile C_ij stays in the MFMA accumulators while it subtracts  X_i,kk X_j,kk'  for the columns kk left of it, each awaited
+//     through a flag (xready[i][kk]);
+//   * then it becomes a factor tile: it waits for L_jj^-1 (ready[j]), multiplies by it and stores X_ij to W2 (raises xready[i][j]);
+//   * the FIRST tile below the diagonal, (j+1, j), goes on: it holds X_j+1,j -- the last thing the next diagonal tile is waiting
+//     for -- so it subtracts X X' from that tile itself (fetched beforehand: tile (j+1, j+1) stops one step early and publishes
+//     its partial sum, dpart[j+1]), factors it (tile_potrf64), inverts the factor (inv64) and raises ready[j+1].  The pivot chain
+//     thus runs  ... -> L_jj^-1 -> X_j+1,j -> L_j+1,j+1^-1 -> ...  inside one workgroup per column, with ONE flag between columns
+//     (31 us -> 22 us per column against handing X_j+1,j to the diagonal tile's own workgroup: a flag, a 32 KB coherent read).
+// Every wait is for a workgroup with a smaller blockIdx, so the chain cannot deadlock whatever part of the grid is resident.
+// History: one trsm + one update launch per block column (round 1, 145 launches) 4.46 ms; one launch per block column 1.97 ms --
+// of each 31 us step ~15 us were two agent-scope releases (L2 write-backs, see st_coh); this kernel 1.5 ms before the merge above.
+__global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, double *__restrict__ W2, double *__restrict__ Ldiag, int ld, int nb,
+                                                    int *__restrict__ ready, int *__restrict__ xcount, int *__restrict__ dpart, double *__restrict__ scal)
 {
     __shared__ double Xi[CB * ULD];
     __shared__ double Xj[CB * ULD];
@@ -229,26 +248,39 @@ __global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W,
     __shared__ double scratch[4][SB * VLD];
     __shared__ double rd[CB];
     __shared__ int fail;
-    const int m = nb - k - 1;  // square trailing block rows
-    int t = blockIdx.x, i, j;
-    // tile order: block column k + 1 first (its workgroups end with a wait and a second product: they must not be dispatched in the
-    // last round), i = k+1 .. nb; then the rest of the trailing triangle row by row, then the rest of the right-hand side's row
-    if (k < 0) { i = t; j = 0; }                        // the first launch only has block column 0 to do
-    else if (t <= m) { i = k + 1 + t; j = k + 1; }
-    else {
-        t -= m + 1;
-        const int tri = (m - 1) * m / 2;                // tiles (i, j), k + 2 <= j <= i <= nb - 1
-        if (t < tri) {
-            int ri = 0, rj = t;
-            while (rj > ri) { rj -= ri + 1; ++ri; }
-            i = k + 2 + ri; j = k + 2 + rj;
-        } else {
-            i = nb; j = k + 2 + (t - tri);
-        }
+    int t = blockIdx.x, i = -1, j = -1;
+    for (int c = 0; c < nb; ++c) {
+        const int cnt = nb - c + 1;
+        if (t < cnt) { i = c + t; j = c; break; }
+        t -= cnt;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // C = A_ij - X_i X_j' in the D layout (this wave: rows 16 wave + (lane >> 4) + 4 g, columns 16 cb + (lane & 15)): the
-    // accumulators start from A_ij -- its loads are in flight together with the X tiles' -- and the product is subtracted
+    if (tid == 0) fail = 0;
+#ifdef ESFM_CHOL_PROFILE
+    const long long t_entry = wall_clock64();
+    long long t_loop = 0; int n_waits = 0;
+#endif
+    __shared__ int seen;
+    auto wait_flag = [&](const int *f, bool urgent, int at_least = 1) {  // thread 0 polls (relaxed) until *f >= at_least, then a workgroup-scope acquire
+        if (tid == 0) {
+            long spins = 0;
+            while ((seen = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < at_least) {
+                if (urgent) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(100);     // (hundreds of resident pollers: the far ones back off)
+                if (++spins > (1L << 27)) { scal[SC_CHOL_FAIL] = 1.0; break; }     // never seen; keeps a broken launch from hanging the device
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto factor_and_publish = [&](double *T, double *O, int c) {      // T: the finished diagonal tile of column c (LDS); O: scratch tile
+        tile_potrf64(T, Vi, rd, &fail);
+        inv64(O, T, Vi, scratch);
+        __syncthreads();
+        publish_diag2(Ldiag + (size_t)c * LSLOT, O);
+        if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
+        publish_flag(&ready[c]);
+    };
+    // C = A_ij in the D layout (this wave: rows 16 wave + (lane >> 4) + 4 g, columns 16 cb + (lane & 15))
     doublex4 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
@@ -257,96 +289,163 @@ __global__ __launch_bounds__(256) void chol2_step_kernel(double *__restrict__ W,
             const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
             acc[cb][g] = (i != j || c <= r) ? W[(size_t)(i * CB + r) * ld + j * CB + c] : 0.0;
         }
-    if (tid == 0) fail = 0;
-    if (k >= 0) {
-        for (int e = tid; e < CB * CB; e += 256) {
-            const int r = e / CB, c = e % CB;
-            Xi[r * ULD + c] = W2[(size_t)(i * CB + r) * ld + k * CB + c];
-            if (j != i) Xj[r * ULD + c] = W2[(size_t)(j * CB + r) * ld + k * CB + c];
+    const bool diag = i == j;
+    const int kk_end = diag ? j - 1 : j;               // a diagonal tile leaves its last step to the workgroup that produces X_j,j-1
+    // xcount[r] = number of factor tiles of block row r that are in W2 (they appear in column order): one poll per row tells how
+    // many steps can run without waiting -- a tile dispatched late has dozens of columns to catch up with.  The factor tiles are
+    // read with plain loads: nobody reads one before its flag, so no cache holds an older copy, and the many readers share L2.
+    // The loop is software-pipelined through registers: the loads of step kk + 1 are in flight during the MFMAs of step kk
+    // (11 us -> ~6 us per step; with one workgroup per CU nothing else hides the latency).
+    int have = 0;
+    double rx[CB * CB / 256], ry[CB * CB / 256];
+    auto ensure = [&](int kk, bool block) -> bool {   // are X_i,kk and X_j,kk there?  (block: wait for them)
+        if (kk < have) return true;
+        const bool urgent = j - kk <= 2;               // the next columns' tiles are the critical chain
+#ifdef ESFM_CHOL_PROFILE
+        ++n_waits;
+#endif
+        wait_flag(&xcount[i], urgent, block ? kk + 1 : 0);
+        have = seen;
+        if (!diag) { __syncthreads(); wait_flag(&xcount[j], urgent, block ? kk + 1 : 0); have = min(have, seen); }
+        __syncthreads();
+        return kk < have;
+    };
+    auto fetch = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < CB * CB / 256; ++q) {
+            const int e = tid + 256 * q, r = e / CB, c = e % CB;
+            rx[q] = W2[(size_t)(i * CB + r) * ld + kk * CB + c];
+            if (!diag) ry[q] = W2[(size_t)(j * CB + r) * ld + kk * CB + c];
+        }
+    };
+    bool fetched = false;
+    if (kk_end > 0) { ensure(0, true); fetch(0); fetched = true; }
+    for (int kk = 0; kk < kk_end; ++kk) {
+        if (!fetched) { ensure(kk, true); fetch(kk); }
+#pragma unroll
+        for (int q = 0; q < CB * CB / 256; ++q) {
+            const int e = tid + 256 * q, r = e / CB, c = e % CB;
+            Xi[r * ULD + c] = rx[q];
+            if (!diag) Xj[r * ULD + c] = ry[q];
         }
         __syncthreads();
-        strip_pqt64<true>(acc, Xi, (j != i) ? Xj : Xi, wave, lane);
-        if (i == j) {                // (the part above the diagonal of a diagonal tile is not stored)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-                    if (c > r) acc[cb][g] = 0.0;
-                }
-        }
+        fetched = kk + 1 < kk_end && ensure(kk + 1, false);
+        if (fetched) fetch(kk + 1);
+        strip_pqt64<true>(acc, Xi, diag ? Xi : Xj, wave, lane);
+        __syncthreads();               // every wave is past its reads of Xi / Xj
     }
-    if (j != k + 1) {
+#ifdef ESFM_CHOL_PROFILE
+    t_loop = wall_clock64();
+    if (tid == 0 && ((i == 26 && j == 25) || (i == 30 && j == 25) || (i == 26 && j == 26)))
+        printf("tile(%d,%d): entry %lld, %d steps done at %lld (%lld us later), polls %d\n", i, j, t_entry % 100000000, kk_end, t_loop % 100000000, (t_loop - t_entry) / 100, n_waits);
+#endif
+    if (diag) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-                if (i != j || c <= r) W[(size_t)(i * CB + r) * ld + j * CB + c] = acc[cb][g];
+                if (c > r) acc[cb][g] = 0.0;            // (the part above the diagonal is not stored)
             }
+        if (j == 0) {                                   // nothing to its left: factor it here
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
+            __syncthreads();
+            factor_and_publish(Xi, Xj, 0);
+            return;
+        }
+        // the partial sum goes back to W for workgroup (j, j-1) to finish
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+                st_coh(&W[(size_t)(i * CB + r) * ld + j * CB + c], acc[cb][g]);
+            }
+        publish_flag(&dpart[j]);
         return;
     }
-#ifdef ESFM_CHOL_PROFILE
-    long long tq[8]; int nq = 0;
-#define STEP_MARK() do { if (k == 40) tq[nq++] = wall_clock64(); } while (0)
-#else
-#define STEP_MARK() do { } while (0)
-#endif
-    STEP_MARK();
-    __syncthreads();                 // every wave is past its reads of Xi / Xj
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
-    if (i == k + 1) {
-        // the next diagonal tile: factor, invert, publish
-        __syncthreads();
-        STEP_MARK();
-        tile_potrf64(Xi, Vi, rd, &fail);
-        STEP_MARK();
-        inv64(Xj, Xi, Vi, scratch);
-        __syncthreads();
-        STEP_MARK();
-        publish_diag2(Ldiag + (size_t)(k + 1) * LSLOT, Xj);
-        if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&ready[k + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        STEP_MARK();
+    // the first tile below the diagonal also finishes the next diagonal tile: fetch its partial sum while waiting for L_jj^-1
+    const bool next_diag = (i == j + 1 && i < nb);
+    doublex4 dacc[4] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
+    if (next_diag) {
+        wait_flag(&dpart[i], false);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+                dacc[cb][g] = ld_coh(&W[(size_t)(i * CB + r) * ld + i * CB + c]);
+            }
+    }
+    // X_ij = C L_jj^-T once the inverse is there
 #ifdef ESFM_CHOL_PROFILE
-        if (k == 40 && tid == 0) printf("step40 wg0 [10ns]: start..update %lld potrf %lld inv %lld publish %lld (abs end %lld)\n", tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[4]);
+    long long tq[10]; int nq = 0;
+    const bool prof = next_diag && (j == 24 || j == 25);
+#define DF_MARK() do { if (prof && nq < 10) tq[nq++] = wall_clock64(); } while (0)
+#else
+#define DF_MARK() do { } while (0)
 #endif
-        return;
-    }
-    // a tile of the next block column: X_i,k+1 = C L_k+1,k+1^-T once the inverse is there
-    if (tid == 0) {
-        long spins = 0;
-        // relaxed polls (an acquire per poll invalidates caches the other workgroups are working from), one acquire at the end
-        while (__hip_atomic_load(&ready[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1L << 22)) { scal[SC_CHOL_FAIL] = 1.0; break; }     // never seen; keeps a broken launch from hanging the device
-        }
-    }
-    __syncthreads();
-    STEP_MARK();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    DF_MARK();
+    wait_flag(&ready[j], true);
+    DF_MARK();
     {
-        const double *Lk = Ldiag + (size_t)(k + 1) * LSLOT + LINV_OFF;
+        const double *Lk = Ldiag + (size_t)j * LSLOT + LINV_OFF;
         for (int e = tid; e < CB * CB; e += 256) Xj[(e / CB) * ULD + (e % CB)] = Lk[e];
     }
     __syncthreads();
+    DF_MARK();
     doublex4 x[4] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
     strip_pqt64<false>(x, Xi, Xj, wave, lane);
+    DF_MARK();
+    if (!next_diag) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+                st_coh(&W2[(size_t)(i * CB + r) * ld + j * CB + c], x[cb][g]);
+            }
+        publish_flag(&xcount[i], j + 1);
+        return;
+    }
+    // (j+1, j): X goes to LDS as the operand of the next diagonal tile's last step, and to W2 for everybody else (its flag is
+    // raised after the factorisation has been started -- nobody on the critical chain waits for it)
+    __syncthreads();                                    // every wave is past its reads of Xi (C) and Xj (L^-1)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, x[cb], lane);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-            W2[(size_t)(i * CB + r) * ld + (k + 1) * CB + c] = x[cb][g];
+            st_coh(&W2[(size_t)(i * CB + r) * ld + j * CB + c], x[cb][g]);
         }
+    __syncthreads();
+    strip_pqt64<true>(dacc, Xi, Xi, wave, lane);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
+            if (c > r) dacc[cb][g] = 0.0;
+        }
+    __syncthreads();                                    // every wave is past its reads of Xi
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) store_d16(Xj + (16 * wave) * ULD + 16 * cb, ULD, dacc[cb], lane);
+    __syncthreads();
+    DF_MARK();
+    publish_flag(&xcount[i], j + 1);                    // (the X stores above have long been acknowledged)
+    DF_MARK();
+    factor_and_publish(Xj, Xi, i);
 #ifdef ESFM_CHOL_PROFILE
-    STEP_MARK();
-    if (k == 40 && tid == 0 && blockIdx.x == 1) printf("step40 wg1 [10ns]: update-done..flag seen %lld, tail %lld (abs flag seen %lld, end %lld)\n", tq[1] - tq[0], tq[2] - tq[1], tq[1], tq[2]);
+    DF_MARK();
+    if (prof && tid == 0) printf("chain(%d,%d): wait %lld (seen %lld) loadLinv %lld prodX %lld storeX+prodD %lld xflag %lld factor+inv+publish %lld | end %lld\n", i, j,
+                                 tq[1] - tq[0], tq[1] % 100000000, tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5], tq[6] % 100000000);
 #endif
-#undef STEP_MARK
+#undef DF_MARK
 }
 
 // The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles; flags: nb ints,
@@ -376,8 +475,8 @@ __global__ __launch_bounds__(256) void chol2_back_kernel(BADev d, const double *
             }
         }
         __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        if (tid < CB) y[tid] = ybuf[i * CB + tid];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (tid < CB) y[tid] = ld_coh(&ybuf[i * CB + tid]);
         __syncthreads();
         double s = 0.0;
 #pragma unroll
@@ -397,14 +496,12 @@ __global__ __launch_bounds__(256) void chol2_back_kernel(BADev d, const double *
         __syncthreads();
         if (tid < CB) {
             const double yb = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-            ybuf[b * CB + tid] = yb;
+            st_coh(&ybuf[b * CB + tid], yb);
             const bool fail = d.scal[SC_CHOL_FAIL] != 0.0 || gave_up;
             if (b * CB + tid < 6 * d.n_cam) d.y_c[b * CB + tid] = fail ? 0.0 : yb;
             if (gave_up && tid == 0) d.scal[SC_CHOL_FAIL] = 1.0;
         }
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&flags[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        publish_flag(&flags[b]);
     }
 }
 
@@ -595,8 +692,8 @@ int ba_solve_reduced_small(hipStream_t st, const BADev &d, double radius, double
 size_t ba_chol_large_doubles(int n_cam)
 {
     const int n = 6 * n_cam, nb = (n + CB - 1) / CB;
-    // W, W2 (the factor), the diagonal slots, y, flags
-    return 2 * (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT + (size_t)nb * CB + (size_t)nb + 1;
+    // W, W2 (the factor), the diagonal slots, y, flags (y-ready, inverse-ready, partial-diagonal-ready: nb each; factor tiles per block row: nb + 1 ints)
+    return 2 * (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT + (size_t)nb * CB + (size_t)(4 * nb + 2) / 2 + 1;
 }
 
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
@@ -606,17 +703,13 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
     double *W = d.chol, *W2 = W + wsz;
     double *Ldiag = W2 + wsz;
     double *ybuf = Ldiag + (size_t)nb * LSLOT;
-    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);
+    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] y | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row
     const long long tot = (long long)wsz;
     hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag);
     ESFM_HIP_TRY(hipGetLastError());
-    ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * 2 * (size_t)nb, st));     // y-ready and factor-ready
-    for (int k = -1; k < nb - 1; ++k) {
-        // block column k's trailing update; its first workgroup factors and inverts the next diagonal tile, the workgroups of the
-        // next block column turn their tiles into factor tiles (see chol2_step_kernel).  k = -1 starts the chain.
-        const int m = nb - k - 1;
-        hipLaunchKernelGGL(chol2_step_kernel, dim3(k < 0 ? nb + 1 : m * (m + 1) / 2 + m), dim3(256), 0, st, W, W2, Ldiag, ld, nb, k, flags + nb, d.scal);
-    }
+    ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(4 * nb + 1), st));
+    const long long tiles = (long long)nb * (nb + 1) / 2 + nb;           // (i, j), 0 <= j <= i <= nb, j <= nb - 1
+    hipLaunchKernelGGL(chol3_kernel, dim3((unsigned)tiles), dim3(256), 0, st, W, W2, Ldiag, ld, nb, flags + nb, flags + 3 * nb, flags + 2 * nb, d.scal);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(chol2_back_kernel, dim3(nb), dim3(256), 0, st, d, W2, Ldiag, ld, nb, ybuf, flags);
     ESFM_HIP_TRY(hipGetLastError());
