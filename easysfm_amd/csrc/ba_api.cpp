@@ -587,9 +587,12 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             if (int rc = esfm::ba_solve_reduced(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal)) return finish(rc);
         }
         if (int rc = esfm::ba_camera_step(st, d)) return finish(rc);
-        if (int rc = esfm::ba_backsub(st, d)) return finish(rc);
-        // the candidate at full step; bounded problems also need the slope there for the line search
-        if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, constrained)) return finish(rc);
+        // back-substitution; the candidate's cost at full step comes out of the same launch -- bounded problems also need the slope
+        // there for the line search, which is ba_cost's job
+        if (int rc = esfm::ba_backsub(st, d, !constrained, opt.cauchy_a)) return finish(rc);
+        if (constrained) {
+            if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, true)) return finish(rc);
+        }
         if (int rc = S.fetch_scal()) return finish(rc);
         reuse_diagonal = true;
         const double model_cost_change = h[esfm::SC_MODEL_CHANGE];

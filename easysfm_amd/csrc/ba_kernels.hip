@@ -1291,17 +1291,40 @@ __global__ __launch_bounds__(256) void ba_camera_step_kernel(BADev d)
 // trips on an 8-observation track, 43 us on the 25-camera problem; and, from 2^20 observations, two observation-parallel passes
 // joined by f64 atomics.)  A single point with more observations than a chunk holds gets a chunk of its own and loops.
 
-__global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, ScalBase sbase)
+// 1/2 rho(|r|^2) of observation k at the candidate (d.cand_c, point X): what ba_cost_kernel<false> evaluates, here inside the
+// back-substitution that has just produced X (WITH_COST: unbounded problems, where no slope along the step is needed)
+__device__ __forceinline__ void candidate_cost(const BADev &d, int k, const double (&X)[3], double cauchy_a, double &cost, double &bad)
+{
+    const int c = d.obs_cam[k];
+    const float2 uv = d.obs_uv[k];
+    double in4[4];
+    load_intrinsics(d, d.cand_c, c, in4);
+    double cam[6], pt[3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) cam[q] = d.cand_c[6 * (size_t)c + q];
+    transform_point<false>(cam, X, pt, nullptr, nullptr);
+    const double x = pt[0] / pt[2], y = pt[1] / pt[2];
+    const double r0 = (double)uv.x - (x * in4[0] + in4[1]), r1 = (double)uv.y - (y * in4[2] + in4[3]);
+    const double s2 = r0 * r0 + r1 * r1;
+    if (!isfinite(s2)) { bad += 1.0; return; }
+    double rho0, rho1;
+    loss_eval(cauchy_a, s2, rho0, rho1);
+    cost += 0.5 * rho0;
+}
+
+template <bool WITH_COST>
+__global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, ScalBase sbase, double cauchy_a)
 {
     __shared__ double red[8];
     __shared__ double tE[kPtChunkObs][3];
     __shared__ double sps[kPtChunkObs][3];
+    __shared__ double cnd[kPtChunkObs][3];      // WITH_COST: the candidate points of the chunk
     const int tid = threadIdx.x;
     const int p0 = d.pchunk_pt0[blockIdx.x], p1 = d.pchunk_pt0[blockIdx.x + 1];
     const int k0 = d.pt_start[p0], k1 = d.pt_start[p1];
     const int nobs = k1 - k0;
     const size_t n = d.n_obs;
-    double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0;
+    double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0, ccost = 0.0, cbad = 0.0;
     double yk[4] = {0.0, 0.0, 0.0, 0.0};
     if (d.has_calib) {
 #pragma unroll
@@ -1355,6 +1378,10 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, 
                 for (int o = b; o < e; ++o) { g[0] -= tE[o][0]; g[1] -= tE[o][1]; g[2] -= tE[o][2]; }
                 const auto sp = point_step(p, g);
                 sps[tid][0] = sp[0]; sps[tid][1] = sp[1]; sps[tid][2] = sp[2];
+                if (WITH_COST) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) cnd[tid][a] = d.cand_p[3 * (size_t)p + a];      // (this thread's own stores)
+                }
             } else {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -1370,6 +1397,10 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, 
             for (int a = 0; a < 3; ++a) { m0 += Jp[a] * sps[pl][a]; m1 += Jp[3 + a] * sps[pl][a]; }
             mc = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
             gd = m0 * r0 + m1 * r1;
+            if (WITH_COST) {
+                const double X[3] = {cnd[pl][0], cnd[pl][1], cnd[pl][2]};
+                candidate_cost(d, k, X, cauchy_a, ccost, cbad);
+            }
         }
     } else {
         // one point, more observations than threads: strided passes, block-wide sums in a fixed tree
@@ -1393,6 +1424,8 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, 
         if (tid == 0) {
             const auto sp = point_step(p, g);
             sps[0][0] = sp[0]; sps[0][1] = sp[1]; sps[0][2] = sp[2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) cnd[0][a] = d.cand_p[3 * (size_t)p + a];
         }
         __syncthreads();
         for (int k = k0 + tid; k < k1; k += kPtChunkObs) {
@@ -1409,11 +1442,21 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, 
             const double r0 = d.res[k], r1 = d.res[n + k];
             mc -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
             gd += m0 * r0 + m1 * r1;
+            if (WITH_COST) {
+                const double X[3] = {cnd[0][0], cnd[0][1], cnd[0][2]};
+                candidate_cost(d, k, X, cauchy_a, ccost, cbad);
+            }
         }
     }
-    const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
-    const double vals[4] = {mc, ssq, csq, d.constrained ? gd : 0.0};
-    scal_commit<4>(d, sbase, slots, vals, red);
+    if (WITH_COST) {
+        const int slots[6] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD, SC_CAND_COST, SC_CAND_BAD};
+        const double vals[6] = {mc, ssq, csq, d.constrained ? gd : 0.0, ccost, cbad};
+        scal_commit<6>(d, sbase, slots, vals, red);
+    } else {
+        const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
+        const double vals[4] = {mc, ssq, csq, d.constrained ? gd : 0.0};
+        scal_commit<4>(d, sbase, slots, vals, red);
+    }
     if (d.constrained) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
@@ -1746,10 +1789,12 @@ __global__ __launch_bounds__(1024) void ba_publish_scalars_kernel(const double *
     scal_reduce_pending(scal_part, scal_cap, scal, c);
     __syncthreads();
     const int i = threadIdx.x;
-    if (i < SC_COUNT) host[i] = scal[i];
-    __threadfence_system();
+    // system-scope stores (write-through to the pinned host page) ordered against the flag by a workgroup-scope fence (s_waitcnt) and
+    // a barrier: a system-scope release fence here is a write-back of the whole L2 on this part (see ba_chol_large.hip, st_coh)
+    if (i < SC_COUNT) __hip_atomic_store(&host[i], scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static ScalCounts take_counts(const BADev &d)
@@ -1789,13 +1834,20 @@ int ba_camera_step(hipStream_t st, const BADev &d)
     return ESFM_OK;
 }
 
-int ba_backsub(hipStream_t st, const BADev &d)
+int ba_backsub(hipStream_t st, const BADev &d, bool with_cost, double cauchy_a)
 {
     if (d.n_pt <= 0 || d.n_pchunks <= 0) return ESFM_OK;
     ScalBase sbase;
-    const int bs_slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
-    if (int rc = scal_reserve<4>(st, d, bs_slots, d.n_pchunks, sbase)) return rc;
-    hipLaunchKernelGGL(ba_backsub_chunk_kernel, dim3(d.n_pchunks), dim3(kPtChunkObs), 0, st, d, sbase);
+    if (with_cost) {
+        // the candidate's cost comes out of the same launch (SC_CAND_COST / SC_CAND_BAD): no ba_cost pass over the observations
+        const int slots[6] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD, SC_CAND_COST, SC_CAND_BAD};
+        if (int rc = scal_reserve<6>(st, d, slots, d.n_pchunks, sbase)) return rc;
+        hipLaunchKernelGGL(ba_backsub_chunk_kernel<true>, dim3(d.n_pchunks), dim3(kPtChunkObs), 0, st, d, sbase, cauchy_a);
+    } else {
+        const int slots[4] = {SC_MODEL_CHANGE, SC_STEP_SQ_PT, SC_CAND_SQ_PT, SC_GDOTD};
+        if (int rc = scal_reserve<4>(st, d, slots, d.n_pchunks, sbase)) return rc;
+        hipLaunchKernelGGL(ba_backsub_chunk_kernel<false>, dim3(d.n_pchunks), dim3(kPtChunkObs), 0, st, d, sbase, cauchy_a);
+    }
     LAUNCH_CHECK();
     return ESFM_OK;
 }

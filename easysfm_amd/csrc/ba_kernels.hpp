@@ -34,7 +34,7 @@ struct ScalParts {                             // host-side bookkeeping of one p
     bool grad_done = false;                    // the camera part of max|gradient| came with the last linearisation
 };
 struct ScalCounts { int n[SC_SUM_COUNT]; };   // kernel argument: how many partials each slot has pending
-struct ScalBase { int b[4]; };                // kernel argument: first partial index of this launch, per slot it commits
+struct ScalBase { int b[6]; };                // kernel argument: first partial index of this launch, per slot it commits
 
 struct BADev {
     int n_cam = 0, n_pt = 0, n_obs = 0;
@@ -185,7 +185,8 @@ __device__ inline void ba_camera_step_body(const BADev &d, const double *y, doub
 #endif
 
 int ba_camera_step(hipStream_t st, const BADev &d);
-int ba_backsub(hipStream_t st, const BADev &d);
+// with_cost: also 1/2 sum rho of the candidate into SC_CAND_COST / SC_CAND_BAD (what ba_cost(cand_c, cand_p) would add)
+int ba_backsub(hipStream_t st, const BADev &d, bool with_cost, double cauchy_a);
 // with_slope: also the derivative of the cost along (delta_c, delta_p) at (cams, pts) into SC_LS_GRAD
 int ba_cost(hipStream_t st, const BADev &d, int num_cu, const double *cams, const double *pts, double cauchy_a, int slot, int bad_slot,
             bool with_slope = false);
