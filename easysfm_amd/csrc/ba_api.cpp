@@ -589,9 +589,12 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         if (int rc = esfm::ba_camera_step(st, d)) return finish(rc);
         // back-substitution; the candidate's cost at full step comes out of the same launch -- bounded problems also need the slope
         // there for the line search, which is ba_cost's job
-        if (int rc = esfm::ba_backsub(st, d, !constrained, opt.cauchy_a)) return finish(rc);
-        if (constrained) {
-            if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, true)) return finish(rc);
+        // (fused only on small problems: it saves a launch gap, but the chunk kernel's occupancy is LDS-bound and the extra f64
+        // work costs more than ba_cost's own pass from ~1M observations: BA-512 281 us fused against 140 + 42 us)
+        const bool fuse_cost = !constrained && d.n_obs < (1 << 20);
+        if (int rc = esfm::ba_backsub(st, d, fuse_cost, opt.cauchy_a)) return finish(rc);
+        if (!fuse_cost) {
+            if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, constrained)) return finish(rc);
         }
         if (int rc = S.fetch_scal()) return finish(rc);
         reuse_diagonal = true;

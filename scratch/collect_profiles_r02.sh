@@ -6,8 +6,10 @@ cd $R
 O=gpurun_out/prof_r02
 rm -rf $O; mkdir -p $O
 python3 bench.py > $O/bench_line.json 2> $O/bench_stderr.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py --no-cpu-baseline > $O/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py --no-cpu-baseline --no-config45 > $O/bench_prof.log 2>&1
 python3 tools/rocprof_csv_summary.py $O/bench > $O/r02_bench_kernel_stats.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench45 -o bench45 -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/bench45_prof.log 2>&1
+python3 tools/rocprof_csv_summary.py $O/bench45 > $O/r02_bench_config45_kernel_stats.txt
 M="python3 bench.py --steps 2 --warmup 1 --no-ba --no-cpu-baseline --no-config45"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- $M > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- $M > $O/pmc_write.log 2>&1
