@@ -172,7 +172,8 @@ __device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp,
 
 // 256 threads: O (LDS, 64 x 64, row-major ULD) = inverse of the lower-triangular factor T (LDS, ULD) whose diagonal sub-block
 // inverses are in Vi.  Wave j computes block column j:  O_jj = Vi_j,  O_ij = -Vi_i (sum_{m=j}^{i-1} T_im O_mj)  for i > j.
-__device__ __forceinline__ void inv64(double *O, const double *T, const double *Vi, double (*scratch)[SB * VLD])
+// The intermediate sum is parked in O_ij's own place (no scratch: 9 KB of LDS less is what lets two workgroups share a CU).
+__device__ __forceinline__ void inv64(double *O, const double *T, const double *Vi)
 {
     const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
     for (int e = lane; e < SB * CB; e += 64) {          // this wave's block column: zero above the diagonal block, Vi_j on it
@@ -183,11 +184,12 @@ __device__ __forceinline__ void inv64(double *O, const double *T, const double *
     for (int i = j + 1; i < 4; ++i) {
         doublex4 acc = doublex4{0.0, 0.0, 0.0, 0.0};
         for (int m = j; m < i; ++m) acc = pq16(acc, T + (SB * i) * ULD + SB * m, ULD, O + (SB * m) * ULD + SB * j, ULD, 1.0, lane);
-        store_d16(scratch[j], VLD, acc, lane);
+        double *Oij = O + (SB * i) * ULD + SB * j;
+        store_d16(Oij, ULD, acc, lane);
         __builtin_amdgcn_wave_barrier();
-        acc = pq16(doublex4{0.0, 0.0, 0.0, 0.0}, Vi + i * SB * VLD, VLD, scratch[j], VLD, -1.0, lane);
+        acc = pq16(doublex4{0.0, 0.0, 0.0, 0.0}, Vi + i * SB * VLD, VLD, Oij, ULD, -1.0, lane);
         __builtin_amdgcn_wave_barrier();
-        store_d16(O + (SB * i) * ULD + SB * j, ULD, acc, lane);
+        store_d16(Oij, ULD, acc, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -245,7 +247,6 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     __shared__ double Xi[CB * ULD];
     __shared__ double Xj[CB * ULD];
     __shared__ double Vi[4 * SB * VLD];
-    __shared__ double scratch[4][SB * VLD];
     __shared__ double rd[CB];
     __shared__ int fail;
     int t = blockIdx.x, i = -1, j = -1;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     };
     auto factor_and_publish = [&](double *T, double *O, int c) {      // T: the finished diagonal tile of column c (LDS); O: scratch tile
         tile_potrf64(T, Vi, rd, &fail);
-        inv64(O, T, Vi, scratch);
+        inv64(O, T, Vi);
         __syncthreads();
         publish_diag2(Ldiag + (size_t)c * LSLOT, O);
         if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
