@@ -251,8 +251,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
             std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lo[(size_t)a] < lo[(size_t)b]; });
             int64_t total = 0;
             for (int p : perm) total += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
-            static const int chunks_per_cu = [] { const char *e = getenv("ESFM_SCHUR_CHUNKS_PER_CU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? v : 2; }();
-            const int want_chunks = std::max(1, chunks_per_cu * ctx->num_cu);
+            const int want_chunks = std::max(1, 2 * ctx->num_cu);     // (1 to 6 chunks per CU measured alike on BA-512: 0.85-0.89 ms)
             const int64_t per = std::max<int64_t>(1024, (total + want_chunks - 1) / want_chunks);
             slots.reserve((size_t)total);
             int64_t in_chunk = 0;

@@ -664,6 +664,73 @@ __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radiu
     scal_commit<1>(d, sbase, slots, vals, red);
 }
 
+// The fresh-Jacobian variant for large problems, one workgroup per point chunk (pchunk_pt0, <= 256 observations): thread =
+// observation forms its nine products from ONE coalesced read of its Jp / res rows -> LDS; thread = point adds them in observation
+// order (the same order, hence the same bits, as ba_point_prep_kernel's walk over the track) and inverts its block.  Throughput
+// against latency: on BA-512 (3M observations) the walk costs 0.27 ms, this form 0.15 ms; on BA-25 (240k) this form is
+// slower (17.6 us against 12 us: the 3 x 3 inverse's sqrt / divide chain runs in one half-filled wave per chunk), so the
+// launcher picks by size.  A single point with more observations than a chunk holds walks its track like the plain kernel.
+__global__ __launch_bounds__(kPtChunkObs) void ba_point_prep_chunk_kernel(BADev d, double radius, double min_diag, double max_diag, ScalBase sbase)
+{
+    __shared__ double red[8];
+    __shared__ double prod[kPtChunkObs][9];
+    const int tid = threadIdx.x;
+    const int p0 = d.pchunk_pt0[blockIdx.x], p1 = d.pchunk_pt0[blockIdx.x + 1];
+    const int k0 = d.pt_start[p0], k1 = d.pt_start[p1];
+    const int nobs = k1 - k0;
+    const size_t n = d.n_obs;
+    double gmax = 0.0, sing = 0.0;
+    const bool small = nobs <= kPtChunkObs;
+    if (small && tid < nobs) {
+        const int k = k0 + tid;
+        const double j0 = d.Jp[k], j1 = d.Jp[n + k], j2 = d.Jp[2 * n + k];
+        const double j3 = d.Jp[3 * n + k], j4 = d.Jp[4 * n + k], j5 = d.Jp[5 * n + k];
+        const double r0 = d.res[k], r1 = d.res[n + k];
+        prod[tid][0] = j0 * j0 + j3 * j3; prod[tid][1] = j0 * j1 + j3 * j4; prod[tid][2] = j0 * j2 + j3 * j5;
+        prod[tid][3] = j1 * j1 + j4 * j4; prod[tid][4] = j1 * j2 + j4 * j5; prod[tid][5] = j2 * j2 + j5 * j5;
+        prod[tid][6] = j0 * r0 + j3 * r1; prod[tid][7] = j1 * r0 + j4 * r1; prod[tid][8] = j2 * r0 + j5 * r1;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+        const int p = p0 + tid;
+        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        if (e > b) {
+            double A[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+            if (small) {
+                for (int o = b - k0; o < e - k0; ++o) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) A[q] += prod[o][q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) g[q] += prod[o][6 + q];
+                }
+            } else {
+                for (int k = b; k < e; ++k) {
+                    const double j0 = d.Jp[k], j1 = d.Jp[n + k], j2 = d.Jp[2 * n + k];
+                    const double j3 = d.Jp[3 * n + k], j4 = d.Jp[4 * n + k], j5 = d.Jp[5 * n + k];
+                    const double r0 = d.res[k], r1 = d.res[n + k];
+                    A[0] += j0 * j0 + j3 * j3; A[1] += j0 * j1 + j3 * j4; A[2] += j0 * j2 + j3 * j5;
+                    A[3] += j1 * j1 + j4 * j4; A[4] += j1 * j2 + j4 * j5; A[5] += j2 * j2 + j5 * j5;
+                    g[0] += j0 * r0 + j3 * r1; g[1] += j1 * r0 + j4 * r1; g[2] += j2 * r0 + j5 * r1;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) d.EtE[6 * (size_t)p + q] = A[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                d.Etr[3 * (size_t)p + q] = g[q];
+                gmax = fmax(gmax, fabs(g[q] / d.scale_p[3 * (size_t)p + q]));  // gradient of the unscaled problem
+            }
+            sing = point_block_invert(d, p, A, g, radius, min_diag, max_diag);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], gmax);
+    const int slots[1] = {SC_PT_SINGULAR};
+    const double vals[1] = {sing};
+    scal_commit<1>(d, sbase, slots, vals, red);
+}
+
 // Jacobi scaling 1/(1 + sqrt(squared column norm)) from the unscaled linearisation
 // (trust_region_minimizer.cc, iteration 0).  Point norms = diag(E'E); camera norms = diag(F'F).
 __global__ void ba_jacobi_scaling_kernel(BADev d)
@@ -1669,11 +1736,14 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh)
 {
     if (d.n_pt <= 0) return ESFM_OK;
-    // (a chunked variant -- thread = observation forms the nine products from one coalesced read, thread = point adds them from LDS
-    // -- measured 17.6 us against this kernel's 12 us on the 25-camera problem: the 3 x 3 inverse's sqrt / divide chain then runs
-    // in one half-filled wave per chunk)
     ScalBase sbase;
     const int slots[1] = {SC_PT_SINGULAR};
+    if (fresh && d.n_pchunks > 0 && d.n_obs >= (1 << 20)) {        // (see ba_point_prep_chunk_kernel for the crossover)
+        if (int rc = scal_reserve<1>(st, d, slots, d.n_pchunks, sbase)) return rc;
+        hipLaunchKernelGGL(ba_point_prep_chunk_kernel, dim3(d.n_pchunks), dim3(kPtChunkObs), 0, st, d, radius, min_diag, max_diag, sbase);
+        LAUNCH_CHECK();
+        return ESFM_OK;
+    }
     if (int rc = scal_reserve<1>(st, d, slots, div_up(d.n_pt, 64), sbase)) return rc;
     hipLaunchKernelGGL(ba_point_prep_kernel, dim3(div_up(d.n_pt, 64)), dim3(64), 0, st, d, radius, min_diag, max_diag, fresh ? 1 : 0, sbase);
     LAUNCH_CHECK();
@@ -1727,7 +1797,7 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
     const int slab_doubles = nblk * 36 + 6 * d.n_cam;
     const size_t lds_bytes = sizeof(double) * ((size_t)nblk * kSchurPitch + 6 * (size_t)d.n_cam) + sizeof(int) * 6 * (size_t)d.n_cam;
-    static const int schur_threads = [] { const char *e = getenv("ESFM_SCHUR_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
+    constexpr int schur_threads = 1024;     // (512: 39 us, 256: 52 us against 35 us on BA-25 -- every workgroup zeroes and writes out a 96 KB slab)
     const int n_slabs = std::max(1, std::min(num_cu, div_up(d.n_obs, schur_threads)));
     if (lds_bytes <= 156 * 1024 && slabs && (size_t)n_slabs * slab_doubles <= slab_capacity_doubles) {
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_lds_kernel),

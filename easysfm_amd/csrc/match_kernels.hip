@@ -679,6 +679,8 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     // <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-15 |k| being the certificate's bound on |(|q|^2 + key) - d^2|;
     // every row of a group with |q|^2 + k - E(k) > U (1 + 2^-20) -- k its minimum -- is farther than both even after sqrtf's
     // rounding.  Keys only grow with the rank, so the rounds stop at the first one no lane of the wave needs.
+    // (Starting the second workgroup of every CU half a run time late, so that the two never sit in their MFMA-free tails together,
+    // was measured: no gain, 1.51 -> 1.51-1.53 ms.)
     // (The tail is ~6 memory round trips per workgroup and bound by L1 requests -- a load instruction of 64 lanes touches 64
     // different lines; fetching both sets' query rows together would save one trip but needs 128 more VGPRs than there are.)
 #pragma unroll
