@@ -257,10 +257,6 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) fail = 0;
-#ifdef ESFM_CHOL_PROFILE
-    const long long t_entry = wall_clock64();
-    long long t_loop = 0; int n_waits = 0;
-#endif
     __shared__ int seen;
     auto wait_flag = [&](const int *f, bool urgent, int at_least = 1) {  // thread 0 polls (relaxed) until *f >= at_least, then a workgroup-scope acquire
         if (tid == 0) {
@@ -302,9 +298,6 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     auto ensure = [&](int kk, bool block) -> bool {   // are X_i,kk and X_j,kk there?  (block: wait for them)
         if (kk < have) return true;
         const bool urgent = j - kk <= 2;               // the next columns' tiles are the critical chain
-#ifdef ESFM_CHOL_PROFILE
-        ++n_waits;
-#endif
         wait_flag(&xcount[i], urgent, block ? kk + 1 : 0);
         have = seen;
         if (!diag) { __syncthreads(); wait_flag(&xcount[j], urgent, block ? kk + 1 : 0); have = min(have, seen); }
@@ -335,11 +328,6 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
         strip_pqt64<true>(acc, Xi, diag ? Xi : Xj, wave, lane);
         __syncthreads();               // every wave is past its reads of Xi / Xj
     }
-#ifdef ESFM_CHOL_PROFILE
-    t_loop = wall_clock64();
-    if (tid == 0 && ((i == 26 && j == 25) || (i == 30 && j == 25) || (i == 26 && j == 26)))
-        printf("tile(%d,%d): entry %lld, %d steps done at %lld (%lld us later), polls %d\n", i, j, t_entry % 100000000, kk_end, t_loop % 100000000, (t_loop - t_entry) / 100, n_waits);
-#endif
     if (diag) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -382,25 +370,14 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
             }
     }
     // X_ij = C L_jj^-T once the inverse is there
-#ifdef ESFM_CHOL_PROFILE
-    long long tq[10]; int nq = 0;
-    const bool prof = next_diag && (j == 24 || j == 25);
-#define DF_MARK() do { if (prof && nq < 10) tq[nq++] = wall_clock64(); } while (0)
-#else
-#define DF_MARK() do { } while (0)
-#endif
-    DF_MARK();
     wait_flag(&ready[j], true);
-    DF_MARK();
     {
         const double *Lk = Ldiag + (size_t)j * LSLOT + LINV_OFF;
         for (int e = tid; e < CB * CB; e += 256) Xj[(e / CB) * ULD + (e % CB)] = Lk[e];
     }
     __syncthreads();
-    DF_MARK();
     doublex4 x[4] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
     strip_pqt64<false>(x, Xi, Xj, wave, lane);
-    DF_MARK();
     if (!next_diag) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -437,16 +414,8 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) store_d16(Xj + (16 * wave) * ULD + 16 * cb, ULD, dacc[cb], lane);
     __syncthreads();
-    DF_MARK();
     publish_flag(&xcount[i], j + 1);                    // (the X stores above have long been acknowledged)
-    DF_MARK();
     factor_and_publish(Xj, Xi, i);
-#ifdef ESFM_CHOL_PROFILE
-    DF_MARK();
-    if (prof && tid == 0) printf("chain(%d,%d): wait %lld (seen %lld) loadLinv %lld prodX %lld storeX+prodD %lld xflag %lld factor+inv+publish %lld | end %lld\n", i, j,
-                                 tq[1] - tq[0], tq[1] % 100000000, tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5], tq[6] % 100000000);
-#endif
-#undef DF_MARK
 }
 
 // The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles; flags: nb ints,
