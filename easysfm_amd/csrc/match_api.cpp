@@ -89,12 +89,23 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
             if (esfm::l2_bf16_pass(width)) {
                 if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
+                if (int rc = ctx->pair_cnt.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
+                if (int rc = ctx->pair_list.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
+                ESFM_HIP_TRY(hipMemsetAsync(ctx->pair_cnt.ptr, 0, sizeof(int32_t) * (size_t)n_pairs, st));
                 if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>())) return rc;
-                esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
-                if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
-                                                      plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
-                                                      ctx->counters.as<int32_t>(), (int)cap64))
-                    return rc;
+                {
+                    esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
+                    if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
+                                                          plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
+                                                          ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt.as<int32_t>(),
+                                                          ctx->pair_list.as<int32_t>()))
+                        return rc;
+                }
+                if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the pass's own answer in place
+                // certificate failures, binned per pair by the pass: exact re-scan, the pair's queries sharing every train row
+                esfm::KernelTimer tm(ctx, ESFM_K_L2_RESCAN);
+                return esfm::launch_l2_rescan64_pairs(st, desc, dev_tab, n_pairs, ctx->pair_cnt.as<int32_t>(), ctx->pair_list.as<int32_t>(),
+                                                      knn_idx, knn_dist);
             } else {
                 if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
 __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
                                                              const u32x4 *__restrict__ split_q, const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
-                                                             int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap)
+                                                             int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
+                                                             int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
 {
     constexpr int TT = 128, NS = 2, GRP = 4;                     // train rows per LDS tile, query sets of 32 per wave, rows per fold group
     constexpr int DIM = 64, QB = 128 * NS, SLOTS = 16, KS = 4;
@@ -679,96 +680,126 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     // <= U = |q|^2 + kb + E(kb), E(k) = 2^-15 (|q|^2 + max|t|^2) + 2^-15 |k| being the certificate's bound on |(|q|^2 + key) - d^2|;
     // every row of a group with |q|^2 + k - E(k) > U (1 + 2^-20) -- k its minimum -- is farther than both even after sqrtf's
     // rounding.  Keys only grow with the rank, so the rounds stop at the first one no lane of the wave needs.
-    // (Starting the second workgroup of every CU half a run time late, so that the two never sit in their MFMA-free tails together,
-    // was measured: no gain, 1.51 -> 1.51-1.53 ms.)
-    // (The tail is ~6 memory round trips per workgroup and bound by L1 requests -- a load instruction of 64 lanes touches 64
-    // different lines; fetching both sets' query rows together would save one trip but needs 128 more VGPRs than there are.)
+    //
+    // The rows come in by LDS-DMA (round 2, second half).  With one row per lane a load instruction touches 64 cache lines and the
+    // L1 looks up about one line per clock: the 160 such instructions per wave kept the texture path busy for ~21 us per workgroup
+    // (measured: 0.40 ms per launch with one workgroup per CU, 0.22 ms with two) and the OTHER workgroup's tile transfers queued
+    // behind them -- with wave-uniform (coalesced) addresses in the same instructions the kernel ran 0.10 ms faster.  Now 16 lanes
+    // fetch one 256-B row (4 rows = 1 KiB per wave instruction, every line touched once) into the wave's quarter of the idle tile
+    // area, XOR-swizzled on the source side like the tiles, and lane l reads "its" row back with 16 conflict-free ds_read_b128; the
+    // row of sub-round u + 1 is in flight while row u is compared.  A wave's chain is now latency-bound (ten sub-rounds of
+    // ~1.3 us), which costs little: the other workgroup of the CU alone keeps the matrix pipe 93 % busy (measured, one workgroup
+    // per CU without tail: 1.39 ms against 1.29).  Measured: 1.50-1.52 -> 1.42-1.44 ms per launch.
+    // (Measured and dropped: s_setprio 3 for the main loop / 0 for the tail, 1.50 ms; the query rows by per-lane loads in the
+    // shadow of the first row transfer instead of their own sub-round, 1.50 ms -- 32 lines per instruction are enough to disturb
+    // the tile transfers again; starting the second workgroup of every CU half a run time late, no gain.)
+    __syncthreads();   // every wave is through its last tile: the tile area becomes four private 16-KiB landing zones
+    const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
+    const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);
+    const uint32_t lds_land = lds_tile_addr + (uint32_t)wave_s * 16384u;
+    const float4 *land = reinterpret_cast<const float4 *>(smem) + (size_t)wave * 1024;
+    int swz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
-        Cand b0 = {FLT_MAX, -1, 0.f}, b1 = {FLT_MAX, -1, 0.f};
+        // the two best (distance, index, d^2) as plain scalars, updated without a branch (the struct form went through scratch
+        // memory here, and every scratch access waits for the row transfer in flight)
+        float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
+        auto insert2 = [&](bool valid, float d, int i, float d2) {
+            const bool c1 = valid && (b1i < 0 || d < b1d || (d == b1d && i < b1i));
+            const bool c0 = valid && (b0i < 0 || d < b0d || (d == b0d && i < b0i));
+            b1d = c0 ? b0d : (c1 ? d : b1d); b1i = c0 ? b0i : (c1 ? i : b1i); b1q = c0 ? b0q : (c1 ? d2 : b1q);
+            b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
+        };
+        // the 32 query rows of this set -> landing slots 0..31 (lanes j and j + 32 read the same slot); the group ranking below
+        // runs in the transfer's shadow
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
         const Master mst = master_load(s);
         const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
-        {
-            const float vk[3] = {mst.v0, mst.v1, mst.v2};
-            const int g0[3] = {group_row0_of(mst.v0, mst.c0), group_row0_of(mst.v1, mst.c1), group_row0_of(mst.v2, mst.c2)};
-            float pk[3]; int pg[3], rank_own[3], rank_par[3];
+        const float vk[3] = {mst.v0, mst.v1, mst.v2};
+        const int g0[3] = {group_row0_of(mst.v0, mst.c0), group_row0_of(mst.v1, mst.c1), group_row0_of(mst.v2, mst.c2)};
+        float pk[3]; int pg[3], rank_own[3], rank_par[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
+        for (int i = 0; i < 3; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
-                rank_own[i] = i; rank_par[i] = i;
+        for (int i = 0; i < 3; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
+            rank_own[i] = i; rank_par[i] = i;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    rank_own[i] += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
-                    rank_par[i] += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
-                }
+            for (int k = 0; k < 3; ++k) {
+                rank_own[i] += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
+                rank_par[i] += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
             }
-            const float kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));
-            const double qn = (double)qnorm_s;
-            const double e1 = (qn + (double)tmax) * (1.0 / 32768.0);
-            constexpr double kTrunc = 1.0001 / 32768.0;   // |key - s| < 2^8 ulp(s) <= 2^-15 |s|: 8 mantissa bits hold the position code
-            const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
-            const float4 *qp = reinterpret_cast<const float4 *>(Q + (size_t)(qvalid ? qrow : 0) * DIM);
-            float4 qv[16];
+        }
+        const float kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));
+        const double qn = (double)qnorm_s;
+        const double e1 = (qn + (double)tmax) * (1.0 / 32768.0);
+        constexpr double kTrunc = 1.0001 / 32768.0;
+        const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
+        float4 qv[16];
+        lds_dma_wait();
 #pragma unroll
-            for (int c = 0; c < 16; ++c) qv[c] = qp[c];
-            for (int r = 0; r < 3; ++r) {
-                const int want = 2 * r + h;
-                float key = kBig; int row0 = -1;
+        for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
+        for (int r = 0; r < 3; ++r) {
+            const int want = 2 * r + h;
+            float key = kBig; int row0 = -1;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
-                    if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
+            for (int i = 0; i < 3; ++i) {
+                if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
+                if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
+            }
+            const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
+            const bool need = row0 >= 0 && qvalid && !cannot;
+            if (__ballot(need) == 0ull) break;
+            // 16 lanes fetch one 256-B row: DMA instruction i serves the lanes 4 i .. 4 i + 3 (their row of sub-round u)
+            const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
+            int rowsrc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (swz[i & 3] & 255);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents are in registers
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                float4 ra_[16];
+                lds_dma_wait();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) ra_[c] = land[lane * 16 + (c ^ (lane & 15))];
+                if (u + 1 < GRP) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
                 }
-                const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-                const bool need = row0 >= 0 && qvalid && !cannot;
-                if (__ballot(need) == 0ull) break;      // (measured on M-SURF-4k: round 0 in every workgroup, round 1 in one of ten)
-                if (need) {
-                    // four consecutive 256-B rows, two at a time (their 32 loads in flight together); a group at the end of the
-                    // train set may reach into the padding: clamped address, result dropped
-#pragma unroll
-                    for (int u = 0; u < GRP; u += 2) {
-                        const int ta_ = row0 + u, tb_ = row0 + u + 1;
-                        const float4 *pa = reinterpret_cast<const float4 *>(T + (size_t)min(ta_, nt - 1) * DIM);
-                        const float4 *pb = reinterpret_cast<const float4 *>(T + (size_t)min(tb_, nt - 1) * DIM);
-                        float4 ra_[16], rb_[16];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) ra_[c] = pa[c];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) rb_[c] = pb[c];
-                        const float da = l2sqr64_canonical_regs(qv, ra_), db = l2sqr64_canonical_regs(qv, rb_);
-                        if (ta_ < nt) best2_insert(b0, b1, sqrt_rn_f32(da), ta_, da);
-                        if (tb_ < nt) best2_insert(b0, b1, sqrt_rn_f32(db), tb_, db);
-                    }
-                }
+                const float da = l2sqr64_canonical_regs(qv, ra_);
+                const int ta_ = row0 + u;
+                insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
             }
         }
         {
-            // the other half-wave evaluated the other groups of this query: merge its two best ((distance, index) is a total order)
-            const float pd0 = __shfl_xor(b0.d, 32), pq0 = __shfl_xor(b0.d2, 32), pd1 = __shfl_xor(b1.d, 32), pq1 = __shfl_xor(b1.d2, 32);
-            const int pi0 = __shfl_xor(b0.i, 32), pi1 = __shfl_xor(b1.i, 32);
-            best2_insert(b0, b1, pd0, pi0, pq0);
-            best2_insert(b0, b1, pd1, pi1, pq1);
+            const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
+            const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
+            insert2(pi0 >= 0, pd0, pi0, pq0);
+            insert2(pi1 >= 0, pd1, pi1, pq1);
         }
-        const float tau = fminf(mst.v2, __shfl_xor(mst.v2, 32));  // every train outside the 6 kept groups has key >= its group's key >= tau
+        const float tau = fminf(mst.v2, __shfl_xor(mst.v2, 32));
         if (qvalid && h == 0) {
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
-            knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
-            knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
-            // Certificate: |(|q|^2 + s(t)) - D(t)| <= 2^-15 (|q|^2 + max|t|^2) for every train t -- split 193 u,
-            // bf16-MFMA accumulation 36 u (3 u per MFMA; measured 0.75 u, profiles/r01_ubench_bf16_acc.txt), norms and the
-            // canonical distance 96 u, of |q|^2 + 2 |t|^2 at most; keys are s with 8 mantissa bits replaced (< 2^-15 |s|).
+            knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
+            knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
             bool certified = !(tau < 1.0e38f);
-            if (!certified && b1.i >= 0) {
-                const double qn = (double)qnorm_s;
+            if (!certified && b1i >= 0) {
                 const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0001 / 32768.0);
-                certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
+                certified = (qn + (double)tau - eps) > (double)b1q * (1.0 + 1.0 / 2097152.0);
             }
             if (!certified) {
                 const int slot = atomicAdd(&counters[0], 1);
                 if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
+                pair_list[pd.out_off + atomicAdd(&pair_cnt[pi], 1)] = qrow;
             }
         }
     }
@@ -875,6 +906,125 @@ __global__ __launch_bounds__(256) void l2_rescan64_kernel(const float *__restric
             knn_idx[o] = a0.i; knn_idx[o + 1] = a1.i;
             knn_dist[o] = a0.i >= 0 ? a0.d : FLT_MAX;
             knn_dist[o + 1] = a1.i >= 0 ? a1.d : FLT_MAX;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The re-scan of l2_knn_bf16_kernel's uncertified queries, pair by pair.  l2_rescan64_kernel above streams a whole train set per
+// QUERY (662 MiB through the L2s for the 662 queries of M-SURF-4k, 295 GB for the 148 k of M-SURF-8k) with one row per lane: a
+// load instruction touches 64 cache lines, and the L1 looks up one line per clock -- measured, a workgroup's pass over 1 MiB
+// took ~50 us whatever else the chip was doing.  Here
+//  * a workgroup takes up to `chunk` uncertified queries of ONE pair (the distance pass bins them per pair) and every train row
+//    is compared with all of them; workgroup (p, c) of the chunks_per_pair workgroups of pair p takes the chunks c,
+//    c + chunks_per_pair, ... of the pair's list, so one pair with thousands of uncertified queries (duplicated descriptors)
+//    still spreads over the chip;
+//  * train rows come in by LDS-DMA, 16 lanes per 256-B row (4 rows = 1 KiB per wave instruction, every line touched once), XOR
+//    swizzled on the source side like the distance pass's tiles; a wave stages exactly the 64 rows its own lanes consume -- lane l
+//    reads row l back with 16 conflict-free ds_read_b128 -- so no workgroup barrier is involved, and the next 64 rows are in
+//    flight into the same LDS slice while the current ones (now in registers) are compared;
+//  * the queries are read through the scalar cache (their address is wave-uniform): no vector registers; a thread's two best
+//    keys per query live in LDS (a private 16-B slot per query: the query loop is a real loop, NQ x 4 registers indexed by it
+//    would go to scratch).
+// Same arithmetic as l2_exact_scan_kernel (l2sqr_canonical's 8 chains and final order, sqrtf, (distance, index) order): the
+// result is identical.
+template <int NQ>
+__global__ __launch_bounds__(256) void l2_rescan64_pairs_kernel(const float *__restrict__ desc, const PairDesc *__restrict__ pairs,
+                                                                const int32_t *__restrict__ pair_cnt, const int32_t *__restrict__ pair_list,
+                                                                int chunks_per_pair, int chunk /* <= NQ */, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+{
+    // (distance, train index) as one 64-bit key: distances are >= +0 and not NaN for finite descriptors, so the bit pattern of the
+    // float orders like the float and key order is the (distance, index) order of best2_insert; the two smallest keys are kept
+    // without a branch.  ~0 is the empty slot (index -1).
+    typedef unsigned long long u64;
+    constexpr u64 kEmpty = ~0ull;
+    auto key_of = [](float d, int t) { return ((u64)__float_as_uint(d) << 32) | (u64)(uint32_t)t; };
+    auto insert2 = [](u64 &b0, u64 &b1, u64 k) {
+        const u64 hi = k > b0 ? k : b0;
+        b0 = k > b0 ? b0 : k;
+        b1 = hi < b1 ? hi : b1;
+    };
+    __shared__ int s_qrow[NQ];
+    __shared__ u64 s_k[2][NQ][4];
+    extern __shared__ __attribute__((aligned(16))) char smem_rescan[];
+    float4 *s_rows = reinterpret_cast<float4 *>(smem_rescan);                                 // [4 waves][64 rows][16 slots]
+    ulonglong2 *s_state = reinterpret_cast<ulonglong2 *>(smem_rescan + 4 * 64 * 256);         // [NQ][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x / chunks_per_pair, c0 = blockIdx.x - p * chunks_per_pair;
+    const PairDesc pd = pairs[p];
+    const int cnt = min(pair_cnt[p], pd.nq);
+    if (c0 * chunk >= cnt) return;
+    const float *Q = desc + (size_t)pd.q_row0 * 64;
+    const u32x4 trsrc = raw_buffer_rsrc(desc + (size_t)pd.t_row0 * 64, (uint32_t)pd.nt * 256u);   // rows past nt read as zeros
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lds_rows = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_rows) + (uint32_t)wave_s * (64 * 256);
+    const float4 *my_row = s_rows + (size_t)(wave * 64 + lane) * 16;
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * i + (lane >> 4);                       // rows 16 apart share the swizzle
+        voff[i] = row * 256 + (((lane & 15) ^ (row & 15)) * 16);
+    }
+    const int ngroups = (pd.nt + 255) / 256;                       // 256 train rows per step of the workgroup, 64 per wave
+    auto dma_rows = [&](int g) {
+        // the whole offset travels in the per-lane operand, which is what the descriptor's range check covers
+        const int base = (g * 256 + wave_s * 64) * 256;            // byte offset of this wave's 64 rows
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds_dma_b128(lds_rows + (uint32_t)i * 1024u, voff[i & 3] + base + (i >> 2) * (16 * 256), trsrc, 0);
+    };
+    for (int c = c0; c * chunk < cnt; c += chunks_per_pair) {
+        const int nqc = min(chunk, cnt - c * chunk);       // workgroup-uniform
+        if (tid < nqc) s_qrow[tid] = pair_list[pd.out_off + c * chunk + tid];
+        for (int k = 0; k < nqc; ++k) s_state[k * 256 + tid] = make_ulonglong2(kEmpty, kEmpty);
+        if (ngroups > 0) dma_rows(0);
+        __syncthreads();
+        for (int g = 0; g < ngroups; ++g) {
+            const int t = g * 256 + wave * 64 + lane;
+            float4 ta[16];
+            lds_dma_wait();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ta[j] = my_row[j ^ (lane & 15)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slice is in registers: the next rows may overwrite it
+            if (g + 1 < ngroups) dma_rows(g + 1);
+            for (int k = 0; k < nqc; ++k) {
+                const float *__restrict__ qk = Q + (size_t)__builtin_amdgcn_readfirstlane(s_qrow[k]) * 64;
+                float aa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float av[8] = {ta[2 * j].x, ta[2 * j].y, ta[2 * j].z, ta[2 * j].w, ta[2 * j + 1].x, ta[2 * j + 1].y, ta[2 * j + 1].z, ta[2 * j + 1].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float da = __fsub_rn(qk[8 * j + e], av[e]);
+                        aa[e] = __fadd_rn(aa[e], __fmul_rn(da, da));
+                    }
+                }
+                const float da = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(aa[0], aa[4]), __fadd_rn(aa[1], aa[5])), __fadd_rn(aa[2], aa[6])), __fadd_rn(aa[3], aa[7]));
+                ulonglong2 st = s_state[k * 256 + tid];
+                insert2(st.x, st.y, t < pd.nt ? key_of(sqrt_rn_f32(da), t) : kEmpty);
+                s_state[k * 256 + tid] = st;
+            }
+        }
+        for (int k = 0; k < nqc; ++k) {
+            const ulonglong2 st = s_state[k * 256 + tid];
+            u64 x0 = st.x, x1 = st.y;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 y0 = __shfl_xor(x0, o), y1 = __shfl_xor(x1, o);
+                insert2(x0, x1, y0);
+                insert2(x0, x1, y1);
+            }
+            if (lane == 0) { s_k[0][k][wave] = x0; s_k[1][k][wave] = x1; }
+        }
+        __syncthreads();
+        if (tid < nqc) {
+            u64 x0 = kEmpty, x1 = kEmpty;
+            for (int w = 0; w < 4; ++w) { insert2(x0, x1, s_k[0][tid][w]); insert2(x0, x1, s_k[1][tid][w]); }
+            const size_t o = 2 * ((size_t)pd.out_off + s_qrow[tid]);
+            const int i0 = (int)(uint32_t)x0, i1 = (int)(uint32_t)x1;
+            knn_idx[o] = i0; knn_idx[o + 1] = i1;
+            knn_dist[o] = i0 >= 0 ? __uint_as_float((uint32_t)(x0 >> 32)) : FLT_MAX;
+            knn_dist[o + 1] = i1 >= 0 ? __uint_as_float((uint32_t)(x1 >> 32)) : FLT_MAX;
         }
         __syncthreads();
     }
@@ -1223,6 +1373,7 @@ bool l2_bf16_pass(int dim)
     static const bool forced_f32 = [] { const char *e = getenv("ESFM_L2_PASS"); return e && strcmp(e, "f32") == 0; }();
     return dim == 64 && !forced_f32;
 }
+constexpr int kL2RescanQueries = 8;   // uncertified queries of one pair that share a pass over the train set (l2_rescan64_pairs_kernel)
 constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_kernel (1: 3 waves per SIMD, measured 7-15 % slower)
 int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
@@ -1240,7 +1391,8 @@ int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows
 }
 
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
-                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap)
+                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
+                       int32_t *pair_cnt, int32_t *pair_list)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
@@ -1248,7 +1400,25 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     hipLaunchKernelGGL(l2_knn_bf16_kernel, dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
                        reinterpret_cast<const u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, pairs,
-                       n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap);
+                       n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *pairs, int n_pairs, const int32_t *pair_cnt,
+                             const int32_t *pair_list, int32_t *knn_idx, float *knn_dist)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    // about 4096 workgroups whatever the pair count: a workgroup without work leaves after one load.  Few pairs: the launch is as
+    // long as its longest workgroup, so the chunks are small (more workgroups, every train row loaded more often); many pairs:
+    // throughput counts, the chunks are as large as the kernel's LDS allows.
+    const int chunks_per_pair = std::max(1, std::min(512, 4096 / n_pairs));
+    ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_rescan64_pairs_kernel<kL2RescanQueries>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256 + kL2RescanQueries * 256 * 16));
+    const int chunk = n_pairs >= 2048 ? kL2RescanQueries : 2;
+    hipLaunchKernelGGL(l2_rescan64_pairs_kernel<kL2RescanQueries>, dim3((unsigned)n_pairs * (unsigned)chunks_per_pair), dim3(256),
+                       (size_t)4 * 64 * 256 + (size_t)chunk * 256 * 16, st, desc, pairs,
+                       pair_cnt, pair_list, chunks_per_pair, chunk, knn_idx, knn_dist);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

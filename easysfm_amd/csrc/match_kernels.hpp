@@ -26,7 +26,11 @@ size_t l2_split_bytes(int dim, long long total_rows);
 // writes the hi/lo image AND the row norms
 int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms);
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
-                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap);
+                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
+                       int32_t *pair_cnt, int32_t *pair_list);
+// exact re-scan of the queries launch_l2_knn_bf16 binned per pair (pair_cnt[p] entries at pair_list[out_off[p]...])
+int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *pairs, int n_pairs, const int32_t *pair_cnt,
+                             const int32_t *pair_list, int32_t *knn_idx, float *knn_dist);
 int launch_l2_exact_scan(hipStream_t st, int dim, const float *desc, const PairDesc *pairs, int n_pairs,
                          const int32_t *flagged, const int32_t *counters, long long total_queries, int grid,
                          int32_t *knn_idx, float *knn_dist);
