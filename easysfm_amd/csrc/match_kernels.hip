@@ -130,6 +130,8 @@ __device__ __forceinline__ float l2sqr_canonical(const float *__restrict__ a, co
 }
 
 // l2sqr_canonical for 64-float rows held in registers: the same 8 chains, the same final order.
+// (Measured in the distance pass's tail: the packed form below made the whole kernel 1.5 % SLOWER -- 1.499 -> 1.522 ms; the
+// tail's arithmetic runs beside the other workgroup's MFMAs and the chip is power-limited there -- so the tail keeps this one.)
 __device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], const float4 (&b)[16])
 {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -151,6 +153,9 @@ __device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], c
     d = __fadd_rn(d, s2);
     return __fadd_rn(d, s3);
 }
+// The same with two neighbouring chains per packed instruction (v_pk_add_f32 / v_pk_mul_f32: every half is an IEEE single
+// operation, the result is bit-identical): the re-scan kernels, which have the chip to themselves, run on these.
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 // Correctly rounded f32 square root.  NOT __fsqrt_rn: in this toolchain that maps to
 // __ocml_native_sqrt_f32 (about 1 ulp), while sqrtf is IEEE-exact under hipcc's default
@@ -989,17 +994,19 @@ __global__ __launch_bounds__(256) void l2_rescan64_pairs_kernel(const float *__r
             if (g + 1 < ngroups) dma_rows(g + 1);
             for (int k = 0; k < nqc; ++k) {
                 const float *__restrict__ qk = Q + (size_t)__builtin_amdgcn_readfirstlane(s_qrow[k]) * 64;
-                float aa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // l2sqr64_canonical_regs with the query in SGPRs
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float av[8] = {ta[2 * j].x, ta[2 * j].y, ta[2 * j].z, ta[2 * j].w, ta[2 * j + 1].x, ta[2 * j + 1].y, ta[2 * j + 1].z, ta[2 * j + 1].w};
+                    const float2v av[4] = {{ta[2 * j].x, ta[2 * j].y}, {ta[2 * j].z, ta[2 * j].w}, {ta[2 * j + 1].x, ta[2 * j + 1].y}, {ta[2 * j + 1].z, ta[2 * j + 1].w}};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float da = __fsub_rn(qk[8 * j + e], av[e]);
-                        aa[e] = __fadd_rn(aa[e], __fmul_rn(da, da));
+                    for (int e = 0; e < 4; ++e) {
+                        const float2v qe = {qk[8 * j + 2 * e], qk[8 * j + 2 * e + 1]};
+                        const float2v d = qe - av[e];
+                        acc[e] = acc[e] + d * d;
                     }
                 }
-                const float da = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(aa[0], aa[4]), __fadd_rn(aa[1], aa[5])), __fadd_rn(aa[2], aa[6])), __fadd_rn(aa[3], aa[7]));
+                const float2v s01 = acc[0] + acc[2], s23 = acc[1] + acc[3];
+                const float da = __fadd_rn(__fadd_rn(__fadd_rn(s01.x, s01.y), s23.x), s23.y);
                 ulonglong2 st = s_state[k * 256 + tid];
                 insert2(st.x, st.y, t < pd.nt ? key_of(sqrt_rn_f32(da), t) : kEmpty);
                 s_state[k * 256 + tid] = st;
