@@ -198,6 +198,37 @@ def test_batched_pairs_match_single_calls(gpu_ctx, oracle_lib):
     assert 0 <= n_rescan <= n_q
 
 
+def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
+    """The re-scan of uncertified queries works pair by pair, in chunks of the pair's list (l2_rescan64_pairs_kernel); launches
+    of 2048 pairs and more use the large chunks and ONE workgroup per pair that loops over them.  70 small sets full of
+    duplicated rows: 2415 pairs, nearly every query uncertified (more duplicates than the pass keeps candidates), tens of
+    chunks per pair -- every pair against the oracle, bit for bit."""
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((12, 64)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    sets = []
+    for i in range(70):
+        n = 80 + (i % 5) * 9
+        x = base[rng.integers(0, 12, n)].copy()
+        fresh = rng.random(n) < 0.15
+        x[fresh] = rng.standard_normal((int(fresh.sum()), 64)).astype(np.float32)
+        x[fresh] /= np.linalg.norm(x[fresh], axis=1, keepdims=True)
+        sets.append(np.ascontiguousarray(x))
+    pairs = synth.all_pairs(70)
+    assert len(pairs) >= 2048
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
+    pm = E.PairMatcher(bank, pairs)
+    idx, dist = pm.knn2()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    n_q, n_rescan = pm.stats()
+    assert n_rescan > n_q // 2          # the case is about the re-scan
+    off = pm.offset
+    for k, (i, j) in enumerate(pairs):
+        ridx, rdist = oracle_lib.knn2_l2(sets[i], sets[j])
+        sl = slice(int(off[k]), int(off[k + 1]))
+        assert np.array_equal(idx[sl], ridx) and np.array_equal(_bits(dist[sl]), _bits(rdist)), (i, j)
+
+
 def test_full_size_properties(gpu_ctx, oracle_lib):
     """BASELINE size (4096 x 4096 x 64): size-independent checks -- a query that IS a train row
     finds it at distance 0; a sample of rows agrees with the oracle bit for bit; permuting the train
