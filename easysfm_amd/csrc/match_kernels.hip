@@ -698,6 +698,10 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     // (Measured and dropped: s_setprio 3 for the main loop / 0 for the tail, 1.50 ms; the query rows by per-lane loads in the
     // shadow of the first row transfer instead of their own sub-round, 1.50 ms -- 32 lines per instruction are enough to disturb
     // the tile transfers again; starting the second workgroup of every CU half a run time late, no gain.)
+    // The segment code issues the transfer of tile t + 2 unconditionally (a tile that does not exist reads zeros through the
+    // descriptor): the last two of them are still in flight, aimed at rows of the tile area that now become OTHER waves' landing
+    // zones -- every wave drains its own before the barrier.
+    lds_dma_wait();
     __syncthreads();   // every wave is through its last tile: the tile area becomes four private 16-KiB landing zones
     const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
     const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);

@@ -219,6 +219,7 @@ def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
     bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
     pm = E.PairMatcher(bank, pairs)
     idx, dist = pm.knn2()
+    pm.ctx.synchronize()               # the library's own stream: torch's copies below do not wait for it
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     n_q, n_rescan = pm.stats()
     assert n_rescan > n_q // 2          # the case is about the re-scan
