@@ -933,9 +933,10 @@ __global__ __launch_bounds__(256) void l2_rescan64_kernel(const float *__restric
 //    swizzled on the source side like the distance pass's tiles; a wave stages exactly the 64 rows its own lanes consume -- lane l
 //    reads row l back with 16 conflict-free ds_read_b128 -- so no workgroup barrier is involved, and the next 64 rows are in
 //    flight into the same LDS slice while the current ones (now in registers) are compared;
-//  * the queries are read through the scalar cache (their address is wave-uniform): no vector registers; a thread's two best
-//    keys per query live in LDS (a private 16-B slot per query: the query loop is a real loop, NQ x 4 registers indexed by it
-//    would go to scratch).
+//  * the queries sit in LDS and are read as broadcasts (every lane the same address); through the scalar cache -- no vector
+//    registers at all -- the four s_load_dwordx16 of a row came back one after the other into the same SGPRs, ~1 us per query
+//    and group; a thread's two best keys per query live in LDS too (a private 16-B slot per query: the query loop is a real
+//    loop, NQ x 4 registers indexed by it would go to scratch).
 // Same arithmetic as l2_exact_scan_kernel (l2sqr_canonical's 8 chains and final order, sqrtf, (distance, index) order): the
 // result is identical.
 template <int NQ>
@@ -954,6 +955,7 @@ __global__ __launch_bounds__(256) void l2_rescan64_pairs_kernel(const float *__r
         b0 = k > b0 ? b0 : k;
         b1 = hi < b1 ? hi : b1;
     };
+    __shared__ float4 s_q[NQ][16];
     __shared__ int s_qrow[NQ];
     __shared__ u64 s_k[2][NQ][4];
     extern __shared__ __attribute__((aligned(16))) char smem_rescan[];
@@ -984,7 +986,11 @@ __global__ __launch_bounds__(256) void l2_rescan64_pairs_kernel(const float *__r
     };
     for (int c = c0; c * chunk < cnt; c += chunks_per_pair) {
         const int nqc = min(chunk, cnt - c * chunk);       // workgroup-uniform
-        if (tid < nqc) s_qrow[tid] = pair_list[pd.out_off + c * chunk + tid];
+        if (tid < nqc * 16) {
+            const int k = tid >> 4, qrow = pair_list[pd.out_off + c * chunk + k];
+            s_q[k][tid & 15] = reinterpret_cast<const float4 *>(Q)[(size_t)qrow * 16 + (tid & 15)];
+            if ((tid & 15) == 0) s_qrow[k] = qrow;
+        }
         for (int k = 0; k < nqc; ++k) s_state[k * 256 + tid] = make_ulonglong2(kEmpty, kEmpty);
         if (ngroups > 0) dma_rows(0);
         __syncthreads();
@@ -997,15 +1003,16 @@ __global__ __launch_bounds__(256) void l2_rescan64_pairs_kernel(const float *__r
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slice is in registers: the next rows may overwrite it
             if (g + 1 < ngroups) dma_rows(g + 1);
             for (int k = 0; k < nqc; ++k) {
-                const float *__restrict__ qk = Q + (size_t)__builtin_amdgcn_readfirstlane(s_qrow[k]) * 64;
-                float2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // l2sqr64_canonical_regs with the query in SGPRs
+                const float4 *qk = s_q[k];       // every lane the same address: LDS broadcast reads
+                float2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // l2sqr64_canonical_regs, packed
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float2v av[4] = {{ta[2 * j].x, ta[2 * j].y}, {ta[2 * j].z, ta[2 * j].w}, {ta[2 * j + 1].x, ta[2 * j + 1].y}, {ta[2 * j + 1].z, ta[2 * j + 1].w}};
+                    const float4 q0 = qk[2 * j], q1 = qk[2 * j + 1];
+                    const float2v qe[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float2v qe = {qk[8 * j + 2 * e], qk[8 * j + 2 * e + 1]};
-                        const float2v d = qe - av[e];
+                        const float2v d = qe[e] - av[e];
                         acc[e] = acc[e] + d * d;
                     }
                 }
@@ -1421,12 +1428,13 @@ int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *
 {
     if (n_pairs <= 0) return ESFM_OK;
     // about 4096 workgroups whatever the pair count: a workgroup without work leaves after one load.  Few pairs: the launch is as
-    // long as its longest workgroup, so the chunks are small (more workgroups, every train row loaded more often); many pairs:
-    // throughput counts, the chunks are as large as the kernel's LDS allows.
+    // long as its longest workgroup (a 16-step latency chain per 4096 train rows), so the chunks are small -- more workgroups, two
+    // per CU; many pairs: throughput counts, the chunks are as large as the kernel's LDS allows (M-SURF-8k-like launch of 2415
+    // pairs: 1.85 ms with chunks of 2, 1.33 with 3, 1.28 with 8).
     const int chunks_per_pair = std::max(1, std::min(512, 4096 / n_pairs));
     ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_rescan64_pairs_kernel<kL2RescanQueries>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256 + kL2RescanQueries * 256 * 16));
-    const int chunk = n_pairs >= 2048 ? kL2RescanQueries : 2;
+    const int chunk = n_pairs >= 2048 ? kL2RescanQueries : 3;     // 3: 64 + 12 + 3 KB of LDS, still two workgroups per CU (measured 1: 69, 2: 65, 3: 60, 4: 92 us)
     hipLaunchKernelGGL(l2_rescan64_pairs_kernel<kL2RescanQueries>, dim3((unsigned)n_pairs * (unsigned)chunks_per_pair), dim3(256),
                        (size_t)4 * 64 * 256 + (size_t)chunk * 256 * 16, st, desc, pairs,
                        pair_cnt, pair_list, chunks_per_pair, chunk, knn_idx, knn_dist);
