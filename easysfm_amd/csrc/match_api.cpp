@@ -36,6 +36,7 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
         d.q_row0 = set_row_offset[qs]; d.nq = set_row_offset[qs + 1] - set_row_offset[qs];
         d.t_row0 = set_row_offset[ts]; d.nt = set_row_offset[ts + 1] - set_row_offset[ts];
         ESFM_REQUIRE(d.nt < (1 << 21), "train sets are limited to 2^21-1 rows");   // index field of the packed top-2 keys
+        ESFM_REQUIRE(d.nq < (1 << 23), "query sets are limited to 2^23-1 rows");   // 32-bit byte offsets into a set (row fetches through buffer descriptors)
         d.out_off = off; d.blk_off = (int32_t)blk; d.pad = 0;
         if (out_offset) out_offset[p] = off;
         off += d.nq;
