@@ -1329,41 +1329,57 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
 // ---------------------------------------------------------------------------------------------
 // Lowe ratio test (feature_matching.cpp:88 / :133: float < double * float, i.e. in double) and an
 // order-preserving compaction: one workgroup per pair, survivors written query-ascending.
-__global__ __launch_bounds__(256) void ratio_compact_kernel(const PairDesc *__restrict__ pairs, const int32_t *__restrict__ knn_idx,
-                                                            const float *__restrict__ knn_dist, double ratio,
-                                                            int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
-                                                            float *__restrict__ distance, int32_t *__restrict__ n_out)
+constexpr int kRatioThreads = 1024, kRatioPer = 4;     // 4096 queries per sweep of the workgroup: one round of loads for a 4096-row set
+__global__ __launch_bounds__(kRatioThreads) void ratio_compact_kernel(const PairDesc *__restrict__ pairs, const int32_t *__restrict__ knn_idx,
+                                                                      const float *__restrict__ knn_dist, double ratio,
+                                                                      int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
+                                                                      float *__restrict__ distance, int32_t *__restrict__ n_out)
 {
-    __shared__ int s_wave[4];
+    // A thread takes kRatioPer CONSECUTIVE queries (their 2-NN records are 32 + 32 contiguous bytes), so the survivors' order is
+    // thread order, then query order inside the thread: an exclusive scan of the threads' counts places them.
+    // (Round 1: 256 threads, one query each, 16 sweeps of three barriers for a 4096-row set: 14 us per launch.)
+    __shared__ int s_wave[kRatioThreads / 64];
     __shared__ int s_base;
     const PairDesc pd = pairs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int q0 = 0; q0 < pd.nq; q0 += 256) {
-        const int q = q0 + tid;
-        bool pass = false;
-        int ti = -1; float d0 = 0.f;
-        if (q < pd.nq) {
-            const size_t o = 2 * ((size_t)pd.out_off + q);
-            const int i0 = knn_idx[o], i1 = knn_idx[o + 1];
-            d0 = knn_dist[o];
-            const float d1 = knn_dist[o + 1];
-            ti = i0;
-            pass = (i0 >= 0) && (i1 >= 0) && ((double)d0 < ratio * (double)d1);
+    for (int q0 = 0; q0 < pd.nq; q0 += kRatioThreads * kRatioPer) {
+        const int qa = q0 + tid * kRatioPer;
+        int ti[kRatioPer]; float d0[kRatioPer]; bool pass[kRatioPer];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < kRatioPer; ++u) {
+            const int q = qa + u;
+            pass[u] = false; ti[u] = -1; d0[u] = 0.f;
+            if (q < pd.nq) {
+                const size_t o = 2 * ((size_t)pd.out_off + q);
+                const int i0 = knn_idx[o], i1 = knn_idx[o + 1];
+                d0[u] = knn_dist[o];
+                const float d1 = knn_dist[o + 1];
+                ti[u] = i0;
+                pass[u] = (i0 >= 0) && (i1 >= 0) && ((double)d0[u] < ratio * (double)d1);
+            }
+            cnt += pass[u] ? 1 : 0;
         }
-        const unsigned long long m = __ballot(pass);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wave] = __popcll(m);
+        // exclusive scan of cnt over the workgroup: inside the wave by shuffles, across waves through LDS
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (pass) {
-            const size_t o = (size_t)pd.out_off + off + before;
-            query_idx[o] = q; train_idx[o] = ti; distance[o] = d0;
+        size_t o = (size_t)pd.out_off + off + (incl - cnt);
+#pragma unroll
+        for (int u = 0; u < kRatioPer; ++u) {
+            if (pass[u]) { query_idx[o] = qa + u; train_idx[o] = ti[u]; distance[o] = d0[u]; ++o; }
         }
         __syncthreads();
-        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 0) { int t = 0; for (int w = 0; w < kRatioThreads / 64; ++w) t += s_wave[w]; s_base += t; }
         __syncthreads();
     }
     if (tid == 0) n_out[blockIdx.x] = s_base;
@@ -1520,7 +1536,7 @@ int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, con
                          double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
 {
     if (n_pairs <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(ratio_compact_kernel, dim3(n_pairs), dim3(256), 0, st, pairs, knn_idx, knn_dist, ratio, query_idx,
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(n_pairs), dim3(kRatioThreads), 0, st, pairs, knn_idx, knn_dist, ratio, query_idx,
                        train_idx, distance, n_out);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
