@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void key_insert_max(uint32_t &m1, uint32_t &m2, uint3
 }
 
 __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned char *__restrict__ ex, const int32_t *__restrict__ start,
-                                                               const PairDesc *__restrict__ pairs, int n_pairs,
+                                                               const uint32_t *__restrict__ packed, const PairDesc *__restrict__ pairs, int n_pairs,
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][kHmTT * 256];   // 256-B rows, 16-B slots XOR-swizzled with row & 15
@@ -1184,11 +1184,18 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         }
         qpop[s] = pop + __shfl_xor(pop, 32);
     }
-    uint32_t m1[2][4], m2[2][4];
+    // Two-level top-2, as in l2_knn_bf16_kernel: a lane's 16 results of a 32-train step are four groups of four consecutive
+    // train rows (accumulator registers 4g .. 4g+3 = rows 8g + 4h + 0..3); the hot loop keeps the two best GROUPS per lane
+    // (key = group maximum << 21 | 2^21 - 1 - (4 step + g): two v_max3, one v_lshl_add, max + med3 = 5 VALU per 4 results instead of
+    // 12), and the tail counts the bits of the kept groups' rows exactly.  No certificate is involved: the scores are exact
+    // integers, the two nearest rows lie in the two groups with the best maxima of the lane half that holds them (a group that
+    // precedes the second nearest row's group in key order contains a row that precedes that row in (distance, index) order, and
+    // there is only one such row), and ties between groups go to the lower train index like ties between rows.
+    uint32_t m1[2][2], m2[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { m1[s][r] = 0u; m2[s][r] = 0u; }
+        for (int r = 0; r < 2; ++r) { m1[s][r] = 0u; m2[s][r] = 0u; }
 
     const int n_tiles = (nt + kHmTT - 1) / kHmTT;
     const int n_full = nt / kHmTT;       // tiles with all 64 rows inside the set: the software-pipelined loop
@@ -1229,23 +1236,25 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         const i32x4 g0 = sp[0], g1 = sp[2], g2 = sp[4], g3 = sp[6];
         return i32x16{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
     };
-    // One 32-train step: 16 MFMAs into (c0, c1), with the top-2 fold of the PREVIOUS step's results (p0, p1) issued
-    // in their shadow -- two inserts (6 VALU) behind each MFMA -- so the matrix pipe and the VALU run concurrently.
-    // pK = 2^21 - 1 - (16 * step number of p): key = acc << 21 + (pK - r)
+    // group g of a step's results p (set s) into the lane's two best groups; pK = 2^21 - 1 - 4 (step number of p)
+    auto group_insert = [&](int s, int g, const i32x16 &p, uint32_t pK) {
+        const int gm = max(max(p[4 * g], p[4 * g + 1]), max(p[4 * g + 2], p[4 * g + 3]));
+        key_insert_max(m1[s][g & 1], m2[s][g & 1], ((uint32_t)gm << 21) + (pK - g));
+    };
+    // One 32-train step: 16 MFMAs into (c0, c1), with the fold of the PREVIOUS step's results (p0, p1) issued in their shadow --
+    // one group insert (5 VALU) behind every second MFMA of a set -- so the matrix pipe and the VALU run concurrently.
     // arow = the lane's train row in LDS; its K-chunk c is the 16-B slot 2 c + h, stored at slot ^ (row & 15) = ^ (j & 15)
     auto step = [&](const unsigned char *arow, const i32x16 &c_init, i32x16 &c0, i32x16 &c1, const i32x16 &p0, const i32x16 &p1, uint32_t pK) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const i32x4 a = *reinterpret_cast<const i32x4 *>(arow + (((2 * c + h) ^ (j & 15)) * 16));
             c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], c == 0 ? c_init : c0, 0, 0, 0);
-            key_insert_max(m1[0][(2 * c) & 3], m2[0][(2 * c) & 3], ((uint32_t)p0[2 * c] << 21) + (pK - 2 * c));
-            key_insert_max(m1[0][(2 * c + 1) & 3], m2[0][(2 * c + 1) & 3], ((uint32_t)p0[2 * c + 1] << 21) + (pK - 2 * c - 1));
+            if (c & 1) group_insert(0, c >> 1, p0, pK);
             c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], c == 0 ? c_init : c1, 0, 0, 0);
-            key_insert_max(m1[1][(2 * c) & 3], m2[1][(2 * c) & 3], ((uint32_t)p1[2 * c] << 21) + (pK - 2 * c));
-            key_insert_max(m1[1][(2 * c + 1) & 3], m2[1][(2 * c + 1) & 3], ((uint32_t)p1[2 * c + 1] << 21) + (pK - 2 * c - 1));
+            if (c & 1) group_insert(1, c >> 1, p1, pK);
         }
     };
-    // start-up placeholders: acc 0 with pK = 15 gives keys 0..15, below every real key (real L < 2^21 - 16)
+    // start-up placeholders: acc 0 with pK = 15 gives keys 12..15, below every real key (real 4 step + g < 2^21 - 16)
     i32x16 pa0, pa1, pb0, pb1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { pb0[r] = 0; pb1[r] = 0; }
@@ -1260,8 +1269,8 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         }
         const unsigned char *arow = &lds[buf][j * 256];
         step(arow, load_start(buf, 0), pa0, pa1, pb0, pb1, pbK);                                        // sub 0, folding the previous tile's sub 1
-        step(arow + 32 * 256, load_start(buf, 1), pb0, pb1, pa0, pa1, kHmLMask - (uint32_t)(tile * 2) * 16u);   // sub 1, folding sub 0
-        pbK = kHmLMask - (uint32_t)(tile * 2 + 1) * 16u;
+        step(arow + 32 * 256, load_start(buf, 1), pb0, pb1, pa0, pa1, kHmLMask - (uint32_t)(tile * 2) * 4u);   // sub 1, folding sub 0
+        pbK = kHmLMask - (uint32_t)(tile * 2 + 1) * 4u;
         __builtin_amdgcn_sched_barrier(0);
         if (more) start_store(buf ^ 1, nxt_start);
         lds_dma_wait();                                                        // the DMA issued above has landed
@@ -1269,11 +1278,9 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
     }
     // drain the pipeline
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        key_insert_max(m1[0][r & 3], m2[0][r & 3], ((uint32_t)pb0[r] << 21) + (pbK - r));
-        key_insert_max(m1[1][r & 3], m2[1][r & 3], ((uint32_t)pb1[r] << 21) + (pbK - r));
-    }
-    // the partial tile at the end of the set, rows past it masked out
+    for (int g = 0; g < 4; ++g) { group_insert(0, g, pb0, pbK); group_insert(1, g, pb1, pbK); }
+    // the partial tile at the end of the set; rows past it are zero-filled with start value 0: their score 0 is the worst there
+    // is, and the tail skips them by index
     if (n_full < n_tiles) {
         const int tile = n_full, buf = tile & 1;
 #pragma unroll 1
@@ -1287,41 +1294,61 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], acc1, 0, 0, 0);
             }
-            const uint32_t K0 = kHmLMask - (uint32_t)(tile * 2 + sub) * 16u;
+            const uint32_t K0 = kHmLMask - (uint32_t)(tile * 2 + sub) * 4u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = (tile * 2 + sub) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool ok = idx < nt;   // zero-filled rows past the end of the set
-                key_insert_max(m1[0][r & 3], m2[0][r & 3], ok ? (((uint32_t)acc0[r] << 21) + (K0 - r)) : 0u);
-                key_insert_max(m1[1][r & 3], m2[1][r & 3], ok ? (((uint32_t)acc1[r] << 21) + (K0 - r)) : 0u);
-            }
+            for (int g = 0; g < 4; ++g) { group_insert(0, g, acc0, K0); group_insert(1, g, acc1, K0); }
         }
     }
-    // merge the slots, rebuild full keys (acc << 21 | 2^21 - 1 - train index), then merge the lane halves
+    // ---- tail: the kept groups' rows counted exactly on the packed descriptors (32 B per row), then the lane halves merged ----
+    // row key = distance << 21 | train index: the smallest two are the (distance, index)-first two.
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    auto key_insert_min = [](uint32_t &k1, uint32_t &k2, uint32_t key) {
+        const uint32_t hi = max(k1, key);
+        k1 = min(k1, key);
+        k2 = min(k2, hi);
+    };
+    const u32x4 *P = reinterpret_cast<const u32x4 *>(packed);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        uint32_t b1 = 0u, b2 = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { key_insert_max(b1, b2, m1[s][r]); key_insert_max(b1, b2, m2[s][r]); }
-        auto full_key = [&](uint32_t k) {
-            const uint32_t L = kHmLMask - (k & kHmLMask), r = L & 15u;
-            const uint32_t idx = (L >> 4) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
-            return k < 16u ? 0u : ((k & ~kHmLMask) | (kHmLMask - idx));
-        };
-        // the pipeline's start-up placeholders and the masked rows (keys below 16) lose to every real key; with fewer
-        // than two trains they can surface and are discarded by the nt gates below
-        b1 = full_key(b1); b2 = full_key(b2);
-        const uint32_t o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
-        key_insert_max(b1, b2, o1);
-        key_insert_max(b1, b2, o2);
         const int qrow = qbase + 32 * s + j;
-        if (h == 0 && qrow < nq) {
+        const bool qvalid = qrow < nq;
+        uint32_t g1 = 0u, g2 = 0u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { key_insert_max(g1, g2, m1[s][r]); key_insert_max(g1, g2, m2[s][r]); }
+        const u32x4 *qp = P + ((size_t)pd.q_row0 + (qvalid ? qrow : 0)) * 2;
+        const u32x4 q0 = qp[0], q1 = qp[1];
+        uint32_t k1 = kNone, k2 = kNone;
+        const uint32_t gk[2] = {g1, g2};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool live = gk[e] >= 16u && qvalid;                       // below 16: a start-up placeholder
+            const uint32_t L = kHmLMask - (gk[e] & kHmLMask);
+            const int row0 = (int)(L >> 2) * 32 + 8 * (int)(L & 3u) + 4 * h;
+            u32x4 t0[4], t1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(row0 + u, max(nt - 1, 0));
+                const u32x4 *tp = P + ((size_t)pd.t_row0 + (live ? t : 0)) * 2;
+                t0[u] = tp[0]; t1[u] = tp[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = row0 + u;
+                const int dist = __popc(q0.x ^ t0[u].x) + __popc(q0.y ^ t0[u].y) + __popc(q0.z ^ t0[u].z) + __popc(q0.w ^ t0[u].w) +
+                                 __popc(q1.x ^ t1[u].x) + __popc(q1.y ^ t1[u].y) + __popc(q1.z ^ t1[u].z) + __popc(q1.w ^ t1[u].w);
+                key_insert_min(k1, k2, (live && t < nt) ? (((uint32_t)dist << 21) | (uint32_t)t) : kNone);
+            }
+        }
+        const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+        key_insert_min(k1, k2, o1);
+        key_insert_min(k1, k2, o2);
+        if (h == 0 && qvalid) {
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
-            const bool h0 = nt >= 1, h1 = nt >= 2;
-            knn_idx[o] = h0 ? (int)(kHmLMask - (b1 & kHmLMask)) : -1;
-            knn_idx[o + 1] = h1 ? (int)(kHmLMask - (b2 & kHmLMask)) : -1;
-            knn_dist[o] = h0 ? (float)(256 + qpop[s] - (int)(b1 >> 21)) : FLT_MAX;
-            knn_dist[o + 1] = h1 ? (float)(256 + qpop[s] - (int)(b2 >> 21)) : FLT_MAX;
+            const bool h0 = k1 != kNone, h1 = k2 != kNone;
+            knn_idx[o] = h0 ? (int)(k1 & kHmLMask) : -1;
+            knn_idx[o + 1] = h1 ? (int)(k2 & kHmLMask) : -1;
+            knn_dist[o] = h0 ? (float)(k1 >> 21) : FLT_MAX;
+            knn_dist[o + 1] = h1 ? (float)(k2 >> 21) : FLT_MAX;
         }
     }
 }
@@ -1517,7 +1544,7 @@ int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long t
         hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d, n_words,
                            reinterpret_cast<uint32_t *>(exp_scratch), start);
         hipLaunchKernelGGL(hamming_knn_mfma_kernel, dim3(n_blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(exp_scratch),
-                           start, pairs, n_pairs, knn_idx, knn_dist);
+                           start, d, pairs, n_pairs, knn_idx, knn_dist);
     } else if (nbytes == 32)
         hipLaunchKernelGGL(hamming_knn_kernel<8>, dim3(n_blocks), dim3(256), 0, st, d, pairs, n_pairs, knn_idx, knn_dist);
     else if (nbytes == 64)
