@@ -82,7 +82,8 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
     if (metric == ESFM_L2_F32) {
         const float *desc = reinterpret_cast<const float *>(desc_dev);
         if (int rc = ctx->counters.reserve(64)) return rc;
-        ESFM_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 64, st));
+        const bool bf16_pass = esfm::l2_mfma_supported(width) && ctx->l2_audit != 2 && esfm::l2_bf16_pass(width);
+        if (!bf16_pass) ESFM_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 64, st));     // (the bf16 pass's split kernel zeroes them)
         ctx->last_n_queries = plan.total_queries;
         if (esfm::l2_mfma_supported(width) && ctx->l2_audit != 2) {
             if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
@@ -92,8 +93,9 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                 if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
                 if (int rc = ctx->pair_cnt.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
                 if (int rc = ctx->pair_list.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
-                ESFM_HIP_TRY(hipMemsetAsync(ctx->pair_cnt.ptr, 0, sizeof(int32_t) * (size_t)n_pairs, st));
-                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>())) return rc;
+                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>(),
+                                                        ctx->pair_cnt.as<int32_t>(), n_pairs))
+                    return rc;
                 {
                     esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                     if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,

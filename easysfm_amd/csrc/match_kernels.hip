@@ -470,33 +470,43 @@ __device__ __forceinline__ void bf16_split8(float4 a, float4 b, float scale, u32
     lo = u32x4{lv[0], lv[1], lv[2], lv[3]};
 }
 
-// one thread per (row, 16-feature group): 64 B in, 32 B of hi + 32 B of lo out, twice (train image, query image = -2 x);
-// the 4 threads of a row also leave |row|^2
-// (the approximate pass and the certificate only need it to 64 u: the summation order is free)
-__global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_groups, u32x4 *__restrict__ out,
-                                                            u32x4 *__restrict__ out_q, float *__restrict__ norms)
+// One thread per 16-B piece of a row (4 floats): the load and both stores of a wave are contiguous kilobytes.  A 16-B piece of
+// the image holds the hi (or lo) halves of EIGHT floats, so neighbouring lanes swap what the other one assembles: the even lane
+// of a pair stores the hi piece, the odd lane the lo piece -- slots 0, 2, 1, 3 of the 64-B group for four consecutive lanes.
+// Twice (train image, query image = the same split of -2 x); the 16 lanes of a row also leave |row|^2 (the approximate pass and
+// the certificate only need it to 64 u: the summation order is free).  The launch also zeroes the pass's counters (the global
+// list's and one per pair): two memset launches less per call.
+// (Round 1: one thread per 16-feature group, four loads and eight stores of 16 B at a 64-B lane stride: 31 us per 25 x 4096 rows.)
+__global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_pieces, u32x4 *__restrict__ out,
+                                                            u32x4 *__restrict__ out_q, float *__restrict__ norms,
+                                                            int32_t *__restrict__ counters, int32_t *__restrict__ pair_cnt, int n_pairs)
 {
-    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = g < n_groups;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 v0 = ok ? desc[4 * g] : z, v1 = ok ? desc[4 * g + 1] : z, v2 = ok ? desc[4 * g + 2] : z, v3 = ok ? desc[4 * g + 3] : z;
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f < 16) counters[f] = 0;
+    if (f < n_pairs) pair_cnt[f] = 0;
+    const bool ok = f < n_pieces;
+    const float4 v = ok ? desc[f] : make_float4(0.f, 0.f, 0.f, 0.f);
     float s = 0.f;
-    s = fmaf(v0.x, v0.x, s); s = fmaf(v0.y, v0.y, s); s = fmaf(v0.z, v0.z, s); s = fmaf(v0.w, v0.w, s);
-    s = fmaf(v1.x, v1.x, s); s = fmaf(v1.y, v1.y, s); s = fmaf(v1.z, v1.z, s); s = fmaf(v1.w, v1.w, s);
-    s = fmaf(v2.x, v2.x, s); s = fmaf(v2.y, v2.y, s); s = fmaf(v2.z, v2.z, s); s = fmaf(v2.w, v2.w, s);
-    s = fmaf(v3.x, v3.x, s); s = fmaf(v3.y, v3.y, s); s = fmaf(v3.z, v3.z, s); s = fmaf(v3.w, v3.w, s);
+    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    if (!ok) return;
-    if ((g & 3) == 0) norms[g >> 2] = s;
-    u32x4 h0, h1, l0, l1;
-    bf16_split8(v0, v1, 1.f, h0, l0);
-    bf16_split8(v2, v3, 1.f, h1, l1);
-    out[4 * g] = h0; out[4 * g + 1] = h1; out[4 * g + 2] = l0; out[4 * g + 3] = l1;
-    // the same rows as the matcher's QUERY operand: -2 q, split the same way (scaling by -2 commutes with the split)
-    bf16_split8(v0, v1, -2.f, h0, l0);
-    bf16_split8(v2, v3, -2.f, h1, l1);
-    out_q[4 * g] = h0; out_q[4 * g + 1] = h1; out_q[4 * g + 2] = l0; out_q[4 * g + 3] = l1;
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    const bool odd = (threadIdx.x & 1) != 0;
+    const long long g = f >> 2;                                  // 16-feature group
+    const int slot = (odd ? 2 : 0) + (int)((f >> 1) & 1);        // hi pieces: slots 0, 1; lo pieces: 2, 3
+#pragma unroll
+    for (int img = 0; img < 2; ++img) {
+        const float sc = img == 0 ? 1.f : -2.f;                 // scaling by -2 is exact and commutes with the split
+        uint32_t h0, l0, h1, l1;
+        bf16_split2(sc * v.x, sc * v.y, h0, l0);
+        bf16_split2(sc * v.z, sc * v.w, h1, l1);
+        // the even lane needs its partner's hi halves, the odd lane its partner's lo halves
+        const uint32_t r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
+        const u32x4 piece = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
+        if (ok) (img == 0 ? out : out_q)[4 * g + slot] = piece;
+    }
+    if (ok && (f & 15) == 0) norms[f >> 4] = s;
 }
 
 __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
@@ -1439,14 +1449,14 @@ constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_ker
 int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
 
-int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms)
+int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms, int32_t *counters,
+                         int32_t *pair_cnt, int n_pairs)
 {
     // `split` holds two images of 256 B per row: the train operand, then the query operand (-2 x)
-    const long long n_groups = total_rows * 4;
-    if (n_groups <= 0) return ESFM_OK;
-    hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float4 *>(desc), n_groups, reinterpret_cast<u32x4 *>(split),
-                       reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms);
+    const long long n_pieces = std::max(total_rows * 16, (long long)std::max(n_pairs, 16));     // the launch also zeroes counters / pair_cnt
+    hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(desc), total_rows * 16, reinterpret_cast<u32x4 *>(split),
+                       reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, counters, pair_cnt, n_pairs);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -24,7 +24,9 @@ bool l2_bf16_pass(int dim);
 int l2_query_block(int dim);
 size_t l2_split_bytes(int dim, long long total_rows);
 // writes the hi/lo image AND the row norms
-int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms);
+// also zeroes counters[0..16) and pair_cnt[0..n_pairs)
+int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms, int32_t *counters,
+                         int32_t *pair_cnt, int n_pairs);
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
                        int32_t *pair_cnt, int32_t *pair_list);
