@@ -115,9 +115,10 @@ struct Solver {
     int linearize(bool use_scaling, double radius)
     {
         const BADev &d = P->d;
-        if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling, P->ctx)) return rc;
+        int deferred = 0;      // one rank: the slab reduction of the sweep's per-camera sums rides in the per-point launch
+        if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling, P->ctx, ar ? nullptr : &deferred)) return rc;
         if (int rc = allreduce(d.camacc, (int64_t)esfm::ba_camacc_doubles(d.n_cam), ESFM_REDUCE_SUM)) return rc;
-        if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, true)) return rc;
+        if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, true, deferred)) return rc;
         return ESFM_OK;
     }
 };

@@ -61,12 +61,14 @@ constexpr int kRedEnt = 32, kRedGrp = 8;
 // (A first version let the last workgroup to take a ticket do the sum inside the producing kernel: the fence + ticket + tail cost
 // ~10 us per kernel on the 25-camera problem, a tenth of the LM iteration.)
 template <int N>
-__device__ __forceinline__ void scal_commit(const BADev &d, const ScalBase &base, const int (&slots)[N], const double (&vals)[N], double *lds /* >= 8 */)
+__device__ __forceinline__ void scal_commit(const BADev &d, const ScalBase &base, const int (&slots)[N], const double (&vals)[N], double *lds /* >= 8 */,
+                                            int bidx = -1 /* the workgroup's index among those that commit; default blockIdx.x */)
 {
+    const int b = bidx < 0 ? (int)blockIdx.x : bidx;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         const double t = block_sum(vals[q], lds);
-        if (threadIdx.x == 0) d.scal_part[(size_t)slots[q] * d.scal_cap + base.b[q] + blockIdx.x] = t;
+        if (threadIdx.x == 0) d.scal_part[(size_t)slots[q] * d.scal_cap + base.b[q] + b] = t;
     }
 }
 
@@ -432,10 +434,9 @@ __device__ __forceinline__ double camera_gradient_entry(const BADev &d, int i, d
 
 // Sum of entry e over n_slabs per-workgroup slabs, computed by a 32 x 8 thread tile: thread (ent, grp) adds slabs grp, grp + 8, ...
 // (independent loads, coalesced across ent), then the 8 partial sums are combined in a fixed order through LDS.  Deterministic.
-__global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const double *__restrict__ slabs, int n_slabs, int with_gradient)
+__device__ __forceinline__ void camacc_reduce_block(const BADev &d, const double *__restrict__ slabs, int n_slabs, int with_gradient, int bidx, double *lds /* 256 */)
 {
-    __shared__ double lds[256];
-    const int e = blockIdx.x * kRedEnt + (threadIdx.x % kRedEnt);
+    const int e = bidx * kRedEnt + (threadIdx.x % kRedEnt);
     const int per = d.n_cam * 27;
     const int grp = threadIdx.x / kRedEnt;
     // thread (ent, grp) adds slabs grp, grp + 8, ... in that order; eight loads in flight per round (the loop used to wait for
@@ -468,6 +469,12 @@ __global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const do
     d.camacc[36 * (size_t)c + 6 * a + b2] = v;
     d.camacc[36 * (size_t)c + 6 * b2 + a] = v;
     if (a == b2) d.qexp[6 * c + a] = qexp_of(v);
+}
+
+__global__ __launch_bounds__(256) void ba_camacc_reduce_kernel(BADev d, const double *__restrict__ slabs, int n_slabs, int with_gradient)
+{
+    __shared__ double lds[256];
+    camacc_reduce_block(d, slabs, n_slabs, with_gradient, blockIdx.x, lds);
 }
 
 // Per-camera sums from the stored Jacobian, chunk by chunk: ONE WAVE per chunk adds F'F (upper triangle, 21), F'r (6) -- and with
@@ -616,44 +623,48 @@ __device__ __forceinline__ double point_block_invert(const BADev &d, int p, cons
     return sing;
 }
 
+// one thread = one point: (fresh) E'E and E'r from the track, then the damped 3 x 3 inverse; returns its |gradient| share and singular flag
+__device__ __forceinline__ void point_prep_thread(const BADev &d, int p, double radius, double min_diag, double max_diag, int fresh, double &gmax, double &sing)
+{
+    gmax = 0.0; sing = 0.0;
+    if (p >= d.n_pt) return;
+    const int b = d.pt_start[p], e = d.pt_start[p + 1];
+    if (e <= b) return;
+    double A[6], g[3];
+    if (fresh) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i] = 0.0;
+        g[0] = g[1] = g[2] = 0.0;
+        const size_t n = d.n_obs;
+        for (int k = b; k < e; ++k) {
+            const double j0 = d.Jp[k], j1 = d.Jp[n + k], j2 = d.Jp[2 * n + k];
+            const double j3 = d.Jp[3 * n + k], j4 = d.Jp[4 * n + k], j5 = d.Jp[5 * n + k];
+            const double r0 = d.res[k], r1 = d.res[n + k];
+            A[0] += j0 * j0 + j3 * j3; A[1] += j0 * j1 + j3 * j4; A[2] += j0 * j2 + j3 * j5;
+            A[3] += j1 * j1 + j4 * j4; A[4] += j1 * j2 + j4 * j5; A[5] += j2 * j2 + j5 * j5;
+            g[0] += j0 * r0 + j3 * r1; g[1] += j1 * r0 + j4 * r1; g[2] += j2 * r0 + j5 * r1;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d.EtE[6 * (size_t)p + i] = A[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            d.Etr[3 * (size_t)p + i] = g[i];
+            gmax = fmax(gmax, fabs(g[i] / d.scale_p[3 * (size_t)p + i]));  // gradient of the unscaled problem
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i] = d.EtE[6 * (size_t)p + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = d.Etr[3 * (size_t)p + i];
+    }
+    sing = point_block_invert(d, p, A, g, radius, min_diag, max_diag);
+}
+
 __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radius, double min_diag, double max_diag, int fresh, ScalBase sbase)
 {
     __shared__ double red[8];
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    double gmax = 0.0, sing = 0.0;
-    if (p < d.n_pt) {
-        const int b = d.pt_start[p], e = d.pt_start[p + 1];
-        if (e > b) {
-            double A[6], g[3];
-            if (fresh) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) A[i] = 0.0;
-                g[0] = g[1] = g[2] = 0.0;
-                const size_t n = d.n_obs;
-                for (int k = b; k < e; ++k) {
-                    const double j0 = d.Jp[k], j1 = d.Jp[n + k], j2 = d.Jp[2 * n + k];
-                    const double j3 = d.Jp[3 * n + k], j4 = d.Jp[4 * n + k], j5 = d.Jp[5 * n + k];
-                    const double r0 = d.res[k], r1 = d.res[n + k];
-                    A[0] += j0 * j0 + j3 * j3; A[1] += j0 * j1 + j3 * j4; A[2] += j0 * j2 + j3 * j5;
-                    A[3] += j1 * j1 + j4 * j4; A[4] += j1 * j2 + j4 * j5; A[5] += j2 * j2 + j5 * j5;
-                    g[0] += j0 * r0 + j3 * r1; g[1] += j1 * r0 + j4 * r1; g[2] += j2 * r0 + j5 * r1;
-                }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d.EtE[6 * (size_t)p + i] = A[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    d.Etr[3 * (size_t)p + i] = g[i];
-                    gmax = fmax(gmax, fabs(g[i] / d.scale_p[3 * (size_t)p + i]));  // gradient of the unscaled problem
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) A[i] = d.EtE[6 * (size_t)p + i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) g[i] = d.Etr[3 * (size_t)p + i];
-            }
-            sing = point_block_invert(d, p, A, g, radius, min_diag, max_diag);
-        }
-    }
+    double gmax, sing;
+    point_prep_thread(d, blockIdx.x * 64 + threadIdx.x, radius, min_diag, max_diag, fresh, gmax, sing);
     if (fresh) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
@@ -662,6 +673,27 @@ __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radiu
     const int slots[1] = {SC_PT_SINGULAR};
     const double vals[1] = {sing};
     scal_commit<1>(d, sbase, slots, vals, red);
+}
+
+// The per-point blocks of a fresh Jacobian AND the reduction of the sweep's per-camera slabs in one launch (one rank, small
+// problems): the two are independent -- the slab sums are first needed by the reduced solve -- and each leaves most of the chip
+// idle (22 workgroups for 25 cameras; a latency-bound walk over the tracks), so back to back they cost 8 + 12 us of a 180-us
+// LM iteration on BA-25 and together 12.  The first n_red workgroups are ba_camacc_reduce_kernel's, the others take 256 points
+// each (the singular-point count is an integer-valued sum and the gradient maximum a maximum: the wider workgroup changes no bit).
+__global__ __launch_bounds__(256) void ba_point_prep_camacc_kernel(BADev d, double radius, double min_diag, double max_diag, ScalBase sbase,
+                                                                   const double *__restrict__ slabs, int n_slabs, int with_gradient, int n_red)
+{
+    __shared__ double lds[256];
+    if ((int)blockIdx.x < n_red) { camacc_reduce_block(d, slabs, n_slabs, with_gradient, blockIdx.x, lds); return; }
+    const int pb = (int)blockIdx.x - n_red;
+    double gmax, sing;
+    point_prep_thread(d, pb * 256 + threadIdx.x, radius, min_diag, max_diag, 1, gmax, sing);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0) atomic_max_nonneg(&d.scal[SC_GMAX], gmax);
+    const int slots[1] = {SC_PT_SINGULAR};
+    const double vals[1] = {sing};
+    scal_commit<1>(d, sbase, slots, vals, lds, pb);
 }
 
 // The fresh-Jacobian variant for large problems, one workgroup per point chunk (pchunk_pt0, <= 256 observations): thread =
@@ -1695,8 +1727,9 @@ int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack)
     return ESFM_OK;
 }
 
-int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx)
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx, int *deferred_slabs)
 {
+    if (deferred_slabs) *deferred_slabs = 0;
     if (d.n_obs <= 0 || d.n_cchunks <= 0) {
         ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
         ESFM_HIP_TRY(hipMemsetAsync(d.qexp, 0, sizeof(int32_t) * 6 * (size_t)d.n_cam, st));
@@ -1715,8 +1748,10 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, sbase, d.lin_slabs);
         }
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid, d.parts->single_rank ? 1 : 0);
         d.parts->grad_done = d.parts->single_rank;
+        // one rank, per-point blocks by the walking kernel next: the slab reduction rides in that launch (ba_point_prep_camacc)
+        if (deferred_slabs && d.parts->single_rank && !(d.n_pchunks > 0 && d.n_obs >= (1 << 20)) && d.n_pt > 0) { *deferred_slabs = grid; return ESFM_OK; }
+        hipLaunchKernelGGL(ba_camacc_reduce_kernel, dim3(div_up(d.n_cam * 27, kRedEnt)), dim3(256), 0, st, d, d.lin_slabs, grid, d.parts->single_rank ? 1 : 0);
         LAUNCH_CHECK();
         return ESFM_OK;
     }
@@ -1733,11 +1768,19 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     return ESFM_OK;
 }
 
-int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh)
+int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh, int deferred_slabs)
 {
-    if (d.n_pt <= 0) return ESFM_OK;
     ScalBase sbase;
     const int slots[1] = {SC_PT_SINGULAR};
+    if (deferred_slabs > 0) {      // ba_linearize left the slab reduction to this launch (it checked that this path is taken)
+        const int n_red = div_up(d.n_cam * 27, kRedEnt), n_prep = div_up(d.n_pt, 256);
+        if (int rc = scal_reserve<1>(st, d, slots, n_prep, sbase)) return rc;
+        hipLaunchKernelGGL(ba_point_prep_camacc_kernel, dim3(n_red + n_prep), dim3(256), 0, st, d, radius, min_diag, max_diag, sbase, d.lin_slabs,
+                           deferred_slabs, 1, n_red);
+        LAUNCH_CHECK();
+        return ESFM_OK;
+    }
+    if (d.n_pt <= 0) return ESFM_OK;
     if (fresh && d.n_pchunks > 0 && d.n_obs >= (1 << 20)) {        // (see ba_point_prep_chunk_kernel for the crossover)
         if (int rc = scal_reserve<1>(st, d, slots, d.n_pchunks, sbase)) return rc;
         hipLaunchKernelGGL(ba_point_prep_chunk_kernel, dim3(d.n_pchunks), dim3(kPtChunkObs), 0, st, d, radius, min_diag, max_diag, sbase);

@@ -122,8 +122,10 @@ inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; re
 inline size_t ba_red_packed_doubles(int n_cam) { return (size_t)18 * (size_t)n_cam * ((size_t)n_cam + 1) + 6 * (size_t)n_cam; }
 int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack);
 
-int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx);
-int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian);
+// deferred_slabs != NULL: on one rank with the walking per-point kernel next, the reduction of the sweep's per-camera slabs is NOT
+// launched; *deferred_slabs (> 0) must then be handed to the ba_point_prep call that follows, which does both in one launch
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx, int *deferred_slabs = nullptr);
+int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian, int deferred_slabs = 0);
 int ba_jacobi_scaling(hipStream_t st, const BADev &d);
 int ba_camera_gradient(hipStream_t st, const BADev &d);
 // slabs: scratch for the LDS-privatised variant (n_cam small), >= ba_schur_slab_doubles(n_cam, num_cu) doubles, or NULL
