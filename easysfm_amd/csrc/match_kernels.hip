@@ -460,16 +460,6 @@ __device__ __forceinline__ void bf16_split2(float a0, float a1, uint32_t &hi, ui
     lo = bf16_rne_bits(r0) | (bf16_rne_bits(r1) << 16);
 }
 
-// 8 consecutive floats, scaled by `scale` (a power of two: exact), as 8 hi and 8 lo bf16 values
-__device__ __forceinline__ void bf16_split8(float4 a, float4 b, float scale, u32x4 &hi, u32x4 &lo)
-{
-    uint32_t hv[4], lv[4];
-    bf16_split2(scale * a.x, scale * a.y, hv[0], lv[0]); bf16_split2(scale * a.z, scale * a.w, hv[1], lv[1]);
-    bf16_split2(scale * b.x, scale * b.y, hv[2], lv[2]); bf16_split2(scale * b.z, scale * b.w, hv[3], lv[3]);
-    hi = u32x4{hv[0], hv[1], hv[2], hv[3]};
-    lo = u32x4{lv[0], lv[1], lv[2], lv[3]};
-}
-
 // One thread per 16-B piece of a row (4 floats): the load and both stores of a wave are contiguous kilobytes.  A 16-B piece of
 // the image holds the hi (or lo) halves of EIGHT floats, so neighbouring lanes swap what the other one assembles: the even lane
 // of a pair stores the hi piece, the odd lane the lo piece -- slots 0, 2, 1, 3 of the 64-B group for four consecutive lanes.
@@ -1309,7 +1299,10 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
             for (int g = 0; g < 4; ++g) { group_insert(0, g, acc0, K0); group_insert(1, g, acc1, K0); }
         }
     }
-    // ---- tail: the kept groups' rows counted exactly on the packed descriptors (32 B per row), then the lane halves merged ----
+    // ---- tail: the kept groups' rows counted exactly on the packed descriptors (32 B per row) ----
+    // The two nearest rows of a query lie in the two best groups of ALL its groups, so the four kept ones (two per lane half) are
+    // first merged -- keys rebuilt with the group's first train row in the position field, which orders groups of different lane
+    // halves like their rows -- and each lane of the pair counts ONE group: 4 rows, 8 loads.
     // row key = distance << 21 | train index: the smallest two are the (distance, index)-first two.
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     auto key_insert_min = [](uint32_t &k1, uint32_t &k2, uint32_t key) {
@@ -1325,29 +1318,34 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
         uint32_t g1 = 0u, g2 = 0u;
 #pragma unroll
         for (int r = 0; r < 2; ++r) { key_insert_max(g1, g2, m1[s][r]); key_insert_max(g1, g2, m2[s][r]); }
+        // position field: 2^21 - 1 - (first row / 4) = 2^21 - 1 - (8 step + 2 g + h); placeholders (below 16) become 0
+        auto global_key = [&](uint32_t k) {
+            const uint32_t L = kHmLMask - (k & kHmLMask);
+            return k < 16u ? 0u : ((k & ~kHmLMask) | (kHmLMask - (2u * L + (uint32_t)h)));
+        };
+        g1 = global_key(g1); g2 = global_key(g2);
+        const uint32_t p1 = __shfl_xor(g1, 32), p2 = __shfl_xor(g2, 32);
+        key_insert_max(g1, g2, p1);
+        key_insert_max(g1, g2, p2);                                        // both lanes of the pair now hold the query's two best groups
+        const uint32_t mine = h == 0 ? g1 : g2;
+        const bool live = mine != 0u && qvalid;
+        const int row0 = (int)(kHmLMask - (mine & kHmLMask)) * 4;
         const u32x4 *qp = P + ((size_t)pd.q_row0 + (qvalid ? qrow : 0)) * 2;
         const u32x4 q0 = qp[0], q1 = qp[1];
+        u32x4 t0[4], t1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(row0 + u, max(nt - 1, 0));
+            const u32x4 *tp = P + ((size_t)pd.t_row0 + (live ? t : 0)) * 2;
+            t0[u] = tp[0]; t1[u] = tp[1];
+        }
         uint32_t k1 = kNone, k2 = kNone;
-        const uint32_t gk[2] = {g1, g2};
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const bool live = gk[e] >= 16u && qvalid;                       // below 16: a start-up placeholder
-            const uint32_t L = kHmLMask - (gk[e] & kHmLMask);
-            const int row0 = (int)(L >> 2) * 32 + 8 * (int)(L & 3u) + 4 * h;
-            u32x4 t0[4], t1[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = min(row0 + u, max(nt - 1, 0));
-                const u32x4 *tp = P + ((size_t)pd.t_row0 + (live ? t : 0)) * 2;
-                t0[u] = tp[0]; t1[u] = tp[1];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = row0 + u;
-                const int dist = __popc(q0.x ^ t0[u].x) + __popc(q0.y ^ t0[u].y) + __popc(q0.z ^ t0[u].z) + __popc(q0.w ^ t0[u].w) +
-                                 __popc(q1.x ^ t1[u].x) + __popc(q1.y ^ t1[u].y) + __popc(q1.z ^ t1[u].z) + __popc(q1.w ^ t1[u].w);
-                key_insert_min(k1, k2, (live && t < nt) ? (((uint32_t)dist << 21) | (uint32_t)t) : kNone);
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int t = row0 + u;
+            const int dist = __popc(q0.x ^ t0[u].x) + __popc(q0.y ^ t0[u].y) + __popc(q0.z ^ t0[u].z) + __popc(q0.w ^ t0[u].w) +
+                             __popc(q1.x ^ t1[u].x) + __popc(q1.y ^ t1[u].y) + __popc(q1.z ^ t1[u].z) + __popc(q1.w ^ t1[u].w);
+            key_insert_min(k1, k2, (live && t < nt) ? (((uint32_t)dist << 21) | (uint32_t)t) : kNone);
         }
         const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
         key_insert_min(k1, k2, o1);
