@@ -92,8 +92,8 @@ def cpu_baseline_ba(scene, iters: int = 25):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)     # 0.3 s of timed work: the first tens of steps run ~3 % slower (clock ramp), 20 were noisy
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ba-iters", type=int, default=50, help="LM iterations timed for the BA half of the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
