@@ -83,7 +83,14 @@ struct Solver {
         }
         return ESFM_OK;
     }
-    int zero_scal() { ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st)); esfm::ba_scal_discard(P->d, 0, esfm::SC_SUM_COUNT); return ESFM_OK; }
+    bool scal_zeroed = false;   // the read-back kernel (ba_publish_scalars) leaves d.scal zeroed: a reset right after a fetch needs no memset
+    int zero_scal()
+    {
+        if (!scal_zeroed) ESFM_HIP_TRY(hipMemsetAsync(P->d.scal, 0, sizeof(double) * esfm::SC_COUNT, st));
+        scal_zeroed = false;
+        esfm::ba_scal_discard(P->d, 0, esfm::SC_SUM_COUNT);
+        return ESFM_OK;
+    }
     // SUM the partial-sum slots and MAX the gradient slot across ranks, then fetch all scalars.
     int fetch_scal()
     {
@@ -109,6 +116,7 @@ struct Solver {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(200));
             }
         }
+        scal_zeroed = true;
         return ESFM_OK;
     }
     // residuals + Jacobian at x, per-camera sums, per-point blocks; leaves cost/gmax in h[].

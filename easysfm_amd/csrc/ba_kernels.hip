@@ -1904,7 +1904,10 @@ __global__ __launch_bounds__(1024) void ba_publish_scalars_kernel(const double *
     const int i = threadIdx.x;
     // system-scope stores (write-through to the pinned host page) ordered against the flag by a workgroup-scope fence (s_waitcnt) and
     // a barrier: a system-scope release fence here is a write-back of the whole L2 on this part (see ba_chol_large.hip, st_coh)
-    if (i < SC_COUNT) __hip_atomic_store(&host[i], scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (i < SC_COUNT) {
+        __hip_atomic_store(&host[i], scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        scal[i] = 0.0;       // every read-back is followed by a reset before the next scalar-producing launch: done here, not by a memset launch
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
