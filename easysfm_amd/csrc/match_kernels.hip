@@ -168,7 +168,8 @@ struct Cand { float d; int i; float d2; };
 
 __device__ __forceinline__ bool cand_better(float d, int i, const Cand &b)
 {
-    return (i >= 0) && (b.i < 0 || d < b.d || (d == b.d && i < b.i));
+    // an empty slot holds FLT_MAX: like the oracle's strict `d < d1`, a distance of FLT_MAX, +inf or NaN is never a neighbour
+    return (i >= 0) && (d < b.d || (d == b.d && i < b.i));
 }
 
 __device__ __forceinline__ void best2_insert(Cand &b0, Cand &b1, float d, int i, float d2)
@@ -718,8 +719,8 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
         // memory here, and every scratch access waits for the row transfer in flight)
         float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
         auto insert2 = [&](bool valid, float d, int i, float d2) {
-            const bool c1 = valid && (b1i < 0 || d < b1d || (d == b1d && i < b1i));
-            const bool c0 = valid && (b0i < 0 || d < b0d || (d == b0d && i < b0i));
+            const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
+            const bool c0 = valid && (d < b0d || (d == b0d && i < b0i));
             b1d = c0 ? b0d : (c1 ? d : b1d); b1i = c0 ? b0i : (c1 ? i : b1i); b1q = c0 ? b0q : (c1 ? d2 : b1q);
             b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
         };
@@ -949,7 +950,7 @@ __global__ __launch_bounds__(256) void l2_rescan64_pairs_kernel(const float *__r
     // without a branch.  ~0 is the empty slot (index -1).
     typedef unsigned long long u64;
     constexpr u64 kEmpty = ~0ull;
-    auto key_of = [](float d, int t) { return ((u64)__float_as_uint(d) << 32) | (u64)(uint32_t)t; };
+    auto key_of = [](float d, int t) { return d < FLT_MAX ? (((u64)__float_as_uint(d) << 32) | (u64)(uint32_t)t) : ~0ull; };   // FLT_MAX, +inf, NaN: never a neighbour (oracle: `d < d1`)
     auto insert2 = [](u64 &b0, u64 &b1, u64 k) {
         const u64 hi = k > b0 ? k : b0;
         b0 = k > b0 ? b0 : k;

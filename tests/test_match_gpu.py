@@ -230,6 +230,21 @@ def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
         assert np.array_equal(idx[sl], ridx) and np.array_equal(_bits(dist[sl]), _bits(rdist)), (i, j)
 
 
+def test_l2_overflowing_and_nan_rows(gpu_ctx, oracle_lib):
+    """Rows whose distance overflows f32 (+inf) or is NaN are never neighbours (the oracle's strict `d < d1` against FLT_MAX):
+    a few such train rows, a NaN query row, and a train set made of nothing else (no neighbours at all: indices -1)."""
+    rng = np.random.default_rng(21)
+    q = rng.standard_normal((300, 64)).astype(np.float32); t = rng.standard_normal((700, 64)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    t[[3, 77, 500]] *= np.float32(1e25)
+    t[123, 5] = np.nan
+    q[17, 40] = np.nan
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)
+    with np.errstate(over="ignore", invalid="ignore"):
+        huge = (t[:50] * np.float32(1e25)).astype(np.float32)         # some entries overflow to inf themselves
+    _check_knn_l2(gpu_ctx, oracle_lib, q, huge)
+
+
 def test_full_size_properties(gpu_ctx, oracle_lib):
     """BASELINE size (4096 x 4096 x 64): size-independent checks -- a query that IS a train row
     finds it at distance 0; a sample of rows agrees with the oracle bit for bit; permuting the train
