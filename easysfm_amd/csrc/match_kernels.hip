@@ -258,6 +258,8 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
     float v0 = kBig, v1 = kBig, v2 = kBig;             // master keys
     int c0 = -1, c1 = -1, c2 = -1;                     // master train rows
     float tmax = 0.f;  // max |t|^2 seen by this thread (threads < TT only)
+    int poison = 0;    // a train row with a non-finite norm (inf / NaN entries, or an overflowing |t|^2): its scores can be NaN, and a NaN key
+                       // corrupts the v_med3 network -- no query of this workgroup is certified, the exact re-scan decides
     unsigned kmask = 0xFFFFFF00u;
     asm volatile("" : "+v"(kmask));   // keep the mask in a VGPR: v_and_or_b32 can then take the code as its one SGPR operand
     auto fold = [&](float s, int code /* wave-uniform */) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
             const int s = tid + 256 * i, row = s / SLOTS, slot = s % SLOTS;
             lds_tile[buf * TT * SLOTS + row * SLOTS + (slot ^ (row & 15))] = stage[i];
         }
-        if (tid < TT) { lds_norm[buf * TT + tid] = stage_n; if (stage_n < 1.0e38f) tmax = fmaxf(tmax, stage_n); }
+        if (tid < TT) { lds_norm[buf * TT + tid] = stage_n; if (stage_n < 1.0e38f) tmax = fmaxf(tmax, stage_n); else if (!(stage_n == kBig)) poison = 1; }
     };
 
     if (ntiles > 0) { gload(0); lstore(0); }
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) lds_red[wave] = m;
-        __syncthreads();
+        poison = __syncthreads_or(poison);
         tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     }
 
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         // every train outside the candidates has key >= tau, hence s >= tau - 2^-14 |tau| (truncation);
         // the candidate set provably contains the two best iff |q|^2 + tau - eps exceeds the second
         // best exact d^2 by more than sqrt's rounding can hide.
-        bool certified = !(tau < 1.0e38f);   // an empty slot in either lane: every train row is a candidate
-        if (!certified && b1.i >= 0) {
+        bool certified = !(tau < 1.0e38f) && !poison;   // an empty slot in either lane: every train row is a candidate
+        if (!certified && b1.i >= 0 && !poison) {
             const double qn = (double)norms[pd.q_row0 + qrow];
             const double eps = (qn + (double)tmax) * (1.0 / 65536.0) + fabs((double)tau) * (1.0 / 16384.0);
             certified = (qn + (double)tau - eps) > (double)b1.d2 * (1.0 + 1.0 / 2097152.0);
