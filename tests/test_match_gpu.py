@@ -243,6 +243,10 @@ def test_l2_overflowing_and_nan_rows(gpu_ctx, oracle_lib):
     with np.errstate(over="ignore", invalid="ignore"):
         huge = (t[:50] * np.float32(1e25)).astype(np.float32)         # some entries overflow to inf themselves
     _check_knn_l2(gpu_ctx, oracle_lib, q, huge)
+    # the same on 128-float descriptors (f32-input MFMA pass: a NaN key would corrupt its med3 network)
+    q2 = rng.standard_normal((200, 128)).astype(np.float32); t2 = rng.standard_normal((500, 128)).astype(np.float32)
+    t2[[1, 300]] *= np.float32(1e25); t2[42, 100] = np.nan; q2[9, 3] = np.nan
+    _check_knn_l2(gpu_ctx, oracle_lib, q2, t2)
 
 
 def test_full_size_properties(gpu_ctx, oracle_lib):
