@@ -564,15 +564,42 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     // ---- main loop (TrustRegionMinimizer::Minimize) ----
     int iter = 0;
     double last_gmax = gmax;
+    // One rank, no bounds: the read-back that follows the re-linearisation of an accepted step is DEFERRED to the next step's --
+    // the next Schur complement and solve are enqueued straight behind the sweep (one host round trip and one read-back launch
+    // less per accepted step).  What that read-back delivers -- the cost, gradient norm and validity at the accepted point --
+    // is only needed after the next step has been computed: the right-hand side's fixed-point exponent takes its bound from the
+    // candidate's cost (the same function value, computed by the back-substitution launch), the gradient-tolerance test and the
+    // log entry of the accepted iteration are completed one read-back later (a step computed past convergence is discarded).
+    const bool may_defer = !multi && !constrained && !opt.verbose;
+    bool pending_lin = false;
+    double pending_cost_bound = 0.0;
+    // completes the accepted iteration `it_acc` from the scalars of its re-linearisation; false: the solve ends here
+    auto resolve_pending = [&](int it_acc) -> bool {
+        pending_lin = false;
+        if (h[esfm::SC_LIN_BAD] > 0.0) {
+            esfm::set_error("non-finite residual or Jacobian after an accepted step");
+            sum->termination = ESFM_BA_FAILURE; rc_final = ESFM_ERR_NUMERIC; terminated = true;
+        }
+        x_cost = h[esfm::SC_COST];
+        prep_singular = h[esfm::SC_PT_SINGULAR] > 0.0;
+        gmax = h[esfm::SC_GMAX]; last_gmax = gmax;
+        if (it_acc < ESFM_BA_MAX_LOG) { sum->iterations[it_acc].cost = x_cost; sum->iterations[it_acc].gradient_max_norm = gmax; }
+        if (!terminated && gmax <= opt.gradient_tolerance) { sum->termination = ESFM_BA_CONVERGENCE; terminated = true; }
+        return !terminated;
+    };
     while (!terminated) {
         if (iter >= opt.max_num_iterations) { sum->termination = ESFM_BA_NO_CONVERGENCE; break; }
-        if (radius <= opt.min_trust_region_radius) { sum->termination = ESFM_BA_CONVERGENCE; break; }
+        if (radius <= opt.min_trust_region_radius) {
+            if (pending_lin) { if (int rc = S.fetch_scal()) return finish(rc); if (!resolve_pending(iter)) break; }
+            sum->termination = ESFM_BA_CONVERGENCE; break;
+        }
         ++iter;
         esfm_ba_iteration cur;
         memset(&cur, 0, sizeof(cur));
         cur.iteration = iter; cur.gradient_max_norm = last_gmax;
         // LevenbergMarquardtStrategy::ComputeStep: D^2 = clamp(diag(J'J)) / radius, then the Schur solve
-        if (int rc = S.zero_scal()) return finish(rc);
+        // (a deferred read-back: the slots were reset by the last read-back and hold the sweep's sums -- nothing to reset, nothing to forget)
+        if (!pending_lin) { if (int rc = S.zero_scal()) return finish(rc); }
         bool reprepped = false;
         if (prep_radius != radius) {
             if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, false)) return finish(rc);
@@ -580,7 +607,8 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
         }
         {
             esfm::KernelTimer tm(P->ctx, ESFM_K_BA_SCHUR);
-            const double rhs_bound = std::sqrt(2.0 * std::max(x_cost, 0.0));   // |robustified residual vector| over all ranks
+            // |robustified residual vector| over all ranks (deferred read-back: the candidate's cost bounds the cost at the same point)
+            const double rhs_bound = std::sqrt(2.0 * std::max(pending_lin ? pending_cost_bound : x_cost, 0.0));
             if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap, rhs_bound)) return finish(rc);
             if (int rc = esfm::ba_schur_calib(st, d, rhs_bound)) return finish(rc);
         }
@@ -605,6 +633,11 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             if (int rc = esfm::ba_cost(st, d, P->ctx->num_cu, d.cand_c, d.cand_p, opt.cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD, constrained)) return finish(rc);
         }
         if (int rc = S.fetch_scal()) return finish(rc);
+        if (pending_lin) {
+            // the accepted iteration iter - 1 is completed first; past convergence (or on failure) the step just computed is dropped
+            if (!resolve_pending(iter - 1)) { sum->num_iterations = iter - 1; break; }
+            cur.gradient_max_norm = last_gmax;
+        }
         reuse_diagonal = true;
         const double model_cost_change = h[esfm::SC_MODEL_CHANGE];
         double step_norm = std::sqrt(h[esfm::SC_STEP_SQ_PT] + h[esfm::SC_STEP_SQ_CAM]);
@@ -686,6 +719,17 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             if (int rc = S.linearize(opt.jacobi_scaling != 0, radius)) return finish(rc);
             prep_radius = radius;
             if (int rc = esfm::ba_camera_gradient(st, d)) return finish(rc);
+            if (may_defer && iter < opt.max_num_iterations && radius > opt.min_trust_region_radius) {
+                // read-back deferred to the next step's (see may_defer); cost and gradient norm of this log entry follow then
+                pending_lin = true;
+                pending_cost_bound = cand_cost * (1.0 + 1e-9);
+                cur.step_is_successful = 1; cur.cost = cand_cost; cur.gradient_max_norm = last_gmax;
+                sum->num_successful_steps++;
+                cur.trust_region_radius = radius;
+                if (iter < ESFM_BA_MAX_LOG) sum->iterations[iter] = cur;
+                sum->num_iterations = iter;
+                continue;
+            }
             if (int rc = S.fetch_scal()) return finish(rc);
             if (h[esfm::SC_LIN_BAD] > 0.0) {
                 esfm::set_error("non-finite residual or Jacobian after an accepted step");
