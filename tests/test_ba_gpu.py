@@ -78,6 +78,44 @@ def test_ba_trace_and_params_match_oracle(gpu_ctx, oracle_lib, n_cam, n_pt, k, s
     assert abs(oracle_lib.ba_cost(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, cams, pts) - summ.final_cost) <= 1e-10 * summ.final_cost
 
 
+@pytest.mark.parametrize("max_iter", [1, 2, 3, 4, 6])
+def test_ba_iteration_caps_match_oracle(gpu_ctx, oracle_lib, max_iter):
+    """The read-back behind an accepted step's re-linearisation is deferred to the next step's -- unless the iteration cap says
+    there is no next step.  Every cap from 1 on: same termination, counts, log and parameters as the oracle."""
+    sc = synth.ba_scene(6, 300, 4, seed=2)
+    opt, ropt = _solve_both(oracle_lib, sc, max_iter)
+    cams, pts, summ = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
+    rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, ropt)
+    _compare(summ, rs, oracle_lib)
+    assert abs(summ.final_cost - rs.final_cost) <= RTOL_TRACE * rs.final_cost
+    assert np.allclose(cams, rc, rtol=RTOL_PAR, atol=ATOL_PAR) and np.allclose(pts, rp, rtol=RTOL_PAR, atol=ATOL_PAR)
+
+
+def test_ba_gradient_tolerance_termination_matches_oracle(gpu_ctx, oracle_lib):
+    """Convergence by gradient tolerance is detected one read-back late (the step computed meanwhile is dropped): iteration count,
+    termination, log and parameters must not show it.  The tolerance is set between the gradient norms of two accepted iterations
+    of the oracle's own run, for several such places."""
+    sc = synth.ba_scene(6, 300, 4, seed=2)
+    ropt = oracle_lib.ba_default_options(); ropt.max_num_iterations = 12
+    ropt.function_tolerance = 0.0; ropt.parameter_tolerance = 0.0
+    _, _, rs0 = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, ropt)
+    g = [it.gradient_max_norm for it in oracle_lib.iterations(rs0) if it.step_is_successful]
+    tried = 0
+    for k in range(1, min(len(g), 6)):
+        if not (g[k] < g[k - 1]):
+            continue
+        tol = float(np.sqrt(g[k] * g[k - 1]))          # reached at accepted iteration k, not before
+        opt, ropt = _solve_both(oracle_lib, sc, 12, gradient_tolerance=tol, function_tolerance=0.0, parameter_tolerance=0.0)
+        cams, pts, summ = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
+        rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, ropt)
+        _compare(summ, rs, oracle_lib)
+        assert rs.num_iterations < 12
+        assert abs(summ.final_cost - rs.final_cost) <= RTOL_TRACE * rs.final_cost
+        assert np.allclose(cams, rc, rtol=RTOL_PAR, atol=ATOL_PAR) and np.allclose(pts, rp, rtol=RTOL_PAR, atol=ATOL_PAR)
+        tried += 1
+    assert tried >= 2
+
+
 def test_ba_cost_kernel(gpu_ctx, oracle_lib):
     sc = synth.ba_scene(8, 500, 5, seed=4)
     prob = E.BAProblem(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, gpu_ctx)
