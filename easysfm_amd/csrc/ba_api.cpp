@@ -564,13 +564,13 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     // ---- main loop (TrustRegionMinimizer::Minimize) ----
     int iter = 0;
     double last_gmax = gmax;
-    // One rank, no bounds: the read-back that follows the re-linearisation of an accepted step is DEFERRED to the next step's --
+    // No bounds: the read-back that follows the re-linearisation of an accepted step is DEFERRED to the next step's --
     // the next Schur complement and solve are enqueued straight behind the sweep (one host round trip and one read-back launch
     // less per accepted step).  What that read-back delivers -- the cost, gradient norm and validity at the accepted point --
     // is only needed after the next step has been computed: the right-hand side's fixed-point exponent takes its bound from the
     // candidate's cost (the same function value, computed by the back-substitution launch), the gradient-tolerance test and the
     // log entry of the accepted iteration are completed one read-back later (a step computed past convergence is discarded).
-    const bool may_defer = !multi && !constrained && !opt.verbose;
+    const bool may_defer = !constrained && !opt.verbose;     // (sharded solves too: the deferred scalars are all-reduced like the others, every rank decides alike)
     bool pending_lin = false;
     double pending_cost_bound = 0.0;
     // completes the accepted iteration `it_acc` from the scalars of its re-linearisation; false: the solve ends here
