@@ -116,6 +116,24 @@ def test_ba_gradient_tolerance_termination_matches_oracle(gpu_ctx, oracle_lib):
     assert tried >= 2
 
 
+def test_ba_non_finite_inputs_fail_like_the_oracle(gpu_ctx, oracle_lib):
+    """A NaN observation makes the initial linearisation invalid: both solvers refuse (Ceres: "Residual and Jacobian evaluation
+    failed").  A point at 1e30 is legal input: same termination, iteration count and cost."""
+    sc = synth.ba_scene(6, 300, 4, seed=2)
+    opt, ropt = _solve_both(oracle_lib, sc, 5)
+    uv = sc.uv.copy(); uv[17, 0] = np.nan
+    with pytest.raises(Exception) as gi:
+        E.ba_solve(sc.cam_idx, sc.pt_idx, uv, sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
+    assert "NUMERIC" in str(gi.value)
+    with pytest.raises(Exception):
+        oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, uv, sc.K4, sc.cams0, sc.pts0, ropt)
+    pts0 = sc.pts0.copy(); pts0[5] = [1e30, -1e30, 1e30]
+    cams, pts, summ = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, pts0, opt, gpu_ctx)
+    rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, pts0, ropt)
+    assert summ.termination == rs.termination and summ.num_iterations == rs.num_iterations
+    assert abs(summ.final_cost - rs.final_cost) <= RTOL_TRACE * max(1.0, abs(rs.final_cost))
+
+
 def test_ba_cost_kernel(gpu_ctx, oracle_lib):
     sc = synth.ba_scene(8, 500, 5, seed=4)
     prob = E.BAProblem(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, gpu_ctx)
