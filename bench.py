@@ -56,25 +56,41 @@ def frames_for(world: int) -> int:
     return f
 
 
-def cpu_baseline_match(sets, budget_s: float = 12.0):
+def cpu_baseline_match(sets, pairs, gpu_results=None, budget_s: float = 12.0):
     """Oracle (exact brute-force 2-NN + ratio, OpenMP over query rows like OpenCV's BFMatcher) on the
-    host cores, on whole 4096 x 4096 pairs of the same workload until ~budget_s have elapsed."""
+    host cores, on whole 4096 x 4096 pairs of the same workload: the step's whole pair list once (every
+    pair's match list compared bit for bit with the GPU's when `gpu_results` is given), then more of
+    the same until ~budget_s have elapsed.  Returns (cpu_baseline object, verification object)."""
     import oracle
     path = oracle.build(arch="native", out="libesfm_oracle_native.so")
     oracle.load(path)
     cores = os.cpu_count() or 1
     oracle.set_num_threads(cores)
-    n, t0 = 0, time.perf_counter()
-    pairs = [(i, j) for i in range(len(sets)) for j in range(i)]
+    n, t0, t_cmp = 0, time.perf_counter(), 0.0
+    checked, bad = 0, []
     while True:
-        i, j = pairs[n % len(pairs)]
-        oracle.match_l2(sets[i], sets[j], 0.5)
+        k = n % len(pairs)
+        i, j = pairs[k]
+        rq, rt, rd = oracle.match_l2(sets[i], sets[j], 0.5)
         n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 2400:
+        if gpu_results is not None and n <= len(pairs):
+            tc = time.perf_counter()
+            q, t, d = gpu_results[k]
+            if not (np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))):
+                bad.append(k)
+            checked += 1
+            t_cmp += time.perf_counter() - tc
+        el = time.perf_counter() - t0 - t_cmp
+        if (el >= budget_s and n >= (len(pairs) if gpu_results is not None else 1)) or n >= 2400 or el >= 4 * budget_s:
             break
-    return {"value": n / el, "unit": "image-pairs/s", "cores": oracle.num_threads(), "kind": "port",
+    base = {"value": n / el, "unit": "image-pairs/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"{n} pairs of 4096x4096x64 (M-SURF-4k) in {el:.1f}s, OpenMP over query rows"}
+    ver = None
+    if gpu_results is not None:
+        ver = {"ok": not bad and checked > 0, "pairs_checked": checked, "pairs_per_step": len(pairs), "queries_checked": checked * N_FEATS,
+               "mismatching_pairs": bad[:16],
+               "what": "every (queryIdx, trainIdx, distance bits) of the ratio-test survivors, match lists in order"}
+    return base, ver
 
 
 def cpu_baseline_ba(scene, iters: int = 25):
@@ -89,6 +105,50 @@ def cpu_baseline_ba(scene, iters: int = 25):
             "sample": f"{s.num_iterations} LM iterations of BA-25 (25 cams, 30k pts, 240k obs) in {s.solve_seconds:.1f}s"}
 
 
+def dry_run(args) -> int:
+    """The launcher path without a GPU: every rank reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exactly as the real run does,
+    the ranks meet on MASTER_ADDR:MASTER_PORT (rank 0 listens, the others report in), and rank 0 prints the one JSON line."""
+    import socket
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    # (MASTER_PORT itself may be taken: torch.distributed.run's agent keeps its store there.  The dry run meets next door.)
+    port = port + 1 if port < 65535 else port - 1
+    print(f"[bench dry-run] RANK={rank} LOCAL_RANK={local_rank} WORLD_SIZE={world} MASTER={addr}:{port}", file=sys.stderr, flush=True)
+    n_frames = frames_for(world)
+    n_pairs = n_frames * (n_frames - 1) // 2
+    mine = len(range(rank, n_pairs, world))      # stand-in for esfm_shard_pair_list (equal-cost pairs: round robin)
+    seen = {rank: mine}
+    if world > 1:
+        if rank == 0:
+            srv = socket.socket(); srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port)); srv.listen(world); srv.settimeout(60.0)
+            for _ in range(world - 1):
+                c, _a = srv.accept()
+                r, m = (int(x) for x in c.makefile().readline().split())
+                seen[r] = m; c.close()
+            srv.close()
+        else:
+            deadline = time.time() + 60.0
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0); break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            c.sendall(f"{rank} {mine}\n".encode()); c.close()
+    if rank == 0:
+        ok = sorted(seen) == list(range(world)) and sum(seen.values()) == n_pairs
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "ranks_seen": sorted(seen), "pairs_per_rank": [seen[r] for r in sorted(seen)],
+                          "pairs_total": n_pairs, "torch_imported": "torch" in sys.modules, "ok": bool(ok)}), flush=True)
+        return 0 if ok else 4
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +160,9 @@ def main() -> int:
     ap.add_argument("--no-config45", action="store_true", help="skip the config-4 / config-5 strong-scaling legs")
     ap.add_argument("--config4-steps", type=int, default=2)
     ap.add_argument("--ba512-iters", type=int, default=20)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the launcher and the rank environment only: no torch / HIP import, no GPU; ranks meet over a "
+                         "TCP socket on MASTER_ADDR:MASTER_PORT and rank 0 prints one JSON line with n_gpus")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -115,6 +178,9 @@ def main() -> int:
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         rcs = [p.wait() for p in procs]
         return max(rcs, key=abs)
+
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -179,18 +245,21 @@ def main() -> int:
     total_pairs = float(npairs.item())
     value = total_pairs * args.steps / elapsed
 
-    # correctness spot check (outside the timed region): one pair against the oracle, bit for bit
-    verified = None
+    # correctness check (outside the timed region).  With the CPU baseline leg on (rank 0, N = 1) the oracle runs the step's WHOLE
+    # pair list there and every pair's match list is compared bit for bit (`verified_scope` says how much was checked); otherwise
+    # a spot check: 512 queries of this rank's first pair.
+    verified, verified_scope, res_host = None, None, None
     if rank == 0:
         try:
             import oracle
-            res = pm.match(ratio).to_host()
+            res_host = pm.match(ratio).to_host()
             i, j = pairs[0]
             rq, rt, rd = oracle.match_l2(sets[i][:512], sets[j], ratio)
-            q, t, d = res[0]
+            q, t, d = res_host[0]
             m = q < 512
             verified = bool(np.array_equal(q[m], rq) and np.array_equal(t[m], rt) and
                             np.array_equal(d[m].view(np.uint32), rd.view(np.uint32)))
+            verified_scope = "spot check: 512 queries of pair 0"
         except Exception as e:  # the checker must never take the measurement down
             verified = f"check failed to run: {e!r}"
 
@@ -227,7 +296,7 @@ def main() -> int:
                                f"{n_frames} imgs x {N_FEATS} feats x {DIM} f32, {int(total_pairs)} pairs/step, "
                                "pair list partitioned over ranks, no collective",
                    "pairs_per_step": int(total_pairs), "features_per_image": N_FEATS, "descriptor_dim": DIM, "ratio": ratio},
-        "roofline": roofline, "verified_vs_oracle": verified,
+        "roofline": roofline, "verified_vs_oracle": verified, "verified_scope": verified_scope,
     }
 
     # ---------------------------------------------------------------- BA half of the metric
@@ -287,8 +356,10 @@ def main() -> int:
         if world > 1:
             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
         ba_el = float(tt2.item())
-        # compulsory bytes of the Jacobian sweep: 16 B in, 304 B out per observation (Jc 96 + Jp 48 + res 16 + W = F'E 144), DESIGN 4
-        sweep_bytes = 320.0 * len(ci) + 48.0 * scene.n_cam + 24.0 * scene.n_pt
+        # compulsory bytes of the Jacobian sweep = 176 Nobs + 48 Nc + 24 Np (16 B in, J 144 B + r 16 B out per
+        # observation) -- the figure `achieved` / `frac` use.  What the kernel is built to write is reported beside it.
+        sweep_bytes = 176.0 * len(ci) + 48.0 * scene.n_cam + 24.0 * scene.n_pt
+        sweep_bytes_design = float(E.ba_sweep_bytes_per_obs()) * len(ci) + 48.0 * scene.n_cam + 24.0 * scene.n_pt
         lin_s = (l_ms / max(l_n, 1)) * 1e-3
         n_red = 6 * scene.n_cam
         leg = {
@@ -304,14 +375,17 @@ def main() -> int:
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0,
                          "traffic": traffic_ba if name == "ba" else None,
-                         "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes},
+                         "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes,
+                         "algorithmic_bytes_formula": "176*Nobs + 48*Nc + 24*Np (SURVEY 8d)",
+                         "designed_bytes_per_launch": sweep_bytes_design,
+                         "frac_designed_bytes": (sweep_bytes_design / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0},
             "schur_kernel_avg_ms": s_ms / max(s_n, 1), "solve_kernel_avg_ms": c_ms / max(c_n, 1),
             "solve_gflops_f64": (n_red ** 3 / 3.0) / (c_ms / max(c_n, 1) * 1e-3) / 1e9 if c_n else None,
         }
         return leg, summ
 
     if not args.no_ba:
-        watchdog = threading.Timer(400.0, lambda: (out.setdefault("ba", {"error": "BA leg timed out"}), emit(), os._exit(0)))
+        watchdog = threading.Timer(400.0, lambda: (out.setdefault("ba", {"error": "BA leg timed out"}), emit(), os._exit(3)))
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -340,7 +414,7 @@ def main() -> int:
 
     # ---------------------------------------------------------------- BASELINE configs 4 and 5 (strong scaling over the ranks)
     if not args.no_config45 and not args.no_ba:
-        watchdog = threading.Timer(900.0, lambda: (out.setdefault("config4", {"error": "config 4/5 legs timed out"}), emit(), os._exit(0)))
+        watchdog = threading.Timer(900.0, lambda: (out.setdefault("config4", {"error": "config 4/5 legs timed out"}), emit(), os._exit(3)))
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -577,7 +651,13 @@ def main() -> int:
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline_match(sets)
+            out["cpu_baseline"], ver = cpu_baseline_match(sets, pairs, res_host)
+            if ver is not None:
+                out["verified_vs_oracle"] = bool(ver["ok"])
+                out["verified_scope"] = (f"all {ver['pairs_checked']} of {ver['pairs_per_step']} pairs of the step "
+                                         f"({ver['queries_checked']} queries): {ver['what']}")
+                if ver["mismatching_pairs"]:
+                    out["verified_mismatching_pairs"] = ver["mismatching_pairs"]
             if "ba" in out and "error" not in out["ba"]:
                 out["ba"]["cpu_baseline"] = cpu_baseline_ba(synth.ba_scene(25, 30000, 8, radius=10.0, extent=2.0, seed=4000))
         except Exception as e:

@@ -17,6 +17,15 @@ from ._lib import ALLREDUCE_FN, BAOptions, BASummary, Context, ESFM_REDUCE_MAX, 
 from .types import Frame, SparsePointCloud
 
 
+# Bytes per observation the Jacobian sweep (ba_linearize_kernel) is BUILT to move: 16 in (cam / point index, uv) + Jc 96 + Jp 48 +
+# res 16 + W = F'E 144 out.  SURVEY 8(d)'s compulsory figure (no W) is 176; bench.py prices the kernel on that one.
+BA_SWEEP_BYTES_PER_OBS = 320
+
+
+def ba_sweep_bytes_per_obs() -> int:
+    return BA_SWEEP_BYTES_PER_OBS
+
+
 def default_options() -> BAOptions:
     o = BAOptions()
     lib().esfm_ba_options_default(C.byref(o))

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <thread>
 #include <climits>
+#include <cstdlib>
 #include <cmath>
 #include <cfloat>
 #include <vector>
@@ -33,6 +34,17 @@ struct esfm_ba_problem {
 };
 
 namespace {
+
+// upper bound (seconds) on the host's wait for one scalar read-back; see Solver::fetch_scal
+long readback_timeout_s()
+{
+    static const long v = [] {
+        const char *e = getenv("ESFM_BA_READBACK_TIMEOUT_S");
+        const long t = e ? atol(e) : 0;
+        return t > 0 ? t : 600L;
+    }();
+    return v;
+}
 
 template <class T> int dev_alloc(esfm_ba_problem *p, T **out, size_t count)
 {
@@ -111,9 +123,16 @@ struct Solver {
                     esfm::set_error("BA scalar publication was not observed");
                     return ESFM_ERR_HIP;
                 }
-                // no wall-clock limit: a large reduced system (6 n_cam up to 46 000) legitimately keeps the stream busy for
-                // seconds; hipStreamQuery above is what detects completion and failure.  After a while stop burning a core.
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+                // A large reduced system (6 n_cam up to 46 000) legitimately keeps the stream busy for seconds; hipStreamQuery above
+                // is what detects completion and failure.  After a while stop burning a core -- and past a generous bound (10 min,
+                // ESFM_BA_READBACK_TIMEOUT_S overrides) give up with an error instead of spinning forever behind a wedged stream
+                // (a dataflow kernel that lost a flag, a stuck collective of a sharded solve).
+                const auto waited = std::chrono::steady_clock::now() - t0;
+                if (waited > std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+                if (waited > std::chrono::seconds(readback_timeout_s())) {
+                    esfm::set_error("BA scalar read-back timed out (stream never completed)");
+                    return ESFM_ERR_HIP;
+                }
             }
         }
         scal_zeroed = true;

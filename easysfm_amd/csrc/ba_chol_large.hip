@@ -203,7 +203,11 @@ __device__ __forceinline__ void st_coh(double *p, double v) { __hip_atomic_store
 __device__ __forceinline__ double ld_coh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void publish_flag(int *f, int value = 1)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have been acknowledged
+    // The workgroup-scope release fence alone emits NO s_waitcnt vmcnt(0) on gfx950 (a workgroup shares its L1 outside tgsplit
+    // mode, so the compiler has nothing to wait for): the flag store could overtake the sc1 data stores on another channel.  The
+    // explicit wait makes every wave's write-through stores L2-acknowledged before the barrier lets the flag out.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores have been acknowledged by L2
     __syncthreads();                                            // ... and everybody else's
     if (threadIdx.x == 0) __hip_atomic_store(f, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -1908,7 +1908,9 @@ __global__ __launch_bounds__(1024) void ba_publish_scalars_kernel(const double *
         __hip_atomic_store(&host[i], scal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         scal[i] = 0.0;       // every read-back is followed by a reset before the next scalar-producing launch: done here, not by a memset launch
     }
+    // (the workgroup-scope fence emits no s_waitcnt vmcnt(0) on gfx950: the explicit one is what keeps the flag behind the slots)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
         // every train outside the candidates has key >= tau, hence s >= tau - 2^-14 |tau| (truncation);
         // the candidate set provably contains the two best iff |q|^2 + tau - eps exceeds the second
         // best exact d^2 by more than sqrt's rounding can hide.
-        bool certified = !(tau < 1.0e38f) && !poison;   // an empty slot in either lane: every train row is a candidate
+        bool certified = (tau >= 1.0e38f) && !poison;   // an empty slot in either lane: every train row is a candidate (a NaN tau is NOT certified)
         if (!certified && b1.i >= 0 && !poison) {
             const double qn = (double)norms[pd.q_row0 + qrow];
             const double eps = (qn + (double)tmax) * (1.0 / 65536.0) + fabs((double)tau) * (1.0 / 16384.0);
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
             knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
             knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
-            bool certified = !(tau < 1.0e38f);
+            bool certified = (tau >= 1.0e38f);       // the empty-slot sentinel; a NaN tau compares false and goes to the re-scan
             if (!certified && b1i >= 0) {
                 const double eps = (qn + (double)tmax) * (1.0 / 32768.0) + fabs((double)tau) * (1.0001 / 32768.0);
                 certified = (qn + (double)tau - eps) > (double)b1q * (1.0 + 1.0 / 2097152.0);

@@ -277,3 +277,54 @@ def test_config3_orb_pipeline_fountain(tmp_path):
     for out in (out_c, out_p):
         xyz, rgb, cam = E.read_ply_vertices(str(out))
         assert len(xyz) > 1000 and np.all(np.isfinite(xyz))
+
+
+def test_config1_run_fountain_small_as_stated(tmp_path):
+    """BASELINE config 1 AS STATED (reference cpp_code/script/run_fountain_small.sh:1-24, test/sfm.cpp:35-61): the 11 shipped
+    fountain images at their full 768 x 512, feature type S with minHessian 300, RANSAC threshold 1.0, initial-pair search on,
+    fixed calibration, BA every 4 frames -- launched through THIS repo's script/run_fountain_small.sh (the 13 positional
+    arguments in the reference's order) with SFM_DATA pointing at a test_data-shaped directory, once per driver
+    (bin/sfm_native, bin/sfm).  Status 1 (the reference's success code), all 11 frames registered, both drivers agree on every
+    deterministic stage before the first BA, more than 1000 finite points in the .ply."""
+    import os
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "sfm_native")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(root, "easysfm_amd", "csrc"), "../../bin/sfm_native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+    z = np.load(os.path.join(root, "tests", "golden", "fountain11_gray.npz"))
+    assert z["images"].shape == (11, 512, 768)
+    data = tmp_path / "test_data"
+    (data / "images_25").mkdir(parents=True); (data / "k_25").mkdir()
+    names = []
+    for i, img in enumerate(z["images"]):
+        names.append(f"{i:04d}.png")
+        PIL.fromarray(np.stack([img] * 3, axis=2)).save(str(data / "images_25" / names[-1]))
+    (data / "image_list.txt").write_text("\n".join(names) + "\n")
+    (data / "k_25" / "K.txt").write_text("689.87 0 380.17\r\n0 691.04 251.70\r\n0 0 1")          # test_data/k_25/K.txt
+    outs, logs = {}, {}
+    for tag, drv in (("native", "bin/sfm_native"), ("python", "bin/sfm")):
+        out = tmp_path / tag / "sfm_sparse_point_cloud_fountain.ply"
+        env = dict(os.environ, SFM_DATA=str(data), SFM_OUT=str(out), SFM_BIN=drv)
+        for k in ("FEATURE", "FEATURE_PARAM"):
+            env.pop(k, None)                                       # the script's defaults ARE config 1: S, 300
+        r = subprocess.run(["bash", os.path.join("script", "run_fountain_small.sh")], cwd=root, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 1, r.stdout[-3000:]
+        assert "sfm finished (status 1" in r.stdout and "Output ply file done." in r.stdout
+        assert r.stdout.count("Found ") == 11                      # detectFeaturesSURF on every image
+        assert "Progress: [ 11 / 11 ]" in r.stdout                 # every frame went through the registration loop
+        xyz, rgb, cam = E.read_ply_vertices(str(out))
+        assert len(xyz) > 1000 and np.all(np.isfinite(xyz)), len(xyz)
+        outs[tag], logs[tag] = xyz, r.stdout
+
+    def stages(text):
+        keys = ("verified matches", "total unique feature point number", "Initialization frames", "Found ")
+        return [l.strip() for l in text.splitlines() if any(k in l for k in keys)]
+    sn, sp = stages(logs["native"]), stages(logs["python"])
+    assert len(sn) > 30 and sn == sp
+    print("config 1:", [l for l in sn if l.startswith("Found ")][:3], "...", [l for l in sn if "Initialization" in l],
+          "points:", len(outs["native"]), len(outs["python"]))
+    assert abs(len(outs["native"]) - len(outs["python"])) <= 0.1 * len(outs["python"])
