@@ -37,6 +37,9 @@ Operands: %0-%5 out: segment keys k0 k1 k2 of set 0, then set 1;  %6-%13 in: Bhi
 import os
 import sys
 
+# timing-only experiment knobs (the shipped file is generated with the defaults): products per K-step, keys kept by the fold
+PRODUCTS = int(os.environ.get("ESFM_GEN_PRODUCTS", "3"))
+KEEP = int(os.environ.get("ESFM_GEN_KEEP", "3"))
 DMA_SPREAD = int(os.environ.get("ESFM_GEN_DMA_SPREAD", "1"))   # 0: all eight pieces back to back after the barrier (measured 2 % slower)
 KBIG = 0x7F61B1E6          # 3.0e38f
 NKBIG = 0xFF61B1E6
@@ -133,9 +136,10 @@ def gen():
     def fold(s, ks, p):
         b = p[s] + 4 * ks
         t, key = 130 + 2 * s, 131 + 2 * s
+        extra = [f"v_med3_f32 v{136 + 4 * s + i}, v{136 + 4 * s + i}, {OP_K(s, 2)}, v{key}" for i in range(KEEP - 3)]   # timing only
         return [f"v_min3_f32 v{t}, v{b}, s46, v{b + 1}",
                 f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
-                f"v_and_or_b32 v{key}, v{t}, v134, s44",
+                f"v_and_or_b32 v{key}, v{t}, v134, s44"] + extra + [
                 f"v_med3_f32 {OP_K(s, 2)}, {OP_K(s, 1)}, {OP_K(s, 2)}, v{key}",
                 f"v_med3_f32 {OP_K(s, 1)}, {OP_K(s, 0)}, {OP_K(s, 1)}, v{key}",
                 f"v_med3_f32 {OP_K(s, 0)}, {OP_K(s, 0)}, v{key}, s47"]
@@ -166,21 +170,30 @@ def gen():
             e(f"s_waitcnt lgkmcnt({WAIT[ks]})")
         e(f"s_add_u32 s44, s41, {ks}")
         c = [vr(96), vr(96)] if ks == 0 else [vr(n[0]), vr(n[1])]
-        for s in range(2):
-            e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, 0)}, {OP_BLO(s, ks)}, {c[s]}")
+        if PRODUCTS >= 3:
+            for s in range(2):
+                e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, 0)}, {OP_BLO(s, ks)}, {c[s]}")
+            c = [vr(n[0]), vr(n[1])]
         for x in extra[0]:
             e(x)
+        if PRODUCTS == 1:          # one MFMA per set: each set's fold behind the other set's MFMA
+            e(f"v_mfma_f32_32x32x16_bf16 {vr(n[0])}, {fr(ks, 0)}, {OP_BHI(0, ks)}, {c[0]}")
         for x in fold(0, ks, p):
             e(x)
         second, third = ((0, 1) if os.environ.get("ESFM_GEN_A_ORDER", "hl") == "hh" else (1, 0))   # which A half goes second
-        for s in range(2):
-            e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, second)}, {OP_BHI(s, ks)}, {vr(n[s])}")
+        if PRODUCTS >= 2:
+            for s in range(2):
+                e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, second)}, {OP_BHI(s, ks)}, {c[s]}")
+            c = [vr(n[0]), vr(n[1])]
+        else:
+            e(f"v_mfma_f32_32x32x16_bf16 {vr(n[1])}, {fr(ks, 0)}, {OP_BHI(1, ks)}, {c[1]}")
         for x in extra[1]:
             e(x)
         for x in fold(1, ks, p):
             e(x)
-        for s in range(2):
-            e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, third)}, {OP_BHI(s, ks)}, {vr(n[s])}")
+        if PRODUCTS >= 2:
+            for s in range(2):
+                e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, third)}, {OP_BHI(s, ks)}, {vr(n[s])}")
         for x in extra[2]:
             e(x)
         for x in loads(ks, buf, base, nbuf, nbase):
@@ -281,7 +294,7 @@ def gen():
 
 def main():
     lines = gen()
-    clob = [f"v{i}" for i in range(136)] + [f"s{i}" for i in range(40, 54)] + ["scc", "vcc", "memory"]
+    clob = [f"v{i}" for i in range(136 if KEEP == 3 else 144)] + [f"s{i}" for i in range(40, 54)] + ["scc", "vcc", "memory"]
     out = ["// GENERATED by gen_l2_segment_asm.py -- do not edit; see that file for the schedule and the register map",
            "#define ESFM_L2_SEGMENT_ASM \\"]
     for l in lines:

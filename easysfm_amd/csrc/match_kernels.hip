@@ -22,7 +22,10 @@
 //
 // DESIGN.md "Matching" explains the data layout and the certificate.
 #include "match_kernels.hpp"
-#include "l2_segment_gfx950.inc"   // ESFM_L2_SEGMENT_ASM: the matcher's hand-scheduled main loop (gen_l2_segment_asm.py)
+#ifndef ESFM_L2_SEGMENT_INC            // (scratch/build_variant.sh swaps in experimental schedules)
+#define ESFM_L2_SEGMENT_INC "l2_segment_gfx950.inc"
+#endif
+#include ESFM_L2_SEGMENT_INC           // ESFM_L2_SEGMENT_ASM: the matcher's hand-scheduled main loop (gen_l2_segment_asm.py)
 
 #include <float.h>
 #include <type_traits>
