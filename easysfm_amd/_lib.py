@@ -19,7 +19,7 @@ ESFM_L2_F32 = 0
 ESFM_HAMMING = 1
 ESFM_REDUCE_SUM = 0
 ESFM_REDUCE_MAX = 1
-K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN, K_SOR_KNN, K_TRIANGULATE, K_RANSAC, K_SURF_DET, K_SURF_DESC, K_UNDISTORT, K_ORB_FAST = range(13)
+K_L2_KNN, K_HAMMING_KNN, K_BA_LINEARIZE, K_BA_SCHUR, K_BA_SOLVE, K_L2_RESCAN, K_SOR_KNN, K_TRIANGULATE, K_RANSAC, K_SURF_DET, K_SURF_DESC, K_UNDISTORT, K_ORB_FAST, K_L2_SECOND = range(14)
 BA_MAX_LOG = 256
 
 STATUS_NAMES = {
@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "esfm_version", "esfm_last_error", "esfm_device_count", "esfm_ctx_create", "esfm_ctx_destroy",
     "esfm_ctx_synchronize", "esfm_ctx_stream", "esfm_ctx_set_kernel_timing", "esfm_ctx_kernel_time",
     "esfm_knn2_l2_f32", "esfm_knn2_hamming", "esfm_match_l2_f32", "esfm_match_hamming",
-    "esfm_match_pairs_dev", "esfm_knn2_pairs_dev", "esfm_match_last_stats", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
+    "esfm_match_pairs_dev", "esfm_knn2_pairs_dev", "esfm_match_last_stats", "esfm_match_last_second_pass", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
     "esfm_shard_pair_list",
     "esfm_comm_get_unique_id", "esfm_comm_create", "esfm_comm_destroy", "esfm_comm_rank", "esfm_comm_world", "esfm_comm_allreduce",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
     L.esfm_match_pairs_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp]
     L.esfm_knn2_pairs_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
     L.esfm_match_last_stats.argtypes = [vp, i64p, i64p]
+    L.esfm_match_last_second_pass.argtypes = [vp, i64p]
     L.esfm_ctx_set_l2_audit.argtypes = [vp, C.c_int]
     L.esfm_match_last_flagged.argtypes = [vp, vp, C.c_int64, i64p]
     L.esfm_shard_pair_list.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]

@@ -56,13 +56,15 @@ struct esfm_ctx {
     // matching scratch
     esfm::DevBuf norms, pair_tab, knn_idx, knn_dist, flagged, counters, stage_a, stage_b, stage_c, stage_d, stage_e;
     esfm::DevBuf pair_cnt, pair_list;   // uncertified queries of the L2 pass binned per pair (one counter per pair; the pair's slice of the query numbering)
+    esfm::DevBuf pair_cnt2, pair_list2;   // the same for the second (three-product) pass over what the one-product pass left uncertified
+    esfm::DevBuf l2_hi;    // one-product pass: bf16(t) and bf16(-2 q) images (128 B per row each) and the two residual norms per row
     esfm::DevBuf hm_exp;   // expanded descriptor image: 0/1 bytes + start values (Hamming MFMA) or bf16 hi/lo halves (L2), 256 B per row
     // pinned host staging for small tables / counters
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     int64_t last_n_queries = 0;
     size_t last_pair_bytes = 0;
-    int l2_audit = 0;   // esfm_ctx_set_l2_audit: 0 product path, 1 no re-scan, 2 exact scan of every query
+    int l2_audit = 0;   // esfm_ctx_set_l2_audit: 0 product path, 1 no re-scan, 2 exact scan of every query, 3 one-product pass alone
     int pin(size_t bytes);
     // optional per-kernel hipEvent timing (esfm_ctx_set_kernel_timing)
     bool timing = false;

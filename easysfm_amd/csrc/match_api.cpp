@@ -82,6 +82,10 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
     if (metric == ESFM_L2_F32) {
         const float *desc = reinterpret_cast<const float *>(desc_dev);
         if (int rc = ctx->counters.reserve(64)) return rc;
+        if (ctx->l2_audit == 3 && !(esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass())) {
+            esfm::set_error("audit mode 3 needs the one-product pass (64-float descriptors, ESFM_L2_PASS unset)");
+            return ESFM_ERR_UNSUPPORTED;
+        }
         const bool bf16_pass = esfm::l2_mfma_supported(width) && ctx->l2_audit != 2 && esfm::l2_bf16_pass(width);
         if (!bf16_pass) ESFM_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 64, st));     // (the bf16 pass's split kernel zeroes them)
         ctx->last_n_queries = plan.total_queries;
@@ -90,21 +94,43 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
             if (esfm::l2_bf16_pass(width)) {
+                // 64-float rows.  Pass A: one bf16 product per f32 product, certifies most queries (l2_knn_bf16x1_kernel); pass B: its
+                // uncertified queries, pair by pair, through the three-product kernel in list mode; what THAT cannot certify takes
+                // the exact re-scan.  Audit modes: 1 stops after pass B, 3 runs pass A alone (its failures on the flagged list).
+                const bool front = esfm::l2_one_product_pass();
                 if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
                 if (int rc = ctx->pair_cnt.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
                 if (int rc = ctx->pair_list.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
+                if (front) {
+                    if (int rc = ctx->l2_hi.reserve(esfm::l2_hi_bytes(plan.total_rows))) return rc;
+                    if (int rc = ctx->pair_cnt2.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
+                    if (int rc = ctx->pair_list2.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
+                }
                 if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>(),
-                                                        ctx->pair_cnt.as<int32_t>(), n_pairs))
+                                                        ctx->pair_cnt.as<int32_t>(), n_pairs, front ? ctx->l2_hi.ptr : nullptr,
+                                                        front ? ctx->pair_cnt2.as<int32_t>() : nullptr))
                     return rc;
+                if (front) {
+                    {
+                        esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
+                        if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
+                                                                plan.n_blocks, knn_idx, knn_dist, ctx->l2_audit == 3 ? ctx->flagged.as<int32_t>() : nullptr,
+                                                                ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt2.as<int32_t>(),
+                                                                ctx->pair_list2.as<int32_t>()))
+                            return rc;
+                    }
+                    if (ctx->l2_audit == 3) return ESFM_OK;   // audit: the one-product pass's own answers and failures
+                }
                 {
-                    esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
+                    esfm::KernelTimer tm(ctx, front ? ESFM_K_L2_SECOND : ESFM_K_L2_KNN);
                     if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
                                                           plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
                                                           ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt.as<int32_t>(),
-                                                          ctx->pair_list.as<int32_t>()))
+                                                          ctx->pair_list.as<int32_t>(), front ? ctx->pair_cnt2.as<int32_t>() : nullptr,
+                                                          front ? ctx->pair_list2.as<int32_t>() : nullptr))
                         return rc;
                 }
-                if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the pass's own answer in place
+                if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the passes' own answer in place
                 // certificate failures, binned per pair by the pass: exact re-scan, the pair's queries sharing every train row
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_RESCAN);
                 return esfm::launch_l2_rescan64_pairs(st, desc, dev_tab, n_pairs, ctx->pair_cnt.as<int32_t>(), ctx->pair_list.as<int32_t>(),
@@ -292,9 +318,22 @@ int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanne
     return ESFM_OK;
 }
 
+int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass)
+{
+    if (!ctx || !n_second_pass) { esfm::set_error("esfm_match_last_second_pass: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+    int32_t c[2] = {0, 0};
+    if (ctx->counters.ptr) {
+        ESFM_HIP_TRY(hipMemcpyAsync(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *n_second_pass = c[1];
+    return ESFM_OK;
+}
+
 int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 2) { esfm::set_error("esfm_ctx_set_l2_audit: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    if (!ctx || mode < 0 || mode > 3) { esfm::set_error("esfm_ctx_set_l2_audit: bad arguments"); return ESFM_ERR_INVALID_ARG; }
     ctx->l2_audit = mode;
     return ESFM_OK;
 }

@@ -26,6 +26,10 @@
 #define ESFM_L2_SEGMENT_INC "l2_segment_gfx950.inc"
 #endif
 #include ESFM_L2_SEGMENT_INC           // ESFM_L2_SEGMENT_ASM: the matcher's hand-scheduled main loop (gen_l2_segment_asm.py)
+#ifndef ESFM_L2X1_SEGMENT_INC
+#define ESFM_L2X1_SEGMENT_INC "l2x1_segment_gfx950.inc"
+#endif
+#include ESFM_L2X1_SEGMENT_INC         // ESFM_L2X1_SEGMENT_ASM, ESFM_L2X1_KEEP: the one-product pass's main loop (gen_l2x1_segment_asm.py)
 
 #include <float.h>
 #include <type_traits>
@@ -475,11 +479,13 @@ __device__ __forceinline__ void bf16_split2(float a0, float a1, uint32_t &hi, ui
 // (Round 1: one thread per 16-feature group, four loads and eight stores of 16 B at a 64-B lane stride: 31 us per 25 x 4096 rows.)
 __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__restrict__ desc, long long n_pieces, u32x4 *__restrict__ out,
                                                             u32x4 *__restrict__ out_q, float *__restrict__ norms,
-                                                            int32_t *__restrict__ counters, int32_t *__restrict__ pair_cnt, int n_pairs)
+                                                            int32_t *__restrict__ counters, int32_t *__restrict__ pair_cnt, int n_pairs,
+                                                            u32x4 *__restrict__ hi_t, u32x4 *__restrict__ hi_q, float *__restrict__ rho_t,
+                                                            float *__restrict__ rho_q, int32_t *__restrict__ pair_cnt2)
 {
     const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
     if (f < 16) counters[f] = 0;
-    if (f < n_pairs) pair_cnt[f] = 0;
+    if (f < n_pairs) { pair_cnt[f] = 0; if (pair_cnt2) pair_cnt2[f] = 0; }
     const bool ok = f < n_pieces;
     const float4 v = ok ? desc[f] : make_float4(0.f, 0.f, 0.f, 0.f);
     float s = 0.f;
@@ -501,15 +507,35 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
         const uint32_t r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
         const u32x4 piece = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
         if (ok) (img == 0 ? out : out_q)[4 * g + slot] = piece;
+        if (hi_t) {
+            // The one-product pass (l2_knn_bf16x1_kernel) multiplies the hi halves only.  Its images are dense -- 128 B per row, the
+            // even lane's piece IS the 16-B slot of eight consecutive features -- and its certificate needs |x - hi(x)|_2 of every
+            // row in both roles (x = t and x = -2 q: the same number times two, except for denormals).  The residuals are exact in
+            // f32; the sum is rounded up by more than its 64-term error.
+            if (ok && !odd) (img == 0 ? hi_t : hi_q)[f >> 1] = piece;
+            const float e0 = __fsub_rn(sc * v.x, __uint_as_float(h0 << 16)), e1 = __fsub_rn(sc * v.y, __uint_as_float(h0 & 0xFFFF0000u));
+            const float e2 = __fsub_rn(sc * v.z, __uint_as_float(h1 << 16)), e3 = __fsub_rn(sc * v.w, __uint_as_float(h1 & 0xFFFF0000u));
+            float r = 0.f;
+            r = fmaf(e0, e0, r); r = fmaf(e1, e1, r); r = fmaf(e2, e2, r); r = fmaf(e3, e3, r);
+            r += __shfl_xor(r, 1);
+            r += __shfl_xor(r, 2);
+            r += __shfl_xor(r, 4);
+            r += __shfl_xor(r, 8);
+            if (ok && (f & 15) == 0) (img == 0 ? rho_t : rho_q)[f >> 4] = sqrtf(r) * 1.0005f;
+        }
     }
     if (ok && (f & 15) == 0) norms[f >> 4] = s;
 }
 
+// LIST: the workgroups of a pair take the queries named in the pair's slice of in_list (in_cnt[pair] of them: what the one-product
+// pass could not certify) instead of the query set's rows in order; a workgroup past the end of the list leaves at once.
+template <bool LIST>
 __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
                                                              const u32x4 *__restrict__ split_q, const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                              int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
-                                                             int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
+                                                             int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
+                                                             const int32_t *__restrict__ in_cnt, const int32_t *__restrict__ in_list)
 {
     constexpr int TT = 128, NS = 2, GRP = 4;                     // train rows per LDS tile, query sets of 32 per wave, rows per fold group
     constexpr int DIM = 64, QB = 128 * NS, SLOTS = 16, KS = 4;
@@ -530,6 +556,10 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
     const float *__restrict__ tn = norms + pd.t_row0;
     const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
+    const int nslots = LIST ? min(in_cnt[pi], nq) : nq;        // query slots of this pair: list entries, or the rows themselves
+    if (LIST && (lb - pd.blk_off) * QB >= nslots) return;      // (workgroup-uniform, before any barrier)
+    // query row of slot q of this pair (LIST: through the pair's list)
+    auto row_of_slot = [&](int q) { return LIST ? (q < nslots ? in_list[pd.out_off + q] : nq) : q; };
 
     // Running top-3 per query set, TWO levels deep in the hot loop (l2_segment_gfx950.inc).  A lane's 16 results of a 32-train
     // step are four groups of four consecutive train rows (accumulator registers 4g .. 4g+3 = rows 8g + 4h + 0..3).  Per group:
@@ -637,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     u32x4 bhi[NS][KS], blo[NS][KS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int qrow = qbase + 32 * s + j;
+        const int qrow = row_of_slot(qbase + 32 * s + j);
         const bool ok = qrow < nq;
         const u32x4 *qp = split_q + ((size_t)pd.q_row0 + (ok ? qrow : 0)) * SLOTS + h;
 #pragma unroll
@@ -718,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int qrow = qbase + 32 * s + j;
+        const int qrow = row_of_slot(qbase + 32 * s + j);
         const bool qvalid = qrow < nq;
         // the two best (distance, index, d^2) as plain scalars, updated without a branch (the struct form went through scratch
         // memory here, and every scratch access waits for the row transfer in flight)
@@ -732,9 +762,18 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
         // the 32 query rows of this set -> landing slots 0..31 (lanes j and j + 32 read the same slot); the group ranking below
         // runs in the transfer's shadow
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (LIST) {      // the 32 query rows are scattered: landing slot r takes the row lane r holds
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
+            for (int i = 0; i < 8; ++i) {
+                const int r = 4 * i + (lane >> 4);
+                const int src = __builtin_amdgcn_ds_bpermute(r * 4, qrow) * 256 + (swz[i & 3] & 255);
+                lds_dma_b128(lds_land + (uint32_t)i * 1024u, src, frsrc_q, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
+        }
         const Master mst = master_load(s);
         const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
         const float vk[3] = {mst.v0, mst.v1, mst.v2};
@@ -814,6 +853,280 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
             if (!certified) {
                 const int slot = atomicAdd(&counters[0], 1);
                 if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
+                pair_list[pd.out_off + atomicAdd(&pair_cnt[pi], 1)] = qrow;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The ONE-product distance pass (round 3): q.t ~ bf16(q).bf16(t), four v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 tile instead of
+// twelve.  Everything else is the machinery of l2_knn_bf16_kernel -- group-of-four fold, exact re-rank of the kept groups in the
+// oracle's order, certificate -- with three changes:
+//  * the operand rounding is part of the certificate's bound.  With B = bf16(-2 q), a = bf16(t), rB = |(-2 q) - B|_2 and
+//    rho_t = |t - a|_2 (both measured per row by l2_split_bf16_kernel):  |(-2 q).t - B.a| <= rB |t| + |B| rho_t, so
+//        E1 = (rB T + (2 |q| + rB) R) (1 + 2^-9) + 2^-15 (|q|^2 + max|t|^2),    T = max |t|,  R = max rho_t  over the train set,
+//    bounds |(|q|^2 + score) - d^2| for every train row (the 2^-15 term is the three-product pass's whole budget: norms, MFMA
+//    accumulation, the canonical distance; it has room to spare now that the dropped split terms are gone).  For unit-norm
+//    descriptors E1 ~ 0.008 against 6e-5: the pass keeps K = ESFM_L2X1_KEEP groups per lane instead of 3, which pushes tau -- the
+//    bound on every row outside the kept groups -- about as many ranks out as the larger error needs (simulated on M-SURF-4k,
+//    scratch/sim_bf16x1_cert.py: K = 3 leaves 6.9 % of the queries uncertified, K = 4 0.6 %, K = 6 0.01 %; the reference's own
+//    fountain descriptors 37 % / 15 % / 3.6 %);
+//  * what it cannot certify goes to the pair's list and from there through l2_knn_bf16_kernel<LIST> (three products, eps 2^-15),
+//    whose own failures take the exact re-scan as before -- the result stays bit-identical to the oracle whatever the data;
+//  * main loop l2x1_segment_gfx950.inc: ring of four 16-KiB tiles of bf16(t) rows, fragments prefetched a step ahead.
+// The master top-K lives in registers (the ring takes the LDS the three-product kernel's master had).
+__global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
+                                                               const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
+                                                               const float *__restrict__ rho_t, const float *__restrict__ rho_q,
+                                                               const PairDesc *__restrict__ pairs, int n_pairs,
+                                                               int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
+                                                               int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
+                                                               int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
+{
+    constexpr int TT = 128, NS = 2, GRP = 4, K = ESFM_L2X1_KEEP, RING = 4;
+    constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
+    constexpr int TILE_BYTES = TT * HS * 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [RING][TT * HS]: 64 KiB, later four landing zones
+    float *lds_norm = reinterpret_cast<float *>(smem + RING * TILE_BYTES);     // [RING][TT]   (the asm segment assumes norms right behind the ring)
+    float *lds_red = lds_norm + RING * TT;                                     // [8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = find_pair_by_block(pairs, n_pairs, lb);
+    const PairDesc pd = pairs[pi];
+    const int nq = pd.nq, nt = pd.nt;
+    const float *__restrict__ Q = desc + (size_t)pd.q_row0 * DIM;
+    const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
+    const float *__restrict__ tn = norms + pd.t_row0;
+    const float *__restrict__ tr = rho_t + pd.t_row0;
+    const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
+
+    constexpr float kBig = 3.0e38f;
+    constexpr int NG = 16 / GRP;
+    constexpr int kSegSub = 256 / NG;         // steps per segment: the 8-bit code is (step in segment) * NG + group
+    constexpr int kSegTiles = kSegSub / (TT / 32);
+    // master top-K per set: (key, first step of the key's segment), ascending
+    float mk[NS][K]; int mc[NS][K];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int m = 0; m < K; ++m) { mk[s][m] = kBig; mc[s][m] = -1; }
+    }
+    auto master_insert = [&](float (&v)[K], int (&c)[K], float key, int seg_sub0 /* wave-uniform */) {
+        const bool live = key < 1.0e38f;
+        bool lt[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) lt[m] = live && key < v[m];
+#pragma unroll
+        for (int m = K - 1; m >= 1; --m) {
+            v[m] = lt[m - 1] ? v[m - 1] : (lt[m] ? key : v[m]);
+            c[m] = lt[m - 1] ? c[m - 1] : (lt[m] ? seg_sub0 : c[m]);
+        }
+        v[0] = lt[0] ? key : v[0];
+        c[0] = lt[0] ? seg_sub0 : c[0];
+    };
+    auto group_row0_of = [&](float key, int seg_sub0) {
+        const int code = (int)(__float_as_uint(key) & 0xFFu);
+        const int r0 = GRP * (code % NG);
+        return key < 1.0e38f ? (seg_sub0 + code / NG) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h : -1;
+    };
+
+    const int ntiles = (nt + TT - 1) / TT;
+    const u32x4 trsrc = raw_buffer_rsrc(hi_t + (size_t)pd.t_row0 * HS, (uint32_t)nt * (HS * 16));   // reads past it return 0
+    const u32x4 nrsrc = raw_buffer_rsrc(tn, (uint32_t)nt * 4u);
+    const uint32_t lds_tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_tile);   // LDS byte address
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    // LDS-DMA of one tile: wave w stages rows [32 w, 32 w + 32), 8 rows = 1 KiB per instruction, lane l -> byte 16 l of the piece:
+    // row l >> 3, physical slot l & 7, which holds logical slot (l & 7) ^ ((row >> 1) & 7) (the asm's reads use the same map)
+    auto dma_tile = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave_s * 32 + 8 * i + (lane >> 3);
+            const int voff = row * (HS * 16) + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+            lds_dma_b128(lds_tile_addr + (uint32_t)(buf * TILE_BYTES + (wave_s * 32 + 8 * i) * (HS * 16)), voff, trsrc, tile * TILE_BYTES);
+        }
+    };
+    // Uninitialised LDS under rows that are never transferred (past nt in the last tile) must at least not hold huge finite values
+    if (ntiles * TT != nt || ntiles < RING) {
+        for (int i = tid; i < RING * TT * HS; i += 256) lds_tile[i] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+
+    // B operands: bf16(-2 q), this lane's 8 features of every K-step
+    u32x4 bq[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool ok = qrow < nq;
+        const u32x4 *qp = hi_q + ((size_t)pd.q_row0 + (ok ? qrow : 0)) * HS + h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 v = qp[2 * ks];
+            if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+            bq[s][ks] = v;
+        }
+    }
+    // norms of the first RING tiles: tile 0 straight to LDS, tiles 1..3 into the ring's norm registers (the segment code writes a
+    // tile's norms at the hand-over that publishes it, rows past nt as kBig)
+    if (tid < TT) lds_norm[tid] = tid < nt ? tn[tid] : kBig;
+    float nr[RING];
+    nr[0] = 0.f;
+#pragma unroll
+    for (int b = 1; b < RING; ++b) {
+        const int row = b * TT + wave * 32 + (lane & 31);
+        nr[b] = row < nt ? tn[row] : 0.f;
+    }
+    // max |t|^2 and max rho_t over the train set (the certificate's bound needs both in the tail)
+    {
+        float m = 0.f, r = 0.f;
+        for (int t = tid; t < nt; t += 256) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
+        if (lane == 0) { lds_red[wave] = m; lds_red[4 + wave] = r; }
+    }
+    // the ring's first four tiles (a tile that does not exist reads zeros through the descriptor); tile 0 must have landed
+    // before the first segment starts -- the three younger transfers (12 pieces) may stay in flight
+    dma_tile(0, 0);
+    dma_tile(1, 1); dma_tile(2, 2); dma_tile(3, 3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __syncthreads();
+
+    for (int t0 = 0; t0 < ntiles; t0 += kSegTiles) {
+        const int t1 = min(t0 + kSegTiles, ntiles);
+        float kk[NS][K];
+        static_assert(K == 4, "operand list below is written for four keys per set");
+        asm volatile(ESFM_L2X1_SEGMENT_ASM
+                     : "=&v"(kk[0][0]), "=&v"(kk[0][1]), "=&v"(kk[0][2]), "=&v"(kk[0][3]), "=&v"(kk[1][0]), "=&v"(kk[1][1]), "=&v"(kk[1][2]), "=&v"(kk[1][3]),
+                       "+v"(nr[0]), "+v"(nr[1]), "+v"(nr[2]), "+v"(nr[3])
+                     : "v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[0][2]), "v"(bq[0][3]), "v"(bq[1][0]), "v"(bq[1][1]), "v"(bq[1][2]), "v"(bq[1][3]),
+                       "s"(t0), "s"(t1), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
+                     : ESFM_L2X1_SEGMENT_CLOBBERS);
+        const int seg_sub0 = t0 * (TT / 32);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int m = 0; m < K; ++m) master_insert(mk[s], mc[s], kk[s][m], seg_sub0);
+        }
+    }
+
+    const float tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
+    const float rmax = fmaxf(fmaxf(lds_red[4], lds_red[5]), fmaxf(lds_red[6], lds_red[7]));
+
+    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate (see l2_knn_bf16_kernel: the same scheme with
+    // 2 K groups per query, dealt out over K rounds) ----
+    lds_dma_wait();
+    __syncthreads();   // every wave is through its last tile: the ring becomes four private 16-KiB landing zones
+    const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
+    const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);
+    const uint32_t lds_land = lds_tile_addr + (uint32_t)wave_s * 16384u;
+    const float4 *land = reinterpret_cast<const float4 *>(smem) + (size_t)wave * 1024;
+    int swz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool qvalid = qrow < nq;
+        float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
+        auto insert2 = [&](bool valid, float d, int i, float d2) {
+            const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
+            const bool c0 = valid && (d < b0d || (d == b0d && i < b0i));
+            b1d = c0 ? b0d : (c1 ? d : b1d); b1i = c0 ? b0i : (c1 ? i : b1i); b1q = c0 ? b0q : (c1 ? d2 : b1q);
+            b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
+        const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
+        const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
+        float vk[K], pk[K]; int g0[K], pg[K], rank_own[K], rank_par[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { vk[i] = mk[s][i]; g0[i] = group_row0_of(mk[s][i], mc[s][i]); }
+#pragma unroll
+        for (int i = 0; i < K; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
+            rank_own[i] = i; rank_par[i] = i;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                rank_own[i] += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
+                rank_par[i] += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
+            }
+        }
+        const float kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));     // second smallest of the 2 K keys
+        const double qn = (double)qnorm_s;
+        const double e1 = ((double)qrho_s * sqrt((double)tmax) + (2.0 * sqrt(qn) + (double)qrho_s) * (double)rmax) * (1.0 + 1.0 / 512.0) +
+                          (qn + (double)tmax) * (1.0 / 32768.0);
+        constexpr double kTrunc = 1.0001 / 32768.0;
+        const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
+        float4 qv[16];
+        lds_dma_wait();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
+#ifdef ESFM_X1_NOTAIL            // (timing experiments)
+        for (int r = 0; r < 0; ++r) {
+#else
+        for (int r = 0; r < K; ++r) {
+#endif
+            const int want = 2 * r + h;
+            float key = kBig; int row0 = -1;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
+                if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
+            }
+            const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
+            const bool need = row0 >= 0 && qvalid && !cannot;
+            if (__ballot(need) == 0ull) break;
+            const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
+            int rowsrc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (swz[i & 3] & 255);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents are in registers
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                float4 ra_[16];
+                lds_dma_wait();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) ra_[c] = land[lane * 16 + (c ^ (lane & 15))];
+                if (u + 1 < GRP) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
+                }
+                const float da = l2sqr64_canonical_regs(qv, ra_);
+                const int ta_ = row0 + u;
+                insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
+            }
+        }
+        {
+            const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
+            const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
+            insert2(pi0 >= 0, pd0, pi0, pq0);
+            insert2(pi1 >= 0, pd1, pi1, pq1);
+        }
+        const float tau = fminf(vk[K - 1], pk[K - 1]);
+        if (qvalid && h == 0) {
+            const size_t o = 2 * ((size_t)pd.out_off + qrow);
+            knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
+            knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
+            bool certified = (tau >= 1.0e38f);       // the empty-slot sentinel: every train row is a candidate (a NaN tau compares false)
+            if (!certified && b1i >= 0) {
+                const double eps = e1 + fabs((double)tau) * kTrunc;
+                certified = (qn + (double)tau - eps) > (double)b1q * (1.0 + 1.0 / 2097152.0);     // false on NaN (e1 of non-finite rows)
+            }
+            if (!certified) {
+                atomicAdd(&counters[1], 1);
+                if (flagged) {           // audit of THIS pass's certificate: its failures on the global list
+                    const int slot = atomicAdd(&counters[0], 1);
+                    if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
+                }
                 pair_list[pd.out_off + atomicAdd(&pair_cnt[pi], 1)] = qrow;
             }
         }
@@ -1453,29 +1766,73 @@ constexpr int kL2BfSets = 2;     // query sets of 32 per wave in l2_knn_bf16_ker
 int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; }
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
 
+// one-product pass scratch: [bf16(t) image: 128 B/row][bf16(-2 q) image: 128 B/row][rho_t: 4 B/row][rho_q: 4 B/row]
+size_t l2_hi_bytes(long long total_rows) { return (size_t)(128 + 128 + 4 + 4) * (size_t)std::max(total_rows, 1LL); }
+static inline char *l2_hi_part(void *hi, long long total_rows, int part)
+{
+    const size_t n = (size_t)std::max(total_rows, 1LL);
+    const size_t off[4] = {0, 128 * n, 256 * n, 260 * n};
+    return static_cast<char *>(hi) + off[part];
+}
+bool l2_one_product_pass()
+{
+    static const bool off = [] { const char *e = getenv("ESFM_L2_PASS"); return e && strcmp(e, "bf16x3") == 0; }();
+    return !off;
+}
+
 int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms, int32_t *counters,
-                         int32_t *pair_cnt, int n_pairs)
+                         int32_t *pair_cnt, int n_pairs, void *hi, int32_t *pair_cnt2)
 {
     // `split` holds two images of 256 B per row: the train operand, then the query operand (-2 x)
     const long long n_pieces = std::max(total_rows * 16, (long long)std::max(n_pairs, 16));     // the launch also zeroes counters / pair_cnt
     hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st,
                        reinterpret_cast<const float4 *>(desc), total_rows * 16, reinterpret_cast<u32x4 *>(split),
-                       reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, counters, pair_cnt, n_pairs);
+                       reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, counters, pair_cnt, n_pairs,
+                       hi ? reinterpret_cast<u32x4 *>(l2_hi_part(hi, total_rows, 0)) : nullptr,
+                       hi ? reinterpret_cast<u32x4 *>(l2_hi_part(hi, total_rows, 1)) : nullptr,
+                       hi ? reinterpret_cast<float *>(l2_hi_part(hi, total_rows, 2)) : nullptr,
+                       hi ? reinterpret_cast<float *>(l2_hi_part(hi, total_rows, 3)) : nullptr, pair_cnt2);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
 
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                       int32_t *pair_cnt, int32_t *pair_list)
+                       int32_t *pair_cnt, int32_t *pair_list, const int32_t *in_cnt, const int32_t *in_list)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
     constexpr size_t lds = 2 * TT * 16 * 16 + 2 * TT * 4 + 16 + kL2BfSets * 6 * 256 * 4;   // two tiles, their norms, the master top-3
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    hipLaunchKernelGGL(l2_knn_bf16_kernel, dim3(n_blocks), dim3(256), lds, st, desc, reinterpret_cast<const u32x4 *>(split),
-                       reinterpret_cast<const u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, pairs,
-                       n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
+    const u32x4 *sp = reinterpret_cast<const u32x4 *>(split);
+    const u32x4 *sq = sp + (size_t)std::max(total_rows, 1LL) * 16;
+    if (in_cnt)     // (the grid is the full one: the list's length is only known on the device; a workgroup past its end leaves at once)
+        hipLaunchKernelGGL(l2_knn_bf16_kernel<true>, dim3(n_blocks), dim3(256), lds, st, desc, sp, sq, norms, pairs,
+                           n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, in_cnt, in_list);
+    else
+        hipLaunchKernelGGL(l2_knn_bf16_kernel<false>, dim3(n_blocks), dim3(256), lds, st, desc, sp, sq, norms, pairs,
+                           n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, in_cnt, in_list);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
+                         int32_t *pair_cnt, int32_t *pair_list)
+{
+    if (n_blocks <= 0) return ESFM_OK;
+    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_knn_bf16x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    void *h = const_cast<void *>(hi);
+    hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(n_blocks), dim3(256), lds, st, desc,
+                       reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
+                       reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
+                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -24,12 +24,21 @@ bool l2_bf16_pass(int dim);
 int l2_query_block(int dim);
 size_t l2_split_bytes(int dim, long long total_rows);
 // writes the hi/lo image AND the row norms
-// also zeroes counters[0..16) and pair_cnt[0..n_pairs)
+// also zeroes counters[0..16), pair_cnt[0..n_pairs) and (if given) pair_cnt2[0..n_pairs).
+// hi != NULL: also the one-product pass's images and residual norms (l2_hi_bytes(total_rows) of scratch, layout l2_hi_*() below)
 int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms, int32_t *counters,
-                         int32_t *pair_cnt, int n_pairs);
+                         int32_t *pair_cnt, int n_pairs, void *hi, int32_t *pair_cnt2);
+// three-product pass.  in_cnt / in_list != NULL: list mode -- the queries of pair p are in_list[out_off[p] ...][0, in_cnt[p]).
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                       int32_t *pair_cnt, int32_t *pair_list);
+                       int32_t *pair_cnt, int32_t *pair_list, const int32_t *in_cnt, const int32_t *in_list);
+// one-product pass (64-float rows): certifies most queries, bins the rest per pair (pair_cnt / pair_list) for the three-product
+// pass in list mode; counters[1] counts them.  flagged != NULL (audit): its failures also go to the global list, counters[0].
+size_t l2_hi_bytes(long long total_rows);
+int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
+                         int32_t *pair_cnt, int32_t *pair_list);
+bool l2_one_product_pass();   // ESFM_L2_PASS=bf16x3 in the environment switches the one-product front pass off (measurement)
 // exact re-scan of the queries launch_l2_knn_bf16 binned per pair (pair_cnt[p] entries at pair_list[out_off[p]...])
 int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *pairs, int n_pairs, const int32_t *pair_cnt,
                              const int32_t *pair_list, int32_t *knn_idx, float *knn_dist);

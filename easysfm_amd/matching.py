@@ -256,7 +256,7 @@ class PairMatcher:
         return self.knn_idx, self.knn_dist
 
     def set_l2_audit(self, mode: int) -> None:
-        """Certificate audit (tests): 0 product path, 1 skip the exact re-scan, 2 brute-force every query (esfm.h)."""
+        """Certificate audit (tests): 0 product path, 1 skip the exact re-scan, 2 brute-force every query, 3 the one-product pass alone (esfm.h)."""
         check(lib().esfm_ctx_set_l2_audit(self.ctx.handle, int(mode)))
 
     def flagged(self) -> np.ndarray:
@@ -273,6 +273,12 @@ class PairMatcher:
         check(lib().esfm_match_last_stats(self.ctx.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+
+    def second_pass(self) -> int:
+        """Queries of the last L2 call the one-product bf16 pass handed to the three-product pass (64-float descriptors); synchronises."""
+        a = C.c_int64(0)
+        check(lib().esfm_match_last_second_pass(self.ctx.handle, C.byref(a)))
+        return a.value
 
 def shard_pair_list(n_frames: int, rows_per_frame: Optional[np.ndarray], rank: int, world: int) -> np.ndarray:
     """This rank's share of the (i, j<i) pair list (host-only, no GPU)."""

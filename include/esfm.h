@@ -75,7 +75,7 @@ void *esfm_ctx_stream(esfm_ctx *ctx);
  * elapsed times of all launches since the last call for that kernel to
  * *total_ms / *launches (caller zero-initialises) and recycles the events. */
 typedef enum esfm_kernel_id {
-    ESFM_K_L2_KNN = 0,        /* l2_knn_bf16_kernel (dim 64) / l2_knn_mfma_kernel: MFMA distance pass + fused top-k + re-rank */
+    ESFM_K_L2_KNN = 0,        /* l2_knn_bf16x1_kernel (dim 64) / l2_knn_mfma_kernel: MFMA distance pass + fused top-k + re-rank */
     ESFM_K_HAMMING_KNN = 1,   /* hamming_expand_kernel + hamming_knn_mfma_kernel / hamming_knn_kernel */
     ESFM_K_BA_LINEARIZE = 2,  /* ba_linearize_kernel: the Jacobian sweep                        */
     ESFM_K_BA_SCHUR = 3,      /* ba_schur_kernel                                                */
@@ -88,7 +88,8 @@ typedef enum esfm_kernel_id {
     ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
     ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
     ESFM_K_ORB_FAST = 12,     /* orb_fast_kernel: FAST-9/16 score of every pyramid pixel          */
-    ESFM_K_COUNT = 13
+    ESFM_K_L2_SECOND = 13,    /* l2_knn_bf16_kernel<LIST>: three-product pass over the queries the one-product pass left uncertified */
+    ESFM_K_COUNT = 14
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
 int esfm_ctx_kernel_time(esfm_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
@@ -162,11 +163,16 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
  * queries whose MFMA candidate list could not be certified and were re-scanned
  * exactly (see DESIGN.md "certified re-rank").  For tests and profiling. */
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned);
+/* 64-float descriptors: queries the one-product bf16 pass could not certify and handed to the three-product pass
+ * (of which n_rescanned went on to the exact re-scan).  0 for other widths. */
+int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass);
 
 /* Audit of the L2 certificate (tests only; the default mode 0 is the product path).
  *   mode 1: the MFMA pass runs but the exact re-scan of uncertified queries is SKIPPED, so the
  *           2-NN table holds the pass's own answer for every query;
- *   mode 2: every query is brute-forced by l2_exact_scan_kernel (no MFMA pass).
+ *   mode 2: every query is brute-forced by l2_exact_scan_kernel (no MFMA pass);
+ *   mode 3: (64-float descriptors) the one-product bf16 pass ALONE: the table holds its answer for every query and
+ *           esfm_match_last_flagged() lists what it could not certify (mode 1 audits the two MFMA passes together).
  * Diffing the two tables row by row and removing the rows esfm_match_last_flagged() lists gives
  * the number of queries the certificate accepted with a wrong answer; it must be 0. */
 int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode);

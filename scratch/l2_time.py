@@ -12,4 +12,8 @@ t = time.perf_counter()
 for _ in range(10): pm.match(0.5)
 pm.ctx.synchronize(); el = time.perf_counter() - t
 ms, n = pm.ctx.kernel_time(_lib.K_L2_KNN); rs, rn = pm.ctx.kernel_time(_lib.K_L2_RESCAN)
-print('pairs/s', 3000 / el, 'knn ms', ms / n, 'rescan ms', rs / max(rn, 1), 'stats', pm.stats())
+try:
+    ss, sn = pm.ctx.kernel_time(_lib.K_L2_SECOND); sp = pm.second_pass()
+except Exception:
+    ss, sn, sp = 0.0, 0, -1
+print('pairs/s', 3000 / el, 'knn ms', ms / n, 'second ms', ss / max(sn, 1), 'rescan ms', rs / max(rn, 1), 'stats', pm.stats(), 'second-pass queries', sp)

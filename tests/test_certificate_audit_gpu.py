@@ -3,7 +3,7 @@
 The split-bf16 distance pass answers a query from a handful of candidates and CERTIFIES that answer, or flags the query for an exact
 re-scan.  A wrong-but-certified answer would be a silent parity failure, so the library can be driven in two audit modes
 (esfm_ctx_set_l2_audit): 1 = the pass's own answers with the re-scan switched off, 2 = a brute force of every query in the
-oracle's summation order.  The audit: every query whose pass-only answer differs from the brute force MUST be on the flagged list
+oracle's summation order (and 3 = the one-product front pass alone, with ITS list of failures).  The audit: every query whose pass-only answer differs from the brute force MUST be on the flagged list
 (certified_but_wrong == []), the brute force must equal the product path bit for bit, and the flagged list must have the size the
 product path reports.  tests/test_metric_workloads_gpu.py runs this on M-SURF-4k; here: a rank's shard of config 4 (8192 x 8192
 pairs -- the regime where the certificate is busiest), the reference's fountain images' own SURF descriptors, and the seven
@@ -38,6 +38,9 @@ def _audit(sets, pairs, ctx=None, label=""):
     pm.set_l2_audit(1)
     a_idx, a_dist = run()
     flagged = pm.flagged()
+    pm.set_l2_audit(3)           # the one-product bf16 pass alone: its answers, its own list of failures
+    f_idx, f_dist = run()
+    front_flagged = pm.flagged()
     pm.set_l2_audit(2)
     e_idx, e_dist = run()
     pm.set_l2_audit(0)
@@ -50,6 +53,14 @@ def _audit(sets, pairs, ctx=None, label=""):
     print(f"\n{label}: {n_q} queries, {len(flagged)} flagged ({100.0 * len(flagged) / max(n_q, 1):.3f} %), {len(wrong)} pass-only answers differ "
           f"from brute force, certified-but-wrong {len(certified_but_wrong)}")
     assert certified_but_wrong == [], (label, certified_but_wrong[:10])
+    # the same for the front pass on its own (its certificate carries the bf16 rounding of the operands)
+    f_wrong = np.nonzero(np.any(f_idx != e_idx, axis=1) | np.any(_bits(f_dist) != _bits(e_dist), axis=1))[0]
+    f_rows = set((off[front_flagged[:, 0]] + front_flagged[:, 1]).tolist()) if len(front_flagged) else set()
+    f_cbw = [int(r) for r in f_wrong if int(r) not in f_rows]
+    print(f"{label}: one-product pass alone: {len(front_flagged)} uncertified ({100.0 * len(front_flagged) / max(n_q, 1):.3f} %), {len(f_wrong)} of its answers "
+          f"differ from brute force, certified-but-wrong {len(f_cbw)}")
+    assert f_cbw == [], (label, f_cbw[:10])
+    assert len(front_flagged) >= len(flagged)           # the second pass only sees what the first one left
     return n_q, len(flagged), len(wrong)
 
 

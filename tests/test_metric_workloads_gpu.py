@@ -51,6 +51,10 @@ def test_msurf4k_every_query_bitexact_and_certificate_sound(oracle_lib):
     a_idx, a_dist = pm.knn2(); pm.ctx.synchronize()
     a_idx = a_idx.cpu().numpy().copy(); a_dist = a_dist.cpu().numpy().copy()
     flagged = pm.flagged()
+    pm.set_l2_audit(3)           # the one-product front pass alone
+    f_idx, f_dist = pm.knn2(); pm.ctx.synchronize()
+    f_idx = f_idx.cpu().numpy().copy(); f_dist = f_dist.cpu().numpy().copy()
+    f_flagged = pm.flagged()
     pm.set_l2_audit(2)
     e_idx, e_dist = pm.knn2(); pm.ctx.synchronize()
     e_idx = e_idx.cpu().numpy().copy(); e_dist = e_dist.cpu().numpy().copy()
@@ -63,6 +67,12 @@ def test_msurf4k_every_query_bitexact_and_certificate_sound(oracle_lib):
     print(f"\nM-SURF-4k audit: {n_q} queries, {len(flagged)} flagged by the certificate, {len(wrong)} of the pass's answers differ "
           f"from brute force, certified-but-wrong {len(certified_but_wrong)}")
     assert certified_but_wrong == []
+    f_wrong = np.nonzero(np.any(f_idx != e_idx, axis=1) | np.any(_bits(f_dist) != _bits(e_dist), axis=1))[0]
+    f_rows = set((f_flagged[:, 0].astype(np.int64) * n_feat + f_flagged[:, 1]).tolist())
+    f_cbw = [int(r) for r in f_wrong if int(r) not in f_rows]
+    print(f"M-SURF-4k audit, one-product pass alone: {len(f_flagged)} uncertified ({100.0 * len(f_flagged) / n_q:.3f} %), {len(f_wrong)} answers differ, "
+          f"certified-but-wrong {len(f_cbw)}")
+    assert f_cbw == [] and len(f_flagged) < n_q // 20
 
 
 def test_ba25_metric_size_trace_matches_oracle(gpu_ctx, oracle_lib):
