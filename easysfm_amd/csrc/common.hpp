@@ -57,6 +57,7 @@ struct esfm_ctx {
     esfm::DevBuf norms, pair_tab, knn_idx, knn_dist, flagged, counters, stage_a, stage_b, stage_c, stage_d, stage_e;
     esfm::DevBuf pair_cnt, pair_list;   // uncertified queries of the L2 pass binned per pair (one counter per pair; the pair's slice of the query numbering)
     esfm::DevBuf pair_cnt2, pair_list2;   // the same for the second (three-product) pass over what the one-product pass left uncertified
+    esfm::DevBuf knn_d2;   // exact second-best d^2 of the queries the one-product pass left uncertified (the refine pass's thresholds)
     esfm::DevBuf l2_hi;    // one-product pass: bf16(t) and bf16(-2 q) images (128 B per row each) and the two residual norms per row
     esfm::DevBuf hm_exp;   // expanded descriptor image: 0/1 bytes + start values (Hamming MFMA) or bf16 hi/lo halves (L2), 256 B per row
     // pinned host staging for small tables / counters

@@ -157,7 +157,7 @@ int esfm_ctx_destroy(esfm_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     esfm::DevBuf *bufs[] = {&ctx->norms, &ctx->pair_tab, &ctx->knn_idx, &ctx->knn_dist, &ctx->flagged, &ctx->counters,
                             &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->stage_e, &ctx->hm_exp, &ctx->pair_cnt, &ctx->pair_list,
-                            &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi};
+                            &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi, &ctx->knn_d2};
     for (auto *b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }

@@ -1,41 +1,47 @@
 #!/usr/bin/env python3
 """Generates l2x1_segment_gfx950.inc: the hand-scheduled main loop of l2_knn_bf16x1_kernel (match_kernels.hip), the ONE-product
-bf16 distance pass -- q.t ~ bf16(q).bf16(t), 4 instead of 12 v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 tile -- as one inline-asm
-block per SEGMENT (<= 16 tiles of 128 train rows = 64 steps of 32) for a wave's two sets of 32 queries, with the fused two-level
-top-K fold (K = KEEP group keys per lane and set; the certificate of the one-product pass needs K > 3).
+bf16 distance pass -- q.t ~ bf16(q).bf16(t), 4 instead of 12 v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 tile -- as ONE inline-asm
+block for a wave's FOUR sets of 32 queries over the whole train set (<= 65536 rows), with the fused top-K fold (K = KEEP group
+keys per lane and set; the certificate of the one-product pass needs K > 3).
 
 Differences from gen_l2_segment_asm.py (the three-product pass, which now only sees the queries this pass cannot certify):
+  * four query sets per wave (512 queries per workgroup): with a third of the MFMAs per train row the L2 -> LDS stream, the LDS
+    reads and the per-tile barrier of the 256-query shape were as long as the matrix work (measured: 0.26 ms of 0.66 with all
+    arithmetic removed).  ONE accumulator per set (v0-v63): the fold of a set's results sits right in front of the MFMA that
+    overwrites them in the next step ("skew"), in the shadow of the previous set's MFMA and of the SIMD's other wave;
   * the train image is bf16(t) only: 128-B rows, 16-B slot 2 ks + h holds a lane's A fragment of K-step ks; in LDS slot s of row r
     sits at physical slot s ^ ((r >> 1) & 7) -- every 16-lane group of a ds_read_b128 then covers the 64 banks exactly once;
-  * a RING of four 16-KiB tile buffers instead of two 32-KiB ones (a tile is a third of the matrix-pipe time it used to be: the
-    LDS-DMA of tile t + 4 is issued when tile t hands its buffer over and has three tiles' time to land); a tile's |t|^2 travel
-    through one VGPR per ring slot (in/out operands: they live across segments) and are written to LDS -- kBig for rows past nt --
-    at the hand-over that publishes the tile;
-  * the A fragments are prefetched a whole 32-train step ahead (two register sets of four fragments): with 2 instead of 6 MFMAs
-    per K-step the two-K-step distance of the three-product schedule is shorter than the LDS latency;
-  * K keys per set: 3 + K VALU per group of four results (2 v_min3, v_and_or, K v_med3).
+  * a RING of four 16-KiB tile buffers: the LDS-DMA of tile t + 4 is issued when tile t hands its buffer over and has three tiles'
+    time to land; a tile's |t|^2 travel through one VGPR per ring slot and are written to LDS -- kBig for rows past nt -- at the
+    hand-over that publishes the tile;
+  * the A fragments are prefetched a whole 32-train step ahead (two register sets of four fragments);
+  * a 13-bit position code (11 bits step, 2 bits group) in the low mantissa bits of a group key instead of 8: no segments, no
+    master list -- the keys the block ends with name their rows directly.  The coarser keys (2^-10 relative) are noise next to
+    the one-product pass's operand rounding (2^-8); train sets beyond 65536 rows skip this pass;
+  * K keys per set: 3 + K VALU per group of four results (2 v_min3, v_and_or, K v_med3).  The 4 K keys leave through LDS (the
+    ring is dead by then): key i of set s of thread tid at float (K s + i) * 256 + tid.
 
-  K-step ks of a 32-train step (2 MFMAs: one per query set)
-      s_waitcnt lgkmcnt(n)            the fragment of THIS K-step (read one step ago) has landed
-      MFMA  n[0] (+)= A(ks) * B[0](ks)      (ks == 0: on top of the |t|^2 start values)
-      3 + K VALU   fold of group ks of set 0 of the PREVIOUS step
-      MFMA  n[1] (+)= A(ks) * B[1](ks)
-      3 + K VALU   fold of group ks of set 1
-      ds_read_b128  A(ks) of the next step (ks == 2: its 16 start values first)
+  step (32 train rows x 128 queries, 16 MFMAs):
+      K-step 0   s_waitcnt; for s = 0..3: [fold of set s's results of the PREVIOUS step, 4 groups]  MFMA acc[s] = A(0) B[s](0) + |t|^2
+                 ds_read A(0) of the next step
+      K-step 1   s_waitcnt; 4 MFMAs; ds_read A(1)'         K-step 2   ... ; ds_read the next step's 16 start values, A(2)'
+      K-step 3   ... ; ds_read A(3)'
   hand-over of tile t = the top of its last step: every read of the tile has been issued a step ago and is waited for, the wave's own
   transfers of tile t + 1 are waited for (vmcnt) and its norms written, barrier, then the norm load and the four DMA pieces of
   tile t + 4 go out (LDS-DMA destinations stay below 64 KiB: M0 carries the address).
 
 Register map (all clobbered):
-  v[0:15] v[16:31]   accumulators "a" of query set 0 / 1      v[32:47] v[48:63]  accumulators "b"
+  v[0:63]            accumulators of query sets 0..3
   v[64:79] v[80:95]  A fragments of even / odd steps: K-step ks = v[64 + 16 par + 4 ks : +3]
   v[96:111]          start values (|t|^2 of the step's 32 train rows, this lane's 16)
-  v112-v115 a_addr   v120 n_addr   v121-v124 DMA source offsets   v125 norm source offset   v126 norm LDS address
-  v127-v129, v135 scratch   v130-v133 fold temporaries   v134 key mask 0xFFFFFF00
-  s40 tile  s41 code base of the step being folded  s42 step index  s43 saved M0  s44-s51 scratch
-Operands: %0..%(2K-1) out: segment keys of set 0, then set 1 (ascending);  then in/out: the four norm registers (ring slot 0..3);
-  then in: B[s][ks] (s major, 8 operands);  then tile0, tile_end, nt, train image buffer descriptor, train norms buffer
-  descriptor, LDS address of the ring (norms behind it), wave index.
+  v[112 : 112 + 4K)  keys: set s, rank i = v[112 + K s + i]           (K <= 6: up to v135)
+  v136-v139 a_addr   v140 n_addr   v141-v144 DMA source offsets   v145 norm source offset   v146 norm LDS address
+  v147-v150 ring norm registers   v151-v154 scratch   v155-v158 fold temporaries   v159 key mask
+  s40 tile  s41 code base of the step being folded  s42 step index  s43 saved M0  s44-s47 codes of the four groups
+  s48-s51 scratch  s52 kBig  s53 -kBig
+Operands (inputs only): %0-%15 B[s][ks] (s major);  %16-%19 norms of tiles 0..3 for the ring's norm registers;  %20 tile count;
+  %21 nt;  %22 train image buffer descriptor;  %23 train norms buffer descriptor;  %24 LDS address of the ring (norms behind it);
+  %25 wave index.
 """
 import os
 import sys
@@ -43,23 +49,30 @@ import sys
 KEEP = int(os.environ.get("ESFM_GEN_KEEP", "4"))
 NOFOLD = int(os.environ.get("ESFM_GEN_NOFOLD", "0"))      # timing experiments only: no fold / no MFMA
 NOMFMA = int(os.environ.get("ESFM_GEN_NOMFMA", "0"))
+NS = 4
+CODE_BITS = 13
 KBIG = 0x7F61B1E6          # 3.0e38f
 NKBIG = 0xFF61B1E6
 TT, ROW_BYTES, RING = 128, 128, 4
 TILE_BYTES = TT * ROW_BYTES          # 16 KiB
 NORM_BASE = RING * TILE_BYTES        # the ring's norms sit behind the tiles: RING x TT floats
+assert 3 <= KEEP <= 6
 
-OP_K = lambda s, i: f"%{KEEP * s + i}"
-OP_NR = lambda b: f"%{2 * KEEP + b}"
-OP_B = lambda s, ks: f"%{2 * KEEP + 4 + 4 * s + ks}"
-_o = 2 * KEEP + 12
-OP_TILE0, OP_TILE_END, OP_NT, OP_TRSRC, OP_NRSRC, OP_LDS, OP_WAVE = (f"%{_o + i}" for i in range(7))
+OP_B = lambda s, ks: f"%{4 * s + ks}"
+OP_NR = lambda b: f"%{16 + b}"
+OP_NTILES, OP_NT, OP_TRSRC, OP_NRSRC, OP_LDS, OP_WAVE = (f"%{20 + i}" for i in range(6))
 
-ACC = {"a": (0, 16), "b": (32, 48)}
+KEY = lambda s, i: f"v{112 + KEEP * s + i}"
+A_ADDR, N_ADDR, DMA_OFF, NSRC_OFF, NLDS = 136, 140, 141, 145, 146
+NR = lambda b: f"v{147 + b}"
+SCR = 151                      # v151..v154
+FTMP = 155                     # v155..v158: (t, key) pairs, alternating
+MASK = 159
+N_CLOBBER = 160
 
 
-def vr(base, n=16):
-    return f"v[{base}:{base + n - 1}]"
+def acc(s):
+    return f"v[{16 * s}:{16 * s + 15}]"
 
 
 def fr(ks, par):
@@ -72,166 +85,180 @@ def gen():
     e = L.append
     # ------------------------------------------------------------------ set-up
     e("s_mov_b32 s43, m0")
-    e("v_mbcnt_lo_u32_b32 v128, -1, 0")
-    e("v_mbcnt_hi_u32_b32 v128, -1, v128")                  # lane
-    e("v_and_b32 v129, 31, v128")                            # j
-    e("v_lshrrev_b32 v135, 5, v128")                         # h
-    e("v_bfe_u32 v127, v129, 1, 3")                          # (j >> 1) & 7: the row's swizzle
-    e("v_lshlrev_b32 v126, 7, v129")                         # j * 128
-    e(f"v_add_u32 v126, {OP_LDS}, v126")                     # row j of buffer 0, step 0
+    e(f"v_mbcnt_lo_u32_b32 v{SCR}, -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 v{SCR}, -1, v{SCR}")             # lane
+    e(f"v_and_b32 v{SCR + 1}, 31, v{SCR}")                   # j
+    e(f"v_lshrrev_b32 v{SCR + 2}, 5, v{SCR}")                # h
+    e(f"v_bfe_u32 v{SCR + 3}, v{SCR + 1}, 1, 3")             # (j >> 1) & 7: the row's swizzle
+    e(f"v_lshlrev_b32 v{NLDS}, 7, v{SCR + 1}")               # j * 128
+    e(f"v_add_u32 v{NLDS}, {OP_LDS}, v{NLDS}")               # row j of buffer 0, step 0
     for ks in range(4):
-        e(f"v_or_b32 v130, {2 * ks}, v135")                   # logical slot 2 ks + h
-        e("v_xor_b32 v130, v130, v127")
-        e(f"v_lshl_add_u32 v{112 + ks}, v130, 4, v126")
-    e("v_lshlrev_b32 v120, 4, v135")
-    e(f"v_add_u32 v120, {OP_LDS}, v120")
-    e(f"v_add_u32 v120, {NORM_BASE}, v120")                   # n_addr = lds_norm + 16 h
+        e(f"v_or_b32 v{FTMP}, {2 * ks}, v{SCR + 2}")          # logical slot 2 ks + h
+        e(f"v_xor_b32 v{FTMP}, v{FTMP}, v{SCR + 3}")
+        e(f"v_lshl_add_u32 v{A_ADDR + ks}, v{FTMP}, 4, v{NLDS}")
+    e(f"v_lshlrev_b32 v{N_ADDR}, 4, v{SCR + 2}")
+    e(f"v_add_u32 v{N_ADDR}, {OP_LDS}, v{N_ADDR}")
+    e(f"v_add_u32 v{N_ADDR}, {NORM_BASE}, v{N_ADDR}")         # n_addr = lds_norm + 16 h
     # LDS-DMA source offsets: wave w stages rows [32 w, 32 w + 32) of a tile, 8 rows (1 KiB) per instruction
-    e(f"s_lshl_b32 s44, {OP_WAVE}, 5")
-    e("v_lshrrev_b32 v129, 3, v128")                          # lane >> 3
-    e("v_and_b32 v127, 7, v128")                              # lane & 7: physical slot
+    e(f"s_lshl_b32 s48, {OP_WAVE}, 5")
+    e(f"v_lshrrev_b32 v{SCR + 1}, 3, v{SCR}")                 # lane >> 3
+    e(f"v_and_b32 v{SCR + 3}, 7, v{SCR}")                     # lane & 7: physical slot
     for i in range(4):
-        e("v_add_u32 v130, s44, v129")
-        e(f"v_add_u32 v130, {8 * i}, v130")                   # row in the tile
-        e("v_bfe_u32 v131, v130, 1, 3")
-        e("v_xor_b32 v131, v131, v127")                       # logical slot fetched into this physical slot
-        e("v_lshlrev_b32 v131, 4, v131")
-        e(f"v_lshl_add_u32 v{121 + i}, v130, 7, v131")
+        e(f"v_add_u32 v{FTMP}, s48, v{SCR + 1}")
+        e(f"v_add_u32 v{FTMP}, {8 * i}, v{FTMP}")             # row in the tile
+        e(f"v_bfe_u32 v{FTMP + 1}, v{FTMP}, 1, 3")
+        e(f"v_xor_b32 v{FTMP + 1}, v{FTMP + 1}, v{SCR + 3}")  # logical slot fetched into this physical slot
+        e(f"v_lshlrev_b32 v{FTMP + 1}, 4, v{FTMP + 1}")
+        e(f"v_lshl_add_u32 v{DMA_OFF + i}, v{FTMP}, 7, v{FTMP + 1}")
     # norms: lane l of wave w moves |t|^2 of row 32 w + (l & 31) (both halves of the wave the same row: no masking needed)
-    e("v_and_b32 v130, 31, v128")
-    e("v_add_u32 v130, s44, v130")                            # row in the tile
-    e("v_lshlrev_b32 v125, 2, v130")                          # byte offset inside a tile's norms
-    e(f"v_add_u32 v126, {OP_LDS}, v125")
-    e(f"v_add_u32 v126, {NORM_BASE}, v126")                   # lds_norm + 4 row (ring slot 0)
-    e(f"s_mov_b32 s46, 0x{KBIG:08x}")
-    e(f"s_mov_b32 s47, 0x{NKBIG:08x}")
-    e("v_mov_b32 v134, 0xffffff00")
-    for s in range(2):
+    e(f"v_and_b32 v{FTMP}, 31, v{SCR}")
+    e(f"v_add_u32 v{FTMP}, s48, v{FTMP}")                     # row in the tile
+    e(f"v_lshlrev_b32 v{NSRC_OFF}, 2, v{FTMP}")               # byte offset inside a tile's norms
+    e(f"v_add_u32 v{NLDS}, {OP_LDS}, v{NSRC_OFF}")
+    e(f"v_add_u32 v{NLDS}, {NORM_BASE}, v{NLDS}")             # lds_norm + 4 row (ring slot 0)
+    for b in range(RING):
+        e(f"v_mov_b32 {NR(b)}, {OP_NR(b)}")
+    e(f"s_mov_b32 s52, 0x{KBIG:08x}")
+    e(f"s_mov_b32 s53, 0x{NKBIG:08x}")
+    e(f"v_mov_b32 v{MASK}, 0x{(0xFFFFFFFF << CODE_BITS) & 0xFFFFFFFF:08x}")
+    for s in range(NS):
         for i in range(KEEP):
-            e(f"v_mov_b32 {OP_K(s, i)}, s46")
-    for r in range(32, 64):
-        e(f"v_mov_b32 v{r}, s46")                             # placeholders for the step before the first: never live
-    e(f"s_mov_b32 s40, {OP_TILE0}")
+            e(f"v_mov_b32 {KEY(s, i)}, s52")
+    for r in range(0, 64):
+        e(f"v_mov_b32 v{r}, s52")                             # placeholders for the step before the first: never live
+    e("s_mov_b32 s40, 0")
     e("s_mov_b32 s41, 0")
     e("s_mov_b32 s42, 0")
-    # tile0 has landed for every wave: the caller's barrier (first segment) or the previous segment's last hand-over.
-    # pipeline fill: the start values and the four fragments of step 0 (buffer 0: segments start on multiples of the ring)
     for g in range(4):
-        e(f"ds_read_b128 v[{96 + 4 * g}:{99 + 4 * g}], v120 offset:{32 * g}")
+        e(f"s_mov_b32 s{44 + g}, {g}")
+    # tile 0 has landed for every wave (the caller's barrier).  Pipeline fill: the start values and the four fragments of step 0
+    for g in range(4):
+        e(f"ds_read_b128 v[{96 + 4 * g}:{99 + 4 * g}], v{N_ADDR} offset:{32 * g}")
     for ks in range(4):
-        e(f"ds_read_b128 {fr(ks, 0)}, v{112 + ks}")
+        e(f"ds_read_b128 {fr(ks, 0)}, v{A_ADDR + ks}")
 
-    def fold(s, ks, p):
+    cnt = [0]
+
+    def fold_group(s, g):
         if NOFOLD:
             return []
-        b = p[s] + 4 * ks
-        t, key = 130 + 2 * s, 131 + 2 * s
-        out = [f"v_min3_f32 v{t}, v{b}, s46, v{b + 1}",
+        b = 16 * s + 4 * g
+        cnt[0] ^= 1
+        t, key = FTMP + 2 * cnt[0], FTMP + 1 + 2 * cnt[0]
+        out = [f"v_min3_f32 v{t}, v{b}, s52, v{b + 1}",
                f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
-               f"v_and_or_b32 v{key}, v{t}, v134, s44"]
+               f"v_and_or_b32 v{key}, v{t}, v{MASK}, s{44 + g}"]
         for i in range(KEEP - 1, 0, -1):
-            out.append(f"v_med3_f32 {OP_K(s, i)}, {OP_K(s, i - 1)}, {OP_K(s, i)}, v{key}")
-        out.append(f"v_med3_f32 {OP_K(s, 0)}, {OP_K(s, 0)}, v{key}, s47")
+            out.append(f"v_med3_f32 {KEY(s, i)}, {KEY(s, i - 1)}, {KEY(s, i)}, v{key}")
+        out.append(f"v_med3_f32 {KEY(s, 0)}, {KEY(s, 0)}, v{key}, s53")
         return out
 
-    WAIT = {0: 2, 1: None, 2: 3, 3: 7}   # younger reads that may stay in flight (see the module docstring's queue order)
+    WAIT = {0: 2, 1: None, 2: 3, 3: 7}   # younger reads that may stay in flight (queue order per step: F0 | F1 | N x 4, F2 | F3)
 
-    def kstep(ks, accs, par, nbuf, nstep, first_wait=None, extra=((), ())):
-        """K-step ks of a step accumulating into `accs` with the fragments of parity `par`; prefetches the next step's
-        fragment ks (and at ks == 2 its start values) from buffer nbuf, step nstep."""
-        n = ACC[accs]
-        p = ACC["b" if accs == "a" else "a"]
-        w = WAIT[ks] if first_wait is None else first_wait
-        if w is not None:
-            e(f"s_waitcnt lgkmcnt({w})")
-        e(f"s_add_u32 s44, s41, {ks}")
-        c = [vr(96), vr(96)] if ks == 0 else [vr(n[0]), vr(n[1])]
-        for s in range(2):
-            if not NOMFMA:
-                e(f"v_mfma_f32_32x32x16_bf16 {vr(n[s])}, {fr(ks, par)}, {OP_B(s, ks)}, {c[s]}")
-            for x in extra[s]:
-                e(x)
-            for x in fold(s, ks, p):
-                e(x)
-        if ks == 2:
-            for g in range(4):
-                e(f"ds_read_b128 v[{96 + 4 * g}:{99 + 4 * g}], v120 offset:{(nbuf * TT + nstep * 32 + 8 * g) * 4}")
-        e(f"ds_read_b128 {fr(ks, par ^ 1)}, v{112 + ks} offset:{nbuf * TILE_BYTES + nstep * 32 * ROW_BYTES}")
-
-    def end_step():
-        e("s_lshl_b32 s41, s42, 2")
-        e("s_add_u32 s42, s42, 1")
+    def step(par, nbuf, nstep, extra=None):
+        """One 32-train step with the fragments of parity `par`; prefetches the next step (buffer nbuf, step nstep).
+        extra: instruction lists issued behind the MFMAs of K-steps 1 and 2 (the hand-over's transfers)."""
+        extra = list(extra or [])
+        for ks in range(4):
+            if WAIT[ks] is not None:
+                e(f"s_waitcnt lgkmcnt({WAIT[ks]})")
+            for s in range(NS):
+                if ks == 0:
+                    for g in range(4):
+                        for x in fold_group(s, g):
+                            e(x)
+                if not NOMFMA:
+                    e(f"v_mfma_f32_32x32x16_bf16 {acc(s)}, {fr(ks, par)}, {OP_B(s, ks)}, {'v[96:111]' if ks == 0 else acc(s)}")
+                if ks >= 1 and extra:
+                    for x in extra.pop(0):
+                        e(x)
+            if ks == 0:
+                # the step being folded from now on is this one
+                e("s_lshl_b32 s41, s42, 2")
+                e("s_add_u32 s42, s42, 1")
+                for g in range(4):
+                    e(f"s_add_u32 s{44 + g}, s41, {g}")
+            if ks == 2:
+                for g in range(4):
+                    e(f"ds_read_b128 v[{96 + 4 * g}:{99 + 4 * g}], v{N_ADDR} offset:{(nbuf * TT + nstep * 32 + 8 * g) * 4}")
+            e(f"ds_read_b128 {fr(ks, par ^ 1)}, v{A_ADDR + ks} offset:{nbuf * TILE_BYTES + nstep * 32 * ROW_BYTES}")
+        assert not extra
 
     def dma_piece(i, buf):
         return [f"s_add_u32 s50, s49, {buf * TILE_BYTES + i * 1024}",
                 "s_mov_b32 m0, s50",
-                f"buffer_load_dwordx4 v{121 + i}, {OP_TRSRC}, s48 offen lds"]
-
-    def norm_piece(buf):
-        return [f"buffer_load_dword {OP_NR(buf)}, v125, {OP_NRSRC}, s51 offen"]
+                f"buffer_load_dwordx4 v{DMA_OFF + i}, {OP_TRSRC}, s48 offen lds"]
 
     def tile(buf, tag):
         nb = (buf + 1) % RING
-        for st, accs in ((0, "a"), (1, "b"), (2, "a")):
-            for ks in range(4):
-                kstep(ks, accs, st & 1, buf, st + 1)
-            end_step()
+        for st in range(3):
+            step(st & 1, buf, st + 1)
         # ---- step 3: hand-over first
         e("s_waitcnt lgkmcnt(0)")                               # every read of this tile has landed
-        e(f"s_waitcnt vmcnt({2 * 5})")                          # this wave's five transfers of tile + 1 have landed (tile + 2, + 3 may fly)
+        e("s_waitcnt vmcnt(8)")                                 # this wave's transfers of tile + 1 have landed (tile + 2, + 3 may fly;
+        #                                                         8, not 10: the caller's first three tiles are 4 transfers each)
         # norms of tile + 1 -> LDS, rows past nt as kBig
-        e("s_add_u32 s44, s40, 1")
-        e("s_lshl_b32 s44, s44, 7")
-        e("v_lshrrev_b32 v128, 2, v125")
-        e("v_add_u32 v128, s44, v128")                         # train row of this lane's norm
-        e(f"v_cmp_gt_u32 vcc, {OP_NT}, v128")
-        e("v_mov_b32 v129, s46")
-        e(f"v_cndmask_b32 v129, v129, {OP_NR(nb)}, vcc")
-        e(f"ds_write_b32 v126, v129 offset:{nb * TT * 4}")
+        e("s_add_u32 s48, s40, 1")
+        e("s_lshl_b32 s48, s48, 7")
+        e(f"v_lshrrev_b32 v{SCR}, 2, v{NSRC_OFF}")
+        e(f"v_add_u32 v{SCR}, s48, v{SCR}")                    # train row of this lane's norm
+        e(f"v_cmp_gt_u32 vcc, {OP_NT}, v{SCR}")
+        e(f"v_mov_b32 v{SCR + 1}, s52")
+        e(f"v_cndmask_b32 v{SCR + 1}, v{SCR + 1}, {NR(nb)}, vcc")
+        e(f"ds_write_b32 v{NLDS}, v{SCR + 1} offset:{nb * TT * 4}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
-        e("s_add_u32 s44, s40, 4")
-        e("s_lshl_b32 s51, s44, 9")                             # (tile + 4) * 128 * 4
-        e("s_lshl_b32 s48, s44, 14")                            # (tile + 4) * 128 rows * 128 B
+        e("s_add_u32 s48, s40, 4")
+        e("s_lshl_b32 s51, s48, 9")                             # (tile + 4) * 128 * 4
+        e("s_lshl_b32 s48, s48, 14")                            # (tile + 4) * 128 rows * 128 B
         e(f"s_lshl_b32 s49, {OP_WAVE}, 12")                     # wave * 32 rows * 128 B
         e(f"s_add_u32 s49, s49, {OP_LDS}")
-        pcs = [dma_piece(i, buf) for i in range(4)]
-        npc = norm_piece(buf)
         # (a tile that does not exist reads zeros through the descriptors into a buffer nobody reads again: unconditional)
-        kstep(0, "b", 1, nb, 0, extra=(npc + pcs[0], pcs[1]))
-        kstep(1, "b", 1, nb, 0, extra=(pcs[2], pcs[3]))
-        kstep(2, "b", 1, nb, 0)
-        kstep(3, "b", 1, nb, 0)
-        end_step()
+        pcs = [[f"buffer_load_dword {NR(buf)}, v{NSRC_OFF}, {OP_NRSRC}, s51 offen"]] + [dma_piece(i, buf) for i in range(4)]
+        step(1, nb, 0, extra=pcs)
         e("s_add_u32 s40, s40, 1")
 
     e("L_top_%=:")
     for buf in range(RING):
         tile(buf, f"t{buf}")
         if buf < RING - 1:
-            e(f"s_cmp_ge_u32 s40, {OP_TILE_END}")
+            e(f"s_cmp_ge_u32 s40, {OP_NTILES}")
             e("s_cbranch_scc1 L_done_%=")
-    e(f"s_cmp_lt_u32 s40, {OP_TILE_END}")
+    e(f"s_cmp_lt_u32 s40, {OP_NTILES}")
     e("s_cbranch_scc1 L_top_%=")
     e("L_done_%=:")
-    # the last step's results (accumulators "b"): wait for the matrix pipe before the VALU reads them
+    # the last step's results: wait for the matrix pipe before the VALU reads them
     e("s_nop 15")
     e("s_nop 15")
-    e("s_waitcnt lgkmcnt(0)")                                   # the prefetches past the segment's end land in dead registers
-    for ks in range(4):
-        e(f"s_add_u32 s44, s41, {ks}")
-        for s in range(2):
-            for x in fold(s, ks, ACC["b"]):
+    e("s_waitcnt lgkmcnt(0)")                                   # the prefetches past the end land in dead registers
+    for s in range(NS):
+        for g in range(4):
+            for x in fold_group(s, g):
                 e(x)
+    # keys -> LDS (the ring is dead once every wave is here and every transfer has landed)
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    e(f"v_mbcnt_lo_u32_b32 v{SCR}, -1, 0")
+    e(f"v_mbcnt_hi_u32_b32 v{SCR}, -1, v{SCR}")
+    e(f"s_lshl_b32 s48, {OP_WAVE}, 6")
+    e(f"v_add_u32 v{SCR}, s48, v{SCR}")                         # tid
+    e(f"v_lshlrev_b32 v{SCR}, 2, v{SCR}")
+    e(f"v_add_u32 v{SCR}, {OP_LDS}, v{SCR}")
+    for s in range(NS):
+        for i in range(KEEP):
+            e(f"ds_write_b32 v{SCR}, {KEY(s, i)} offset:{(KEEP * s + i) * 1024}")
+    e("s_waitcnt lgkmcnt(0)")
     e("s_mov_b32 m0, s43")
     return L
 
 
 def main():
     lines = gen()
-    clob = [f"v{i}" for i in range(136)] + [f"s{i}" for i in range(40, 52)] + ["scc", "vcc", "memory"]
+    clob = [f"v{i}" for i in range(N_CLOBBER)] + [f"s{i}" for i in range(40, 54)] + ["scc", "vcc", "memory"]
     out = ["// GENERATED by gen_l2x1_segment_asm.py -- do not edit; see that file for the schedule and the register map",
            f"#define ESFM_L2X1_KEEP {KEEP}",
+           f"#define ESFM_L2X1_SETS {NS}",
+           f"#define ESFM_L2X1_CODE_BITS {CODE_BITS}",
            "#define ESFM_L2X1_SEGMENT_ASM \\"]
     for l in lines:
         out.append(f'    "{l}\\n" \\')

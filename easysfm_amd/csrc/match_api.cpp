@@ -14,6 +14,8 @@ namespace {
 struct PairPlan {
     std::vector<PairDesc> tab;
     int n_blocks = 0;
+    int n_blocks2 = 0;      // workgroups of the one-product front pass
+    int max_nt = 0;
     int64_t total_queries = 0;
     int64_t total_rows = 0;
 };
@@ -28,7 +30,8 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
     plan->total_rows = set_row_offset[n_sets];
     plan->tab.resize((size_t)n_pairs);
     int64_t off = 0;
-    int64_t blk = 0;
+    int64_t blk = 0, blk2 = 0;
+    const int qb2 = esfm::l2_x1_query_block();
     for (int p = 0; p < n_pairs; ++p) {
         const int qs = pairs[2 * p], ts = pairs[2 * p + 1];
         ESFM_REQUIRE(qs >= 0 && qs < n_sets && ts >= 0 && ts < n_sets, "pair refers to a set out of range");
@@ -37,14 +40,17 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
         d.t_row0 = set_row_offset[ts]; d.nt = set_row_offset[ts + 1] - set_row_offset[ts];
         ESFM_REQUIRE(d.nt < (1 << 21), "train sets are limited to 2^21-1 rows");   // index field of the packed top-2 keys
         ESFM_REQUIRE(d.nq < (1 << 23), "query sets are limited to 2^23-1 rows");   // 32-bit byte offsets into a set (row fetches through buffer descriptors)
-        d.out_off = off; d.blk_off = (int32_t)blk; d.pad = 0;
+        d.out_off = off; d.blk_off = (int32_t)blk; d.blk_off2 = (int32_t)blk2;
+        plan->max_nt = std::max(plan->max_nt, (int)d.nt);
         if (out_offset) out_offset[p] = off;
         off += d.nq;
         blk += (d.nq + query_block - 1) / query_block;
+        blk2 += (d.nq + qb2 - 1) / qb2;
         ESFM_REQUIRE(blk < (int64_t)1 << 31, "too many workgroups for one launch; split the pair list");
     }
     if (out_offset) out_offset[n_pairs] = off;
     plan->n_blocks = (int)blk;
+    plan->n_blocks2 = (int)blk2;
     plan->total_queries = off;
     return ESFM_OK;
 }
@@ -82,8 +88,8 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
     if (metric == ESFM_L2_F32) {
         const float *desc = reinterpret_cast<const float *>(desc_dev);
         if (int rc = ctx->counters.reserve(64)) return rc;
-        if (ctx->l2_audit == 3 && !(esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass())) {
-            esfm::set_error("audit mode 3 needs the one-product pass (64-float descriptors, ESFM_L2_PASS unset)");
+        if (ctx->l2_audit == 3 && !(esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt))) {
+            esfm::set_error("audit mode 3 needs the one-product pass (64-float descriptors, train sets <= 65536 rows, ESFM_L2_PASS unset)");
             return ESFM_ERR_UNSUPPORTED;
         }
         const bool bf16_pass = esfm::l2_mfma_supported(width) && ctx->l2_audit != 2 && esfm::l2_bf16_pass(width);
@@ -95,9 +101,11 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
             if (esfm::l2_bf16_pass(width)) {
                 // 64-float rows.  Pass A: one bf16 product per f32 product, certifies most queries (l2_knn_bf16x1_kernel); pass B: its
-                // uncertified queries, pair by pair, through the three-product kernel in list mode; what THAT cannot certify takes
-                // the exact re-scan.  Audit modes: 1 stops after pass B, 3 runs pass A alone (its failures on the flagged list).
-                const bool front = esfm::l2_one_product_pass();
+                // uncertified queries, pair by pair, through a threshold-filter sweep (l2_refine_kernel) that makes them exact; a
+                // chunk whose hit list overflows there takes the exact re-scan.  Without pass A (ESFM_L2_PASS=bf16x3, train sets of
+                // more than 65536 rows): the three-product kernel + re-scan of round 2.  Audit modes: 1 stops before the re-scan,
+                // 3 runs pass A alone (its failures on the flagged list).
+                const bool front = esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt);
                 if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
                 if (int rc = ctx->pair_cnt.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
                 if (int rc = ctx->pair_list.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
@@ -105,6 +113,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                     if (int rc = ctx->l2_hi.reserve(esfm::l2_hi_bytes(plan.total_rows))) return rc;
                     if (int rc = ctx->pair_cnt2.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
                     if (int rc = ctx->pair_list2.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
+                    if (int rc = ctx->knn_d2.reserve(sizeof(float) * (size_t)plan.total_queries)) return rc;
                 }
                 if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>(),
                                                         ctx->pair_cnt.as<int32_t>(), n_pairs, front ? ctx->l2_hi.ptr : nullptr,
@@ -114,20 +123,26 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                     {
                         esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                         if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
-                                                                plan.n_blocks, knn_idx, knn_dist, ctx->l2_audit == 3 ? ctx->flagged.as<int32_t>() : nullptr,
+                                                                plan.n_blocks2, knn_idx, knn_dist, ctx->l2_audit == 3 ? ctx->flagged.as<int32_t>() : nullptr,
                                                                 ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt2.as<int32_t>(),
-                                                                ctx->pair_list2.as<int32_t>()))
+                                                                ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>()))
                             return rc;
                     }
                     if (ctx->l2_audit == 3) return ESFM_OK;   // audit: the one-product pass's own answers and failures
                 }
-                {
-                    esfm::KernelTimer tm(ctx, front ? ESFM_K_L2_SECOND : ESFM_K_L2_KNN);
+                if (front) {
+                    esfm::KernelTimer tm(ctx, ESFM_K_L2_SECOND);
+                    if (int rc = esfm::launch_l2_refine(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
+                                                        ctx->pair_cnt2.as<int32_t>(), ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(),
+                                                        knn_idx, knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64,
+                                                        ctx->pair_cnt.as<int32_t>(), ctx->pair_list.as<int32_t>()))
+                        return rc;
+                } else {
+                    esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                     if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
                                                           plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
                                                           ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt.as<int32_t>(),
-                                                          ctx->pair_list.as<int32_t>(), front ? ctx->pair_cnt2.as<int32_t>() : nullptr,
-                                                          front ? ctx->pair_list2.as<int32_t>() : nullptr))
+                                                          ctx->pair_list.as<int32_t>(), nullptr, nullptr))
                         return rc;
                 }
                 if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the passes' own answer in place

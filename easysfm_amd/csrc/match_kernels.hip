@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------
 // The ONE-product distance pass (round 3): q.t ~ bf16(q).bf16(t), four v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 tile instead of
 // twelve.  Everything else is the machinery of l2_knn_bf16_kernel -- group-of-four fold, exact re-rank of the kept groups in the
-// oracle's order, certificate -- with three changes:
+// oracle's order, certificate -- with these changes:
 //  * the operand rounding is part of the certificate's bound.  With B = bf16(-2 q), a = bf16(t), rB = |(-2 q) - B|_2 and
 //    rho_t = |t - a|_2 (both measured per row by l2_split_bf16_kernel):  |(-2 q).t - B.a| <= rB |t| + |B| rho_t, so
 //        E1 = (rB T + (2 |q| + rB) R) (1 + 2^-9) + 2^-15 (|q|^2 + max|t|^2),    T = max |t|,  R = max rho_t  over the train set,
@@ -874,64 +874,55 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
 //    fountain descriptors 37 % / 15 % / 3.6 %);
 //  * what it cannot certify goes to the pair's list and from there through l2_knn_bf16_kernel<LIST> (three products, eps 2^-15),
 //    whose own failures take the exact re-scan as before -- the result stays bit-identical to the oracle whatever the data;
-//  * main loop l2x1_segment_gfx950.inc: ring of four 16-KiB tiles of bf16(t) rows, fragments prefetched a step ahead.
-// The master top-K lives in registers (the ring takes the LDS the three-product kernel's master had).
+//  * 512 queries per workgroup (four sets of 32 per wave), a ring of four 16-KiB tiles of bf16(t) rows, 13-bit position codes in
+//    the group keys (no segments, no master list): l2x1_segment_gfx950.inc is the whole main loop.  Train sets of more than
+//    65536 rows do not fit the code and skip this pass (l2_x1_supported).
 __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
                                                                const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
                                                                const float *__restrict__ rho_t, const float *__restrict__ rho_q,
                                                                const PairDesc *__restrict__ pairs, int n_pairs,
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                                int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
-                                                               int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
+                                                               int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
+                                                               float *__restrict__ knn_d2)
 {
-    constexpr int TT = 128, NS = 2, GRP = 4, K = ESFM_L2X1_KEEP, RING = 4;
+    constexpr int TT = 128, NS = ESFM_L2X1_SETS, GRP = 4, K = ESFM_L2X1_KEEP, RING = 4;
     constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
     constexpr int TILE_BYTES = TT * HS * 16;
+    static_assert(NS == 4, "operand list below is written for four query sets");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [RING][TT * HS]: 64 KiB, later four landing zones
-    float *lds_norm = reinterpret_cast<float *>(smem + RING * TILE_BYTES);     // [RING][TT]   (the asm segment assumes norms right behind the ring)
+    float *lds_norm = reinterpret_cast<float *>(smem + RING * TILE_BYTES);     // [RING][TT]   (the asm block assumes norms right behind the ring)
     float *lds_red = lds_norm + RING * TT;                                     // [8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int pi = find_pair_by_block(pairs, n_pairs, lb);
+    int pi;
+    {
+        int lo = 0, hi = n_pairs - 1;  // last p with blk_off2[p] <= lb
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pairs[mid].blk_off2 <= lb) lo = mid; else hi = mid - 1;
+        }
+        pi = lo;
+    }
     const PairDesc pd = pairs[pi];
     const int nq = pd.nq, nt = pd.nt;
     const float *__restrict__ Q = desc + (size_t)pd.q_row0 * DIM;
     const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
     const float *__restrict__ tn = norms + pd.t_row0;
     const float *__restrict__ tr = rho_t + pd.t_row0;
-    const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
+    const int qbase = (lb - pd.blk_off2) * QB + wave * 32 * NS;
 
     constexpr float kBig = 3.0e38f;
     constexpr int NG = 16 / GRP;
-    constexpr int kSegSub = 256 / NG;         // steps per segment: the 8-bit code is (step in segment) * NG + group
-    constexpr int kSegTiles = kSegSub / (TT / 32);
-    // master top-K per set: (key, first step of the key's segment), ascending
-    float mk[NS][K]; int mc[NS][K];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int m = 0; m < K; ++m) { mk[s][m] = kBig; mc[s][m] = -1; }
-    }
-    auto master_insert = [&](float (&v)[K], int (&c)[K], float key, int seg_sub0 /* wave-uniform */) {
-        const bool live = key < 1.0e38f;
-        bool lt[K];
-#pragma unroll
-        for (int m = 0; m < K; ++m) lt[m] = live && key < v[m];
-#pragma unroll
-        for (int m = K - 1; m >= 1; --m) {
-            v[m] = lt[m - 1] ? v[m - 1] : (lt[m] ? key : v[m]);
-            c[m] = lt[m - 1] ? c[m - 1] : (lt[m] ? seg_sub0 : c[m]);
-        }
-        v[0] = lt[0] ? key : v[0];
-        c[0] = lt[0] ? seg_sub0 : c[0];
-    };
-    auto group_row0_of = [&](float key, int seg_sub0) {
-        const int code = (int)(__float_as_uint(key) & 0xFFu);
-        const int r0 = GRP * (code % NG);
-        return key < 1.0e38f ? (seg_sub0 + code / NG) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h : -1;
+    constexpr uint32_t kCodeMask = (1u << ESFM_L2X1_CODE_BITS) - 1u;
+    // first of the GRP consecutive train rows of the group a key names (-1: empty slot): the code is step * NG + group, accumulator
+    // register r holds row (r & 3) + 8 (r >> 2) + 4 h of its step
+    auto group_row0_of = [&](float key) {
+        const int code = (int)(__float_as_uint(key) & kCodeMask);
+        return key < 1.0e38f ? (code / NG) * 32 + 8 * (code % NG) + 4 * h : -1;
     };
 
     const int ntiles = (nt + TT - 1) / TT;
@@ -969,7 +960,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             bq[s][ks] = v;
         }
     }
-    // norms of the first RING tiles: tile 0 straight to LDS, tiles 1..3 into the ring's norm registers (the segment code writes a
+    // norms of the first RING tiles: tile 0 straight to LDS, tiles 1..3 into the ring's norm registers (the asm block writes a
     // tile's norms at the hand-over that publishes it, rows past nt as kBig)
     if (tid < TT) lds_norm[tid] = tid < nt ? tn[tid] : kBig;
     float nr[RING];
@@ -988,37 +979,35 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         if (lane == 0) { lds_red[wave] = m; lds_red[4 + wave] = r; }
     }
     // the ring's first four tiles (a tile that does not exist reads zeros through the descriptor); tile 0 must have landed
-    // before the first segment starts -- the three younger transfers (12 pieces) may stay in flight
+    // before the main loop starts -- the three younger transfers (12 pieces) may stay in flight
     dma_tile(0, 0);
     dma_tile(1, 1); dma_tile(2, 2); dma_tile(3, 3);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __syncthreads();
 
-    for (int t0 = 0; t0 < ntiles; t0 += kSegTiles) {
-        const int t1 = min(t0 + kSegTiles, ntiles);
-        float kk[NS][K];
-        static_assert(K == 4, "operand list below is written for four keys per set");
+    if (ntiles > 0) {
         asm volatile(ESFM_L2X1_SEGMENT_ASM
-                     : "=&v"(kk[0][0]), "=&v"(kk[0][1]), "=&v"(kk[0][2]), "=&v"(kk[0][3]), "=&v"(kk[1][0]), "=&v"(kk[1][1]), "=&v"(kk[1][2]), "=&v"(kk[1][3]),
-                       "+v"(nr[0]), "+v"(nr[1]), "+v"(nr[2]), "+v"(nr[3])
+                     :
                      : "v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[0][2]), "v"(bq[0][3]), "v"(bq[1][0]), "v"(bq[1][1]), "v"(bq[1][2]), "v"(bq[1][3]),
-                       "s"(t0), "s"(t1), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
+                       "v"(bq[2][0]), "v"(bq[2][1]), "v"(bq[2][2]), "v"(bq[2][3]), "v"(bq[3][0]), "v"(bq[3][1]), "v"(bq[3][2]), "v"(bq[3][3]),
+                       "v"(nr[0]), "v"(nr[1]), "v"(nr[2]), "v"(nr[3]),
+                       "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
                      : ESFM_L2X1_SEGMENT_CLOBBERS);
-        const int seg_sub0 = t0 * (TT / 32);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int m = 0; m < K; ++m) master_insert(mk[s], mc[s], kk[s][m], seg_sub0);
-        }
     }
-
+    // the block left this thread's keys in LDS: key i of set s at float (K s + i) * 256 + tid
+    float keys[NS][K];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) keys[s][i] = ntiles > 0 ? reinterpret_cast<const float *>(smem)[(K * s + i) * 256 + tid] : kBig;
+    }
     const float tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     const float rmax = fmaxf(fmaxf(lds_red[4], lds_red[5]), fmaxf(lds_red[6], lds_red[7]));
 
     // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate (see l2_knn_bf16_kernel: the same scheme with
     // 2 K groups per query, dealt out over K rounds) ----
     lds_dma_wait();
-    __syncthreads();   // every wave is through its last tile: the ring becomes four private 16-KiB landing zones
+    __syncthreads();   // every wave is through its last tile and has its keys: the ring becomes four private 16-KiB landing zones
     const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
     const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);
     const uint32_t lds_land = lds_tile_addr + (uint32_t)wave_s * 16384u;
@@ -1026,10 +1015,12 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     int swz[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
-#pragma unroll
+    constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
+#pragma unroll 1
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
+        if (__ballot(qvalid) == 0ull) break;           // (wave-uniform: the sets past the end of the query set)
         float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
         auto insert2 = [&](bool valid, float d, int i, float d2) {
             const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
@@ -1045,7 +1036,13 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
         float vk[K], pk[K]; int g0[K], pg[K], rank_own[K], rank_par[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) { vk[i] = mk[s][i]; g0[i] = group_row0_of(mk[s][i], mc[s][i]); }
+        for (int i = 0; i < K; ++i) {
+            // (the set loop is a real loop: pick the set's keys without indexing registers by s)
+            float kv = keys[0][i];
+#pragma unroll
+            for (int t = 1; t < NS; ++t) kv = s == t ? keys[t][i] : kv;
+            vk[i] = kv; g0[i] = group_row0_of(kv);
+        }
 #pragma unroll
         for (int i = 0; i < K; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
 #pragma unroll
@@ -1061,7 +1058,6 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         const double qn = (double)qnorm_s;
         const double e1 = ((double)qrho_s * sqrt((double)tmax) + (2.0 * sqrt(qn) + (double)qrho_s) * (double)rmax) * (1.0 + 1.0 / 512.0) +
                           (qn + (double)tmax) * (1.0 / 32768.0);
-        constexpr double kTrunc = 1.0001 / 32768.0;
         const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
         float4 qv[16];
         lds_dma_wait();
@@ -1123,6 +1119,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             }
             if (!certified) {
                 atomicAdd(&counters[1], 1);
+                knn_d2[pd.out_off + qrow] = b1i >= 0 ? b1q : FLT_MAX;     // the refine pass's threshold: the exact second best so far
                 if (flagged) {           // audit of THIS pass's certificate: its failures on the global list
                     const int slot = atomicAdd(&counters[0], 1);
                     if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
@@ -1130,6 +1127,141 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                 pair_list[pd.out_off + atomicAdd(&pair_cnt[pi], 1)] = qrow;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The second pass over what l2_knn_bf16x1_kernel could not certify: a THRESHOLD FILTER instead of a second top-k.
+// For such a query the first pass has left the exact two best of its candidates; U = the exact second-best d^2.  Every train row
+// that can still change the answer has d^2 <= U, hence a one-product score s <= U - |q|^2 + E1 (E1: the first pass's bound on
+// |(|q|^2 + s) - d^2|, same formula).  So: the same bf16(-2 q).bf16(t) product on the matrix cores over the whole train set, a
+// compare of every score with the query's threshold, the few rows that pass (0.1 - 1.2 per query on the data simulated in
+// scratch/sim_bf16x1_cert.py) evaluated exactly in the oracle's order and merged with the two known neighbours.  The result is exact;
+// a chunk whose hit list overflows (adversarial inputs: every row inside the error) goes to the exact re-scan instead.
+// Work item = (pair, chunk of 32 uncertified queries); the four waves of the workgroup split the train set, fragments straight
+// from the bf16 image in global memory (the pass handles a fraction of a per cent of the queries: latency matters, not reuse).
+// Grid: `per_pair` workgroups per pair, workgroup (p, c) takes the chunks c, c + per_pair, ... of pair p's list.
+__global__ __launch_bounds__(256) void l2_refine_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
+                                                        const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
+                                                        const float *__restrict__ rho_t, const float *__restrict__ rho_q,
+                                                        const PairDesc *__restrict__ pairs, int per_pair,
+                                                        const int32_t *__restrict__ in_cnt, const int32_t *__restrict__ in_list,
+                                                        const float *__restrict__ knn_d2, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
+                                                        int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
+                                                        int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
+{
+    constexpr int CAP = 1024, HS = 8;
+    constexpr float kBig = 3.0e38f;
+    __shared__ int s_nhit;
+    __shared__ int s_hq[CAP], s_ht[CAP];
+    __shared__ float s_hd[CAP], s_hd2[CAP];
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    // (chunk-major numbering: the workgroups that usually have work -- chunk 0 of every pair -- are consecutive, hence spread over
+    // the XCDs; pair-major put every one of them on XCD 0: 0.42 ms instead of 0.0x)
+    const int n_pairs = gridDim.x / per_pair;
+    const int c0 = blockIdx.x / n_pairs, p = blockIdx.x - c0 * n_pairs;
+    const PairDesc pd = pairs[p];
+    const int nq = pd.nq, nt = pd.nt;
+    const int cnt = min(in_cnt[p], nq);
+    if (c0 * 32 >= cnt) return;
+    const float *__restrict__ tn = norms + pd.t_row0;
+    const float *__restrict__ tr = rho_t + pd.t_row0;
+    const u32x4 *__restrict__ ht = hi_t + (size_t)pd.t_row0 * HS;
+    {   // max |t|^2 and max rho_t over the train set
+        float m = 0.f, r = 0.f;
+        for (int t = tid; t < nt; t += 256) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
+        if (lane == 0) { s_red[wave] = m; s_red[4 + wave] = r; }
+    }
+    __syncthreads();
+    const float tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float rmax = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    // this wave's share of the train set, in steps of 32 rows
+    const int nsteps = (nt + 31) / 32;
+    const int st0 = (nsteps * wave) / 4, st1 = (nsteps * (wave + 1)) / 4;
+    for (int c = c0; c * 32 < cnt; c += per_pair) {
+        if (tid == 0) s_nhit = 0;
+        const int slot = c * 32 + j;
+        const bool qok = slot < cnt;
+        const int qrow = qok ? in_list[pd.out_off + slot] : 0;
+        // threshold on the score: s <= U - |q|^2 + E1, rounded up
+        float thr = -kBig;
+        if (qok) {
+            const double qn = (double)norms[pd.q_row0 + qrow], rq = (double)rho_q[pd.q_row0 + qrow];
+            const double e1 = (rq * sqrt((double)tmax) + (2.0 * sqrt(qn) + rq) * (double)rmax) * (1.0 + 1.0 / 512.0) + (qn + (double)tmax) * (1.0 / 32768.0);
+            const double u = (double)knn_d2[pd.out_off + qrow];
+            const double x = u * (1.0 + 1.0 / 1048576.0) - qn + e1;
+            const double xs = x + fabs(x) * (1.0 / 1048576.0);
+            thr = xs < 3.0e38 ? (float)xs : kBig;                 // (NaN compares false: kBig, everything passes -> overflow -> re-scan)
+            if (!(xs < 3.0e38)) thr = kBig;
+            if ((double)thr < xs) thr = nextafterf(thr, kBig);
+        }
+        bf16x8 bq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 v = qok ? hi_q[((size_t)pd.q_row0 + qrow) * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
+            bq[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+        __syncthreads();
+        for (int st = st0; st < st1; ++st) {
+            const int row = st * 32 + j;
+            floatx16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = st * 32 + 8 * g + 4 * h + u;
+                    acc[4 * g + u] = t < nt ? tn[t] : kBig;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 a = row < nt ? ht[(size_t)row * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], acc, 0, 0, 0);
+            }
+            float m = kBig;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fminf(m, acc[r]);       // (fminf drops NaN scores: never neighbours)
+            if (__ballot(m <= thr) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (acc[r] <= thr && t < nt) {
+                        const int k = atomicAdd(&s_nhit, 1);
+                        if (k < CAP) { s_hq[k] = j; s_ht[k] = t; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nhit = s_nhit;
+        if (nhit <= CAP) {
+            // exact distances of the hits, the oracle's order
+            for (int k = tid; k < nhit; k += 256) {
+                const int qr = in_list[pd.out_off + c * 32 + s_hq[k]];
+                const float d2 = l2sqr_canonical<true>(desc + ((size_t)pd.q_row0 + qr) * 64, desc + ((size_t)pd.t_row0 + s_ht[k]) * 64, 64);
+                s_hd2[k] = d2; s_hd[k] = sqrt_rn_f32(d2);
+            }
+            __syncthreads();
+            if (tid < 32 && qok) {
+                const size_t o = 2 * ((size_t)pd.out_off + qrow);
+                Cand b0 = {knn_dist[o], knn_idx[o], 0.f}, b1 = {knn_dist[o + 1], knn_idx[o + 1], 0.f};
+                if (b0.i < 0) b0.d = FLT_MAX;
+                if (b1.i < 0) b1.d = FLT_MAX;
+                for (int k = 0; k < nhit; ++k)
+                    if (s_hq[k] == tid && s_ht[k] != b0.i && s_ht[k] != b1.i) best2_insert(b0, b1, s_hd[k], s_ht[k], s_hd2[k]);
+                knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
+                knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
+            }
+        } else if (tid < 32 && qok) {
+            // too many rows inside the error bound: the exact re-scan takes the chunk's queries
+            const int sl = atomicAdd(&counters[0], 1);
+            if (sl < flag_cap) { flagged[2 * sl] = p; flagged[2 * sl + 1] = qrow; }
+            pair_list[pd.out_off + atomicAdd(&pair_cnt[p], 1)] = qrow;
+        }
+        __syncthreads();
     }
 }
 
@@ -1816,9 +1948,12 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
     return ESFM_OK;
 }
 
+int l2_x1_query_block() { return 128 * ESFM_L2X1_SETS; }
+bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS - 2)) * 32; }   // the position code names a 32-row step
+
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list)
+                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
@@ -1832,7 +1967,23 @@ int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long
     hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(n_blocks), dim3(256), lds, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
+                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, knn_d2);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_l2_refine(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                     int n_pairs, const int32_t *in_cnt, const int32_t *in_list, const float *knn_d2, int32_t *knn_idx, float *knn_dist,
+                     int32_t *flagged, int32_t *counters, int flag_cap, int32_t *pair_cnt, int32_t *pair_list)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    // a handful of workgroups per pair (a workgroup without work leaves after one load), about 4096 in all
+    const int per_pair = std::max(1, std::min(8, 4096 / n_pairs));
+    void *h = const_cast<void *>(hi);
+    hipLaunchKernelGGL(l2_refine_kernel, dim3((unsigned)n_pairs * (unsigned)per_pair), dim3(256), 0, st, desc,
+                       reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
+                       reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
+                       pairs, per_pair, in_cnt, in_list, knn_d2, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -12,7 +12,7 @@ struct PairDesc {
     int32_t t_row0, nt;   // train set
     int64_t out_off;      // first output slot of this pair (exclusive prefix sum of nq)
     int32_t blk_off;      // first workgroup of this pair in the knn launch
-    int32_t pad;
+    int32_t blk_off2;     // ... in the launch of the one-product front pass (l2_x1_query_block() queries per workgroup)
 };
 
 int launch_l2_norms(hipStream_t st, const float *desc, int dim, long long n_rows, float *norms);
@@ -37,7 +37,14 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 size_t l2_hi_bytes(long long total_rows);
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list);
+                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2 /* one float per query: exact second-best d^2 of an uncertified query */);
+// threshold-filter second pass over the one-product pass's uncertified queries (in_cnt / in_list): exact results written in place;
+// chunks whose hit list overflows are binned for the exact re-scan (pair_cnt / pair_list, flagged, counters[0])
+int launch_l2_refine(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                     int n_pairs, const int32_t *in_cnt, const int32_t *in_list, const float *knn_d2, int32_t *knn_idx, float *knn_dist,
+                     int32_t *flagged, int32_t *counters, int flag_cap, int32_t *pair_cnt, int32_t *pair_list);
+int l2_x1_query_block();
+bool l2_x1_supported(int max_nt);          // train sets the front pass's position code covers
 bool l2_one_product_pass();   // ESFM_L2_PASS=bf16x3 in the environment switches the one-product front pass off (measurement)
 // exact re-scan of the queries launch_l2_knn_bf16 binned per pair (pair_cnt[p] entries at pair_list[out_off[p]...])
 int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *pairs, int n_pairs, const int32_t *pair_cnt,

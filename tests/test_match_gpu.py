@@ -222,7 +222,37 @@ def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
     pm.ctx.synchronize()               # the library's own stream: torch's copies below do not wait for it
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     n_q, n_rescan = pm.stats()
-    assert n_rescan > n_q // 2          # the case is about the re-scan
+    assert pm.second_pass() > n_q // 2     # the case is about the passes behind the first one (round 3: the threshold-filter pass
+                                           # resolves these duplicates exactly; its overflow path to the re-scan: next test)
+    off = pm.offset
+    for k, (i, j) in enumerate(pairs):
+        ridx, rdist = oracle_lib.knn2_l2(sets[i], sets[j])
+        sl = slice(int(off[k]), int(off[k + 1]))
+        assert np.array_equal(idx[sl], ridx) and np.array_equal(_bits(dist[sl]), _bits(rdist)), (i, j)
+
+
+def test_refine_overflow_takes_the_rescan(gpu_ctx, oracle_lib):
+    """Train sets made of thousands of copies of a few rows: every query ties with more rows than the threshold-filter pass keeps
+    hits for (1024 per chunk of 32 queries), so its chunks overflow and the exact re-scan (l2_rescan64_pairs_kernel) decides --
+    lowest train index first, like the oracle."""
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal((3, 64)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    sets = []
+    for i in range(5):
+        n = 2500 + 37 * i
+        x = base[rng.integers(0, 3, n)].copy()
+        fresh = rng.random(n) < 0.02
+        x[fresh] = rng.standard_normal((int(fresh.sum()), 64)).astype(np.float32)
+        sets.append(np.ascontiguousarray(x))
+    pairs = synth.all_pairs(5)
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
+    pm = E.PairMatcher(bank, pairs)
+    idx, dist = pm.knn2()
+    pm.ctx.synchronize()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    n_q, n_rescan = pm.stats()
+    assert n_rescan > n_q // 2
     off = pm.offset
     for k, (i, j) in enumerate(pairs):
         ridx, rdist = oracle_lib.knn2_l2(sets[i], sets[j])
