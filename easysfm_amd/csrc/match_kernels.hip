@@ -1004,34 +1004,44 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     const float tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     const float rmax = fmaxf(fmaxf(lds_red[4], lds_red[5]), fmaxf(lds_red[6], lds_red[7]));
 
-    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate (see l2_knn_bf16_kernel: the same scheme with
-    // 2 K groups per query, dealt out over K rounds) ----
+    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate ----
+    // Which groups: a query's 2 K kept groups ranked by key across its two lanes; with ka <= kb the two smallest keys, both of their
+    // minima rows have exact d^2 <= U = |q|^2 + kb + E(kb), so a group with |q|^2 + key - E(key) > U (1 + 2^-20) cannot hold one of
+    // the two nearest: the needed groups are a prefix of the ranking, 2.6 per query on M-SURF-4k.
+    // How (round 3): the three-product kernel deals the ranks out to the query's own two lanes, round by round, and a round runs
+    // for the whole wave as long as ANY of its 32 queries needs it -- 3.4 rounds of 4 rows per set, measured, where the average
+    // query needs 1.3: the re-rank was as many VALU instructions as the fold (124 M of 262 M per launch), and VALU time is what
+    // bounds the one-product kernel.  Here the (query, group) items of a set are COMPACTED: the queries' item counts are prefix-summed
+    // across the wave, every query writes its items into a small LDS table, and lane l of dense round r takes item 64 r + l --
+    // whichever query it belongs to (1.3 rounds per set).  The item's query row arrives by LDS-DMA like its train rows (one more
+    // sub-round), the lane's best two of the group are merged with the other items of the same query by a segmented shuffle
+    // reduction (a query's items are neighbours), and the segment's first lane folds the result into the query's entry in LDS.
+    // The distance arithmetic is the packed form (v_pk_add/mul_f32: every half an IEEE single operation, bit-identical).
     lds_dma_wait();
     __syncthreads();   // every wave is through its last tile and has its keys: the ring becomes four private 16-KiB landing zones
     const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
     const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);
     const uint32_t lds_land = lds_tile_addr + (uint32_t)wave_s * 16384u;
     const float4 *land = reinterpret_cast<const float4 *>(smem) + (size_t)wave * 1024;
+    uint32_t *items = reinterpret_cast<uint32_t *>(lds_red + 8) + wave * (32 * 2 * K);          // [32 queries x 2 K] item descriptors of this wave
+    float *res = reinterpret_cast<float *>(lds_red + 8) + 4 * (32 * 2 * K) + wave * (32 * 6);    // [32][6]: the queries' running best two
     int swz[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
+    // a lane's running best two as plain scalars (d, i, d^2), branch-free insert
+    struct Best { float d0, d1, q0, q1; int i0, i1; };
+    auto ins = [](Best &b, bool valid, float d, int i, float d2) {
+        const bool c1 = valid && (d < b.d1 || (d == b.d1 && i < b.i1));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
+        const bool c0 = valid && (d < b.d0 || (d == b.d0 && i < b.i0));
+        b.d1 = c0 ? b.d0 : (c1 ? d : b.d1); b.i1 = c0 ? b.i0 : (c1 ? i : b.i1); b.q1 = c0 ? b.q0 : (c1 ? d2 : b.q1);
+        b.d0 = c0 ? d : b.d0; b.i0 = c0 ? i : b.i0; b.q0 = c0 ? d2 : b.q0;
+    };
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
         if (__ballot(qvalid) == 0ull) break;           // (wave-uniform: the sets past the end of the query set)
-        float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
-        auto insert2 = [&](bool valid, float d, int i, float d2) {
-            const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
-            const bool c0 = valid && (d < b0d || (d == b0d && i < b0i));
-            b1d = c0 ? b0d : (c1 ? d : b1d); b1i = c0 ? b0i : (c1 ? i : b1i); b1q = c0 ? b0q : (c1 ? d2 : b1q);
-            b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
-        };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
         const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
         const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
         float vk[K], pk[K]; int g0[K], pg[K], rank_own[K], rank_par[K];
@@ -1059,56 +1069,124 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         const double e1 = ((double)qrho_s * sqrt((double)tmax) + (2.0 * sqrt(qn) + (double)qrho_s) * (double)rmax) * (1.0 + 1.0 / 512.0) +
                           (qn + (double)tmax) * (1.0 / 32768.0);
         const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
-        float4 qv[16];
-        lds_dma_wait();
+        // the query's items: rank r is needed iff its group exists and can hold one of the two nearest (a prefix of the ranking)
+        int n_items = 0;
+        if (h == 0) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
+            for (int r = 0; r < 2 * K; ++r) {
+                float key = kBig; int row0 = -1;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    if (rank_own[i] == r) { key = vk[i]; row0 = g0[i]; }
+                    if (rank_par[i] == r) { key = pk[i]; row0 = pg[i]; }
+                }
+                const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
+                const bool need = row0 >= 0 && qvalid && !cannot;
 #ifdef ESFM_X1_NOTAIL            // (timing experiments)
-        for (int r = 0; r < 0; ++r) {
+                if (false)
 #else
-        for (int r = 0; r < K; ++r) {
+                if (need)
 #endif
-            const int want = 2 * r + h;
-            float key = kBig; int row0 = -1;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
-                if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
+                    items[j * (2 * K) + n_items++] = ((uint32_t)j << 20) | (uint32_t)row0;      // (need is a prefix: the slots fill in rank order)
             }
-            const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-            const bool need = row0 >= 0 && qvalid && !cannot;
-            if (__ballot(need) == 0ull) break;
-            const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
+        }
+        // exclusive prefix sum of the item counts over the 32 queries (lanes 0..31; lanes 32..63 carry zeros)
+        int incl = n_items;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 31);
+        const int excl = incl - n_items;
+        if (h == 0) {           // this query's running best two: empty
+            res[j * 6 + 0] = FLT_MAX; res[j * 6 + 1] = FLT_MAX; res[j * 6 + 2] = 0.f; res[j * 6 + 3] = 0.f;
+            res[j * 6 + 4] = __int_as_float(-1); res[j * 6 + 5] = __int_as_float(-1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (wave-private LDS tables: no barrier, the wave runs in lockstep)
+        for (int base = 0; base < total; base += 64) {
+            // item base + lane: binary search of the owner query in the prefix sums (excl of lane j = first item of query j)
+            const int it = base + lane;
+            const bool ivalid = it < total;
+            int jq = 0;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const int e = __shfl(excl, jq + o);
+                if (ivalid && e <= it) jq += o;
+            }
+            const int first = __shfl(excl, jq);
+            const uint32_t dsc = ivalid ? items[jq * (2 * K) + (it - first)] : 0u;
+            const int row0 = ivalid ? (int)(dsc & 0xFFFFFu) : nt;          // nt: past the descriptor, zeros
+            // sub-round 0: the items' query rows; then GRP sub-rounds of train rows (16 lanes fetch one 256-B row; DMA
+            // instruction i serves the lanes 4 i .. 4 i + 3)
+            const int qsel = ivalid ? qbase + 32 * s + jq : nq;
             int rowsrc[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (swz[i & 3] & 255);
+            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, qsel) * 256 + (swz[i & 3] & 255);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents are in registers
 #pragma unroll
+            for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_q, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, row0) * 256 + (swz[i & 3] & 255);
+            float4 qv[16];
+            lds_dma_wait();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) qv[c] = land[lane * 16 + (c ^ (lane & 15))];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
             for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
+            Best lb = {FLT_MAX, FLT_MAX, 0.f, 0.f, -1, -1};
 #pragma unroll
             for (int u = 0; u < GRP; ++u) {
-                float4 ra_[16];
+                float4 ta[16];
                 lds_dma_wait();
 #pragma unroll
-                for (int c = 0; c < 16; ++c) ra_[c] = land[lane * 16 + (c ^ (lane & 15))];
+                for (int c = 0; c < 16; ++c) ta[c] = land[lane * 16 + (c ^ (lane & 15))];
                 if (u + 1 < GRP) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
                 }
-                const float da = l2sqr64_canonical_regs(qv, ra_);
+                float2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // l2sqr64_canonical_regs, packed
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float2v av[4] = {{ta[2 * c].x, ta[2 * c].y}, {ta[2 * c].z, ta[2 * c].w}, {ta[2 * c + 1].x, ta[2 * c + 1].y}, {ta[2 * c + 1].z, ta[2 * c + 1].w}};
+                    const float2v qe[4] = {{qv[2 * c].x, qv[2 * c].y}, {qv[2 * c].z, qv[2 * c].w}, {qv[2 * c + 1].x, qv[2 * c + 1].y}, {qv[2 * c + 1].z, qv[2 * c + 1].w}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float2v d = qe[e] - av[e];
+                        acc[e] = acc[e] + d * d;
+                    }
+                }
+                const float2v s01 = acc[0] + acc[2], s23 = acc[1] + acc[3];
+                const float da = __fadd_rn(__fadd_rn(__fadd_rn(s01.x, s01.y), s23.x), s23.y);
                 const int ta_ = row0 + u;
-                insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
+                ins(lb, ivalid && ta_ < nt, sqrt_rn_f32(da), ta_, da);
             }
-        }
-        {
-            const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
-            const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
-            insert2(pi0 >= 0, pd0, pi0, pq0);
-            insert2(pi1 >= 0, pd1, pi1, pq1);
+            // segmented merge: the items of a query sit on neighbouring lanes (at most 2 K of them)
+#pragma unroll
+            for (int o = 1; o < 2 * K; o <<= 1) {
+                const int pj = __shfl_down(ivalid ? jq : -1, o);
+                const float pd0 = __shfl_down(lb.d0, o), pq0 = __shfl_down(lb.q0, o), pd1 = __shfl_down(lb.d1, o), pq1 = __shfl_down(lb.q1, o);
+                const int pi0 = __shfl_down(lb.i0, o), pi1 = __shfl_down(lb.i1, o);
+                const bool same = ivalid && lane + o < 64 && pj == jq;
+                ins(lb, same && pi0 >= 0, pd0, pi0, pq0);
+                ins(lb, same && pi1 >= 0, pd1, pi1, pq1);
+            }
+            const int prevj = __shfl_up(ivalid ? jq : -1, 1);
+            if (ivalid && (lane == 0 || prevj != jq)) {          // the segment's first lane: fold into the query's entry
+                float *e = res + jq * 6;
+                Best rb = {e[0], e[1], e[2], e[3], __float_as_int(e[4]), __float_as_int(e[5])};
+                ins(rb, lb.i0 >= 0, lb.d0, lb.i0, lb.q0);
+                ins(rb, lb.i1 >= 0, lb.d1, lb.i1, lb.q1);
+                e[0] = rb.d0; e[1] = rb.d1; e[2] = rb.q0; e[3] = rb.q1; e[4] = __int_as_float(rb.i0); e[5] = __int_as_float(rb.i1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         const float tau = fminf(vk[K - 1], pk[K - 1]);
         if (qvalid && h == 0) {
+            const float b0d = res[j * 6 + 0], b1d = res[j * 6 + 1], b1q = res[j * 6 + 3];
+            const int b0i = __float_as_int(res[j * 6 + 4]), b1i = __float_as_int(res[j * 6 + 5]);
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
             knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
             knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
@@ -1956,7 +2034,8 @@ int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long
                          int32_t *pair_cnt, int32_t *pair_list, float *knn_d2)
 {
     if (n_blocks <= 0) return ESFM_OK;
-    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
+    // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions, the tail's item tables and result entries
+    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32 + 4 * (32 * 2 * ESFM_L2X1_KEEP) * 4 + 4 * (32 * 6) * 4;
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {

@@ -35,7 +35,7 @@ def test_msurf4k_every_query_bitexact_and_certificate_sound(oracle_lib):
     pm.ctx.synchronize()
     idx = idx.cpu().numpy().copy(); dist = dist.cpu().numpy().copy()
     n_q, n_rescan = pm.stats()
-    assert n_q == 300 * n_feat and 0 < n_rescan < n_q // 200
+    assert n_q == 300 * n_feat and n_rescan < n_q // 200 and 0 < pm.second_pass() < n_q // 20
 
     # (1) product path == oracle, all 1 228 800 queries
     oracle_lib.set_num_threads(os.cpu_count() or 1)
