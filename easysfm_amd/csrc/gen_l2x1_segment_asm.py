@@ -7,8 +7,9 @@ keys per lane and set; the certificate of the one-product pass needs K > 3, DESI
 Differences from gen_l2_segment_asm.py (the three-product pass, which now only sees the queries this pass cannot certify):
   * four query sets per wave (512 queries per workgroup): with a third of the MFMAs per train row the L2 -> LDS stream, the LDS
     reads and the per-tile barrier of the 256-query shape were as long as the matrix work (measured: 0.26 ms of 0.66 with all
-    arithmetic removed).  ONE accumulator per set (v0-v63): the fold of a set's results sits right in front of the MFMA that
-    overwrites them in the next step ("skew"), in the shadow of the previous set's MFMA and of the SIMD's other wave;
+    arithmetic removed).  Two accumulators per set do not fit beside 64 registers of B operands: six register sets and a skewed
+    MFMA order (below) let every fold ride behind an MFMA all the same (a first version with four sets folded each set right in
+    front of the MFMA that overwrote it: no overlap at all, fold and matrix time simply added up -- 0.47 + 0.21 = 0.68 ms);
   * the train image is bf16(t) only: 128-B rows, 16-B slot 2 ks + h holds a lane's A fragment of K-step ks; in LDS slot s of row r
     sits at physical slot s ^ ((r >> 1) & 7) -- every 16-lane group of a ds_read_b128 then covers the 64 banks exactly once;
   * a RING of four 16-KiB tile buffers: the LDS-DMA of tile t + 4 is issued when tile t hands its buffer over and has three tiles'
@@ -21,27 +22,31 @@ Differences from gen_l2_segment_asm.py (the three-product pass, which now only s
   * K keys per set: 3 + K VALU per group of four results (2 v_min3, v_and_or, K v_med3).  The 4 K keys leave through LDS (the
     ring is dead by then): key i of set s of thread tid at float (K s + i) * 256 + tid.
 
-  step (32 train rows x 128 queries, 16 MFMAs):
-      K-step 0   s_waitcnt; for s = 0..3: [fold of set s's results of the PREVIOUS step, 4 groups]  MFMA acc[s] = A(0) B[s](0) + |t|^2
-                 ds_read A(0) of the next step
-      K-step 1   s_waitcnt; 4 MFMAs; ds_read A(1)'         K-step 2   ... ; ds_read the next step's 16 start values, A(2)'
-      K-step 3   ... ; ds_read A(3)'
+  step (32 train rows x 128 queries, 16 MFMAs).  Six accumulator register sets for the four query sets: sets 2 and 3 have ONE
+  each, sets 0 and 1 alternate between two (even / odd steps).  MFMA order inside a step
+      slot   0      1      2      3      4      5      6      7      8      9      10     11     12     13     14     15
+      MFMA  (0,0)  (1,0)  (2,0)  (3,0)  (2,1)  (3,1)  (2,2)  (3,2)  (2,3)  (3,3)  (0,1)  (1,1)  (0,2)  (1,2)  (0,3)  (1,3)     (set, K-step)
+  so that the single-buffered sets finish at slots 8 / 9 and are overwritten at slots 2 / 3 of the next step: their folds (two
+  slots after the last MFMA: the results must have left the pipe) take the eight gaps behind slots 10 .. 15, 0', 1'; the folds
+  of sets 0 and 1 (whose registers are not touched by the next step) the eight gaps behind slots 2' .. 9'.  Every gap carries
+  (3 + K) VALU of one group of one set and a K-step's worth of LDS reads at most: uniform, 7 VALU per MFMA at K = 4.
   hand-over of tile t = the top of its last step: every read of the tile has been issued a step ago and is waited for, the wave's own
   transfers of tile t + 1 are waited for (vmcnt) and its norms written, barrier, then the norm load and the four DMA pieces of
   tile t + 4 go out (LDS-DMA destinations stay below 64 KiB: M0 carries the address).
 
-Register map (all clobbered):
-  v[0:63]            accumulators of query sets 0..3
+Register map (all clobbered; b = 112 + 4 K):
+  v[0:15] v[16:31]   accumulators of query sets 0, 1 in even steps      v[b+24 : b+56)  ... in odd steps
+  v[32:47] v[48:63]  accumulators of query sets 2, 3
   v[64:79] v[80:95]  A fragments of even / odd steps: K-step ks = v[64 + 16 par + 4 ks : +3]
   v[96:111]          start values (|t|^2 of the step's 32 train rows, this lane's 16)
-  v[112 : 112 + 4K)  keys: set s, rank i = v[112 + K s + i]           (K <= 6: up to v135)
-  v136-v139 a_addr   v140 n_addr   v141-v144 DMA source offsets   v145 norm source offset   v146 norm LDS address
-  v147-v150 ring norm registers   v151-v154 scratch   v155-v158 fold temporaries   v159 key mask
+  v[112 : b)         keys: set s, rank i = v[112 + K s + i]
+  b..b+3 a_addr   b+4 n_addr   b+5..b+8 DMA source offsets   b+9 norm source offset   b+10 norm LDS address
+  b+11..b+14 ring norm registers   b+15..b+18 scratch   b+19..b+22 fold temporaries   b+23 key mask
   s40 tile  s41 code base of the step being folded  s42 step index  s43 saved M0  s44-s47 codes of the four groups
   s48-s51 scratch  s52 kBig  s53 -kBig
-Operands (inputs only): %0-%15 B[s][ks] (s major);  %16-%19 norms of tiles 0..3 for the ring's norm registers;  %20 tile count;
-  %21 nt;  %22 train image buffer descriptor;  %23 train norms buffer descriptor;  %24 LDS address of the ring (norms behind it);
-  %25 wave index.
+Operands (inputs only): %0-%15 B[s][ks] (s major);  %16 tile count;  %17 nt;  %18 train image buffer descriptor;  %19 train
+  norms buffer descriptor;  %20 LDS address of the ring (norms behind it: the caller has written those of the first four tiles);
+  %21 wave index.
 """
 import os
 import sys
@@ -59,20 +64,26 @@ NORM_BASE = RING * TILE_BYTES        # the ring's norms sit behind the tiles: RI
 assert 3 <= KEEP <= 6
 
 OP_B = lambda s, ks: f"%{4 * s + ks}"
-OP_NR = lambda b: f"%{16 + b}"
-OP_NTILES, OP_NT, OP_TRSRC, OP_NRSRC, OP_LDS, OP_WAVE = (f"%{20 + i}" for i in range(6))
+OP_NTILES, OP_NT, OP_TRSRC, OP_NRSRC, OP_LDS, OP_WAVE = (f"%{16 + i}" for i in range(6))
 
 KEY = lambda s, i: f"v{112 + KEEP * s + i}"
-A_ADDR, N_ADDR, DMA_OFF, NSRC_OFF, NLDS = 136, 140, 141, 145, 146
-NR = lambda b: f"v{147 + b}"
-SCR = 151                      # v151..v154
-FTMP = 155                     # v155..v158: (t, key) pairs, alternating
-MASK = 159
-N_CLOBBER = 160
+_b = 112 + 4 * KEEP            # (registers are packed: beside 64 registers of B operands every one counts)
+A_ADDR, N_ADDR, DMA_OFF, NSRC_OFF, NLDS = _b, _b + 4, _b + 5, _b + 9, _b + 10
+NR = lambda b: f"v{_b + 11 + b}"
+SCR = _b + 15                  # 4 scratch registers
+FTMP = _b + 19                 # 4: (t, key) pairs, alternating
+MASK = _b + 23
+ACC_ODD = _b + 24              # accumulators of sets 0, 1 in odd steps: 32 registers
+N_CLOBBER = ACC_ODD + 32
 
 
-def acc(s):
-    return f"v[{16 * s}:{16 * s + 15}]"
+def acc(s, par=0):
+    return 16 * s if (s >= 2 or par == 0) else ACC_ODD + 16 * s
+
+
+def accr(s, par=0):
+    b = acc(s, par)
+    return f"v[{b}:{b + 15}]"
 
 
 def fr(ks, par):
@@ -116,15 +127,13 @@ def gen():
     e(f"v_lshlrev_b32 v{NSRC_OFF}, 2, v{FTMP}")               # byte offset inside a tile's norms
     e(f"v_add_u32 v{NLDS}, {OP_LDS}, v{NSRC_OFF}")
     e(f"v_add_u32 v{NLDS}, {NORM_BASE}, v{NLDS}")             # lds_norm + 4 row (ring slot 0)
-    for b in range(RING):
-        e(f"v_mov_b32 {NR(b)}, {OP_NR(b)}")
     e(f"s_mov_b32 s52, 0x{KBIG:08x}")
     e(f"s_mov_b32 s53, 0x{NKBIG:08x}")
     e(f"v_mov_b32 v{MASK}, 0x{(0xFFFFFFFF << CODE_BITS) & 0xFFFFFFFF:08x}")
     for s in range(NS):
         for i in range(KEEP):
             e(f"v_mov_b32 {KEY(s, i)}, s52")
-    for r in range(0, 64):
+    for r in list(range(0, 64)) + list(range(ACC_ODD, ACC_ODD + 32)):
         e(f"v_mov_b32 v{r}, s52")                             # placeholders for the step before the first: never live
     e("s_mov_b32 s40, 0")
     e("s_mov_b32 s41, 0")
@@ -139,10 +148,11 @@ def gen():
 
     cnt = [0]
 
-    def fold_group(s, g):
+    def fold_group(s, g, par):
+        """(3 + K) VALU: group g (accumulator registers 4 g .. 4 g + 3) of set s of the step with parity `par`."""
         if NOFOLD:
             return []
-        b = 16 * s + 4 * g
+        b = acc(s, par) + 4 * g
         cnt[0] ^= 1
         t, key = FTMP + 2 * cnt[0], FTMP + 1 + 2 * cnt[0]
         out = [f"v_min3_f32 v{t}, v{b}, s52, v{b + 1}",
@@ -153,35 +163,50 @@ def gen():
         out.append(f"v_med3_f32 {KEY(s, 0)}, {KEY(s, 0)}, v{key}, s53")
         return out
 
-    WAIT = {0: 2, 1: None, 2: 3, 3: 7}   # younger reads that may stay in flight (queue order per step: F0 | F1 | N x 4, F2 | F3)
+    # slot -> (set, K-step)
+    ORDER = [(0, 0), (1, 0), (2, 0), (3, 0), (2, 1), (3, 1), (2, 2), (3, 2), (2, 3), (3, 3), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (1, 3)]
+    # fold of the group behind each slot: ("cur", set, group) = this step's results, ("prev", ...) = the previous step's
+    GAP = {10: ("cur", 2, 0), 11: ("cur", 3, 0), 12: ("cur", 2, 1), 13: ("cur", 3, 1), 14: ("cur", 2, 2), 15: ("cur", 3, 2),
+           0: ("prev", 2, 3), 1: ("prev", 3, 3),
+           2: ("prev", 0, 0), 3: ("prev", 1, 0), 4: ("prev", 0, 1), 5: ("prev", 1, 1), 6: ("prev", 0, 2), 7: ("prev", 1, 2), 8: ("prev", 0, 3), 9: ("prev", 1, 3)}
+    # LDS reads behind a slot: fragment ks of the next step (into the other parity's registers) and, behind slot 9, the next
+    # step's 16 start values (this step's were last read by slot 3)
+    READS = {1: ("frag", 0), 5: ("frag", 1), 9: ("start", None), 11: ("frag", 2), 13: ("frag", 3)}
+    # Waits in front of a slot: the fragment it reads (issued one step ago) must have landed.  Queue order per step:
+    # F0 (slot 1) | F1 (slot 5) | N x 4 (slot 9) | F2 (slot 11) | F3 (slot 13).  Slot 0 needs F0 and the start values: the younger
+    # F2, F3 may fly (F1 is older: landed as well, nothing to wait for at its first use, slot 4); slot 6 needs F2: younger are F3 and
+    # this step's F0', F1'; slot 8 needs F3: younger are F0', F1'.
+    WAITS = {0: 2, 6: 3, 8: 2}
 
-    def step(par, nbuf, nstep, extra=None):
-        """One 32-train step with the fragments of parity `par`; prefetches the next step (buffer nbuf, step nstep).
-        extra: instruction lists issued behind the MFMAs of K-steps 1 and 2 (the hand-over's transfers)."""
+    def step(par, spar, nbuf, nstep, extra=None):
+        """One 32-train step: fragments of parity `par`, accumulators of sets 0 / 1 of parity `spar`; prefetches the next step
+        (buffer nbuf, step nstep).  extra: instruction lists issued behind slots 4 .. 8 (the hand-over's transfers)."""
         extra = list(extra or [])
-        for ks in range(4):
-            if WAIT[ks] is not None:
-                e(f"s_waitcnt lgkmcnt({WAIT[ks]})")
-            for s in range(NS):
-                if ks == 0:
-                    for g in range(4):
-                        for x in fold_group(s, g):
-                            e(x)
-                if not NOMFMA:
-                    e(f"v_mfma_f32_32x32x16_bf16 {acc(s)}, {fr(ks, par)}, {OP_B(s, ks)}, {'v[96:111]' if ks == 0 else acc(s)}")
-                if ks >= 1 and extra:
-                    for x in extra.pop(0):
-                        e(x)
-            if ks == 0:
+        for slot, (s, ks) in enumerate(ORDER):
+            if slot in WAITS:
+                e(f"s_waitcnt lgkmcnt({WAITS[slot]})")
+            if slot == 10:
                 # the step being folded from now on is this one
                 e("s_lshl_b32 s41, s42, 2")
                 e("s_add_u32 s42, s42, 1")
                 for g in range(4):
                     e(f"s_add_u32 s{44 + g}, s41, {g}")
-            if ks == 2:
-                for g in range(4):
-                    e(f"ds_read_b128 v[{96 + 4 * g}:{99 + 4 * g}], v{N_ADDR} offset:{(nbuf * TT + nstep * 32 + 8 * g) * 4}")
-            e(f"ds_read_b128 {fr(ks, par ^ 1)}, v{A_ADDR + ks} offset:{nbuf * TILE_BYTES + nstep * 32 * ROW_BYTES}")
+            if not NOMFMA:
+                a = accr(s, spar)
+                e(f"v_mfma_f32_32x32x16_bf16 {a}, {fr(ks, par)}, {OP_B(s, ks)}, {'v[96:111]' if ks == 0 else a}")
+            if 4 <= slot <= 8 and extra:
+                for x in extra.pop(0):
+                    e(x)
+            which, fs, fg = GAP[slot]
+            for x in fold_group(fs, fg, spar if which == "cur" else spar ^ 1):
+                e(x)
+            if slot in READS:
+                kind, k = READS[slot]
+                if kind == "start":
+                    for g in range(4):
+                        e(f"ds_read_b128 v[{96 + 4 * g}:{99 + 4 * g}], v{N_ADDR} offset:{(nbuf * TT + nstep * 32 + 8 * g) * 4}")
+                else:
+                    e(f"ds_read_b128 {fr(k, par ^ 1)}, v{A_ADDR + k} offset:{nbuf * TILE_BYTES + nstep * 32 * ROW_BYTES}")
         assert not extra
 
     def dma_piece(i, buf):
@@ -192,12 +217,14 @@ def gen():
     def tile(buf, tag):
         nb = (buf + 1) % RING
         for st in range(3):
-            step(st & 1, buf, st + 1)
+            step(st & 1, st & 1, buf, st + 1)
         # ---- step 3: hand-over first
         e("s_waitcnt lgkmcnt(0)")                               # every read of this tile has landed
         e("s_waitcnt vmcnt(8)")                                 # this wave's transfers of tile + 1 have landed (tile + 2, + 3 may fly;
         #                                                         8, not 10: the caller's first three tiles are 4 transfers each)
-        # norms of tile + 1 -> LDS, rows past nt as kBig
+        # norms of tile + 1 -> LDS, rows past nt as kBig (the first RING tiles' norms were written by the caller)
+        e(f"s_cmp_lt_u32 s40, {RING - 1}")
+        e(f"s_cbranch_scc1 L_nonorm_{tag}_%=")
         e("s_add_u32 s48, s40, 1")
         e("s_lshl_b32 s48, s48, 7")
         e(f"v_lshrrev_b32 v{SCR}, 2, v{NSRC_OFF}")
@@ -207,6 +234,7 @@ def gen():
         e(f"v_cndmask_b32 v{SCR + 1}, v{SCR + 1}, {NR(nb)}, vcc")
         e(f"ds_write_b32 v{NLDS}, v{SCR + 1} offset:{nb * TT * 4}")
         e("s_waitcnt lgkmcnt(0)")
+        e(f"L_nonorm_{tag}_%=:")
         e("s_barrier")
         e("s_add_u32 s48, s40, 4")
         e("s_lshl_b32 s51, s48, 9")                             # (tile + 4) * 128 * 4
@@ -215,7 +243,7 @@ def gen():
         e(f"s_add_u32 s49, s49, {OP_LDS}")
         # (a tile that does not exist reads zeros through the descriptors into a buffer nobody reads again: unconditional)
         pcs = [[f"buffer_load_dword {NR(buf)}, v{NSRC_OFF}, {OP_NRSRC}, s51 offen"]] + [dma_piece(i, buf) for i in range(4)]
-        step(1, nb, 0, extra=pcs)
+        step(1, 1, nb, 0, extra=pcs)
         e("s_add_u32 s40, s40, 1")
 
     e("L_top_%=:")
@@ -227,14 +255,14 @@ def gen():
     e(f"s_cmp_lt_u32 s40, {OP_NTILES}")
     e("s_cbranch_scc1 L_top_%=")
     e("L_done_%=:")
-    # the last step's results: wait for the matrix pipe before the VALU reads them
+    # what the last step (parity 1) left unfolded: group 3 of its sets 2 and 3, all of its sets 0 and 1 -- after the matrix pipe
+    # has delivered them
     e("s_nop 15")
     e("s_nop 15")
     e("s_waitcnt lgkmcnt(0)")                                   # the prefetches past the end land in dead registers
-    for s in range(NS):
-        for g in range(4):
-            for x in fold_group(s, g):
-                e(x)
+    for fs, fg in [(2, 3), (3, 3)] + [(s_, g_) for s_ in (0, 1) for g_ in range(4)]:
+        for x in fold_group(fs, fg, 1):
+            e(x)
     # keys -> LDS (the ring is dead once every wave is here and every transfer has landed)
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")

@@ -960,16 +960,9 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             bq[s][ks] = v;
         }
     }
-    // norms of the first RING tiles: tile 0 straight to LDS, tiles 1..3 into the ring's norm registers (the asm block writes a
-    // tile's norms at the hand-over that publishes it, rows past nt as kBig)
-    if (tid < TT) lds_norm[tid] = tid < nt ? tn[tid] : kBig;
-    float nr[RING];
-    nr[0] = 0.f;
-#pragma unroll
-    for (int b = 1; b < RING; ++b) {
-        const int row = b * TT + wave * 32 + (lane & 31);
-        nr[b] = row < nt ? tn[row] : 0.f;
-    }
+    // norms of the first RING tiles straight to LDS, rows past nt as kBig (the asm block takes over from tile RING on: it writes a
+    // tile's norms at the hand-over that publishes it)
+    for (int t = tid; t < RING * TT; t += 256) lds_norm[t] = t < nt ? tn[t] : kBig;
     // max |t|^2 and max rho_t over the train set (the certificate's bound needs both in the tail)
     {
         float m = 0.f, r = 0.f;
@@ -990,7 +983,6 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                      :
                      : "v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[0][2]), "v"(bq[0][3]), "v"(bq[1][0]), "v"(bq[1][1]), "v"(bq[1][2]), "v"(bq[1][3]),
                        "v"(bq[2][0]), "v"(bq[2][1]), "v"(bq[2][2]), "v"(bq[2][3]), "v"(bq[3][0]), "v"(bq[3][1]), "v"(bq[3][2]), "v"(bq[3][3]),
-                       "v"(nr[0]), "v"(nr[1]), "v"(nr[2]), "v"(nr[3]),
                        "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
                      : ESFM_L2X1_SEGMENT_CLOBBERS);
     }
@@ -1004,44 +996,39 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     const float tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     const float rmax = fmaxf(fmaxf(lds_red[4], lds_red[5]), fmaxf(lds_red[6], lds_red[7]));
 
-    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate ----
-    // Which groups: a query's 2 K kept groups ranked by key across its two lanes; with ka <= kb the two smallest keys, both of their
-    // minima rows have exact d^2 <= U = |q|^2 + kb + E(kb), so a group with |q|^2 + key - E(key) > U (1 + 2^-20) cannot hold one of
-    // the two nearest: the needed groups are a prefix of the ranking, 2.6 per query on M-SURF-4k.
-    // How (round 3): the three-product kernel deals the ranks out to the query's own two lanes, round by round, and a round runs
-    // for the whole wave as long as ANY of its 32 queries needs it -- 3.4 rounds of 4 rows per set, measured, where the average
-    // query needs 1.3: the re-rank was as many VALU instructions as the fold (124 M of 262 M per launch), and VALU time is what
-    // bounds the one-product kernel.  Here the (query, group) items of a set are COMPACTED: the queries' item counts are prefix-summed
-    // across the wave, every query writes its items into a small LDS table, and lane l of dense round r takes item 64 r + l --
-    // whichever query it belongs to (1.3 rounds per set).  The item's query row arrives by LDS-DMA like its train rows (one more
-    // sub-round), the lane's best two of the group are merged with the other items of the same query by a segmented shuffle
-    // reduction (a query's items are neighbours), and the segment's first lane folds the result into the query's entry in LDS.
-    // The distance arithmetic is the packed form (v_pk_add/mul_f32: every half an IEEE single operation, bit-identical).
+    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate (see l2_knn_bf16_kernel: the same scheme with
+    // 2 K groups per query, dealt out over K rounds) ----
+    // (Round 3, measured on one box against this form, 0.906 - 0.916 ms per launch: the (query, group) items of a set compacted
+    // across the wave -- prefix sums, an LDS item table, a segmented shuffle merge, packed f32 arithmetic: 1.3 dense rounds per set
+    // instead of 3.4 and 83 M instead of 124 M VALU instructions -- 0.926 - 0.931 ms; the same with the rows through registers and
+    // ds_write_b128 instead of LDS-DMA, the next row's loads in flight during the arithmetic: 0.983 - 0.988 ms, 29 spilled
+    // registers.  The tail costs 0.3 ms whatever its instruction count: its row fetches are what it waits for.)
     lds_dma_wait();
     __syncthreads();   // every wave is through its last tile and has its keys: the ring becomes four private 16-KiB landing zones
     const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
     const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);
     const uint32_t lds_land = lds_tile_addr + (uint32_t)wave_s * 16384u;
     const float4 *land = reinterpret_cast<const float4 *>(smem) + (size_t)wave * 1024;
-    uint32_t *items = reinterpret_cast<uint32_t *>(lds_red + 8) + wave * (32 * 2 * K);          // [32 queries x 2 K] item descriptors of this wave
-    float *res = reinterpret_cast<float *>(lds_red + 8) + 4 * (32 * 2 * K) + wave * (32 * 6);    // [32][6]: the queries' running best two
     int swz[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
-    // a lane's running best two as plain scalars (d, i, d^2), branch-free insert
-    struct Best { float d0, d1, q0, q1; int i0, i1; };
-    auto ins = [](Best &b, bool valid, float d, int i, float d2) {
-        const bool c1 = valid && (d < b.d1 || (d == b.d1 && i < b.i1));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
-        const bool c0 = valid && (d < b.d0 || (d == b.d0 && i < b.i0));
-        b.d1 = c0 ? b.d0 : (c1 ? d : b.d1); b.i1 = c0 ? b.i0 : (c1 ? i : b.i1); b.q1 = c0 ? b.q0 : (c1 ? d2 : b.q1);
-        b.d0 = c0 ? d : b.d0; b.i0 = c0 ? i : b.i0; b.q0 = c0 ? d2 : b.q0;
-    };
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
         if (__ballot(qvalid) == 0ull) break;           // (wave-uniform: the sets past the end of the query set)
+        float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
+        auto insert2 = [&](bool valid, float d, int i, float d2) {
+            const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
+            const bool c0 = valid && (d < b0d || (d == b0d && i < b0i));
+            b1d = c0 ? b0d : (c1 ? d : b1d); b1i = c0 ? b0i : (c1 ? i : b1i); b1q = c0 ? b0q : (c1 ? d2 : b1q);
+            b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
         const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
         const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
         float vk[K], pk[K]; int g0[K], pg[K], rank_own[K], rank_par[K];
@@ -1069,124 +1056,56 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         const double e1 = ((double)qrho_s * sqrt((double)tmax) + (2.0 * sqrt(qn) + (double)qrho_s) * (double)rmax) * (1.0 + 1.0 / 512.0) +
                           (qn + (double)tmax) * (1.0 / 32768.0);
         const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
-        // the query's items: rank r is needed iff its group exists and can hold one of the two nearest (a prefix of the ranking)
-        int n_items = 0;
-        if (h == 0) {
+        float4 qv[16];
+        lds_dma_wait();
 #pragma unroll
-            for (int r = 0; r < 2 * K; ++r) {
-                float key = kBig; int row0 = -1;
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    if (rank_own[i] == r) { key = vk[i]; row0 = g0[i]; }
-                    if (rank_par[i] == r) { key = pk[i]; row0 = pg[i]; }
-                }
-                const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-                const bool need = row0 >= 0 && qvalid && !cannot;
+        for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
 #ifdef ESFM_X1_NOTAIL            // (timing experiments)
-                if (false)
+        for (int r = 0; r < 0; ++r) {
 #else
-                if (need)
+        for (int r = 0; r < K; ++r) {
 #endif
-                    items[j * (2 * K) + n_items++] = ((uint32_t)j << 20) | (uint32_t)row0;      // (need is a prefix: the slots fill in rank order)
-            }
-        }
-        // exclusive prefix sum of the item counts over the 32 queries (lanes 0..31; lanes 32..63 carry zeros)
-        int incl = n_items;
+            const int want = 2 * r + h;
+            float key = kBig; int row0 = -1;
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        const int total = __shfl(incl, 31);
-        const int excl = incl - n_items;
-        if (h == 0) {           // this query's running best two: empty
-            res[j * 6 + 0] = FLT_MAX; res[j * 6 + 1] = FLT_MAX; res[j * 6 + 2] = 0.f; res[j * 6 + 3] = 0.f;
-            res[j * 6 + 4] = __int_as_float(-1); res[j * 6 + 5] = __int_as_float(-1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (wave-private LDS tables: no barrier, the wave runs in lockstep)
-        for (int base = 0; base < total; base += 64) {
-            // item base + lane: binary search of the owner query in the prefix sums (excl of lane j = first item of query j)
-            const int it = base + lane;
-            const bool ivalid = it < total;
-            int jq = 0;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                const int e = __shfl(excl, jq + o);
-                if (ivalid && e <= it) jq += o;
+            for (int i = 0; i < K; ++i) {
+                if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
+                if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
             }
-            const int first = __shfl(excl, jq);
-            const uint32_t dsc = ivalid ? items[jq * (2 * K) + (it - first)] : 0u;
-            const int row0 = ivalid ? (int)(dsc & 0xFFFFFu) : nt;          // nt: past the descriptor, zeros
-            // sub-round 0: the items' query rows; then GRP sub-rounds of train rows (16 lanes fetch one 256-B row; DMA
-            // instruction i serves the lanes 4 i .. 4 i + 3)
-            const int qsel = ivalid ? qbase + 32 * s + jq : nq;
+            const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
+            const bool need = row0 >= 0 && qvalid && !cannot;
+            if (__ballot(need) == 0ull) break;
+            const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
             int rowsrc[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, qsel) * 256 + (swz[i & 3] & 255);
+            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (swz[i & 3] & 255);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents are in registers
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_q, 0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, row0) * 256 + (swz[i & 3] & 255);
-            float4 qv[16];
-            lds_dma_wait();
-#pragma unroll
-            for (int c = 0; c < 16; ++c) qv[c] = land[lane * 16 + (c ^ (lane & 15))];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
             for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
-            Best lb = {FLT_MAX, FLT_MAX, 0.f, 0.f, -1, -1};
 #pragma unroll
             for (int u = 0; u < GRP; ++u) {
-                float4 ta[16];
+                float4 ra_[16];
                 lds_dma_wait();
 #pragma unroll
-                for (int c = 0; c < 16; ++c) ta[c] = land[lane * 16 + (c ^ (lane & 15))];
+                for (int c = 0; c < 16; ++c) ra_[c] = land[lane * 16 + (c ^ (lane & 15))];
                 if (u + 1 < GRP) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
                 }
-                float2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // l2sqr64_canonical_regs, packed
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float2v av[4] = {{ta[2 * c].x, ta[2 * c].y}, {ta[2 * c].z, ta[2 * c].w}, {ta[2 * c + 1].x, ta[2 * c + 1].y}, {ta[2 * c + 1].z, ta[2 * c + 1].w}};
-                    const float2v qe[4] = {{qv[2 * c].x, qv[2 * c].y}, {qv[2 * c].z, qv[2 * c].w}, {qv[2 * c + 1].x, qv[2 * c + 1].y}, {qv[2 * c + 1].z, qv[2 * c + 1].w}};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float2v d = qe[e] - av[e];
-                        acc[e] = acc[e] + d * d;
-                    }
-                }
-                const float2v s01 = acc[0] + acc[2], s23 = acc[1] + acc[3];
-                const float da = __fadd_rn(__fadd_rn(__fadd_rn(s01.x, s01.y), s23.x), s23.y);
+                const float da = l2sqr64_canonical_regs(qv, ra_);
                 const int ta_ = row0 + u;
-                ins(lb, ivalid && ta_ < nt, sqrt_rn_f32(da), ta_, da);
+                insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
             }
-            // segmented merge: the items of a query sit on neighbouring lanes (at most 2 K of them)
-#pragma unroll
-            for (int o = 1; o < 2 * K; o <<= 1) {
-                const int pj = __shfl_down(ivalid ? jq : -1, o);
-                const float pd0 = __shfl_down(lb.d0, o), pq0 = __shfl_down(lb.q0, o), pd1 = __shfl_down(lb.d1, o), pq1 = __shfl_down(lb.q1, o);
-                const int pi0 = __shfl_down(lb.i0, o), pi1 = __shfl_down(lb.i1, o);
-                const bool same = ivalid && lane + o < 64 && pj == jq;
-                ins(lb, same && pi0 >= 0, pd0, pi0, pq0);
-                ins(lb, same && pi1 >= 0, pd1, pi1, pq1);
-            }
-            const int prevj = __shfl_up(ivalid ? jq : -1, 1);
-            if (ivalid && (lane == 0 || prevj != jq)) {          // the segment's first lane: fold into the query's entry
-                float *e = res + jq * 6;
-                Best rb = {e[0], e[1], e[2], e[3], __float_as_int(e[4]), __float_as_int(e[5])};
-                ins(rb, lb.i0 >= 0, lb.d0, lb.i0, lb.q0);
-                ins(rb, lb.i1 >= 0, lb.d1, lb.i1, lb.q1);
-                e[0] = rb.d0; e[1] = rb.d1; e[2] = rb.q0; e[3] = rb.q1; e[4] = __int_as_float(rb.i0); e[5] = __int_as_float(rb.i1);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        {
+            const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
+            const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
+            insert2(pi0 >= 0, pd0, pi0, pq0);
+            insert2(pi1 >= 0, pd1, pi1, pq1);
         }
         const float tau = fminf(vk[K - 1], pk[K - 1]);
         if (qvalid && h == 0) {
-            const float b0d = res[j * 6 + 0], b1d = res[j * 6 + 1], b1q = res[j * 6 + 3];
-            const int b0i = __float_as_int(res[j * 6 + 4]), b1i = __float_as_int(res[j * 6 + 5]);
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
             knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
             knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
@@ -1219,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 // Work item = (pair, chunk of 32 uncertified queries); the four waves of the workgroup split the train set, fragments straight
 // from the bf16 image in global memory (the pass handles a fraction of a per cent of the queries: latency matters, not reuse).
 // Grid: `per_pair` workgroups per pair, workgroup (p, c) takes the chunks c, c + per_pair, ... of pair p's list.
-__global__ __launch_bounds__(256) void l2_refine_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
+__global__ __launch_bounds__(512) void l2_refine_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
                                                         const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
                                                         const float *__restrict__ rho_t, const float *__restrict__ rho_q,
                                                         const PairDesc *__restrict__ pairs, int per_pair,
@@ -1233,7 +1152,8 @@ __global__ __launch_bounds__(256) void l2_refine_kernel(const float *__restrict_
     __shared__ int s_nhit;
     __shared__ int s_hq[CAP], s_ht[CAP];
     __shared__ float s_hd[CAP], s_hd2[CAP];
-    __shared__ float s_red[8];
+    constexpr int NW = 8;                 // waves per workgroup (256 registers each): the train set is split NW ways (the pass is a latency chain per wave)
+    __shared__ float s_red[2 * NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     // (chunk-major numbering: the workgroups that usually have work -- chunk 0 of every pair -- are consecutive, hence spread over
     // the XCDs; pair-major put every one of them on XCD 0: 0.42 ms instead of 0.0x)
@@ -1245,20 +1165,22 @@ __global__ __launch_bounds__(256) void l2_refine_kernel(const float *__restrict_
     if (c0 * 32 >= cnt) return;
     const float *__restrict__ tn = norms + pd.t_row0;
     const float *__restrict__ tr = rho_t + pd.t_row0;
-    const u32x4 *__restrict__ ht = hi_t + (size_t)pd.t_row0 * HS;
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(hi_t + (size_t)pd.t_row0 * HS), 0, nt * (HS * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tn), 0, nt * 4, 0x00020000);
     {   // max |t|^2 and max rho_t over the train set
         float m = 0.f, r = 0.f;
-        for (int t = tid; t < nt; t += 256) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
+        for (int t = tid; t < nt; t += 64 * NW) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
-        if (lane == 0) { s_red[wave] = m; s_red[4 + wave] = r; }
+        if (lane == 0) { s_red[wave] = m; s_red[NW + wave] = r; }
     }
     __syncthreads();
-    const float tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const float rmax = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    float tmax = 0.f, rmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { tmax = fmaxf(tmax, s_red[w]); rmax = fmaxf(rmax, s_red[NW + w]); }
     // this wave's share of the train set, in steps of 32 rows
     const int nsteps = (nt + 31) / 32;
-    const int st0 = (nsteps * wave) / 4, st1 = (nsteps * (wave + 1)) / 4;
+    const int st0 = (nsteps * wave) / NW, st1 = (nsteps * (wave + 1)) / NW;
     for (int c = c0; c * 32 < cnt; c += per_pair) {
         if (tid == 0) s_nhit = 0;
         const int slot = c * 32 + j;
@@ -1283,43 +1205,69 @@ __global__ __launch_bounds__(256) void l2_refine_kernel(const float *__restrict_
             bq[ks] = __builtin_bit_cast(bf16x8, v);
         }
         __syncthreads();
+        // Branch-free loads through buffer descriptors (rows past nt read as zeros; their norms become kBig), the next step's
+        // eight loads in flight during this step's MFMAs.  (The first version guarded every load with `row < nt`: hipcc turned
+        // each into a branch and waited for every fragment before its MFMA -- 6.5 us per step, 52 us per chunk.)
+        auto load_step = [&](int st, u32x4 (&a)[4], u32x4 (&nv)[4]) {
+            const int voff = (st * 32 + j) * (HS * 16) + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, voff + 32 * ks, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nv[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (st * 32 + 8 * g + 4 * h) * 4, 0, 0);
+        };
+        u32x4 fa[4], fn[4];
+        if (st0 < st1) load_step(st0, fa, fn);
         for (int st = st0; st < st1; ++st) {
-            const int row = st * 32 + j;
+            u32x4 ca[4], cn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ca[k] = fa[k]; cn[k] = fn[k]; }
+            if (st + 1 < st1) load_step(st + 1, fa, fn);
             floatx16 acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = st * 32 + 8 * g + 4 * h + u;
-                    acc[4 * g + u] = t < nt ? tn[t] : kBig;
-                }
+                for (int u = 0; u < 4; ++u) acc[4 * g + u] = (st * 32 + 8 * g + 4 * h + u) < nt ? __uint_as_float(cn[g][u]) : kBig;
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const u32x4 a = row < nt ? ht[(size_t)row * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bq[ks], acc, 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca[ks]), bq[ks], acc, 0, 0, 0);
             float m = kBig;
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fminf(m, acc[r]);       // (fminf drops NaN scores: never neighbours)
-            if (__ballot(m <= thr) != 0ull) {
+            if (__ballot(m <= thr) != 0ull) {       // (true in most steps: some query of the chunk has a row under its threshold)
+                uint32_t mask = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int t = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (acc[r] <= thr && t < nt) {
-                        const int k = atomicAdd(&s_nhit, 1);
-                        if (k < CAP) { s_hq[k] = j; s_ht[k] = t; }
+                    mask |= (acc[r] <= thr && t < nt) ? (1u << r) : 0u;
+                }
+                if (mask) {                         // one atomic per lane with hits, then its slots in order
+                    int k = atomicAdd(&s_nhit, __popc(mask));
+                    while (mask) {
+                        const int r = __ffs(mask) - 1;
+                        mask &= mask - 1;
+                        if (k < CAP) { s_hq[k] = j; s_ht[k] = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
+                        ++k;
                     }
                 }
             }
         }
         __syncthreads();
+#ifdef ESFM_REFINE_NOHITS
+        const int nhit = 0;
+#else
         const int nhit = s_nhit;
+#endif
         if (nhit <= CAP) {
             // exact distances of the hits, the oracle's order
-            for (int k = tid; k < nhit; k += 256) {
+            for (int k = tid; k < nhit; k += 64 * NW) {
                 const int qr = in_list[pd.out_off + c * 32 + s_hq[k]];
-                const float d2 = l2sqr_canonical<true>(desc + ((size_t)pd.q_row0 + qr) * 64, desc + ((size_t)pd.t_row0 + s_ht[k]) * 64, 64);
+                const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + qr) * 64);
+                const float4 *tp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.t_row0 + s_ht[k]) * 64);
+                float4 qa[16], tb[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { qa[c] = qp[c]; tb[c] = tp[c]; }
+                const float d2 = l2sqr64_canonical_regs(qa, tb);
                 s_hd2[k] = d2; s_hd[k] = sqrt_rn_f32(d2);
             }
             __syncthreads();
@@ -2034,8 +1982,7 @@ int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long
                          int32_t *pair_cnt, int32_t *pair_list, float *knn_d2)
 {
     if (n_blocks <= 0) return ESFM_OK;
-    // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions, the tail's item tables and result entries
-    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32 + 4 * (32 * 2 * ESFM_L2X1_KEEP) * 4 + 4 * (32 * 6) * 4;
+    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
@@ -2059,7 +2006,7 @@ int launch_l2_refine(hipStream_t st, const float *desc, const void *hi, long lon
     // a handful of workgroups per pair (a workgroup without work leaves after one load), about 4096 in all
     const int per_pair = std::max(1, std::min(8, 4096 / n_pairs));
     void *h = const_cast<void *>(hi);
-    hipLaunchKernelGGL(l2_refine_kernel, dim3((unsigned)n_pairs * (unsigned)per_pair), dim3(256), 0, st, desc,
+    hipLaunchKernelGGL(l2_refine_kernel, dim3((unsigned)n_pairs * (unsigned)per_pair), dim3(512), 0, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
                        pairs, per_pair, in_cnt, in_list, knn_d2, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
