@@ -18,8 +18,8 @@ from .types import Frame, SparsePointCloud
 
 
 # Bytes per observation the Jacobian sweep (ba_linearize_kernel) is BUILT to move: 16 in (cam / point index, uv) + Jc 96 + Jp 48 +
-# res 16 + W = F'E 144 out.  SURVEY 8(d)'s compulsory figure (no W) is 176; bench.py prices the kernel on that one.
-BA_SWEEP_BYTES_PER_OBS = 320
+# res 16 out = SURVEY 8(d)'s compulsory 176 (round 2 also wrote W = F'E, 144 B more; round 3 re-forms it in the Schur kernels).
+BA_SWEEP_BYTES_PER_OBS = 176
 
 
 def ba_sweep_bytes_per_obs() -> int:

@@ -216,7 +216,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     A(&d.lo_c, nc6); A(&d.up_c, nc6); A(&d.delta_c, nc6); A(&d.delta_p, np3);
     A(&d.cam_nobs, (size_t)n_cam);
     A(&d.x_c, nc6); A(&d.x_p, np3); A(&d.cand_c, nc6); A(&d.cand_p, np3); A(&d.x0_p, np3);
-    A(&d.Jc, 12 * no); A(&d.Jp, 6 * no); A(&d.res, 2 * no); A(&d.W, 18 * no);
+    A(&d.Jc, 12 * no); A(&d.Jp, 6 * no); A(&d.res, 2 * no);
     A(&d.scale_c, nc6); A(&d.scale_p, np3);
     A(&d.EtE, (size_t)6 * n_pt); A(&d.Etr, np3); A(&d.Minv, (size_t)6 * n_pt); A(&d.Aig, np3);
     A(&d.camacc, esfm::ba_camacc_doubles(n_cam)); A(&d.red, esfm::ba_red_doubles(n_cam));

@@ -238,6 +238,23 @@ __device__ __forceinline__ void reproject_jac(const double cam[6], const double 
     xn = x; yn = y;
 }
 
+// W_i = F_i'E_i (6 x 3, row-major) of observation i, re-formed from its 18 Jacobian entries.  (Round 2 had the sweep store W -- 144 B
+// per observation -- and the Schur kernels load it: as many loads here, 36 multiply-adds less.  Measured in round 3: without the
+// store the sweep of BA-512 takes 262 us instead of 369, the Schur kernels 927 against 928 us; BA-25 29.2 against 30.7 and 41.5
+// against 40.6 us.  The array is gone: 432 MB less written per sweep at BA-512, 912 MB -> 480 MB of linearisation resident.)
+__device__ __forceinline__ void load_W(const BADev &d, size_t n_obs, int i, double W[18])
+{
+    double Jc[12], Jp[6];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) Jc[q] = d.Jc[q * n_obs + i];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Jp[q] = d.Jp[q * n_obs + i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) W[3 * a + m] = Jc[a] * Jp[m] + Jc[6 + a] * Jp[3 + m];
+}
+
 // e with sqrt(diag(F'F)_i) < 2^e (BADev::qexp)
 __device__ __forceinline__ int qexp_of(double diag)
 {
@@ -257,6 +274,11 @@ __device__ __forceinline__ int qexp_of(double diag)
 // then  sum_k f_a f_b <= sqrt(n_c m[c][a]) sqrt(n_c m[c][b]) < 2^(ex[c][a] + ex[c][b])  bounds every partial sum and pass 2 re-reads
 // the workgroup's own Jacobian rows (L2) and adds round(v 2^(60 - ex[c][a] - ex[c][b])).
 // !PRIV: the sweep only; ba_camacc_chunk_kernel then forms the sums by gathering each camera's observations in order.
+// (Round 3, BA-25, one observation per thread: the kernel takes 29 - 31 us whether it writes 160 or 304 B per observation, re-reads
+// its rows in pass 2 or keeps them in registers, shares one set of LDS sums per workgroup or keeps one per wave -- every variant
+// measured.  It is one dependent chain per workgroup: index load -> parameter gather -> sincos / divide in f64 -> stores -> LDS
+// maxima -> barrier -> exponents -> barrier -> 27 LDS adds -> barrier -> slab.  43 MB in 30 us is 0.18 of the HBM roofline and
+// not what limits it.)
 constexpr int kLinThreads = 512;
 constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
 
@@ -279,6 +301,11 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
     }
     double cost = 0.0, bad = 0.0;
     double kacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // PRIV, at most one observation per thread (the grid covers the observations: BA-25): pass 2 quantises the rows from REGISTERS
+    // instead of re-reading the thread's own stores (112 B per observation fetched back: 33 MB of the 108 MB the kernel moved)
+    const bool single = PRIV && (long long)gridDim.x * kLinThreads >= n_obs;
+    double keepJ[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, keepR0 = 0.0, keepR1 = 0.0;
+    int keepC = -1;
     for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
         const int c = d.obs_cam[k], p = d.obs_pt[k];
         const float2 uv = d.obs_uv[k];
@@ -344,16 +371,16 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.Jp[(size_t)i * n_obs + k] = Jp[i];
         d.res[k] = r0; d.res[(size_t)n_obs + k] = r1;
-        // W_k = F_k'E_k (6 x 3): what the Schur complement needs of this observation -- W_i M^-1 W_j' per pair of a point's observations
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) d.W[(size_t)(3 * a + m) * n_obs + k] = Jc[a] * Jp[m] + Jc[6 + a] * Jp[3 + m];
         if (PRIV) {
             atomicAdd(&cnt[c], 1);
 #pragma unroll
             for (int a = 0; a < 6; ++a) atomicMax(&mx[c * 7 + a], (unsigned long long)__double_as_longlong(Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]));
             atomicMax(&mx[c * 7 + 6], (unsigned long long)__double_as_longlong(r0 * r0 + r1 * r1));
+            if (single) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) keepJ[i] = Jc[i];
+                keepR0 = r0; keepR1 = r1; keepC = c;
+            }
         }
     }
     {
@@ -376,11 +403,18 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
     }
     __syncthreads();
     for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
-        const int c = d.obs_cam[k];
-        double J[12];
+        int c;
+        double J[12], r0, r1;
+        if (single) {
+            c = keepC; r0 = keepR0; r1 = keepR1;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) J[i] = d.Jc[(size_t)i * n_obs + k];    // this thread's own stores
-        const double r0 = d.res[k], r1 = d.res[(size_t)n_obs + k];
+            for (int i = 0; i < 12; ++i) J[i] = keepJ[i];
+        } else {
+            c = d.obs_cam[k];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) J[i] = d.Jc[(size_t)i * n_obs + k];    // this thread's own stores
+            r0 = d.res[k]; r1 = d.res[(size_t)n_obs + k];
+        }
         // every factor carries 2^(30 - exponent of its column): the products are scaled by 2^(60 - ex[a] - ex[b]) exactly
 #pragma unroll
         for (int a = 0; a < 6; ++a) { const int sh = kFxBits / 2 - ex[c * 7 + a]; J[a] = ldexp(J[a], sh); J[6 + a] = ldexp(J[6 + a], sh); }
@@ -826,8 +860,7 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp, con
     const int n = 6 * d.n_cam;
     const int p = d.obs_pt[i], ci = d.obs_cam[i];
     double W[18];
-#pragma unroll
-    for (int q = 0; q < 18; ++q) W[q] = d.W[q * n_obs + i];
+    load_W(d, n_obs, i, W);
     const double *Mi = d.Minv + 6 * (size_t)p;
     const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
     const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
@@ -849,8 +882,7 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BADev d, int rhs_exp, con
         const int j = b + q;
         const int cj = d.obs_cam[j];
         double Wj[18];
-#pragma unroll
-        for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
+        load_W(d, n_obs, j, Wj);
         const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
         double *Sb = d.red + (size_t)(6 * hi) * n + 6 * lo;
         if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : n, cj > ci ? n : 1, Y, Wj, d.qexp + 6 * cj);
@@ -878,8 +910,7 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
     for (int i = blockIdx.x * blockDim.x + tid; i < d.n_obs; i += gridDim.x * blockDim.x) {
         const int p = d.obs_pt[i], ci = d.obs_cam[i];
         double W[18];
-#pragma unroll
-        for (int q = 0; q < 18; ++q) W[q] = d.W[q * n_obs + i];
+        load_W(d, n_obs, i, W);
         const double *Mi = d.Minv + 6 * (size_t)p;
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
         const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
@@ -904,8 +935,7 @@ __global__ __launch_bounds__(1024) void ba_schur_lds_kernel(BADev d, double *__r
             const int j = b + q;
             const int cj = d.obs_cam[j];
             double Wj[18];
-#pragma unroll
-            for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
+            load_W(d, n_obs, j, Wj);
             const int hi = cj > ci ? cj : ci, lo = cj > ci ? ci : cj;
             double *Sb = sl + (size_t)(hi * (hi + 1) / 2 + lo) * kSchurPitch;
             if (cj != ci) schur_pair<false>(Sb, cj > ci ? 1 : 6, cj > ci ? 6 : 1, Y, Wj, qe + 6 * cj);
@@ -947,8 +977,7 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
         const int i = slot_obs[s];
         const int p = d.obs_pt[i], ci = d.obs_cam[i];
         double W[18];
-#pragma unroll
-        for (int q = 0; q < 18; ++q) W[q] = d.W[q * n_obs + i];
+        load_W(d, n_obs, i, W);
         const double *Mi = d.Minv + 6 * (size_t)p;
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
         const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
@@ -977,8 +1006,7 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
             const int j = b + q;
             const int cj = d.obs_cam[j];
             double Wj[18];
-#pragma unroll
-            for (int u = 0; u < 18; ++u) Wj[u] = d.W[u * n_obs + j];
+            load_W(d, n_obs, j, Wj);
             const int wj = rotated(cj) - cw;
             const bool in_w = in_i && wj >= 0 && wj < kWinCams;
             // (two call sites on purpose: with the address space known the window gets ds_add_u64; one merged pointer made every

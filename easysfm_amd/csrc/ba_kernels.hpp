@@ -55,7 +55,6 @@ struct BADev {
     double *Jc = nullptr;   // 12 arrays: row 0 cols 0..5, then row 1 cols 0..5
     double *Jp = nullptr;   // 6 arrays: row 0 cols 0..2, row 1 cols 0..2
     double *res = nullptr;  // 2 arrays
-    double *W = nullptr;    // 18 arrays: F'E (6 x 3, row-major), written by the Jacobian sweep for the Schur complement
     double *Jk = nullptr;   // has_calib, 4 arrays: d r0/d fx, d r0/d cx, d r1/d fy, d r1/d cy (the other four are 0)
     double *lo_c = nullptr, *up_c = nullptr;          // box bounds [6 n_cam]
     double *delta_c = nullptr, *delta_p = nullptr;    // the LM step in parameter units, [6 n_cam], [3 n_pt]
