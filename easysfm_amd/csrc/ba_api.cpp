@@ -257,6 +257,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     // camera count, takes the tracks that are only narrow there (the seam of a closed camera loop); what is wide in both
     // index spaces goes to the plain kernel.
     std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0, slot_obs_b, chunk_slot_b, chunk_cam0_b, wide_obs;
+    std::vector<int32_t> mslot_obs[2], mbatch_slot[2], mchunk_batch0[2], mchunk_cam0[2];
     if (d.slab_cap == 0 && n_obs > 0) {
         const int rot = n_real / 2;
         auto rotated = [&](int c) { const int r = c + rot; return r >= n_real ? r - n_real : r; };
@@ -267,9 +268,50 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
             lo_a[p] = std::min(lo_a[p], c); hi_a[p] = std::max(hi_a[p], c);
             lo_b[p] = std::min(lo_b[p], cr); hi_b[p] = std::max(hi_b[p], cr);
         }
+        // Narrow tracks -- at most kSchurMfCams camera indices wide, no camera twice -- take the matrix-core kernel: per point the
+        // Schur update is the rank-3 product (W M^-1) W' over its cameras' rows, a small dense GEMM once points with the same
+        // cameras are processed together.
+        std::vector<int32_t> mperm[2];
+        std::vector<char> taken((size_t)n_pt, 0);
+        for (int p = 0; p < n_pt; ++p) {
+            const int b = pt_start[(size_t)p], e = pt_start[(size_t)p + 1];
+            if (e <= b || e - b > esfm::kSchurMfCams) continue;
+            bool dup = false;
+            for (int t = b; t < e && !dup; ++t) for (int u = b; u < t; ++u) if (s_cam[(size_t)t] == s_cam[(size_t)u]) { dup = true; break; }
+            if (dup) continue;
+            if (hi_a[(size_t)p] - lo_a[(size_t)p] < esfm::kSchurMfCams) { mperm[0].push_back(p); taken[(size_t)p] = 1; }
+            else if (hi_b[(size_t)p] - lo_b[(size_t)p] < esfm::kSchurMfCams) { mperm[1].push_back(p); taken[(size_t)p] = 1; }
+        }
+        for (int tb = 0; tb < 2; ++tb) {
+            std::vector<int32_t> &perm = mperm[tb];
+            const std::vector<int32_t> &lo = tb ? lo_b : lo_a, &hi = tb ? hi_b : hi_a;
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lo[(size_t)a] < lo[(size_t)b]; });
+            int64_t total = 0;
+            for (int p : perm) total += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+            const int64_t per = std::max<int64_t>(512, (total + 2 * ctx->num_cu - 1) / (2 * ctx->num_cu));
+            int64_t in_chunk = 0; int cw = 0, in_batch = 0, pts_batch = 0;
+            for (int p : perm) {
+                const int t = pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+                const bool new_chunk = mchunk_cam0[tb].empty() || in_chunk >= per || hi[(size_t)p] - cw >= esfm::kSchurMfCams;
+                if (new_chunk) {
+                    mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size());
+                    mchunk_cam0[tb].push_back(lo[(size_t)p]); cw = lo[(size_t)p]; in_chunk = 0;
+                }
+                if (new_chunk || in_batch + t > 64 || pts_batch >= 16) { mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size()); in_batch = 0; pts_batch = 0; }
+                for (int k = pt_start[(size_t)p]; k < pt_start[(size_t)p + 1]; ++k) mslot_obs[tb].push_back(k);
+                in_batch += t; ++pts_batch; in_chunk += t;
+            }
+            mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size());
+            mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size() - 1);
+            d.n_mchunks[tb] = (int)mchunk_cam0[tb].size();
+            if (d.n_mchunks[tb]) {
+                A(&d.mslot_obs[tb], mslot_obs[tb].size()); A(&d.mbatch_slot[tb], mbatch_slot[tb].size());
+                A(&d.mchunk_batch0[tb], mchunk_batch0[tb].size()); A(&d.mchunk_cam0[tb], mchunk_cam0[tb].size());
+            }
+        }
         std::vector<int32_t> perm_a, perm_b;
         for (int p = 0; p < n_pt; ++p) {
-            if (pt_start[(size_t)p + 1] <= pt_start[(size_t)p]) continue;
+            if (pt_start[(size_t)p + 1] <= pt_start[(size_t)p] || taken[(size_t)p]) continue;
             if (hi_a[(size_t)p] - lo_a[(size_t)p] < esfm::kSchurWinCams) perm_a.push_back(p);
             else if (hi_b[(size_t)p] - lo_b[(size_t)p] < esfm::kSchurWinCams) perm_b.push_back(p);
             else for (int t = pt_start[(size_t)p]; t < pt_start[(size_t)p + 1]; ++t) wide_obs.push_back(t);
@@ -333,7 +375,14 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         up(d.slot_obs, slot_obs.data(), sizeof(int32_t) * slot_obs.size());
         up(d.chunk_slot, chunk_slot.data(), sizeof(int32_t) * chunk_slot.size());
         up(d.chunk_cam0, chunk_cam0.data(), sizeof(int32_t) * chunk_cam0.size());
-        up(d.wide_obs, wide_obs.data(), sizeof(int32_t) * wide_obs.size());
+    }
+    if (d.n_wide_obs) up(d.wide_obs, wide_obs.data(), sizeof(int32_t) * wide_obs.size());
+    for (int tb = 0; tb < 2; ++tb) {
+        if (!d.n_mchunks[tb]) continue;
+        up(d.mslot_obs[tb], mslot_obs[tb].data(), sizeof(int32_t) * mslot_obs[tb].size());
+        up(d.mbatch_slot[tb], mbatch_slot[tb].data(), sizeof(int32_t) * mbatch_slot[tb].size());
+        up(d.mchunk_batch0[tb], mchunk_batch0[tb].data(), sizeof(int32_t) * mchunk_batch0[tb].size());
+        up(d.mchunk_cam0[tb], mchunk_cam0[tb].data(), sizeof(int32_t) * mchunk_cam0[tb].size());
     }
     if (d.n_chunks_b) {
         up(d.slot_obs_b, slot_obs_b.data(), sizeof(int32_t) * slot_obs_b.size());

@@ -1047,6 +1047,150 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Point-block Schur complement on the f64 matrix cores (round 3).  For one point p with observations i = 1..T,
+//     sum over the pairs (i, j) of p of  -Y_i W_j'  =  -(Yhat_p)(What_p)',      Yhat_p = [Y_i]_i (6 T x 3),  Y_i = W_i M_p^-1,
+// a rank-3 update of the rows / columns of p's cameras -- and the sum over the points of a chunk whose cameras lie in one window of
+// kSchurMfCams indices is a dense product  G = sum_p Yw_p Ww_p'  (80 x 80, rows = 6 (camera - window base) + a), symmetric because
+// M^-1 is.  ba_schur_window_kernel adds the 36 entries of every pair with 64-bit LDS atomics, and consecutive points see the same
+// cameras: up to 64 lanes on one address, 0.93 ms per pass over BA-512 (25 x what conflict-free LDS adds would take).  Here a wave
+// takes a batch of whole points (<= 64 observations, one per lane): the lanes form W_i and Y_i of their observation (the same loads
+// and arithmetic as the atomic kernels) and park them in a wave-private LDS table; then point by point the 16-row operand
+// fragments are gathered from that table (a lane's row belongs to one camera slot: looked up in the point's slot -> lane table,
+// zero if the point does not see it) and the lower block triangle of G is accumulated with v_mfma_f64_16x16x4_f64 -- K = 4 = the
+// three columns of a point and a zero -- in registers for the whole chunk.  No atomics until the end: the four waves' tiles are
+// added in wave order through LDS and the chunk's G goes into d.red as fixed-point integers like every other contribution (one
+// atomic per entry and chunk), so the result does not depend on how workgroups are scheduled.
+// Points with a camera twice, or spanning more than kSchurMfCams indices in both numberings, stay with the atomic kernels.
+constexpr int kMfRows = 80, kMfBR = 5, kMfYPitch = 37, kMfMaxPts = 16;
+constexpr int kMfWaveDoubles = 64 * kMfYPitch + kMfMaxPts * 16 / 2;     // Y | W table (36 doubles per observation, pitch 37) + slot -> lane table (ints)
+constexpr size_t kMfLdsBytes = sizeof(double) * (4 * kMfWaveDoubles + 6 * kSchurMfCams);
+static_assert(4 * kMfWaveDoubles >= kMfRows * (kMfRows + 1), "the staging area is reused for the 80 x 81 result");
+
+__global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs,
+                                                               const int32_t *__restrict__ batch_slot, const int32_t *__restrict__ chunk_batch0,
+                                                               const int32_t *__restrict__ chunk_cam0, int rot)
+{
+    typedef double doublex4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) double sl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *Yw = sl + (size_t)wave * kMfWaveDoubles;                               // [64][kMfYPitch]
+    int *s2o = reinterpret_cast<int *>(Yw + 64 * kMfYPitch);                       // [kMfMaxPts][16]: camera slot -> lane of the point's observation
+    unsigned long long *srhs = reinterpret_cast<unsigned long long *>(sl + 4 * (size_t)kMfWaveDoubles);   // [6 * kSchurMfCams]
+    const int n = 6 * d.n_cam, nrc = d.n_real_cam;
+    const size_t n_obs = d.n_obs;
+    const int chunk = blockIdx.x;
+    const int cw = chunk_cam0[chunk];
+    const int b0 = chunk_batch0[chunk], b1 = chunk_batch0[chunk + 1];
+    auto rotated = [&](int c) { const int r = c + rot; return r >= nrc ? r - nrc : r; };
+    for (int e = tid; e < 6 * kSchurMfCams; e += 256) srhs[e] = 0ull;
+    __syncthreads();
+    doublex4 acc[kMfBR * (kMfBR + 1) / 2];
+#pragma unroll
+    for (int t = 0; t < kMfBR * (kMfBR + 1) / 2; ++t) acc[t] = doublex4{0.0, 0.0, 0.0, 0.0};
+    const int r16 = lane & 15, m4 = lane >> 4;          // this lane's row inside a block row, and its K index (point column; 3 = zero)
+    for (int b = b0 + wave; b < b1; b += 4) {
+        const int s0 = batch_slot[b], nob = batch_slot[b + 1] - s0;
+        const bool valid = lane < nob;
+        const int i = slot_obs[s0 + (valid ? lane : 0)];
+        const int p = d.obs_pt[i], ci = d.obs_cam[i];
+        const int slot = rotated(ci) - cw;                                          // 0 .. kSchurMfCams - 1 by construction
+        // local index of the lane's point inside the batch (the batch is whole points, in order)
+        const int pprev = __shfl_up(p, 1);
+        const unsigned long long starts = __ballot(valid && (lane == 0 || pprev != p));
+        const int q = __popcll(starts & ((2ull << lane) - 1ull)) - 1;
+        const int npts = __popcll(starts);
+        for (int e = lane; e < kMfMaxPts * 16; e += 64) s2o[e] = -1;
+        double W[18];
+        load_W(d, n_obs, i, W);
+        const double *Mi = d.Minv + 6 * (size_t)p;
+        const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
+        const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double w0 = W[3 * a], w1 = W[3 * a + 1], w2 = W[3 * a + 2];
+                const int ei = kFxBits - d.qexp[6 * ci + a];
+                atomicAdd(&srhs[6 * slot + a], fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei - rhs_exp));
+                double *y = Yw + lane * kMfYPitch + 3 * a;
+                y[0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
+                y[1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
+                y[2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
+                y[18] = w0; y[19] = w1; y[20] = w2;
+            }
+            s2o[q * 16 + slot] = lane;
+        }
+        // block rows the batch touches (wave-uniform)
+        int smin = valid ? slot : kSchurMfCams, smax = valid ? slot : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { smin = min(smin, __shfl_xor(smin, o)); smax = max(smax, __shfl_xor(smax, o)); }
+        const int R0 = __builtin_amdgcn_readfirstlane((6 * smin) / 16), R1 = __builtin_amdgcn_readfirstlane((6 * smax + 5) / 16);
+        // (the wave's own LDS writes are visible to its later reads: DS operations of a wave execute in order)
+        for (int pq = 0; pq < npts; ++pq) {
+            double fa[kMfBR], fb[kMfBR];
+#pragma unroll
+            for (int R = 0; R < kMfBR; ++R) {
+                const int row = 16 * R + r16, sc = row / 6, a = row - 6 * sc;
+                const int o = (sc < kSchurMfCams && m4 < 3 && R >= R0 && R <= R1) ? s2o[pq * 16 + sc] : -1;
+                const double *y = Yw + (o >= 0 ? o : 0) * kMfYPitch + 3 * a + (m4 < 3 ? m4 : 0);
+                fa[R] = o >= 0 ? y[0] : 0.0;
+                fb[R] = o >= 0 ? y[18] : 0.0;
+            }
+#pragma unroll
+            for (int R = 0; R < kMfBR; ++R) {
+                if (R < R0 || R > R1) continue;
+#pragma unroll
+                for (int C = 0; C <= R; ++C) {
+                    if (C < R0) continue;
+                    acc[R * (R + 1) / 2 + C] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[R], fb[C], acc[R * (R + 1) / 2 + C], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the table has been read before the next batch overwrites it
+    }
+    // the chunk's G: the waves' tiles added in wave order (fixed), lower block triangle, in the staging area
+    __syncthreads();
+    double *G = sl;                                // [kMfRows][kMfRows + 1]
+    for (int e = tid; e < kMfRows * (kMfRows + 1); e += 256) G[e] = 0.0;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int R = 0; R < kMfBR; ++R)
+#pragma unroll
+                for (int C = 0; C <= R; ++C)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) G[(16 * R + m4 + 4 * g) * (kMfRows + 1) + 16 * C + r16] += acc[R * (R + 1) / 2 + C][g];
+        }
+        __syncthreads();
+    }
+    // S -= G on the entry's fixed-point grid.  Window order (row >= col) is not camera order once the indices are rotated: the stored
+    // triangle wants row camera >= column camera in TRUE indices, a diagonal camera block in full.
+    auto true_cam = [&](int w) { int c = cw + w - rot; if (c < 0) c += nrc; return c; };
+    unsigned long long *redq = reinterpret_cast<unsigned long long *>(d.red);
+    for (int e = tid; e < kMfRows * kMfRows; e += 256) {
+        const int row = e / kMfRows, col = e - row * kMfRows;
+        if (col > row) continue;
+        const int si = row / 6, a = row - 6 * si, sj = col / 6, b2 = col - 6 * sj;
+        if (si >= kSchurMfCams) continue;
+        const double v = G[row * (kMfRows + 1) + col];
+        if (v == 0.0) continue;
+        const int ci = true_cam(si), cj = true_cam(sj);
+        if (ci >= nrc || cj >= nrc) continue;
+        const int ri = 6 * ci + a, rj = 6 * cj + b2;
+        const unsigned long long qv = fx64(-v, kFxBits - d.qexp[ri] - d.qexp[rj]);
+        if (ci > cj) atomicAdd(&redq[(size_t)ri * n + rj], qv);
+        else if (ci < cj) atomicAdd(&redq[(size_t)rj * n + ri], qv);
+        else { atomicAdd(&redq[(size_t)ri * n + rj], qv); if (a != b2) atomicAdd(&redq[(size_t)rj * n + ri], qv); }
+    }
+    for (int e = tid; e < 6 * kSchurMfCams; e += 256) {
+        const unsigned long long v = srhs[e];
+        if (v == 0ull) continue;
+        const int c = true_cam(e / 6);
+        if (c < nrc) atomicAdd(&redq[(size_t)n * n + 6 * c + e % 6], v);
+    }
+}
+
 // Free intrinsics: the block row of the reduced system that belongs to fx, cx, fy, cy (block index n_real_cam).
 // One thread per point p.  With G_i the intrinsics columns of observation i (2 x 4, two non-zeros per row),
 //   Wk_p = sum_i G_i'E_i (4x3), Yk = Wk_p M^-1:
@@ -1880,12 +2024,24 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         LAUNCH_CHECK();
         return ESFM_OK;
     }
-    if (d.n_chunks > 0 && d.slot_obs) {
+    const bool tables = d.n_mchunks[0] + d.n_mchunks[1] + d.n_chunks + d.n_chunks_b + d.n_wide_obs > 0;
+    if (tables) {
+        // narrow tracks (nearly all of them in a sequence capture): the matrix-core kernel, plain and rotated camera numbering
+        for (int tb = 0; tb < 2; ++tb) {
+            if (d.n_mchunks[tb] <= 0) continue;
+            ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLdsBytes));
+            hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(d.n_mchunks[tb]), dim3(256), kMfLdsBytes, st, d, rhs_exp, d.mslot_obs[tb], d.mbatch_slot[tb],
+                               d.mchunk_batch0[tb], d.mchunk_cam0[tb], tb ? d.n_real_cam / 2 : 0);
+            LAUNCH_CHECK();
+        }
         constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * kSchurPitch + 6 * kWinCams);
-        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_window_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
-        hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d, rhs_exp, d.slot_obs, d.chunk_slot, d.chunk_cam0, 0);
-        LAUNCH_CHECK();
+        if (d.n_chunks > 0 || d.n_chunks_b > 0)
+            ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_window_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+        if (d.n_chunks > 0) {
+            hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks), dim3(1024), win_bytes, st, d, rhs_exp, d.slot_obs, d.chunk_slot, d.chunk_cam0, 0);
+            LAUNCH_CHECK();
+        }
         if (d.n_chunks_b > 0) {        // the tracks that are narrow once the camera indices are rotated by half the loop
             hipLaunchKernelGGL(ba_schur_window_kernel, dim3(d.n_chunks_b), dim3(1024), win_bytes, st, d, rhs_exp, d.slot_obs_b, d.chunk_slot_b, d.chunk_cam0_b,
                                d.n_real_cam / 2);

@@ -84,6 +84,14 @@ struct BADev {
     int n_chunks_b = 0;
     int32_t *wide_obs = nullptr;    // [n_wide_obs] observations of the points whose cameras span kSchurWinCams or more (not in slot_obs)
     int n_wide_obs = 0;
+    // matrix-core Schur (ba_schur_mfma_kernel): the points whose cameras span at most kSchurMfCams indices (plain or rotated by half
+    // the camera count: tables [0] and [1]), ordered by lowest camera and cut into chunks with one window base; a chunk's
+    // observations in batches of whole points, <= 64 observations and <= 16 points each
+    int n_mchunks[2] = {0, 0};
+    int32_t *mslot_obs[2] = {nullptr, nullptr};      // observation indices in chunk / batch order
+    int32_t *mbatch_slot[2] = {nullptr, nullptr};    // [n_batches + 1] first slot of each batch
+    int32_t *mchunk_batch0[2] = {nullptr, nullptr};  // [n_mchunks + 1] first batch of each chunk
+    int32_t *mchunk_cam0[2] = {nullptr, nullptr};    // [n_mchunks] window base (rotated index for table 1)
     // per-camera sums F'F / F'r of LARGE camera counts (the small ones are summed inside the sweep, see ba_linearize_kernel): the observations of every camera in ascending order (cam_obs, a CSR over
     // cameras built once per problem), cut into chunks of kCamChunk; one wave sums a chunk in a fixed order, a second
     // launch adds a camera's chunk sums in order.  Bit-reproducible whatever the launch timing.
@@ -114,6 +122,7 @@ struct BADev {
 constexpr int kCamChunk = 256, kCamPart = 37;
 constexpr int kPtChunkObs = 256;               // observations per point chunk (back-substitution, per-point normal blocks)
 constexpr int kSchurWinCams = 28;              // cameras in the windowed Schur kernel's LDS window
+constexpr int kSchurMfCams = 13;               // cameras in the matrix-core Schur kernel's window (80 rows = 5 MFMA block rows)
 
 inline size_t ba_camacc_doubles(int n_cam) { return (size_t)42 * (size_t)n_cam; }
 inline size_t ba_red_doubles(int n_cam) { const size_t n = 6 * (size_t)n_cam; return n * n + n; }
