@@ -1060,11 +1060,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         lds_dma_wait();
 #pragma unroll
         for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
-#ifdef ESFM_X1_NOTAIL            // (timing experiments)
-        for (int r = 0; r < 0; ++r) {
-#else
         for (int r = 0; r < K; ++r) {
-#endif
             const int want = 2 * r + h;
             float key = kBig; int row0 = -1;
 #pragma unroll
@@ -1253,11 +1249,7 @@ __global__ __launch_bounds__(512) void l2_refine_kernel(const float *__restrict_
             }
         }
         __syncthreads();
-#ifdef ESFM_REFINE_NOHITS
-        const int nhit = 0;
-#else
         const int nhit = s_nhit;
-#endif
         if (nhit <= CAP) {
             // exact distances of the hits, the oracle's order
             for (int k = tid; k < nhit; k += 64 * NW) {
