@@ -12,9 +12,10 @@ Differences from gen_l2_segment_asm.py (the three-product pass, which now only s
     front of the MFMA that overwrote it: no overlap at all, fold and matrix time simply added up -- 0.47 + 0.21 = 0.68 ms);
   * the train image is bf16(t) only: 128-B rows, 16-B slot 2 ks + h holds a lane's A fragment of K-step ks; in LDS slot s of row r
     sits at physical slot s ^ ((r >> 1) & 7) -- every 16-lane group of a ds_read_b128 then covers the 64 banks exactly once;
-  * a RING of four 16-KiB tile buffers: the LDS-DMA of tile t + 4 is issued when tile t hands its buffer over and has three tiles'
-    time to land; a tile's |t|^2 travel through one VGPR per ring slot and are written to LDS -- kBig for rows past nt -- at the
-    hand-over that publishes the tile;
+  * a RING of tile buffers, 64 KiB in all: the LDS-DMA of tile t + RING is issued when tile t hands its buffer over; a tile's |t|^2
+    travel through one VGPR per ring slot and are written to LDS -- kBig for rows past nt -- at the hand-over that publishes the
+    tile.  Shipped: two tiles of 256 rows (one hand-over -- drain of the LDS queue, barrier, nine transfers to issue -- per 128
+    MFMA slots; four tiles of 128 rows, measured on the same box: 0.91 - 0.92 ms against 0.89);
   * the A fragments are prefetched a whole 32-train step ahead (two register sets of four fragments);
   * a 13-bit position code (11 bits step, 2 bits group) in the low mantissa bits of a group key instead of 8: no segments, no
     master list -- the keys the block ends with name their rows directly.  The coarser keys (2^-10 relative) are noise next to
@@ -58,8 +59,14 @@ NS = 4
 CODE_BITS = 13
 KBIG = 0x7F61B1E6          # 3.0e38f
 NKBIG = 0xFF61B1E6
-TT, ROW_BYTES, RING = 128, 128, 4
-TILE_BYTES = TT * ROW_BYTES          # 16 KiB
+TT = int(os.environ.get("ESFM_GEN_TT", "256"))            # train rows per tile (128 or 256)
+RING = int(os.environ.get("ESFM_GEN_RING", "2"))          # tile buffers (TT * RING = 512: 64 KiB of LDS)
+ROW_BYTES = 128
+assert TT in (128, 256) and TT * RING == 512
+STEPS = TT // 32                      # 32-train steps per tile
+NP = TT // 32                         # LDS-DMA pieces (8 rows = 1 KiB) per wave and tile
+WROWS = TT // 4                       # rows of a tile staged by one wave
+TILE_BYTES = TT * ROW_BYTES          # 16 / 32 KiB
 NORM_BASE = RING * TILE_BYTES        # the ring's norms sit behind the tiles: RING x TT floats
 assert 3 <= KEEP <= 6
 
@@ -110,8 +117,9 @@ def gen():
     e(f"v_lshlrev_b32 v{N_ADDR}, 4, v{SCR + 2}")
     e(f"v_add_u32 v{N_ADDR}, {OP_LDS}, v{N_ADDR}")
     e(f"v_add_u32 v{N_ADDR}, {NORM_BASE}, v{N_ADDR}")         # n_addr = lds_norm + 16 h
-    # LDS-DMA source offsets: wave w stages rows [32 w, 32 w + 32) of a tile, 8 rows (1 KiB) per instruction
-    e(f"s_lshl_b32 s48, {OP_WAVE}, 5")
+    # LDS-DMA source offsets: wave w stages rows [WROWS w, WROWS (w + 1)) of a tile, 8 rows (1 KiB) per instruction; pieces i and
+    # i + 4 share the swizzle (32 rows apart) and the register
+    e(f"s_mul_i32 s48, {OP_WAVE}, {WROWS}")
     e(f"v_lshrrev_b32 v{SCR + 1}, 3, v{SCR}")                 # lane >> 3
     e(f"v_and_b32 v{SCR + 3}, 7, v{SCR}")                     # lane & 7: physical slot
     for i in range(4):
@@ -121,8 +129,8 @@ def gen():
         e(f"v_xor_b32 v{FTMP + 1}, v{FTMP + 1}, v{SCR + 3}")  # logical slot fetched into this physical slot
         e(f"v_lshlrev_b32 v{FTMP + 1}, 4, v{FTMP + 1}")
         e(f"v_lshl_add_u32 v{DMA_OFF + i}, v{FTMP}, 7, v{FTMP + 1}")
-    # norms: lane l of wave w moves |t|^2 of row 32 w + (l & 31) (both halves of the wave the same row: no masking needed)
-    e(f"v_and_b32 v{FTMP}, 31, v{SCR}")
+    # norms: lane l of wave w moves |t|^2 of row WROWS w + (l & (WROWS - 1)) (lanes that share a row move the same value)
+    e(f"v_and_b32 v{FTMP}, {WROWS - 1}, v{SCR}")
     e(f"v_add_u32 v{FTMP}, s48, v{FTMP}")                     # row in the tile
     e(f"v_lshlrev_b32 v{NSRC_OFF}, 2, v{FTMP}")               # byte offset inside a tile's norms
     e(f"v_add_u32 v{NLDS}, {OP_LDS}, v{NSRC_OFF}")
@@ -194,7 +202,7 @@ def gen():
             if not NOMFMA:
                 a = accr(s, spar)
                 e(f"v_mfma_f32_32x32x16_bf16 {a}, {fr(ks, par)}, {OP_B(s, ks)}, {'v[96:111]' if ks == 0 else a}")
-            if 4 <= slot <= 8 and extra:
+            if slot >= 4 and extra:
                 for x in extra.pop(0):
                     e(x)
             which, fs, fg = GAP[slot]
@@ -210,23 +218,26 @@ def gen():
         assert not extra
 
     def dma_piece(i, buf):
-        return [f"s_add_u32 s50, s49, {buf * TILE_BYTES + i * 1024}",
-                "s_mov_b32 m0, s50",
-                f"buffer_load_dwordx4 v{DMA_OFF + i}, {OP_TRSRC}, s48 offen lds"]
+        out = [f"s_add_u32 s50, s49, {buf * TILE_BYTES + i * 1024}",
+               "s_mov_b32 m0, s50"]
+        if i >= 4:
+            out.append(f"s_add_u32 s50, s48, {(i >> 2) * 32 * ROW_BYTES}")
+        out.append(f"buffer_load_dwordx4 v{DMA_OFF + (i & 3)}, {OP_TRSRC}, {'s50' if i >= 4 else 's48'} offen lds")
+        return out
 
     def tile(buf, tag):
         nb = (buf + 1) % RING
-        for st in range(3):
+        for st in range(STEPS - 1):
             step(st & 1, st & 1, buf, st + 1)
-        # ---- step 3: hand-over first
+        # ---- last step: hand-over first
         e("s_waitcnt lgkmcnt(0)")                               # every read of this tile has landed
-        e("s_waitcnt vmcnt(8)")                                 # this wave's transfers of tile + 1 have landed (tile + 2, + 3 may fly;
-        #                                                         8, not 10: the caller's first three tiles are 4 transfers each)
+        e(f"s_waitcnt vmcnt({(RING - 2) * NP})")               # this wave's transfers of tile + 1 have landed (younger tiles may fly;
+        #                                                         counted in pieces only: the caller's first tiles come without norm loads)
         # norms of tile + 1 -> LDS, rows past nt as kBig (the first RING tiles' norms were written by the caller)
         e(f"s_cmp_lt_u32 s40, {RING - 1}")
         e(f"s_cbranch_scc1 L_nonorm_{tag}_%=")
         e("s_add_u32 s48, s40, 1")
-        e("s_lshl_b32 s48, s48, 7")
+        e(f"s_mul_i32 s48, s48, {TT}")
         e(f"v_lshrrev_b32 v{SCR}, 2, v{NSRC_OFF}")
         e(f"v_add_u32 v{SCR}, s48, v{SCR}")                    # train row of this lane's norm
         e(f"v_cmp_gt_u32 vcc, {OP_NT}, v{SCR}")
@@ -236,13 +247,13 @@ def gen():
         e("s_waitcnt lgkmcnt(0)")
         e(f"L_nonorm_{tag}_%=:")
         e("s_barrier")
-        e("s_add_u32 s48, s40, 4")
-        e("s_lshl_b32 s51, s48, 9")                             # (tile + 4) * 128 * 4
-        e("s_lshl_b32 s48, s48, 14")                            # (tile + 4) * 128 rows * 128 B
-        e(f"s_lshl_b32 s49, {OP_WAVE}, 12")                     # wave * 32 rows * 128 B
+        e(f"s_add_u32 s48, s40, {RING}")
+        e(f"s_mul_i32 s51, s48, {TT * 4}")                      # (tile + RING) * TT * 4: its norms
+        e(f"s_mul_i32 s48, s48, {TILE_BYTES}")                  # ... its rows
+        e(f"s_mul_i32 s49, {OP_WAVE}, {WROWS * ROW_BYTES}")     # this wave's rows inside a tile
         e(f"s_add_u32 s49, s49, {OP_LDS}")
         # (a tile that does not exist reads zeros through the descriptors into a buffer nobody reads again: unconditional)
-        pcs = [[f"buffer_load_dword {NR(buf)}, v{NSRC_OFF}, {OP_NRSRC}, s51 offen"]] + [dma_piece(i, buf) for i in range(4)]
+        pcs = [[f"buffer_load_dword {NR(buf)}, v{NSRC_OFF}, {OP_NRSRC}, s51 offen"]] + [dma_piece(i, buf) for i in range(NP)]
         step(1, 1, nb, 0, extra=pcs)
         e("s_add_u32 s40, s40, 1")
 
@@ -287,6 +298,8 @@ def main():
            f"#define ESFM_L2X1_KEEP {KEEP}",
            f"#define ESFM_L2X1_SETS {NS}",
            f"#define ESFM_L2X1_CODE_BITS {CODE_BITS}",
+           f"#define ESFM_L2X1_TT {TT}",
+           f"#define ESFM_L2X1_RING {RING}",
            "#define ESFM_L2X1_SEGMENT_ASM \\"]
     for l in lines:
         out.append(f'    "{l}\\n" \\')

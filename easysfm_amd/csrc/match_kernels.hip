@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                                                                int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
                                                                float *__restrict__ knn_d2)
 {
-    constexpr int TT = 128, NS = ESFM_L2X1_SETS, GRP = 4, K = ESFM_L2X1_KEEP, RING = 4;
+    constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, GRP = 4, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
     constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
     constexpr int TILE_BYTES = TT * HS * 16;
     static_assert(NS == 4, "operand list below is written for four query sets");
@@ -934,10 +934,10 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     // row l >> 3, physical slot l & 7, which holds logical slot (l & 7) ^ ((row >> 1) & 7) (the asm's reads use the same map)
     auto dma_tile = [&](int tile, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave_s * 32 + 8 * i + (lane >> 3);
+        for (int i = 0; i < TT / 32; ++i) {
+            const int row = wave_s * (TT / 4) + 8 * i + (lane >> 3);
             const int voff = row * (HS * 16) + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
-            lds_dma_b128(lds_tile_addr + (uint32_t)(buf * TILE_BYTES + (wave_s * 32 + 8 * i) * (HS * 16)), voff, trsrc, tile * TILE_BYTES);
+            lds_dma_b128(lds_tile_addr + (uint32_t)(buf * TILE_BYTES + (wave_s * (TT / 4) + 8 * i) * (HS * 16)), voff, trsrc, tile * TILE_BYTES);
         }
     };
     // Uninitialised LDS under rows that are never transferred (past nt in the last tile) must at least not hold huge finite values
@@ -971,11 +971,12 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
         if (lane == 0) { lds_red[wave] = m; lds_red[4 + wave] = r; }
     }
-    // the ring's first four tiles (a tile that does not exist reads zeros through the descriptor); tile 0 must have landed
-    // before the main loop starts -- the three younger transfers (12 pieces) may stay in flight
+    // the ring's first tiles (a tile that does not exist reads zeros through the descriptor); tile 0 must have landed
+    // before the main loop starts -- the younger transfers may stay in flight
     dma_tile(0, 0);
-    dma_tile(1, 1); dma_tile(2, 2); dma_tile(3, 3);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#pragma unroll
+    for (int b = 1; b < RING; ++b) dma_tile(b, b);
+    if (RING == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (RING - 1) tiles of TT / 32 pieces
     __syncthreads();
 
     if (ntiles > 0) {
