@@ -1064,8 +1064,9 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
 // Points with a camera twice, or spanning more than kSchurMfCams indices in both numberings, stay with the atomic kernels.
 // Measured on BA-512 (3 M observations, 512 chunks): 276 us for the plain numbering + 50 us for the seam's rotated table, against
 // 856 + 45 us of the atomic window kernel; with the matrix products AND the flush compiled out the launch still takes ~180 us --
-// what is left is the gather of the Jacobian rows (432 MB in chunk order = points sorted by lowest camera, 80-B runs per array)
-// at ~2.4 TB/s.  Issuing a batch's loads one batch ahead changed nothing (345 against 341 us): the bytes, not the latency.
+// what is left is the lanes' own loads and arithmetic (432 MB of Jacobian rows, the point blocks, 36 LDS stores per lane).  Issuing a
+// batch's loads one batch ahead changed nothing (345 against 341 us, 47 spilled registers) and neither did a scene whose points are
+// numbered by lowest camera, i.e. contiguous reads (465 against 487 us on a slower box: the kernel also varies 340 - 490 us box to box).
 constexpr int kMfRows = 80, kMfBR = 5, kMfYPitch = 37, kMfMaxPts = 16;
 constexpr int kMfWaveDoubles = 64 * kMfYPitch + kMfMaxPts * 16 / 2;     // Y | W table (36 doubles per observation, pitch 37) + slot -> lane table (ints)
 constexpr size_t kMfLdsBytes = sizeof(double) * (4 * kMfWaveDoubles + 6 * kSchurMfCams);
@@ -1093,35 +1094,11 @@ __global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_
 #pragma unroll
     for (int t = 0; t < kMfBR * (kMfBR + 1) / 2; ++t) acc[t] = doublex4{0.0, 0.0, 0.0, 0.0};
     const int r16 = lane & 15, m4 = lane >> 4;          // this lane's row inside a block row, and its K index (point column; 3 = zero)
-    // A batch's loads (observation index -> point / camera -> Jacobian rows, point block, exponents: three dependent round trips to
-    // memory, the Jacobian rows from HBM) are issued one batch AHEAD, so that they fly during the previous batch's arithmetic: with
-    // 256 registers a CU holds eight of these waves and nothing else hides the latency (12 us per batch without, measured).
-    struct Pre { int i, p, ci, nob; double Jc[12], Jp[6], Mi[6], ag[3]; int qe[6]; };
-    auto load_pre = [&](int b, Pre &x) {
-        if (b >= b1) { x.nob = 0; return; }
-        const int s0 = batch_slot[b];
-        x.nob = batch_slot[b + 1] - s0;
-        x.i = slot_obs[s0 + (lane < x.nob ? lane : 0)];
-        x.p = d.obs_pt[x.i]; x.ci = d.obs_cam[x.i];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) x.Jc[q] = d.Jc[q * n_obs + x.i];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) x.Jp[q] = d.Jp[q * n_obs + x.i];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) x.Mi[q] = d.Minv[6 * (size_t)x.p + q];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) x.ag[q] = d.Aig[3 * (size_t)x.p + q];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) x.qe[q] = d.qexp[6 * x.ci + q];
-    };
-    Pre pre;
-    load_pre(b0 + wave, pre);
     for (int b = b0 + wave; b < b1; b += 4) {
-        const Pre cur = pre;
-        load_pre(b + 4, pre);
-        const int nob = cur.nob;
+        const int s0 = batch_slot[b], nob = batch_slot[b + 1] - s0;
         const bool valid = lane < nob;
-        const int p = cur.p, ci = cur.ci;
+        const int i = slot_obs[s0 + (valid ? lane : 0)];
+        const int p = d.obs_pt[i], ci = d.obs_cam[i];
         const int slot = rotated(ci) - cw;                                          // 0 .. kSchurMfCams - 1 by construction
         // local index of the lane's point inside the batch (the batch is whole points, in order)
         const int pprev = __shfl_up(p, 1);
@@ -1129,14 +1106,17 @@ __global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_
         const int q = __popcll(starts & ((2ull << lane) - 1ull)) - 1;
         const int npts = __popcll(starts);
         for (int e = lane; e < kMfMaxPts * 16; e += 64) s2o[e] = -1;
-        const double M[9] = {cur.Mi[0], cur.Mi[1], cur.Mi[2], cur.Mi[1], cur.Mi[3], cur.Mi[4], cur.Mi[2], cur.Mi[4], cur.Mi[5]};
+        double W[18];
+        load_W(d, n_obs, i, W);
+        const double *Mi = d.Minv + 6 * (size_t)p;
+        const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
+        const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
         if (valid) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-                const double w0 = cur.Jc[a] * cur.Jp[0] + cur.Jc[6 + a] * cur.Jp[3], w1 = cur.Jc[a] * cur.Jp[1] + cur.Jc[6 + a] * cur.Jp[4],
-                             w2 = cur.Jc[a] * cur.Jp[2] + cur.Jc[6 + a] * cur.Jp[5];          // W_i = F_i'E_i (load_W)
-                const int ei = kFxBits - cur.qe[a];
-                atomicAdd(&srhs[6 * slot + a], fx64(-(w0 * cur.ag[0] + w1 * cur.ag[1] + w2 * cur.ag[2]), ei - rhs_exp));
+                const double w0 = W[3 * a], w1 = W[3 * a + 1], w2 = W[3 * a + 2];
+                const int ei = kFxBits - d.qexp[6 * ci + a];
+                atomicAdd(&srhs[6 * slot + a], fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei - rhs_exp));
                 double *y = Yw + lane * kMfYPitch + 3 * a;
                 y[0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
                 y[1] = w0 * M[1] + w1 * M[4] + w2 * M[7];
