@@ -257,7 +257,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     // camera count, takes the tracks that are only narrow there (the seam of a closed camera loop); what is wide in both
     // index spaces goes to the plain kernel.
     std::vector<int32_t> slot_obs, chunk_slot, chunk_cam0, slot_obs_b, chunk_slot_b, chunk_cam0_b, wide_obs;
-    std::vector<int32_t> mslot_obs[2], mbatch_slot[2], mchunk_batch0[2], mchunk_cam0[2];
+    std::vector<int32_t> mslot_obs[2], mslot_pc[2], mbatch_slot[2], mchunk_batch0[2], mchunk_cam0[2];
     if (d.slab_cap == 0 && n_obs > 0) {
         const int rot = n_real / 2;
         auto rotated = [&](int c) { const int r = c + rot; return r >= n_real ? r - n_real : r; };
@@ -305,6 +305,11 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
             mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size() - 1);
             d.n_mchunks[tb] = (int)mchunk_cam0[tb].size();
             if (d.n_mchunks[tb]) {
+                mslot_pc[tb].resize(2 * mslot_obs[tb].size());
+                for (size_t k = 0; k < mslot_obs[tb].size(); ++k) {
+                    mslot_pc[tb][2 * k] = s_pt[(size_t)mslot_obs[tb][k]]; mslot_pc[tb][2 * k + 1] = s_cam[(size_t)mslot_obs[tb][k]];
+                }
+                A(&d.mslot_pc[tb], mslot_pc[tb].size());
                 A(&d.mslot_obs[tb], mslot_obs[tb].size()); A(&d.mbatch_slot[tb], mbatch_slot[tb].size());
                 A(&d.mchunk_batch0[tb], mchunk_batch0[tb].size()); A(&d.mchunk_cam0[tb], mchunk_cam0[tb].size());
             }
@@ -380,6 +385,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     for (int tb = 0; tb < 2; ++tb) {
         if (!d.n_mchunks[tb]) continue;
         up(d.mslot_obs[tb], mslot_obs[tb].data(), sizeof(int32_t) * mslot_obs[tb].size());
+        up(d.mslot_pc[tb], mslot_pc[tb].data(), sizeof(int32_t) * mslot_pc[tb].size());
         up(d.mbatch_slot[tb], mbatch_slot[tb].data(), sizeof(int32_t) * mbatch_slot[tb].size());
         up(d.mchunk_batch0[tb], mchunk_batch0[tb].data(), sizeof(int32_t) * mchunk_batch0[tb].size());
         up(d.mchunk_cam0[tb], mchunk_cam0[tb].data(), sizeof(int32_t) * mchunk_cam0[tb].size());

@@ -1072,7 +1072,7 @@ constexpr int kMfWaveDoubles = 64 * kMfYPitch + kMfMaxPts * 16 / 2;     // Y | W
 constexpr size_t kMfLdsBytes = sizeof(double) * (4 * kMfWaveDoubles + 6 * kSchurMfCams);
 static_assert(4 * kMfWaveDoubles >= kMfRows * (kMfRows + 1), "the staging area is reused for the 80 x 81 result");
 
-__global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs,
+__global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs, const int2 *__restrict__ slot_pc,
                                                                const int32_t *__restrict__ batch_slot, const int32_t *__restrict__ chunk_batch0,
                                                                const int32_t *__restrict__ chunk_cam0, int rot)
 {
@@ -1094,11 +1094,23 @@ __global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_
 #pragma unroll
     for (int t = 0; t < kMfBR * (kMfBR + 1) / 2; ++t) acc[t] = doublex4{0.0, 0.0, 0.0, 0.0};
     const int r16 = lane & 15, m4 = lane >> 4;          // this lane's row inside a block row, and its K index (point column; 3 = zero)
+    // A lane's observation, point and camera come from slot-ordered tables (contiguous, one load level) and are fetched one batch
+    // AHEAD: the Jacobian rows / point block / exponents they address can then be requested the moment a batch starts -- one
+    // round trip to memory per batch where the chain  slot -> observation -> point, camera -> rows  made three (8 us per batch).
+    int nx_i = 0, nx_nob = 0; int2 nx_pc = make_int2(0, 0);
+    auto fetch_ids = [&](int b) {
+        if (b >= b1) { nx_nob = 0; return; }
+        const int s0 = batch_slot[b];
+        nx_nob = batch_slot[b + 1] - s0;
+        const int sl_ = s0 + (lane < nx_nob ? lane : 0);
+        nx_i = slot_obs[sl_]; nx_pc = slot_pc[sl_];
+    };
+    fetch_ids(b0 + wave);
     for (int b = b0 + wave; b < b1; b += 4) {
-        const int s0 = batch_slot[b], nob = batch_slot[b + 1] - s0;
+        const int nob = nx_nob;
         const bool valid = lane < nob;
-        const int i = slot_obs[s0 + (valid ? lane : 0)];
-        const int p = d.obs_pt[i], ci = d.obs_cam[i];
+        const int i = nx_i, p = nx_pc.x, ci = nx_pc.y;
+        fetch_ids(b + 4);
         const int slot = rotated(ci) - cw;                                          // 0 .. kSchurMfCams - 1 by construction
         // local index of the lane's point inside the batch (the batch is whole points, in order)
         const int pprev = __shfl_up(p, 1);
@@ -2035,7 +2047,8 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         for (int tb = 0; tb < 2; ++tb) {
             if (d.n_mchunks[tb] <= 0) continue;
             ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLdsBytes));
-            hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(d.n_mchunks[tb]), dim3(256), kMfLdsBytes, st, d, rhs_exp, d.mslot_obs[tb], d.mbatch_slot[tb],
+            hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(d.n_mchunks[tb]), dim3(256), kMfLdsBytes, st, d, rhs_exp, d.mslot_obs[tb],
+                               reinterpret_cast<const int2 *>(d.mslot_pc[tb]), d.mbatch_slot[tb],
                                d.mchunk_batch0[tb], d.mchunk_cam0[tb], tb ? d.n_real_cam / 2 : 0);
             LAUNCH_CHECK();
         }

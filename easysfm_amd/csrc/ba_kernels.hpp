@@ -89,6 +89,7 @@ struct BADev {
     // observations in batches of whole points, <= 64 observations and <= 16 points each
     int n_mchunks[2] = {0, 0};
     int32_t *mslot_obs[2] = {nullptr, nullptr};      // observation indices in chunk / batch order
+    int32_t *mslot_pc[2] = {nullptr, nullptr};       // [2 x slots] the observation's point and camera (one dependent load less per batch)
     int32_t *mbatch_slot[2] = {nullptr, nullptr};    // [n_batches + 1] first slot of each batch
     int32_t *mchunk_batch0[2] = {nullptr, nullptr};  // [n_mchunks + 1] first batch of each chunk
     int32_t *mchunk_cam0[2] = {nullptr, nullptr};    // [n_mchunks] window base (rotated index for table 1)
