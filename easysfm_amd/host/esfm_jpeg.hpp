@@ -193,6 +193,7 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
                 if ((nc != 1 && nc != 3) || dl < 6 + (size_t)3 * nc) return path + ": only 1- or 3-component JPEGs are supported";
                 if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || (uint64_t)width * height > (1ull << 28)) return path + ": implausible JPEG dimensions";
                 comp.assign((size_t)nc, Component());
+                hmax = vmax = 1;                                   // (a second SOF starts over)
                 for (int c = 0; c < nc; ++c) {
                     comp[c].id = d[6 + 3 * c]; comp[c].h = d[7 + 3 * c] >> 4; comp[c].v = d[7 + 3 * c] & 15; comp[c].tq = d[8 + 3 * c];
                     if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) return path + ": unsupported sampling factors";
@@ -250,8 +251,14 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
                                     const int t = decode_symbol(br, dc[c.td]);
                                     if (t < 0 || t > 15) return path + ": bad DC code";
                                     const int diff = t ? extend(br.get_bits(t), t) : 0;
-                                    c.pred += diff;
-                                    coef[0] = c.pred * qt[c.tq][0];
+                                    // (a crafted stream can run the predictor or a dequantised coefficient out of int: libjpeg bounds
+                                    // coefficients to 16 bits after dequantisation; anything beyond 2^15 * 255 is rejected here)
+                                    const long long pred = (long long)c.pred + diff;
+                                    if (pred < -(1 << 20) || pred > (1 << 20)) return path + ": DC predictor out of range";
+                                    c.pred = (int)pred;
+                                    const long long dcq = pred * (long long)qt[c.tq][0];
+                                    if (dcq < -8355840LL || dcq > 8355840LL) return path + ": coefficient out of range";
+                                    coef[0] = (int)dcq;
                                     for (int k = 1; k < 64;) {
                                         const int rs = decode_symbol(br, ac[c.ta]);
                                         if (rs < 0) return path + ": bad AC code";
@@ -259,7 +266,9 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
                                         if (s == 0) { if (r == 15) { k += 16; continue; } break; }
                                         k += r;
                                         if (k > 63) return path + ": AC run past the block";
-                                        coef[zz[k]] = extend(br.get_bits(s), s) * qt[c.tq][zz[k]];
+                                        const long long acq = (long long)extend(br.get_bits(s), s) * (long long)qt[c.tq][zz[k]];
+                                        if (acq < -8355840LL || acq > 8355840LL) return path + ": coefficient out of range";
+                                        coef[zz[k]] = (int)acq;
                                         ++k;
                                     }
                                     const int px = (mx * c.h + bx) * 8, py = (my * c.v + by) * 8;
@@ -305,7 +314,7 @@ inline std::string read_bgr(const std::string &path, int &rows, int &cols, std::
                         else if (x == 0) v = (t * 4 + 8) >> 4;
                         else if (x == 2 * c.dw - 1) v = (t * 4 + 7) >> 4;
                         else v = (x & 1) ? (t * 3 + colsum(i + 1) + 7) >> 4 : (t * 3 + colsum(i - 1) + 8) >> 4;
-                    } else v = S(y / vs, x / hs);          // h1v2: replication
+                    } else v = S(y / vs, x / hs);          // h1v2: replication (libjpeg-turbo has a triangle filter for this rare layout too: such files are NOT bit-identical to cv::imread)
                     o[(size_t)y * cols + x] = (uint8_t)v;
                 }
         }
