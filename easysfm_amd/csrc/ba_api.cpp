@@ -139,11 +139,11 @@ struct Solver {
         return ESFM_OK;
     }
     // residuals + Jacobian at x, per-camera sums, per-point blocks; leaves cost/gmax in h[].
-    int linearize(bool use_scaling, double radius)
+    int linearize(bool use_scaling, double radius, double cost_bound = -1.0)
     {
         const BADev &d = P->d;
         int deferred = 0;      // one rank: the slab reduction of the sweep's per-camera sums rides in the per-point launch
-        if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling, P->ctx, ar ? nullptr : &deferred)) return rc;
+        if (int rc = esfm::ba_linearize(st, d, P->ctx->num_cu, opt.cauchy_a, use_scaling, P->ctx, ar ? nullptr : &deferred, cost_bound)) return rc;
         if (int rc = allreduce(d.camacc, (int64_t)esfm::ba_camacc_doubles(d.n_cam), ESFM_REDUCE_SUM)) return rc;
         if (int rc = esfm::ba_point_prep(st, d, radius, opt.min_lm_diagonal, opt.max_lm_diagonal, true, deferred)) return rc;
         return ESFM_OK;
@@ -790,7 +790,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             radius = std::min(opt.max_trust_region_radius, radius);
             decrease_factor = 2.0; reuse_diagonal = false;
             if (int rc = S.zero_scal()) return finish(rc);
-            if (int rc = S.linearize(opt.jacobi_scaling != 0, radius)) return finish(rc);
+            if (int rc = S.linearize(opt.jacobi_scaling != 0, radius, cand_cost < DBL_MAX ? cand_cost * (1.0 + 1e-9) : -1.0)) return finish(rc);
             prep_radius = radius;
             if (int rc = esfm::ba_camera_gradient(st, d)) return finish(rc);
             if (may_defer && iter < opt.max_num_iterations && radius > opt.min_trust_region_radius) {

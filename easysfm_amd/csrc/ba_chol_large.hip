@@ -5,7 +5,7 @@
 // whole chip, the right-hand side carried as an extra block row (forward substitution for free), then the backward substitution.
 //   chol_assemble_kernel   W = F'F + D_c^2 + S_schur (lower), rhs row = F'r + rhs_corr, identity padding
 //   chol2_step_kernel(k)   ONE launch per block column: trailing update C_ij -= X_ik X_jk' on v_mfma_f64_16x16x4_f64; its first
-//                          workgroup factors the next diagonal tile (tile_potrf64) and inverts the factor (inv64); the workgroups
+//                          workgroup factors the next diagonal tile and inverts the factor (tile_potrf64_inv); the workgroups
 //                          of the next block column wait for that inverse and turn their tiles into factor tiles X_i,k+1
 //   chol2_back_kernel      the whole backward substitution in one launch, solution blocks handed on through flags in memory
 // n <= 176 (BASELINE's BA-25: n = 150): ba_chol_small_kernel, the whole solve and the camera step in one workgroup.
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
 // 64 x 64 tile kernels built from 16 x 16 sub-blocks on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
 // A[l & 15][l >> 4] and B[l >> 4][l & 15]; its four results are D[(l >> 4) + 4 g][l & 15]).
 //   pqt16 / pq16:      acc += sign * P Q' / P Q  for 16 x 16 row-major blocks in LDS  -- 4 MFMAs
-//   tile_potrf64:      4 sub-block steps: potrf16_fused_full, panel X = A Linv' (MFMA), trailing update (MFMA)
-//   inv64:             the inverse of the factored tile from its sub-block inverses
+//   tile_potrf64_inv:  4 sub-block steps: potrf16_fused_full, panel X = A Linv' (MFMA), trailing update (MFMA); the inverse of the
+//                      factored tile from its sub-block inverses alongside
 // History of the diagonal-block factorisation, per 16 x 16 block: 256 threads out of LDS between barriers (round 1): 11 us; one
 // wave, block in registers, v_readlane broadcasts, factor then invert: 4 us; one pass of scheduled asm with DPP broadcasts: 1.5 us.
 constexpr int SB = 16;                  // sub-block edge
@@ -107,26 +107,69 @@ __device__ __forceinline__ void potrf16_fused_full(double *D, int ldd, double *V
     if (__any(bad) && lane == 0) *fail = 1;
 }
 
-// 256 threads: in-place Cholesky of the 64 x 64 tile T (LDS, row-major ULD; upper part must be zero).  Vi: 4 blocks of
-// 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.  Sub-block column b: panel X_i = A_i Linv_bb'
-// (waves b+1 .. 3), then the trailing update -- during which wave 0 updates sub-block (b+1, b+1) first and factors it at once
-// (look-ahead: the next pivot chain runs while the other waves finish the update); two barriers per sub-block column.
-__device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, int *fail)
+// ---------------------------------------------------------------------------------------------
+// Second generation of the large solve (this round): ONE launch per block column and ONE for the whole backward substitution.
+//   * the workgroup that factors a diagonal tile also inverts the factor (tile_potrf64_inv: the four 16 x 16 sub-block inverses are there
+//     already; the six blocks below them are products), so "X_ik = A_ik L_kk^-T" is a dense product with L_kk^-1 and needs no
+//     triangular sweep -- every trailing-update workgroup forms the X_ik, X_jk it needs itself (3 tile products instead of 1:
+//     the matrix cores are idle anyway, the launch and the sweep were what cost 11 us per block column);
+//   * the factor tiles X_ik go to a second matrix W2 (the update workgroups of the same launch still read A_ik from W);
+//   * the backward substitution is one launch of nb workgroups that hand the solution blocks on through flags in memory:
+//     workgroup b folds  z_b -= L_ib' y_i  for i = nb-1 .. b+1 as the y_i appear, then publishes  y_b = L_bb^-T z_b.
+//     Workgroup b has blockIdx nb-1-b: it only ever waits for workgroups dispatched before it, so the chain cannot deadlock
+//     whatever part of the grid is resident.  (48 launches of 16 us before.)
+__device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp, const double *Q, int ldq, double sign, int lane)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (wave == 0) potrf16_fused_full(T, ULD, Vi, rd, fail, lane);
+    // acc += sign * P (16 x 16 row-major) * Q (16 x 16 row-major)
+    const double *pp = P + (lane & 15) * ldp + (lane >> 4), *qp = Q + (lane >> 4) * ldq + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * pp[4 * kk], qp[4 * kk * ldq], acc, 0, 0, 0);
+    return acc;
+}
+
+// 256 threads: in-place Cholesky of the 64 x 64 tile T (LDS, row-major ULD; upper part must be zero) AND the inverse of the factor
+// in O (LDS, ULD).  Vi: 4 blocks of 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.
+// Factorisation, sub-block column b: panel X_i = A_i Linv_bb' (waves b+1 .. 3), then the trailing update -- during which wave 0
+// updates sub-block (b+1, b+1) first and factors it at once (look-ahead: the next pivot chain runs while the other waves finish the
+// update); two barriers per sub-block column.
+// Inverse:  O_jj = Vi_j,  O_ij = -Vi_i S_ij,  S_ij = sum_{m=j}^{i-1} L_im O_mj  for i > j.  Block column jc is wave jc + 1's, and its
+// rows are formed IN THE SHADOW of wave 0's pivot chains instead of after them: while wave 0 factors sub-block b + 1 (potrf16: ~1.6
+// us, nothing for the others to do once their few trailing blocks are updated), wave jc + 1 finishes row b of its column and sums
+// S_b+1,jc -- every operand is final by then: Vi_b since the barrier before the window, L_b+1,m since this step's panel.  After the
+// last pivot chain one product per wave is left (O_3,jc = -Vi_3 S_3,jc).  S_ij is parked in O_ij's own place (no scratch: 9 KB of
+// LDS less is what lets two workgroups share a CU).  (Until round 3 the inverse was a pass of its own after the factorisation:
+// 2.8 us of the block column's critical chain, now 0.4.)
+__device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *Vi, double *rd, int *fail)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jc = wave - 1;
+    auto copy_vi = [&](int b) {                          // O_bb = Vi_b
+        for (int e = lane; e < SB * SB; e += 64) O[(SB * b + e / SB) * ULD + SB * b + e % SB] = Vi[b * SB * VLD + (e / SB) * VLD + e % SB];
+    };
+    auto finish_row = [&](int b) {                       // O_b,jc = -Vi_b S_b,jc  (jc < b; S is parked in O_b,jc's place)
+        double *Obj = O + (SB * b) * ULD + SB * jc;
+        const doublex4 acc = pq16(doublex4{0.0, 0.0, 0.0, 0.0}, Vi + b * SB * VLD, VLD, Obj, ULD, -1.0, lane);
+        __builtin_amdgcn_wave_barrier();
+        store_d16(Obj, ULD, acc, lane);
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (wave == 0) {
+        potrf16_fused_full(T, ULD, Vi, rd, fail, lane);
+    } else {
+        // zeros above the diagonal blocks: block column jc (rows < 16 jc), and wave 1 also takes block column 3
+        for (int e = lane; e < SB * jc * SB; e += 64) O[(e / SB) * ULD + SB * jc + e % SB] = 0.0;
+        if (wave == 1) for (int e = lane; e < SB * 3 * SB; e += 64) O[(e / SB) * ULD + SB * 3 + e % SB] = 0.0;
+    }
     __syncthreads();
 #pragma unroll 1
     for (int b = 0; b < 3; ++b) {
-        // panel: strips i = b+1 .. 3:  X_i = A_i Linv_bb^T   (A_i is read whole before it is overwritten: one wave per strip)
-        if (wave > b) {
+        if (wave > b) {                                  // panel: strip i = wave (A_i is read whole before it is overwritten)
             const int i = wave;
             doublex4 acc = pqt16(doublex4{0.0, 0.0, 0.0, 0.0}, T + (SB * i) * ULD + SB * b, ULD, Vi + b * SB * VLD, VLD, 1.0, lane);
             __builtin_amdgcn_wave_barrier();
             store_d16(T + (SB * i) * ULD + SB * b, ULD, acc, lane);
         }
         __syncthreads();
-        // trailing update: blocks (i, j), b < j <= i <= 3; wave 0 takes (b+1, b+1) and goes on to factor it
         if (wave == 0) {
             const int i = b + 1;
             doublex4 acc = load_d16(T + (SB * i) * ULD + SB * i, ULD, lane);
@@ -145,53 +188,18 @@ __device__ __forceinline__ void tile_potrf64(double *T, double *Vi, double *rd, 
                         store_d16(T + (SB * i) * ULD + SB * j, ULD, acc, lane);
                     }
                 }
+            // the inverse: row b of block column jc, then the sum for row b + 1
+            if (jc <= b) {
+                if (jc == b) copy_vi(b); else finish_row(b);
+                __builtin_amdgcn_wave_barrier();
+                doublex4 acc = doublex4{0.0, 0.0, 0.0, 0.0};
+                for (int m = jc; m <= b; ++m) acc = pq16(acc, T + (SB * (b + 1)) * ULD + SB * m, ULD, O + (SB * m) * ULD + SB * jc, ULD, 1.0, lane);
+                store_d16(O + (SB * (b + 1)) * ULD + SB * jc, ULD, acc, lane);
+            }
         }
         __syncthreads();
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Second generation of the large solve (this round): ONE launch per block column and ONE for the whole backward substitution.
-//   * the workgroup that factors a diagonal tile also inverts the factor (inv64: the four 16 x 16 sub-block inverses are there
-//     already; the six blocks below them are products), so "X_ik = A_ik L_kk^-T" is a dense product with L_kk^-1 and needs no
-//     triangular sweep -- every trailing-update workgroup forms the X_ik, X_jk it needs itself (3 tile products instead of 1:
-//     the matrix cores are idle anyway, the launch and the sweep were what cost 11 us per block column);
-//   * the factor tiles X_ik go to a second matrix W2 (the update workgroups of the same launch still read A_ik from W);
-//   * the backward substitution is one launch of nb workgroups that hand the solution blocks on through flags in memory:
-//     workgroup b folds  z_b -= L_ib' y_i  for i = nb-1 .. b+1 as the y_i appear, then publishes  y_b = L_bb^-T z_b.
-//     Workgroup b has blockIdx nb-1-b: it only ever waits for workgroups dispatched before it, so the chain cannot deadlock
-//     whatever part of the grid is resident.  (48 launches of 16 us before.)
-__device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp, const double *Q, int ldq, double sign, int lane)
-{
-    // acc += sign * P (16 x 16 row-major) * Q (16 x 16 row-major)
-    const double *pp = P + (lane & 15) * ldp + (lane >> 4), *qp = Q + (lane >> 4) * ldq + (lane & 15);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * pp[4 * kk], qp[4 * kk * ldq], acc, 0, 0, 0);
-    return acc;
-}
-
-// 256 threads: O (LDS, 64 x 64, row-major ULD) = inverse of the lower-triangular factor T (LDS, ULD) whose diagonal sub-block
-// inverses are in Vi.  Wave j computes block column j:  O_jj = Vi_j,  O_ij = -Vi_i (sum_{m=j}^{i-1} T_im O_mj)  for i > j.
-// The intermediate sum is parked in O_ij's own place (no scratch: 9 KB of LDS less is what lets two workgroups share a CU).
-__device__ __forceinline__ void inv64(double *O, const double *T, const double *Vi)
-{
-    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
-    for (int e = lane; e < SB * CB; e += 64) {          // this wave's block column: zero above the diagonal block, Vi_j on it
-        const int r = e / SB, c = e % SB;
-        O[r * ULD + SB * j + c] = (r >= SB * j && r < SB * (j + 1)) ? Vi[j * SB * VLD + (r - SB * j) * VLD + c] : 0.0;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = j + 1; i < 4; ++i) {
-        doublex4 acc = doublex4{0.0, 0.0, 0.0, 0.0};
-        for (int m = j; m < i; ++m) acc = pq16(acc, T + (SB * i) * ULD + SB * m, ULD, O + (SB * m) * ULD + SB * j, ULD, 1.0, lane);
-        double *Oij = O + (SB * i) * ULD + SB * j;
-        store_d16(Oij, ULD, acc, lane);
-        __builtin_amdgcn_wave_barrier();
-        acc = pq16(doublex4{0.0, 0.0, 0.0, 0.0}, Vi + i * SB * VLD, VLD, Oij, ULD, -1.0, lane);
-        __builtin_amdgcn_wave_barrier();
-        store_d16(Oij, ULD, acc, lane);
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (wave == 0) copy_vi(3); else finish_row(3);
 }
 
 // Data handed from one workgroup to another INSIDE a launch (factor tiles, tile inverses, solution blocks) is written and read
@@ -219,16 +227,22 @@ __device__ __forceinline__ void publish_diag2(double *__restrict__ Ld, const dou
 }
 
 // this wave's 16-row strip of  P (64 x 64, LDS ULD) * Q' (Q 64 x 64, LDS ULD): four 16 x 16 outputs, K = 64
-template <bool NEGATE = false>
+// QTRI: Q is lower triangular (the inverse of a factor): its 16 x 16 blocks (cb, kb) with kb > cb are zero and are skipped -- 40
+// matrix instructions per wave instead of 64 (v_mfma_f64_16x16x4_f64 issues every 64 cycles: the product is 2 us of a CU otherwise)
+template <bool NEGATE = false, bool QTRI = false>
 __device__ __forceinline__ void strip_pqt64(doublex4 (&acc)[4], const double *P, const double *Q, int wave, int lane)
 {
     const double *ap = P + (16 * wave + (lane & 15)) * ULD + (lane >> 4);
     const double *bp = Q + (lane & 15) * ULD + (lane >> 4);
-#pragma unroll 4
-    for (int kk = 0; kk < CB / 4; ++kk) {
-        const double a = NEGATE ? -ap[4 * kk] : ap[4 * kk];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[16 * cb * ULD + 4 * kk], acc[cb], 0, 0, 0);
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int kk = 4 * kb + k4;
+            const double a = NEGATE ? -ap[4 * kk] : ap[4 * kk];
+#pragma unroll
+            for (int cb = QTRI ? kb : 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[16 * cb * ULD + 4 * kk], acc[cb], 0, 0, 0);
+        }
     }
 }
 
@@ -239,17 +253,27 @@ __device__ __forceinline__ void strip_pqt64(doublex4 (&acc)[4], const double *P,
 //   * then it becomes a factor tile: it waits for L_jj^-1 (ready[j]), multiplies by it and stores X_ij to W2 (raises xready[i][j]);
 //   * the FIRST tile below the diagonal, (j+1, j), goes on: it holds X_j+1,j -- the last thing the next diagonal tile is waiting
 //     for -- so it subtracts X X' from that tile itself (fetched beforehand: tile (j+1, j+1) stops one step early and publishes
-//     its partial sum, dpart[j+1]), factors it (tile_potrf64), inverts the factor (inv64) and raises ready[j+1].  The pivot chain
+//     its partial sum, dpart[j+1]), factors it and inverts the factor (tile_potrf64_inv) and raises ready[j+1].  The pivot chain
 //     thus runs  ... -> L_jj^-1 -> X_j+1,j -> L_j+1,j+1^-1 -> ...  inside one workgroup per column, with ONE flag between columns
 //     (31 us -> 22 us per column against handing X_j+1,j to the diagonal tile's own workgroup: a flag, a 32 KB coherent read).
 // Every wait is for a workgroup with a smaller blockIdx, so the chain cannot deadlock whatever part of the grid is resident.
 // History: one trsm + one update launch per block column (round 1, 145 launches) 4.46 ms; one launch per block column 1.97 ms --
 // of each 31 us step ~15 us were two agent-scope releases (L2 write-backs, see st_coh); this kernel 1.5 ms before the merge above.
+#ifdef ESFM_CHOL_TRACE
+// timing-only build (scratch/build_variant_chol.sh NAME -DESFM_CHOL_TRACE): the chain workgroup (j+1, j) leaves s_memrealtime stamps
+// (10 ns ticks) at its stages; scratch/chol_trace.py reads them through esfm_debug_chol_trace
+__device__ unsigned long long g_chol_trace[64 * 12];
+#define CHOL_T(col, q) do { if (threadIdx.x == 0) g_chol_trace[(col) * 12 + (q)] = wall_clock64(); } while (0)
+extern "C" int esfm_debug_chol_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_trace), sizeof(g_chol_trace)); }
+#else
+#define CHOL_T(col, q) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, double *__restrict__ W2, double *__restrict__ Ldiag, int ld, int nb,
                                                     int *__restrict__ ready, int *__restrict__ xcount, int *__restrict__ dpart, double *__restrict__ scal)
 {
-    __shared__ double Xi[CB * ULD];
-    __shared__ double Xj[CB * ULD];
+    __shared__ __attribute__((aligned(16))) double Xi[CB * ULD];
+    __shared__ __attribute__((aligned(16))) double Xj[CB * ULD];
     __shared__ double Vi[4 * SB * VLD];
     __shared__ double rd[CB];
     __shared__ int fail;
@@ -259,8 +283,10 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
         if (t < cnt) { i = c + t; j = c; break; }
         t -= cnt;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) fail = 0;
+    const bool chain_wg = (i == j + 1 && i < nb);
+    if (chain_wg) CHOL_T(j, 0);
     __shared__ int seen;
     auto wait_flag = [&](const int *f, bool urgent, int at_least = 1) {  // thread 0 polls (relaxed) until *f >= at_least, then a workgroup-scope acquire
         if (tid == 0) {
@@ -274,9 +300,10 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto factor_and_publish = [&](double *T, double *O, int c) {      // T: the finished diagonal tile of column c (LDS); O: scratch tile
-        tile_potrf64(T, Vi, rd, &fail);
-        inv64(O, T, Vi);
+        tile_potrf64_inv(T, O, Vi, rd, &fail);
+        CHOL_T(c - 1, 7);
         __syncthreads();
+        CHOL_T(c - 1, 8);
         publish_diag2(Ldiag + (size_t)c * LSLOT, O);
         if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
         publish_flag(&ready[c]);
@@ -361,27 +388,45 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
     // the first tile below the diagonal also finishes the next diagonal tile: fetch its partial sum while waiting for L_jj^-1
-    const bool next_diag = (i == j + 1 && i < nb);
-    doublex4 dacc[4] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
+    const bool next_diag = chain_wg;
+    if (next_diag) CHOL_T(j, 1);
+    // The ten lower 16 x 16 blocks of the next diagonal tile over the four waves as 3 + 3 + 3 + 1 (a row strip per wave would be
+    // 1 + 2 + 3 + 4: the slowest wave sets the pace, 48 matrix instructions instead of 64): wave w's q-th block is (dbi, dbj)[w][q].
+    const int dbi[3] = {wave == 3 ? 3 : wave, wave == 2 ? 2 : (wave == 1 ? 1 : 3), wave == 2 ? 2 : 3};
+    const int dbj[3] = {wave == 3 ? 3 : 0, wave == 3 ? 3 : (wave == 0 ? 0 : 1), wave == 3 ? 3 : (wave == 0 ? 1 : 2)};
+    const int dnb = wave == 3 ? 1 : 3;      // (wave 3 runs (3, 3) three times and keeps one: no branch around a matrix instruction)
+    doublex4 dacc[3] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
     if (next_diag) {
         wait_flag(&dpart[i], false);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-                dacc[cb][g] = ld_coh(&W[(size_t)(i * CB + r) * ld + i * CB + c]);
+                const int r = 16 * dbi[q] + (lane >> 4) + 4 * g, c = 16 * dbj[q] + (lane & 15);
+                if (q < dnb) dacc[q][g] = ld_coh(&W[(size_t)(i * CB + r) * ld + i * CB + c]);
             }
     }
     // X_ij = C L_jj^-T once the inverse is there
+    if (next_diag) CHOL_T(j, 2);
     wait_flag(&ready[j], true);
+    if (next_diag) CHOL_T(j, 3);
     {
-        const double *Lk = Ldiag + (size_t)j * LSLOT + LINV_OFF;
-        for (int e = tid; e < CB * CB; e += 256) Xj[(e / CB) * ULD + (e % CB)] = Lk[e];
+        // all 32 KB in flight at once (as a loop the compiler made it sixteen round trips, load -> wait -> LDS store: 4 us of the
+        // 25 us a block column takes, on the critical chain)
+        const double2 *Lk = reinterpret_cast<const double2 *>(Ldiag + (size_t)j * LSLOT + LINV_OFF);
+        double2 lv[CB * CB / 512];
+#pragma unroll
+        for (int q = 0; q < CB * CB / 512; ++q) lv[q] = Lk[tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < CB * CB / 512; ++q) {
+            const int e = 2 * (tid + 256 * q);
+            *reinterpret_cast<double2 *>(&Xj[(e / CB) * ULD + (e % CB)]) = lv[q];
+        }
     }
     __syncthreads();
+    if (next_diag) CHOL_T(j, 4);
     doublex4 x[4] = {doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}, doublex4{0, 0, 0, 0}};
-    strip_pqt64<false>(x, Xi, Xj, wave, lane);
+    strip_pqt64<false, true>(x, Xi, Xj, wave, lane);
     if (!next_diag) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -406,20 +451,33 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
             st_coh(&W2[(size_t)(i * CB + r) * ld + j * CB + c], x[cb][g]);
         }
     __syncthreads();
-    strip_pqt64<true>(dacc, Xi, Xi, wave, lane);
+    {
+        const double *xp = Xi + (lane & 15) * ULD + (lane >> 4);
+#pragma unroll 4
+        for (int kk = 0; kk < CB / 4; ++kk) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
-            if (c > r) dacc[cb][g] = 0.0;
+            for (int q = 0; q < 3; ++q)
+                dacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xp[16 * dbi[q] * ULD + 4 * kk], xp[16 * dbj[q] * ULD + 4 * kk], dacc[q], 0, 0, 0);
         }
-    __syncthreads();                                    // every wave is past its reads of Xi
+    }
+    // (the tile above the diagonal is zero: Xj held L_jj^-1, whose upper blocks are zeros, and the waves rewrite the lower ones)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) store_d16(Xj + (16 * wave) * ULD + 16 * cb, ULD, dacc[cb], lane);
+    for (int g = 0; g < 4; ++g)
+        if ((lane & 15) > (lane >> 4) + 4 * g) {
+            dacc[0][g] = wave == 0 || wave == 3 ? 0.0 : dacc[0][g];          // blocks (0,0) and (3,3)
+            dacc[1][g] = wave == 1 ? 0.0 : dacc[1][g];                        // (1,1)
+            dacc[2][g] = wave == 2 ? 0.0 : dacc[2][g];                        // (2,2)
+        }
+    __syncthreads();                                    // every wave is past its reads of Xi and of Xj (L^-1)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < dnb) store_d16(Xj + (16 * dbi[q]) * ULD + 16 * dbj[q], ULD, dacc[q], lane);
     __syncthreads();
+    CHOL_T(j, 5);
     publish_flag(&xcount[i], j + 1);                    // (the X stores above have long been acknowledged)
+    CHOL_T(j, 6);
     factor_and_publish(Xj, Xi, i);
+    CHOL_T(j, 9);
 }
 
 // The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles; flags: nb ints,

@@ -283,8 +283,16 @@ constexpr int kLinThreads = 512;
 constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
 
 template <bool PRIV, bool CALIB>
-__global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, ScalBase sbase, double *__restrict__ slabs)
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, ScalBase sbase, double *__restrict__ slabs,
+                                                                   int prov_rexp)
 {
+    // prov_rexp != INT_MIN (PRIV, several observations per thread: BA-512): PROVISIONAL fixed-point exponents -- the previous
+    // linearisation's global column exponents d.qexp plus one, and prov_rexp for the residual column (sqrt(2 cost) < 2^prov_rexp,
+    // from the host: the accepted candidate's cost) -- let pass 1 quantise and add the rows while they are in registers.  The maxima
+    // and counts are still collected, and after the loop every workgroup checks ITS bound sqrt(n_c max) < 2^exponent for every camera
+    // and column: if one fails (a first linearisation, a problem that changed under the solver) the workgroup clears its sums and
+    // runs the two-pass form below.  Either way the integers are exact sums on the grid the slab is converted with.  (Round 3: the
+    // re-read of pass 2 was 336 MB of BA-512's sweep.)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *red = reinterpret_cast<double *>(lds_raw);                                  // [8] reduction scratch, [10] intrinsics-block sums
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds_raw) + 18;     // PRIV: [n_real_cam * 27]
@@ -293,17 +301,42 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
     int *ex = cnt + d.n_real_cam;                                                       //       [n_real_cam * 7]
     const int tid = threadIdx.x;
     const int n_obs = d.n_obs;
+    const bool single_launch = PRIV && (long long)gridDim.x * kLinThreads >= n_obs;
+    const bool prov = PRIV && !single_launch && prov_rexp != INT_MIN;
     if (PRIV) {
         for (int e = tid; e < d.n_real_cam * 27; e += kLinThreads) acc[e] = 0ull;
-        for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) mx[e] = 0ull;
+        for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) {
+            mx[e] = 0ull;
+            if (prov) ex[e] = e % 7 == 6 ? prov_rexp : d.qexp[6 * (e / 7) + e % 7] + 1;
+        }
         for (int e = tid; e < d.n_real_cam; e += kLinThreads) cnt[e] = 0;
+        if (tid == 0) red[17] = 0.0;         // the guard's verdict (red[8..17] otherwise belong to the intrinsics block, which has no provisional path)
         __syncthreads();
     }
+    // the 27 fixed-point adds of one observation's rows (every factor carries 2^(30 - exponent of its column))
+    auto add_rows = [&](int c, const double (&Jrow)[12], double r0, double r1) {
+        double J[12];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { const int sh = kFxBits / 2 - ex[c * 7 + a]; J[a] = ldexp(Jrow[a], sh); J[6 + a] = ldexp(Jrow[6 + a], sh); }
+        const int shr = kFxBits / 2 - ex[c * 7 + 6];
+        const double q0 = ldexp(r0, shr), q1 = ldexp(r1, shr);
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+                atomicAdd(&acc[c * 27 + e], fx64_scaled(J[a] * J[b] + J[6 + a] * J[6 + b]));
+                ++e;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) atomicAdd(&acc[c * 27 + 21 + a], fx64_scaled(J[a] * q0 + J[6 + a] * q1));
+    };
     double cost = 0.0, bad = 0.0;
     double kacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // PRIV, at most one observation per thread (the grid covers the observations: BA-25): pass 2 quantises the rows from REGISTERS
     // instead of re-reading the thread's own stores (112 B per observation fetched back: 33 MB of the 108 MB the kernel moved)
-    const bool single = PRIV && (long long)gridDim.x * kLinThreads >= n_obs;
+    const bool single = single_launch;
     double keepJ[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, keepR0 = 0.0, keepR1 = 0.0;
     int keepC = -1;
     for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
@@ -381,6 +414,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
                 for (int i = 0; i < 12; ++i) keepJ[i] = Jc[i];
                 keepR0 = r0; keepR1 = r1; keepC = c;
             }
+            if (prov && !CALIB) add_rows(c, Jc, r0, r1);
         }
     }
     {
@@ -397,12 +431,32 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
         }
     }
     __syncthreads();
-    for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) {
-        const double b = sqrt((double)cnt[e / 7] * __longlong_as_double((long long)mx[e]));   // > sqrt(sum): every term is <= the maximum
-        ex[e] = (b > 1e-120 && b < 1e120) ? ilogb(b) + 1 : -400;
+    bool two_pass = !(prov && !CALIB);
+    if (!two_pass) {
+        // the guard: this workgroup's bound on every partial sum against the provisional grid
+        bool viol = false;
+        for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) {
+            if (cnt[e / 7] == 0) continue;
+            const double b = sqrt((double)cnt[e / 7] * __longlong_as_double((long long)mx[e]));
+            const int need = (b > 1e-120 && b < 1e120) ? ilogb(b) + 1 : (b >= 1e120 || b != b ? INT_MAX : -400);
+            viol = viol || need > ex[e];
+        }
+        if (viol) red[17] = 1.0;
+        __syncthreads();
+        two_pass = red[17] != 0.0;            // (workgroup-uniform)
+        if (two_pass) {
+            for (int e = tid; e < d.n_real_cam * 27; e += kLinThreads) acc[e] = 0ull;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
+    if (two_pass) {
+        for (int e = tid; e < d.n_real_cam * 7; e += kLinThreads) {
+            const double b = sqrt((double)cnt[e / 7] * __longlong_as_double((long long)mx[e]));   // > sqrt(sum): every term is <= the maximum
+            ex[e] = (b > 1e-120 && b < 1e120) ? ilogb(b) + 1 : -400;
+        }
+        __syncthreads();
+    }
+    for (int k = blockIdx.x * kLinThreads + tid; two_pass && k < n_obs; k += gridDim.x * kLinThreads) {
         int c;
         double J[12], r0, r1;
         if (single) {
@@ -415,22 +469,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, doub
             for (int i = 0; i < 12; ++i) J[i] = d.Jc[(size_t)i * n_obs + k];    // this thread's own stores
             r0 = d.res[k]; r1 = d.res[(size_t)n_obs + k];
         }
-        // every factor carries 2^(30 - exponent of its column): the products are scaled by 2^(60 - ex[a] - ex[b]) exactly
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { const int sh = kFxBits / 2 - ex[c * 7 + a]; J[a] = ldexp(J[a], sh); J[6 + a] = ldexp(J[6 + a], sh); }
-        const int shr = kFxBits / 2 - ex[c * 7 + 6];
-        const double q0 = ldexp(r0, shr), q1 = ldexp(r1, shr);
-        int e = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int b = a; b < 6; ++b) {
-                atomicAdd(&acc[c * 27 + e], fx64_scaled(J[a] * J[b] + J[6 + a] * J[6 + b]));
-                ++e;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 6; ++a) atomicAdd(&acc[c * 27 + 21 + a], fx64_scaled(J[a] * q0 + J[6 + a] * q1));
+        add_rows(c, J, r0, r1);
     }
     __syncthreads();
     // one coalesced slab of doubles per workgroup; ba_camacc_reduce_kernel sums them in a fixed order
@@ -1916,8 +1955,11 @@ int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack)
     return ESFM_OK;
 }
 
-int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx, int *deferred_slabs)
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx, int *deferred_slabs, double cost_bound)
 {
+    // provisional exponent of the residual column (see the kernel): sqrt(sum r^2) <= sqrt(2 cost) < 2^prov_rexp
+    int prov_rexp = INT_MIN;
+    if (cost_bound > 0.0 && cost_bound < 1e300) prov_rexp = std::ilogb(std::sqrt(2.0 * cost_bound)) + 1;
     if (deferred_slabs) *deferred_slabs = 0;
     if (d.n_obs <= 0 || d.n_cchunks <= 0) {
         ESFM_HIP_TRY(hipMemsetAsync(d.camacc, 0, sizeof(double) * ba_camacc_doubles(d.n_cam), st));
@@ -1934,7 +1976,7 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv_bytes));
         {
             KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep with its in-LDS camera sums (not the slab reduction)
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, sbase, d.lin_slabs);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), priv_bytes, st, d, cauchy_a, use_scaling ? 1 : 0, sbase, d.lin_slabs, prov_rexp);
         }
         LAUNCH_CHECK();
         d.parts->grad_done = d.parts->single_rank;
@@ -1947,7 +1989,7 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     {
         KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone
         auto kern = d.has_calib ? &ba_linearize_kernel<false, true> : &ba_linearize_kernel<false, false>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), 18 * sizeof(double), st, d, cauchy_a, use_scaling ? 1 : 0, sbase, (double *)nullptr);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), 18 * sizeof(double), st, d, cauchy_a, use_scaling ? 1 : 0, sbase, (double *)nullptr, INT_MIN);
     }
     LAUNCH_CHECK();
     if (d.has_calib) hipLaunchKernelGGL(ba_camacc_chunk_kernel<true>, dim3(d.n_cchunks), dim3(64), 0, st, d);

@@ -133,7 +133,10 @@ int ba_red_pack(hipStream_t st, const BADev &d, double *packed, bool unpack);
 
 // deferred_slabs != NULL: on one rank with the walking per-point kernel next, the reduction of the sweep's per-camera slabs is NOT
 // launched; *deferred_slabs (> 0) must then be handed to the ba_point_prep call that follows, which does both in one launch
-int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx, int *deferred_slabs = nullptr);
+// cost_bound > 0: an upper bound on the cost at the point being linearised (the accepted candidate's), which lets the sweep of a large
+// problem use the previous linearisation's fixed-point exponents in ONE pass (ba_linearize_kernel)
+int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bool use_scaling, esfm_ctx *timing_ctx, int *deferred_slabs = nullptr,
+                 double cost_bound = -1.0);
 int ba_point_prep(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag, bool fresh_jacobian, int deferred_slabs = 0);
 int ba_jacobi_scaling(hipStream_t st, const BADev &d);
 int ba_camera_gradient(hipStream_t st, const BADev &d);
