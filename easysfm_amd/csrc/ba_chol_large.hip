@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
 // 64 x 64 tile kernels built from 16 x 16 sub-blocks on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
 // A[l & 15][l >> 4] and B[l >> 4][l & 15]; its four results are D[(l >> 4) + 4 g][l & 15]).
 //   pqt16 / pq16:      acc += sign * P Q' / P Q  for 16 x 16 row-major blocks in LDS  -- 4 MFMAs
-//   tile_potrf64_inv:  4 sub-block steps: potrf16_fused_full, panel X = A Linv' (MFMA), trailing update (MFMA); the inverse of the
+//   tile_potrf64_inv:  4 sub-block steps: potrf16_fused_to, panel X = A Linv' (MFMA), trailing update (MFMA); the inverse of the
 //                      factored tile from its sub-block inverses alongside
 // History of the diagonal-block factorisation, per 16 x 16 block: 256 threads out of LDS between barriers (round 1): 11 us; one
 // wave, block in registers, v_readlane broadcasts, factor then invert: 4 us; one pass of scheduled asm with DPP broadcasts: 1.5 us.
@@ -92,18 +92,18 @@ __device__ __forceinline__ void potrf16_fused_inv(double *D, int *fail, int lane
     const int r = lane & 15;
     const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * VLD), col_addr = (uint32_t)(uintptr_t)(D + r);
     int bad;
-    asm volatile(ESFM_POTRF16_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr), "v"(lane) : ESFM_POTRF16_CLOBBERS);
+    asm volatile(ESFM_POTRF16_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr) : ESFM_POTRF16_CLOBBERS);
     if (__any(bad) && lane == 0) *fail = 1;
 }
 
-// The same for the 64 x 64 tile factorisation: D (row pitch ldd doubles) keeps the factor (upper part zeroed), the inverse goes
-// to Vi (row-major VLD) and the reciprocal diagonal to rd[0..16).
-__device__ __forceinline__ void potrf16_fused_full(double *D, int ldd, double *Vi, double *rd, int *fail, int lane)
+// The same for a 16 x 16 diagonal sub-block of the 64 x 64 tile factorisation: D has row pitch ldd doubles and is NOT written (nothing
+// reads a factored diagonal sub-block again -- the panel and the tile's inverse go through Vi); the inverse goes to Vi (row-major VLD).
+__device__ __forceinline__ void potrf16_fused_to(const double *D, int ldd, double *Vi, int *fail, int lane)
 {
     const int r = lane & 15;
-    const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * ldd), col_addr = (uint32_t)(uintptr_t)(Vi + r), rd_addr = (uint32_t)(uintptr_t)rd;
+    const uint32_t row_addr = (uint32_t)(uintptr_t)(D + r * ldd), col_addr = (uint32_t)(uintptr_t)(Vi + r);
     int bad;
-    asm volatile(ESFM_POTRF16_FULL_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr), "v"(lane), "v"(rd_addr) : ESFM_POTRF16_CLOBBERS);
+    asm volatile(ESFM_POTRF16_ASM : "=&v"(bad) : "v"(row_addr), "v"(col_addr) : ESFM_POTRF16_CLOBBERS);
     if (__any(bad) && lane == 0) *fail = 1;
 }
 
@@ -127,8 +127,21 @@ __device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp,
     return acc;
 }
 
+#ifdef ESFM_CHOL_TRACE
+// timing-only build (scratch/build_variant_chol.sh NAME -DESFM_CHOL_TRACE): the chain workgroup (j+1, j) leaves s_memrealtime stamps
+// (10 ns ticks) at its stages; scratch/chol_trace.py reads them through esfm_debug_chol_trace
+__device__ unsigned long long g_chol_trace[64 * 12];
+#define CHOL_T(col, q) do { if (threadIdx.x == 0) g_chol_trace[(col) * 12 + (q)] = wall_clock64(); } while (0)
+// CHOL_ACC(var): var += ticks since the previous CHOL_ACC (wave 0 only)
+#define CHOL_ACC(var) do { const long long tm1 = wall_clock64(), cy1 = clock64(); var += tm1 - tm0; var##_cyc += cy1 - cy0; tm0 = tm1; cy0 = cy1; } while (0)
+extern "C" int esfm_debug_chol_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_trace), sizeof(g_chol_trace)); }
+#else
+#define CHOL_T(col, q) do { } while (0)
+#define CHOL_ACC(var) do { } while (0)
+#endif
+
 // 256 threads: in-place Cholesky of the 64 x 64 tile T (LDS, row-major ULD; upper part must be zero) AND the inverse of the factor
-// in O (LDS, ULD).  Vi: 4 blocks of 16 x VLD (inverses of the diagonal sub-blocks), rd: 64 reciprocal diagonals.
+// in O (LDS, ULD).  Vi: 4 blocks of 16 x VLD (inverses of the diagonal sub-blocks).
 // Factorisation, sub-block column b: panel X_i = A_i Linv_bb' (waves b+1 .. 3), then the trailing update -- during which wave 0
 // updates sub-block (b+1, b+1) first and factors it at once (look-ahead: the next pivot chain runs while the other waves finish the
 // update); two barriers per sub-block column.
@@ -139,10 +152,13 @@ __device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp,
 // last pivot chain one product per wave is left (O_3,jc = -Vi_3 S_3,jc).  S_ij is parked in O_ij's own place (no scratch: 9 KB of
 // LDS less is what lets two workgroups share a CU).  (Until round 3 the inverse was a pass of its own after the factorisation:
 // 2.8 us of the block column's critical chain, now 0.4.)
-__device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *Vi, double *rd, int *fail)
+__device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *Vi, int *fail, int trace_col = 0)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jc = wave - 1;
+#ifdef ESFM_CHOL_TRACE
+    long long tm0 = wall_clock64(), cy0 = clock64(), t_potrf = 0, t_rest = 0, t_potrf_cyc = 0, t_rest_cyc = 0;
+#endif
     auto copy_vi = [&](int b) {                          // O_bb = Vi_b
         for (int e = lane; e < SB * SB; e += 64) O[(SB * b + e / SB) * ULD + SB * b + e % SB] = Vi[b * SB * VLD + (e / SB) * VLD + e % SB];
     };
@@ -154,7 +170,8 @@ __device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *V
         __builtin_amdgcn_wave_barrier();
     };
     if (wave == 0) {
-        potrf16_fused_full(T, ULD, Vi, rd, fail, lane);
+        potrf16_fused_to(T, ULD, Vi, fail, lane);
+        CHOL_ACC(t_potrf);
     } else {
         // zeros above the diagonal blocks: block column jc (rows < 16 jc), and wave 1 also takes block column 3
         for (int e = lane; e < SB * jc * SB; e += 64) O[(e / SB) * ULD + SB * jc + e % SB] = 0.0;
@@ -176,7 +193,9 @@ __device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *V
             acc = pqt16(acc, T + (SB * i) * ULD + SB * b, ULD, T + (SB * i) * ULD + SB * b, ULD, -1.0, lane);
             store_d16(T + (SB * i) * ULD + SB * i, ULD, acc, lane);
             __builtin_amdgcn_wave_barrier();
-            potrf16_fused_full(T + (SB * i) * ULD + SB * i, ULD, Vi + i * SB * VLD, rd + SB * i, fail, lane);
+            CHOL_ACC(t_rest);
+            potrf16_fused_to(T + (SB * i) * ULD + SB * i, ULD, Vi + i * SB * VLD, fail, lane);
+            CHOL_ACC(t_potrf);
         } else {
             int idx = 0;
             for (int i = b + 1; i < 4; ++i)
@@ -200,6 +219,10 @@ __device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *V
         __syncthreads();
     }
     if (wave == 0) copy_vi(3); else finish_row(3);
+#ifdef ESFM_CHOL_TRACE
+    if (tid == 0) { CHOL_ACC(t_rest); g_chol_trace[trace_col * 12 + 10] = (unsigned long long)t_potrf; g_chol_trace[trace_col * 12 + 11] = (unsigned long long)t_rest;
+                    g_chol_trace[trace_col * 12 + 8] = (unsigned long long)t_potrf_cyc; (void)t_rest_cyc; }    // (slot 8, "inv64", is free since the inverse moved)
+#endif
 }
 
 // Data handed from one workgroup to another INSIDE a launch (factor tiles, tile inverses, solution blocks) is written and read
@@ -259,15 +282,6 @@ __device__ __forceinline__ void strip_pqt64(doublex4 (&acc)[4], const double *P,
 // Every wait is for a workgroup with a smaller blockIdx, so the chain cannot deadlock whatever part of the grid is resident.
 // History: one trsm + one update launch per block column (round 1, 145 launches) 4.46 ms; one launch per block column 1.97 ms --
 // of each 31 us step ~15 us were two agent-scope releases (L2 write-backs, see st_coh); this kernel 1.5 ms before the merge above.
-#ifdef ESFM_CHOL_TRACE
-// timing-only build (scratch/build_variant_chol.sh NAME -DESFM_CHOL_TRACE): the chain workgroup (j+1, j) leaves s_memrealtime stamps
-// (10 ns ticks) at its stages; scratch/chol_trace.py reads them through esfm_debug_chol_trace
-__device__ unsigned long long g_chol_trace[64 * 12];
-#define CHOL_T(col, q) do { if (threadIdx.x == 0) g_chol_trace[(col) * 12 + (q)] = wall_clock64(); } while (0)
-extern "C" int esfm_debug_chol_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_trace), sizeof(g_chol_trace)); }
-#else
-#define CHOL_T(col, q) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, double *__restrict__ W2, double *__restrict__ Ldiag, int ld, int nb,
                                                     int *__restrict__ ready, int *__restrict__ xcount, int *__restrict__ dpart, double *__restrict__ scal)
@@ -275,7 +289,6 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     __shared__ __attribute__((aligned(16))) double Xi[CB * ULD];
     __shared__ __attribute__((aligned(16))) double Xj[CB * ULD];
     __shared__ double Vi[4 * SB * VLD];
-    __shared__ double rd[CB];
     __shared__ int fail;
     int t = blockIdx.x, i = -1, j = -1;
     for (int c = 0; c < nb; ++c) {
@@ -300,10 +313,9 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto factor_and_publish = [&](double *T, double *O, int c) {      // T: the finished diagonal tile of column c (LDS); O: scratch tile
-        tile_potrf64_inv(T, O, Vi, rd, &fail);
+        tile_potrf64_inv(T, O, Vi, &fail, c > 0 ? c - 1 : 63);
         CHOL_T(c - 1, 7);
         __syncthreads();
-        CHOL_T(c - 1, 8);
         publish_diag2(Ldiag + (size_t)c * LSLOT, O);
         if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
         publish_flag(&ready[c]);

@@ -10,7 +10,11 @@ prob.solve(opt); ctx.synchronize()
 lib = _lib.lib()
 buf = (ctypes.c_ulonglong * (64 * 12))()
 rc = lib.esfm_debug_chol_trace(buf)
-t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 12).astype(np.int64)[:47, :10]
+full = np.frombuffer(buf, dtype=np.uint64).reshape(64, 12).astype(np.int64)
+cyc = np.median(full[5:46, 8]); full[:, 8] = full[:, 7]
+t = full[:47, :10]
+print('the 4 pivot chains in shader cycles (s_memtime): %.0f  ->  %.2f GHz while they run' % (cyc, cyc / (np.median(full[5:46, 10]) * 10.0) ))
+print('inside the tile factorisation: 4 pivot chains (potrf16) %.2f us, everything between them %.2f us' % (np.median(full[5:46, 10]) * 10e-3, np.median(full[5:46, 11]) * 10e-3))
 names = ['start', 'loop done', 'dpart got', 'ready seen', 'Linv in LDS', 'X + diag upd', 'xcount pub', 'potrf64', 'inv64', 'published']
 d = np.diff(t, axis=1) * 10e-3          # us
 print('rc', rc, ' per-stage us (median over columns 5..45):')
