@@ -127,6 +127,24 @@ __device__ __forceinline__ doublex4 pq16(doublex4 acc, const double *P, int ldp,
     return acc;
 }
 
+// Data handed from one workgroup to another INSIDE a launch (factor tiles, tile inverses, solution blocks) is written and read
+// with agent-scope relaxed atomics -- plain stores / loads with the coherence bits set, write-through and L2-bypassing -- and
+// ordered against the flag by a WORKGROUP-scope fence (s_waitcnt) plus a barrier.  An agent-scope release (__threadfence) is a
+// write-back of the XCD's whole L2, with megabytes of other workgroups' dirty tiles in it: two of those per block column were
+// ~15 us of the 31 us step.
+__device__ __forceinline__ void st_coh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_coh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_flag(int *f, int value = 1)
+{
+    // The workgroup-scope release fence alone emits NO s_waitcnt vmcnt(0) on gfx950 (a workgroup shares its L1 outside tgsplit
+    // mode, so the compiler has nothing to wait for): the flag store could overtake the sc1 data stores on another channel.  The
+    // explicit wait makes every wave's write-through stores L2-acknowledged before the barrier lets the flag out.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores have been acknowledged by L2
+    __syncthreads();                                            // ... and everybody else's
+    if (threadIdx.x == 0) __hip_atomic_store(f, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifdef ESFM_CHOL_TRACE
 // timing-only build (scratch/build_variant_chol.sh NAME -DESFM_CHOL_TRACE): the chain workgroup (j+1, j) leaves s_memrealtime stamps
 // (10 ns ticks) at its stages; scratch/chol_trace.py reads them through esfm_debug_chol_trace
@@ -152,7 +170,11 @@ extern "C" int esfm_debug_chol_trace(unsigned long long *out) { return (int)hipM
 // last pivot chain one product per wave is left (O_3,jc = -Vi_3 S_3,jc).  S_ij is parked in O_ij's own place (no scratch: 9 KB of
 // LDS less is what lets two workgroups share a CU).  (Until round 3 the inverse was a pass of its own after the factorisation:
 // 2.8 us of the block column's critical chain, now 0.4.)
-__device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *Vi, int *fail, int trace_col = 0)
+// The inverse leaves for memory (Ld: 64 x 64 row-major, read by the next block column's workgroups and by the backward substitution)
+// from here, every wave storing what it computed itself: rows 0..31 while wave 0 is still in the LAST pivot chain -- part_flag counts
+// the three waves that have done so, and a consumer that sees 3 starts fetching those 16 KB a microsecond before the tile is finished
+// -- and rows 32..63 at the end; the caller raises the tile's ready flag behind them (publish_flag).
+__device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *Vi, int *fail, double *__restrict__ Ld, int *part_flag, int trace_col = 0)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jc = wave - 1;
@@ -209,44 +231,33 @@ __device__ __forceinline__ void tile_potrf64_inv(double *T, double *O, double *V
                 }
             // the inverse: row b of block column jc, then the sum for row b + 1
             if (jc <= b) {
+                if (b == 2) {                            // rows 0..31 of this wave's block column(s) are final since the last window: on their way (8 per lane)
+                    for (int e = lane; e < 2 * SB * SB; e += 64) st_coh(&Ld[(e / SB) * CB + SB * jc + e % SB], O[(e / SB) * ULD + SB * jc + e % SB]);
+                    if (wave == 1) for (int e = lane; e < 2 * SB * SB; e += 64) st_coh(&Ld[(e / SB) * CB + SB * 3 + e % SB], 0.0);
+                }
                 if (jc == b) copy_vi(b); else finish_row(b);
                 __builtin_amdgcn_wave_barrier();
                 doublex4 acc = doublex4{0.0, 0.0, 0.0, 0.0};
                 for (int m = jc; m <= b; ++m) acc = pq16(acc, T + (SB * (b + 1)) * ULD + SB * m, ULD, O + (SB * m) * ULD + SB * jc, ULD, 1.0, lane);
                 store_d16(O + (SB * (b + 1)) * ULD + SB * jc, ULD, acc, lane);
+                if (b == 2) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores are acknowledged (issued a microsecond ago)
+                    if (lane == 0) __hip_atomic_fetch_add(part_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads();
     }
     if (wave == 0) copy_vi(3); else finish_row(3);
+    {
+        const int cb = wave == 0 ? 3 : jc;              // rows 32..63 of this wave's block column (wave 0: the last one, zeros over Vi_3)
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < 2 * SB * SB; e += 64) st_coh(&Ld[(2 * SB + e / SB) * CB + SB * cb + e % SB], O[(2 * SB + e / SB) * ULD + SB * cb + e % SB]);
+    }
 #ifdef ESFM_CHOL_TRACE
     if (tid == 0) { CHOL_ACC(t_rest); g_chol_trace[trace_col * 12 + 10] = (unsigned long long)t_potrf; g_chol_trace[trace_col * 12 + 11] = (unsigned long long)t_rest;
                     g_chol_trace[trace_col * 12 + 8] = (unsigned long long)t_potrf_cyc; (void)t_rest_cyc; }    // (slot 8, "inv64", is free since the inverse moved)
 #endif
-}
-
-// Data handed from one workgroup to another INSIDE a launch (factor tiles, tile inverses, solution blocks) is written and read
-// with agent-scope relaxed atomics -- plain stores / loads with the coherence bits set, write-through and L2-bypassing -- and
-// ordered against the flag by a WORKGROUP-scope fence (s_waitcnt) plus a barrier.  An agent-scope release (__threadfence) is a
-// write-back of the XCD's whole L2, with megabytes of other workgroups' dirty tiles in it: two of those per block column were
-// ~15 us of the 31 us step.
-__device__ __forceinline__ void st_coh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_coh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void publish_flag(int *f, int value = 1)
-{
-    // The workgroup-scope release fence alone emits NO s_waitcnt vmcnt(0) on gfx950 (a workgroup shares its L1 outside tgsplit
-    // mode, so the compiler has nothing to wait for): the flag store could overtake the sc1 data stores on another channel.  The
-    // explicit wait makes every wave's write-through stores L2-acknowledged before the barrier lets the flag out.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores have been acknowledged by L2
-    __syncthreads();                                            // ... and everybody else's
-    if (threadIdx.x == 0) __hip_atomic_store(f, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// (only the inverse of the factor is read again -- by the next block column's workgroups and by the backward substitution)
-__device__ __forceinline__ void publish_diag2(double *__restrict__ Ld, const double *O)
-{
-    for (int e = threadIdx.x; e < CB * CB; e += 256) st_coh(&Ld[LINV_OFF + e], O[(e / CB) * ULD + (e % CB)]);
 }
 
 // this wave's 16-row strip of  P (64 x 64, LDS ULD) * Q' (Q 64 x 64, LDS ULD): four 16 x 16 outputs, K = 64
@@ -284,7 +295,8 @@ __device__ __forceinline__ void strip_pqt64(doublex4 (&acc)[4], const double *P,
 // of each 31 us step ~15 us were two agent-scope releases (L2 write-backs, see st_coh); this kernel 1.5 ms before the merge above.
 
 __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, double *__restrict__ W2, double *__restrict__ Ldiag, int ld, int nb,
-                                                    int *__restrict__ ready, int *__restrict__ xcount, int *__restrict__ dpart, double *__restrict__ scal)
+                                                    int *__restrict__ ready, int *__restrict__ xcount, int *__restrict__ dpart, int *__restrict__ rpart,
+                                                    double *__restrict__ scal)
 {
     __shared__ __attribute__((aligned(16))) double Xi[CB * ULD];
     __shared__ __attribute__((aligned(16))) double Xj[CB * ULD];
@@ -313,10 +325,8 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto factor_and_publish = [&](double *T, double *O, int c) {      // T: the finished diagonal tile of column c (LDS); O: scratch tile
-        tile_potrf64_inv(T, O, Vi, &fail, c > 0 ? c - 1 : 63);
+        tile_potrf64_inv(T, O, Vi, &fail, Ldiag + (size_t)c * LSLOT + LINV_OFF, &rpart[c], c > 0 ? c - 1 : 63);
         CHOL_T(c - 1, 7);
-        __syncthreads();
-        publish_diag2(Ldiag + (size_t)c * LSLOT, O);
         if (tid == 0 && fail) scal[SC_CHOL_FAIL] = 1.0;
         publish_flag(&ready[c]);
     };
@@ -420,15 +430,19 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     }
     // X_ij = C L_jj^-T once the inverse is there
     if (next_diag) CHOL_T(j, 2);
-    wait_flag(&ready[j], true);
-    if (next_diag) CHOL_T(j, 3);
     {
         // all 32 KB in flight at once (as a loop the compiler made it sixteen round trips, load -> wait -> LDS store: 4 us of the
-        // 25 us a block column takes, on the critical chain)
+        // 25 us a block column takes, on the critical chain) -- and the first 16 KB (rows 0..31: thread t's q-th load is in row
+        // 8 q + t / 32) as soon as the factoring workgroup has let go of them, a pivot chain before the tile is finished
         const double2 *Lk = reinterpret_cast<const double2 *>(Ldiag + (size_t)j * LSLOT + LINV_OFF);
         double2 lv[CB * CB / 512];
+        wait_flag(&rpart[j], true, 3);
 #pragma unroll
-        for (int q = 0; q < CB * CB / 512; ++q) lv[q] = Lk[tid + 256 * q];
+        for (int q = 0; q < 4; ++q) lv[q] = Lk[tid + 256 * q];
+        wait_flag(&ready[j], true);
+        if (next_diag) CHOL_T(j, 3);
+#pragma unroll
+        for (int q = 4; q < CB * CB / 512; ++q) lv[q] = Lk[tid + 256 * q];
 #pragma unroll
         for (int q = 0; q < CB * CB / 512; ++q) {
             const int e = 2 * (tid + 256 * q);
@@ -736,8 +750,8 @@ int ba_solve_reduced_small(hipStream_t st, const BADev &d, double radius, double
 size_t ba_chol_large_doubles(int n_cam)
 {
     const int n = 6 * n_cam, nb = (n + CB - 1) / CB;
-    // W, W2 (the factor), the diagonal slots, y, flags (y-ready, inverse-ready, partial-diagonal-ready: nb each; factor tiles per block row: nb + 1 ints)
-    return 2 * (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT + (size_t)nb * CB + (size_t)(4 * nb + 2) / 2 + 1;
+    // W, W2 (the factor), the diagonal slots, y, flags (y-ready, inverse-ready, partial-diagonal-ready, inverse-rows-0..31-ready: nb each; factor tiles per block row: nb + 1 ints)
+    return 2 * (size_t)(nb + 1) * CB * (size_t)(nb * CB) + (size_t)nb * LSLOT + (size_t)nb * CB + (size_t)(5 * nb + 2) / 2 + 1;
 }
 
 int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)
@@ -747,13 +761,13 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
     double *W = d.chol, *W2 = W + wsz;
     double *Ldiag = W2 + wsz;
     double *ybuf = Ldiag + (size_t)nb * LSLOT;
-    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] y | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row
+    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] y | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row | [nb] rows 0..31 of the inverse
     const long long tot = (long long)wsz;
     hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag);
     ESFM_HIP_TRY(hipGetLastError());
-    ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(4 * nb + 1), st));
+    ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(5 * nb + 1), st));
     const long long tiles = (long long)nb * (nb + 1) / 2 + nb;           // (i, j), 0 <= j <= i <= nb, j <= nb - 1
-    hipLaunchKernelGGL(chol3_kernel, dim3((unsigned)tiles), dim3(256), 0, st, W, W2, Ldiag, ld, nb, flags + nb, flags + 3 * nb, flags + 2 * nb, d.scal);
+    hipLaunchKernelGGL(chol3_kernel, dim3((unsigned)tiles), dim3(256), 0, st, W, W2, Ldiag, ld, nb, flags + nb, flags + 3 * nb, flags + 2 * nb, flags + 4 * nb + 1, d.scal);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(chol2_back_kernel, dim3(nb), dim3(256), 0, st, d, W2, Ldiag, ld, nb, ybuf, flags);
     ESFM_HIP_TRY(hipGetLastError());
