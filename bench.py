@@ -276,7 +276,7 @@ def main() -> int:
         try:
             tj = json.load(open(tf))
             traffic = tj.get("l2_knn_bf16x1_kernel_bytes_per_launch", tj.get("l2_knn_bf16_kernel_bytes_per_launch"))
-            traffic_ba = tj.get("ba_linearize_kernel_bytes_per_launch")
+            traffic_ba = {"ba": tj.get("ba_linearize_kernel_bytes_per_launch"), "config5": tj.get("ba512_linearize_kernel_bytes_per_launch")}
         except Exception:
             traffic = traffic_ba = None
     # The distance pass runs on the bf16 matrix cores, so the kernel is priced against the dense bf16 MFMA peak; `achieved` is
@@ -380,7 +380,7 @@ def main() -> int:
             "roofline": {"bound": "hbm", "kernel": "ba_linearize_kernel", "achieved": sweep_bytes / lin_s / 1e9 if lin_s > 0 else 0.0,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": (sweep_bytes / lin_s / 1e9 / PEAK_HBM_GBS) if lin_s > 0 else 0.0,
-                         "traffic": traffic_ba if name == "ba" else None,
+                         "traffic": (traffic_ba or {}).get(name),
                          "avg_launch_ms": lin_s * 1e3, "launches": l_n, "algorithmic_bytes_per_launch": sweep_bytes,
                          "algorithmic_bytes_formula": "176*Nobs + 48*Nc + 24*Np (SURVEY 8d)",
                          "designed_bytes_per_launch": sweep_bytes_design,
