@@ -9,7 +9,8 @@
 // best-model / adaptive-iteration-count bookkeeping on the inlier counts -- the result is the one the sequential loop
 // reaches, independent of the chunk size.
 //
-//   essential_solve_kernel   one thread per (pair, iteration): 5-point kernel -> up to 10 essential matrices
+//   essential_setup_kernel   one thread per (pair, iteration): 5-point kernel up to the degree-10 polynomial
+//   essential_roots_kernel   sixteen lanes per (pair, iteration): its roots -> up to 10 essential matrices
 //   essential_score_kernel   one workgroup per (pair, iteration): Sampson inlier count of each of its models
 //   essential_mask_kernel    one workgroup per pair: inlier mask of the winning model
 //   pose_cheirality_kernel   one workgroup per (pair, candidate pose): f64 DLT triangulation + cheirality test per point
@@ -49,76 +50,13 @@ __device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, 
     }
 }
 
-// real roots of c[0] + ... + c[10] z^10 (Durand-Kerner on all ten complex roots, Newton polish of the near-real ones),
-// ascending; returns the count.  Fully unrolled so that the ten root estimates stay in registers; the iteration stops when
-// no estimate moves by more than 1e-13 of its own magnitude (Newton on the real axis then takes the real roots to full
-// precision) or after 300 sweeps -- clusters and multiple roots, which converge linearly, are complex pairs or double roots
-// whose exact position does not decide an inlier count.
-__device__ int real_roots_deg10(const double *c, double *out)
-{
-    if (!(fabs(c[10]) > 0.0)) return 0;
-    double cc[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) cc[k] = c[k] / c[10];
-    double re[10], im[10];
-    double bound = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) bound = fmax(bound, fabs(cc[i]));
-    bound = 1.0 + bound;
-    {
-        double r = 0.5 * bound;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            double sn, cs;
-            sincos(2.0 * 3.14159265358979323846 * i / 10.0 + 0.4, &sn, &cs);
-            re[i] = r * cs; im[i] = r * sn;
-            r *= 0.9;
-        }
-    }
-    for (int it = 0; it < 300; ++it) {
-        double move = 0.0;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            double pr = 1.0, pi = 0.0;
-#pragma unroll
-            for (int k = 9; k >= 0; --k) { const double t = pr * re[i] - pi * im[i] + cc[k]; pi = pr * im[i] + pi * re[i]; pr = t; }
-            double dr = 1.0, di = 0.0;
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                if (j == i) continue;
-                const double ar = re[i] - re[j], ai = im[i] - im[j];
-                const double t = dr * ar - di * ai; di = dr * ai + di * ar; dr = t;
-            }
-            const double den = dr * dr + di * di;
-            const double inv = den > 0.0 ? 1.0 / den : 0.0;
-            const double qr = (pr * dr + pi * di) * inv, qi = (pi * dr - pr * di) * inv;
-            re[i] -= qr; im[i] -= qi;
-            move = fmax(move, (fabs(qr) + fabs(qi)) / (fabs(re[i]) + fabs(im[i]) + 1e-300));
-        }
-        if (move <= 1e-13) break;
-    }
-    int m = 0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        if (fabs(im[i]) > 1e-8 * fmax(1.0, fabs(re[i]))) continue;
-        double z = re[i];
-        for (int nit = 0; nit < 4; ++nit) {
-            double p = 1.0, d = 0.0;
-#pragma unroll
-            for (int k = 9; k >= 0; --k) { d = d * z + p; p = p * z + cc[k]; }
-            if (d == 0.0) break;
-            z -= p / d;
-        }
-        out[m++] = z;
-    }
-    for (int i = 1; i < m; ++i) { const double v = out[i]; int j = i - 1; while (j >= 0 && out[j] > v) { out[j + 1] = out[j]; --j; } out[j + 1] = v; }
-    return m;
-}
-
-// EMEstimatorCallback::runKernel [upstream five-point.cpp]: q1, q2 = 5 normalised correspondences.  Writes up to 10 unit-norm
-// essential matrices (row-major) to E_out, each with its largest-magnitude entry positive, in ascending order of E[0][0]
-// (a basis-independent order; OpenCV's is whatever cv::solvePoly and its SVD basis produce); returns the count.
-__device__ int five_point(const double *q1, const double *q2, double *E_out)
+// EMEstimatorCallback::runKernel [upstream five-point.cpp]: q1, q2 = 5 normalised correspondences -> up to 10 unit-norm essential
+// matrices (row-major), each with its largest-magnitude entry positive, in ascending order of E[0][0] (a basis-independent order;
+// OpenCV's is whatever cv::solvePoly and its SVD basis produce).
+// Split in two since round 3 (see essential_roots_kernel): this part -- null space, the 10 x 20 elimination, B(z) and its determinant
+// -- is one hypothesis per lane and leaves det[11], P[3][4], Qp[3][4], R[3][5], N[4][9] (86 values) in `w`; false = no model.
+constexpr int kSetupDet = 0, kSetupP = 11, kSetupQ = 23, kSetupR = 35, kSetupN = 50;   // (86 values: they fit the 90 doubles a hypothesis owns in `models`)
+__device__ bool five_point_setup(const double *q1, const double *q2, double *w)
 {
     // null space of the 5 x 9 epipolar system by Gauss-Jordan with complete pivoting: 4 basis vectors N[k][9]
     double Q[5][9];
@@ -131,7 +69,7 @@ __device__ int five_point(const double *q1, const double *q2, double *E_out)
     for (int k = 0; k < 5; ++k) {
         int pr = k, pc = k; double best = -1.0;
         for (int r = k; r < 5; ++r) for (int c = k; c < 9; ++c) { const double v = fabs(Q[r][c]); if (v > best) { best = v; pr = r; pc = c; } }
-        if (!(best > 1e-300)) return 0;
+        if (!(best > 1e-300)) return false;
         for (int c = 0; c < 9; ++c) { const double t = Q[k][c]; Q[k][c] = Q[pr][c]; Q[pr][c] = t; }
         for (int r = 0; r < 5; ++r) { const double t = Q[r][k]; Q[r][k] = Q[r][pc]; Q[r][pc] = t; }
         { const int t = colperm[k]; colperm[k] = colperm[pc]; colperm[pc] = t; }
@@ -187,7 +125,7 @@ __device__ int five_point(const double *q1, const double *q2, double *E_out)
     for (int col = 0; col < 10; ++col) {
         int piv = col; double best = fabs(M[col][col]);
         for (int r = col + 1; r < 10; ++r) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
-        if (!(best > 1e-300)) return 0;
+        if (!(best > 1e-300)) return false;
         if (piv != col) for (int c = 0; c < 20; ++c) { const double t = M[col][c]; M[col][c] = M[piv][c]; M[piv][c] = t; }
         const double inv = 1.0 / M[col][col];
         for (int c = col; c < 20; ++c) M[col][c] *= inv;
@@ -218,45 +156,13 @@ __device__ int five_point(const double *q1, const double *q2, double *E_out)
                 for (int k = 0; k < 5; ++k) det[i + j + k] += pq * R[c][k];
             }
     }
-    double zs[10];
-    const int nz = real_roots_deg10(det, zs);
-    int count = 0;
-    for (int t = 0; t < nz && count < 10; ++t) {
-        const double z = zs[t];
-        double Bz[3][3];
-        for (int j = 0; j < 3; ++j) {
-            Bz[j][0] = ((P[j][3] * z + P[j][2]) * z + P[j][1]) * z + P[j][0];
-            Bz[j][1] = ((Qp[j][3] * z + Qp[j][2]) * z + Qp[j][1]) * z + Qp[j][0];
-            Bz[j][2] = (((R[j][4] * z + R[j][3]) * z + R[j][2]) * z + R[j][1]) * z + R[j][0];
-        }
-        // null vector of the (numerically rank-2) B(z): the largest of the three row cross products
-        double bx = 0, by = 0, bw = 0, bn = -1.0;
-        for (int a = 0; a < 3; ++a) {
-            const int b = (a + 1) % 3;
-            const double cx = Bz[a][1] * Bz[b][2] - Bz[a][2] * Bz[b][1], cy = Bz[a][2] * Bz[b][0] - Bz[a][0] * Bz[b][2],
-                         cw = Bz[a][0] * Bz[b][1] - Bz[a][1] * Bz[b][0];
-            const double nn = cx * cx + cy * cy + cw * cw;
-            if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
-        }
-        if (!(bn > 0.0) || fabs(bw) < 1e-10 * sqrt(bn)) continue;
-        const double x = bx / bw, y = by / bw;
-        double Ev[9], nrm = 0.0;
-        for (int a = 0; a < 9; ++a) { Ev[a] = x * N[0][a] + y * N[1][a] + z * N[2][a] + N[3][a]; nrm += Ev[a] * Ev[a]; }
-        nrm = 1.0 / sqrt(nrm);
-        int big = 0;
-        for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
-        if (Ev[big] < 0.0) nrm = -nrm;
-        for (int a = 0; a < 9; ++a) E_out[9 * count + a] = Ev[a] * nrm;
-        ++count;
+    for (int k = 0; k < 11; ++k) w[kSetupDet + k] = det[k];
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 4; ++k) { w[kSetupP + 4 * i + k] = P[i][k]; w[kSetupQ + 4 * i + k] = Qp[i][k]; }
+        for (int k = 0; k < 5; ++k) w[kSetupR + 5 * i + k] = R[i][k];
     }
-    for (int i = 1; i < count; ++i) {   // insertion sort by E[0][0]
-        double tmp[9];
-        for (int a = 0; a < 9; ++a) tmp[a] = E_out[9 * i + a];
-        int j = i - 1;
-        while (j >= 0 && E_out[9 * j] > tmp[0]) { for (int a = 0; a < 9; ++a) E_out[9 * (j + 1) + a] = E_out[9 * j + a]; --j; }
-        for (int a = 0; a < 9; ++a) E_out[9 * (j + 1) + a] = tmp[a];
-    }
-    return count;
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 9; ++a) w[kSetupN + 9 * k + a] = N[k][a];
+    return true;
 }
 
 __device__ __forceinline__ void normalise_pt(const RansacPair &pr, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int i,
@@ -267,8 +173,9 @@ __device__ __forceinline__ void normalise_pt(const RansacPair &pr, const float2 
     x2 = ((double)b.x - pr.cx) / pr.fx; y2 = ((double)b.y - pr.cy) / pr.fy;
 }
 
-// one thread per (pair, iteration of this chunk)
-__global__ __launch_bounds__(64) void essential_solve_kernel(const RansacPair *__restrict__ pairs, int n_pairs, const float2 *__restrict__ p1,
+// one thread per (pair, iteration of this chunk): the polynomial system of its sample -> models[90 g ..] (86 values);
+// n_models[g] = 1 when there is one, -1 when the slot is idle or the sample degenerate (essential_roots_kernel turns both into counts)
+__global__ __launch_bounds__(64) void essential_setup_kernel(const RansacPair *__restrict__ pairs, int n_pairs, const float2 *__restrict__ p1,
                                                              const float2 *__restrict__ p2, const int32_t *__restrict__ samples, int chunk,
                                                              double *__restrict__ models, int32_t *__restrict__ n_models)
 {
@@ -277,14 +184,136 @@ __global__ __launch_bounds__(64) void essential_solve_kernel(const RansacPair *_
     const int pi = g / chunk;
     const RansacPair pr = pairs[pi];
     const int32_t *id = samples + 5 * (size_t)g;
-    if (!pr.active || id[0] < 0) { n_models[g] = 0; return; }
+    if (!pr.active || id[0] < 0) { n_models[g] = -1; return; }
     double q1[10], q2[10];
     for (int k = 0; k < 5; ++k) normalise_pt(pr, p1, p2, id[k], q1[2 * k], q1[2 * k + 1], q2[2 * k], q2[2 * k + 1]);
-    double E[90];
-    const int nm = five_point(q1, q2, E);
-    n_models[g] = nm;
-    double *dst = models + 90 * (size_t)g;
-    for (int k = 0; k < 9 * nm; ++k) dst[k] = E[k];
+    n_models[g] = five_point_setup(q1, q2, models + 90 * (size_t)g) ? 1 : -1;
+}
+
+// Roots of the degree-10 determinant and the models they give: SIXTEEN LANES PER HYPOTHESIS, lane i = root estimate i (ten of them).
+// Until round 3 this was the tail of a one-lane-per-hypothesis kernel whose Durand-Kerner loop updated the ten estimates one after the
+// other, 7.7 us per sweep, and whose launch took as long as its slowest lane: clusters and multiple roots converge linearly and run
+// into the cap of 300 sweeps, so 19 200 hypotheses -- 300 waves, one per CU, 63 lanes of most of them idle -- cost 2.3 ms whatever the
+// average (timing-only builds: cap 80: 0.95 ms, 40: 0.80 ms, 20: 0.72 ms; results change below ~100).  Here a sweep updates all ten
+// estimates at once from the previous sweep's values (Weierstrass / Durand-Kerner in its simultaneous form: the same fixed points,
+// the same quadratic convergence at simple roots): p(z_i) by Horner in every lane, the other estimates through 16-wide shuffles, one
+// division per lane.  A group stops when none of its estimates moves by more than 1e-13 of its magnitude (or after 300 sweeps) and
+// is frozen from then on, so a hypothesis' result does not depend on which others share its wave.  Then lane i polishes its estimate
+// on the real axis if it is real to 1e-8 (Newton), back-substitutes (x, y from the null vector of B(z)), forms E and takes the
+// output slot given by its rank in (E[0][0], z, i) among the group's valid lanes -- the order the sequential code produced by
+// sorting the roots, then the models.
+__global__ __launch_bounds__(256) void essential_roots_kernel(int n, double *__restrict__ models, int32_t *__restrict__ n_models)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int g = t >> 4, i = t & 15, grp = (threadIdx.x & 63) >> 4;
+    const bool in = g < n;
+    const size_t gc = in ? (size_t)g : (size_t)(n - 1);
+    const double *w = models + 90 * gc;
+    const bool have_poly = in && n_models[gc] > 0;
+    const double c10 = have_poly ? w[kSetupDet + 10] : 0.0;
+    const bool have = have_poly && fabs(c10) > 0.0;
+    double cc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) cc[k] = have ? w[kSetupDet + k] / c10 : 0.0;
+    double bound = 0.0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) bound = fmax(bound, fabs(cc[k]));
+    bound = 1.0 + bound;
+    // start: a spiral around the origin inside the Cauchy bound (no symmetry of the polynomial can be a symmetry of the start)
+    double re, im;
+    {
+        double r = 0.5 * bound, sn, cs;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r = k < i ? r * 0.9 : r;
+        sincos(2.0 * 3.14159265358979323846 * (i < 10 ? i : 0) / 10.0 + 0.4, &sn, &cs);
+        re = r * cs; im = r * sn;
+    }
+    bool active = have;                                   // (uniform over the group)
+    for (int it = 0; it < 300; ++it) {
+        if (!__any(active)) break;
+        double pr = 1.0, pim = 0.0;                       // p(z_i), monic, by Horner
+#pragma unroll
+        for (int k = 9; k >= 0; --k) { const double tt = pr * re - pim * im + cc[k]; pim = pr * im + pim * re; pr = tt; }
+        double dr = 1.0, di = 0.0;                        // prod_{j != i} (z_i - z_j), j ascending
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const double zr = __shfl(re, j, 16), zi = __shfl(im, j, 16);
+            const double ar = re - zr, ai = im - zi;
+            const double tt = dr * ar - di * ai, ti = dr * ai + di * ar;
+            dr = j == i ? dr : tt; di = j == i ? di : ti;
+        }
+        const double den = dr * dr + di * di;
+        const double inv = den > 0.0 ? 1.0 / den : 0.0;
+        const double qr = (pr * dr + pim * di) * inv, qi = (pim * dr - pr * di) * inv;
+        const bool upd = active && i < 10;
+        re = upd ? re - qr : re; im = upd ? im - qi : im;
+        const bool still = upd && !((fabs(qr) + fabs(qi)) / (fabs(re) + fabs(im) + 1e-300) <= 1e-13);
+        const unsigned long long moving = __ballot(still);
+        if (((moving >> (16 * grp)) & 0xffffull) == 0ull) active = false;
+    }
+    // near-real estimates: Newton on the real axis
+    const bool is_real = have && i < 10 && !(fabs(im) > 1e-8 * fmax(1.0, fabs(re)));
+    double z = re;
+    for (int nit = 0; nit < 4; ++nit) {
+        double pz = 1.0, dz = 0.0;
+#pragma unroll
+        for (int k = 9; k >= 0; --k) { dz = dz * z + pz; pz = pz * z + cc[k]; }
+        if (dz == 0.0) break;
+        z -= pz / dz;
+    }
+    // B(z), its null vector, E
+    double Bz[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double *P = w + kSetupP + 4 * j, *Q = w + kSetupQ + 4 * j, *R = w + kSetupR + 5 * j;
+        Bz[j][0] = ((P[3] * z + P[2]) * z + P[1]) * z + P[0];
+        Bz[j][1] = ((Q[3] * z + Q[2]) * z + Q[1]) * z + Q[0];
+        Bz[j][2] = (((R[4] * z + R[3]) * z + R[2]) * z + R[1]) * z + R[0];
+    }
+    double bx = 0, by = 0, bw = 0, bn = -1.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int b = (a + 1) % 3;
+        const double cx = Bz[a][1] * Bz[b][2] - Bz[a][2] * Bz[b][1], cy = Bz[a][2] * Bz[b][0] - Bz[a][0] * Bz[b][2],
+                     cw = Bz[a][0] * Bz[b][1] - Bz[a][1] * Bz[b][0];
+        const double nn = cx * cx + cy * cy + cw * cw;
+        if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
+    }
+    const bool valid = is_real && bn > 0.0 && !(fabs(bw) < 1e-10 * sqrt(bn));
+    const double x = bx / bw, y = by / bw;
+    double Ev[9], nrm = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        Ev[a] = x * w[kSetupN + a] + y * w[kSetupN + 9 + a] + z * w[kSetupN + 18 + a] + w[kSetupN + 27 + a];
+        nrm += Ev[a] * Ev[a];
+    }
+    nrm = 1.0 / sqrt(nrm);
+    int big = 0;
+#pragma unroll
+    for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
+    double ebig = Ev[0];
+#pragma unroll
+    for (int a = 1; a < 9; ++a) ebig = a == big ? Ev[a] : ebig;
+    if (ebig < 0.0) nrm = -nrm;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) Ev[a] *= nrm;
+    // output slot: rank in (E[0][0], z, i) among the group's valid lanes
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const double k0 = __shfl(Ev[0], j, 16), kz = __shfl(z, j, 16);
+        const int vj = __shfl((int)valid, j, 16);
+        rank += (vj && (k0 < Ev[0] || (k0 == Ev[0] && (kz < z || (kz == z && j < i))))) ? 1 : 0;
+    }
+    const unsigned long long vm = __ballot(valid);
+    const int count = __popcll((vm >> (16 * grp)) & 0xffffull);
+    // (every lane of the group is past its reads of the setup values: the models take their place)
+    if (valid) {
+        double *dst = models + 90 * gc + 9 * rank;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) dst[a] = Ev[a];
+    }
+    if (in && i == 0) n_models[g] = have ? count : 0;
 }
 
 __device__ __forceinline__ bool sampson_inlier(const double *E, double x1, double y1, double x2, double y2, float t)
@@ -444,8 +473,10 @@ int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs,
     const int n = n_pairs * chunk;
     if (n <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
-    hipLaunchKernelGGL(essential_solve_kernel, dim3((n + 63) / 64), dim3(64), 0, st, pairs, n_pairs, reinterpret_cast<const float2 *>(p1),
+    hipLaunchKernelGGL(essential_setup_kernel, dim3((n + 63) / 64), dim3(64), 0, st, pairs, n_pairs, reinterpret_cast<const float2 *>(p1),
                        reinterpret_cast<const float2 *>(p2), samples, chunk, models, n_models);
+    ESFM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(essential_roots_kernel, dim3((16 * n + 255) / 256), dim3(256), 0, st, n, models, n_models);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(essential_score_kernel, dim3(n), dim3(256), 0, st, pairs, reinterpret_cast<const float2 *>(p1),
                        reinterpret_cast<const float2 *>(p2), chunk, models, n_models, counts);
