@@ -27,9 +27,10 @@ namespace esfm {
 // ---- trivariate polynomial bookkeeping -------------------------------------------------------------------------------
 // cubic monomials in the solver's column order: x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1
 // quadratic order: x2 y2 z2 xy xz yz x y z 1        linear order: x y z 1
-__constant__ signed char kLinLin[4][4] = {      // product of two linear monomials -> quadratic index
+// (constexpr, not __constant__: with the loops unrolled every index below is a compile-time number, so the small arrays live in registers)
+__device__ constexpr signed char kLinLin[4][4] = {      // product of two linear monomials -> quadratic index
     {0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
-__constant__ signed char kQuadLin[10][4] = {    // quadratic monomial x linear monomial -> cubic column
+__device__ constexpr signed char kQuadLin[10][4] = {    // quadratic monomial x linear monomial -> cubic column
     /* x2 */ {0, 2, 4, 5},   /* y2 */ {3, 1, 6, 7},   /* z2 */ {10, 13, 16, 17}, /* xy */ {2, 3, 8, 9}, /* xz */ {4, 8, 10, 11},
     /* yz */ {8, 6, 13, 14}, /* x  */ {5, 9, 11, 12}, /* y  */ {9, 7, 14, 15},   /* z  */ {11, 14, 17, 18}, /* 1 */ {12, 15, 18, 19}};
 
@@ -41,12 +42,23 @@ __device__ __forceinline__ void quad_mul_acc(const double *a, const double *b, d
         for (int j = 0; j < 4; ++j) q[kLinLin[i][j]] += s * a[i] * b[j];
 }
 
-__device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, double s, double *c)  // c += s * q * l (quadratic x linear)
+// The solver's big arrays live in LDS, one column of kSetupLanes lanes per entry (entry e of this lane: lds[e * kSetupLanes + lane]):
+// their rows and columns are picked by data (pivots), which in registers means scratch memory -- 1 400 scratch loads and 1 500 stores
+// in the one-lane-per-hypothesis kernel of rounds 1-2, each a dependent memory round trip.
+constexpr int kSetupLanes = 32;
+struct LdsVec {
+    double *base;                                          // &lds[lane]
+    __device__ __forceinline__ double &operator()(int e) const { return base[e * kSetupLanes]; }
+};
+
+template <typename Row>
+__device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, double s, Row c)  // c += s * q * l (quadratic x linear)
 {
+#pragma unroll
     for (int i = 0; i < 10; ++i) {
         const double qi = s * q[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[kQuadLin[i][j]] += qi * l[j];
+        for (int j = 0; j < 4; ++j) c(kQuadLin[i][j]) += qi * l[j];
     }
 }
 
@@ -56,112 +68,149 @@ __device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, 
 // Split in two since round 3 (see essential_roots_kernel): this part -- null space, the 10 x 20 elimination, B(z) and its determinant
 // -- is one hypothesis per lane and leaves det[11], P[3][4], Qp[3][4], R[3][5], N[4][9] (86 values) in `w`; false = no model.
 constexpr int kSetupDet = 0, kSetupP = 11, kSetupQ = 23, kSetupR = 35, kSetupN = 50;   // (86 values: they fit the 90 doubles a hypothesis owns in `models`)
-__device__ bool five_point_setup(const double *q1, const double *q2, double *w)
+__device__ bool five_point_setup(const double *q1, const double *q2, double *w, LdsVec lds)
 {
     // null space of the 5 x 9 epipolar system by Gauss-Jordan with complete pivoting: 4 basis vectors N[k][9]
-    double Q[5][9];
+    auto Q = [&](int r, int c) -> double & { return lds(9 * r + c); };              // 45 entries (the 10 x 20 system takes their place later)
     for (int i = 0; i < 5; ++i) {
         const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
-        Q[i][0] = x2 * x1; Q[i][1] = x2 * y1; Q[i][2] = x2; Q[i][3] = y2 * x1; Q[i][4] = y2 * y1; Q[i][5] = y2; Q[i][6] = x1; Q[i][7] = y1; Q[i][8] = 1.0;
+        Q(i, 0) = x2 * x1; Q(i, 1) = x2 * y1; Q(i, 2) = x2; Q(i, 3) = y2 * x1; Q(i, 4) = y2 * y1; Q(i, 5) = y2; Q(i, 6) = x1; Q(i, 7) = y1; Q(i, 8) = 1.0;
     }
-    int colperm[9];
-    for (int c = 0; c < 9; ++c) colperm[c] = c;
+    int colperm = 0x876543210 & 0xffffffff;              // nine 4-bit column numbers packed (column 8 in `cp8`): no indexed int array either
+    int cp8 = 8;
+    auto cp_get = [&](int k) { return k == 8 ? cp8 : (colperm >> (4 * k)) & 15; };
+    auto cp_set = [&](int k, int v) { if (k == 8) cp8 = v; else colperm = (colperm & ~(15 << (4 * k))) | (v << (4 * k)); };
     for (int k = 0; k < 5; ++k) {
         int pr = k, pc = k; double best = -1.0;
-        for (int r = k; r < 5; ++r) for (int c = k; c < 9; ++c) { const double v = fabs(Q[r][c]); if (v > best) { best = v; pr = r; pc = c; } }
+        for (int r = k; r < 5; ++r) for (int c = k; c < 9; ++c) { const double v = fabs(Q(r, c)); if (v > best) { best = v; pr = r; pc = c; } }
         if (!(best > 1e-300)) return false;
-        for (int c = 0; c < 9; ++c) { const double t = Q[k][c]; Q[k][c] = Q[pr][c]; Q[pr][c] = t; }
-        for (int r = 0; r < 5; ++r) { const double t = Q[r][k]; Q[r][k] = Q[r][pc]; Q[r][pc] = t; }
-        { const int t = colperm[k]; colperm[k] = colperm[pc]; colperm[pc] = t; }
-        const double inv = 1.0 / Q[k][k];
-        for (int c = 0; c < 9; ++c) Q[k][c] *= inv;
+        for (int c = 0; c < 9; ++c) { const double t = Q(k, c); Q(k, c) = Q(pr, c); Q(pr, c) = t; }
+        for (int r = 0; r < 5; ++r) { const double t = Q(r, k); Q(r, k) = Q(r, pc); Q(r, pc) = t; }
+        { const int t = cp_get(k); cp_set(k, cp_get(pc)); cp_set(pc, t); }
+        const double inv = 1.0 / Q(k, k);
+        for (int c = 0; c < 9; ++c) Q(k, c) *= inv;
         for (int r = 0; r < 5; ++r) {
             if (r == k) continue;
-            const double f = Q[r][k];
-            for (int c = 0; c < 9; ++c) Q[r][c] -= f * Q[k][c];
+            const double f = Q(r, k);
+            for (int c = 0; c < 9; ++c) Q(r, c) -= f * Q(k, c);
         }
     }
-    double N[4][9];
+    auto N = [&](int k, int a) -> double & { return lds(48 + 9 * k + a); };         // 36 entries behind Q
     for (int k = 0; k < 4; ++k) {
         double nn = 1.0;
-        for (int a = 0; a < 9; ++a) N[k][a] = 0.0;
-        N[k][colperm[5 + k]] = 1.0;
-        for (int r = 0; r < 5; ++r) { const double v = -Q[r][5 + k]; N[k][colperm[r]] = v; nn += v * v; }
+        for (int a = 0; a < 9; ++a) N(k, a) = 0.0;
+        N(k, cp_get(5 + k)) = 1.0;
+        for (int r = 0; r < 5; ++r) { const double v = -Q(r, 5 + k); N(k, cp_get(r)) = v; nn += v * v; }
         nn = 1.0 / sqrt(nn);
-        for (int a = 0; a < 9; ++a) N[k][a] *= nn;
+        for (int a = 0; a < 9; ++a) N(k, a) *= nn;
     }
-    // E(x, y, z) = x N0 + y N1 + z N2 + N3: entry (r, c) as the linear polynomial L[r][c][4]
+    // E(x, y, z) = x N0 + y N1 + z N2 + N3: entry (r, c) as the linear polynomial L[r][c][4]; N itself goes out to the roots kernel
     double L[3][3][4];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) for (int k = 0; k < 4; ++k) L[r][c][k] = N[k][3 * r + c];
-    // G = E E' (6 unique quadratic entries) and its trace
-    double G[3][3][10];
+#pragma unroll
     for (int r = 0; r < 3; ++r)
-        for (int c = r; c < 3; ++c) {
-            for (int k = 0; k < 10; ++k) G[r][c][k] = 0.0;
-            for (int k = 0; k < 3; ++k) quad_mul_acc(L[r][k], L[c][k], 1.0, G[r][c]);
-            if (c != r) for (int k = 0; k < 10; ++k) G[c][r][k] = G[r][c][k];
-        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { L[r][c][k] = N(k, 3 * r + c); w[kSetupN + 9 * k + 3 * r + c] = L[r][c][k]; }
+    // G = E E' (6 unique quadratic entries; (r, c) with r <= c is formed as sum_k L[r][k] L[c][k], in that operand order) and its trace
+    auto gram = [&](int r, int c, double (&g)[10]) {
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) g[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) quad_mul_acc(L[lo][k], L[hi][k], 1.0, g);
+    };
     double tr[10];
-    for (int k = 0; k < 10; ++k) tr[k] = G[0][0][k] + G[1][1][k] + G[2][2][k];
-    double M[10][20];
-    for (int r = 0; r < 10; ++r) for (int c = 0; c < 20; ++c) M[r][c] = 0.0;
+    {
+        double g0[10], g1[10], g2[10];
+        gram(0, 0, g0); gram(1, 1, g1); gram(2, 2, g2);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tr[k] = g0[k] + g1[k] + g2[k];
+    }
+    // the 10 x 20 system M (LDS: entry 20 r + c; Q and N above are dead)
+    auto Mrow = [&](int r) { return LdsVec{&lds(20 * r)}; };
+    for (int e = 0; e < 200; ++e) lds(e) = 0.0;
     // row 0: det E = sum_c E[0][c] * cofactor(0, c)
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
         double cof[10];
+#pragma unroll
         for (int k = 0; k < 10; ++k) cof[k] = 0.0;
         quad_mul_acc(L[1][c1], L[2][c2], 1.0, cof);
         quad_mul_acc(L[1][c2], L[2][c1], -1.0, cof);
-        cubic_mul_acc(cof, L[0][c], 1.0, M[0]);
+        cubic_mul_acc(cof, L[0][c], 1.0, Mrow(0));
     }
-    // rows 1..9: 2 (E E') E - tr(E E') E
-    for (int r = 0; r < 3; ++r)
+    // rows 1..9: 2 (E E') E - tr(E E') E   (row r of E E' formed when its three rows of M are)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double G[3][10];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gram(r, k, G[k]);
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            double *row = M[1 + 3 * r + c];
-            for (int k = 0; k < 3; ++k) cubic_mul_acc(G[r][k], L[k][c], 2.0, row);
+            const LdsVec row = Mrow(1 + 3 * r + c);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cubic_mul_acc(G[k], L[k][c], 2.0, row);
             cubic_mul_acc(tr, L[r][c], -1.0, row);
         }
+    }
+    auto M = [&](int r, int c) -> double & { return lds(20 * r + c); };
     // Gauss-Jordan on the first ten columns
     for (int col = 0; col < 10; ++col) {
-        int piv = col; double best = fabs(M[col][col]);
-        for (int r = col + 1; r < 10; ++r) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
+        int piv = col; double best = fabs(M(col, col));
+        for (int r = col + 1; r < 10; ++r) { const double v = fabs(M(r, col)); if (v > best) { best = v; piv = r; } }
         if (!(best > 1e-300)) return false;
-        if (piv != col) for (int c = 0; c < 20; ++c) { const double t = M[col][c]; M[col][c] = M[piv][c]; M[piv][c] = t; }
-        const double inv = 1.0 / M[col][col];
-        for (int c = col; c < 20; ++c) M[col][c] *= inv;
+        if (piv != col) for (int c = 0; c < 20; ++c) { const double t = M(col, c); M(col, c) = M(piv, c); M(piv, c) = t; }
+        const double inv = 1.0 / M(col, col);
+        double prow[20];                                   // the pivot row in registers for the eliminations (c < col: not used)
+#pragma unroll
+        for (int c = 0; c < 20; ++c) { prow[c] = c >= col ? M(col, c) * inv : 0.0; if (c >= col) M(col, c) = prow[c]; }
         for (int r = 0; r < 10; ++r) {
             if (r == col) continue;
-            const double f = M[r][col];
+            const double f = M(r, col);
             if (f == 0.0) continue;
-            for (int c = col; c < 20; ++c) M[r][c] -= f * M[col][c];
+#pragma unroll
+            for (int c = 0; c < 20; ++c) if (c >= col) M(r, c) -= f * prow[c];
         }
     }
     // B(z): rows (4,5), (6,7), (8,9); P, Qp degree 3 and R degree 4, lowest degree first
     double P[3][4], Qp[3][4], R[3][5];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double *a = &M[2 * i + 4][10], *b = &M[2 * i + 5][10];
+        double a[10], b[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { a[k] = M(2 * i + 4, 10 + k); b[k] = M(2 * i + 5, 10 + k); }
         P[i][3] = -b[0]; P[i][2] = a[0] - b[1]; P[i][1] = a[1] - b[2]; P[i][0] = a[2];
         Qp[i][3] = -b[3]; Qp[i][2] = a[3] - b[4]; Qp[i][1] = a[4] - b[5]; Qp[i][0] = a[5];
         R[i][4] = -b[6]; R[i][3] = a[6] - b[7]; R[i][2] = a[7] - b[8]; R[i][1] = a[8] - b[9]; R[i][0] = a[9];
     }
     double det[11];
+#pragma unroll
     for (int k = 0; k < 11; ++k) det[k] = 0.0;
-    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
-    const double sgn[6] = {1, -1, -1, 1, 1, -1};
+    constexpr int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    constexpr double sgn[6] = {1, -1, -1, 1, 1, -1};
+#pragma unroll
     for (int s = 0; s < 6; ++s) {
         const int a = perm[s][0], b = perm[s][1], c = perm[s][2];
+#pragma unroll
         for (int i = 0; i < 4; ++i)
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double pq = sgn[s] * P[a][i] * Qp[b][j];
+#pragma unroll
                 for (int k = 0; k < 5; ++k) det[i + j + k] += pq * R[c][k];
             }
     }
+#pragma unroll
     for (int k = 0; k < 11; ++k) w[kSetupDet + k] = det[k];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
         for (int k = 0; k < 4; ++k) { w[kSetupP + 4 * i + k] = P[i][k]; w[kSetupQ + 4 * i + k] = Qp[i][k]; }
+#pragma unroll
         for (int k = 0; k < 5; ++k) w[kSetupR + 5 * i + k] = R[i][k];
     }
-    for (int k = 0; k < 4; ++k) for (int a = 0; a < 9; ++a) w[kSetupN + 9 * k + a] = N[k][a];
     return true;
 }
 
@@ -173,13 +222,37 @@ __device__ __forceinline__ void normalise_pt(const RansacPair &pr, const float2 
     x2 = ((double)b.x - pr.cx) / pr.fx; y2 = ((double)b.y - pr.cy) / pr.fy;
 }
 
+// value of lane J of the caller's row of 16 lanes: one v_mov_b64_dpp (row_newbcast) instead of the two ds_bpermute_b32 and their LDS
+// round trip that __shfl(v, J, 16) costs.  (The s_nop covers the DPP read-after-VALU-write hazard, which the compiler does not track
+// through inline asm.)
+#ifdef ESFM_DK_HIST
+// timing / diagnosis build: histogram of Durand-Kerner sweeps per hypothesis (scratch/dk_hist.py)
+__device__ unsigned int g_dk_hist[301];
+extern "C" int esfm_debug_dk_hist(unsigned int *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dk_hist), sizeof(g_dk_hist)); }
+#endif
+template <int J>
+__device__ __forceinline__ double row16_bcast(double v)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+    return r;
+}
+template <int J>
+__device__ __forceinline__ void dk_factor(double re, double im, int i, double &dr, double &di)
+{
+    const double ar = re - row16_bcast<J>(re), ai = im - row16_bcast<J>(im);
+    const double tt = dr * ar - di * ai, ti = dr * ai + di * ar;
+    dr = J == i ? dr : tt; di = J == i ? di : ti;
+}
+
 // one thread per (pair, iteration of this chunk): the polynomial system of its sample -> models[90 g ..] (86 values);
 // n_models[g] = 1 when there is one, -1 when the slot is idle or the sample degenerate (essential_roots_kernel turns both into counts)
-__global__ __launch_bounds__(64) void essential_setup_kernel(const RansacPair *__restrict__ pairs, int n_pairs, const float2 *__restrict__ p1,
-                                                             const float2 *__restrict__ p2, const int32_t *__restrict__ samples, int chunk,
-                                                             double *__restrict__ models, int32_t *__restrict__ n_models)
+__global__ __launch_bounds__(kSetupLanes) void essential_setup_kernel(const RansacPair *__restrict__ pairs, int n_pairs, const float2 *__restrict__ p1,
+                                                                      const float2 *__restrict__ p2, const int32_t *__restrict__ samples, int chunk,
+                                                                      double *__restrict__ models, int32_t *__restrict__ n_models)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
+    __shared__ double lds[200 * kSetupLanes];             // 51 KB: three workgroups per CU, 19 200 hypotheses resident at once
+    const int g = blockIdx.x * kSetupLanes + threadIdx.x;
     if (g >= n_pairs * chunk) return;
     const int pi = g / chunk;
     const RansacPair pr = pairs[pi];
@@ -187,7 +260,7 @@ __global__ __launch_bounds__(64) void essential_setup_kernel(const RansacPair *_
     if (!pr.active || id[0] < 0) { n_models[g] = -1; return; }
     double q1[10], q2[10];
     for (int k = 0; k < 5; ++k) normalise_pt(pr, p1, p2, id[k], q1[2 * k], q1[2 * k + 1], q2[2 * k], q2[2 * k + 1]);
-    n_models[g] = five_point_setup(q1, q2, models + 90 * (size_t)g) ? 1 : -1;
+    n_models[g] = five_point_setup(q1, q2, models + 90 * (size_t)g, LdsVec{lds + threadIdx.x}) ? 1 : -1;
 }
 
 // Roots of the degree-10 determinant and the models they give: SIXTEEN LANES PER HYPOTHESIS, lane i = root estimate i (ten of them).
@@ -196,9 +269,9 @@ __global__ __launch_bounds__(64) void essential_setup_kernel(const RansacPair *_
 // into the cap of 300 sweeps, so 19 200 hypotheses -- 300 waves, one per CU, 63 lanes of most of them idle -- cost 2.3 ms whatever the
 // average (timing-only builds: cap 80: 0.95 ms, 40: 0.80 ms, 20: 0.72 ms; results change below ~100).  Here a sweep updates all ten
 // estimates at once from the previous sweep's values (Weierstrass / Durand-Kerner in its simultaneous form: the same fixed points,
-// the same quadratic convergence at simple roots): p(z_i) by Horner in every lane, the other estimates through 16-wide shuffles, one
-// division per lane.  A group stops when none of its estimates moves by more than 1e-13 of its magnitude (or after 300 sweeps) and
-// is frozen from then on, so a hypothesis' result does not depend on which others share its wave.  Then lane i polishes its estimate
+// the same quadratic convergence at simple roots): p(z_i) by Horner in every lane, the other estimates through DPP row broadcasts, one
+// division per lane.  A group stops when every estimate is at rest (step <= 1e-13 of its magnitude, or down at its evaluation noise;
+// or after 300 sweeps) and is frozen from then on, so a hypothesis' result does not depend on which others share its wave.  Then lane i polishes its estimate
 // on the real axis if it is real to 1e-8 (Newton), back-substitutes (x, y from the null vector of B(z)), forms E and takes the
 // output slot given by its rank in (E[0][0], z, i) among the group's valid lanes -- the order the sequential code produced by
 // sorting the roots, then the models.
@@ -215,42 +288,61 @@ __global__ __launch_bounds__(256) void essential_roots_kernel(int n, double *__r
     double cc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) cc[k] = have ? w[kSetupDet + k] / c10 : 0.0;
-    double bound = 0.0;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) bound = fmax(bound, fabs(cc[k]));
-    bound = 1.0 + bound;
-    // start: a spiral around the origin inside the Cauchy bound (no symmetry of the polynomial can be a symmetry of the start)
+    // start: a spiral around the origin (no symmetry of the polynomial can be a symmetry of the start)
     double re, im;
     {
-        double r = 0.5 * bound, sn, cs;
+        // start radius: half of Fujiwara's bound 2 max_k |c_{n-k}|^(1/k) (every root lies within it).  Cauchy's 1 + max |c_k|, used
+        // until round 3, is looser by orders of magnitude here, and the estimates approach from outside by a factor ~ 9/10 per sweep:
+        // mean sweeps per hypothesis 75 -> 45, median 60 -> 28 (scratch/dk_hist.py), the same RANSAC outcome on every test
+        double fuji = 0.0, sn, cs;
+#pragma unroll
+        for (int k = 1; k <= 10; ++k) fuji = fmax(fuji, pow(fabs(cc[10 - k]) * (k == 10 ? 0.5 : 1.0), 1.0 / k));
+        double r = fuji;
+        if (!(r > 1e-300)) r = 1.0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) r = k < i ? r * 0.9 : r;
         sincos(2.0 * 3.14159265358979323846 * (i < 10 ? i : 0) / 10.0 + 0.4, &sn, &cs);
         re = r * cs; im = r * sn;
     }
     bool active = have;                                   // (uniform over the group)
+    double best_mv = 1e300;
+    int stale = 0;
+#ifdef ESFM_DK_HIST
+    int my_sweeps = 0;
+#endif
     for (int it = 0; it < 300; ++it) {
         if (!__any(active)) break;
+#ifdef ESFM_DK_HIST
+        my_sweeps += active ? 1 : 0;
+#endif
         double pr = 1.0, pim = 0.0;                       // p(z_i), monic, by Horner
 #pragma unroll
         for (int k = 9; k >= 0; --k) { const double tt = pr * re - pim * im + cc[k]; pim = pr * im + pim * re; pr = tt; }
         double dr = 1.0, di = 0.0;                        // prod_{j != i} (z_i - z_j), j ascending
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const double zr = __shfl(re, j, 16), zi = __shfl(im, j, 16);
-            const double ar = re - zr, ai = im - zi;
-            const double tt = dr * ar - di * ai, ti = dr * ai + di * ar;
-            dr = j == i ? dr : tt; di = j == i ? di : ti;
-        }
+        dk_factor<0>(re, im, i, dr, di); dk_factor<1>(re, im, i, dr, di); dk_factor<2>(re, im, i, dr, di); dk_factor<3>(re, im, i, dr, di);
+        dk_factor<4>(re, im, i, dr, di); dk_factor<5>(re, im, i, dr, di); dk_factor<6>(re, im, i, dr, di); dk_factor<7>(re, im, i, dr, di);
+        dk_factor<8>(re, im, i, dr, di); dk_factor<9>(re, im, i, dr, di);
         const double den = dr * dr + di * di;
         const double inv = den > 0.0 ? 1.0 / den : 0.0;
         const double qr = (pr * dr + pim * di) * inv, qi = (pim * dr - pr * di) * inv;
         const bool upd = active && i < 10;
         re = upd ? re - qr : re; im = upd ? im - qi : im;
-        const bool still = upd && !((fabs(qr) + fabs(qi)) / (fabs(re) + fabs(im) + 1e-300) <= 1e-13);
+        // An estimate is at rest when its step is below 1e-13 of its magnitude -- or when it has reached the noise of its own
+        // evaluation: an ill-conditioned root of this degree-10 polynomial never gets its step under 1e-13 (5.4 % of the hypotheses
+        // used to run into the cap of 300 sweeps for that), it jitters at 1e-12 .. 1e-9 instead.  So: a step that is already small
+        // (< 1e-7) and has not halved for twelve sweeps is noise.  Linear convergence at a cluster (ratio (m - 1) / m <= 0.9 per
+        // sweep) halves within seven and goes on; the approach from the start circle has steps of ~0.1 and is not affected.
+        const double mv = (fabs(qr) + fabs(qi)) / (fabs(re) + fabs(im) + 1e-300);
+        const bool better = mv < 0.5 * best_mv;
+        best_mv = better ? mv : best_mv;
+        stale = better ? 0 : stale + 1;
+        const bool still = upd && !(mv <= 1e-13) && !(stale >= 12 && best_mv < 1e-7);
         const unsigned long long moving = __ballot(still);
         if (((moving >> (16 * grp)) & 0xffffull) == 0ull) active = false;
     }
+#ifdef ESFM_DK_HIST
+    if (have && i == 0) atomicAdd(&g_dk_hist[my_sweeps], 1u);
+#endif
     // near-real estimates: Newton on the real axis
     const bool is_real = have && i < 10 && !(fabs(im) > 1e-8 * fmax(1.0, fabs(re)));
     double z = re;
@@ -473,7 +565,7 @@ int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs,
     const int n = n_pairs * chunk;
     if (n <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
-    hipLaunchKernelGGL(essential_setup_kernel, dim3((n + 63) / 64), dim3(64), 0, st, pairs, n_pairs, reinterpret_cast<const float2 *>(p1),
+    hipLaunchKernelGGL(essential_setup_kernel, dim3((n + kSetupLanes - 1) / kSetupLanes), dim3(kSetupLanes), 0, st, pairs, n_pairs, reinterpret_cast<const float2 *>(p1),
                        reinterpret_cast<const float2 *>(p2), samples, chunk, models, n_models);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(essential_roots_kernel, dim3((16 * n + 255) / 256), dim3(256), 0, st, n, models, n_models);
