@@ -67,6 +67,10 @@ struct esfm_ctx {
     size_t last_pair_bytes = 0;
     int l2_audit = 0;   // esfm_ctx_set_l2_audit: 0 product path, 1 no re-scan, 2 exact scan of every query, 3 one-product pass alone
     int pin(size_t bytes);
+    // a second pinned area for the per-round tables of the RANSAC loops (samples up, model counts and inlier counts down)
+    void *pinned_rounds = nullptr;
+    size_t pinned_rounds_cap = 0;
+    int pin_rounds(size_t bytes);
     // optional per-kernel hipEvent timing (esfm_ctx_set_kernel_timing)
     bool timing = false;
     struct TimedLaunch { int id; hipEvent_t a, b; };

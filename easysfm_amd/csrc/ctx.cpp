@@ -52,6 +52,18 @@ int esfm_ctx::pin(size_t bytes)
     return ESFM_OK;
 }
 
+int esfm_ctx::pin_rounds(size_t bytes)
+{
+    if (bytes <= pinned_rounds_cap) return ESFM_OK;
+    if (pinned_rounds) (void)hipHostFree(pinned_rounds);
+    pinned_rounds = nullptr; pinned_rounds_cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    hipError_t e = hipHostMalloc(&pinned_rounds, want, hipHostMallocDefault);
+    if (e != hipSuccess) { esfm::set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); return ESFM_ERR_OOM; }
+    pinned_rounds_cap = want;
+    return ESFM_OK;
+}
+
 hipEvent_t esfm_ctx::take_event()
 {
     if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
@@ -160,6 +172,7 @@ int esfm_ctx_destroy(esfm_ctx *ctx)
                             &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi, &ctx->knn_d2};
     for (auto *b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_rounds) (void)hipHostFree(ctx->pinned_rounds);
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

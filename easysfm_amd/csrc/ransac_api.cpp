@@ -148,13 +148,14 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
     if (int rc = ctx->stage_a.reserve(sizeof(float) * 2 * (size_t)std::max(n_total, 1))) return rc;
     if (int rc = ctx->stage_b.reserve(sizeof(float) * 2 * (size_t)std::max(n_total, 1))) return rc;
     if (int rc = ctx->stage_c.reserve(sizeof(RansacPair) * (size_t)n_pairs)) return rc;
-    if (int rc = ctx->stage_d.reserve(sizeof(int32_t) * 5 * n_slots + sizeof(int32_t) * 11 * n_slots)) return rc;   // samples | n_models | counts
+    if (int rc = ctx->stage_d.reserve(sizeof(int32_t) * (16 * n_slots + 3 * (size_t)n_pairs))) return rc;   // samples | n_models | counts | take
     if (int rc = ctx->stage_e.reserve(sizeof(double) * 90 * n_slots + sizeof(double) * 9 * (size_t)n_pairs + (size_t)std::max(n_total, 1))) return rc;
     float *d_p1 = ctx->stage_a.as<float>(), *d_p2 = ctx->stage_b.as<float>();
     RansacPair *d_tab = ctx->stage_c.as<RansacPair>();
     int32_t *d_samples = ctx->stage_d.as<int32_t>();
     int32_t *d_nmodels = d_samples + 5 * n_slots;
     int32_t *d_counts = d_nmodels + n_slots;
+    int32_t *d_take = d_counts + 10 * n_slots;
     double *d_models = ctx->stage_e.as<double>();
     double *d_best = d_models + 90 * n_slots;
     uint8_t *d_mask = reinterpret_cast<uint8_t *>(d_best + 9 * (size_t)n_pairs);
@@ -164,7 +165,10 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
     }
     ESFM_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(double) * 9 * (size_t)n_pairs, st));
 
-    std::vector<int32_t> samples(5 * n_slots), nmodels(n_slots), counts(10 * n_slots);
+    // the per-round tables in pinned memory (pageable copies of 0.4 MB up and 0.85 MB down per round were staged by the runtime)
+    if (int rc = ctx->pin_rounds(sizeof(int32_t) * (16 * n_slots + 3 * (size_t)n_pairs))) return rc;
+    int32_t *samples = static_cast<int32_t *>(ctx->pinned_rounds), *nmodels = samples + 5 * n_slots, *counts = nmodels + n_slots,
+            *take = counts + 10 * n_slots;
     for (;;) {
         bool any = false;
         for (int p = 0; p < n_pairs; ++p) {
@@ -181,13 +185,13 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
         }
         if (!any) break;
         ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * 5 * n_slots, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples, sizeof(int32_t) * 5 * n_slots, hipMemcpyHostToDevice, st));
         ESFM_HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * 10 * n_slots, st));
         if (int rc = esfm::launch_essential_chunk(st, d_tab, n_pairs, d_p1, d_p2, d_samples, kChunk, d_models, d_nmodels, d_counts, ctx)) return rc;
-        ESFM_HIP_TRY(hipMemcpyAsync(nmodels.data(), d_nmodels, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, sizeof(int32_t) * 10 * n_slots, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(hipMemcpyAsync(nmodels, d_nmodels, sizeof(int32_t) * 11 * n_slots, hipMemcpyDeviceToHost, st));   // n_models | counts
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         // replay RANSACPointSetRegistrator::run over this chunk
+        int n_take = 0;
         for (int p = 0; p < n_pairs; ++p) {
             State &s = S[(size_t)p];
             if (s.done) continue;
@@ -210,9 +214,13 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
                 }
                 if (s.iter >= s.niters) s.done = true;
             }
-            if (best_slot >= 0)
-                ESFM_HIP_TRY(hipMemcpyAsync(d_best + 9 * (size_t)p, d_models + 90 * (size_t)best_slot + 9 * (size_t)best_m, sizeof(double) * 9,
-                                            hipMemcpyDeviceToDevice, st));
+            if (best_slot >= 0) { take[3 * n_take] = p; take[3 * n_take + 1] = (int32_t)best_slot; take[3 * n_take + 2] = best_m; ++n_take; }
+        }
+        // the pairs' new best models in ONE launch (a 72-byte device-to-device copy per pair was 300 API calls per round: most of the
+        // batch's host time once the solver stopped being it)
+        if (n_take > 0) {
+            ESFM_HIP_TRY(hipMemcpyAsync(d_take, take, sizeof(int32_t) * 3 * (size_t)n_take, hipMemcpyHostToDevice, st));
+            if (int rc = esfm::launch_essential_take_best(st, d_take, n_take, d_models, d_best)) return rc;
         }
     }
     for (int p = 0; p < n_pairs; ++p) {

@@ -576,6 +576,23 @@ int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs,
     return ESFM_OK;
 }
 
+__global__ __launch_bounds__(256) void essential_take_best_kernel(const int32_t *__restrict__ take, int n_take, const double *__restrict__ models,
+                                                                  double *__restrict__ best)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 9 * n_take) return;
+    const int e = t / 9, a = t % 9;
+    best[9 * (size_t)take[3 * e] + a] = models[90 * (size_t)take[3 * e + 1] + 9 * (size_t)take[3 * e + 2] + a];
+}
+
+int launch_essential_take_best(hipStream_t st, const int32_t *take, int n_take, const double *models, double *best)
+{
+    if (n_take <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(essential_take_best_kernel, dim3((9 * n_take + 255) / 256), dim3(256), 0, st, take, n_take, models, best);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
 int launch_essential_mask(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *best, uint8_t *mask)
 {
     if (n_pairs <= 0) return ESFM_OK;

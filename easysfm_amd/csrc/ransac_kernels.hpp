@@ -16,6 +16,8 @@ struct RansacPair {       // one image pair's correspondences inside the concate
 
 int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const int32_t *samples,
                            int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx);
+// best[9 take[3 e]] = models[90 take[3 e + 1] + 9 take[3 e + 2]] (9 doubles) for e < n_take
+int launch_essential_take_best(hipStream_t st, const int32_t *take, int n_take, const double *models, double *best);
 int launch_essential_mask(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *best, uint8_t *mask);
 int launch_pose_cheirality(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *poses,
                            const uint8_t *in_mask, int n_total, uint8_t *cand_mask, int32_t *good);
