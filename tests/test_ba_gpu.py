@@ -295,6 +295,19 @@ def test_ba_medium_large_camera_count_paths(gpu_ctx, oracle_lib):
     assert np.allclose(cams, rc, rtol=RTOL_PAR, atol=ATOL_PAR) and np.allclose(pts, rp, rtol=RTOL_PAR, atol=ATOL_PAR)
 
 
+@pytest.mark.parametrize("n_cam,n_pt,k,seed", [(30, 2500, 5, 31), (43, 4000, 6, 32), (107, 9000, 6, 33)])
+def test_ba_tiled_cholesky_sizes(gpu_ctx, oracle_lib, n_cam, n_pt, k, seed):
+    """Reduced systems of 180, 258 and 642 unknowns: 3, 5 and 11 block columns of the dataflow Cholesky (chol3_kernel), with 12, 62
+    and 62 identity-padded rows in the last tile -- the chain workgroup's hand-over (early rows of the tile inverse on a second flag,
+    the inverse formed beside the pivot chains) at the shortest chains there are; the trace must follow the oracle's."""
+    sc = synth.ba_scene(n_cam, n_pt, k, radius=15.0, extent=3.0, seed=seed)
+    opt, ropt = _solve_both(oracle_lib, sc, 3)
+    cams, pts, summ = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
+    rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, ropt)
+    _compare(summ, rs, oracle_lib)
+    assert np.allclose(cams, rc, rtol=RTOL_PAR, atol=ATOL_PAR) and np.allclose(pts, rp, rtol=RTOL_PAR, atol=ATOL_PAR)
+
+
 def test_ba_512_full_size_properties(gpu_ctx, oracle_lib):
     """BASELINE config 5 size on one GPU (512 cams, 300k pts, 3M obs; reduced system 3072 x 3072): too big for
     an oracle solve in the CPU test budget, so size-independent properties: every LM step the solver accepts
