@@ -57,6 +57,56 @@ def test_sor_full_size_properties(gpu_ctx):
     assert 0.9 * n < keep.sum() <= n
 
 
+def _sor_clouds():
+    rng = np.random.default_rng(7)
+    out = {}
+    n = 100000
+    c = rng.uniform(-20, 20, (40, 3))
+    P = (c[rng.integers(0, 40, n)] + rng.normal(0, 0.3, (n, 3)) * rng.uniform(0.2, 3, (n, 1))).astype(np.float32)
+    P[:2000] = rng.uniform(-60, 60, (2000, 3)).astype(np.float32)            # far outliers: the points the filter exists for
+    out["clustered"] = P
+    P = rng.uniform(-5, 5, (50000, 3)).astype(np.float32); P[:, 0] = 1.25      # no extent along x: the sort axis must be another one
+    out["plane"] = P
+    P = np.zeros((20000, 3), np.float32); P[:, 1] = rng.uniform(-5, 5, 20000)   # one axis only, thousands of exactly equal keys elsewhere
+    out["line"] = P
+    P = np.repeat(rng.uniform(-1, 1, (300, 3)).astype(np.float32), 40, axis=0)  # every point 40 times: the window's edge falls inside ties
+    out["duplicates"] = P
+    for P in out.values():
+        P[17] = [np.nan, 0, 0]; P[123, 2] = np.inf                              # non-finite points are neither queries nor candidates
+    return out
+
+
+def test_sor_sorted_window_equals_all_candidates(gpu_ctx):
+    """From 4096 points on the k-NN pass sweeps a window of the cloud sorted along its longest axis instead of every point (round 3).
+    The distances it keeps must be the brute-force ones bit for bit on any cloud: checked against a float32 numpy evaluation in the
+    kernel's operation order on sampled points of clustered / planar / collinear / duplicated clouds with non-finite entries, and
+    against the all-candidates kernel itself (ESFM_SOR_BRUTE=1, a fresh process) on every point."""
+    import subprocess, sys, tempfile
+    clouds = _sor_clouds()
+    rng = np.random.default_rng(3)
+    got = {}
+    for name, P in clouds.items():
+        keep, md, thr = E.sor_filter(P, 50, 2.0, gpu_ctx)
+        got[name] = md
+        fin = np.isfinite(P).all(1)
+        assert np.all(md[~fin] == 0)                                               # (non-finite points: distance 0, as in PCL)
+        Pf = P[fin]
+        for i in rng.choice(np.nonzero(fin)[0], 48, replace=False):
+            d = P[i][None, :] - Pf
+            d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
+            row = np.sort(d2)[1:51]
+            assert md[i] == np.float32(np.cumsum(np.sqrt(row).astype(np.float64))[-1] / 50), (name, int(i))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), **clouds)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import easysfm_amd as E; z = np.load(%r); ctx = E.Context(0); "
+                "np.savez(%r, **{k: E.sor_filter(z[k], 50, 2.0, ctx)[1] for k in z.files})"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "in.npz"), os.path.join(td, "out.npz")))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, ESFM_SOR_BRUTE="1"))
+        ref = np.load(os.path.join(td, "out.npz"))
+        for name in clouds:
+            assert np.array_equal(got[name].view(np.uint32), ref[name].view(np.uint32)), name
+
+
 def test_sor_mirror_and_ply_roundtrip(gpu_ctx, tmp_path):
     """CProceesing.SORFilter + DataIO.writePlyFile as sfm.cpp:333-337 chains them."""
     rng = np.random.default_rng(2)
