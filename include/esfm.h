@@ -83,7 +83,7 @@ typedef enum esfm_kernel_id {
     ESFM_K_L2_RESCAN = 5,     /* l2_exact_scan_kernel                                           */
     ESFM_K_SOR_KNN = 6,       /* sor_knn_mean_kernel: k-NN mean distances of the outlier filter   */
     ESFM_K_TRIANGULATE = 7,   /* triangulate_dlt_kernel                                         */
-    ESFM_K_RANSAC = 8,        /* essential_solve_kernel + essential_score_kernel (one chunk)    */
+    ESFM_K_RANSAC = 8,        /* essential_setup + _roots + _score kernels (one chunk)         */
     ESFM_K_SURF_DET = 9,      /* surf_det_trace_kernel                                          */
     ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
     ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
