@@ -7,7 +7,7 @@
 //   chol2_step_kernel(k)   ONE launch per block column: trailing update C_ij -= X_ik X_jk' on v_mfma_f64_16x16x4_f64; its first
 //                          workgroup factors the next diagonal tile and inverts the factor (tile_potrf64_inv); the workgroups
 //                          of the next block column wait for that inverse and turn their tiles into factor tiles X_i,k+1
-//   chol2_back_kernel      the whole backward substitution in one launch, solution blocks handed on through flags in memory
+//   chol2_back_kernel      the whole backward substitution in one launch, solution blocks handed on through memory (a block is its own flag)
 // n <= 176 (BASELINE's BA-25: n = 150): ba_chol_small_kernel, the whole solve and the camera step in one workgroup.
 // Both sit on potrf16_fused_*: one wave factors a 16 x 16 block and inverts the factor in one pass of generated, scheduled asm.
 #include "ba_kernels.hpp"
@@ -16,12 +16,16 @@ namespace esfm {
 
 constexpr int CB = 64;          // tile edge
 
+// "not there yet" in the solution buffer of the backward substitution: all ones, a NaN no arithmetic produces (chol2_back_kernel)
+constexpr unsigned long long kYPending = ~0ull;
+
 __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__restrict__ W, int ld, int nb, double radius,
-                                                            double min_diag, double max_diag)
+                                                            double min_diag, double max_diag, double *__restrict__ ybuf)
 {
     const int n = 6 * d.n_cam;
     const long long rows = (long long)(nb + 1) * CB;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long long)nb * CB) reinterpret_cast<unsigned long long *>(ybuf)[e] = kYPending;
     if (e >= rows * ld) return;
     const int i = (int)(e / ld), j = (int)(e % ld);
     double v = 0.0;
@@ -506,10 +510,13 @@ __global__ __launch_bounds__(256) void chol3_kernel(double *__restrict__ W, doub
     CHOL_T(j, 9);
 }
 
-// The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles; flags: nb ints,
-// zeroed before the launch.
+// The whole backward substitution L' y = z.  z_b = row 0 of the factor's tile (nb, b) in W2; ybuf: nb * CB doubles, every one the
+// "pending" pattern before the launch (chol_assemble_kernel).  A solution block is its own flag: the 64 threads that need y_i poll
+// its 64 words until none is pending -- one memory round trip per link of the chain instead of two (flag, then data: 2.35 us per
+// block, 113 us for BA-512's 48; now see DESIGN.md), and the publisher just stores.  8-byte stores are single transactions, so a
+// word is either pending or final.
 __global__ __launch_bounds__(256) void chol2_back_kernel(BADev d, const double *__restrict__ W2, const double *__restrict__ Ldiag, int ld, int nb,
-                                                         double *__restrict__ ybuf, int *__restrict__ flags)
+                                                         double *__restrict__ ybuf)
 {
     __shared__ double z[CB];
     __shared__ double y[CB];
@@ -525,16 +532,16 @@ __global__ __launch_bounds__(256) void chol2_back_kernel(BADev d, const double *
         double l[CB / 4];
 #pragma unroll
         for (int q = 0; q < CB / 4; ++q) l[q] = W2[(size_t)(i * CB + g + 4 * q) * ld + b * CB + t];
-        if (tid == 0) {
+        if (tid < CB) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(ybuf) + i * CB + tid;
+            unsigned long long v;
             long spins = 0;
-            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            while ((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kYPending) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1L << 24)) { gave_up = 1; break; }        // never seen; keeps a broken launch from hanging the device
+                if (++spins > (1L << 24)) { gave_up = 1; v = 0ull; break; }    // never seen; keeps a broken launch from hanging the device
             }
+            y[tid] = __longlong_as_double((long long)v);
         }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (tid < CB) y[tid] = ld_coh(&ybuf[i * CB + tid]);
         __syncthreads();
         double s = 0.0;
 #pragma unroll
@@ -553,13 +560,13 @@ __global__ __launch_bounds__(256) void chol2_back_kernel(BADev d, const double *
         part[g][t] = s;
         __syncthreads();
         if (tid < CB) {
-            const double yb = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
-            st_coh(&ybuf[b * CB + tid], yb);
+            double yb = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
             const bool fail = d.scal[SC_CHOL_FAIL] != 0.0 || gave_up;
+            if (__double_as_longlong(yb) == (long long)kYPending) yb = __longlong_as_double(0x7ff8000000000000ll);   // (never: keep the chain alive anyway)
+            st_coh(&ybuf[b * CB + tid], yb);
             if (b * CB + tid < 6 * d.n_cam) d.y_c[b * CB + tid] = fail ? 0.0 : yb;
             if (gave_up && tid == 0) d.scal[SC_CHOL_FAIL] = 1.0;
         }
-        publish_flag(&flags[b]);
     }
 }
 
@@ -761,15 +768,15 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
     double *W = d.chol, *W2 = W + wsz;
     double *Ldiag = W2 + wsz;
     double *ybuf = Ldiag + (size_t)nb * LSLOT;
-    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] y | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row | [nb] rows 0..31 of the inverse
+    int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] (unused: a solution block is its own flag) | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row | [nb] rows 0..31 of the inverse
     const long long tot = (long long)wsz;
-    hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag);
+    hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag, ybuf);
     ESFM_HIP_TRY(hipGetLastError());
     ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(5 * nb + 1), st));
     const long long tiles = (long long)nb * (nb + 1) / 2 + nb;           // (i, j), 0 <= j <= i <= nb, j <= nb - 1
     hipLaunchKernelGGL(chol3_kernel, dim3((unsigned)tiles), dim3(256), 0, st, W, W2, Ldiag, ld, nb, flags + nb, flags + 3 * nb, flags + 2 * nb, flags + 4 * nb + 1, d.scal);
     ESFM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(chol2_back_kernel, dim3(nb), dim3(256), 0, st, d, W2, Ldiag, ld, nb, ybuf, flags);
+    hipLaunchKernelGGL(chol2_back_kernel, dim3(nb), dim3(256), 0, st, d, W2, Ldiag, ld, nb, ybuf);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
