@@ -20,12 +20,13 @@ constexpr int CB = 64;          // tile edge
 constexpr unsigned long long kYPending = ~0ull;
 
 __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__restrict__ W, int ld, int nb, double radius,
-                                                            double min_diag, double max_diag, double *__restrict__ ybuf)
+                                                            double min_diag, double max_diag, double *__restrict__ ybuf, int *__restrict__ flags)
 {
     const int n = 6 * d.n_cam;
     const long long rows = (long long)(nb + 1) * CB;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e < (long long)nb * CB) reinterpret_cast<unsigned long long *>(ybuf)[e] = kYPending;
+    if (e < 5 * nb + 1) flags[e] = 0;                     // chol3_kernel's flags (a memset launch of its own until round 3)
     if (e >= rows * ld) return;
     const int i = (int)(e / ld), j = (int)(e % ld);
     double v = 0.0;
@@ -770,9 +771,8 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
     double *ybuf = Ldiag + (size_t)nb * LSLOT;
     int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] (unused: a solution block is its own flag) | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row | [nb] rows 0..31 of the inverse
     const long long tot = (long long)wsz;
-    hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag, ybuf);
+    hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag, ybuf, flags);
     ESFM_HIP_TRY(hipGetLastError());
-    ESFM_HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(5 * nb + 1), st));
     const long long tiles = (long long)nb * (nb + 1) / 2 + nb;           // (i, j), 0 <= j <= i <= nb, j <= nb - 1
     hipLaunchKernelGGL(chol3_kernel, dim3((unsigned)tiles), dim3(256), 0, st, W, W2, Ldiag, ld, nb, flags + nb, flags + 3 * nb, flags + 2 * nb, flags + 4 * nb + 1, d.scal);
     ESFM_HIP_TRY(hipGetLastError());
