@@ -75,13 +75,17 @@ constexpr int kSorQ = 4;
 // workgroup's 64 queries are sorted points 64 b .. 64 b + 63.
 template <bool SORTED>
 __global__ __launch_bounds__(kSorThreads) void sor_knn_mean_kernel(const float *__restrict__ pts, int n, int stride, int mean_k,
-                                                                   float *__restrict__ mean_dist, const int32_t *__restrict__ perm)
+                                                                   float *__restrict__ mean_dist, const int32_t *__restrict__ perm,
+                                                                   int max_tiles, int32_t *__restrict__ hard_cnt, int32_t *__restrict__ hard_list)
 {
     __shared__ float tx[kSorTile], ty[kSorTile], tz[kSorTile];
     __shared__ float buf[kSorWaves][kSorQ][128];
     __shared__ int open_waves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = (blockIdx.x * kSorWaves + wave) * kSorQ;
+    // sorted: the workgroups at the two ends of the order first (even blockIdx from the front, odd from the back) -- that is where the
+    // cloud's stragglers are, the far points whose window grows to most of the cloud, and a launch is as long as its last workgroup
+    const int bid = SORTED ? ((blockIdx.x & 1) ? (int)gridDim.x - 1 - (int)(blockIdx.x >> 1) : (int)(blockIdx.x >> 1)) : (int)blockIdx.x;
+    const int q0 = (bid * kSorWaves + wave) * kSorQ;
     const float *sk = pts, *sx = pts + (SORTED ? n : 0), *sy = pts + (SORTED ? 2 * (size_t)n : 0), *sz = pts + (SORTED ? 3 * (size_t)n : 0);
     float qk[kSorQ];                                      // the queries' sort keys
     float qx[kSorQ], qy[kSorQ], qz[kSorQ], cur[kSorQ], T[kSorQ];
@@ -108,10 +112,10 @@ __global__ __launch_bounds__(kSorThreads) void sor_knn_mean_kernel(const float *
     };
 
     // the window of the sorted cloud swept so far is [lo, hi); unsorted: one pass over [0, n)
-    int lo = 0, hi = 0, t0 = 0;
-    bool go_right = true;
+    int lo = 0, hi = 0, t0 = 0, n_tiles = 0, q_hard = 0, lag = 0;
+    bool go_right = true, wave_open = true;
     if (SORTED) {
-        const int c = min(blockIdx.x * (kSorWaves * kSorQ) + (kSorWaves * kSorQ) / 2, n - 1);
+        const int c = min(bid * (kSorWaves * kSorQ) + (kSorWaves * kSorQ) / 2, n - 1);
         lo = hi = t0 = max(0, min(c - kSorTile / 2, n - kSorTile));
     }
     int t1 = min(t0 + kSorTile, n);                      // this step's candidates: [t0, t1)
@@ -132,8 +136,10 @@ __global__ __launch_bounds__(kSorThreads) void sor_knn_mean_kernel(const float *
         // Two candidate blocks of 64 per step, their distances as the two halves of packed f32 instructions (v_pk_add_f32 /
         // v_pk_mul_f32: each half an IEEE single operation, bit-identical to the scalar form): 8 arithmetic instructions per 128
         // candidates and query.  Padding candidates are NaN: never pass.
+        // (a wave whose four queries are certified sits the rest of the sweep out: what keeps a workgroup going is usually ONE far point
+        // among its 64 queries, and the SIMDs are then that wave's alone)
         for (int c = 0; c < kSorTile; c += 128) {
-            if (c >= t1 - t0) break;
+            if (c >= t1 - t0 || !wave_open) break;
             const float2v cx = {tx[c + lane], tx[c + 64 + lane]}, cy = {ty[c + lane], ty[c + 64 + lane]}, cz = {tz[c + lane], tz[c + 64 + lane]};
 #pragma unroll
             for (int u = 0; u < kSorQ; ++u) {
@@ -164,19 +170,33 @@ __global__ __launch_bounds__(kSorThreads) void sor_knn_mean_kernel(const float *
         if (!SORTED) { t0 = t1; t1 = min(t0 + kSorTile, n); if (t0 >= n) break; continue; }
         // widen the window; stop when every query of the workgroup is certified against both of its edges (or it is the whole cloud)
         if (t0 < lo) lo = t0; else hi = t1;
-        if (lo == 0 && hi == n) break;
+        if (lo == 0 && hi == n) { q_hard = 0; break; }
         bool open = false;
+        q_hard = 0;
 #pragma unroll
         for (int u = 0; u < kSorQ; ++u) {
-            if (!q_ok[u]) continue;
+            if (!q_ok[u] || !wave_open) continue;
             // T = the 64th smallest so far (pending survivors only make it smaller): an upper bound of the (mean_k + 1)-th
             const float dl = qk[u] - sk[lo], dr = sk[hi < n ? hi : n - 1] - qk[u];
             const bool left_ok = lo == 0 || T[u] <= dl * dl, right_ok = hi == n || T[u] <= dr * dr;
             open = open || !(left_ok && right_ok);
+            q_hard |= (left_ok && right_ok) ? 0 : (1 << u);
         }
+        wave_open = open;
         if (lane == 0 && open) atomicAdd(&open_waves, 1);
         __syncthreads();
         if (open_waves == 0) break;
+        // One or two waves that keep the workgroup going long after the others are done hold far points (or points in a thin part of
+        // the cloud): their windows would grow to most of the cloud while sixty certified queries wait.  Once they have cost half as
+        // many steps again as everybody else needed (and at least max_tiles), they go on a list instead; sor_knn_hard_kernel gives each
+        // of them a workgroup of its own.  (A fixed cap on the steps would send a whole uniform cloud there: at 200 k points every
+        // query needs 27 of them.)
+        ++n_tiles;
+        lag = open_waves <= 2 ? lag + 1 : 0;
+        if (lag >= max(max_tiles, (n_tiles + 1) / 2)) break;
+        // ... and a workgroup whose window has grown to half of the cloud without finishing (sixty-four far points: the ends of the
+        // order) hands over whatever is still open: a sixteenth of the cloud per wave there is no more than what is left here
+        if (n_tiles >= 8 && 2 * (hi - lo) >= n) break;
         go_right = lo == 0 ? true : (hi == n ? false : !go_right);
         if (go_right) { t0 = hi; t1 = min(hi + kSorTile, n); } else { t0 = max(0, lo - kSorTile); t1 = lo; }
     }
@@ -185,6 +205,7 @@ __global__ __launch_bounds__(kSorThreads) void sor_knn_mean_kernel(const float *
         const int q = q0 + u;
         if (q >= n) continue;
         if (!q_ok[u]) { if (lane == 0) mean_dist[SORTED ? perm[q] : q] = 0.0f; continue; }
+        if (SORTED && (q_hard >> u & 1)) { if (lane == 0) hard_list[atomicAdd(hard_cnt, 1)] = q; continue; }
         if (nbuf[u] > 0) merge64(u, lane < nbuf[u] ? buf[wave][u][lane] : INFINITY);
         // dist_sum += sqrt(nn_dists[k]), k = 1..mean_k, ascending, double accumulator, float sqrt [upstream]
         double s = 0.0;
@@ -196,11 +217,78 @@ __global__ __launch_bounds__(kSorThreads) void sor_knn_mean_kernel(const float *
     }
 }
 
+// The queries the windowed sweep gave up on (hard_list: indices into the sorted order), one WORKGROUP each: the sixteen waves take a
+// sixteenth of the cloud each -- every finite point is a candidate, as in the all-candidates sweep -- and their sixteen sorted lists of
+// 64 are merged pairwise through LDS (an ascending list against the partner's read backwards is bitonic).  A fixed grid strides over
+// the list, whose length only the device knows.
+__global__ __launch_bounds__(kSorThreads) void sor_knn_hard_kernel(const float *__restrict__ planes, int n, int mean_k, float *__restrict__ mean_dist,
+                                                                   const int32_t *__restrict__ perm, const int32_t *__restrict__ hard_cnt,
+                                                                   const int32_t *__restrict__ hard_list)
+{
+    __shared__ float buf[kSorWaves][128];
+    __shared__ float lists[kSorWaves][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *sx = planes + n, *sy = planes + 2 * (size_t)n, *sz = planes + 3 * (size_t)n;
+    const int cnt = *hard_cnt;
+    const int chunk = ((n + kSorWaves - 1) / kSorWaves + 63) & ~63;
+    for (int h = blockIdx.x; h < cnt; h += gridDim.x) {
+        const int q = hard_list[h];
+        const float qx = sx[q], qy = sy[q], qz = sz[q];
+        float cur = INFINITY, T = INFINITY;
+        int nbuf = 0;
+        auto merge64 = [&](float b) {
+            b = bitonic_sort_desc(b, lane);
+            cur = bitonic_merge_asc(fminf(cur, b), lane);
+            T = __shfl(cur, 63);
+        };
+        const int c0 = wave * chunk, c1 = min(c0 + chunk, n);
+        for (int c = c0; c < c1; c += 64) {
+            const int j = c + lane;
+            float x = NAN, y = 0.f, z = 0.f;
+            if (j < c1) { x = sx[j]; y = sy[j]; z = sz[j]; if (!(isfinite(x) && isfinite(y) && isfinite(z))) x = NAN; }
+            const float dx = qx - x, dy = qy - y, dz = qz - z;
+            float d2 = dx * dx;
+            d2 = d2 + dy * dy;
+            d2 = d2 + dz * dz;
+            const bool pass = d2 < T;
+            const unsigned long long mask = __ballot(pass);
+            if (mask == 0ull) continue;
+            const int pos = nbuf + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (pass) buf[wave][pos] = d2;
+            nbuf += __popcll(mask);
+            if (nbuf >= 64) {
+                const float bb = buf[wave][lane], hi = buf[wave][64 + lane];
+                merge64(bb);
+                nbuf -= 64;
+                if (lane < nbuf) buf[wave][lane] = hi;
+            }
+        }
+        if (nbuf > 0) merge64(lane < nbuf ? buf[wave][lane] : INFINITY);
+        // pairwise merges: after round r the waves whose index is a multiple of 2^(r+1) hold the smallest 64 of 2^(r+1) lists
+        for (int r = 1; r < kSorWaves; r <<= 1) {
+            __syncthreads();
+            lists[wave][lane] = cur;
+            __syncthreads();
+            if ((wave & (2 * r - 1)) == 0) cur = bitonic_merge_asc(fminf(cur, lists[wave + r][63 - lane]), lane);
+        }
+        if (wave == 0) {
+            double s = 0.0;
+            for (int k = 1; k <= mean_k; ++k) {
+                const float v = __shfl(cur, k);
+                if (v < INFINITY) s += (double)sqrtf(v);
+            }
+            if (lane == 0) mean_dist[perm[q]] = (float)(s / (double)mean_k);
+        }
+        __syncthreads();
+    }
+}
+
 // bounding box of the finite points as order-preserving integers (bb[0..2] = min, bb[3..5] = max; initialised to 0xff.. / 0)
 __device__ __forceinline__ unsigned int float_order(float f) { const unsigned int u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float order_float(unsigned int o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 __global__ __launch_bounds__(256) void sor_bbox_kernel(const float *__restrict__ pts, int n, int stride, unsigned int *__restrict__ bb)
 {
+    __shared__ unsigned int wlo[4][3], whi[4][3];
     unsigned int lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float c[3] = {pts[(size_t)i * stride], pts[(size_t)i * stride + 1], pts[(size_t)i * stride + 2]};
@@ -212,7 +300,13 @@ __global__ __launch_bounds__(256) void sor_bbox_kernel(const float *__restrict__
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], (unsigned int)__shfl_xor((int)lo[a], o)); hi[a] = max(hi[a], (unsigned int)__shfl_xor((int)hi[a], o)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&bb[a], lo[a]); atomicMax(&bb[3 + a], hi[a]); }
+        if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6][a] = lo[a]; whi[threadIdx.x >> 6][a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {              // one pair of atomics per workgroup and axis
+        const int a = threadIdx.x;
+        atomicMin(&bb[a], min(min(wlo[0][a], wlo[1][a]), min(wlo[2][a], wlo[3][a])));
+        atomicMax(&bb[3 + a], max(max(whi[0][a], whi[1][a]), max(whi[2][a], whi[3][a])));
     }
 }
 
@@ -243,6 +337,7 @@ __global__ void sor_gather_kernel(const float *__restrict__ pts, int n, int stri
     planes[(size_t)n + j] = pts[i * stride]; planes[2 * (size_t)n + j] = pts[i * stride + 1]; planes[3 * (size_t)n + j] = pts[i * stride + 2];
 }
 
+constexpr int kSorMaxTiles = 2;         // least number of window steps one or two straggling waves are waited for before they are handed to sor_knn_hard_kernel
 constexpr int kSorSortFrom = 4096;      // below this the sort and the gather cost more than the sweep they save
 
 int launch_sor_knn_mean(hipStream_t st, const float *pts_dev, int n, int stride, int mean_k, float *mean_dist_dev, esfm_ctx *ctx)
@@ -252,31 +347,37 @@ int launch_sor_knn_mean(hipStream_t st, const float *pts_dev, int n, int stride,
     static const bool brute = getenv("ESFM_SOR_BRUTE") != nullptr;      // developer switch: the all-candidates sweep at every size (tests compare the two)
     if (n < kSorSortFrom || brute || !ctx) {
         KernelTimer tm(ctx, ESFM_K_SOR_KNN);
-        hipLaunchKernelGGL(sor_knn_mean_kernel<false>, dim3(grid), dim3(kSorThreads), 0, st, pts_dev, n, stride, mean_k, mean_dist_dev, (const int32_t *)nullptr);
+        hipLaunchKernelGGL(sor_knn_mean_kernel<false>, dim3(grid), dim3(kSorThreads), 0, st, pts_dev, n, stride, mean_k, mean_dist_dev, (const int32_t *)nullptr,
+                           0, (int32_t *)nullptr, (int32_t *)nullptr);
         ESFM_HIP_TRY(hipGetLastError());
         return ESFM_OK;
     }
     // sorted by the key: bounding box | keys | idx | perm | planes (4 n: the sorted keys, x, y, z) | radix-sort scratch
     size_t tmp_bytes = 0;
     ESFM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const float *)nullptr, (float *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, n, 0, 32, st));
-    const size_t words = 7 * (size_t)n + 8;
+    const size_t words = 8 * (size_t)n + 8;
     if (int rc = ctx->stage_e.reserve(sizeof(float) * words + tmp_bytes + 256)) return rc;
     unsigned int *bb = ctx->stage_e.as<unsigned int>();
     float *keys = reinterpret_cast<float *>(bb + 8);
     int32_t *idx = reinterpret_cast<int32_t *>(keys + n), *perm = idx + n;
     float *planes = reinterpret_cast<float *>(perm + n);        // plane 0 = the sorted keys themselves (+inf for non-finite points)
-    void *tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(planes + 4 * (size_t)n) + 255) & ~(uintptr_t)255);
+    int32_t *hard_list = reinterpret_cast<int32_t *>(planes + 4 * (size_t)n);
+    int32_t *hard_cnt = reinterpret_cast<int32_t *>(bb + 6);
+    void *tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(hard_list + n) + 255) & ~(uintptr_t)255);
     KernelTimer tm(ctx, ESFM_K_SOR_KNN);
     ESFM_HIP_TRY(hipMemsetAsync(bb, 0xff, 3 * sizeof(unsigned int), st));
-    ESFM_HIP_TRY(hipMemsetAsync(bb + 3, 0, 3 * sizeof(unsigned int), st));
-    hipLaunchKernelGGL(sor_bbox_kernel, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, st, pts_dev, n, stride, bb);
+    ESFM_HIP_TRY(hipMemsetAsync(bb + 3, 0, 4 * sizeof(unsigned int), st));      // the box's maxima and the hard-query counter
+    hipLaunchKernelGGL(sor_bbox_kernel, dim3(std::min((n + 1023) / 1024, 1024)), dim3(256), 0, st, pts_dev, n, stride, bb);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sor_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts_dev, n, stride, bb, keys, idx);
     ESFM_HIP_TRY(hipGetLastError());
     ESFM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, planes, idx, perm, n, 0, 32, st));
     hipLaunchKernelGGL(sor_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts_dev, n, stride, perm, planes);
     ESFM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sor_knn_mean_kernel<true>, dim3(grid), dim3(kSorThreads), 0, st, planes, n, stride, mean_k, mean_dist_dev, perm);
+    hipLaunchKernelGGL(sor_knn_mean_kernel<true>, dim3(grid), dim3(kSorThreads), 0, st, planes, n, stride, mean_k, mean_dist_dev, perm, kSorMaxTiles,
+                       hard_cnt, hard_list);
+    ESFM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sor_knn_hard_kernel, dim3(std::max(1, ctx->num_cu)), dim3(kSorThreads), 0, st, planes, n, mean_k, mean_dist_dev, perm, hard_cnt, hard_list);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
