@@ -70,10 +70,33 @@ __device__ __forceinline__ void scal_commit(const BADev &d, const ScalBase &base
                                             int bidx = -1 /* the workgroup's index among those that commit; default blockIdx.x */)
 {
     const int b = bidx < 0 ? (int)blockIdx.x : bidx;
+    if (N == 1) {
+        const double t = block_sum(vals[0], lds);
+        if (threadIdx.x == 0) d.scal_part[(size_t)slots[0] * d.scal_cap + base.b[0] + b] = t;
+        return;
+    }
+    // all N sums behind ONE pair of barriers (block_sum's shuffle tree and wave order per sum, hence its bits; N calls of it were 2 N
+    // barriers at the end of every workgroup: twelve in the back-substitution)
+    __shared__ double part[N][16];
+    double t[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-        const double t = block_sum(vals[q], lds);
-        if (threadIdx.x == 0) d.scal_part[(size_t)slots[q] * d.scal_cap + base.b[q] + b] = t;
+        t[q] = vals[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t[q] += __shfl_xor(t[q], o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) part[q][wave] = t[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int q = threadIdx.x;
+        double sum = 0.0;
+        for (int w = 0; w < nw; ++w) sum += part[q][w];
+        d.scal_part[(size_t)slots[q] * d.scal_cap + base.b[q] + b] = sum;
     }
 }
 
