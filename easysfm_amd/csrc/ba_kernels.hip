@@ -309,10 +309,14 @@ __device__ __forceinline__ int qexp_of(double diag)
 // measured.  It is one dependent chain per workgroup: index load -> parameter gather -> sincos / divide in f64 -> stores -> LDS
 // maxima -> barrier -> exponents -> barrier -> 27 LDS adds -> barrier -> slab.  43 MB in 30 us is 0.18 of the HBM roofline and
 // not what limits it.)
-constexpr int kLinThreads = 512;
+// threads per workgroup of the sweep: 512 from 2^20 observations on, 256 below (BA-25, 240 k observations, two per thread: 28.7 -> 22.8
+// us -- finer workgroups get out of each other's phase and finish unevenly loaded CUs sooner; 128: 36 us, the slab count doubles;
+// 1024: 33 us.  BA-512: 223 us with 512, 313 with 256)
+constexpr int kLinThreadsLarge = 512, kLinThreadsSmall = 256;
+constexpr int kLinSmallObs = 1 << 20;
 constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
 
-template <bool PRIV, bool CALIB>
+template <bool PRIV, bool CALIB, int kLinThreads>
 __global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, ScalBase sbase, double *__restrict__ slabs,
                                                                    int prov_rexp)
 {
@@ -1997,12 +2001,15 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
         return ESFM_OK;
     }
     const size_t priv_bytes = 18 * sizeof(double) + (size_t)d.n_real_cam * kLinLdsPerCam;
+    const bool small = d.n_obs < kLinSmallObs;
+    const int kLinThreads = small ? kLinThreadsSmall : kLinThreadsLarge;
     const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
     const bool priv = priv_bytes <= 160 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
     ScalBase sbase;
     { const int slots[2] = {SC_COST, SC_LIN_BAD}; if (int rc = scal_reserve<2>(st, d, slots, grid, sbase)) return rc; }
     if (priv) {
-        auto kern = d.has_calib ? &ba_linearize_kernel<true, true> : &ba_linearize_kernel<true, false>;
+        auto kern = small ? (d.has_calib ? &ba_linearize_kernel<true, true, kLinThreadsSmall> : &ba_linearize_kernel<true, false, kLinThreadsSmall>)
+                          : (d.has_calib ? &ba_linearize_kernel<true, true, kLinThreadsLarge> : &ba_linearize_kernel<true, false, kLinThreadsLarge>);
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv_bytes));
         {
             KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep with its in-LDS camera sums (not the slab reduction)
@@ -2018,7 +2025,8 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     }
     {
         KernelTimer tm(timing_ctx, ESFM_K_BA_LINEARIZE);   // the Jacobian sweep alone
-        auto kern = d.has_calib ? &ba_linearize_kernel<false, true> : &ba_linearize_kernel<false, false>;
+        auto kern = small ? (d.has_calib ? &ba_linearize_kernel<false, true, kLinThreadsSmall> : &ba_linearize_kernel<false, false, kLinThreadsSmall>)
+                          : (d.has_calib ? &ba_linearize_kernel<false, true, kLinThreadsLarge> : &ba_linearize_kernel<false, false, kLinThreadsLarge>);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kLinThreads), 18 * sizeof(double), st, d, cauchy_a, use_scaling ? 1 : 0, sbase, (double *)nullptr, INT_MIN);
     }
     LAUNCH_CHECK();
