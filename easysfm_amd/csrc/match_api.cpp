@@ -106,7 +106,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                 // more than 65536 rows): the three-product kernel + re-scan of round 2.  Audit modes: 1 stops before the re-scan,
                 // 3 runs pass A alone (its failures on the flagged list).
                 const bool front = esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt);
-                if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
+                if (!front) { if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc; }
                 if (int rc = ctx->pair_cnt.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
                 if (int rc = ctx->pair_list.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
                 if (front) {
@@ -115,7 +115,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                     if (int rc = ctx->pair_list2.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
                     if (int rc = ctx->knn_d2.reserve(sizeof(float) * (size_t)plan.total_queries)) return rc;
                 }
-                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>(),
+                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, front ? nullptr : ctx->hm_exp.ptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>(),
                                                         ctx->pair_cnt.as<int32_t>(), n_pairs, front ? ctx->l2_hi.ptr : nullptr,
                                                         front ? ctx->pair_cnt2.as<int32_t>() : nullptr))
                     return rc;

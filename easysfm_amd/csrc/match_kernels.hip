@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
         // the even lane needs its partner's hi halves, the odd lane its partner's lo halves
         const uint32_t r0 = __shfl_xor(odd ? h0 : l0, 1), r1 = __shfl_xor(odd ? h1 : l1, 1);
         const u32x4 piece = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
-        if (ok) (img == 0 ? out : out_q)[4 * g + slot] = piece;
+        if (ok && out) (img == 0 ? out : out_q)[4 * g + slot] = piece;      // (the hi / lo images: the three-product pass's operands only)
         if (hi_t) {
             // The one-product pass (l2_knn_bf16x1_kernel) multiplies the hi halves only.  Its images are dense -- 128 B per row, the
             // even lane's piece IS the 16-B slot of eight consecutive features -- and its certificate needs |x - hi(x)|_2 of every
@@ -1934,11 +1934,12 @@ bool l2_one_product_pass()
 int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms, int32_t *counters,
                          int32_t *pair_cnt, int n_pairs, void *hi, int32_t *pair_cnt2)
 {
-    // `split` holds two images of 256 B per row: the train operand, then the query operand (-2 x)
+    // `split` holds two images of 256 B per row: the train operand, then the query operand (-2 x); NULL when only the one-product
+    // pass and its refine pass follow (they read the dense hi images in `hi`): 52 MB less to write per 25 x 4096 rows
     const long long n_pieces = std::max(total_rows * 16, (long long)std::max(n_pairs, 16));     // the launch also zeroes counters / pair_cnt
     hipLaunchKernelGGL(l2_split_bf16_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, st,
                        reinterpret_cast<const float4 *>(desc), total_rows * 16, reinterpret_cast<u32x4 *>(split),
-                       reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16, norms, counters, pair_cnt, n_pairs,
+                       split ? reinterpret_cast<u32x4 *>(split) + (size_t)std::max(total_rows, 1LL) * 16 : nullptr, norms, counters, pair_cnt, n_pairs,
                        hi ? reinterpret_cast<u32x4 *>(l2_hi_part(hi, total_rows, 0)) : nullptr,
                        hi ? reinterpret_cast<u32x4 *>(l2_hi_part(hi, total_rows, 1)) : nullptr,
                        hi ? reinterpret_cast<float *>(l2_hi_part(hi, total_rows, 2)) : nullptr,
