@@ -546,16 +546,16 @@ __device__ __forceinline__ void camacc_reduce_block(const BADev &d, const double
     const int e = bidx * kRedEnt + (threadIdx.x % kRedEnt);
     const int per = d.n_cam * 27;
     const int grp = threadIdx.x / kRedEnt;
-    // thread (ent, grp) adds slabs grp, grp + 8, ... in that order; eight loads in flight per round (the loop used to wait for
-    // every load: ~1 us each)
+    // thread (ent, grp) adds slabs grp, grp + 8, ... in that order; 32 loads in flight per round (512 slabs: two round trips; the loop
+    // used to wait for every load, ~1 us each, then for every eighth)
     double v0 = 0.0;
     if (e < per) {
-        for (int b = grp; b < n_slabs; b += 8 * kRedGrp) {
-            double t[8];
+        for (int b = grp; b < n_slabs; b += 32 * kRedGrp) {
+            double t[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (b + u * kRedGrp < n_slabs) ? slabs[(size_t)(b + u * kRedGrp) * per + e] : 0.0;
+            for (int u = 0; u < 32; ++u) t[u] = (b + u * kRedGrp < n_slabs) ? slabs[(size_t)(b + u * kRedGrp) * per + e] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v0 += t[u];
+            for (int u = 0; u < 32; ++u) v0 += t[u];
         }
     }
     lds[threadIdx.x] = v0;
