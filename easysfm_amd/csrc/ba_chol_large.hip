@@ -19,8 +19,12 @@ constexpr int CB = 64;          // tile edge
 // "not there yet" in the solution buffer of the backward substitution: all ones, a NaN no arithmetic produces (chol2_back_kernel)
 constexpr unsigned long long kYPending = ~0ull;
 
+// FIXED: d.red still holds the Schur kernels' fixed-point integers (entry (i, j) scaled by 2^(60 - qexp[i] - qexp[j]), the right-hand
+// side by 2^(60 - qexp[j] - rhs_exp)): converted here as ba_schur_to_double_kernel would have, and what has been read is cleared, so
+// that the next LM iteration's Schur kernels start from zeros without a memset of the whole buffer.
+template <bool FIXED>
 __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__restrict__ W, int ld, int nb, double radius,
-                                                            double min_diag, double max_diag, double *__restrict__ ybuf, int *__restrict__ flags)
+                                                            double min_diag, double max_diag, double *__restrict__ ybuf, int *__restrict__ flags, int rhs_exp)
 {
     const int n = 6 * d.n_cam;
     const long long rows = (long long)(nb + 1) * CB;
@@ -30,9 +34,15 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
     if (e >= rows * ld) return;
     const int i = (int)(e / ld), j = (int)(e % ld);
     double v = 0.0;
+    unsigned long long *redq = reinterpret_cast<unsigned long long *>(d.red);
     if (i < n) {
+        if (FIXED && j < n && j < 6 * (i / 6 + 1)) {     // everything the Schur kernels can have written in this row (full diagonal blocks)
+            const unsigned long long q = redq[(size_t)i * n + j];
+            if (j <= i && q != 0ull) v = fx64_to_double(q, kFxBits - d.qexp[i] - d.qexp[j]);
+            if (q != 0ull) redq[(size_t)i * n + j] = 0ull;
+        }
         if (j <= i) {
-            v = d.red[(size_t)i * n + j];
+            if (!FIXED) v = d.red[(size_t)i * n + j];
             if (i / 6 == j / 6) {
                 const int c = i / 6;
                 v += d.camacc[36 * (size_t)c + 6 * (i % 6) + (j % 6)];
@@ -42,7 +52,15 @@ __global__ __launch_bounds__(256) void chol_assemble_kernel(BADev d, double *__r
     } else if (i < nb * CB) {
         v = (i == j) ? 1.0 : 0.0;  // padding rows: identity
     } else if (i == nb * CB) {
-        v = (j < n) ? d.camacc[36 * (size_t)d.n_cam + j] + d.red[(size_t)n * n + j] : 0.0;  // rhs row
+        if (FIXED) {
+            if (j < n) {
+                const unsigned long long q = redq[(size_t)n * n + j];
+                v = d.camacc[36 * (size_t)d.n_cam + j] + fx64_to_double(q, kFxBits - d.qexp[j] - rhs_exp);
+                redq[(size_t)n * n + j] = 0ull;
+            }
+        } else {
+            v = (j < n) ? d.camacc[36 * (size_t)d.n_cam + j] + d.red[(size_t)n * n + j] : 0.0;  // rhs row
+        }
     }
     W[(size_t)i * ld + j] = v;
 }
@@ -771,7 +789,13 @@ int ba_solve_reduced_large(hipStream_t st, const BADev &d, double radius, double
     double *ybuf = Ldiag + (size_t)nb * LSLOT;
     int *flags = reinterpret_cast<int *>(ybuf + (size_t)nb * CB);        // [nb] (unused: a solution block is its own flag) | [nb] inverse | [nb] partial diagonal | [nb + 1] factor tiles per row | [nb] rows 0..31 of the inverse
     const long long tot = (long long)wsz;
-    hipLaunchKernelGGL(chol_assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag, ybuf, flags);
+    if (d.parts->red_fixed) {
+        hipLaunchKernelGGL(chol_assemble_kernel<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag, ybuf, flags,
+                           d.parts->red_rhs_exp);
+        d.parts->red_fixed = false; d.parts->red_clean = true;
+    } else {
+        hipLaunchKernelGGL(chol_assemble_kernel<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d, W, ld, nb, radius, min_diag, max_diag, ybuf, flags, 0);
+    }
     ESFM_HIP_TRY(hipGetLastError());
     const long long tiles = (long long)nb * (nb + 1) / 2 + nb;           // (i, j), 0 <= j <= i <= nb, j <= nb - 1
     hipLaunchKernelGGL(chol3_kernel, dim3((unsigned)tiles), dim3(256), 0, st, W, W2, Ldiag, ld, nb, flags + nb, flags + 3 * nb, flags + 2 * nb, flags + 4 * nb + 1, d.scal);

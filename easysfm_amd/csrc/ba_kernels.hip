@@ -156,10 +156,8 @@ __device__ __forceinline__ unsigned long long fx64_scaled(double x)
     return ((unsigned long long)hi << 32) | (unsigned int)__double2loint(B);
 }
 __device__ __forceinline__ unsigned long long fx64(double v, int sh) { return fx64_scaled(ldexp(v, sh)); }
-__device__ __forceinline__ double fx64_to_double(unsigned long long q, int sh) { return ldexp((double)(long long)q, -sh); }
 __device__ __forceinline__ void fx_add(double *slot, double v, int sh) { atomicAdd(reinterpret_cast<unsigned long long *>(slot), fx64(v, sh)); }
 __device__ __forceinline__ void fx_add_scaled(double *slot, double x) { atomicAdd(reinterpret_cast<unsigned long long *>(slot), fx64_scaled(x)); }
-constexpr int kFxBits = 60;   // |v| <= B < 2^e  ->  |v 2^(kFxBits - e)| < 2^60: three bits of head-room in an int64
 
 // ceres::CauchyLoss::Evaluate [upstream]; a <= 0 selects the trivial (squared) loss.
 __device__ __forceinline__ void loss_eval(double a, double s, double &rho0, double &rho1)
@@ -2102,8 +2100,10 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
     // paths and the free-intrinsics kernel accumulate into it)
     const bool slab_path = d.n_obs > 0 && !d.has_calib && slabs &&
                            sizeof(double) * ((size_t)(d.n_cam * (d.n_cam + 1) / 2) * kSchurPitch + 6 * (size_t)d.n_cam) + sizeof(int) * 6 * (size_t)d.n_cam <= 156 * 1024;
-    if (!slab_path) ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
+    d.parts->red_fixed = false;
+    if (!slab_path && !d.parts->red_clean) ESFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * ba_red_doubles(d.n_cam), st));
     if (d.n_obs <= 0) return ESFM_OK;
+    d.parts->red_clean = false;
     const int rhs_exp = bound_exponent(rhs_bound);
     const bool finish = !d.has_calib;    // with free intrinsics ba_schur_calib adds its block row first, then converts
     const int nblk = d.n_cam * (d.n_cam + 1) / 2;
@@ -2155,7 +2155,18 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, rhs_exp, (const int32_t *)nullptr, 0);
         LAUNCH_CHECK();
     }
+    if (finish && d.parts->single_rank && ba_solve_is_tiled(d.n_cam)) {
+        // the tiled solve's assembly kernel reads red next: it converts on the way and clears what it has read
+        d.parts->red_fixed = true; d.parts->red_rhs_exp = rhs_exp;
+        return ESFM_OK;
+    }
     return finish ? schur_to_double(st, d, rhs_exp) : ESFM_OK;
+}
+
+bool ba_solve_is_tiled(int n_cam)
+{
+    const int n = 6 * n_cam;
+    return n_cam > 0 && !ba_chol_small_fits(n_cam) && sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + n + 2) > 150 * 1024;
 }
 
 int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_diag, double max_diag)

@@ -32,7 +32,15 @@ struct ScalParts {                             // host-side bookkeeping of one p
     int n[SC_SUM_COUNT];                       // per-workgroup scalar partials pending on the device, per slot
     bool single_rank = true;                   // no all-reduce callback in the running solve
     bool grad_done = false;                    // the camera part of max|gradient| came with the last linearisation
+    // the Schur buffer `red` between ba_schur and the tiled solve (one rank, no free intrinsics): left in FIXED POINT for
+    // chol_assemble_kernel, which converts while it reads and leaves zeros behind -- one conversion pass over 75 MB and one memset of
+    // it less per LM iteration at 512 cameras
+    bool red_fixed = false;                    // red holds fixed-point integers (scaled by qexp / red_rhs_exp), not doubles
+    bool red_clean = false;                    // red is all zeros: the next ba_schur need not clear it
+    int red_rhs_exp = 0;
 };
+// does ba_solve_reduced take the tiled path (ba_solve_reduced_large) for this camera count?
+bool ba_solve_is_tiled(int n_cam);
 struct ScalCounts { int n[SC_SUM_COUNT]; };   // kernel argument: how many partials each slot has pending
 struct ScalBase { int b[6]; };                // kernel argument: first partial index of this launch, per slot it commits
 
@@ -163,6 +171,8 @@ int ba_scal_reduce(hipStream_t st, const BADev &d);
 void ba_scal_discard(const BADev &d, int first_slot, int end_slot);
 int ba_publish_scalars(hipStream_t st, const BADev &d, double *host, unsigned long long *flag, unsigned long long seq);
 #ifdef __HIPCC__
+constexpr int kFxBits = 60;   // |v| <= B < 2^e  ->  |v 2^(kFxBits - e)| < 2^60: three bits of head-room in an int64
+__device__ __forceinline__ double fx64_to_double(unsigned long long q, int sh) { return ldexp((double)(long long)q, -sh); }
 // Candidate cameras from the reduced solve's y (one workgroup of up to 1024 threads; lds: >= 48 doubles): x + (-y) .* scaling for cameras that
 // have observations, projected onto the box when the problem is bounded; step / candidate norms and max |delta|.
 __device__ inline void ba_camera_step_body(const BADev &d, const double *y, double *lds)
