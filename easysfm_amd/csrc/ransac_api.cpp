@@ -149,7 +149,8 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
     if (int rc = ctx->stage_b.reserve(sizeof(float) * 2 * (size_t)std::max(n_total, 1))) return rc;
     if (int rc = ctx->stage_c.reserve(sizeof(RansacPair) * (size_t)n_pairs)) return rc;
     if (int rc = ctx->stage_d.reserve(sizeof(int32_t) * (16 * n_slots + 3 * (size_t)n_pairs))) return rc;   // samples | n_models | counts | take
-    if (int rc = ctx->stage_e.reserve(sizeof(double) * 90 * n_slots + sizeof(double) * 9 * (size_t)n_pairs + (size_t)std::max(n_total, 1))) return rc;
+    if (int rc = ctx->stage_e.reserve(sizeof(double) * 90 * n_slots + sizeof(double) * 9 * (size_t)n_pairs + sizeof(double) * 4 * (size_t)std::max(n_total, 1) + 32 +
+                                      (size_t)std::max(n_total, 1))) return rc;
     float *d_p1 = ctx->stage_a.as<float>(), *d_p2 = ctx->stage_b.as<float>();
     RansacPair *d_tab = ctx->stage_c.as<RansacPair>();
     int32_t *d_samples = ctx->stage_d.as<int32_t>();
@@ -158,12 +159,16 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
     int32_t *d_take = d_counts + 10 * n_slots;
     double *d_models = ctx->stage_e.as<double>();
     double *d_best = d_models + 90 * n_slots;
-    uint8_t *d_mask = reinterpret_cast<uint8_t *>(d_best + 9 * (size_t)n_pairs);
+    double *d_npts = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(d_best + 9 * (size_t)n_pairs) + 31) & ~(uintptr_t)31);   // (double4 records)
+    uint8_t *d_mask = reinterpret_cast<uint8_t *>(d_npts + 4 * (size_t)std::max(n_total, 1));
     if (n_total > 0) {
         ESFM_HIP_TRY(hipMemcpyAsync(d_p1, pts1, sizeof(float) * 2 * (size_t)n_total, hipMemcpyHostToDevice, st));
         ESFM_HIP_TRY(hipMemcpyAsync(d_p2, pts2, sizeof(float) * 2 * (size_t)n_total, hipMemcpyHostToDevice, st));
     }
     ESFM_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(double) * 9 * (size_t)n_pairs, st));
+    // the correspondences in normalised coordinates, once for all rounds (the table's geometry does not change between rounds)
+    ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+    if (int rc = esfm::launch_essential_normalise(st, d_tab, n_pairs, d_p1, d_p2, d_npts)) return rc;
 
     // the per-round tables in pinned memory (pageable copies of 0.4 MB up and 0.85 MB down per round were staged by the runtime)
     if (int rc = ctx->pin_rounds(sizeof(int32_t) * (16 * n_slots + 3 * (size_t)n_pairs))) return rc;
@@ -187,7 +192,7 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
         ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
         ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples, sizeof(int32_t) * 5 * n_slots, hipMemcpyHostToDevice, st));
         ESFM_HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * 10 * n_slots, st));
-        if (int rc = esfm::launch_essential_chunk(st, d_tab, n_pairs, d_p1, d_p2, d_samples, kChunk, d_models, d_nmodels, d_counts, ctx)) return rc;
+        if (int rc = esfm::launch_essential_chunk(st, d_tab, n_pairs, d_p1, d_p2, d_npts, d_samples, kChunk, d_models, d_nmodels, d_counts, ctx)) return rc;
         ESFM_HIP_TRY(hipMemcpyAsync(nmodels, d_nmodels, sizeof(int32_t) * 11 * n_slots, hipMemcpyDeviceToHost, st));   // n_models | counts
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         // replay RANSACPointSetRegistrator::run over this chunk

@@ -417,10 +417,31 @@ __device__ __forceinline__ bool sampson_inlier(const double *E, double x1, doubl
     return err <= t;
 }
 
+// the correspondences in normalised coordinates (x1, y1, x2, y2), once per call: one workgroup per pair
+__global__ __launch_bounds__(256) void essential_normalise_kernel(const RansacPair *__restrict__ pairs, const float2 *__restrict__ p1,
+                                                                  const float2 *__restrict__ p2, double4 *__restrict__ npts)
+{
+    const RansacPair pr = pairs[blockIdx.x];
+    for (int i = threadIdx.x; i < pr.count; i += 256) {
+        double x1, y1, x2, y2;
+        normalise_pt(pr, p1, p2, i, x1, y1, x2, y2);
+        npts[pr.first + i] = make_double4(x1, y1, x2, y2);
+    }
+}
+
+int launch_essential_normalise(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, double *npts)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(essential_normalise_kernel, dim3(n_pairs), dim3(256), 0, st, pairs, reinterpret_cast<const float2 *>(p1),
+                       reinterpret_cast<const float2 *>(p2), reinterpret_cast<double4 *>(npts));
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
 // one workgroup per (pair, iteration): counts[g][m] = inliers of model m
-__global__ __launch_bounds__(256) void essential_score_kernel(const RansacPair *__restrict__ pairs, const float2 *__restrict__ p1,
-                                                              const float2 *__restrict__ p2, int chunk, const double *__restrict__ models,
-                                                              const int32_t *__restrict__ n_models, int32_t *__restrict__ counts)
+__global__ __launch_bounds__(256) void essential_score_kernel(const RansacPair *__restrict__ pairs, const double4 *__restrict__ npts, int chunk,
+                                                              const double *__restrict__ models, const int32_t *__restrict__ n_models,
+                                                              int32_t *__restrict__ counts)
 {
     __shared__ int red[10][4];
     __shared__ double sE[90];
@@ -434,11 +455,12 @@ __global__ __launch_bounds__(256) void essential_score_kernel(const RansacPair *
 #pragma unroll
     for (int m = 0; m < 10; ++m) cnt[m] = 0;
     for (int i = threadIdx.x; i < pr.count; i += 256) {
-        double x1, y1, x2, y2;
-        normalise_pt(pr, p1, p2, i, x1, y1, x2, y2);
+        // (normalised once per call by essential_normalise_kernel: the four f64 divisions per correspondence were 40 % of this
+        // kernel's instructions, repeated for every hypothesis of every round)
+        const double4 v = npts[pr.first + i];
 #pragma unroll
         for (int m = 0; m < 10; ++m)
-            if (m < nm) cnt[m] += sampson_inlier(sE + 9 * m, x1, y1, x2, y2, pr.thresh_sq) ? 1 : 0;
+            if (m < nm) cnt[m] += sampson_inlier(sE + 9 * m, v.x, v.y, v.z, v.w, pr.thresh_sq) ? 1 : 0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -559,8 +581,8 @@ __global__ __launch_bounds__(256) void pose_cheirality_kernel(const RansacPair *
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
-int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const int32_t *samples,
-                           int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx)
+int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *npts,
+                           const int32_t *samples, int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx)
 {
     const int n = n_pairs * chunk;
     if (n <= 0) return ESFM_OK;
@@ -570,8 +592,7 @@ int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs,
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(essential_roots_kernel, dim3((16 * n + 255) / 256), dim3(256), 0, st, n, models, n_models);
     ESFM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(essential_score_kernel, dim3(n), dim3(256), 0, st, pairs, reinterpret_cast<const float2 *>(p1),
-                       reinterpret_cast<const float2 *>(p2), chunk, models, n_models, counts);
+    hipLaunchKernelGGL(essential_score_kernel, dim3(n), dim3(256), 0, st, pairs, reinterpret_cast<const double4 *>(npts), chunk, models, n_models, counts);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

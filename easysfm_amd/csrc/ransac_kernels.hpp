@@ -14,7 +14,9 @@ struct RansacPair {       // one image pair's correspondences inside the concate
     double dist_thresh;   // recoverPose's distanceThresh (50)
 };
 
-int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const int32_t *samples,
+// npts[4 i ..] = correspondence i in normalised coordinates (x1, y1, x2, y2), doubles; `active` is not looked at
+int launch_essential_normalise(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, double *npts);
+int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *npts, const int32_t *samples,
                            int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx);
 // best[9 take[3 e]] = models[90 take[3 e + 1] + 9 take[3 e + 2]] (9 doubles) for e < n_take
 int launch_essential_take_best(hipStream_t st, const int32_t *take, int n_take, const double *models, double *best);
