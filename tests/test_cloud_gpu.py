@@ -71,6 +71,12 @@ def _sor_clouds():
     out["line"] = P
     P = np.repeat(rng.uniform(-1, 1, (300, 3)).astype(np.float32), 40, axis=0)  # every point 40 times: the window's edge falls inside ties
     out["duplicates"] = P
+    out["all_equal"] = np.full((5000, 3), 0.75, np.float32)                     # every key and every distance equal: T = 0 against an edge of 0
+    P = rng.uniform(-3, 3, (4096, 3)).astype(np.float32)                        # the smallest cloud that takes the sorted path, ...
+    P[40:] = np.nan                                                             # ... with fewer finite points than neighbours asked for
+    out["mostly_nan"] = P
+    P = rng.uniform(-1, 1, (6000, 3)).astype(np.float32); P[:, 2] *= 1e-30      # denormal-scale spread along one axis
+    out["flat"] = P
     for P in out.values():
         P[17] = [np.nan, 0, 0]; P[123, 2] = np.inf                              # non-finite points are neither queries nor candidates
     return out
@@ -91,7 +97,7 @@ def test_sor_sorted_window_equals_all_candidates(gpu_ctx):
         fin = np.isfinite(P).all(1)
         assert np.all(md[~fin] == 0)                                               # (non-finite points: distance 0, as in PCL)
         Pf = P[fin]
-        for i in rng.choice(np.nonzero(fin)[0], 48, replace=False):
+        for i in rng.choice(np.nonzero(fin)[0], min(48, int(fin.sum())), replace=False):
             d = P[i][None, :] - Pf
             d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
             row = np.sort(d2)[1:51]
