@@ -65,7 +65,7 @@ struct esfm_ctx {
     size_t pinned_cap = 0;
     int64_t last_n_queries = 0;
     size_t last_pair_bytes = 0;
-    int l2_audit = 0;   // esfm_ctx_set_l2_audit: 0 product path, 1 no re-scan, 2 exact scan of every query, 3 one-product pass alone
+    int l2_audit = 0;   // esfm_ctx_set_l2_audit: 0 product path, 1 no re-scan, 2 exact scan of every query, 3 one-product pass alone, 4 one-product pass alone with the ratio screen's rejections listed
     int pin(size_t bytes);
     // a second pinned area for the per-round tables of the RANSAC loops (samples up, model counts and inlier counts down)
     void *pinned_rounds = nullptr;

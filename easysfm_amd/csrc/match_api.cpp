@@ -2,6 +2,7 @@
 // Host logic only: argument checks, the pair table, scratch management, kernel sequencing.
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <vector>
 
 #include "match_kernels.hpp"
@@ -79,8 +80,10 @@ int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
 }
 
 // 2-NN table for every query of every pair, written to knn_idx/knn_dist (device, 2 per query).
+// `ratio`: the caller will only keep the queries with d0 < ratio d1 (the match entry points), so the one-product pass may drop the
+// ones that provably fail (train index -2, see l2_knn_bf16x1_kernel); INFINITY: every query's exact 2-NN (the knn2 entry points).
 int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width, const PairPlan &plan,
-              const PairDesc *dev_tab, int32_t *knn_idx, float *knn_dist)
+              const PairDesc *dev_tab, int32_t *knn_idx, float *knn_dist, double ratio)
 {
     const int n_pairs = (int)plan.tab.size();
     if (n_pairs == 0 || plan.total_queries == 0) return ESFM_OK;
@@ -88,8 +91,8 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
     if (metric == ESFM_L2_F32) {
         const float *desc = reinterpret_cast<const float *>(desc_dev);
         if (int rc = ctx->counters.reserve(64)) return rc;
-        if (ctx->l2_audit == 3 && !(esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt))) {
-            esfm::set_error("audit mode 3 needs the one-product pass (64-float descriptors, train sets <= 65536 rows, ESFM_L2_PASS unset)");
+        if ((ctx->l2_audit == 3 || ctx->l2_audit == 4) && !(esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt))) {
+            esfm::set_error("audit modes 3 and 4 need the one-product pass (64-float descriptors, train sets <= 65536 rows, ESFM_L2_PASS unset)");
             return ESFM_ERR_UNSUPPORTED;
         }
         const bool bf16_pass = esfm::l2_mfma_supported(width) && ctx->l2_audit != 2 && esfm::l2_bf16_pass(width);
@@ -125,10 +128,11 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                         if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
                                                                 plan.n_blocks2, knn_idx, knn_dist, ctx->l2_audit == 3 ? ctx->flagged.as<int32_t>() : nullptr,
                                                                 ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt2.as<int32_t>(),
-                                                                ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>()))
+                                                                ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(), ratio,
+                                                                ctx->l2_audit == 4 ? ctx->flagged.as<int32_t>() : nullptr))
                             return rc;
                     }
-                    if (ctx->l2_audit == 3) return ESFM_OK;   // audit: the one-product pass's own answers and failures
+                    if (ctx->l2_audit == 3 || ctx->l2_audit == 4) return ESFM_OK;   // audit: the one-product pass's own answers and failures / rejections
                 }
                 if (front) {
                     esfm::KernelTimer tm(ctx, ESFM_K_L2_SECOND);
@@ -222,7 +226,7 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
     if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)nq)) return rc;
     if (int rc = ctx->knn_dist.reserve(sizeof(float) * 2 * (size_t)nq)) return rc;
-    if (int rc = knn2_core(ctx, metric, d, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>())) return rc;
+    if (int rc = knn2_core(ctx, metric, d, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), filtered ? ratio : (double)INFINITY)) return rc;
     if (!filtered) {
         ESFM_HIP_TRY(hipMemcpyAsync(o_a, ctx->knn_idx.ptr, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
         ESFM_HIP_TRY(hipMemcpyAsync(o_c, ctx->knn_dist.ptr, sizeof(float) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
@@ -294,7 +298,7 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
     ESFM_REQUIRE(desc_dev && knn_idx_dev && knn_dist_dev, "device pointer is NULL");
     const PairDesc *dev_tab = nullptr;
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
-    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev);
+    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev, (double)INFINITY);
 }
 
 int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
@@ -314,7 +318,7 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
     if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(plan.total_queries, 1))) return rc;
     if (int rc = ctx->knn_dist.reserve(sizeof(float) * 2 * (size_t)std::max<int64_t>(plan.total_queries, 1))) return rc;
-    if (int rc = knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>())) return rc;
+    if (int rc = knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio)) return rc;
     return esfm::launch_ratio_compact(ctx->stream, dev_tab, n_pairs, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio,
                                       query_idx_dev, train_idx_dev, distance_dev, n_out_dev);
 }
@@ -348,7 +352,7 @@ int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass)
 
 int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 3) { esfm::set_error("esfm_ctx_set_l2_audit: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    if (!ctx || mode < 0 || mode > 4) { esfm::set_error("esfm_ctx_set_l2_audit: bad arguments"); return ESFM_ERR_INVALID_ARG; }
     ctx->l2_audit = mode;
     return ESFM_OK;
 }

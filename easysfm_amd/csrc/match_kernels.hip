@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                                int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
                                                                int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
-                                                               float *__restrict__ knn_d2)
+                                                               float *__restrict__ knn_d2, double ratio2m, int32_t *__restrict__ rejected)
 {
     constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, GRP = 4, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
     constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
@@ -999,11 +999,24 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 
     // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate (see l2_knn_bf16_kernel: the same scheme with
     // 2 K groups per query, dealt out over K rounds) ----
-    // (Round 3, measured on one box against this form, 0.906 - 0.916 ms per launch: the (query, group) items of a set compacted
+    // (Round 3, measured on one box against the per-set form, 0.906 - 0.916 ms per launch: the (query, group) items of a set compacted
     // across the wave -- prefix sums, an LDS item table, a segmented shuffle merge, packed f32 arithmetic: 1.3 dense rounds per set
     // instead of 3.4 and 83 M instead of 124 M VALU instructions -- 0.926 - 0.931 ms; the same with the rows through registers and
     // ds_write_b128 instead of LDS-DMA, the next row's loads in flight during the arithmetic: 0.983 - 0.988 ms, 29 spilled
-    // registers.  The tail costs 0.3 ms whatever its instruction count: its row fetches are what it waits for.)
+    // registers.  The tail cost 0.3 ms whatever its instruction count: its row fetches are what it waits for.)
+    //
+    // Round 4: RATIO SCREEN in front of the re-rank.  The reference keeps a query only if d0 < ratio d1 (feature_matching.cpp:133);
+    // everything else is dropped one kernel later, and on the metric's workload that is > 90 % of the queries.  With k0 <= kb the two
+    // smallest of a query's 2 K group keys (two groups, hence two different train rows: the groups' minima) and E1 the pass's bound
+    // on |(|q|^2 + score) - D| (D = the canonical float d^2), kTrunc the key's truncation:
+    //     every train row has   D >= L0 = |q|^2 + k0 - kTrunc |k0| - E1        (k0 is the smallest key of all groups),
+    //     two rows have         D <= U1 = |q|^2 + kb + kTrunc |kb| + E1,
+    // so the nearest has D0 >= L0 and the second nearest D1 <= U1.  If L0 >= ratio^2 (1 + 2^-20) U1 then sqrtf(D0) >= ratio sqrtf(D1)
+    // whatever the two roundings of sqrtf and the double product do (their relative error is < 2^-22 together): the query cannot
+    // pass the test.  It gets a marker (train index -2) and NO row is fetched for it.  The survivors of the wave's four sets are
+    // compacted into virtual sets of 32 (list in the dead norm area, keys gathered across lanes by ds_bpermute), so the re-rank's
+    // latency chain -- query rows, then up to K rounds of four row transfers -- runs once per 32 SURVIVORS instead of once per 32
+    // queries.  ratio2m = ratio^2 (1 + 2^-20); +inf switches the screen off (the knn2 entry points: every query exact).
     lds_dma_wait();
     __syncthreads();   // every wave is through its last tile and has its keys: the ring becomes four private 16-KiB landing zones
     const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
@@ -1014,11 +1027,62 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 #pragma unroll
     for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
+    const double sqrt_tmax = sqrt((double)tmax);
+    auto e1_of = [&](double qn, double rq) {
+        return (rq * sqrt_tmax + (2.0 * sqrt(qn) + rq) * (double)rmax) * (1.0 + 1.0 / 512.0) + (qn + (double)tmax) * (1.0 / 32768.0);
+    };
+    auto mark_rejected = [&](int qrow) {
+        const size_t o = 2 * ((size_t)pd.out_off + qrow);
+        knn_idx[o] = -2; knn_idx[o + 1] = -2;
+        knn_dist[o] = FLT_MAX; knn_dist[o + 1] = FLT_MAX;
+        if (rejected) {          // audit of the screen: what it dropped, on the global list
+            const int slot = atomicAdd(&counters[0], 1);
+            if (slot < flag_cap) { rejected[2 * slot] = pi; rejected[2 * slot + 1] = qrow; }
+        }
+    };
+
+    // ---- phase A: the ratio screen, every query of the wave's four sets; survivors -> wlist (entry = 32 set + j)
+    int *wlist = reinterpret_cast<int *>(lds_norm) + wave * (32 * NS);     // (RING * TT floats = 4 x 128 entries: the ring's norms are dead)
+    static_assert(RING * TT >= 4 * 32 * NS, "survivor lists live in the norm area");
+    int nsurv = 0;
+    {
+        float qn_s[NS], rq_s[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int qrow = qbase + 32 * s + j;
+            qn_s[s] = norms[pd.q_row0 + (qrow < nq ? qrow : 0)];
+            rq_s[s] = rho_q[pd.q_row0 + (qrow < nq ? qrow : 0)];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int qrow = qbase + 32 * s + j;
+            const bool qvalid = qrow < nq;
+            const float v0 = keys[s][0], v1 = keys[s][1];
+            const float p0 = __shfl_xor(v0, 32), p1 = __shfl_xor(v1, 32);
+            const float k0 = fminf(v0, p0), kb = fminf(fmaxf(v0, p0), fminf(v1, p1));     // the two smallest of the 2 K keys
+            const double qn = (double)qn_s[s];
+            const double e1 = e1_of(qn, (double)rq_s[s]);
+            const double L0 = qn + (double)k0 - e1 - fabs((double)k0) * kTrunc;
+            const double U1 = qn + (double)kb + e1 + fabs((double)kb) * kTrunc;
+            const bool rej = qvalid && (L0 >= ratio2m * U1);                              // false on NaN / inf: re-rank
+            const bool surv = qvalid && !rej;
+            const uint32_t m = (uint32_t)__ballot(surv);                                  // lanes 0 .. 31 (both halves agree)
+            if (h == 0 && surv) wlist[nsurv + __popc(m & ((1u << j) - 1u))] = 32 * s + j;
+            if (h == 0 && rej) mark_rejected(qrow);
+            nsurv += __popc(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase B: virtual sets of 32 survivors
 #pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
-        const int qrow = qbase + 32 * s + j;
-        const bool qvalid = qrow < nq;
-        if (__ballot(qvalid) == 0ull) break;           // (wave-uniform: the sets past the end of the query set)
+    for (int v0 = 0; v0 < nsurv; v0 += 32) {
+        const bool qvalid = v0 + j < nsurv;
+        const int src = qvalid ? wlist[v0 + j] : 0;
+        const int qrow = qvalid ? qbase + src : nq;        // nq: past the descriptor, zeros
+        const int nv = min(32, nsurv - v0);                // wave-uniform: queries of this virtual set
         float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
         auto insert2 = [&](bool valid, float d, int i, float d2) {
             const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
@@ -1027,58 +1091,82 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
         };
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the query rows -> landing slots 0 .. nv - 1: slot r takes the row lane r names (lanes j and j + 32 read the same slot)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
-        const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
-        const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
-        float vk[K], pk[K]; int g0[K], pg[K], rank_own[K], rank_par[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            // (the set loop is a real loop: pick the set's keys without indexing registers by s)
-            float kv = keys[0][i];
-#pragma unroll
-            for (int t = 1; t < NS; ++t) kv = s == t ? keys[t][i] : kv;
-            vk[i] = kv; g0[i] = group_row0_of(kv);
-        }
-#pragma unroll
-        for (int i = 0; i < K; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
-#pragma unroll
-        for (int i = 0; i < K; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
-            rank_own[i] = i; rank_par[i] = i;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                rank_own[i] += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
-                rank_par[i] += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
+        for (int i = 0; i < 8; ++i) {
+            if (4 * i < nv) {
+                const int r = 4 * i + (lane >> 4);
+                const int qsrc = __builtin_amdgcn_ds_bpermute(r * 4, qrow) * 256 + (swz[i & 3] & 255);
+                lds_dma_b128(lds_land + (uint32_t)i * 1024u, qsrc, frsrc_q, 0);
             }
         }
-        const float kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));     // second smallest of the 2 K keys
+        const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
+        const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
+        // this lane's keys: those of lane (src & 31) + 32 h for set src >> 5.  The 2 K groups of the query are ranked by key across
+        // the lane pair and dealt out alternately: this lane takes global rank 2 r + h in round r (rkey / rrow); everything else
+        // about the ranking is dead before the rows arrive.
+        float rkey[K]; int rrow[K]; float kb, tau;
+        {
+            float vk[K], pk[K]; int g0[K], pg[K];
+            const int srcl = ((src & 31) + 32 * h) * 4, sset = src >> 5;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float kv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(keys[0][i])));
+#pragma unroll
+                for (int t = 1; t < NS; ++t) {
+                    const float o = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(keys[t][i])));
+                    kv = sset == t ? o : kv;
+                }
+                vk[i] = qvalid ? kv : kBig; g0[i] = group_row0_of(vk[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
+#pragma unroll
+            for (int r = 0; r < K; ++r) { rkey[r] = kBig; rrow[r] = -1; }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
+                int rank_own = i, rank_par = i;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    rank_own += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
+                    rank_par += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
+                }
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    if (rank_own == 2 * r + h) { rkey[r] = vk[i]; rrow[r] = g0[i]; }
+                    if (rank_par == 2 * r + h) { rkey[r] = pk[i]; rrow[r] = pg[i]; }
+                }
+            }
+            kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));     // second smallest of the 2 K keys
+            tau = fminf(vk[K - 1], pk[K - 1]);
+        }
         const double qn = (double)qnorm_s;
-        const double e1 = ((double)qrho_s * sqrt((double)tmax) + (2.0 * sqrt(qn) + (double)qrho_s) * (double)rmax) * (1.0 + 1.0 / 512.0) +
-                          (qn + (double)tmax) * (1.0 / 32768.0);
+        const double e1 = e1_of(qn, (double)qrho_s);
         const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
         float4 qv[16];
         lds_dma_wait();
 #pragma unroll
         for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
-        for (int r = 0; r < K; ++r) {
-            const int want = 2 * r + h;
-            float key = kBig; int row0 = -1;
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                if (rank_own[i] == want) { key = vk[i]; row0 = g0[i]; }
-                if (rank_par[i] == want) { key = pk[i]; row0 = pg[i]; }
-            }
+        for (int r = 0; r < K; ++r) {
+            const float key = rkey[r]; const int row0 = rrow[r];
             const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
             const bool need = row0 >= 0 && qvalid && !cannot;
             if (__ballot(need) == 0ull) break;
             const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
+            // 16 lanes fetch one 256-B row: DMA instruction i serves the lanes 4 i .. 4 i + 3 (their row of sub-round u).  The
+            // survivors sit in the lanes [0, nv) and [32, 32 + nv): instructions i and i + 8 are issued while 4 i < nv
             int rowsrc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (swz[i & 3] & 255);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents are in registers
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
+            for (int i = 0; i < 8; ++i) {
+                if (4 * i < nv) {
+                    lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
+                    lds_dma_b128(lds_land + (uint32_t)(i + 8) * 1024u, rowsrc[i + 8], frsrc_t, 0);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < GRP; ++u) {
                 float4 ra_[16];
@@ -1088,7 +1176,12 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                 if (u + 1 < GRP) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
+                    for (int i = 0; i < 8; ++i) {
+                        if (4 * i < nv) {
+                            lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
+                            lds_dma_b128(lds_land + (uint32_t)(i + 8) * 1024u, rowsrc[i + 8] + (u + 1) * 256, frsrc_t, 0);
+                        }
+                    }
                 }
                 const float da = l2sqr64_canonical_regs(qv, ra_);
                 const int ta_ = row0 + u;
@@ -1101,17 +1194,24 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             insert2(pi0 >= 0, pd0, pi0, pq0);
             insert2(pi1 >= 0, pd1, pi1, pq1);
         }
-        const float tau = fminf(vk[K - 1], pk[K - 1]);
         if (qvalid && h == 0) {
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
-            knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
-            knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
             bool certified = (tau >= 1.0e38f);       // the empty-slot sentinel: every train row is a candidate (a NaN tau compares false)
+            double lmiss = 0.0;
             if (!certified && b1i >= 0) {
                 const double eps = e1 + fabs((double)tau) * kTrunc;
-                certified = (qn + (double)tau - eps) > (double)b1q * (1.0 + 1.0 / 2097152.0);     // false on NaN (e1 of non-finite rows)
+                lmiss = qn + (double)tau - eps;                                                    // every row outside the kept groups has D >= lmiss
+                certified = lmiss > (double)b1q * (1.0 + 1.0 / 2097152.0);     // false on NaN (e1 of non-finite rows)
             }
-            if (!certified) {
+            // Not certified, but the ratio test is already decided: the true second-nearest has D1 <= b1q, the true nearest
+            // D0 >= min(b0q, lmiss); if that is >= ratio^2 (1 + 2^-20) b1q the query cannot pass whatever the other rows are.
+            const bool lost = !certified && b1i >= 0 && lmiss >= ratio2m * (double)b1q && (double)b0q >= ratio2m * (double)b1q;   // false on NaN
+            if (lost) mark_rejected(qrow);
+            else {
+                knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
+                knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
+            }
+            if (!certified && !lost) {
                 atomicAdd(&counters[1], 1);
                 knn_d2[pd.out_off + qrow] = b1i >= 0 ? b1q : FLT_MAX;     // the refine pass's threshold: the exact second best so far
                 if (flagged) {           // audit of THIS pass's certificate: its failures on the global list
@@ -1973,21 +2073,20 @@ bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS -
 
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2)
+                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2, double ratio, int32_t *rejected)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_knn_bf16x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // (set on every launch, like the other large-LDS kernels: the attribute belongs to the current device)
+    ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_knn_bf16x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the ratio screen's constant: ratio^2 (1 + 2^-20); a ratio that is not a finite number >= 0 switches the screen off
+    const double ratio2m = (ratio >= 0.0 && ratio < 1.0e150) ? ratio * ratio * (1.0 + 1.0 / 1048576.0) : (double)INFINITY;
     void *h = const_cast<void *>(hi);
     hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(n_blocks), dim3(256), lds, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, knn_d2);
+                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, knn_d2, ratio2m, rejected);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -37,7 +37,9 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 size_t l2_hi_bytes(long long total_rows);
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2 /* one float per query: exact second-best d^2 of an uncertified query */);
+                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2 /* one float per query: exact second-best d^2 of an uncertified query */,
+                         double ratio /* the ratio screen (queries that provably fail d0 < ratio d1 get train index -2 and no re-rank); +inf: off */,
+                         int32_t *rejected /* audit: the screen's rejections on this list (counters[0]), or NULL */);
 // threshold-filter second pass over the one-product pass's uncertified queries (in_cnt / in_list): exact results written in place;
 // chunks whose hit list overflows are binned for the exact re-scan (pair_cnt / pair_list, flagged, counters[0])
 int launch_l2_refine(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,

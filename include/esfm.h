@@ -88,7 +88,7 @@ typedef enum esfm_kernel_id {
     ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
     ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
     ESFM_K_ORB_FAST = 12,     /* orb_fast_kernel: FAST-9/16 score of every pyramid pixel          */
-    ESFM_K_L2_SECOND = 13,    /* l2_knn_bf16_kernel<LIST>: three-product pass over the queries the one-product pass left uncertified */
+    ESFM_K_L2_SECOND = 13,    /* l2_refine_kernel: threshold-filter pass over the queries the one-product pass left uncertified */
     ESFM_K_COUNT = 14
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
@@ -163,8 +163,9 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
  * queries whose MFMA candidate list could not be certified and were re-scanned
  * exactly (see DESIGN.md "certified re-rank").  For tests and profiling. */
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned);
-/* 64-float descriptors: queries the one-product bf16 pass could not certify and handed to the three-product pass
- * (of which n_rescanned went on to the exact re-scan).  0 for other widths. */
+/* 64-float descriptors: queries the one-product bf16 pass could not certify and handed to the threshold-filter
+ * pass (l2_refine_kernel), of which n_rescanned went on to the exact re-scan.  0 for other widths.  Queries the
+ * ratio screen dropped (esfm_match_*: provably d0 >= ratio d1) are in neither count. */
 int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass);
 
 /* Audit of the L2 certificate (tests only; the default mode 0 is the product path).
@@ -172,7 +173,11 @@ int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass);
  *           2-NN table holds the pass's own answer for every query;
  *   mode 2: every query is brute-forced by l2_exact_scan_kernel (no MFMA pass);
  *   mode 3: (64-float descriptors) the one-product bf16 pass ALONE: the table holds its answer for every query and
- *           esfm_match_last_flagged() lists what it could not certify (mode 1 audits the two MFMA passes together).
+ *           esfm_match_last_flagged() lists what it could not certify (mode 1 audits the two MFMA passes together);
+ *   mode 4: (64-float descriptors, esfm_match_pairs_dev) the one-product pass alone WITH its ratio screen:
+ *           esfm_match_last_flagged() lists the queries it dropped as "cannot pass d0 < ratio d1" (the reference's
+ *           test, feature_matching.cpp:133).  Every listed query must fail that test on the brute-force table
+ *           (rejected_but_would_pass == 0).  The match lists of a mode-4 call are not final (no second pass).
  * Diffing the two tables row by row and removing the rows esfm_match_last_flagged() lists gives
  * the number of queries the certificate accepted with a wrong answer; it must be 0. */
 int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode);

@@ -64,6 +64,41 @@ def _audit(sets, pairs, ctx=None, label=""):
     return n_q, len(flagged), len(front_flagged)
 
 
+def _audit_screen(sets, pairs, ctx=None, label="", ratios=(0.5, 0.8, 1.0)):
+    """Audit mode 4 (round 4): the one-product pass drops the queries it can PROVE fail the reference's test d0 < ratio d1
+    (feature_matching.cpp:133) without re-ranking them.  Every dropped query must fail the test on the brute-force table
+    (rejected_but_would_pass == 0), and the product path's match lists must be the brute force's survivors, bit for bit."""
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
+    pm = E.PairMatcher(bank, pairs, ctx) if ctx is not None else E.PairMatcher(bank, pairs)
+    pm.set_l2_audit(2)
+    e_idx, e_dist = pm.knn2(); pm.ctx.synchronize()
+    e_idx = e_idx.cpu().numpy().copy(); e_dist = e_dist.cpu().numpy().copy()
+    pm.set_l2_audit(0)
+    out = {}
+    for ratio in ratios:
+        res = pm.match(ratio).to_host()
+        n_q, n_rescan = pm.stats(); n_second = pm.second_pass()
+        off = np.asarray(pm.offset, np.int64)
+        pm.set_l2_audit(4)
+        pm.match(ratio); pm.ctx.synchronize()
+        rej = pm.flagged()
+        pm.set_l2_audit(0)
+        would_pass = (e_idx[:, 0] >= 0) & (e_idx[:, 1] >= 0) & (e_dist[:, 0].astype(np.float64) < ratio * e_dist[:, 1].astype(np.float64))
+        rows = (off[rej[:, 0]] + rej[:, 1]) if len(rej) else np.zeros(0, np.int64)
+        assert len(set(rows.tolist())) == len(rows), f"{label}: a query was rejected twice"
+        rbwp = int(would_pass[rows].sum())
+        print(f"\n{label}, ratio {ratio}: {n_q} queries, {len(rows)} dropped by the ratio screen ({100.0 * len(rows) / max(n_q, 1):.2f} %), "
+              f"{int(would_pass.sum())} pass the test, second pass {n_second}, re-scan {n_rescan}, rejected-but-would-pass {rbwp}")
+        assert rbwp == 0, (label, ratio, rows[would_pass[rows]][:10])
+        for p in range(len(pairs)):
+            sl = slice(int(off[p]), int(off[p + 1]))
+            keep = np.nonzero(would_pass[sl])[0]
+            q, t, d = res[p]
+            assert np.array_equal(q, keep) and np.array_equal(t, e_idx[sl][keep, 0]) and np.array_equal(_bits(d), _bits(e_dist[sl][keep, 0])), (label, ratio, p)
+        out[ratio] = (n_q, len(rows), n_second)
+    return out
+
+
 def test_audit_config4_shard():
     """Rank 3 of 8 of config 4's pair list, pairs at full size (8192 x 8192 x 64; 96 images instead of 256 -- the image count only
     multiplies the number of pairs: 570 here, 4080 at 256)."""
@@ -72,6 +107,8 @@ def test_audit_config4_shard():
     pairs = E.shard_pair_list(n_img, np.full(n_img, n_feat, np.int32), rank, world)
     n_q, n_flag, n_front = _audit(sets, pairs, label="config-4 shard (570 pairs of 8192 x 8192)")
     assert n_q == len(pairs) * n_feat and n_flag < n_q // 50 and 0 < n_front < n_q // 20
+    scr = _audit_screen(sets, pairs, label="config-4 shard (570 pairs of 8192 x 8192)")
+    assert scr[0.5][1] > n_q // 2            # the screen is doing the work at the reference's ratio
 
 
 def test_audit_fountain_surf_descriptors(gpu_ctx):
@@ -80,6 +117,7 @@ def test_audit_fountain_surf_descriptors(gpu_ctx):
     sets = [E.surf_detect_and_compute(imgs[k], 300.0, None, gpu_ctx)[1] for k in range(len(imgs))]
     n_q, n_flag, n_front = _audit(sets, synth.all_pairs(len(sets)), label="fountain SURF-300 descriptors (55 pairs)")
     assert n_q == sum(len(sets[i]) for i, _ in synth.all_pairs(len(sets)))
+    _audit_screen(sets, synth.all_pairs(len(sets)), gpu_ctx, label="fountain SURF-300 descriptors (55 pairs)")
 
 
 def _adversarial(case):
@@ -117,6 +155,7 @@ def test_audit_adversarial_sets(gpu_ctx, oracle_lib, case):
     """The inputs of test_l2_split_bf16_pass_adversarial (same seeds): audited, and the brute force itself against the oracle."""
     q, t = _adversarial(case)
     _audit([t, q], np.array([[1, 0]], np.int32), label=f"adversarial '{case}'")
+    _audit_screen([t, q], np.array([[1, 0]], np.int32), label=f"adversarial '{case}'")
     idx, dist = E.knn_match_l2(q, t, gpu_ctx)
     ridx, rdist = oracle_lib.knn2_l2(q, t)
     assert np.array_equal(idx, ridx) and np.array_equal(_bits(dist), _bits(rdist))

@@ -75,6 +75,15 @@ def test_msurf4k_every_query_bitexact_and_certificate_sound(oracle_lib):
     assert f_cbw == [] and len(f_flagged) < n_q // 20
 
 
+def test_msurf4k_ratio_screen_audit():
+    """Round 4: the matcher's ratio screen on the metric's workload (audit mode 4), ratios 0.5 (the reference's) / 0.8 / 1.0."""
+    from test_certificate_audit_gpu import _audit_screen
+    sets = synth.surf_like_sets(25, 4096, pool=16384, seed_base=1000)
+    scr = _audit_screen(sets, synth.all_pairs(25), label="M-SURF-4k")
+    n_q, n_rej, n_second = scr[0.5]
+    assert n_q == 300 * 4096 and n_rej > n_q * 8 // 10 and n_second < n_q // 100
+
+
 def test_ba25_metric_size_trace_matches_oracle(gpu_ctx, oracle_lib):
     """BA-25: 25 cams, 30 000 pts, 240 000 obs, seed 4000 -- 8 LM iterations, cost 1e-9 / radius 1e-6 per iteration,
     accept pattern exact, parameters at the reference's f32 write-back precision."""
