@@ -57,6 +57,16 @@ struct esfm_ctx {
     esfm::DevBuf norms, pair_tab, knn_idx, knn_dist, flagged, counters, stage_a, stage_b, stage_c, stage_d, stage_e;
     esfm::DevBuf pair_cnt, pair_list;   // uncertified queries of the L2 pass binned per pair (one counter per pair; the pair's slice of the query numbering)
     esfm::DevBuf pair_cnt2, pair_list2;   // the same for the second (three-product) pass over what the one-product pass left uncertified
+    esfm::DevBuf pair_cnt2b;           // second phase of pair_cnt2: a call fills one phase, its one-product kernel zeroes the other for the next call
+    int l2_phase = 0;                  // phase the NEXT one-product call fills
+    int l2_phase_pairs[2] = {0, 0};    // entries of each phase that may be non-zero
+    int32_t *counters_cur = nullptr;   // the 16 counters of the last L2 call (esfm_match_last_stats / _second_pass / _flagged)
+    esfm::DevBuf fin_pool, fin_region_cnt, fin_done;   // l2_finish_kernel: hit pool (one region per chunk of 32 uncertified queries), its fill counts, per-pair arrival counters
+    // esfm_match_prepare_dev: the derived per-row operands (bf16 images, norms, residual norms; 0/1 byte image for Hamming) in l2_hi /
+    // norms / hm_exp belong to this descriptor buffer and are not recomputed by the match calls
+    const void *prep_desc = nullptr;
+    int prep_metric = 0, prep_width = 0;
+    int64_t prep_rows = 0;
     esfm::DevBuf knn_d2;   // exact second-best d^2 of the queries the one-product pass left uncertified (the refine pass's thresholds)
     esfm::DevBuf l2_hi;    // one-product pass: bf16(t) and bf16(-2 q) images (128 B per row each) and the two residual norms per row
     esfm::DevBuf hm_exp;   // expanded descriptor image: 0/1 bytes + start values (Hamming MFMA) or bf16 hi/lo halves (L2), 256 B per row

@@ -79,86 +79,137 @@ int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
     return ESFM_OK;
 }
 
+// Where the ratio test's survivors go (the match entry points); NULL: the raw 2-NN table is the result.
+struct MatchOut { int32_t *query_idx, *train_idx; float *distance; int32_t *n_out; };
+
+// (re)allocates a buffer of counters that must read zero: a fresh allocation is cleared once, after that the kernels leave it clean
+int reserve_zeroed(esfm::DevBuf &b, size_t bytes, hipStream_t st, bool *grew = nullptr)
+{
+    if (bytes <= b.cap) return ESFM_OK;
+    if (int rc = b.reserve(bytes)) return rc;
+    ESFM_HIP_TRY(hipMemsetAsync(b.ptr, 0, b.cap, st));
+    if (grew) *grew = true;
+    return ESFM_OK;
+}
+
+bool is_prepared(const esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int64_t total_rows, int width)
+{
+    return ctx->prep_desc != nullptr && ctx->prep_desc == desc_dev && ctx->prep_metric == (int)metric && ctx->prep_rows == total_rows &&
+           ctx->prep_width == width;
+}
+
 // 2-NN table for every query of every pair, written to knn_idx/knn_dist (device, 2 per query).
 // `ratio`: the caller will only keep the queries with d0 < ratio d1 (the match entry points), so the one-product pass may drop the
 // ones that provably fail (train index -2, see l2_knn_bf16x1_kernel); INFINITY: every query's exact 2-NN (the knn2 entry points).
+// `mo` != NULL: the path may run the ratio test + compaction itself (64-float L2: inside l2_finish_kernel) and says so in *ratio_done.
 int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width, const PairPlan &plan,
-              const PairDesc *dev_tab, int32_t *knn_idx, float *knn_dist, double ratio)
+              const PairDesc *dev_tab, int32_t *knn_idx, float *knn_dist, double ratio, const MatchOut *mo, bool *ratio_done)
 {
+    if (ratio_done) *ratio_done = false;
     const int n_pairs = (int)plan.tab.size();
     if (n_pairs == 0 || plan.total_queries == 0) return ESFM_OK;
     hipStream_t st = ctx->stream;
+    const bool prepared = is_prepared(ctx, metric, desc_dev, plan.total_rows, width);
     if (metric == ESFM_L2_F32) {
         const float *desc = reinterpret_cast<const float *>(desc_dev);
-        if (int rc = ctx->counters.reserve(64)) return rc;
+        // counters: [0,16) and [16,32) the two phases of the one-product path, [32,48) the other L2 passes, [48,64) scratch
+        if (int rc = reserve_zeroed(ctx->counters, 64 * sizeof(int32_t), st)) return rc;
         if ((ctx->l2_audit == 3 || ctx->l2_audit == 4) && !(esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt))) {
             esfm::set_error("audit modes 3 and 4 need the one-product pass (64-float descriptors, train sets <= 65536 rows, ESFM_L2_PASS unset)");
             return ESFM_ERR_UNSUPPORTED;
         }
-        const bool bf16_pass = esfm::l2_mfma_supported(width) && ctx->l2_audit != 2 && esfm::l2_bf16_pass(width);
-        if (!bf16_pass) ESFM_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 64, st));     // (the bf16 pass's split kernel zeroes them)
         ctx->last_n_queries = plan.total_queries;
+        int32_t *cnt_other = ctx->counters.as<int32_t>() + 32;       // the passes that zero their counters themselves
+        ctx->counters_cur = cnt_other;
         if (esfm::l2_mfma_supported(width) && ctx->l2_audit != 2) {
-            if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
             const int64_t cap64 = std::min<int64_t>(plan.total_queries, (int64_t)1 << 30);
             if (int rc = ctx->flagged.reserve(sizeof(int32_t) * 2 * (size_t)cap64)) return rc;
+            const bool front = esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt);
+            if (front) {
+                // 64-float rows.  Launch 1 (only when the descriptor buffer has not been prepared): bf16 images, norms, residual norms.
+                // Launch 2: one bf16 product per f32 product, ratio screen, exact re-rank of the survivors, certificate
+                // (l2_knn_bf16x1_kernel).  Launch 3: its uncertified queries through the threshold filter, overflowed chunks by
+                // brute force, ratio test + compaction (l2_finish_kernel).  Audit modes: 1 no brute force, 3 / 4 launch 2 alone.
+                bool grew = false;
+                if (!prepared) {
+                    ctx->prep_desc = nullptr;          // the images below replace whatever was prepared
+                    if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
+                    if (int rc = ctx->l2_hi.reserve(esfm::l2_hi_bytes(plan.total_rows))) return rc;
+                }
+                if (int rc = ctx->pair_list2.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
+                if (int rc = ctx->knn_d2.reserve(sizeof(float) * (size_t)plan.total_queries)) return rc;
+                grew = false;
+                if (int rc = reserve_zeroed(ctx->pair_cnt2, sizeof(int32_t) * (size_t)n_pairs, st, &grew)) return rc;
+                if (grew) ctx->l2_phase_pairs[0] = 0;
+                grew = false;
+                if (int rc = reserve_zeroed(ctx->pair_cnt2b, sizeof(int32_t) * (size_t)n_pairs, st, &grew)) return rc;
+                if (grew) ctx->l2_phase_pairs[1] = 0;
+                if (int rc = reserve_zeroed(ctx->fin_done, sizeof(int32_t) * (size_t)n_pairs, st)) return rc;
+                const int n_regions = (int)std::min<int64_t>(plan.total_queries / 32 + n_pairs, 65536);
+                if (int rc = reserve_zeroed(ctx->fin_region_cnt, sizeof(int32_t) * (size_t)n_regions, st)) return rc;
+                if (int rc = ctx->fin_pool.reserve(esfm::l2_finish_region_bytes() * (size_t)n_regions)) return rc;
+                const int ph = ctx->l2_phase;
+                int32_t *cur_cnt = (ph ? ctx->pair_cnt2b : ctx->pair_cnt2).as<int32_t>(), *oth_cnt = (ph ? ctx->pair_cnt2 : ctx->pair_cnt2b).as<int32_t>();
+                int32_t *cur_counters = ctx->counters.as<int32_t>() + 16 * ph, *oth_counters = ctx->counters.as<int32_t>() + 16 * (1 - ph);
+                ctx->counters_cur = cur_counters;
+                if (!prepared) {
+                    if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, nullptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>() + 48,
+                                                            nullptr, 0, ctx->l2_hi.ptr, nullptr))
+                        return rc;
+                }
+                {
+                    esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
+                    int32_t *audit_list = (ctx->l2_audit == 3 || ctx->l2_audit == 4) ? ctx->flagged.as<int32_t>() : nullptr;
+                    if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
+                                                            plan.n_blocks2, knn_idx, knn_dist, ctx->l2_audit == 3 ? audit_list : nullptr,
+                                                            cur_counters, (int)cap64, cur_cnt, ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(),
+                                                            ratio, ctx->l2_audit == 4 ? audit_list : nullptr, oth_cnt, ctx->l2_phase_pairs[1 - ph], oth_counters))
+                        return rc;
+                }
+                ctx->l2_phase_pairs[1 - ph] = 0;
+                ctx->l2_phase_pairs[ph] = n_pairs;
+                ctx->l2_phase = 1 - ph;
+                if (ctx->l2_audit == 3 || ctx->l2_audit == 4) return ESFM_OK;   // audit: the one-product pass's own answers and failures / rejections
+                esfm::KernelTimer tm(ctx, ESFM_K_L2_SECOND);
+                if (int rc = esfm::launch_l2_finish(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs, cur_cnt,
+                                                    ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(), knn_idx, knn_dist, cur_counters,
+                                                    ctx->flagged.as<int32_t>(), (int)cap64, ctx->fin_pool.as<int32_t>(), ctx->fin_region_cnt.as<int32_t>(),
+                                                    n_regions, ctx->fin_done.as<int32_t>(), ctx->l2_audit == 1, mo != nullptr, ratio,
+                                                    mo ? mo->query_idx : nullptr, mo ? mo->train_idx : nullptr, mo ? mo->distance : nullptr, mo ? mo->n_out : nullptr))
+                    return rc;
+                if (mo && ratio_done) *ratio_done = true;
+                return ESFM_OK;
+            }
+            ctx->prep_desc = nullptr;          // the passes below write their own norms / images
+            if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
             if (esfm::l2_bf16_pass(width)) {
-                // 64-float rows.  Pass A: one bf16 product per f32 product, certifies most queries (l2_knn_bf16x1_kernel); pass B: its
-                // uncertified queries, pair by pair, through a threshold-filter sweep (l2_refine_kernel) that makes them exact; a
-                // chunk whose hit list overflows there takes the exact re-scan.  Without pass A (ESFM_L2_PASS=bf16x3, train sets of
-                // more than 65536 rows): the three-product kernel + re-scan of round 2.  Audit modes: 1 stops before the re-scan,
-                // 3 runs pass A alone (its failures on the flagged list).
-                const bool front = esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt);
-                if (!front) { if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc; }
+                // 64-float rows without the one-product pass (ESFM_L2_PASS=bf16x3, train sets of more than 65536 rows): the three-product
+                // kernel of round 2 + the exact re-scan of its uncertified queries, pair by pair.  Audit mode 1 stops before the re-scan.
+                if (int rc = ctx->hm_exp.reserve(esfm::l2_split_bytes(width, plan.total_rows))) return rc;
                 if (int rc = ctx->pair_cnt.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
                 if (int rc = ctx->pair_list.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
-                if (front) {
-                    if (int rc = ctx->l2_hi.reserve(esfm::l2_hi_bytes(plan.total_rows))) return rc;
-                    if (int rc = ctx->pair_cnt2.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
-                    if (int rc = ctx->pair_list2.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
-                    if (int rc = ctx->knn_d2.reserve(sizeof(float) * (size_t)plan.total_queries)) return rc;
-                }
-                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, front ? nullptr : ctx->hm_exp.ptr, ctx->norms.as<float>(), ctx->counters.as<int32_t>(),
-                                                        ctx->pair_cnt.as<int32_t>(), n_pairs, front ? ctx->l2_hi.ptr : nullptr,
-                                                        front ? ctx->pair_cnt2.as<int32_t>() : nullptr))
+                if (int rc = esfm::launch_l2_split_bf16(st, desc, plan.total_rows, ctx->hm_exp.ptr, ctx->norms.as<float>(), cnt_other,
+                                                        ctx->pair_cnt.as<int32_t>(), n_pairs, nullptr, nullptr))
                     return rc;
-                if (front) {
-                    {
-                        esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
-                        if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
-                                                                plan.n_blocks2, knn_idx, knn_dist, ctx->l2_audit == 3 ? ctx->flagged.as<int32_t>() : nullptr,
-                                                                ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt2.as<int32_t>(),
-                                                                ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(), ratio,
-                                                                ctx->l2_audit == 4 ? ctx->flagged.as<int32_t>() : nullptr))
-                            return rc;
-                    }
-                    if (ctx->l2_audit == 3 || ctx->l2_audit == 4) return ESFM_OK;   // audit: the one-product pass's own answers and failures / rejections
-                }
-                if (front) {
-                    esfm::KernelTimer tm(ctx, ESFM_K_L2_SECOND);
-                    if (int rc = esfm::launch_l2_refine(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
-                                                        ctx->pair_cnt2.as<int32_t>(), ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(),
-                                                        knn_idx, knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64,
-                                                        ctx->pair_cnt.as<int32_t>(), ctx->pair_list.as<int32_t>()))
-                        return rc;
-                } else {
+                {
                     esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                     if (int rc = esfm::launch_l2_knn_bf16(st, desc, ctx->hm_exp.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
                                                           plan.n_blocks, knn_idx, knn_dist, ctx->flagged.as<int32_t>(),
-                                                          ctx->counters.as<int32_t>(), (int)cap64, ctx->pair_cnt.as<int32_t>(),
-                                                          ctx->pair_list.as<int32_t>(), nullptr, nullptr))
+                                                          cnt_other, (int)cap64, ctx->pair_cnt.as<int32_t>(), ctx->pair_list.as<int32_t>()))
                         return rc;
                 }
-                if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the passes' own answer in place
+                if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the pass's own answer in place
                 // certificate failures, binned per pair by the pass: exact re-scan, the pair's queries sharing every train row
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_RESCAN);
                 return esfm::launch_l2_rescan64_pairs(st, desc, dev_tab, n_pairs, ctx->pair_cnt.as<int32_t>(), ctx->pair_list.as<int32_t>(),
                                                       knn_idx, knn_dist);
-            } else {
-                if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
+            }
+            ESFM_HIP_TRY(hipMemsetAsync(cnt_other, 0, 64, st));
+            if (int rc = esfm::launch_l2_norms(st, desc, width, plan.total_rows, ctx->norms.as<float>())) return rc;
+            {
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                 if (int rc = esfm::launch_l2_knn_mfma(st, width, desc, ctx->norms.as<float>(), dev_tab, n_pairs, plan.n_blocks, knn_idx,
-                                                      knn_dist, ctx->flagged.as<int32_t>(), ctx->counters.as<int32_t>(), (int)cap64))
+                                                      knn_dist, ctx->flagged.as<int32_t>(), cnt_other, (int)cap64))
                     return rc;
             }
             if (ctx->l2_audit == 1) return ESFM_OK;   // audit: leave the pass's own answer in place
@@ -166,12 +217,13 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             const int grid = (int)std::min<int64_t>(plan.total_queries, 8 * (int64_t)ctx->num_cu);
             esfm::KernelTimer tm(ctx, ESFM_K_L2_RESCAN);
             if (int rc = esfm::launch_l2_exact_scan(st, width, desc, dev_tab, n_pairs, ctx->flagged.as<int32_t>(),
-                                                    ctx->counters.as<int32_t>(), plan.total_queries, grid, knn_idx, knn_dist))
+                                                    cnt_other, plan.total_queries, grid, knn_idx, knn_dist))
                 return rc;
         } else {
-            // no MFMA build for this width: exact scan of every query (correct, not fast)
+            // no MFMA build for this width (or audit mode 2): exact scan of every query (correct, not fast)
+            ESFM_HIP_TRY(hipMemsetAsync(cnt_other, 0, 64, st));
             const int grid = (int)std::min<int64_t>(plan.total_queries, 64 * (int64_t)ctx->num_cu);
-            if (int rc = esfm::launch_l2_exact_scan(st, width, desc, dev_tab, n_pairs, nullptr, ctx->counters.as<int32_t>(),
+            if (int rc = esfm::launch_l2_exact_scan(st, width, desc, dev_tab, n_pairs, nullptr, cnt_other,
                                                     plan.total_queries, grid, knn_idx, knn_dist))
                 return rc;
         }
@@ -182,10 +234,13 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             esfm::set_error("hamming descriptors must be 16, 32 or 64 bytes (got %d)", width);
             return ESFM_ERR_UNSUPPORTED;
         }
-        if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, plan.total_rows))) return rc;
+        if (!prepared) {
+            ctx->prep_desc = nullptr;
+            if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, plan.total_rows))) return rc;
+        }
         esfm::KernelTimer tm(ctx, ESFM_K_HAMMING_KNN);
         return esfm::launch_hamming_knn(st, width, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, n_pairs, plan.n_blocks, knn_idx,
-                                        knn_dist);
+                                        knn_dist, /*expanded=*/prepared);
     }
     esfm::set_error("unknown metric %d", (int)metric);
     return ESFM_ERR_INVALID_ARG;
@@ -226,21 +281,27 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
     if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)nq)) return rc;
     if (int rc = ctx->knn_dist.reserve(sizeof(float) * 2 * (size_t)nq)) return rc;
-    if (int rc = knn2_core(ctx, metric, d, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), filtered ? ratio : (double)INFINITY)) return rc;
+    if (filtered) {
+        if (int rc = ctx->stage_b.reserve(sizeof(int32_t) * (size_t)nq)) return rc;
+        if (int rc = ctx->stage_c.reserve(sizeof(int32_t) * (size_t)nq)) return rc;
+        if (int rc = ctx->stage_d.reserve(sizeof(float) * (size_t)nq)) return rc;
+        if (int rc = ctx->stage_e.reserve(sizeof(int32_t))) return rc;
+    }
+    const MatchOut mo = {ctx->stage_b.as<int32_t>(), ctx->stage_c.as<int32_t>(), ctx->stage_d.as<float>(), ctx->stage_e.as<int32_t>()};
+    bool ratio_done = false;
+    if (int rc = knn2_core(ctx, metric, d, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), filtered ? ratio : (double)INFINITY,
+                           filtered ? &mo : nullptr, &ratio_done))
+        return rc;
     if (!filtered) {
         ESFM_HIP_TRY(hipMemcpyAsync(o_a, ctx->knn_idx.ptr, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
         ESFM_HIP_TRY(hipMemcpyAsync(o_c, ctx->knn_dist.ptr, sizeof(float) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         return ESFM_OK;
     }
-    if (int rc = ctx->stage_b.reserve(sizeof(int32_t) * (size_t)nq)) return rc;
-    if (int rc = ctx->stage_c.reserve(sizeof(int32_t) * (size_t)nq)) return rc;
-    if (int rc = ctx->stage_d.reserve(sizeof(float) * (size_t)nq)) return rc;
-    if (int rc = ctx->stage_e.reserve(sizeof(int32_t))) return rc;
-    if (int rc = esfm::launch_ratio_compact(st, dev_tab, 1, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio,
-                                            ctx->stage_b.as<int32_t>(), ctx->stage_c.as<int32_t>(), ctx->stage_d.as<float>(),
-                                            ctx->stage_e.as<int32_t>()))
-        return rc;
+    if (!ratio_done)
+        if (int rc = esfm::launch_ratio_compact(st, dev_tab, 1, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio,
+                                                mo.query_idx, mo.train_idx, mo.distance, mo.n_out))
+            return rc;
     int32_t n = 0;
     ESFM_HIP_TRY(hipMemcpyAsync(&n, ctx->stage_e.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
@@ -298,7 +359,7 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
     ESFM_REQUIRE(desc_dev && knn_idx_dev && knn_dist_dev, "device pointer is NULL");
     const PairDesc *dev_tab = nullptr;
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
-    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev, (double)INFINITY);
+    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev, (double)INFINITY, nullptr, nullptr);
 }
 
 int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
@@ -318,9 +379,45 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
     if (int rc = ctx->knn_idx.reserve(sizeof(int32_t) * 2 * (size_t)std::max<int64_t>(plan.total_queries, 1))) return rc;
     if (int rc = ctx->knn_dist.reserve(sizeof(float) * 2 * (size_t)std::max<int64_t>(plan.total_queries, 1))) return rc;
-    if (int rc = knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio)) return rc;
+    const MatchOut mo = {query_idx_dev, train_idx_dev, distance_dev, n_out_dev};
+    bool ratio_done = false;
+    if (plan.total_queries == 0) ESFM_HIP_TRY(hipMemsetAsync(n_out_dev, 0, sizeof(int32_t) * (size_t)n_pairs, ctx->stream));
+    if (int rc = knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio, &mo, &ratio_done)) return rc;
+    if (ratio_done || plan.total_queries == 0) return ESFM_OK;
     return esfm::launch_ratio_compact(ctx->stream, dev_tab, n_pairs, ctx->knn_idx.as<int32_t>(), ctx->knn_dist.as<float>(), ratio,
                                       query_idx_dev, train_idx_dev, distance_dev, n_out_dev);
+}
+
+int esfm_match_prepare_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int64_t total_rows, int width)
+{
+    if (int rc = check_common(ctx, metric, width)) return rc;
+    ESFM_REQUIRE(total_rows >= 0 && total_rows < ((int64_t)1 << 31), "total_rows");
+    ESFM_REQUIRE(total_rows == 0 || desc_dev != nullptr, "desc_dev is NULL");
+    ctx->prep_desc = nullptr;
+    if (total_rows == 0) return ESFM_OK;
+    hipStream_t st = ctx->stream;
+    if (metric == ESFM_L2_F32 && esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass()) {
+        if (int rc = reserve_zeroed(ctx->counters, 64 * sizeof(int32_t), st)) return rc;
+        if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)total_rows)) return rc;
+        if (int rc = ctx->l2_hi.reserve(esfm::l2_hi_bytes(total_rows))) return rc;
+        if (int rc = esfm::launch_l2_split_bf16(st, reinterpret_cast<const float *>(desc_dev), total_rows, nullptr, ctx->norms.as<float>(),
+                                                ctx->counters.as<int32_t>() + 48, nullptr, 0, ctx->l2_hi.ptr, nullptr))
+            return rc;
+    } else if (metric == ESFM_HAMMING && esfm::hamming_supported(width) && esfm::hamming_expanded_bytes(width, total_rows) > 0) {
+        if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, total_rows))) return rc;
+        if (int rc = esfm::launch_hamming_expand(st, width, desc_dev, total_rows, ctx->hm_exp.ptr)) return rc;
+    } else {
+        return ESFM_OK;       // nothing to derive for this metric / width: the match calls work on the rows themselves
+    }
+    ctx->prep_desc = desc_dev; ctx->prep_metric = (int)metric; ctx->prep_rows = total_rows; ctx->prep_width = width;
+    return ESFM_OK;
+}
+
+int esfm_match_release_prepared(esfm_ctx *ctx)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    ctx->prep_desc = nullptr;
+    return ESFM_OK;
 }
 
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned)
@@ -328,8 +425,8 @@ int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanne
     if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(ctx)) return rc;
     int32_t c = 0;
-    if (ctx->counters.ptr) {
-        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->counters_cur) {
+        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters_cur, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (n_queries) *n_queries = ctx->last_n_queries;
@@ -342,8 +439,8 @@ int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass)
     if (!ctx || !n_second_pass) { esfm::set_error("esfm_match_last_second_pass: bad arguments"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(ctx)) return rc;
     int32_t c[2] = {0, 0};
-    if (ctx->counters.ptr) {
-        ESFM_HIP_TRY(hipMemcpyAsync(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->counters_cur) {
+        ESFM_HIP_TRY(hipMemcpyAsync(c, ctx->counters_cur, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     *n_second_pass = c[1];
@@ -362,8 +459,8 @@ int esfm_match_last_flagged(esfm_ctx *ctx, int32_t *out, int64_t cap, int64_t *n
     if (!ctx || !n || cap < 0 || (cap > 0 && !out)) { esfm::set_error("esfm_match_last_flagged: bad arguments"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(ctx)) return rc;
     int32_t c = 0;
-    if (ctx->counters.ptr) {
-        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->counters_cur) {
+        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters_cur, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     *n = c;

@@ -515,27 +515,29 @@ __global__ __launch_bounds__(256) void l2_split_bf16_kernel(const float4 *__rest
             if (ok && !odd) (img == 0 ? hi_t : hi_q)[f >> 1] = piece;
             const float e0 = __fsub_rn(sc * v.x, __uint_as_float(h0 << 16)), e1 = __fsub_rn(sc * v.y, __uint_as_float(h0 & 0xFFFF0000u));
             const float e2 = __fsub_rn(sc * v.z, __uint_as_float(h1 << 16)), e3 = __fsub_rn(sc * v.w, __uint_as_float(h1 & 0xFFFF0000u));
-            float r = 0.f;
-            r = fmaf(e0, e0, r); r = fmaf(e1, e1, r); r = fmaf(e2, e2, r); r = fmaf(e3, e3, r);
+            // (summed in double: the squares of residuals below ~1e-19 are denormal or zero in f32, and a residual norm that comes out
+            // too small would make the certificate's bound too small)
+            double r = (double)e0 * (double)e0 + (double)e1 * (double)e1 + (double)e2 * (double)e2 + (double)e3 * (double)e3;
             r += __shfl_xor(r, 1);
             r += __shfl_xor(r, 2);
             r += __shfl_xor(r, 4);
             r += __shfl_xor(r, 8);
-            if (ok && (f & 15) == 0) (img == 0 ? rho_t : rho_q)[f >> 4] = sqrtf(r) * 1.0005f;
+            if (ok && (f & 15) == 0) {
+                const double rd = sqrt(r) * 1.0005;
+                float rf = (float)rd;
+                if ((double)rf < rd) rf = nextafterf(rf, FLT_MAX);     // rounded up
+                (img == 0 ? rho_t : rho_q)[f >> 4] = rf;
+            }
         }
     }
     if (ok && (f & 15) == 0) norms[f >> 4] = s;
 }
 
-// LIST: the workgroups of a pair take the queries named in the pair's slice of in_list (in_cnt[pair] of them: what the one-product
-// pass could not certify) instead of the query set's rows in order; a workgroup past the end of the list leaves at once.
-template <bool LIST>
 __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ split,
                                                              const u32x4 *__restrict__ split_q, const float *__restrict__ norms, const PairDesc *__restrict__ pairs,
                                                              int n_pairs, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                              int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
-                                                             int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
-                                                             const int32_t *__restrict__ in_cnt, const int32_t *__restrict__ in_list)
+                                                             int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
 {
     constexpr int TT = 128, NS = 2, GRP = 4;                     // train rows per LDS tile, query sets of 32 per wave, rows per fold group
     constexpr int DIM = 64, QB = 128 * NS, SLOTS = 16, KS = 4;
@@ -556,10 +558,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
     const float *__restrict__ tn = norms + pd.t_row0;
     const int qbase = (lb - pd.blk_off) * QB + wave * 32 * NS;
-    const int nslots = LIST ? min(in_cnt[pi], nq) : nq;        // query slots of this pair: list entries, or the rows themselves
-    if (LIST && (lb - pd.blk_off) * QB >= nslots) return;      // (workgroup-uniform, before any barrier)
-    // query row of slot q of this pair (LIST: through the pair's list)
-    auto row_of_slot = [&](int q) { return LIST ? (q < nslots ? in_list[pd.out_off + q] : nq) : q; };
+    auto row_of_slot = [&](int q) { return q; };
 
     // Running top-3 per query set, TWO levels deep in the hot loop (l2_segment_gfx950.inc).  A lane's 16 results of a 32-train
     // step are four groups of four consecutive train rows (accumulator registers 4g .. 4g+3 = rows 8g + 4h + 0..3).  Per group:
@@ -762,18 +761,9 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
         // the 32 query rows of this set -> landing slots 0..31 (lanes j and j + 32 read the same slot); the group ranking below
         // runs in the transfer's shadow
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (LIST) {      // the 32 query rows are scattered: landing slot r takes the row lane r holds
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = 4 * i + (lane >> 4);
-                const int src = __builtin_amdgcn_ds_bpermute(r * 4, qrow) * 256 + (swz[i & 3] & 255);
-                lds_dma_b128(lds_land + (uint32_t)i * 1024u, src, frsrc_q, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
-        }
+        for (int i = 0; i < 8; ++i)
+            lds_dma_b128(lds_land + (uint32_t)i * 1024u, (qbase + 32 * s) * 256 + (i >> 2) * 4096 + swz[i & 3], frsrc_q, 0);
         const Master mst = master_load(s);
         const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
         const float vk[3] = {mst.v0, mst.v1, mst.v2};
@@ -859,6 +849,16 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     }
 }
 
+// The one-product pass's bound E1 on |(|q|^2 + score) - D| for every train row (D = the canonical float d^2; see the comment of
+// l2_knn_bf16x1_kernel): operand rounding (rB T + (2 |q| + rB) R), the three-product pass's 2^-15 (|q|^2 + max |t|^2) for norms, MFMA
+// accumulation and the canonical distance, and an ABSOLUTE floor of 2^-118 for whatever is flushed to zero or loses bits as a
+// denormal on the way (64 products and sums below 2^-126 each, in the norms, the matrix pipe and the residual norms: descriptors of
+// magnitude ~1e-20 and less).  Used by the first pass's certificate and ratio screen and by the threshold-filter pass: one formula.
+__device__ __forceinline__ double l2x1_e1(double qn, double rq, double sqrt_tmax, double tmax, double rmax)
+{
+    return (rq * sqrt_tmax + (2.0 * sqrt(qn) + rq) * rmax) * (1.0 + 1.0 / 512.0) + (qn + tmax) * (1.0 / 32768.0) + 0x1p-118;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The ONE-product distance pass (round 3): q.t ~ bf16(q).bf16(t), four v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 tile instead of
 // twelve.  Everything else is the machinery of l2_knn_bf16_kernel -- group-of-four fold, exact re-rank of the kept groups in the
@@ -884,8 +884,13 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                                int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
                                                                int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
-                                                               float *__restrict__ knn_d2, double ratio2m, int32_t *__restrict__ rejected)
+                                                               float *__restrict__ knn_d2, double ratio2m, int32_t *__restrict__ rejected,
+                                                               int32_t *__restrict__ zero_cnt, int zero_n, int32_t *__restrict__ zero_counters)
 {
+    // The per-pair list counters and the global counters exist twice: this launch fills one phase and zeroes the other for the NEXT
+    // call (whose finish kernel needs them immutable while it runs) -- no memset launch, no zeroing pass in front of this one.
+    if (threadIdx.x == 0) for (int e = blockIdx.x; e < zero_n; e += gridDim.x) zero_cnt[e] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 16) zero_counters[threadIdx.x] = 0;
     constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, GRP = 4, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
     constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
     constexpr int TILE_BYTES = TT * HS * 16;
@@ -1028,9 +1033,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
     const double sqrt_tmax = sqrt((double)tmax);
-    auto e1_of = [&](double qn, double rq) {
-        return (rq * sqrt_tmax + (2.0 * sqrt(qn) + rq) * (double)rmax) * (1.0 + 1.0 / 512.0) + (qn + (double)tmax) * (1.0 / 32768.0);
-    };
+    auto e1_of = [&](double qn, double rq) { return l2x1_e1(qn, rq, sqrt_tmax, (double)tmax, (double)rmax); };
     auto mark_rejected = [&](int qrow) {
         const size_t o = 2 * ((size_t)pd.out_off + qrow);
         knn_idx[o] = -2; knn_idx[o + 1] = -2;
@@ -1225,163 +1228,346 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-// The second pass over what l2_knn_bf16x1_kernel could not certify: a THRESHOLD FILTER instead of a second top-k.
-// For such a query the first pass has left the exact two best of its candidates; U = the exact second-best d^2.  Every train row
-// that can still change the answer has d^2 <= U, hence a one-product score s <= U - |q|^2 + E1 (E1: the first pass's bound on
-// |(|q|^2 + s) - d^2|, same formula).  So: the same bf16(-2 q).bf16(t) product on the matrix cores over the whole train set, a
-// compare of every score with the query's threshold, the few rows that pass (0.1 - 1.2 per query on the data simulated in
-// scratch/sim_bf16x1_cert.py) evaluated exactly in the oracle's order and merged with the two known neighbours.  The result is exact;
-// a chunk whose hit list overflows (adversarial inputs: every row inside the error) goes to the exact re-scan instead.
-// Work item = (pair, chunk of 32 uncertified queries); the four waves of the workgroup split the train set, fragments straight
-// from the bf16 image in global memory (the pass handles a fraction of a per cent of the queries: latency matters, not reuse).
-// Grid: `per_pair` workgroups per pair, workgroup (p, c) takes the chunks c, c + per_pair, ... of pair p's list.
-__global__ __launch_bounds__(512) void l2_refine_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
-                                                        const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
-                                                        const float *__restrict__ rho_t, const float *__restrict__ rho_q,
-                                                        const PairDesc *__restrict__ pairs, int per_pair,
-                                                        const int32_t *__restrict__ in_cnt, const int32_t *__restrict__ in_list,
-                                                        const float *__restrict__ knn_d2, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
-                                                        int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
-                                                        int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list)
+// Lowe ratio test (feature_matching.cpp:88 / :133: float < double * float, i.e. in double) and an order-preserving compaction of one
+// pair's survivors, by the THREADS threads of a workgroup, THREADS * kRatioPer queries per sweep (one round of loads for a 4096-row
+// set in either instantiation).  A thread takes kRatioPer CONSECUTIVE queries (their 2-NN records are
+// 32 + 32 contiguous bytes), so the survivors' order is thread order, then query order inside the thread: an exclusive scan of the
+// threads' counts places them.  A train index < 0 (no neighbour; -2: dropped by the one-product pass's ratio screen) never passes.
+// (Round 1: 256 threads, one query each, 16 sweeps of three barriers for a 4096-row set: 14 us per launch.)
+template <int THREADS, int kRatioPer>
+__device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int32_t *__restrict__ knn_idx, const float *__restrict__ knn_dist,
+                                                   double ratio, int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
+                                                   float *__restrict__ distance, int32_t *__restrict__ n_out_p, int *s_wave /* [THREADS / 64] */,
+                                                   int *s_base)
 {
-    constexpr int CAP = 1024, HS = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *s_base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < pd.nq; q0 += THREADS * kRatioPer) {
+        const int qa = q0 + tid * kRatioPer;
+        int ti[kRatioPer]; float d0[kRatioPer]; bool pass[kRatioPer];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < kRatioPer; ++u) {
+            const int q = qa + u;
+            pass[u] = false; ti[u] = -1; d0[u] = 0.f;
+            if (q < pd.nq) {
+                const size_t o = 2 * ((size_t)pd.out_off + q);
+                const int i0 = knn_idx[o], i1 = knn_idx[o + 1];
+                d0[u] = knn_dist[o];
+                const float d1 = knn_dist[o + 1];
+                ti[u] = i0;
+                pass[u] = (i0 >= 0) && (i1 >= 0) && ((double)d0[u] < ratio * (double)d1);
+            }
+            cnt += pass[u] ? 1 : 0;
+        }
+        // exclusive scan of cnt over the workgroup: inside the wave by shuffles, across waves through LDS
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = *s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        size_t o = (size_t)pd.out_off + off + (incl - cnt);
+#pragma unroll
+        for (int u = 0; u < kRatioPer; ++u) {
+            if (pass[u]) { query_idx[o] = qa + u; train_idx[o] = ti[u]; distance[o] = d0[u]; ++o; }
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < THREADS / 64; ++w) t += s_wave[w]; *s_base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out_p = *s_base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Everything behind the one-product pass in ONE launch (round 4; round 3 had three: l2_refine_kernel, l2_rescan64_pairs_kernel,
+// ratio_compact_kernel, and every launch boundary costs 5 - 10 us on this part):
+//   (1) the second pass over what l2_knn_bf16x1_kernel could not certify -- a THRESHOLD FILTER instead of a second top-k.  For such
+//       a query the first pass has left the exact two best of its candidates; U = the exact second-best d^2.  Every train row that
+//       can still change the answer has d^2 <= U, hence a one-product score s <= U - |q|^2 + E1 (E1: l2x1_e1).  So: the same
+//       bf16(-2 q).bf16(t) product on the matrix cores over the whole train set, a compare of every score with the query's
+//       threshold, the few rows that pass (0.1 - 1.2 per query on the data simulated in scratch/sim_bf16x1_cert.py) evaluated
+//       exactly in the oracle's order and merged with the two known neighbours;
+//   (2) the exact brute force of a chunk whose hit list overflows (adversarial inputs: every row inside the error);
+//   (3) the ratio test and the ordered compaction of the pair's survivors (ratio_compact_pair).
+// Work split: S workgroups per pair (blockIdx = (S - 1 - slice) * n_pairs + pair).  A pair without uncertified queries -- nearly all of them
+// once the ratio screen has run -- is finished by its slice-0 workgroup alone: (3), nothing else.  Otherwise workgroup (p, s) sweeps
+// the s-th slice of the train set for EVERY chunk of 32 queries of the pair's list (eight waves split the slice: with S = 8 a wave
+// sees 2 steps of 32 rows of a 4096-row set -- the pass is a latency chain, and this is what makes it short), appends its hits to
+// the chunk's region of a global pool, and arrives at the pair's counter; the LAST workgroup to arrive evaluates the hits exactly,
+// merges, brute-forces the overflowed chunks, and runs (3).  Nobody waits for anybody: no assumption about which workgroups are
+// resident.  in_cnt is immutable during the launch (the one-product pass of the NEXT call zeroes it: two phases), so every
+// workgroup derives the same region numbers from a prefix sum over the pairs' chunk counts.
+#ifndef ESFM_FIN_THREADS
+#define ESFM_FIN_THREADS 256
+#endif
+constexpr int kFinThreads = ESFM_FIN_THREADS, kFinCap = 1024, kFinWaves = kFinThreads / 64;
+
+// exact 2-NN of up to 32 listed queries of one pair by the whole workgroup, the oracle's arithmetic and (distance, index) order:
+// thread = train row (16 x 16 B in registers), the queries as LDS broadcasts; the 64 keys of a wave's rows are reduced to the two
+// smallest by shuffles and merged into lane k's running pair for query k.  The fallback of the fallback: ~3 us per query.
+__device__ __forceinline__ void finish_bruteforce_chunk(const float *__restrict__ desc, const PairDesc &pd, const int32_t *__restrict__ qrows /* LDS, nqc */,
+                                                        int nqc, float4 (*s_q)[16] /* LDS [32][16] */, unsigned long long (*s_keys)[32][2] /* LDS [waves][32][2] */,
+                                                        int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist)
+{
+    typedef unsigned long long u64;
+    constexpr u64 kEmpty = ~0ull;
+    auto key_of = [](float d, int t) { return d < FLT_MAX ? (((u64)__float_as_uint(d) << 32) | (u64)(uint32_t)t) : ~0ull; };   // FLT_MAX, +inf, NaN: never a neighbour
+    auto insert2 = [](u64 &b0, u64 &b1, u64 k) {
+        const u64 hi = k > b0 ? k : b0;
+        b0 = k > b0 ? b0 : k;
+        b1 = hi < b1 ? hi : b1;
+    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 *Q = reinterpret_cast<const float4 *>(desc + (size_t)pd.q_row0 * 64);
+    const float4 *T = reinterpret_cast<const float4 *>(desc + (size_t)pd.t_row0 * 64);
+    for (int e = tid; e < nqc * 16; e += kFinThreads) s_q[e >> 4][e & 15] = Q[(size_t)qrows[e >> 4] * 16 + (e & 15)];
+    __syncthreads();
+    u64 m0 = kEmpty, m1 = kEmpty;                    // lane k: query k's two best over this wave's rows
+    for (int t0 = wave * 64; t0 < pd.nt; t0 += kFinThreads) {
+        const int t = t0 + lane;
+        float4 ta[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ta[c] = t < pd.nt ? T[(size_t)t * 16 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nqc; ++k) {
+            float4 qa[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) qa[c] = s_q[k][c];
+            const float d2 = l2sqr64_canonical_regs(qa, ta);
+            u64 x0 = t < pd.nt ? key_of(sqrt_rn_f32(d2), t) : kEmpty, x1 = kEmpty;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 y0 = __shfl_xor(x0, o), y1 = __shfl_xor(x1, o);
+                insert2(x0, x1, y0);
+                insert2(x0, x1, y1);
+            }
+            if (lane == k) { insert2(m0, m1, x0); insert2(m0, m1, x1); }
+        }
+    }
+    if (lane < 32) { s_keys[wave][lane][0] = m0; s_keys[wave][lane][1] = m1; }
+    __syncthreads();
+    if (tid < nqc) {
+        u64 x0 = kEmpty, x1 = kEmpty;
+        for (int w = 0; w < kFinWaves; ++w) { insert2(x0, x1, s_keys[w][tid][0]); insert2(x0, x1, s_keys[w][tid][1]); }
+        const size_t o = 2 * ((size_t)pd.out_off + qrows[tid]);
+        const int i0 = (int)(uint32_t)x0, i1 = (int)(uint32_t)x1;
+        knn_idx[o] = i0; knn_idx[o + 1] = i1;
+        knn_dist[o] = i0 >= 0 ? __uint_as_float((uint32_t)(x0 >> 32)) : FLT_MAX;
+        knn_dist[o + 1] = i1 >= 0 ? __uint_as_float((uint32_t)(x1 >> 32)) : FLT_MAX;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
+                                                                const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
+                                                                const float *__restrict__ rho_t, const float *__restrict__ rho_q,
+                                                                const PairDesc *__restrict__ pairs, int n_pairs, int S,
+                                                                const int32_t *__restrict__ in_cnt, const int32_t *__restrict__ in_list,
+                                                                const float *__restrict__ knn_d2, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
+                                                                int32_t *__restrict__ counters, int32_t *__restrict__ flagged, int flag_cap,
+                                                                int32_t *__restrict__ pool, int32_t *__restrict__ region_cnt, int n_regions,
+                                                                int32_t *__restrict__ done, int skip_bruteforce, int do_ratio, double ratio,
+                                                                int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
+                                                                float *__restrict__ distance, int32_t *__restrict__ n_out)
+{
+    constexpr int CAP = kFinCap, HS = 8, NW = kFinWaves;
     constexpr float kBig = 3.0e38f;
-    __shared__ int s_nhit;
-    __shared__ int s_hq[CAP], s_ht[CAP];
+    __shared__ int s_nhit, s_kbase, s_last;
+    __shared__ int s_h[CAP];                      // hits of the chunk: (query slot in the chunk) << 21 | train row
     __shared__ float s_hd[CAP], s_hd2[CAP];
-    constexpr int NW = 8;                 // waves per workgroup (256 registers each): the train set is split NW ways (the pass is a latency chain per wave)
     __shared__ float s_red[2 * NW];
+    __shared__ int s_part[NW];
+    __shared__ int s_qrows[32];
+    __shared__ __attribute__((aligned(16))) float4 s_q[32][16];
+    __shared__ unsigned long long s_keys[NW][32][2];
+    __shared__ int s_wave[NW], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    // (chunk-major numbering: the workgroups that usually have work -- chunk 0 of every pair -- are consecutive, hence spread over
-    // the XCDs; pair-major put every one of them on XCD 0: 0.42 ms instead of 0.0x)
-    const int n_pairs = gridDim.x / per_pair;
-    const int c0 = blockIdx.x / n_pairs, p = blockIdx.x - c0 * n_pairs;
+    // slice 0 -- the workgroup that finishes a pair without uncertified queries on its own -- comes LAST in dispatch order: the others
+    // leave at once (or sweep their slice), and none of them waits for a CU behind three hundred ratio stages
+    const int sl = S - 1 - (int)(blockIdx.x / n_pairs), p = blockIdx.x % n_pairs;
     const PairDesc pd = pairs[p];
     const int nq = pd.nq, nt = pd.nt;
     const int cnt = min(in_cnt[p], nq);
-    if (c0 * 32 >= cnt) return;
-    const float *__restrict__ tn = norms + pd.t_row0;
-    const float *__restrict__ tr = rho_t + pd.t_row0;
-    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(hi_t + (size_t)pd.t_row0 * HS), 0, nt * (HS * 16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tn), 0, nt * 4, 0x00020000);
-    {   // max |t|^2 and max rho_t over the train set
-        float m = 0.f, r = 0.f;
-        for (int t = tid; t < nt; t += 64 * NW) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
+    if (cnt > 0) {
+        const int nchunks = (cnt + 31) >> 5;
+        // first region of this pair: chunks of the pairs in front of it
+        {
+            int part = 0;
+            for (int pp = tid; pp < p; pp += kFinThreads) part += (min(in_cnt[pp], pairs[pp].nq) + 31) >> 5;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
-        if (lane == 0) { s_red[wave] = m; s_red[NW + wave] = r; }
-    }
-    __syncthreads();
-    float tmax = 0.f, rmax = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { tmax = fmaxf(tmax, s_red[w]); rmax = fmaxf(rmax, s_red[NW + w]); }
-    // this wave's share of the train set, in steps of 32 rows
-    const int nsteps = (nt + 31) / 32;
-    const int st0 = (nsteps * wave) / NW, st1 = (nsteps * (wave + 1)) / NW;
-    for (int c = c0; c * 32 < cnt; c += per_pair) {
-        if (tid == 0) s_nhit = 0;
-        const int slot = c * 32 + j;
-        const bool qok = slot < cnt;
-        const int qrow = qok ? in_list[pd.out_off + slot] : 0;
-        // threshold on the score: s <= U - |q|^2 + E1, rounded up
-        float thr = -kBig;
-        if (qok) {
-            const double qn = (double)norms[pd.q_row0 + qrow], rq = (double)rho_q[pd.q_row0 + qrow];
-            const double e1 = (rq * sqrt((double)tmax) + (2.0 * sqrt(qn) + rq) * (double)rmax) * (1.0 + 1.0 / 512.0) + (qn + (double)tmax) * (1.0 / 32768.0);
-            const double u = (double)knn_d2[pd.out_off + qrow];
-            const double x = u * (1.0 + 1.0 / 1048576.0) - qn + e1;
-            const double xs = x + fabs(x) * (1.0 / 1048576.0);
-            thr = xs < 3.0e38 ? (float)xs : kBig;                 // (NaN compares false: kBig, everything passes -> overflow -> re-scan)
-            if (!(xs < 3.0e38)) thr = kBig;
-            if ((double)thr < xs) thr = nextafterf(thr, kBig);
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            if (lane == 0) s_part[wave] = part;
         }
-        bf16x8 bq[4];
+        const float *__restrict__ tn = norms + pd.t_row0;
+        const float *__restrict__ tr = rho_t + pd.t_row0;
+        const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(hi_t + (size_t)pd.t_row0 * HS), 0, nt * (HS * 16), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tn), 0, nt * 4, 0x00020000);
+        {   // max |t|^2 and max rho_t over the train set
+            float m = 0.f, r = 0.f;
+            for (int t = tid; t < nt; t += kFinThreads) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            u32x4 v = qok ? hi_q[((size_t)pd.q_row0 + qrow) * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
-            bq[ks] = __builtin_bit_cast(bf16x8, v);
+            for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
+            if (lane == 0) { s_red[wave] = m; s_red[NW + wave] = r; }
         }
         __syncthreads();
-        // Branch-free loads through buffer descriptors (rows past nt read as zeros; their norms become kBig), the next step's
-        // eight loads in flight during this step's MFMAs.  (The first version guarded every load with `row < nt`: hipcc turned
-        // each into a branch and waited for every fragment before its MFMA -- 6.5 us per step, 52 us per chunk.)
-        auto load_step = [&](int st, u32x4 (&a)[4], u32x4 (&nv)[4]) {
-            const int voff = (st * 32 + j) * (HS * 16) + h * 16;
+        float tmax = 0.f, rmax = 0.f; int chunk0 = 0;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, voff + 32 * ks, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) nv[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (st * 32 + 8 * g + 4 * h) * 4, 0, 0);
-        };
-        u32x4 fa[4], fn[4];
-        if (st0 < st1) load_step(st0, fa, fn);
-        for (int st = st0; st < st1; ++st) {
-            u32x4 ca[4], cn[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { ca[k] = fa[k]; cn[k] = fn[k]; }
-            if (st + 1 < st1) load_step(st + 1, fa, fn);
-            floatx16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[4 * g + u] = (st * 32 + 8 * g + 4 * h + u) < nt ? __uint_as_float(cn[g][u]) : kBig;
+        for (int w = 0; w < NW; ++w) { tmax = fmaxf(tmax, s_red[w]); rmax = fmaxf(rmax, s_red[NW + w]); chunk0 += s_part[w]; }
+        const double sqrt_tmax = sqrt((double)tmax);
+        // this wave's share of the train set, in steps of 32 rows: part sl * NW + wave of S * NW
+        const int nsteps = (nt + 31) / 32;
+        const int st0 = (int)(((long long)nsteps * (sl * NW + wave)) / (S * NW)), st1 = (int)(((long long)nsteps * (sl * NW + wave + 1)) / (S * NW));
+        for (int c = 0; c < nchunks; ++c) {
+            if (tid == 0) s_nhit = 0;
+            const int slot = c * 32 + j;
+            const bool qok = slot < cnt;
+            const int qrow = qok ? in_list[pd.out_off + slot] : 0;
+            // threshold on the score: s <= U - |q|^2 + E1, rounded up
+            float thr = -kBig;
+            if (qok) {
+                const double qn = (double)norms[pd.q_row0 + qrow], rq = (double)rho_q[pd.q_row0 + qrow];
+                const double e1 = l2x1_e1(qn, rq, sqrt_tmax, (double)tmax, (double)rmax);
+                const double u = (double)knn_d2[pd.out_off + qrow];
+                const double x = u * (1.0 + 1.0 / 1048576.0) - qn + e1;
+                const double xs = x + fabs(x) * (1.0 / 1048576.0);
+                thr = xs < 3.0e38 ? (float)xs : kBig;                 // (NaN compares false: kBig, everything passes -> overflow -> brute force)
+                if (!(xs < 3.0e38)) thr = kBig;
+                if ((double)thr < xs) thr = nextafterf(thr, kBig);
             }
+            bf16x8 bq[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca[ks]), bq[ks], acc, 0, 0, 0);
-            float m = kBig;
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 v = qok ? hi_q[((size_t)pd.q_row0 + qrow) * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
+                bq[ks] = __builtin_bit_cast(bf16x8, v);
+            }
+            __syncthreads();
+            // Branch-free loads through buffer descriptors (rows past nt read as zeros; their norms become kBig), the next step's
+            // eight loads in flight during this step's MFMAs.  (The first version guarded every load with `row < nt`: hipcc turned
+            // each into a branch and waited for every fragment before its MFMA -- 6.5 us per step, 52 us per chunk.)
+            auto load_step = [&](int st, u32x4 (&a)[4], u32x4 (&nv)[4]) {
+                const int voff = (st * 32 + j) * (HS * 16) + h * 16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fminf(m, acc[r]);       // (fminf drops NaN scores: never neighbours)
-            if (__ballot(m <= thr) != 0ull) {       // (true in most steps: some query of the chunk has a row under its threshold)
-                uint32_t mask = 0;
+                for (int ks = 0; ks < 4; ++ks) a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, voff + 32 * ks, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mask |= (acc[r] <= thr && t < nt) ? (1u << r) : 0u;
+                for (int g = 0; g < 4; ++g) nv[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (st * 32 + 8 * g + 4 * h) * 4, 0, 0);
+            };
+            u32x4 fa[4], fn[4];
+            if (st0 < st1) load_step(st0, fa, fn);
+            for (int st = st0; st < st1; ++st) {
+                u32x4 ca[4], cn[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ca[k] = fa[k]; cn[k] = fn[k]; }
+                if (st + 1 < st1) load_step(st + 1, fa, fn);
+                floatx16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[4 * g + u] = (st * 32 + 8 * g + 4 * h + u) < nt ? __uint_as_float(cn[g][u]) : kBig;
                 }
-                if (mask) {                         // one atomic per lane with hits, then its slots in order
-                    int k = atomicAdd(&s_nhit, __popc(mask));
-                    while (mask) {
-                        const int r = __ffs(mask) - 1;
-                        mask &= mask - 1;
-                        if (k < CAP) { s_hq[k] = j; s_ht[k] = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; }
-                        ++k;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca[ks]), bq[ks], acc, 0, 0, 0);
+                float m = kBig;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fminf(m, acc[r]);       // (fminf drops NaN scores: never neighbours)
+                if (__ballot(m <= thr) != 0ull) {
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int t = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        mask |= (acc[r] <= thr && t < nt) ? (1u << r) : 0u;
+                    }
+                    if (mask) {                         // one atomic per lane with hits, then its slots in order
+                        int k = atomicAdd(&s_nhit, __popc(mask));
+                        while (mask) {
+                            const int r = __ffs(mask) - 1;
+                            mask &= mask - 1;
+                            if (k < CAP) s_h[k] = (j << 21) | (st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                            ++k;
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
-        const int nhit = s_nhit;
-        if (nhit <= CAP) {
-            // exact distances of the hits, the oracle's order
-            for (int k = tid; k < nhit; k += 64 * NW) {
-                const int qr = in_list[pd.out_off + c * 32 + s_hq[k]];
-                const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + qr) * 64);
-                const float4 *tp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.t_row0 + s_ht[k]) * 64);
-                float4 qa[16], tb[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) { qa[c] = qp[c]; tb[c] = tp[c]; }
-                const float d2 = l2sqr64_canonical_regs(qa, tb);
-                s_hd2[k] = d2; s_hd[k] = sqrt_rn_f32(d2);
+            __syncthreads();
+            // this workgroup's hits -> the chunk's region of the pool (a region that does not exist, or more hits than it holds:
+            // the count says "overflow" and the last workgroup brute-forces the chunk)
+            const int nloc = s_nhit, region = chunk0 + c;
+            if (tid == 0)
+                s_kbase = region < n_regions && nloc > 0
+                              ? __hip_atomic_fetch_add(&region_cnt[region], nloc > CAP ? CAP + 1 : nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            __syncthreads();
+            if (region < n_regions && nloc <= CAP) {
+                const int kb = s_kbase;
+                for (int i = tid; i < nloc; i += kFinThreads)
+                    if (kb + i < CAP) __hip_atomic_store(&pool[(size_t)region * CAP + kb + i], s_h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            if (tid < 32 && qok) {
-                const size_t o = 2 * ((size_t)pd.out_off + qrow);
-                Cand b0 = {knn_dist[o], knn_idx[o], 0.f}, b1 = {knn_dist[o + 1], knn_idx[o + 1], 0.f};
-                if (b0.i < 0) b0.d = FLT_MAX;
-                if (b1.i < 0) b1.d = FLT_MAX;
-                for (int k = 0; k < nhit; ++k)
-                    if (s_hq[k] == tid && s_ht[k] != b0.i && s_ht[k] != b1.i) best2_insert(b0, b1, s_hd[k], s_ht[k], s_hd2[k]);
-                knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
-                knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
-            }
-        } else if (tid < 32 && qok) {
-            // too many rows inside the error bound: the exact re-scan takes the chunk's queries
-            const int sl = atomicAdd(&counters[0], 1);
-            if (sl < flag_cap) { flagged[2 * sl] = p; flagged[2 * sl + 1] = qrow; }
-            pair_list[pd.out_off + atomicAdd(&pair_cnt[p], 1)] = qrow;
         }
-        __syncthreads();
+        // arrive; the last of the pair's S workgroups goes on.  The pool travels through relaxed agent-scope atomics (write-through
+        // stores, L2-bypassing loads: no agent-scope fence -- on this part a release is a write-back of the XCD's whole L2, an acquire
+        // an invalidation of it, and hundreds of workgroups would queue for them); every wave waits for its own stores to be
+        // acknowledged before the barrier lets the arrival out.
+        if (S > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) s_last = __hip_atomic_fetch_add(&done[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+            __syncthreads();
+            if (!s_last) return;
+            if (tid == 0) __hip_atomic_store(&done[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (everybody has arrived: nobody touches it again in this launch)
+        }
+        for (int c = 0; c < nchunks; ++c) {
+            const int region = chunk0 + c;
+            const int nqc = min(32, cnt - c * 32);
+            const int nhit = region < n_regions ? __hip_atomic_load(&region_cnt[region], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : CAP + 1;
+            if (tid < 32) s_qrows[tid] = tid < nqc ? in_list[pd.out_off + c * 32 + tid] : 0;
+            __syncthreads();
+            if (region < n_regions && tid == 0 && nhit != 0) __hip_atomic_store(&region_cnt[region], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left clean for the next call
+            if (nhit <= CAP) {
+                // exact distances of the hits, the oracle's order
+                for (int k = tid; k < nhit; k += kFinThreads) {
+                    const int hk = __hip_atomic_load(&pool[(size_t)region * CAP + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_h[k] = hk;
+                    const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + s_qrows[hk >> 21]) * 64);
+                    const float4 *tp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.t_row0 + (hk & 0x1FFFFF)) * 64);
+                    float4 qa[16], tb[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { qa[e] = qp[e]; tb[e] = tp[e]; }
+                    const float d2 = l2sqr64_canonical_regs(qa, tb);
+                    s_hd2[k] = d2; s_hd[k] = sqrt_rn_f32(d2);
+                }
+                __syncthreads();
+                if (tid < nqc) {
+                    const size_t o = 2 * ((size_t)pd.out_off + s_qrows[tid]);
+                    Cand b0 = {knn_dist[o], knn_idx[o], 0.f}, b1 = {knn_dist[o + 1], knn_idx[o + 1], 0.f};
+                    if (b0.i < 0) b0.d = FLT_MAX;
+                    if (b1.i < 0) b1.d = FLT_MAX;
+                    for (int k = 0; k < nhit; ++k) {
+                        const int hk = s_h[k], ht = hk & 0x1FFFFF;
+                        if ((hk >> 21) == tid && ht != b0.i && ht != b1.i) best2_insert(b0, b1, s_hd[k], ht, s_hd2[k]);
+                    }
+                    knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
+                    knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
+                }
+                __syncthreads();
+            } else {
+                // too many rows inside the error bound (or no room in the pool): exact brute force of the chunk's queries
+                if (tid < nqc) {
+                    const int sl2 = atomicAdd(&counters[0], 1);
+                    if (sl2 < flag_cap) { flagged[2 * sl2] = p; flagged[2 * sl2 + 1] = s_qrows[tid]; }
+                }
+                if (!skip_bruteforce) finish_bruteforce_chunk(desc, pd, s_qrows, nqc, s_q, s_keys, knn_idx, knn_dist);
+                __syncthreads();
+            }
+        }
+    } else if (sl != 0) {
+        return;
     }
+    if (do_ratio) ratio_compact_pair<kFinThreads, 4096 / kFinThreads>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + p, s_wave, &s_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1932,62 +2118,18 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lowe ratio test (feature_matching.cpp:88 / :133: float < double * float, i.e. in double) and an
-// order-preserving compaction: one workgroup per pair, survivors written query-ascending.
-constexpr int kRatioThreads = 1024, kRatioPer = 4;     // 4096 queries per sweep of the workgroup: one round of loads for a 4096-row set
+// The ratio test + compaction as a launch of its own (ratio_compact_pair above): one workgroup per pair.  The 64-float L2 path does
+// it inside l2_finish_kernel; this serves Hamming and the other L2 passes.
+constexpr int kRatioThreads = 1024;     // 4096 queries per sweep of the workgroup: one round of loads for a 4096-row set
 __global__ __launch_bounds__(kRatioThreads) void ratio_compact_kernel(const PairDesc *__restrict__ pairs, const int32_t *__restrict__ knn_idx,
                                                                       const float *__restrict__ knn_dist, double ratio,
                                                                       int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
                                                                       float *__restrict__ distance, int32_t *__restrict__ n_out)
 {
-    // A thread takes kRatioPer CONSECUTIVE queries (their 2-NN records are 32 + 32 contiguous bytes), so the survivors' order is
-    // thread order, then query order inside the thread: an exclusive scan of the threads' counts places them.
-    // (Round 1: 256 threads, one query each, 16 sweeps of three barriers for a 4096-row set: 14 us per launch.)
     __shared__ int s_wave[kRatioThreads / 64];
     __shared__ int s_base;
     const PairDesc pd = pairs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int q0 = 0; q0 < pd.nq; q0 += kRatioThreads * kRatioPer) {
-        const int qa = q0 + tid * kRatioPer;
-        int ti[kRatioPer]; float d0[kRatioPer]; bool pass[kRatioPer];
-        int cnt = 0;
-#pragma unroll
-        for (int u = 0; u < kRatioPer; ++u) {
-            const int q = qa + u;
-            pass[u] = false; ti[u] = -1; d0[u] = 0.f;
-            if (q < pd.nq) {
-                const size_t o = 2 * ((size_t)pd.out_off + q);
-                const int i0 = knn_idx[o], i1 = knn_idx[o + 1];
-                d0[u] = knn_dist[o];
-                const float d1 = knn_dist[o + 1];
-                ti[u] = i0;
-                pass[u] = (i0 >= 0) && (i1 >= 0) && ((double)d0[u] < ratio * (double)d1);
-            }
-            cnt += pass[u] ? 1 : 0;
-        }
-        // exclusive scan of cnt over the workgroup: inside the wave by shuffles, across waves through LDS
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        size_t o = (size_t)pd.out_off + off + (incl - cnt);
-#pragma unroll
-        for (int u = 0; u < kRatioPer; ++u) {
-            if (pass[u]) { query_idx[o] = qa + u; train_idx[o] = ti[u]; distance[o] = d0[u]; ++o; }
-        }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < kRatioThreads / 64; ++w) t += s_wave[w]; s_base += t; }
-        __syncthreads();
-    }
-    if (tid == 0) n_out[blockIdx.x] = s_base;
+    ratio_compact_pair<kRatioThreads, 4>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + blockIdx.x, s_wave, &s_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2050,7 +2192,7 @@ int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows
 
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                       int32_t *pair_cnt, int32_t *pair_list, const int32_t *in_cnt, const int32_t *in_list)
+                       int32_t *pair_cnt, int32_t *pair_list)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr int TT = 128;   // train rows per LDS tile: one barrier per 96 MFMAs per wave
@@ -2058,12 +2200,8 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     const u32x4 *sp = reinterpret_cast<const u32x4 *>(split);
     const u32x4 *sq = sp + (size_t)std::max(total_rows, 1LL) * 16;
-    if (in_cnt)     // (the grid is the full one: the list's length is only known on the device; a workgroup past its end leaves at once)
-        hipLaunchKernelGGL(l2_knn_bf16_kernel<true>, dim3(n_blocks), dim3(256), lds, st, desc, sp, sq, norms, pairs,
-                           n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, in_cnt, in_list);
-    else
-        hipLaunchKernelGGL(l2_knn_bf16_kernel<false>, dim3(n_blocks), dim3(256), lds, st, desc, sp, sq, norms, pairs,
-                           n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, in_cnt, in_list);
+    hipLaunchKernelGGL(l2_knn_bf16_kernel, dim3(n_blocks), dim3(256), lds, st, desc, sp, sq, norms, pairs,
+                       n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
@@ -2073,7 +2211,8 @@ bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS -
 
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2, double ratio, int32_t *rejected)
+                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2, double ratio, int32_t *rejected,
+                         int32_t *zero_cnt, int zero_n, int32_t *zero_counters)
 {
     if (n_blocks <= 0) return ESFM_OK;
     constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
@@ -2086,26 +2225,38 @@ int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long
     hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(n_blocks), dim3(256), lds, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, knn_d2, ratio2m, rejected);
+                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, knn_d2, ratio2m, rejected,
+                       zero_cnt, zero_n, zero_counters);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
 
-int launch_l2_refine(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+int l2_finish_slices(int n_pairs)
+{
+    static const int forced = [] { const char *e = getenv("ESFM_FIN_SLICES"); return e ? atoi(e) : 0; }();     // (measurement)
+    if (forced > 0) return forced;
+    // (M-SURF-4k, 300 pairs, 144 uncertified queries per step, one box: S = 8: 54 us, 4: 52, 2: 47, 1: 63 -- the launch is the longest
+    // pair's chain of dependent memory round trips, and a slice more is a few workgroup dispatches more)
+    return std::max(1, std::min(8, 1024 / std::max(n_pairs, 1)));
+}
+
+int launch_l2_finish(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                      int n_pairs, const int32_t *in_cnt, const int32_t *in_list, const float *knn_d2, int32_t *knn_idx, float *knn_dist,
-                     int32_t *flagged, int32_t *counters, int flag_cap, int32_t *pair_cnt, int32_t *pair_list)
+                     int32_t *counters, int32_t *flagged, int flag_cap, int32_t *pool, int32_t *region_cnt, int n_regions, int32_t *done,
+                     bool skip_bruteforce, bool do_ratio, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
 {
     if (n_pairs <= 0) return ESFM_OK;
-    // a handful of workgroups per pair (a workgroup without work leaves after one load), about 4096 in all
-    const int per_pair = std::max(1, std::min(8, 4096 / n_pairs));
+    const int S = l2_finish_slices(n_pairs);
     void *h = const_cast<void *>(hi);
-    hipLaunchKernelGGL(l2_refine_kernel, dim3((unsigned)n_pairs * (unsigned)per_pair), dim3(512), 0, st, desc,
+    hipLaunchKernelGGL(l2_finish_kernel, dim3((unsigned)n_pairs * (unsigned)S), dim3(kFinThreads), 0, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, per_pair, in_cnt, in_list, knn_d2, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list);
+                       pairs, n_pairs, S, in_cnt, in_list, knn_d2, knn_idx, knn_dist, counters, flagged, flag_cap, pool, region_cnt, n_regions, done,
+                       skip_bruteforce ? 1 : 0, do_ratio ? 1 : 0, ratio, query_idx, train_idx, distance, n_out);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
+size_t l2_finish_region_bytes() { return (size_t)kFinCap * sizeof(int32_t); }
 
 int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *pairs, int n_pairs, const int32_t *pair_cnt,
                              const int32_t *pair_list, int32_t *knn_idx, float *knn_dist)
@@ -2174,16 +2325,26 @@ int hamming_query_block(int nbytes) { return 256; }
 // the 0/1 byte image of every descriptor followed by one start value (256 - popcount) per row
 size_t hamming_expanded_bytes(int nbytes, long long total_rows) { return nbytes == 32 ? (size_t)(256 + 4) * (size_t)std::max(total_rows, 1LL) : 0; }
 
+int launch_hamming_expand(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch)
+{
+    if (nbytes != 32 || !exp_scratch || total_rows <= 0) return ESFM_OK;
+    const long long n_words = total_rows * 8;
+    int32_t *start = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(exp_scratch) + (size_t)256 * (size_t)std::max(total_rows, 1LL));
+    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(desc), n_words,
+                       reinterpret_cast<uint32_t *>(exp_scratch), start);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
 int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs,
-                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist)
+                       int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, bool expanded)
 {
     if (n_blocks <= 0) return ESFM_OK;
     const uint32_t *d = reinterpret_cast<const uint32_t *>(desc);
     if (nbytes == 32 && exp_scratch) {
-        const long long n_words = total_rows * 8;
         int32_t *start = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(exp_scratch) + (size_t)256 * (size_t)std::max(total_rows, 1LL));
-        hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d, n_words,
-                           reinterpret_cast<uint32_t *>(exp_scratch), start);
+        if (!expanded)
+            if (int rc = launch_hamming_expand(st, nbytes, desc, total_rows, exp_scratch)) return rc;
         hipLaunchKernelGGL(hamming_knn_mfma_kernel, dim3(n_blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char *>(exp_scratch),
                            start, d, pairs, n_pairs, knn_idx, knn_dist);
     } else if (nbytes == 32)

@@ -28,23 +28,28 @@ size_t l2_split_bytes(int dim, long long total_rows);
 // hi != NULL: also the one-product pass's images and residual norms (l2_hi_bytes(total_rows) of scratch, layout l2_hi_*() below)
 int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows, void *split, float *norms, int32_t *counters,
                          int32_t *pair_cnt, int n_pairs, void *hi, int32_t *pair_cnt2);
-// three-product pass.  in_cnt / in_list != NULL: list mode -- the queries of pair p are in_list[out_off[p] ...][0, in_cnt[p]).
+// three-product pass (round 2's kernel: the fallback for train sets beyond the one-product pass's position code, ESFM_L2_PASS=bf16x3)
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                       int32_t *pair_cnt, int32_t *pair_list, const int32_t *in_cnt, const int32_t *in_list);
-// one-product pass (64-float rows): certifies most queries, bins the rest per pair (pair_cnt / pair_list) for the three-product
-// pass in list mode; counters[1] counts them.  flagged != NULL (audit): its failures also go to the global list, counters[0].
+                       int32_t *pair_cnt, int32_t *pair_list);
+// one-product pass (64-float rows): certifies most queries, bins the rest per pair (pair_cnt / pair_list) for l2_finish_kernel's
+// threshold filter; counters[1] counts them.  flagged != NULL (audit): its failures also go to the global list, counters[0].
 size_t l2_hi_bytes(long long total_rows);
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
                          int32_t *pair_cnt, int32_t *pair_list, float *knn_d2 /* one float per query: exact second-best d^2 of an uncertified query */,
                          double ratio /* the ratio screen (queries that provably fail d0 < ratio d1 get train index -2 and no re-rank); +inf: off */,
-                         int32_t *rejected /* audit: the screen's rejections on this list (counters[0]), or NULL */);
-// threshold-filter second pass over the one-product pass's uncertified queries (in_cnt / in_list): exact results written in place;
-// chunks whose hit list overflows are binned for the exact re-scan (pair_cnt / pair_list, flagged, counters[0])
-int launch_l2_refine(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                         int32_t *rejected /* audit: the screen's rejections on this list (counters[0]), or NULL */,
+                         int32_t *zero_cnt, int zero_n, int32_t *zero_counters /* the other phase's per-pair and global counters, zeroed for the next call */);
+// everything behind the one-product pass in one launch (l2_finish_kernel): the threshold-filter second pass over its uncertified
+// queries (in_cnt / in_list; hits through `pool`, one region of l2_finish_region_bytes() per chunk of 32 queries, region_cnt /
+// done zero on entry and on exit), the exact brute force of overflowed chunks (counted in counters[0], listed in `flagged`;
+// skip_bruteforce: audit), and -- do_ratio -- the ratio test + ordered compaction of every pair
+int launch_l2_finish(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                      int n_pairs, const int32_t *in_cnt, const int32_t *in_list, const float *knn_d2, int32_t *knn_idx, float *knn_dist,
-                     int32_t *flagged, int32_t *counters, int flag_cap, int32_t *pair_cnt, int32_t *pair_list);
+                     int32_t *counters, int32_t *flagged, int flag_cap, int32_t *pool, int32_t *region_cnt, int n_regions, int32_t *done,
+                     bool skip_bruteforce, bool do_ratio, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
+size_t l2_finish_region_bytes();
 int l2_x1_query_block();
 bool l2_x1_supported(int max_nt);          // train sets the front pass's position code covers
 bool l2_one_product_pass();   // ESFM_L2_PASS=bf16x3 in the environment switches the one-product front pass off (measurement)
@@ -59,9 +64,11 @@ int hamming_query_block(int nbytes);
 // 256-bit descriptors take the i8-MFMA path, which needs hamming_expanded_bytes(total_rows) of scratch (exp_scratch);
 // other widths run the XOR/popcount kernel and ignore it.
 size_t hamming_expanded_bytes(int nbytes, long long total_rows);
+int launch_hamming_expand(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch);
+// expanded: exp_scratch already holds this buffer's expansion (esfm_match_prepare_dev)
 int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch,
                        const PairDesc *pairs, int n_pairs, int n_blocks,
-                       int32_t *knn_idx, float *knn_dist);
+                       int32_t *knn_idx, float *knn_dist, bool expanded);
 int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
                          double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
 

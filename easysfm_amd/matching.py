@@ -231,6 +231,13 @@ class PairMatcher:
         self.knn_idx = None
         self.knn_dist = None
         torch.cuda.synchronize(dev)   # the bank upload ran on torch's stream; kernels run on ctx's
+        self.prepare()
+
+    def prepare(self) -> None:
+        """Part of the upload: the per-row operands the matcher derives from the resident descriptors (esfm_match_prepare_dev) --
+        computed once here instead of at the head of every match() / knn2() call."""
+        b = self.bank
+        check(lib().esfm_match_prepare_dev(self.ctx.handle, b.metric, C.c_void_p(b.data.data_ptr()), int(b.row_offset[-1]), b.width))
 
     def match(self, ratio: float) -> PairMatches:
         """Enqueue the whole pair list; does not synchronise."""

@@ -151,6 +151,18 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
                          int32_t *query_idx_dev, int32_t *train_idx_dev, float *distance_dev,
                          int32_t *n_out_dev /*n_pairs*/, int64_t *out_offset /*host, n_pairs+1*/);
 
+/*
+ * Optional, once per resident descriptor buffer: derive and keep what the matcher computes from the rows before it can start --
+ * for 64-float L2 descriptors the bf16 operand images, |row|^2 and the rounding residual norms of every row (l2_split_bf16_kernel),
+ * for 32-byte Hamming descriptors the 0/1 byte image -- so that the esfm_match_pairs_dev / esfm_knn2_pairs_dev calls that follow
+ * on the SAME (desc_dev, total rows, width) skip that launch.  The reference has no counterpart: it re-reads cv::Mat rows in every
+ * knnMatch call (feature_matching.cpp:80,125); here the frames' descriptors are uploaded once for the whole pair loop
+ * (sfm.cpp:140-161) and this is part of the upload.  The caller promises not to modify the rows while they are prepared;
+ * esfm_match_release_prepared, another prepare, or a match call on a different buffer ends it.  Other widths: a no-op.
+ */
+int esfm_match_prepare_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int64_t total_rows, int width);
+int esfm_match_release_prepared(esfm_ctx *ctx);
+
 /* Same pass, but returns the raw 2-NN table instead of the filtered list:
  * knn_idx_dev / knn_dist_dev hold 2 entries per query row, pair p at
  * [2*out_offset[p], 2*(out_offset[p]+nq_p)). */

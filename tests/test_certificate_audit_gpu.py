@@ -121,7 +121,7 @@ def test_audit_fountain_surf_descriptors(gpu_ctx):
 
 
 def _adversarial(case):
-    rng = np.random.default_rng({"cluster": 1, "dynamic_range": 2, "tiny": 3, "huge_norms": 4, "equal_rows": 5, "sparse": 6,
+    rng = np.random.default_rng({"cluster": 1, "dynamic_range": 2, "tiny": 3, "huge_norms": 4, "equal_rows": 5, "sparse": 6, "denormal": 8, "denormal_mixed": 9,
                                  "segment_edges": 7}[case])
     nq, nt = 300, 1500
     q = rng.standard_normal((nq, 64)).astype(np.float32)
@@ -135,6 +135,11 @@ def _adversarial(case):
         t = (t * np.exp(rng.uniform(-14, 14, t.shape))).astype(np.float32)
     elif case == "tiny":
         q = (q * 1e-18).astype(np.float32); t = (t * 1e-18).astype(np.float32)
+    elif case == "denormal":
+        q = (q * 1e-20).astype(np.float32); t = (t * 1e-20).astype(np.float32)
+    elif case == "denormal_mixed":
+        q = (q * np.float32(10.0) ** rng.integers(-23, -16, (nq, 1))).astype(np.float32)
+        t = (t * np.float32(10.0) ** rng.integers(-23, -16, (nt, 1))).astype(np.float32)
     elif case == "huge_norms":
         q = (q + 300.0).astype(np.float32); t = (t + 300.0).astype(np.float32)
     elif case == "equal_rows":
@@ -150,7 +155,7 @@ def _adversarial(case):
     return q, t
 
 
-@pytest.mark.parametrize("case", ["cluster", "dynamic_range", "tiny", "huge_norms", "equal_rows", "sparse", "segment_edges"])
+@pytest.mark.parametrize("case", ["cluster", "dynamic_range", "tiny", "denormal", "denormal_mixed", "huge_norms", "equal_rows", "sparse", "segment_edges"])
 def test_audit_adversarial_sets(gpu_ctx, oracle_lib, case):
     """The inputs of test_l2_split_bf16_pass_adversarial (same seeds): audited, and the brute force itself against the oracle."""
     q, t = _adversarial(case)

@@ -78,12 +78,12 @@ def test_l2_unnormalised_and_dim128(gpu_ctx, oracle_lib):
     _check_knn_l2(gpu_ctx, oracle_lib, q, t)     # odd width: scalar tail of the canonical sum
 
 
-@pytest.mark.parametrize("case", ["cluster", "dynamic_range", "tiny", "huge_norms", "equal_rows", "sparse", "segment_edges"])
+@pytest.mark.parametrize("case", ["cluster", "dynamic_range", "tiny", "denormal", "denormal_mixed", "huge_norms", "equal_rows", "sparse", "segment_edges"])
 def test_l2_split_bf16_pass_adversarial(gpu_ctx, oracle_lib, case):
     """64-float descriptors go through the split-bf16 distance pass, whose scores carry ~2^-16 relative error: inputs built to
     sit inside that error (near-equal distances, cancellation, extreme magnitudes) must still come out bit-identical to the
     oracle, through the certificate's rescan if need be."""
-    rng = np.random.default_rng({"cluster": 1, "dynamic_range": 2, "tiny": 3, "huge_norms": 4, "equal_rows": 5, "sparse": 6,
+    rng = np.random.default_rng({"cluster": 1, "dynamic_range": 2, "tiny": 3, "huge_norms": 4, "equal_rows": 5, "sparse": 6, "denormal": 8, "denormal_mixed": 9,
                                  "segment_edges": 7}[case])
     nq, nt = 300, 1500
     q = rng.standard_normal((nq, 64)).astype(np.float32)
@@ -97,6 +97,11 @@ def test_l2_split_bf16_pass_adversarial(gpu_ctx, oracle_lib, case):
         t = (t * np.exp(rng.uniform(-14, 14, t.shape))).astype(np.float32)
     elif case == "tiny":                    # magnitudes near the bottom of the normal range
         q = (q * 1e-18).astype(np.float32); t = (t * 1e-18).astype(np.float32)
+    elif case == "denormal":                # |row|^2 and the bf16 residuals' squares are denormal or zero in f32
+        q = (q * 1e-20).astype(np.float32); t = (t * 1e-20).astype(np.float32)
+    elif case == "denormal_mixed":          # rows from 1e-23 (squares flush to zero) to 1e-17 (normal) in one train set
+        q = (q * np.float32(10.0) ** rng.integers(-23, -16, (nq, 1))).astype(np.float32)
+        t = (t * np.float32(10.0) ** rng.integers(-23, -16, (nt, 1))).astype(np.float32)
     elif case == "huge_norms":              # large common offset: d^2 << |q|^2 + |t|^2 (catastrophic cancellation in the GEMM form)
         q = (q + 300.0).astype(np.float32); t = (t + 300.0).astype(np.float32)
     elif case == "equal_rows":              # many identical trains and queries equal to trains
