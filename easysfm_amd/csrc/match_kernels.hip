@@ -1150,11 +1150,22 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
         lds_dma_wait();
 #pragma unroll
         for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
+        // Between the rounds the ratio test may already be DECIDED (the match entry points only; the reference emits queryIdx, trainIdx
+        // and d0 of a survivor, never d1): with (m0, m1) the exact two best of the rows evaluated so far and lrest a lower bound on
+        // the D of every other row (the groups of the next ranks, everything outside the kept groups; rows of a group skipped as
+        // `cannot` are farther than m1 anyway),
+        //   verdict 1, cannot pass:  D1 <= m1 and D0 >= min(m0, lrest) >= ratio^2 (1 + 2^-20) m1;
+        //   verdict 2, passes:       lrest > m0 (1 + 2^-20), so m0 IS the nearest row, and m0 (1 + 2^-18) < ratio^2 (1 + 2^-20) min(m1, lrest),
+        //                            so sqrtf(m0) < ratio sqrtf(D1) whatever the second nearest turns out to be -- it is not looked for
+        //                            (second index -3: "not determined, the test passes").
+        // Either way the query's remaining groups are not fetched.
+        const bool screen = ratio2m < 1.0e300;
+        int verdict = 0;
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             const float key = rkey[r]; const int row0 = rrow[r];
             const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-            const bool need = row0 >= 0 && qvalid && !cannot;
+            const bool need = row0 >= 0 && qvalid && !cannot && verdict == 0;
             if (__ballot(need) == 0ull) break;
             const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
             // 16 lanes fetch one 256-B row: DMA instruction i serves the lanes 4 i .. 4 i + 3 (their row of sub-round u).  The
@@ -1190,6 +1201,30 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                 const int ta_ = row0 + u;
                 insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
             }
+            if (screen && r + 1 < K) {
+                // the query's exact two best so far, both lane halves merged (copies: the halves' own lists stay as they are)
+                float m0d = b0d, m1d = b1d, m0q = b0q, m1q = b1q; int m0i = b0i, m1i = b1i;
+                {
+                    const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
+                    const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
+                    auto minsert = [&](bool valid, float d, int i, float d2) {
+                        const bool c1 = valid && (d < m1d || (d == m1d && i < m1i));
+                        const bool c0 = valid && (d < m0d || (d == m0d && i < m0i));
+                        m1d = c0 ? m0d : (c1 ? d : m1d); m1i = c0 ? m0i : (c1 ? i : m1i); m1q = c0 ? m0q : (c1 ? d2 : m1q);
+                        m0d = c0 ? d : m0d; m0i = c0 ? i : m0i; m0q = c0 ? d2 : m0q;
+                    };
+                    minsert(pi0 >= 0, pd0, pi0, pq0);
+                    minsert(pi1 >= 0, pd1, pi1, pq1);
+                }
+                const float nxt = __shfl_xor(rkey[r + 1], 32);
+                const float nk = fminf(h == 0 ? rkey[r + 1] : nxt, tau);                 // the smallest key of anything not evaluated yet
+                const double lrest = qn + (double)nk - e1 - fabs((double)nk) * kTrunc;
+                const double r1 = ratio2m * (double)m1q;
+                const bool fail = m1i >= 0 && lrest >= r1 && (double)m0q >= r1;                            // (every compare false on NaN)
+                const double dlo = lrest < (double)m1q ? lrest : (double)m1q;
+                const bool pass = m1i >= 0 && lrest > (double)m0q * (1.0 + 1.0 / 1048576.0) && (double)m0q * (1.0 + 1.0 / 262144.0) < ratio2m * dlo;
+                if (verdict == 0 && qvalid) verdict = fail ? 1 : (pass ? 2 : 0);
+            }
         }
         {
             const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
@@ -1208,13 +1243,13 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             }
             // Not certified, but the ratio test is already decided: the true second-nearest has D1 <= b1q, the true nearest
             // D0 >= min(b0q, lmiss); if that is >= ratio^2 (1 + 2^-20) b1q the query cannot pass whatever the other rows are.
-            const bool lost = !certified && b1i >= 0 && lmiss >= ratio2m * (double)b1q && (double)b0q >= ratio2m * (double)b1q;   // false on NaN
+            const bool lost = verdict == 1 || (!certified && b1i >= 0 && lmiss >= ratio2m * (double)b1q && (double)b0q >= ratio2m * (double)b1q);   // false on NaN
             if (lost) mark_rejected(qrow);
             else {
-                knn_idx[o] = b0i; knn_idx[o + 1] = b1i;
+                knn_idx[o] = b0i; knn_idx[o + 1] = verdict == 2 ? -3 : b1i;
                 knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
             }
-            if (!certified && !lost) {
+            if (!certified && !lost && verdict == 0) {
                 atomicAdd(&counters[1], 1);
                 knn_d2[pd.out_off + qrow] = b1i >= 0 ? b1q : FLT_MAX;     // the refine pass's threshold: the exact second best so far
                 if (flagged) {           // audit of THIS pass's certificate: its failures on the global list
@@ -1232,7 +1267,8 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 // pair's survivors, by the THREADS threads of a workgroup, THREADS * kRatioPer queries per sweep (one round of loads for a 4096-row
 // set in either instantiation).  A thread takes kRatioPer CONSECUTIVE queries (their 2-NN records are
 // 32 + 32 contiguous bytes), so the survivors' order is thread order, then query order inside the thread: an exclusive scan of the
-// threads' counts places them.  A train index < 0 (no neighbour; -2: dropped by the one-product pass's ratio screen) never passes.
+// threads' counts places them.  A train index < 0 (no neighbour; -2: dropped by the one-product pass's ratio screen) never passes; a
+// SECOND index of -3 says that pass has proved d0 < ratio d1 without looking for the second neighbour.
 // (Round 1: 256 threads, one query each, 16 sweeps of three barriers for a 4096-row set: 14 us per launch.)
 template <int THREADS, int kRatioPer>
 __device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int32_t *__restrict__ knn_idx, const float *__restrict__ knn_dist,
@@ -1257,7 +1293,7 @@ __device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int
                 d0[u] = knn_dist[o];
                 const float d1 = knn_dist[o + 1];
                 ti[u] = i0;
-                pass[u] = (i0 >= 0) && (i1 >= 0) && ((double)d0[u] < ratio * (double)d1);
+                pass[u] = (i0 >= 0) && (i1 == -3 || (i1 >= 0 && (double)d0[u] < ratio * (double)d1));     // -3: the one-product pass proved the test
             }
             cnt += pass[u] ? 1 : 0;
         }
