@@ -447,6 +447,18 @@ int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass)
     return ESFM_OK;
 }
 
+int esfm_match_debug_counters(esfm_ctx *ctx, int32_t *out16)
+{
+    if (!ctx || !out16) { esfm::set_error("esfm_match_debug_counters: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    if (int rc = esfm::set_device(ctx)) return rc;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (ctx->counters_cur) {
+        ESFM_HIP_TRY(hipMemcpyAsync(out16, ctx->counters_cur, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return ESFM_OK;
+}
+
 int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 4) { esfm::set_error("esfm_ctx_set_l2_audit: bad arguments"); return ESFM_ERR_INVALID_ARG; }

@@ -992,6 +992,9 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                        "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
                      : ESFM_L2X1_SEGMENT_CLOBBERS);
     }
+#ifdef ESFM_X1_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // the block left this thread's keys in LDS: key i of set s at float (K s + i) * 256 + tid
     float keys[NS][K];
 #pragma unroll
@@ -1260,6 +1263,13 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             }
         }
     }
+#ifdef ESFM_X1_TRACE
+    if (lane == 0) {
+        const unsigned long long tr3 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&counters[8], (int)(tr1 - tr0)); atomicAdd(&counters[9], (int)(tr2 - tr1)); atomicAdd(&counters[10], (int)(tr3 - tr2));
+        atomicAdd(&counters[11], 1); atomicAdd(&counters[12], (nsurv + 31) / 32); atomicAdd(&counters[13], nsurv);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -193,6 +193,8 @@ int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass);
  * Diffing the two tables row by row and removing the rows esfm_match_last_flagged() lists gives
  * the number of queries the certificate accepted with a wrong answer; it must be 0. */
 int esfm_ctx_set_l2_audit(esfm_ctx *ctx, int mode);
+/* The 16 device-side counters of the last L2 batched call ([0] re-scanned, [1] second pass, the rest: instrumented builds only). */
+int esfm_match_debug_counters(esfm_ctx *ctx, int32_t *out16);
 /* The (pair, query row) entries the last L2 batched call flagged as uncertified: writes
  * min(*n, cap) entries of 2 x int32 to `out` (host) and the count to *n.  Synchronises. */
 int esfm_match_last_flagged(esfm_ctx *ctx, int32_t *out, int64_t cap, int64_t *n);

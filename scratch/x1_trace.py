@@ -1,0 +1,14 @@
+# per-wave stage times of l2_knn_bf16x1_kernel's tail (build with -DESFM_X1_TRACE, ESFM_LIB=...): s_memrealtime ticks of 10 ns
+import sys; sys.path.insert(0, '.')
+import ctypes as C, numpy as np, easysfm_amd as E
+from easysfm_amd import synth, _lib
+pairs = synth.all_pairs(25)
+sets = synth.surf_like_sets(25, 4096, pool=16384, seed_base=1000)
+pm = E.PairMatcher(E.DescriptorBank(sets, E.ESFM_L2_F32), pairs)
+for _ in range(3): pm.match(0.5)
+pm.ctx.synchronize()
+out = (C.c_int32 * 16)()
+_lib.check(_lib.lib().esfm_match_debug_counters(pm.ctx.handle, out))
+c = list(out); w = max(c[11], 1)
+print('waves', c[11], 'virtual sets/wave', c[12] / w, 'survivors/wave', c[13] / w)
+print('us per wave: keys+barrier %.2f  phase A %.2f  phase B %.2f' % (c[8] / w / 100, c[9] / w / 100, c[10] / w / 100))
