@@ -7,8 +7,9 @@
 A "step" is one pass of the all-pairs SURF-64f matcher (2-NN + Lowe ratio, bit-exact with the
 oracle) over this rank's share of the image-pair list, descriptors already resident in HBM.
 N = 1 runs BASELINE.json configs[1] at its metric size: 25 images x 4096 features x 64 floats,
-300 pairs per step (workload "M-SURF-4k").  N > 1 keeps per-GPU work fixed:
-F images with F(F-1)/2 >= 300 N pairs, pair list partitioned over ranks, no data-path collective.
+300 pairs per step (workload "M-SURF-4k").  N > 1 keeps per-GPU work fixed
+("scaling": "weak"): F images with F(F-1)/2 >= 300 N pairs, pair list partitioned over ranks, no data-path
+collective; the metric's own 300-pair list split over the ranks is reported beside it ("strong_m_surf_4k").
 The second half of the metric, bundle-adjustment LM iterations/s on 25 cameras x 30k points
 (240k observations, workload "BA-25"), is measured in the same process and reported under "ba".
 
@@ -50,41 +51,64 @@ N_FEATS, DIM = 4096, 64
 
 
 def frames_for(world: int) -> int:
+    """Images of the headline leg: 25 at N = 1 (M-SURF-4k, the metric's configuration); at N > 1 the smallest F with
+    F (F - 1) / 2 >= 300 N, so that every GPU keeps 300 pairs of 4096 x 4096 per step (WEAK scaling: the metric's 0.7 ms step is
+    too short to be split eight ways).  The line says so in "scaling" and "scaling_note", and carries the same 300-pair list
+    partitioned over the ranks as "strong_m_surf_4k"; BASELINE's own multi-GPU configurations are the strong-scaling legs
+    "config4" / "config5"."""
     f = 25
     while f * (f - 1) // 2 < 300 * world:
         f += 1
     return f
 
 
-def cpu_baseline_match(sets, pairs, gpu_results=None, budget_s: float = 12.0):
-    """Oracle (exact brute-force 2-NN + ratio, OpenMP over query rows like OpenCV's BFMatcher) on the
-    host cores, on whole 4096 x 4096 pairs of the same workload: the step's whole pair list once (every
-    pair's match list compared bit for bit with the GPU's when `gpu_results` is given), then more of
-    the same until ~budget_s have elapsed.  Returns (cpu_baseline object, verification object)."""
+def cpu_baseline_match(sets, pairs, gpu_results=None, budget_s: float = 10.0):
+    """Oracle (exact brute-force 2-NN + ratio; since round 4 with an 8-lane SIMD body in the canonical summation order and ONE
+    parallel region over all (pair, query) items, oracle/match_ref.c esfm_ref_match_pairs_l2 -- the scalar, region-per-pair form of
+    round 3 spent 95 % of its time in fork / join on a 256-thread host) on the host cores, on whole 4096 x 4096 pairs of the same
+    workload, as BASELINE.md section 3 asks: ALL cores (the step's whole pair list, repeated until ~budget_s; every pair's match list
+    compared bit for bit with the GPU's when `gpu_results` is given) and ONE thread (a bounded sample of the same pairs).
+    Returns (cpu_baseline object, verification object)."""
     import oracle
     path = oracle.build(arch="native", out="libesfm_oracle_native.so")
     oracle.load(path)
     cores = os.cpu_count() or 1
     oracle.set_num_threads(cores)
-    n, t0, t_cmp = 0, time.perf_counter(), 0.0
-    checked, bad = 0, []
+    pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+    oracle.match_pairs_l2(sets, pairs[:2], 0.5)                       # thread pool warm-up
+    n, el, first = 0, 0.0, None
     while True:
-        k = n % len(pairs)
-        i, j = pairs[k]
-        rq, rt, rd = oracle.match_l2(sets[i], sets[j], 0.5)
-        n += 1
-        if gpu_results is not None and n <= len(pairs):
-            tc = time.perf_counter()
-            q, t, d = gpu_results[k]
+        t0 = time.perf_counter()
+        res = oracle.match_pairs_l2(sets, pairs, 0.5)
+        el += time.perf_counter() - t0
+        n += len(pairs)
+        if first is None:
+            first = res
+        if el >= budget_s or n >= 64 * len(pairs):
+            break
+    checked, bad = 0, []
+    if gpu_results is not None:
+        for k, ((q, t, d), (rq, rt, rd)) in enumerate(zip(gpu_results, first)):
             if not (np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))):
                 bad.append(k)
             checked += 1
-            t_cmp += time.perf_counter() - tc
-        el = time.perf_counter() - t0 - t_cmp
-        if (el >= budget_s and n >= (len(pairs) if gpu_results is not None else 1)) or n >= 2400 or el >= 4 * budget_s:
+    # one thread: a bounded sample of the same pair list
+    oracle.set_num_threads(1)
+    k1 = max(1, min(len(pairs), 24))
+    t0 = time.perf_counter()
+    n1 = 0
+    while True:
+        oracle.match_pairs_l2(sets, pairs[:k1], 0.5)
+        n1 += k1
+        if time.perf_counter() - t0 >= 0.5 * budget_s:
             break
-    base = {"value": n / el, "unit": "image-pairs/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"{n} pairs of 4096x4096x64 (M-SURF-4k) in {el:.1f}s, OpenMP over query rows"}
+    el1 = time.perf_counter() - t0
+    oracle.set_num_threads(cores)
+    base = {"value": n / el, "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} pairs of 4096x4096x64 (M-SURF-4k: the step's pair list, {n // len(pairs)} times) in {el:.1f}s; SIMD brute force "
+                      "(8 train rows per 256-bit register, canonical summation order), one OpenMP region over all (pair, query) items",
+            "one_thread": {"value": n1 / el1, "unit": "image-pairs/s", "cores": 1, "kind": "port",
+                           "sample": f"{n1} pairs of the same list in {el1:.1f}s, one thread"}}
     ver = None
     if gpu_results is not None:
         ver = {"ok": not bad and checked > 0, "pairs_checked": checked, "pairs_per_step": len(pairs), "queries_checked": checked * N_FEATS,
@@ -94,15 +118,121 @@ def cpu_baseline_match(sets, pairs, gpu_results=None, budget_s: float = 12.0):
 
 
 def cpu_baseline_ba(scene, iters: int = 25):
+    """The oracle's LM loop on BA-25 at the reference's 4 threads (ceres_options_->num_threads = 4, ba.cpp:203) and at all cores
+    (BASELINE.md section 3 asks for both)."""
     import oracle
-    threads = min(4, os.cpu_count() or 1)   # ceres_options_->num_threads = 4 (reference ba.cpp:203)
-    oracle.set_num_threads(threads)
-    opt = oracle.ba_default_options()
-    opt.max_num_iterations = iters; opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
-    _, _, s = oracle.ba_solve(scene.cam_idx, scene.pt_idx, scene.uv, scene.K4, scene.cams0, scene.pts0, opt)
-    oracle.set_num_threads(os.cpu_count() or 1)
-    return {"value": s.num_iterations / s.solve_seconds, "unit": "LM iters/s", "cores": threads, "kind": "port",
-            "sample": f"{s.num_iterations} LM iterations of BA-25 (25 cams, 30k pts, 240k obs) in {s.solve_seconds:.1f}s"}
+
+    def run(threads):
+        oracle.set_num_threads(threads)
+        opt = oracle.ba_default_options()
+        opt.max_num_iterations = iters; opt.function_tolerance = 0.0; opt.parameter_tolerance = 0.0; opt.gradient_tolerance = 0.0
+        _, _, s_ = oracle.ba_solve(scene.cam_idx, scene.pt_idx, scene.uv, scene.K4, scene.cams0, scene.pts0, opt)
+        return {"value": s_.num_iterations / s_.solve_seconds, "unit": "LM iters/s", "cores": threads, "kind": "port",
+                "sample": f"{s_.num_iterations} LM iterations of BA-25 (25 cams, 30k pts, 240k obs) in {s_.solve_seconds:.1f}s"}
+    cores = os.cpu_count() or 1
+    out = run(min(4, cores))
+    out["all_cores"] = run(cores)
+    oracle.set_num_threads(cores)
+    return out
+
+
+def _write_png_rgb(path: str, rgb: np.ndarray) -> None:
+    """8-bit RGB PNG, filter 0, one IDAT (zlib): enough for the drivers' own reader, no imaging library needed on the box."""
+    import struct
+    import zlib
+    h, w, _ = rgb.shape
+    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))
+
+
+def e2e_leg(tag: str, feature: str, param: int, with_cpu: bool):
+    """BASELINE configs 1 / 3 end to end: ./bin/sfm_native (C++ host over the C ABI, batched pair loop) on the reference's 11 fountain
+    images at 768 x 512 through this repo's script/run_fountain_small.sh -- wall seconds and the driver's own stage split (the
+    reference's only instrumentation is its per-stage `... cost = ... seconds` lines, feature_matching.cpp:141, ba.cpp:285) -- and,
+    as the stated CPU baseline, the oracle's detect / match / verify stages on the same images (the stages whose inputs are a
+    function of the images alone)."""
+    import shutil
+    import subprocess
+    import tempfile
+    gold = os.path.join(ROOT, "tests", "golden", "fountain11_gray.npz")
+    exe = os.path.join(ROOT, "bin", "sfm_native")
+    if not (os.path.exists(gold) and os.path.exists(exe)):
+        return {"error": "fixture or bin/sfm_native missing"}
+    imgs = np.load(gold)["images"]
+    tmp = tempfile.mkdtemp(prefix="esfm_e2e_")
+    try:
+        data = os.path.join(tmp, "test_data")
+        os.makedirs(os.path.join(data, "images_25")); os.makedirs(os.path.join(data, "k_25"))
+        names = []
+        for i, im in enumerate(imgs):
+            names.append(f"{i:04d}.png")
+            _write_png_rgb(os.path.join(data, "images_25", names[-1]), np.ascontiguousarray(np.stack([im] * 3, axis=2)))
+        open(os.path.join(data, "image_list.txt"), "w").write("\n".join(names) + "\n")
+        open(os.path.join(data, "k_25", "K.txt"), "w").write("689.87 0 380.17\r\n0 691.04 251.70\r\n0 0 1")
+        out_ply = os.path.join(tmp, "out", "cloud.ply")
+        env = dict(os.environ, SFM_DATA=data, SFM_OUT=out_ply, SFM_BIN="bin/sfm_native", FEATURE=feature, FEATURE_PARAM=str(param))
+        env.pop("ESFM_PAIR_BY_PAIR", None)
+        runs = []
+        for _ in range(2):                    # the first run pays the process' one-off costs (library load, code objects, allocations)
+            t0 = time.perf_counter()
+            r = subprocess.run(["bash", os.path.join("script", "run_fountain_small.sh")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            line = [l for l in r.stdout.splitlines() if l.startswith("stage seconds:")]
+            if r.returncode != 1 or not line:
+                return {"error": f"driver exit status {r.returncode}", "tail": r.stdout[-400:]}
+            tok = line[-1].split()[2:]
+            st, k = {}, 0
+            while k + 1 < len(tok):
+                try:
+                    st[tok[k]] = float(tok[k + 1])
+                except ValueError:
+                    pass
+                k += 2
+            runs.append((wall, st, r.stdout))
+        wall, st, log = min(runs, key=lambda x: x[0])
+        n_pts = sum(1 for l in open(out_ply) if l[:1].isdigit() or l[:1] == "-") if os.path.exists(out_ply) else 0
+        leg = {"metric": "seconds, 11 fountain images (768 x 512) -> sparse cloud, " + ("SURF minHessian 300" if feature == "S" else f"ORB {param} features"),
+               "value": wall, "unit": "s", "higher_is_better": False, "driver": "bin/sfm_native via script/run_fountain_small.sh (13 positional arguments)",
+               "first_run_wall_s": runs[0][0], "stage_seconds": st, "frames_registered": log.count("Progress: ["), "points_in_ply": n_pts,
+               "verified_pairs": log.count("verified matches"), "includes": "process start, library load, PNG decode, every host<->device copy, .ply write"}
+        if with_cpu:
+            import oracle
+            oracle.set_num_threads(os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            feats = [oracle.surf(im, float(param)) if feature == "S" else oracle.orb(im, int(param)) for im in imgs]
+            t_det = time.perf_counter() - t0
+            pairs = np.array([(i, j) for i in range(len(imgs)) for j in range(i)], np.int32)
+            t0 = time.perf_counter()
+            if feature == "S":
+                res = oracle.match_pairs_l2([f[1] for f in feats], pairs, 0.5)
+            else:
+                res = [oracle.match_hamming(feats[i][1], feats[j][1], 0.8) for i, j in pairs]
+            t_match = time.perf_counter() - t0
+            K4 = np.array([689.87, 380.17, 691.04, 251.70], np.float32)
+            t0 = time.perf_counter()
+            n_ver = 0
+            for (i, j), (q, t, d) in zip(pairs, res):
+                if len(q) > 20:
+                    a = np.ascontiguousarray(feats[i][0][q, :2], np.float32); b = np.ascontiguousarray(feats[j][0][t, :2], np.float32)
+                    ok_, Er_, mr_, _it, _c = oracle.find_essential_ransac(a, b, K4, 0.99, 1.0)
+                    if ok_:
+                        oracle.recover_pose(Er_, a, b, K4, mr_)
+                    n_ver += 1
+            t_ver = time.perf_counter() - t0
+            leg["cpu_baseline"] = {"kind": "port", "cores": oracle.num_threads(), "unit": "s",
+                                   "stage_seconds": {"detect": t_det, "match": t_match, "verify": t_ver},
+                                   "value": t_det + t_match + t_ver,
+                                   "sample": f"oracle detect (sequential per image) + match (all 55 pairs, all cores) + 5-point RANSAC / recoverPose of the {n_ver} pairs "
+                                             "with > 20 matches (sequential); BA, PnP and SOR are not in it (their inputs depend on the pipeline's state)",
+                                   "gpu_same_stages_s": st.get("detect", 0.0) + st.get("match", 0.0) + st.get("verify", 0.0)}
+        return leg
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def dry_run(args) -> int:
@@ -158,6 +288,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-config45", action="store_true", help="skip the config-4 / config-5 strong-scaling legs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the config-1 / config-3 end-to-end legs (bin/sfm_native on the fountain images)")
     ap.add_argument("--config4-steps", type=int, default=2)
     ap.add_argument("--ba512-iters", type=int, default=20)
     ap.add_argument("--dry-run", action="store_true",
@@ -232,7 +363,6 @@ def main() -> int:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     k_ms, k_n = ctx.kernel_time(_lib.K_L2_KNN)
-    r_ms, r_n = ctx.kernel_time(_lib.K_L2_RESCAN)
     s_ms, s_n = ctx.kernel_time(_lib.K_L2_SECOND)
     ctx.set_kernel_timing(False)
     n_q, n_rescan = pm.stats()
@@ -282,21 +412,26 @@ def main() -> int:
     # The distance pass runs on the bf16 matrix cores, so the kernel is priced against the dense bf16 MFMA peak; `achieved` is
     # ALGORITHMIC (2 Nq Nt 64 per pair).  Round 3: ONE bf16 product per f32 product (l2_knn_bf16x1_kernel; the operand
     # rounding is inside the certificate's bound), so the executed MFMA work equals the algorithmic work plus the threshold-filter
-    # pass over the queries the first pass leaves uncertified (l2_refine_kernel: `second_pass_queries_per_step` x Nt x 64 x 2).
+    # pass over the queries the first pass leaves uncertified AND undecided (l2_finish_kernel: `second_pass_queries_per_step` x Nt x 64 x 2;
+    # since round 4's ratio screen that is a handful per step).
     exec_flops = flops_per_launch + 2.0 * float(n_second) * N_FEATS * DIM
     roofline = {"bound": "mfma", "kernel": "l2_knn_bf16x1_kernel", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)" if traffic else None,
                 "avg_launch_ms": avg_kernel_s * 1e3, "launches": k_n,
                 "algorithmic_flops_per_launch": flops_per_launch,
                 "executed_mfma_flops_per_step": exec_flops, "products_per_f32_product": 1,
                 "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                "second_pass_kernel": "l2_refine_kernel", "second_pass_kernel_avg_ms": (s_ms / max(s_n, 1)),
-                "second_pass_queries_per_step": n_second,
-                "rescan_kernel_avg_ms": (r_ms / max(r_n, 1)), "rescanned_queries_per_step": n_rescan, "queries_per_step": n_q}
+                "finish_kernel": "l2_finish_kernel (threshold-filter second pass + brute force of overflowed chunks + ratio test + compaction)",
+                "finish_kernel_avg_ms": (s_ms / max(s_n, 1)), "second_pass_queries_per_step": n_second,
+                "launches_per_step": 2, "step_minus_kernels_ms": elapsed / args.steps * 1e3 - (k_ms / max(k_n, 1)) - (s_ms / max(s_n, 1)),
+                "rescanned_queries_per_step": n_rescan, "queries_per_step": n_q}
 
     out = {
         "metric": METRIC, "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "scaling_note": "per-GPU work fixed at 300 pairs of 4096 x 4096 per step (N = 1: exactly M-SURF-4k); NOT comparable with BASELINE's "
+                        "strong-scaling configurations, which are the legs config4 / config5; the metric's 300-pair list split over the ranks: strong_m_surf_4k",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "M-SURF-4k all-pairs SURF-64f match (2-NN + ratio 0.5), "
                                f"{n_frames} imgs x {N_FEATS} feats x {DIM} f32, {int(total_pairs)} pairs/step, "
@@ -304,6 +439,28 @@ def main() -> int:
                    "pairs_per_step": int(total_pairs), "features_per_image": N_FEATS, "descriptor_dim": DIM, "ratio": ratio},
         "roofline": roofline, "verified_vs_oracle": verified, "verified_scope": verified_scope,
     }
+
+    if world > 1:
+        # the metric's own pair list (25 images, 300 pairs) partitioned over the ranks: strong scaling of a 0.7 ms step
+        try:
+            sets_s = sets[:25]
+            pairs_s = E.shard_pair_list(25, np.full(25, N_FEATS, np.int32), rank, world)
+            pm_s = E.PairMatcher(E.DescriptorBank(sets_s, E.ESFM_L2_F32, device=f"cuda:{local_rank}"), pairs_s)
+            for _ in range(args.warmup):
+                pm_s.match(ratio)
+            pm_s.ctx.synchronize(); torch.cuda.synchronize(dev); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pm_s.match(ratio)
+            pm_s.ctx.synchronize(); torch.cuda.synchronize(dev); dist.barrier()
+            ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            out["strong_m_surf_4k"] = {"value": 300.0 * args.steps / float(ts.item()), "unit": "image-pairs/s", "n_gpus": world, "scaling": "strong",
+                                       "ms_per_step": float(ts.item()) / args.steps * 1e3, "pairs_this_rank": int(len(pairs_s)),
+                                       "config": {"workload": "M-SURF-4k: 25 imgs x 4096 feats, all 300 pairs per step partitioned over the ranks"}}
+            del pm_s
+        except Exception as e:
+            out["strong_m_surf_4k"] = {"error": repr(e)}
 
     # ---------------------------------------------------------------- BA half of the metric
     printed = threading.Event()
@@ -656,6 +813,14 @@ def main() -> int:
                                                    "sample": f"24 of the pairs in {t1:.2f}s (sequential RANSAC restatement, one core)"}
         except Exception as e:
             out["geometry"] = {"error": repr(e)}
+
+    # ---------------------------------------------------------------- BASELINE configs 1 and 3 end to end (rank 0 at N = 1)
+    if rank == 0 and world == 1 and not args.no_ba and not args.no_e2e:
+        for tag, feat, par in (("config1", "S", 300), ("config3", "O", 8000)):
+            try:
+                out[tag] = e2e_leg(tag, feat, par, not args.no_cpu_baseline)
+            except Exception as e:
+                out[tag] = {"error": repr(e)}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -54,6 +54,7 @@ struct esfm_ctx {
     bool owns_stream = false;
     int num_cu = 256;
     // matching scratch
+    esfm::DevBuf bank;   // esfm_match_pairs (host-pointer batched form): the uploaded descriptor rows of all sets
     esfm::DevBuf norms, pair_tab, knn_idx, knn_dist, flagged, counters, stage_a, stage_b, stage_c, stage_d, stage_e;
     esfm::DevBuf pair_cnt, pair_list;   // uncertified queries of the L2 pass binned per pair (one counter per pair; the pair's slice of the query numbering)
     esfm::DevBuf pair_cnt2, pair_list2;   // the same for the second (three-product) pass over what the one-product pass left uncertified

@@ -388,6 +388,49 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
                                       query_idx_dev, train_idx_dev, distance_dev, n_out_dev);
 }
 
+// Host-pointer form of the batched pair loop (SURVEY 8b's esfm_match_pairs): upload once, prepare once, one launch sequence for
+// the whole pair list, one read-back.  The uploaded rows stay in the context (ctx->bank) and stay prepared, so a second call on
+// the same host buffer contents would still re-upload (the library cannot know the rows are unchanged) -- callers that match
+// the same sets repeatedly keep them on the device and use esfm_match_pairs_dev.
+int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host, const int32_t *set_row_offset, int n_sets, int width,
+                     const int32_t *pairs, int n_pairs, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance,
+                     int32_t *n_out, int64_t *out_offset)
+{
+    if (int rc = check_common(ctx, metric, width)) return rc;
+    ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
+    PairPlan plan;
+    if (int rc = make_plan(set_row_offset, n_sets, pairs, n_pairs, metric == ESFM_L2_F32 ? esfm::l2_query_block(width) : esfm::hamming_query_block(width),
+                           out_offset, &plan))
+        return rc;
+    if (n_pairs == 0) return ESFM_OK;
+    ESFM_REQUIRE(n_out != nullptr, "n_out is NULL");
+    for (int p = 0; p < n_pairs; ++p) n_out[p] = 0;
+    if (plan.total_queries == 0) return ESFM_OK;
+    ESFM_REQUIRE(desc_host && query_idx && train_idx && distance, "host pointer is NULL");
+    hipStream_t st = ctx->stream;
+    const size_t row_bytes = metric == ESFM_L2_F32 ? sizeof(float) * (size_t)width : (size_t)width;
+    const size_t bytes = row_bytes * (size_t)plan.total_rows;
+    ctx->prep_desc = nullptr;                      // the bank below is rewritten: whatever was prepared from it is stale
+    if (int rc = ctx->bank.reserve(bytes + 16)) return rc;
+    ESFM_HIP_TRY(hipMemcpyAsync(ctx->bank.ptr, desc_host, bytes, hipMemcpyHostToDevice, st));
+    if (int rc = esfm_match_prepare_dev(ctx, metric, ctx->bank.ptr, plan.total_rows, width)) return rc;
+    const size_t nq = (size_t)plan.total_queries;
+    if (int rc = ctx->stage_b.reserve(sizeof(int32_t) * nq)) return rc;
+    if (int rc = ctx->stage_c.reserve(sizeof(int32_t) * nq)) return rc;
+    if (int rc = ctx->stage_d.reserve(sizeof(float) * nq)) return rc;
+    if (int rc = ctx->stage_e.reserve(sizeof(int32_t) * (size_t)n_pairs)) return rc;
+    std::vector<int64_t> off2((size_t)n_pairs + 1);
+    if (int rc = esfm_match_pairs_dev(ctx, metric, ctx->bank.ptr, set_row_offset, n_sets, width, pairs, n_pairs, ratio, ctx->stage_b.as<int32_t>(),
+                                      ctx->stage_c.as<int32_t>(), ctx->stage_d.as<float>(), ctx->stage_e.as<int32_t>(), off2.data()))
+        return rc;
+    ESFM_HIP_TRY(hipMemcpyAsync(n_out, ctx->stage_e.ptr, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipMemcpyAsync(query_idx, ctx->stage_b.ptr, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipMemcpyAsync(train_idx, ctx->stage_c.ptr, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipMemcpyAsync(distance, ctx->stage_d.ptr, sizeof(float) * nq, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    return ESFM_OK;
+}
+
 int esfm_match_prepare_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int64_t total_rows, int width)
 {
     if (int rc = check_common(ctx, metric, width)) return rc;

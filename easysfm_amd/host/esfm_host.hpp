@@ -241,6 +241,52 @@ public:
 
     bool quiet = false;  // the reference prints timing lines (feature_matching.cpp:96-97,141-142)
 
+    // The pair loop of test/sfm.cpp:140-161 in ONE call: matchFeatures{SURF,ORB}(frames[pairs[p].first], frames[pairs[p].second],
+    // matches[p]) for every listed pair -- every frame's descriptors uploaded once, one launch sequence for the whole list
+    // (esfm_match_pairs), the per-pair lines of feature_matching.cpp:96-97 / :141-142 printed with the call's time shared out
+    // evenly.  matches[p] is appended to, like the single-pair members.
+    bool matchFeaturesAllPairs(std::vector<frame_t> &frames, const std::vector<std::pair<int, int>> &pairs, bool hamming,
+                               std::vector<std::vector<DMatch>> &matches, double ratio_thre = -1.0)
+    {
+        if (ratio_thre < 0) ratio_thre = hamming ? 0.8 : 0.5;               // the members' defaults (feature_matching.h:17-21)
+        matches.resize(pairs.size());
+        if (pairs.empty()) return true;
+        int width = 0;
+        for (const frame_t &f : frames) if (f.descriptors.rows > 0) { width = f.descriptors.cols; break; }
+        if (width == 0) return true;                                       // no frame has a descriptor: nothing can match
+        const size_t row_bytes = hamming ? size_t(width) : size_t(width) * 4;
+        std::vector<int32_t> off(frames.size() + 1, 0);
+        for (size_t i = 0; i < frames.size(); ++i) {
+            const DescMat &d = frames[i].descriptors;
+            if (d.rows > 0 && (d.cols != width || d.type != (hamming ? DescMat::U8 : DescMat::F32))) { std::cerr << "descriptor shapes differ\n"; return false; }
+            off[i + 1] = off[i] + d.rows;
+        }
+        std::vector<uint8_t> bank(size_t(off.back()) * row_bytes + 16);
+        for (size_t i = 0; i < frames.size(); ++i)
+            if (frames[i].descriptors.rows > 0) std::memcpy(bank.data() + size_t(off[i]) * row_bytes, frames[i].descriptors.bytes.data(), size_t(frames[i].descriptors.rows) * row_bytes);
+        std::vector<int32_t> pl(2 * pairs.size());
+        size_t total = 0;
+        for (size_t p = 0; p < pairs.size(); ++p) { pl[2 * p] = pairs[p].first; pl[2 * p + 1] = pairs[p].second; total += size_t(frames[size_t(pairs[p].first)].descriptors.rows); }
+        std::vector<int32_t> qi(std::max<size_t>(total, 1)), ti(std::max<size_t>(total, 1)), n_out(pairs.size());
+        std::vector<float> d(std::max<size_t>(total, 1));
+        std::vector<int64_t> out_off(pairs.size() + 1);
+        auto tic = std::chrono::steady_clock::now();
+        const int rc = esfm_match_pairs(default_ctx(), hamming ? ESFM_HAMMING : ESFM_L2_F32, bank.data(), off.data(), int(frames.size()), width, pl.data(),
+                                        int(pairs.size()), ratio_thre, qi.data(), ti.data(), d.data(), n_out.data(), out_off.data());
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        const std::chrono::duration<double> dt = std::chrono::steady_clock::now() - tic;
+        for (size_t p = 0; p < pairs.size(); ++p) {
+            const size_t o = size_t(out_off[p]);
+            for (int k = 0; k < n_out[p]; ++k) matches[p].push_back(DMatch(qi[o + size_t(k)], ti[o + size_t(k)], 0, d[o + size_t(k)]));
+            if (!quiet) {
+                std::cout << "match " << (hamming ? "ORB" : "SURF") << " cost = " << dt.count() / double(pairs.size()) << " seconds. " << std::endl;
+                std::cout << "# Correspondence: Initial [ " << frames[size_t(pairs[p].first)].descriptors.rows << " ]  Filtered by Lowe ratio test [ " << n_out[p]
+                          << " ]" << std::endl;
+            }
+        }
+        return true;
+    }
+
 private:
     bool run(frame_t &f1, frame_t &f2, std::vector<DMatch> &matches, double ratio, bool hamming, const char *tag)
     {
@@ -399,6 +445,75 @@ public:
         T = Matrix4f::Identity();
         for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T(r, c) = float(R[3 * r + c]); T(r, 3) = float(t[r]); }   // :76-85
         if (!quiet) std::cout << "Find [" << inlier_matches.size() << "] inlier matches from [" << matches.size() << "] total matches." << std::endl;
+        return true;
+    }
+
+    // estimate2D2D_E5P_RANSAC + getDepthFast (estimate_motion.cpp:27-97, :234-283; sfm.cpp:163-170) for MANY pairs in shared launches:
+    // job p = (frame_1[p], frame_2[p], matches[p]).  ok[p] / inlier_matches[p] / T[p] / appro_depth[p] are what the per-pair members
+    // return for that job (appro_depth stays untouched where the per-pair getDepthFast is not reached or fails).
+    bool estimate2D2D_E5P_RANSAC_pairs(std::vector<frame_t> &frames, const std::vector<std::pair<int, int>> &jobs, const std::vector<std::vector<DMatch>> &matches,
+                                       std::vector<std::vector<DMatch>> &inlier_matches, std::vector<Matrix4f> &T, std::vector<double> &appro_depth,
+                                       std::vector<char> &ok, double ransac_thre = 1.0, double ransac_prob = 0.99, int random_rate = 20)
+    {
+        const size_t nj = jobs.size();
+        inlier_matches.assign(nj, {}); T.assign(nj, Matrix4f::Identity()); ok.assign(nj, 0);
+        appro_depth.resize(nj, 1.0);
+        if (nj == 0) return true;
+        std::vector<int32_t> off(nj + 1, 0);
+        for (size_t p = 0; p < nj; ++p) off[p + 1] = off[p] + int32_t(matches[p].size());
+        std::vector<float> p1(size_t(2) * size_t(std::max(off[nj], 1))), p2(p1.size()), K4(4 * nj);
+        for (size_t p = 0; p < nj; ++p) {
+            std::vector<float> a, b;
+            gather(frames[size_t(jobs[p].first)], frames[size_t(jobs[p].second)], matches[p], 1, a, b);
+            std::copy(a.begin(), a.end(), p1.begin() + 2 * off[p]); std::copy(b.begin(), b.end(), p2.begin() + 2 * off[p]);
+            k4_of(frames[size_t(jobs[p].first)].K_cam, &K4[4 * p]);                           // frame 1's K for both images (:43-44)
+        }
+        std::vector<double> E(9 * nj), R(9 * nj), t(3 * nj);
+        std::vector<uint8_t> mask(size_t(std::max(off[nj], 1)));
+        std::vector<int32_t> status(nj, 0);
+        int rc = esfm_find_essential_pairs(default_ctx(), int(nj), off.data(), p1.data(), p2.data(), K4.data(), ransac_prob, ransac_thre, E.data(), mask.data(),
+                                           status.data(), nullptr);
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        for (size_t p = 0; p < nj; ++p) {
+            if (!status[p]) { for (int k = off[p]; k < off[p + 1]; ++k) mask[size_t(k)] = 0; continue; }
+            for (int k = off[p]; k < off[p + 1]; ++k) if (mask[size_t(k)]) inlier_matches[p].push_back(matches[p][size_t(k - off[p])]);   // :55-61
+        }
+        rc = esfm_recover_pose_pairs(default_ctx(), int(nj), off.data(), p1.data(), p2.data(), K4.data(), E.data(), mask.data(), R.data(), t.data(), nullptr);   // :67
+        if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+        // getDepthFast: every random_rate-th inlier match between [I | 0] and T_21, one triangulation launch for all jobs
+        std::vector<int32_t> doff(1, 0);
+        std::vector<float> P1s, P2s, da, db;
+        std::vector<size_t> dj;
+        for (size_t p = 0; p < nj; ++p) {
+            if (!status[p]) { if (!quiet) std::cerr << "no essential matrix for pair ( " << jobs[p].first << " , " << jobs[p].second << " )" << std::endl; continue; }
+            ok[p] = 1;
+            for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[p](r, c) = float(R[9 * p + size_t(3 * r + c)]); T[p](r, 3) = float(t[3 * p + size_t(r)]); }   // :76-85
+            if (!quiet) std::cout << "Find [" << inlier_matches[p].size() << "] inlier matches from [" << matches[p].size() << "] total matches." << std::endl;
+            std::vector<float> a, b;
+            frame_t &f1 = frames[size_t(jobs[p].first)];
+            gather(f1, frames[size_t(jobs[p].second)], inlier_matches[p], random_rate, a, b);
+            if (a.empty()) { appro_depth[p] = std::nan(""); continue; }                  // 0 / 0 in the reference (:280)
+            pixel2cam(a, f1.K_cam); pixel2cam(b, f1.K_cam);                               // frame 1's K for both (:245)
+            const float I34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            P1s.insert(P1s.end(), I34, I34 + 12);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) P2s.push_back(T[p](r, c));
+            da.insert(da.end(), a.begin(), a.end()); db.insert(db.end(), b.begin(), b.end());
+            doff.push_back(doff.back() + int32_t(a.size() / 2));
+            dj.push_back(p);
+        }
+        if (!dj.empty()) {
+            std::vector<float> hh(size_t(4) * size_t(doff.back()));
+            rc = esfm_triangulate_pairs(default_ctx(), int(dj.size()), P1s.data(), P2s.data(), doff.data(), da.data(), db.data(), hh.data());
+            if (rc != ESFM_OK) { std::cerr << esfm_last_error() << std::endl; return false; }
+            for (size_t s = 0; s < dj.size(); ++s) {
+                double depth_sum = 0;
+                for (int i = doff[s]; i < doff[s + 1]; ++i) {
+                    const float x = hh[size_t(4 * i)] / hh[size_t(4 * i + 3)], y = hh[size_t(4 * i + 1)] / hh[size_t(4 * i + 3)], z = hh[size_t(4 * i + 2)] / hh[size_t(4 * i + 3)];
+                    depth_sum += double(std::sqrt(x * x + y * y + z * z));   // Eigen::Vector3f::norm()
+                }
+                appro_depth[dj[s]] = depth_sum / double(doff[s + 1] - doff[s]);
+            }
+        }
         return true;
     }
 

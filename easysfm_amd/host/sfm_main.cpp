@@ -2,12 +2,15 @@
 // as a native C++ program over the C ABI of libesfm_hip.so, through the host mirror of the reference's classes
 // (esfm_host.hpp).  Same thirteen positional arguments in the same order, same ASCII .ply of PointXYZRGB at argv[5], exit
 // status 1 on success like the reference (sfm.cpp:339).  The control flow is the one of
-// easysfm_amd/pipeline.py (the Python twin of this file), pair by pair as the reference runs it:
+// easysfm_amd/pipeline.py (the Python twin of this file); the (i, j < i) pair loop of sfm.cpp:140-170 is ONE batched call per stage
+// (every frame's descriptors uploaded once, one match launch sequence, one RANSAC / pose / depth batch -- INTEGRATION.md section 2;
+// ESFM_PAIR_BY_PAIR=1 in the environment runs it pair by pair through host pointers as the reference does, same results):
 //   import -> undistort -> SURF or ORB -> all-pairs match + 5-point RANSAC + depth -> track ids -> initial pair -> triangulate -> BA
 //   -> (next frame by PnP -> triangulate against every registered frame -> periodic BA)* -> final BA -> SOR -> .ply
 // Differences from the reference: ORB's intensity tests use this library's own point pairs (cv::ORB's learned table ships only
 // inside OpenCV); the viewer arguments are accepted and ignored (no display); PNG and baseline JPEG images are read.
 //   bin/sfm_native --dump-image in.png out.raw   writes rows, cols (int32) and the BGR bytes: the decoder's test hook
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <filesystem>
@@ -39,6 +42,19 @@ Matrix4f mul(const Matrix4f &a, const Matrix4f &b)
         }
     return c;
 }
+
+// wall-clock of the stages the reference times with its `... cost = ... seconds` lines (feature_matching.cpp:141, ba.cpp:285), one
+// summary line at the end (`stage seconds: ...`) for bench.py's config-1 / config-3 legs
+struct StageClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap()
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return s;
+    }
+};
 
 int dump_image(const char *in, const char *out)
 {
@@ -78,6 +94,9 @@ int main(int argc, char **argv)
         FeatureMatching fm;
         MotionEstimator ee;
         std::vector<frame_t> frames;
+        double t_import = 0, t_detect = 0, t_match = 0, t_verify = 0, t_tracks = 0, t_ba = 0, t_register = 0, t_sor = 0;
+        int n_ba = 0;
+        StageClock total_clock, clk;
         if (!io.importImageFilenames(image_list_path, image_data_path, frames) || frames.size() < 2) { std::cerr << "need at least two images" << std::endl; return 3; }
         const int frame_number = int(frames.size());
         Matrix3f K_mat = Matrix3f::Identity();
@@ -88,13 +107,16 @@ int main(int argc, char **argv)
         // ---- per frame: import, undistort, SURF (sfm.cpp:84-126)
         std::cout << "Begin feature extraction" << std::endl;
         for (int i = 0; i < frame_number; ++i) {
+            clk.lap();
             if (!io.importImages(frames[size_t(i)], false)) return 3;
             frames[size_t(i)].K_cam = K_mat;
             if (!ee.doUnDistort(frames[size_t(i)], distort_coeff)) return 3;
+            t_import += clk.lap();
             std::cout << "Feature extraction of Frame [ " << i << " ]" << std::endl;
             if (using_feature == 'O' ? !fm.detectFeaturesORB(frames[size_t(i)], feature_extract_parameter)          // sfm.cpp:112-117
                                      : !fm.detectFeaturesSURF(frames[size_t(i)], feature_extract_parameter)) return 3;
             frames[size_t(i)].init_pixel_ids();
+            t_detect += clk.lap();
         }
         std::cout << "Feature extraction done" << std::endl;
 
@@ -102,26 +124,60 @@ int main(int argc, char **argv)
         const int num_min_pair = 20;
         const size_t nf = size_t(frame_number);
         std::vector<std::vector<frame_pair_t>> graph(nf, std::vector<frame_pair_t>(nf));
-        for (int i = 0; i < frame_number; ++i)
-            for (int j = 0; j < i; ++j) {
-                frame_pair_t &g = graph[size_t(i)][size_t(j)];
-                std::vector<DMatch> temp_matches, inlier_matches;
-                if (using_feature == 'O') fm.matchFeaturesORB(frames[size_t(i)], frames[size_t(j)], temp_matches);   // sfm.cpp:153-160
-                else fm.matchFeaturesSURF(frames[size_t(i)], frames[size_t(j)], temp_matches);
-                if (int(temp_matches.size()) > num_min_pair) {
-                    Matrix4f T = Matrix4f::Identity();
-                    if (ee.estimate2D2D_E5P_RANSAC(frames[size_t(i)], frames[size_t(j)], temp_matches, inlier_matches, T, ransac_reproj_distance)) {
-                        g.T_21 = T;
-                        double depth = 1.0;
-                        if (ee.getDepthFast(frames[size_t(i)], frames[size_t(j)], T, inlier_matches, depth)) g.appro_depth = depth;
-                        g.matches.swap(inlier_matches);
-                        if (!g.matches.empty()) std::cout << "Pair ( " << i << " , " << j << " ): [" << g.matches.size() << "] verified matches." << std::endl;
+        const bool pair_by_pair = std::getenv("ESFM_PAIR_BY_PAIR") != nullptr && std::atoi(std::getenv("ESFM_PAIR_BY_PAIR")) != 0;
+        if (pair_by_pair) {
+            for (int i = 0; i < frame_number; ++i)
+                for (int j = 0; j < i; ++j) {
+                    frame_pair_t &g = graph[size_t(i)][size_t(j)];
+                    std::vector<DMatch> temp_matches, inlier_matches;
+                    StageClock pc;
+                    if (using_feature == 'O') fm.matchFeaturesORB(frames[size_t(i)], frames[size_t(j)], temp_matches);   // sfm.cpp:153-160
+                    else fm.matchFeaturesSURF(frames[size_t(i)], frames[size_t(j)], temp_matches);
+                    t_match += pc.lap();
+                    if (int(temp_matches.size()) > num_min_pair) {
+                        Matrix4f T = Matrix4f::Identity();
+                        if (ee.estimate2D2D_E5P_RANSAC(frames[size_t(i)], frames[size_t(j)], temp_matches, inlier_matches, T, ransac_reproj_distance)) {
+                            g.T_21 = T;
+                            double depth = 1.0;
+                            if (ee.getDepthFast(frames[size_t(i)], frames[size_t(j)], T, inlier_matches, depth)) g.appro_depth = depth;
+                            g.matches.swap(inlier_matches);
+                            if (!g.matches.empty()) std::cout << "Pair ( " << i << " , " << j << " ): [" << g.matches.size() << "] verified matches." << std::endl;
+                        }
                     }
+                    t_verify += pc.lap();
                 }
+        } else {
+            // the same loop, batched: one match call for the whole (i, j < i) list, one RANSAC + pose + depth batch for the pairs with
+            // more than num_min_pair matches (none of them depends on another pair's result)
+            StageClock pc;
+            std::vector<std::pair<int, int>> pairs;
+            for (int i = 0; i < frame_number; ++i) for (int j = 0; j < i; ++j) pairs.emplace_back(i, j);
+            std::vector<std::vector<DMatch>> temp_matches;
+            if (!fm.matchFeaturesAllPairs(frames, pairs, using_feature == 'O', temp_matches)) return 3;
+            t_match += pc.lap();
+            std::vector<std::pair<int, int>> jobs;
+            std::vector<std::vector<DMatch>> job_matches;
+            for (size_t p = 0; p < pairs.size(); ++p)
+                if (int(temp_matches[p].size()) > num_min_pair) { jobs.push_back(pairs[p]); job_matches.push_back(std::move(temp_matches[p])); }
+            std::vector<std::vector<DMatch>> inliers;
+            std::vector<Matrix4f> Ts;
+            std::vector<double> depths;
+            std::vector<char> ok;
+            if (!ee.estimate2D2D_E5P_RANSAC_pairs(frames, jobs, job_matches, inliers, Ts, depths, ok, ransac_reproj_distance)) return 3;
+            for (size_t p = 0; p < jobs.size(); ++p) {
+                if (!ok[p]) continue;
+                frame_pair_t &g = graph[size_t(jobs[p].first)][size_t(jobs[p].second)];
+                g.T_21 = Ts[p];
+                g.appro_depth = depths[p];
+                g.matches.swap(inliers[p]);
+                if (!g.matches.empty()) std::cout << "Pair ( " << jobs[p].first << " , " << jobs[p].second << " ): [" << g.matches.size() << "] verified matches." << std::endl;
             }
+            t_verify += pc.lap();
+        }
 
         // ---- track ids (sfm.cpp:173-216): a keypoint takes the id of its verified match in an earlier frame unless the frame
         // already uses that id; the rest get fresh ids
+        clk.lap();
         size_t total_kp = 0;
         for (const frame_t &f : frames) total_kp += f.keypoints.size();
         std::vector<std::vector<bool>> track(nf, std::vector<bool>(std::max<size_t>(total_kp, 1), false));
@@ -147,6 +203,7 @@ int main(int argc, char **argv)
             cur_id += fresh;
         }
         std::cout << "The total unique feature point number is " << cur_id << std::endl;
+        t_tracks += clk.lap();
 
         // ---- initial pair (sfm.cpp:218-247)
         int init_1 = 1, init_2 = 0;
@@ -164,7 +221,9 @@ int main(int argc, char **argv)
         std::vector<bool> todo(nf, true);
         todo[size_t(init_1)] = todo[size_t(init_2)] = false;
         BundleAdjustment ba;
+        t_register += clk.lap();
         ba.doSFMBA(frames, todo, cloud, fix_calib_tolerance_BA);
+        t_ba += clk.lap(); ++n_ba;
 
         // ---- register the remaining frames (sfm.cpp:262-321)
         int remaining = frame_number - 2;
@@ -183,14 +242,18 @@ int main(int argc, char **argv)
             if (!ok) ee.outlierFilter(cloud);
             todo[size_t(nxt)] = false;
             --remaining;
+            t_register += clk.lap();
             if (remaining % frequency_BA == 0) {
                 ba.initBA();
                 ba.doSFMBA(frames, todo, cloud, fix_calib_tolerance_BA);
                 reproj = ransac_reproj_distance;
+                t_ba += clk.lap(); ++n_ba;
             }
             std::cout << "Progress: [ " << frame_number - remaining << " / " << frame_number << " ]" << std::endl;
         }
+        clk.lap();
         ba.doSFMBA(frames, todo, cloud);
+        t_ba += clk.lap(); ++n_ba;
 
         // ---- final cloud: SOR filter, .ply (sfm.cpp:329-337)
         std::vector<PointXYZRGB> filtered;
@@ -198,7 +261,11 @@ int main(int argc, char **argv)
         if (!cp.SORFilter(cloud.points, filtered)) return 3;
         const std::filesystem::path out_dir = std::filesystem::path(output_file_path).parent_path();
         if (!out_dir.empty()) std::filesystem::create_directories(out_dir);
+        t_sor += clk.lap();
         if (!io.writePlyFile(output_file_path, filtered)) return 3;
+        std::cout << "stage seconds: import+undistort " << t_import << " detect " << t_detect << " match " << t_match << " verify " << t_verify << " tracks " << t_tracks
+                  << " register " << t_register << " ba " << t_ba << " ba_calls " << n_ba << " sor " << t_sor << " total " << total_clock.lap()
+                  << " frames " << frame_number << " pairs " << frame_number * (frame_number - 1) / 2 << " batched " << (pair_by_pair ? 0 : 1) << std::endl;
     } catch (const std::exception &e) {       // 1 is the reference's SUCCESS status: a failure must not look like one
         std::cerr << "sfm_native: " << e.what() << std::endl;
         return 3;

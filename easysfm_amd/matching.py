@@ -73,6 +73,25 @@ def match_hamming(q, t, ratio: float = 0.8, ctx: Optional[Context] = None):
     return _match(lib().esfm_match_hamming, _as_desc(q, np.uint8), _as_desc(t, np.uint8), ratio, ctx)
 
 
+def match_pairs_host(sets: Sequence[np.ndarray], pairs, ratio: float, metric: int = ESFM_L2_F32, ctx: Optional[Context] = None):
+    """esfm_match_pairs: the batched pair loop through HOST pointers (upload once, one launch sequence, one read-back) -- what the
+    C++ driver calls.  Returns [(queryIdx, trainIdx, distance)] per pair."""
+    ctx = ctx or default_context()
+    dt = np.float32 if metric == ESFM_L2_F32 else np.uint8
+    sets = [_as_desc(s_, dt) for s_ in sets]
+    width = sets[0].shape[1]
+    off = np.zeros(len(sets) + 1, np.int32)
+    np.cumsum([s_.shape[0] for s_ in sets], out=off[1:])
+    bank = np.ascontiguousarray(np.concatenate(sets, axis=0)) if off[-1] else np.zeros((1, width), dt)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    total = int(sum(sets[i].shape[0] for i, _ in pairs))
+    qi = np.zeros(max(total, 1), np.int32); ti = np.zeros(max(total, 1), np.int32); d = np.zeros(max(total, 1), np.float32)
+    n_out = np.zeros(max(len(pairs), 1), np.int32); out_off = np.zeros(len(pairs) + 1, np.int64)
+    check(lib().esfm_match_pairs(ctx.handle, metric, _ptr(bank), _ptr(off), len(sets), width, _ptr(pairs), len(pairs), float(ratio),
+                                 _ptr(qi), _ptr(ti), _ptr(d), _ptr(n_out), _ptr(out_off)))
+    return [(qi[o:o + k].copy(), ti[o:o + k].copy(), d[o:o + k].copy()) for o, k in zip(out_off[:-1], n_out[:len(pairs)])]
+
+
 class FeatureMatching:
     """Mirror of p3dv::FeatureMatching's matching members (feature_matching.h:17-21)."""
 

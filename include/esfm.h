@@ -151,6 +151,16 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
                          int32_t *query_idx_dev, int32_t *train_idx_dev, float *distance_dev,
                          int32_t *n_out_dev /*n_pairs*/, int64_t *out_offset /*host, n_pairs+1*/);
 
+/* The same with HOST pointers in and out (what a C++ host without a device allocator of its own calls once for the whole pair loop,
+ * sfm.cpp:140-161): `desc_host` holds the rows of all sets back to back; they are uploaded once, prepared (below) once, every pair is
+ * matched in one launch sequence and the per-pair slices come back in one read-back.  query_idx / train_idx / distance need
+ * sum(nq_p) entries, n_out n_pairs, out_offset n_pairs + 1 (all host).  Synchronises. */
+int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host,
+                     const int32_t *set_row_offset, int n_sets, int width /*dim or nbytes*/,
+                     const int32_t *pairs, int n_pairs, double ratio,
+                     int32_t *query_idx, int32_t *train_idx, float *distance,
+                     int32_t *n_out /*n_pairs*/, int64_t *out_offset /*n_pairs+1*/);
+
 /*
  * Optional, once per resident descriptor buffer: derive and keep what the matcher computes from the rows before it can start --
  * for 64-float L2 descriptors the bf16 operand images, |row|^2 and the rounding residual norms of every row (l2_split_bf16_kernel),

@@ -101,6 +101,11 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_l2sqr.argtypes = [_f32p, _f32p, C.c_int]
     lib.esfm_ref_knn2_l2_f32.restype = None
     lib.esfm_ref_knn2_l2_f32.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _i32p, _f32p]
+    lib.esfm_ref_knn2_l2_f32_scalar.restype = None
+    lib.esfm_ref_knn2_l2_f32_scalar.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _i32p, _f32p]
+    lib.esfm_ref_match_pairs_l2.restype = C.c_int
+    lib.esfm_ref_match_pairs_l2.argtypes = [_f32p, _i32p, C.c_int, C.c_int, _i32p, C.c_int, C.c_double, _i32p, _i32p, _f32p, _i32p,
+                                            np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
     lib.esfm_ref_knn2_hamming.restype = None
     lib.esfm_ref_knn2_hamming.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, _i32p, _f32p]
     lib.esfm_ref_ratio_filter.restype = C.c_int
@@ -186,6 +191,33 @@ def knn2_l2(q: np.ndarray, t: np.ndarray):
     nt = t.shape[0]
     idx = np.empty(2 * nq, np.int32); dist = np.empty(2 * nq, np.float32)
     load().esfm_ref_knn2_l2_f32(q.reshape(-1), nq, t.reshape(-1), nt, dim, idx, dist)
+    return idx.reshape(nq, 2), dist.reshape(nq, 2)
+
+
+def match_pairs_l2(sets, pairs, ratio: float):
+    """The pair loop in one call, one parallel region over all (pair, query) items.  Returns [(queryIdx, trainIdx, distance)] per pair."""
+    sets = [np.ascontiguousarray(s_, np.float32) for s_ in sets]
+    dim = sets[0].shape[1]
+    off = np.zeros(len(sets) + 1, np.int32)
+    np.cumsum([s_.shape[0] for s_ in sets], out=off[1:])
+    bank = np.ascontiguousarray(np.concatenate(sets, axis=0)).reshape(-1)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    total = int(sum(sets[i].shape[0] for i, _ in pairs))
+    qi = np.zeros(max(total, 1), np.int32); ti = np.zeros(max(total, 1), np.int32); d = np.zeros(max(total, 1), np.float32)
+    n_out = np.zeros(max(len(pairs), 1), np.int32); out_off = np.zeros(len(pairs) + 1, np.int64)
+    rc = load().esfm_ref_match_pairs_l2(bank, off, len(sets), dim, pairs.reshape(-1), len(pairs), float(ratio), qi, ti, d, n_out, out_off)
+    if rc != 0:
+        raise ValueError("esfm_ref_match_pairs_l2: bad arguments (dim must be a multiple of 8)")
+    return [(qi[o:o + k].copy(), ti[o:o + k].copy(), d[o:o + k].copy()) for o, k in zip(out_off[:-1], n_out[:len(pairs)])]
+
+
+def knn2_l2_scalar(q: np.ndarray, t: np.ndarray):
+    """The plain (query, train) loop over esfm_ref_l2sqr: the definition knn2_l2's SIMD body is tested against."""
+    q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+    nq, dim = q.shape if q.ndim == 2 else (0, t.shape[1])
+    nt = t.shape[0]
+    idx = np.empty(2 * nq, np.int32); dist = np.empty(2 * nq, np.float32)
+    load().esfm_ref_knn2_l2_f32_scalar(q.reshape(-1), nq, t.reshape(-1), nt, dim, idx, dist)
     return idx.reshape(nq, 2), dist.reshape(nq, 2)
 
 

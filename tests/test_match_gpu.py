@@ -203,6 +203,38 @@ def test_batched_pairs_match_single_calls(gpu_ctx, oracle_lib):
     assert 0 <= n_rescan <= n_q
 
 
+def test_match_pairs_host_pointer_batch_equals_single_calls(gpu_ctx, oracle_lib):
+    """esfm_match_pairs (round 4: the batched pair loop through HOST pointers, what the C++ driver calls once for sfm.cpp:140-161):
+    ragged sets incl. an empty one, L2 and Hamming, every pair's list equal to the single-pair entry point's and the oracle's."""
+    rng = np.random.default_rng(21)
+    sizes = [300, 0, 517, 64, 1000]
+    sets = [rng.standard_normal((n, 64)).astype(np.float32) for n in sizes]
+    sets[2][:100] = sets[0][:100] + 1e-3 * rng.standard_normal((100, 64)).astype(np.float32)       # planted matches
+    sets[4][:64] = sets[3] * np.float32(1.0001)
+    pairs = synth.all_pairs(len(sets))
+    res = E.match_pairs_host(sets, pairs, 0.7, E.ESFM_L2_F32, gpu_ctx)
+    n_tot = 0
+    for (i, j), (q, t, d) in zip(pairs, res):
+        rq, rt, rd = oracle_lib.match_l2(sets[i], sets[j], 0.7)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(_bits(d), _bits(rd)), (i, j)
+        if len(sets[i]) and len(sets[j]):
+            sq, st_, sd = E.match_l2(sets[i], sets[j], 0.7, gpu_ctx)
+            assert np.array_equal(q, sq) and np.array_equal(t, st_) and np.array_equal(_bits(d), _bits(sd))
+        n_tot += len(q)
+    assert n_tot >= 150
+    osets = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in sizes]
+    osets[2][:80] = osets[0][:80]; osets[2][:80, 0] ^= 1
+    res = E.match_pairs_host(osets, pairs, 0.8, E.ESFM_HAMMING, gpu_ctx)
+    for (i, j), (q, t, d) in zip(pairs, res):
+        rq, rt, rd = oracle_lib.match_hamming(osets[i], osets[j], 0.8)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(d, rd), (i, j)
+    # a second batch on the same context (other sizes: the bank and every scratch buffer are re-used or re-grown)
+    sets2 = [rng.standard_normal((n, 64)).astype(np.float32) for n in (40, 2100)]
+    (q, t, d), = E.match_pairs_host(sets2, np.array([[1, 0]], np.int32), 1.0, E.ESFM_L2_F32, gpu_ctx)
+    rq, rt, rd = oracle_lib.match_l2(sets2[1], sets2[0], 1.0)
+    assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(_bits(d), _bits(rd))
+
+
 def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
     """The re-scan of uncertified queries works pair by pair, in chunks of the pair's list (l2_rescan64_pairs_kernel); launches
     of 2048 pairs and more use the large chunks and ONE workgroup per pair that loops over them.  70 small sets full of

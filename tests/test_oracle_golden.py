@@ -51,6 +51,42 @@ def test_l2_golden_bitexact(oracle_lib):
     assert z["near_tie_audit"].sum() > 0   # the fixtures really contain near-ties
 
 
+def test_l2_simd_body_equals_the_plain_loop(oracle_lib):
+    """Round 4: knn2_l2 runs a SIMD body (eight train rows per register, every lane the scalar function's operations in its order)
+    so that bench.py's cpu_baseline is an honest brute-force matcher; the plain loop over esfm_ref_l2sqr stays the definition.  Same
+    bits on the golden cases, on ragged sizes (rows past the last block of eight), ties, non-finite rows and denormal scales."""
+    z = np.load(os.path.join(GOLD, "match_l2_cases.npz"))
+    for name in _cases(z):
+        q, t = z[f"{name}.q"], z[f"{name}.t"]
+        if q.ndim != 2:
+            continue
+        a, b = oracle_lib.knn2_l2(q, t), oracle_lib.knn2_l2_scalar(q, t)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])), name
+    rng = np.random.default_rng(77)
+    for nq, nt, dim, scale in [(33, 1, 64, 1.0), (50, 7, 64, 1.0), (64, 9, 64, 1e-20), (40, 1001, 64, 1e3), (17, 260, 128, 1.0), (9, 30, 8, 1.0)]:
+        q = (rng.standard_normal((nq, dim)) * scale).astype(np.float32); t = (rng.standard_normal((nt, dim)) * scale).astype(np.float32)
+        if nt > 5:
+            t[3] = t[1]; q[0] = t[1]                       # exact ties: the lower train index first
+            t[4, 5] = np.inf; t[2, 0] = np.nan             # never neighbours
+        a, b = oracle_lib.knn2_l2(q, t), oracle_lib.knn2_l2_scalar(q, t)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])), (nq, nt, dim, scale)
+
+
+def test_l2_match_pairs_batch_equals_single_calls(oracle_lib):
+    """esfm_ref_match_pairs_l2 (the CPU baseline's batched pair loop: one parallel region) == match_l2 pair by pair."""
+    rng = np.random.default_rng(78)
+    sets = [rng.standard_normal((n, 64)).astype(np.float32) for n in (120, 0, 333, 9)]
+    sets[2][:50] = sets[0][:50] + np.float32(1e-3) * rng.standard_normal((50, 64)).astype(np.float32)
+    pairs = np.array([(i, j) for i in range(4) for j in range(i)], np.int32)
+    res = oracle_lib.match_pairs_l2(sets, pairs, 0.7)
+    tot = 0
+    for (i, j), (q, t, d) in zip(pairs, res):
+        rq, rt, rd = oracle_lib.match_l2(sets[i], sets[j], 0.7)
+        assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(_bits(d), _bits(rd)), (i, j)
+        tot += len(q)
+    assert tot >= 40
+
+
 def test_l2_canonical_sum_known_answer(oracle_lib):
     """Order sensitivity: a vector built so that the 8-accumulator order and a plain left-to-right sum
     round differently; the oracle must produce the 8-accumulator value."""

@@ -201,6 +201,46 @@ def test_native_sfm_matches_the_python_driver(tmp_path):
     assert abs(sc - 1) < 0.15 and np.median(d) < 0.1 * extent
 
 
+def test_native_sfm_batched_pair_loop_equals_pair_by_pair(tmp_path):
+    """bin/sfm_native runs the (i, j < i) loop of sfm.cpp:140-170 as one batched call per stage (esfm_match_pairs,
+    esfm_find_essential_pairs, esfm_recover_pose_pairs, esfm_triangulate_pairs); ESFM_PAIR_BY_PAIR=1 runs it pair by pair through the
+    host-pointer entry points, as the reference does.  Same per-pair lines, same tracks, same initial pair, same triangulation
+    counts; and the run ends with the `stage seconds:` line bench.py's config legs read."""
+    import os
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "sfm_native")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-C", os.path.join(root, "easysfm_amd", "csrc"), "../../bin/sfm_native"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+    z = np.load(os.path.join(root, "tests", "golden", "fountain11_half_gray.npz"))
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    names = []
+    for i, img in enumerate(z["images"][:6]):
+        names.append(f"{i:04d}.png")
+        PIL.fromarray(np.stack([img] * 3, axis=2)).save(str(img_dir / names[-1]))
+    (tmp_path / "image_list.txt").write_text("\n".join(names) + "\n")
+    (tmp_path / "K.txt").write_text(f"{689.87 / 2} 0 {380.17 / 2}\n0 {691.04 / 2} {251.70 / 2}\n0 0 1\n")
+    logs = {}
+    for tag in ("batched", "pairwise"):
+        env = dict(os.environ)
+        env.pop("ESFM_PAIR_BY_PAIR", None)
+        if tag == "pairwise":
+            env["ESFM_PAIR_BY_PAIR"] = "1"
+        r = subprocess.run([exe, str(img_dir), str(tmp_path / "image_list.txt"), str(tmp_path / "K.txt"), "none", str(tmp_path / tag / "cloud.ply"),
+                            "S", "100", "1.0", "1", "0", "4", "1", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 1, r.stdout[-3000:]
+        logs[tag] = r.stdout
+        assert f"batched {1 if tag == 'batched' else 0}" in [l for l in r.stdout.splitlines() if l.startswith("stage seconds:")][-1]
+
+    def stages(text):
+        keys = ("# Correspondence", "inlier matches from", "verified matches", "total unique feature point number", "Initialization frames", "Triangulate [")
+        return sorted(l.strip() for l in text.splitlines() if any(k in l for k in keys))
+    sb, sp = stages(logs["batched"]), stages(logs["pairwise"])
+    assert len(sb) > 40 and sb == sp
+
+
 def test_native_sfm_with_a_distortion_file(tmp_path):
     """argv[4] names a distortion file: both drivers read it the way the reference does (floats stored into a CV_64F matrix,
     SURVEY section 9.10 -- k2 = 1.2 turns into k1' ~ 0.025), undistort every frame on the GPU before detection and still
