@@ -56,7 +56,10 @@ KEEP = int(os.environ.get("ESFM_GEN_KEEP", "4"))
 NOFOLD = int(os.environ.get("ESFM_GEN_NOFOLD", "0"))      # timing experiments only: no fold / no MFMA
 NOMFMA = int(os.environ.get("ESFM_GEN_NOMFMA", "0"))
 NS = 4
-CODE_BITS = 13
+GRP = int(os.environ.get("ESFM_GEN_GRP", "8"))            # results per fold group: 4 (round 3) or 8 (round 4: 4.5 instead of 7 VALU per MFMA at K = 4)
+assert GRP in (4, 8)
+NG = 16 // GRP                                            # groups per lane and 32-train step
+CODE_BITS = 11 + (2 if GRP == 4 else 1)                   # position code: 11 bits step, 2 / 1 bits group
 KBIG = 0x7F61B1E6          # 3.0e38f
 NKBIG = 0xFF61B1E6
 TT = int(os.environ.get("ESFM_GEN_TT", "256"))            # train rows per tile (128 or 256)
@@ -141,12 +144,13 @@ def gen():
     for s in range(NS):
         for i in range(KEEP):
             e(f"v_mov_b32 {KEY(s, i)}, s52")
-    for r in list(range(0, 64)) + list(range(ACC_ODD, ACC_ODD + 32)):
-        e(f"v_mov_b32 v{r}, s52")                             # placeholders for the step before the first: never live
+    for r in list(range(0, 64)) + list(range(ACC_ODD, ACC_ODD + 32)) + [FTMP + 1, FTMP + 3]:
+        e(f"v_mov_b32 v{r}, s52")                             # placeholders for the step before the first: never live (the fold temporaries:
+        #                                                       GRP = 8 runs the second half of a fold of that step in the first step's slots 0 / 1)
     e("s_mov_b32 s40, 0")
     e("s_mov_b32 s41, 0")
     e("s_mov_b32 s42, 0")
-    for g in range(4):
+    for g in range(NG):
         e(f"s_mov_b32 s{44 + g}, {g}")
     # tile 0 has landed for every wave (the caller's barrier).  Pipeline fill: the start values and the four fragments of step 0
     for g in range(4):
@@ -157,15 +161,35 @@ def gen():
     cnt = [0]
 
     def fold_group(s, g, par):
-        """(3 + K) VALU: group g (accumulator registers 4 g .. 4 g + 3) of set s of the step with parity `par`."""
+        """Quarter g (0..3) of the fold of set s' 16 results of the step with parity `par`.
+        GRP = 4: the whole fold of group g (accumulator registers 4 g .. 4 g + 3): 3 + K VALU.
+        GRP = 8: groups are register octets (0..7 = rows {0..3, 8..11} + 4 h of the step, 8..15 = rows {16..19, 24..27} + 4 h); quarter
+        2 G is the first half of group G's fold -- the minimum of its eight scores and the position code, 5 VALU, into the set
+        parity's temporary -- quarter 2 G + 1 the second half: the K v_med3 (it reads the temporary only, so it may run after the
+        octet has been overwritten).  4.5 VALU per MFMA at K = 4 instead of 7."""
         if NOFOLD:
             return []
-        b = acc(s, par) + 4 * g
-        cnt[0] ^= 1
-        t, key = FTMP + 2 * cnt[0], FTMP + 1 + 2 * cnt[0]
-        out = [f"v_min3_f32 v{t}, v{b}, s52, v{b + 1}",
-               f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
-               f"v_and_or_b32 v{key}, v{t}, v{MASK}, s{44 + g}"]
+        if GRP == 4:
+            b = acc(s, par) + 4 * g
+            cnt[0] ^= 1
+            t, key = FTMP + 2 * cnt[0], FTMP + 1 + 2 * cnt[0]
+            out = [f"v_min3_f32 v{t}, v{b}, s52, v{b + 1}",
+                   f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
+                   f"v_and_or_b32 v{key}, v{t}, v{MASK}, s{44 + g}"]
+            for i in range(KEEP - 1, 0, -1):
+                out.append(f"v_med3_f32 {KEY(s, i)}, {KEY(s, i - 1)}, {KEY(s, i)}, v{key}")
+            out.append(f"v_med3_f32 {KEY(s, 0)}, {KEY(s, 0)}, v{key}, s53")
+            return out
+        G, half = g >> 1, g & 1
+        t, key = FTMP + 2 * (s & 1), FTMP + 1 + 2 * (s & 1)        # sets of equal parity never have a fold in flight at the same time
+        if half == 0:
+            b = acc(s, par) + 8 * G
+            return [f"v_min3_f32 v{t}, v{b}, s52, v{b + 1}",
+                    f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
+                    f"v_min3_f32 v{t}, v{t}, v{b + 4}, v{b + 5}",
+                    f"v_min3_f32 v{t}, v{t}, v{b + 6}, v{b + 7}",
+                    f"v_and_or_b32 v{key}, v{t}, v{MASK}, s{44 + G}"]
+        out = []
         for i in range(KEEP - 1, 0, -1):
             out.append(f"v_med3_f32 {KEY(s, i)}, {KEY(s, i - 1)}, {KEY(s, i)}, v{key}")
         out.append(f"v_med3_f32 {KEY(s, 0)}, {KEY(s, 0)}, v{key}, s53")
@@ -195,9 +219,9 @@ def gen():
                 e(f"s_waitcnt lgkmcnt({WAITS[slot]})")
             if slot == 10:
                 # the step being folded from now on is this one
-                e("s_lshl_b32 s41, s42, 2")
+                e(f"s_lshl_b32 s41, s42, {2 if GRP == 4 else 1}")
                 e("s_add_u32 s42, s42, 1")
-                for g in range(4):
+                for g in range(NG):
                     e(f"s_add_u32 s{44 + g}, s41, {g}")
             if not NOMFMA:
                 a = accr(s, spar)
@@ -298,6 +322,7 @@ def main():
            f"#define ESFM_L2X1_KEEP {KEEP}",
            f"#define ESFM_L2X1_SETS {NS}",
            f"#define ESFM_L2X1_CODE_BITS {CODE_BITS}",
+           f"#define ESFM_L2X1_GRP {GRP}",
            f"#define ESFM_L2X1_TT {TT}",
            f"#define ESFM_L2X1_RING {RING}",
            "#define ESFM_L2X1_SEGMENT_ASM \\"]
@@ -307,7 +332,7 @@ def main():
     out.append("#define ESFM_L2X1_SEGMENT_CLOBBERS " + ", ".join(f'"{c}"' for c in clob))
     open(sys.argv[1] if len(sys.argv) > 1 else "l2x1_segment_gfx950.inc", "w").write("\n".join(out) + "\n")
     n_mfma = sum("v_mfma" in l for l in lines)
-    print(f"{len(lines)} instructions, {n_mfma} MFMAs, KEEP = {KEEP}")
+    print(f"{len(lines)} instructions, {n_mfma} MFMAs, KEEP = {KEEP}, GRP = {GRP}")
 
 
 if __name__ == "__main__":

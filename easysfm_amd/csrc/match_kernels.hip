@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     // call (whose finish kernel needs them immutable while it runs) -- no memset launch, no zeroing pass in front of this one.
     if (threadIdx.x == 0) for (int e = blockIdx.x; e < zero_n; e += gridDim.x) zero_cnt[e] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 16) zero_counters[threadIdx.x] = 0;
-    constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, GRP = 4, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
+    constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, GRP = ESFM_L2X1_GRP, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
     constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
     constexpr int TILE_BYTES = TT * HS * 16;
     static_assert(NS == 4, "operand list below is written for four query sets");
@@ -923,11 +923,12 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     constexpr float kBig = 3.0e38f;
     constexpr int NG = 16 / GRP;
     constexpr uint32_t kCodeMask = (1u << ESFM_L2X1_CODE_BITS) - 1u;
-    // first of the GRP consecutive train rows of the group a key names (-1: empty slot): the code is step * NG + group, accumulator
-    // register r holds row (r & 3) + 8 (r >> 2) + 4 h of its step
+    // first train row of the group a key names (-1: empty slot): the code is step * NG + group, accumulator register r holds row
+    // (r & 3) + 8 (r >> 2) + 4 h of its step, a group is GRP consecutive REGISTERS: row u of the group is row0 + (u & 3) + 8 (u >> 2)
+    // (GRP = 4: four consecutive rows; GRP = 8: two runs of four, eight rows apart)
     auto group_row0_of = [&](float key) {
         const int code = (int)(__float_as_uint(key) & kCodeMask);
-        return key < 1.0e38f ? (code / NG) * 32 + 8 * (code % NG) + 4 * h : -1;
+        return key < 1.0e38f ? (code / NG) * 32 + (32 / NG) * (code % NG) + 4 * h : -1;
     };
 
     const int ntiles = (nt + TT - 1) / TT;
@@ -1195,13 +1196,14 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         if (4 * i < nv) {
-                            lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + (u + 1) * 256, frsrc_t, 0);
-                            lds_dma_b128(lds_land + (uint32_t)(i + 8) * 1024u, rowsrc[i + 8] + (u + 1) * 256, frsrc_t, 0);
+                            const int nxt = ((u + 1) & 3) + 8 * ((u + 1) >> 2);       // row u + 1 of the group (u is unrolled: a constant)
+                            lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + nxt * 256, frsrc_t, 0);
+                            lds_dma_b128(lds_land + (uint32_t)(i + 8) * 1024u, rowsrc[i + 8] + nxt * 256, frsrc_t, 0);
                         }
                     }
                 }
                 const float da = l2sqr64_canonical_regs(qv, ra_);
-                const int ta_ = row0 + u;
+                const int ta_ = row0 + (u & 3) + 8 * (u >> 2);
                 insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
             }
             if (screen && r + 1 < K) {

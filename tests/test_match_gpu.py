@@ -259,7 +259,7 @@ def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
     pm.ctx.synchronize()               # the library's own stream: torch's copies below do not wait for it
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     n_q, n_rescan = pm.stats()
-    assert pm.second_pass() > n_q // 2     # the case is about the passes behind the first one (round 3: the threshold-filter pass
+    assert pm.second_pass() > n_q // 3     # the case is about the passes behind the first one (round 3: the threshold-filter pass
                                            # resolves these duplicates exactly; its overflow path to the re-scan: next test)
     off = pm.offset
     for k, (i, j) in enumerate(pairs):
