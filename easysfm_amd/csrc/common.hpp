@@ -62,7 +62,8 @@ struct esfm_ctx {
     int l2_phase = 0;                  // phase the NEXT one-product call fills
     int l2_phase_pairs[2] = {0, 0};    // entries of each phase that may be non-zero
     int32_t *counters_cur = nullptr;   // the 16 counters of the last L2 call (esfm_match_last_stats / _second_pass / _flagged)
-    esfm::DevBuf fin_pool, fin_region_cnt, fin_done;   // l2_finish_kernel: hit pool (one region per chunk of 32 uncertified queries), its fill counts, per-pair arrival counters
+    esfm::DevBuf fin_done;             // l2_finish_kernel: per-pair arrival counters
+    esfm::DevBuf surv_cnt, surv_cntb, surv_list;   // the ratio screen's survivors: per-pair counts (two phases), 48-byte entries in the pair's slice of the query numbering
     // esfm_match_prepare_dev: the derived per-row operands (bf16 images, norms, residual norms; 0/1 byte image for Hamming) in l2_hi /
     // norms / hm_exp belong to this descriptor buffer and are not recomputed by the match calls
     const void *prep_desc = nullptr;

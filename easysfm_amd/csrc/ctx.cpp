@@ -169,7 +169,7 @@ int esfm_ctx_destroy(esfm_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     esfm::DevBuf *bufs[] = {&ctx->norms, &ctx->pair_tab, &ctx->knn_idx, &ctx->knn_dist, &ctx->flagged, &ctx->counters,
                             &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->stage_e, &ctx->hm_exp, &ctx->pair_cnt, &ctx->pair_list,
-                            &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi, &ctx->knn_d2, &ctx->pair_cnt2b, &ctx->fin_pool, &ctx->fin_region_cnt, &ctx->fin_done, &ctx->bank};
+                            &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi, &ctx->knn_d2, &ctx->pair_cnt2b, &ctx->fin_done, &ctx->bank, &ctx->surv_cnt, &ctx->surv_cntb, &ctx->surv_list};
     for (auto *b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_rounds) (void)hipHostFree(ctx->pinned_rounds);

@@ -14,6 +14,8 @@ namespace {
 
 struct PairPlan {
     std::vector<PairDesc> tab;
+    std::vector<int32_t> by_train;   // pair indices sorted by train set (l2_finish_kernel walks the pairs in this order: the workgroups that
+                                     // fetch rows of one train set run next to each other, on one XCD, and find them in its L2)
     int n_blocks = 0;
     int n_blocks2 = 0;      // workgroups of the one-product front pass
     int max_nt = 0;
@@ -50,6 +52,10 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
         ESFM_REQUIRE(blk < (int64_t)1 << 31, "too many workgroups for one launch; split the pair list");
     }
     if (out_offset) out_offset[n_pairs] = off;
+    plan->by_train.resize((size_t)n_pairs);
+    for (int p = 0; p < n_pairs; ++p) plan->by_train[(size_t)p] = p;
+    std::stable_sort(plan->by_train.begin(), plan->by_train.end(),
+                     [&](int32_t a, int32_t b) { return plan->tab[(size_t)a].t_row0 < plan->tab[(size_t)b].t_row0; });
     plan->n_blocks = (int)blk;
     plan->n_blocks2 = (int)blk2;
     plan->total_queries = off;
@@ -60,10 +66,14 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
 // an identical pair list (the common case in a loop over the same frames) is not re-sent.
 int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
 {
-    const size_t bytes = plan.tab.size() * sizeof(PairDesc);
+    // one blob: the pair table, then the pairs' indices sorted by train set (pair_order_of below)
+    const size_t tab_bytes = plan.tab.size() * sizeof(PairDesc), bytes = tab_bytes + plan.by_train.size() * sizeof(int32_t);
     if (bytes == 0) { *dev_tab = nullptr; return ESFM_OK; }
+    std::vector<char> blob(bytes);
+    memcpy(blob.data(), plan.tab.data(), tab_bytes);
+    memcpy(blob.data() + tab_bytes, plan.by_train.data(), bytes - tab_bytes);
     if (ctx->pair_tab.cap >= bytes && ctx->pinned_cap >= bytes && ctx->last_pair_bytes == bytes &&
-        memcmp(ctx->pinned, plan.tab.data(), bytes) == 0) {
+        memcmp(ctx->pinned, blob.data(), bytes) == 0) {
         *dev_tab = ctx->pair_tab.as<PairDesc>();
         return ESFM_OK;
     }
@@ -72,12 +82,13 @@ int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
     ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (int rc = ctx->pin(bytes)) return rc;
     if (int rc = ctx->pair_tab.reserve(bytes)) return rc;
-    memcpy(ctx->pinned, plan.tab.data(), bytes);
+    memcpy(ctx->pinned, blob.data(), bytes);
     ESFM_HIP_TRY(hipMemcpyAsync(ctx->pair_tab.ptr, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     ctx->last_pair_bytes = bytes;
     *dev_tab = ctx->pair_tab.as<PairDesc>();
     return ESFM_OK;
 }
+inline const int32_t *pair_order_of(const PairDesc *dev_tab, int n_pairs) { return reinterpret_cast<const int32_t *>(dev_tab + n_pairs); }
 
 // Where the ratio test's survivors go (the match entry points); NULL: the raw 2-NN table is the result.
 struct MatchOut { int32_t *query_idx, *train_idx; float *distance; int32_t *n_out; };
@@ -127,10 +138,10 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             const bool front = esfm::l2_bf16_pass(width) && esfm::l2_one_product_pass() && esfm::l2_x1_supported(plan.max_nt);
             if (front) {
                 // 64-float rows.  Launch 1 (only when the descriptor buffer has not been prepared): bf16 images, norms, residual norms.
-                // Launch 2: one bf16 product per f32 product, ratio screen, exact re-rank of the survivors, certificate
-                // (l2_knn_bf16x1_kernel).  Launch 3: its uncertified queries through the threshold filter, overflowed chunks by
-                // brute force, ratio test + compaction (l2_finish_kernel).  Audit modes: 1 no brute force, 3 / 4 launch 2 alone.
-                bool grew = false;
+                // Launch 2: one bf16 product per f32 product, fused top-K fold, ratio screen (l2_knn_bf16x1_kernel).  Launch 3: exact
+                // re-rank of the screen's survivors + certificate, the uncertified ones through the threshold filter, overflowed chunks by
+                // brute force, ratio test + compaction (l2_finish_kernel).  Audit modes: 1 no brute force, 3 / 4 launch 3 stops after
+                // the re-rank.
                 if (!prepared) {
                     ctx->prep_desc = nullptr;          // the images below replace whatever was prepared
                     if (int rc = ctx->norms.reserve(sizeof(float) * (size_t)std::max<int64_t>(plan.total_rows, 1))) return rc;
@@ -138,18 +149,21 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                 }
                 if (int rc = ctx->pair_list2.reserve(sizeof(int32_t) * (size_t)plan.total_queries)) return rc;
                 if (int rc = ctx->knn_d2.reserve(sizeof(float) * (size_t)plan.total_queries)) return rc;
-                grew = false;
-                if (int rc = reserve_zeroed(ctx->pair_cnt2, sizeof(int32_t) * (size_t)n_pairs, st, &grew)) return rc;
-                if (grew) ctx->l2_phase_pairs[0] = 0;
-                grew = false;
-                if (int rc = reserve_zeroed(ctx->pair_cnt2b, sizeof(int32_t) * (size_t)n_pairs, st, &grew)) return rc;
-                if (grew) ctx->l2_phase_pairs[1] = 0;
+                if (int rc = ctx->surv_list.reserve(esfm::l2_survivor_entry_bytes() * (size_t)plan.total_queries)) return rc;
+                for (int k = 0; k < 2; ++k) {        // the two phases of the per-pair counters (survivors, uncertified)
+                    bool g1 = false, g2 = false;
+                    if (int rc = reserve_zeroed(k ? ctx->pair_cnt2b : ctx->pair_cnt2, sizeof(int32_t) * (size_t)n_pairs, st, &g1)) return rc;
+                    if (int rc = reserve_zeroed(k ? ctx->surv_cntb : ctx->surv_cnt, sizeof(int32_t) * (size_t)n_pairs, st, &g2)) return rc;
+                    if (g1 || g2) {                  // a fresh allocation is clean as a whole; its sibling is cleared with it
+                        ESFM_HIP_TRY(hipMemsetAsync((k ? ctx->pair_cnt2b : ctx->pair_cnt2).ptr, 0, (k ? ctx->pair_cnt2b : ctx->pair_cnt2).cap, st));
+                        ESFM_HIP_TRY(hipMemsetAsync((k ? ctx->surv_cntb : ctx->surv_cnt).ptr, 0, (k ? ctx->surv_cntb : ctx->surv_cnt).cap, st));
+                        ctx->l2_phase_pairs[k] = 0;
+                    }
+                }
                 if (int rc = reserve_zeroed(ctx->fin_done, sizeof(int32_t) * (size_t)n_pairs, st)) return rc;
-                const int n_regions = (int)std::min<int64_t>(plan.total_queries / 32 + n_pairs, 65536);
-                if (int rc = reserve_zeroed(ctx->fin_region_cnt, sizeof(int32_t) * (size_t)n_regions, st)) return rc;
-                if (int rc = ctx->fin_pool.reserve(esfm::l2_finish_region_bytes() * (size_t)n_regions)) return rc;
                 const int ph = ctx->l2_phase;
-                int32_t *cur_cnt = (ph ? ctx->pair_cnt2b : ctx->pair_cnt2).as<int32_t>(), *oth_cnt = (ph ? ctx->pair_cnt2 : ctx->pair_cnt2b).as<int32_t>();
+                int32_t *cur_unc = (ph ? ctx->pair_cnt2b : ctx->pair_cnt2).as<int32_t>(), *oth_unc = (ph ? ctx->pair_cnt2 : ctx->pair_cnt2b).as<int32_t>();
+                int32_t *cur_surv = (ph ? ctx->surv_cntb : ctx->surv_cnt).as<int32_t>(), *oth_surv = (ph ? ctx->surv_cnt : ctx->surv_cntb).as<int32_t>();
                 int32_t *cur_counters = ctx->counters.as<int32_t>() + 16 * ph, *oth_counters = ctx->counters.as<int32_t>() + 16 * (1 - ph);
                 ctx->counters_cur = cur_counters;
                 if (!prepared) {
@@ -159,24 +173,23 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                 }
                 {
                     esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
-                    int32_t *audit_list = (ctx->l2_audit == 3 || ctx->l2_audit == 4) ? ctx->flagged.as<int32_t>() : nullptr;
                     if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
-                                                            plan.n_blocks2, knn_idx, knn_dist, ctx->l2_audit == 3 ? audit_list : nullptr,
-                                                            cur_counters, (int)cap64, cur_cnt, ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(),
-                                                            ratio, ctx->l2_audit == 4 ? audit_list : nullptr, oth_cnt, ctx->l2_phase_pairs[1 - ph], oth_counters))
+                                                            plan.n_blocks2, knn_idx, knn_dist, cur_counters, (int)cap64, cur_surv, ctx->surv_list.ptr, ratio,
+                                                            ctx->l2_audit == 4 ? ctx->flagged.as<int32_t>() : nullptr, oth_unc, oth_surv,
+                                                            ctx->l2_phase_pairs[1 - ph], oth_counters))
                         return rc;
                 }
                 ctx->l2_phase_pairs[1 - ph] = 0;
                 ctx->l2_phase_pairs[ph] = n_pairs;
                 ctx->l2_phase = 1 - ph;
-                if (ctx->l2_audit == 3 || ctx->l2_audit == 4) return ESFM_OK;   // audit: the one-product pass's own answers and failures / rejections
                 esfm::KernelTimer tm(ctx, ESFM_K_L2_SECOND);
-                if (int rc = esfm::launch_l2_finish(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs, cur_cnt,
-                                                    ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(), knn_idx, knn_dist, cur_counters,
-                                                    ctx->flagged.as<int32_t>(), (int)cap64, ctx->fin_pool.as<int32_t>(), ctx->fin_region_cnt.as<int32_t>(),
-                                                    n_regions, ctx->fin_done.as<int32_t>(), ctx->l2_audit == 1, mo != nullptr, ratio,
+                if (int rc = esfm::launch_l2_finish(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, pair_order_of(dev_tab, n_pairs), n_pairs, cur_surv,
+                                                    ctx->surv_list.ptr, cur_unc, ctx->pair_list2.as<int32_t>(), ctx->knn_d2.as<float>(), knn_idx, knn_dist,
+                                                    cur_counters, ctx->flagged.as<int32_t>(), (int)cap64, ctx->fin_done.as<int32_t>(), ctx->l2_audit,
+                                                    mo != nullptr && ctx->l2_audit != 3 && ctx->l2_audit != 4, ratio,
                                                     mo ? mo->query_idx : nullptr, mo ? mo->train_idx : nullptr, mo ? mo->distance : nullptr, mo ? mo->n_out : nullptr))
                     return rc;
+                if (ctx->l2_audit == 3 || ctx->l2_audit == 4) return ESFM_OK;   // audit: the first pass's own answers and failures / rejections
                 if (mo && ratio_done) *ratio_done = true;
                 return ESFM_OK;
             }

@@ -160,6 +160,37 @@ __device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], c
     d = __fadd_rn(d, s2);
     return __fadd_rn(d, s3);
 }
+// The same on two rows that sit in LDS as 16 x 16 B with their slots XOR-swizzled (slot c of a row at piece c ^ sw): the pieces are
+// read as they are used, so neither row has to be held in 64 registers.  a_row / b_row: LDS byte address of the row, a_sw16 / b_sw16:
+// 16 sw.  The 32 piece addresses are formed HERE, every time, from operands the compiler cannot see through (one v_xad_u32 each): as
+// ordinary loop invariants they are hoisted out of the caller's loops, live across everything, get spilled, and every LDS read then
+// waits for the scratch reload of its own address (seen in the re-rank: 219 spilled registers).  Same 8 chains, same final order.
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const floatx4_t *lds_cf4p;
+__device__ __forceinline__ float l2sqr64_canonical_lds(uint32_t a_row, uint32_t a_sw16, uint32_t b_row, uint32_t b_sw16)
+{
+    asm volatile("" : "+v"(a_sw16), "+v"(b_sw16));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const floatx4_t a0 = *(lds_cf4p)(uintptr_t)((a_sw16 ^ (uint32_t)(32 * j)) + a_row), a1 = *(lds_cf4p)(uintptr_t)((a_sw16 ^ (uint32_t)(32 * j + 16)) + a_row);
+        const floatx4_t b0 = *(lds_cf4p)(uintptr_t)((b_sw16 ^ (uint32_t)(32 * j)) + b_row), b1 = *(lds_cf4p)(uintptr_t)((b_sw16 ^ (uint32_t)(32 * j + 16)) + b_row);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = __fsub_rn(av[c], bv[c]);
+            acc[c] = __fadd_rn(acc[c], __fmul_rn(t, t));
+        }
+    }
+    const float s0 = __fadd_rn(acc[0], acc[4]);
+    const float s1 = __fadd_rn(acc[1], acc[5]);
+    const float s2 = __fadd_rn(acc[2], acc[6]);
+    const float s3 = __fadd_rn(acc[3], acc[7]);
+    float d = __fadd_rn(s0, s1);
+    d = __fadd_rn(d, s2);
+    return __fadd_rn(d, s3);
+}
 // The same with two neighbouring chains per packed instruction (v_pk_add_f32 / v_pk_mul_f32: every half is an IEEE single
 // operation, the result is bit-identical): the re-scan kernels, which have the chip to themselves, run on these.
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -882,17 +913,18 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                                                                const float *__restrict__ rho_t, const float *__restrict__ rho_q,
                                                                const PairDesc *__restrict__ pairs, int n_pairs,
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
-                                                               int32_t *__restrict__ flagged, int32_t *__restrict__ counters, int flag_cap,
-                                                               int32_t *__restrict__ pair_cnt, int32_t *__restrict__ pair_list,
-                                                               float *__restrict__ knn_d2, double ratio2m, int32_t *__restrict__ rejected,
-                                                               int32_t *__restrict__ zero_cnt, int zero_n, int32_t *__restrict__ zero_counters)
+                                                               int32_t *__restrict__ counters, int flag_cap,
+                                                               int32_t *__restrict__ surv_cnt, float4 *__restrict__ surv_list,
+                                                               double ratio2m, int32_t *__restrict__ rejected,
+                                                               int32_t *__restrict__ zero_a, int32_t *__restrict__ zero_b, int zero_n,
+                                                               int32_t *__restrict__ zero_counters)
 {
     // The per-pair list counters and the global counters exist twice: this launch fills one phase and zeroes the other for the NEXT
     // call (whose finish kernel needs them immutable while it runs) -- no memset launch, no zeroing pass in front of this one.
-    if (threadIdx.x == 0) for (int e = blockIdx.x; e < zero_n; e += gridDim.x) zero_cnt[e] = 0;
+    if (threadIdx.x == 0) for (int e = blockIdx.x; e < zero_n; e += gridDim.x) { zero_a[e] = 0; zero_b[e] = 0; }
     if (blockIdx.x == 0 && threadIdx.x < 16) zero_counters[threadIdx.x] = 0;
-    constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, GRP = ESFM_L2X1_GRP, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
-    constexpr int DIM = 64, QB = 128 * NS, HS = 8;               // HS: 16-B slots per row of the hi images
+    constexpr int TT = ESFM_L2X1_TT, NS = ESFM_L2X1_SETS, K = ESFM_L2X1_KEEP, RING = ESFM_L2X1_RING;
+    constexpr int QB = 128 * NS, HS = 8;                         // HS: 16-B slots per row of the hi images
     constexpr int TILE_BYTES = TT * HS * 16;
     static_assert(NS == 4, "operand list below is written for four query sets");
 
@@ -914,23 +946,11 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     }
     const PairDesc pd = pairs[pi];
     const int nq = pd.nq, nt = pd.nt;
-    const float *__restrict__ Q = desc + (size_t)pd.q_row0 * DIM;
-    const float *__restrict__ T = desc + (size_t)pd.t_row0 * DIM;
     const float *__restrict__ tn = norms + pd.t_row0;
     const float *__restrict__ tr = rho_t + pd.t_row0;
     const int qbase = (lb - pd.blk_off2) * QB + wave * 32 * NS;
 
     constexpr float kBig = 3.0e38f;
-    constexpr int NG = 16 / GRP;
-    constexpr uint32_t kCodeMask = (1u << ESFM_L2X1_CODE_BITS) - 1u;
-    // first train row of the group a key names (-1: empty slot): the code is step * NG + group, accumulator register r holds row
-    // (r & 3) + 8 (r >> 2) + 4 h of its step, a group is GRP consecutive REGISTERS: row u of the group is row0 + (u & 3) + 8 (u >> 2)
-    // (GRP = 4: four consecutive rows; GRP = 8: two runs of four, eight rows apart)
-    auto group_row0_of = [&](float key) {
-        const int code = (int)(__float_as_uint(key) & kCodeMask);
-        return key < 1.0e38f ? (code / NG) * 32 + (32 / NG) * (code % NG) + 4 * h : -1;
-    };
-
     const int ntiles = (nt + TT - 1) / TT;
     const u32x4 trsrc = raw_buffer_rsrc(hi_t + (size_t)pd.t_row0 * HS, (uint32_t)nt * (HS * 16));   // reads past it return 0
     const u32x4 nrsrc = raw_buffer_rsrc(tn, (uint32_t)nt * 4u);
@@ -993,67 +1013,44 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                        "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
                      : ESFM_L2X1_SEGMENT_CLOBBERS);
     }
-#ifdef ESFM_X1_TRACE
-    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // the block left this thread's keys in LDS: key i of set s at float (K s + i) * 256 + tid
+    // the block left this thread's keys in LDS: key i of set s at float (K s + i) * 256 + tid  (read unconditionally -- sixteen
+    // `ntiles > 0 ? read : kBig` had become sixteen branches -- and replaced when no tile ran)
     float keys[NS][K];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int i = 0; i < K; ++i) keys[s][i] = ntiles > 0 ? reinterpret_cast<const float *>(smem)[(K * s + i) * 256 + tid] : kBig;
+        for (int i = 0; i < K; ++i) {
+            const float v = reinterpret_cast<const float *>(smem)[(K * s + i) * 256 + tid];
+            keys[s][i] = ntiles > 0 ? v : kBig;
+        }
     }
     const float tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
     const float rmax = fmaxf(fmaxf(lds_red[4], lds_red[5]), fmaxf(lds_red[6], lds_red[7]));
 
-    // ---- exact re-rank of the kept groups' rows in the oracle's order, certificate (see l2_knn_bf16_kernel: the same scheme with
-    // 2 K groups per query, dealt out over K rounds) ----
-    // (Round 3, measured on one box against the per-set form, 0.906 - 0.916 ms per launch: the (query, group) items of a set compacted
-    // across the wave -- prefix sums, an LDS item table, a segmented shuffle merge, packed f32 arithmetic: 1.3 dense rounds per set
-    // instead of 3.4 and 83 M instead of 124 M VALU instructions -- 0.926 - 0.931 ms; the same with the rows through registers and
-    // ds_write_b128 instead of LDS-DMA, the next row's loads in flight during the arithmetic: 0.983 - 0.988 ms, 29 spilled
-    // registers.  The tail cost 0.3 ms whatever its instruction count: its row fetches are what it waits for.)
-    //
-    // Round 4: RATIO SCREEN in front of the re-rank.  The reference keeps a query only if d0 < ratio d1 (feature_matching.cpp:133);
-    // everything else is dropped one kernel later, and on the metric's workload that is > 90 % of the queries.  With k0 <= kb the two
-    // smallest of a query's 2 K group keys (two groups, hence two different train rows: the groups' minima) and E1 the pass's bound
-    // on |(|q|^2 + score) - D| (D = the canonical float d^2), kTrunc the key's truncation:
+    // ---- the RATIO SCREEN (round 4), all that is left of this kernel's tail.  The reference keeps a query only if d0 < ratio d1
+    // (feature_matching.cpp:133); everything else is dropped one kernel later, and on the metric's workload that is > 90 % of the
+    // queries.  With k0 <= kb the two smallest of a query's 2 K group keys (two groups, hence two different train rows: the groups'
+    // minima) and E1 the pass's bound on |(|q|^2 + score) - D| (D = the canonical float d^2), kTrunc the key's truncation:
     //     every train row has   D >= L0 = |q|^2 + k0 - kTrunc |k0| - E1        (k0 is the smallest key of all groups),
     //     two rows have         D <= U1 = |q|^2 + kb + kTrunc |kb| + E1,
     // so the nearest has D0 >= L0 and the second nearest D1 <= U1.  If L0 >= ratio^2 (1 + 2^-20) U1 then sqrtf(D0) >= ratio sqrtf(D1)
     // whatever the two roundings of sqrtf and the double product do (their relative error is < 2^-22 together): the query cannot
-    // pass the test.  It gets a marker (train index -2) and NO row is fetched for it.  The survivors of the wave's four sets are
-    // compacted into virtual sets of 32 (list in the dead norm area, keys gathered across lanes by ds_bpermute), so the re-rank's
-    // latency chain -- query rows, then up to K rounds of four row transfers -- runs once per 32 SURVIVORS instead of once per 32
-    // queries.  ratio2m = ratio^2 (1 + 2^-20); +inf switches the screen off (the knn2 entry points: every query exact).
-    lds_dma_wait();
-    __syncthreads();   // every wave is through its last tile and has its keys: the ring becomes four private 16-KiB landing zones
-    const u32x4 frsrc_t = raw_buffer_rsrc(T, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
-    const u32x4 frsrc_q = raw_buffer_rsrc(Q, (uint32_t)nq * 256u);
-    const uint32_t lds_land = lds_tile_addr + (uint32_t)wave_s * 16384u;
-    const float4 *land = reinterpret_cast<const float4 *>(smem) + (size_t)wave * 1024;
-    int swz[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) swz[i] = (4 * i + (lane >> 4)) * 256 + (((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16);
+    // pass the test.  It gets a marker (train index -2) and nothing more is done for it.  A SURVIVOR leaves one 48-byte entry -- its
+    // 2 K keys, its row, |q|^2 and E1 (as a float, rounded up) -- in the pair's slice of surv_list; l2_finish_kernel re-ranks the
+    // survivors' kept groups exactly.  (Until the middle of round 4 the re-rank ran here, per wave, beside the other workgroup's
+    // main loop whose VALU and LDS ports it shares: 0.06 - 0.075 of 0.605 ms, measured against a build without it; in a kernel of its
+    // own it has the chip to itself.)  ratio2m = ratio^2 (1 + 2^-20); +inf switches the screen off (the knn2 entry points).
+    static_assert(K == 4, "a survivor entry carries a lane's keys as one 16-byte piece");
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
     const double sqrt_tmax = sqrt((double)tmax);
-    auto e1_of = [&](double qn, double rq) { return l2x1_e1(qn, rq, sqrt_tmax, (double)tmax, (double)rmax); };
-    auto mark_rejected = [&](int qrow) {
-        const size_t o = 2 * ((size_t)pd.out_off + qrow);
-        knn_idx[o] = -2; knn_idx[o + 1] = -2;
-        knn_dist[o] = FLT_MAX; knn_dist[o + 1] = FLT_MAX;
-        if (rejected) {          // audit of the screen: what it dropped, on the global list
-            const int slot = atomicAdd(&counters[0], 1);
-            if (slot < flag_cap) { rejected[2 * slot] = pi; rejected[2 * slot + 1] = qrow; }
-        }
-    };
-
-    // ---- phase A: the ratio screen, every query of the wave's four sets; survivors -> wlist (entry = 32 set + j)
-    int *wlist = reinterpret_cast<int *>(lds_norm) + wave * (32 * NS);     // (RING * TT floats = 4 x 128 entries: the ring's norms are dead)
-    static_assert(RING * TT >= 4 * 32 * NS, "survivor lists live in the norm area");
+#ifdef ESFM_X1_NOTAIL
+    if (n_pairs >= 0) return;             // (timing experiments: the kernel without its tail)
+#endif
     int nsurv = 0;
+    int myslot[NS];
+    float qn_s[NS], e1_s[NS];
     {
-        float qn_s[NS], rq_s[NS];
+        float rq_s[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int qrow = qbase + 32 * s + j;
@@ -1068,210 +1065,69 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
             const float p0 = __shfl_xor(v0, 32), p1 = __shfl_xor(v1, 32);
             const float k0 = fminf(v0, p0), kb = fminf(fmaxf(v0, p0), fminf(v1, p1));     // the two smallest of the 2 K keys
             const double qn = (double)qn_s[s];
-            const double e1 = e1_of(qn, (double)rq_s[s]);
+            const double e1 = l2x1_e1(qn, (double)rq_s[s], sqrt_tmax, (double)tmax, (double)rmax);
             const double L0 = qn + (double)k0 - e1 - fabs((double)k0) * kTrunc;
             const double U1 = qn + (double)kb + e1 + fabs((double)kb) * kTrunc;
             const bool rej = qvalid && (L0 >= ratio2m * U1);                              // false on NaN / inf: re-rank
             const bool surv = qvalid && !rej;
             const uint32_t m = (uint32_t)__ballot(surv);                                  // lanes 0 .. 31 (both halves agree)
-            if (h == 0 && surv) wlist[nsurv + __popc(m & ((1u << j) - 1u))] = 32 * s + j;
-            if (h == 0 && rej) mark_rejected(qrow);
+            myslot[s] = surv ? nsurv + __popc(m & ((1u << j) - 1u)) : -1;
+            float ef = (float)e1;
+            if ((double)ef < e1) ef = nextafterf(ef, FLT_MAX);                            // rounded up (NaN stays NaN: every compare false)
+            e1_s[s] = ef;
+            if (h == 0 && rej) {
+                const size_t o = 2 * ((size_t)pd.out_off + qrow);
+                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(-2, -2);
+                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(FLT_MAX, FLT_MAX);
+                if (rejected) {          // audit of the screen: what it dropped, on the global list
+                    const int slot = atomicAdd(&counters[0], 1);
+                    if (slot < flag_cap) { rejected[2 * slot] = pi; rejected[2 * slot + 1] = qrow; }
+                }
+            }
             nsurv += __popc(m);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (nsurv > 0) {
+        int base = 0;
+        if (lane == 0) { base = atomicAdd(&surv_cnt[pi], nsurv); atomicAdd(&counters[2], nsurv); }
+        base = __builtin_amdgcn_readfirstlane(base);
+        float4 *ent = surv_list + 3 * ((size_t)pd.out_off + base);                       // (a pair's slice holds nq entries: it cannot overflow)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (myslot[s] >= 0) {
+                ent[3 * myslot[s] + h] = make_float4(keys[s][0], keys[s][1], keys[s][2], keys[s][3]);
+                if (h == 0) ent[3 * myslot[s] + 2] = make_float4(__int_as_float(qbase + 32 * s + j), qn_s[s], e1_s[s], 0.f);
+            }
+        }
+    }
+}
 
-    // ---- phase B: virtual sets of 32 survivors
-#pragma unroll 1
-    for (int v0 = 0; v0 < nsurv; v0 += 32) {
-        const bool qvalid = v0 + j < nsurv;
-        const int src = qvalid ? wlist[v0 + j] : 0;
-        const int qrow = qvalid ? qbase + src : nq;        // nq: past the descriptor, zeros
-        const int nv = min(32, nsurv - v0);                // wave-uniform: queries of this virtual set
-        float b0d = FLT_MAX, b1d = FLT_MAX, b0q = 0.f, b1q = 0.f; int b0i = -1, b1i = -1;
-        auto insert2 = [&](bool valid, float d, int i, float d2) {
-            const bool c1 = valid && (d < b1d || (d == b1d && i < b1i));     // (an empty slot holds FLT_MAX: +inf and NaN never enter, like the oracle's `d < d1`)
-            const bool c0 = valid && (d < b0d || (d == b0d && i < b0i));
-            b1d = c0 ? b0d : (c1 ? d : b1d); b1i = c0 ? b0i : (c1 ? i : b1i); b1q = c0 ? b0q : (c1 ? d2 : b1q);
-            b0d = c0 ? d : b0d; b0i = c0 ? i : b0i; b0q = c0 ? d2 : b0q;
-        };
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // the query rows -> landing slots 0 .. nv - 1: slot r takes the row lane r names (lanes j and j + 32 read the same slot)
+// ---------------------------------------------------------------------------------------------
+// coherent (agent-scope, relaxed) accesses to what one workgroup of a pair writes and another reads inside l2_finish_kernel's launch
+__device__ __forceinline__ void st_coh_i(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh_f(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ld_coh_i(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_coh_f(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// N x 16 contiguous bytes (dword aligned) with agent-scope coherence (`sc1`: the load is served past this XCD's L2), all in flight at once
+template <int N>
+__device__ __forceinline__ void ld_coh_block(const void *p, uint32_t *out /* 4 N */)
+{
+    static_assert(N == 4 || N == 8 || N == 2, "offsets below are immediates");
+    u32x4 v[N];
+    if constexpr (N == 8)
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off offset:48 sc1\n\tglobal_load_dwordx4 %4, %8, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+                     "global_load_dwordx4 %6, %8, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:112 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(p) : "memory");
+    else if constexpr (N == 4)
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(p) : "memory");
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (4 * i < nv) {
-                const int r = 4 * i + (lane >> 4);
-                const int qsrc = __builtin_amdgcn_ds_bpermute(r * 4, qrow) * 256 + (swz[i & 3] & 255);
-                lds_dma_b128(lds_land + (uint32_t)i * 1024u, qsrc, frsrc_q, 0);
-            }
-        }
-        const float qnorm_s = norms[pd.q_row0 + (qvalid ? qrow : 0)];
-        const float qrho_s = rho_q[pd.q_row0 + (qvalid ? qrow : 0)];
-        // this lane's keys: those of lane (src & 31) + 32 h for set src >> 5.  The 2 K groups of the query are ranked by key across
-        // the lane pair and dealt out alternately: this lane takes global rank 2 r + h in round r (rkey / rrow); everything else
-        // about the ranking is dead before the rows arrive.
-        float rkey[K]; int rrow[K]; float kb, tau;
-        {
-            float vk[K], pk[K]; int g0[K], pg[K];
-            const int srcl = ((src & 31) + 32 * h) * 4, sset = src >> 5;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                float kv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(keys[0][i])));
-#pragma unroll
-                for (int t = 1; t < NS; ++t) {
-                    const float o = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(keys[t][i])));
-                    kv = sset == t ? o : kv;
-                }
-                vk[i] = qvalid ? kv : kBig; g0[i] = group_row0_of(vk[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < K; ++i) { pk[i] = __shfl_xor(vk[i], 32); pg[i] = __shfl_xor(g0[i], 32); }
-#pragma unroll
-            for (int r = 0; r < K; ++r) { rkey[r] = kBig; rrow[r] = -1; }
-#pragma unroll
-            for (int i = 0; i < K; ++i) {        // ties between the halves: half 0 first (both lanes must agree on the order)
-                int rank_own = i, rank_par = i;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    rank_own += (pk[k] < vk[i] || (pk[k] == vk[i] && h == 1)) ? 1 : 0;
-                    rank_par += (vk[k] < pk[i] || (vk[k] == pk[i] && h == 0)) ? 1 : 0;
-                }
-#pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    if (rank_own == 2 * r + h) { rkey[r] = vk[i]; rrow[r] = g0[i]; }
-                    if (rank_par == 2 * r + h) { rkey[r] = pk[i]; rrow[r] = pg[i]; }
-                }
-            }
-            kb = fminf(fmaxf(vk[0], pk[0]), fminf(vk[1], pk[1]));     // second smallest of the 2 K keys
-            tau = fminf(vk[K - 1], pk[K - 1]);
-        }
-        const double qn = (double)qnorm_s;
-        const double e1 = e1_of(qn, (double)qrho_s);
-        const double U = (qn + (double)kb + e1 + fabs((double)kb) * kTrunc) * (1.0 + 1.0 / 1048576.0);
-        float4 qv[16];
-        lds_dma_wait();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) qv[c] = land[j * 16 + (c ^ (j & 15))];
-        // Between the rounds the ratio test may already be DECIDED (the match entry points only; the reference emits queryIdx, trainIdx
-        // and d0 of a survivor, never d1): with (m0, m1) the exact two best of the rows evaluated so far and lrest a lower bound on
-        // the D of every other row (the groups of the next ranks, everything outside the kept groups; rows of a group skipped as
-        // `cannot` are farther than m1 anyway),
-        //   verdict 1, cannot pass:  D1 <= m1 and D0 >= min(m0, lrest) >= ratio^2 (1 + 2^-20) m1;
-        //   verdict 2, passes:       lrest > m0 (1 + 2^-20), so m0 IS the nearest row, and m0 (1 + 2^-18) < ratio^2 (1 + 2^-20) min(m1, lrest),
-        //                            so sqrtf(m0) < ratio sqrtf(D1) whatever the second nearest turns out to be -- it is not looked for
-        //                            (second index -3: "not determined, the test passes").
-        // Either way the query's remaining groups are not fetched.
-        const bool screen = ratio2m < 1.0e300;
-        int verdict = 0;
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-            const float key = rkey[r]; const int row0 = rrow[r];
-            const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-            const bool need = row0 >= 0 && qvalid && !cannot && verdict == 0;
-            if (__ballot(need) == 0ull) break;
-            const int rsel = need ? row0 : nt;          // nt: past the descriptor, zeros
-            // 16 lanes fetch one 256-B row: DMA instruction i serves the lanes 4 i .. 4 i + 3 (their row of sub-round u).  The
-            // survivors sit in the lanes [0, nv) and [32, 32 + nv): instructions i and i + 8 are issued while 4 i < nv
-            int rowsrc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) rowsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (swz[i & 3] & 255);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents are in registers
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (4 * i < nv) {
-                    lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i], frsrc_t, 0);
-                    lds_dma_b128(lds_land + (uint32_t)(i + 8) * 1024u, rowsrc[i + 8], frsrc_t, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                float4 ra_[16];
-                lds_dma_wait();
-#pragma unroll
-                for (int c = 0; c < 16; ++c) ra_[c] = land[lane * 16 + (c ^ (lane & 15))];
-                if (u + 1 < GRP) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (4 * i < nv) {
-                            const int nxt = ((u + 1) & 3) + 8 * ((u + 1) >> 2);       // row u + 1 of the group (u is unrolled: a constant)
-                            lds_dma_b128(lds_land + (uint32_t)i * 1024u, rowsrc[i] + nxt * 256, frsrc_t, 0);
-                            lds_dma_b128(lds_land + (uint32_t)(i + 8) * 1024u, rowsrc[i + 8] + nxt * 256, frsrc_t, 0);
-                        }
-                    }
-                }
-                const float da = l2sqr64_canonical_regs(qv, ra_);
-                const int ta_ = row0 + (u & 3) + 8 * (u >> 2);
-                insert2(need && ta_ < nt, sqrt_rn_f32(da), ta_, da);
-            }
-            if (screen && r + 1 < K) {
-                // the query's exact two best so far, both lane halves merged (copies: the halves' own lists stay as they are)
-                float m0d = b0d, m1d = b1d, m0q = b0q, m1q = b1q; int m0i = b0i, m1i = b1i;
-                {
-                    const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
-                    const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
-                    auto minsert = [&](bool valid, float d, int i, float d2) {
-                        const bool c1 = valid && (d < m1d || (d == m1d && i < m1i));
-                        const bool c0 = valid && (d < m0d || (d == m0d && i < m0i));
-                        m1d = c0 ? m0d : (c1 ? d : m1d); m1i = c0 ? m0i : (c1 ? i : m1i); m1q = c0 ? m0q : (c1 ? d2 : m1q);
-                        m0d = c0 ? d : m0d; m0i = c0 ? i : m0i; m0q = c0 ? d2 : m0q;
-                    };
-                    minsert(pi0 >= 0, pd0, pi0, pq0);
-                    minsert(pi1 >= 0, pd1, pi1, pq1);
-                }
-                const float nxt = __shfl_xor(rkey[r + 1], 32);
-                const float nk = fminf(h == 0 ? rkey[r + 1] : nxt, tau);                 // the smallest key of anything not evaluated yet
-                const double lrest = qn + (double)nk - e1 - fabs((double)nk) * kTrunc;
-                const double r1 = ratio2m * (double)m1q;
-                const bool fail = m1i >= 0 && lrest >= r1 && (double)m0q >= r1;                            // (every compare false on NaN)
-                const double dlo = lrest < (double)m1q ? lrest : (double)m1q;
-                const bool pass = m1i >= 0 && lrest > (double)m0q * (1.0 + 1.0 / 1048576.0) && (double)m0q * (1.0 + 1.0 / 262144.0) < ratio2m * dlo;
-                if (verdict == 0 && qvalid) verdict = fail ? 1 : (pass ? 2 : 0);
-            }
-        }
-        {
-            const float pd0 = __shfl_xor(b0d, 32), pq0 = __shfl_xor(b0q, 32), pd1 = __shfl_xor(b1d, 32), pq1 = __shfl_xor(b1q, 32);
-            const int pi0 = __shfl_xor(b0i, 32), pi1 = __shfl_xor(b1i, 32);
-            insert2(pi0 >= 0, pd0, pi0, pq0);
-            insert2(pi1 >= 0, pd1, pi1, pq1);
-        }
-        if (qvalid && h == 0) {
-            const size_t o = 2 * ((size_t)pd.out_off + qrow);
-            bool certified = (tau >= 1.0e38f);       // the empty-slot sentinel: every train row is a candidate (a NaN tau compares false)
-            double lmiss = 0.0;
-            if (!certified && b1i >= 0) {
-                const double eps = e1 + fabs((double)tau) * kTrunc;
-                lmiss = qn + (double)tau - eps;                                                    // every row outside the kept groups has D >= lmiss
-                certified = lmiss > (double)b1q * (1.0 + 1.0 / 2097152.0);     // false on NaN (e1 of non-finite rows)
-            }
-            // Not certified, but the ratio test is already decided: the true second-nearest has D1 <= b1q, the true nearest
-            // D0 >= min(b0q, lmiss); if that is >= ratio^2 (1 + 2^-20) b1q the query cannot pass whatever the other rows are.
-            const bool lost = verdict == 1 || (!certified && b1i >= 0 && lmiss >= ratio2m * (double)b1q && (double)b0q >= ratio2m * (double)b1q);   // false on NaN
-            if (lost) mark_rejected(qrow);
-            else {
-                knn_idx[o] = b0i; knn_idx[o + 1] = verdict == 2 ? -3 : b1i;
-                knn_dist[o] = b0d; knn_dist[o + 1] = b1d;
-            }
-            if (!certified && !lost && verdict == 0) {
-                atomicAdd(&counters[1], 1);
-                knn_d2[pd.out_off + qrow] = b1i >= 0 ? b1q : FLT_MAX;     // the refine pass's threshold: the exact second best so far
-                if (flagged) {           // audit of THIS pass's certificate: its failures on the global list
-                    const int slot = atomicAdd(&counters[0], 1);
-                    if (slot < flag_cap) { flagged[2 * slot] = pi; flagged[2 * slot + 1] = qrow; }
-                }
-                pair_list[pd.out_off + atomicAdd(&pair_cnt[pi], 1)] = qrow;
-            }
-        }
-    }
-#ifdef ESFM_X1_TRACE
-    if (lane == 0) {
-        const unsigned long long tr3 = __builtin_amdgcn_s_memrealtime();
-        atomicAdd(&counters[8], (int)(tr1 - tr0)); atomicAdd(&counters[9], (int)(tr2 - tr1)); atomicAdd(&counters[10], (int)(tr3 - tr2));
-        atomicAdd(&counters[11], 1); atomicAdd(&counters[12], (nsurv + 31) / 32); atomicAdd(&counters[13], nsurv);
-    }
-#endif
+    for (int i = 0; i < N; ++i) { out[4 * i] = v[i][0]; out[4 * i + 1] = v[i][1]; out[4 * i + 2] = v[i][2]; out[4 * i + 3] = v[i][3]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1282,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 // threads' counts places them.  A train index < 0 (no neighbour; -2: dropped by the one-product pass's ratio screen) never passes; a
 // SECOND index of -3 says that pass has proved d0 < ratio d1 without looking for the second neighbour.
 // (Round 1: 256 threads, one query each, 16 sweeps of three barriers for a 4096-row set: 14 us per launch.)
-template <int THREADS, int kRatioPer>
+template <int THREADS, int kRatioPer, bool COHERENT = false>
 __device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int32_t *__restrict__ knn_idx, const float *__restrict__ knn_dist,
                                                    double ratio, int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
                                                    float *__restrict__ distance, int32_t *__restrict__ n_out_p, int *s_wave /* [THREADS / 64] */,
@@ -1295,18 +1151,28 @@ __device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int
         const int qa = q0 + tid * kRatioPer;
         int ti[kRatioPer]; float d0[kRatioPer]; bool pass[kRatioPer];
         int cnt = 0;
+        // COHERENT: the records may have been written by another workgroup of this launch (l2_finish_kernel, through write-through
+        // stores): they are read past this XCD's L2 -- `sc1` loads -- sixteen bytes at a time (one asm statement per array: as
+        // 4-byte atomic loads the same reads took 80 us per launch)
+        int iv[2 * kRatioPer]; float dv[2 * kRatioPer];
+        if (COHERENT && (kRatioPer % 2) == 0 && qa + kRatioPer <= pd.nq) {
+            ld_coh_block<kRatioPer / 2>(knn_idx + 2 * ((size_t)pd.out_off + qa), reinterpret_cast<uint32_t *>(iv));
+            ld_coh_block<kRatioPer / 2>(knn_dist + 2 * ((size_t)pd.out_off + qa), reinterpret_cast<uint32_t *>(dv));
+        } else {
+#pragma unroll
+            for (int u = 0; u < kRatioPer; ++u) {
+                const size_t o = 2 * ((size_t)pd.out_off + min(qa + u, max(pd.nq - 1, 0)));
+                iv[2 * u] = COHERENT ? ld_coh_i(knn_idx + o) : knn_idx[o]; iv[2 * u + 1] = COHERENT ? ld_coh_i(knn_idx + o + 1) : knn_idx[o + 1];
+                dv[2 * u] = COHERENT ? ld_coh_f(knn_dist + o) : knn_dist[o]; dv[2 * u + 1] = COHERENT ? ld_coh_f(knn_dist + o + 1) : knn_dist[o + 1];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < kRatioPer; ++u) {
             const int q = qa + u;
-            pass[u] = false; ti[u] = -1; d0[u] = 0.f;
-            if (q < pd.nq) {
-                const size_t o = 2 * ((size_t)pd.out_off + q);
-                const int i0 = knn_idx[o], i1 = knn_idx[o + 1];
-                d0[u] = knn_dist[o];
-                const float d1 = knn_dist[o + 1];
-                ti[u] = i0;
-                pass[u] = (i0 >= 0) && (i1 == -3 || (i1 >= 0 && (double)d0[u] < ratio * (double)d1));     // -3: the one-product pass proved the test
-            }
+            const int i0 = iv[2 * u], i1 = iv[2 * u + 1];
+            const float d1 = dv[2 * u + 1];
+            d0[u] = dv[2 * u]; ti[u] = i0;
+            pass[u] = q < pd.nq && (i0 >= 0) && (i1 == -3 || (i1 >= 0 && (double)d0[u] < ratio * (double)d1));     // -3: the one-product pass proved the test
             cnt += pass[u] ? 1 : 0;
         }
         // exclusive scan of cnt over the workgroup: inside the wave by shuffles, across waves through LDS
@@ -1333,24 +1199,24 @@ __device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Everything behind the one-product pass in ONE launch (round 4; round 3 had three: l2_refine_kernel, l2_rescan64_pairs_kernel,
-// ratio_compact_kernel, and every launch boundary costs 5 - 10 us on this part):
-//   (1) the second pass over what l2_knn_bf16x1_kernel could not certify -- a THRESHOLD FILTER instead of a second top-k.  For such
-//       a query the first pass has left the exact two best of its candidates; U = the exact second-best d^2.  Every train row that
-//       can still change the answer has d^2 <= U, hence a one-product score s <= U - |q|^2 + E1 (E1: l2x1_e1).  So: the same
-//       bf16(-2 q).bf16(t) product on the matrix cores over the whole train set, a compare of every score with the query's
-//       threshold, the few rows that pass (0.1 - 1.2 per query on the data simulated in scratch/sim_bf16x1_cert.py) evaluated
-//       exactly in the oracle's order and merged with the two known neighbours;
-//   (2) the exact brute force of a chunk whose hit list overflows (adversarial inputs: every row inside the error);
-//   (3) the ratio test and the ordered compaction of the pair's survivors (ratio_compact_pair).
-// Work split: S workgroups per pair (blockIdx = (S - 1 - slice) * n_pairs + pair).  A pair without uncertified queries -- nearly all of them
-// once the ratio screen has run -- is finished by its slice-0 workgroup alone: (3), nothing else.  Otherwise workgroup (p, s) sweeps
-// the s-th slice of the train set for EVERY chunk of 32 queries of the pair's list (eight waves split the slice: with S = 8 a wave
-// sees 2 steps of 32 rows of a 4096-row set -- the pass is a latency chain, and this is what makes it short), appends its hits to
-// the chunk's region of a global pool, and arrives at the pair's counter; the LAST workgroup to arrive evaluates the hits exactly,
-// merges, brute-forces the overflowed chunks, and runs (3).  Nobody waits for anybody: no assumption about which workgroups are
-// resident.  in_cnt is immutable during the launch (the one-product pass of the NEXT call zeroes it: two phases), so every
-// workgroup derives the same region numbers from a prefix sum over the pairs' chunk counts.
+// Everything behind the one-product pass's main loop and ratio screen in ONE launch (round 4; round 3 had three: l2_refine_kernel,
+// l2_rescan64_pairs_kernel, ratio_compact_kernel, and every launch boundary costs 5 - 10 us on this part):
+//   (1) the exact RE-RANK of the screen's survivors (surv_cnt / surv_list: one 48-byte entry per survivor): the rows of the kept
+//       groups in the oracle's order, the certificate, and the ratio verdicts that make most second neighbours unnecessary
+//       (finish_rerank_vset below).  Uncertified and undecided queries go on the pair's list (unc_cnt / unc_list, knn_d2);
+//   (2) the second pass over that list -- a THRESHOLD FILTER instead of a second top-k.  For such a query (1) has left the exact
+//       two best of its candidates; U = an upper bound of the second-best d^2.  Every train row that can still change the answer
+//       has d^2 <= U, hence a one-product score s <= U - |q|^2 + E1 (E1: l2x1_e1).  So: the same bf16(-2 q).bf16(t) product on the
+//       matrix cores over the whole train set, a compare of every score with the query's threshold, the few rows that pass (0.1 -
+//       1.2 per query on the data simulated in scratch/sim_bf16x1_cert.py) evaluated exactly in the oracle's order and merged;
+//   (3) the exact brute force of a chunk whose hit list overflows (adversarial inputs: every row inside the error);
+//   (4) the ratio test and the ordered compaction of the pair's survivors (ratio_compact_pair).
+// Work split: S workgroups per pair (blockIdx = slice * n_pairs + pair).  Stage (1) is shared: the pair's virtual sets of seven
+// survivors are dealt out over the S x 4 waves.  Then every workgroup arrives at the pair's counter and the LAST one runs (2) - (4)
+// alone (after the screen and the verdicts (2) and (3) see a handful of queries per launch).  Nobody waits for anybody: no
+// assumption about which workgroups are resident.  What stage (1) writes for the last workgroup -- results, list entries -- travels
+// through relaxed agent-scope atomics (write-through stores, L2-bypassing loads), not through agent-scope fences: on this part a
+// release is a write-back of the XCD's whole L2, an acquire an invalidation, and hundreds of workgroups would queue for them.
 #ifndef ESFM_FIN_THREADS
 #define ESFM_FIN_THREADS 256
 #endif
@@ -1404,53 +1270,313 @@ __device__ __forceinline__ void finish_bruteforce_chunk(const float *__restrict_
         for (int w = 0; w < kFinWaves; ++w) { insert2(x0, x1, s_keys[w][tid][0]); insert2(x0, x1, s_keys[w][tid][1]); }
         const size_t o = 2 * ((size_t)pd.out_off + qrows[tid]);
         const int i0 = (int)(uint32_t)x0, i1 = (int)(uint32_t)x1;
-        knn_idx[o] = i0; knn_idx[o + 1] = i1;
-        knn_dist[o] = i0 >= 0 ? __uint_as_float((uint32_t)(x0 >> 32)) : FLT_MAX;
-        knn_dist[o + 1] = i1 >= 0 ? __uint_as_float((uint32_t)(x1 >> 32)) : FLT_MAX;
+        st_coh_i(knn_idx + o, i0); st_coh_i(knn_idx + o + 1, i1);           // (read back by the ratio stage past the L2)
+        st_coh_f(knn_dist + o, i0 >= 0 ? __uint_as_float((uint32_t)(x0 >> 32)) : FLT_MAX);
+        st_coh_f(knn_dist + o + 1, i1 >= 0 ? __uint_as_float((uint32_t)(x1 >> 32)) : FLT_MAX);
     }
     __syncthreads();
 }
 
+// Stage (1) for ONE virtual set of up to QV = 7 survivors, by one wave, DENSE: eight lanes per query.  In round r lane l (query slot
+// l >> 3, i = l & 7) evaluates row i of the query's group of rank r -- a kept group is eight rows: two runs of four, eight apart -- so
+// a round is ONE batch of row transfers into the wave's 16-KiB landing zone (56 candidate rows, 16 lanes per 256-B row: every cache
+// line touched once; round 0 also brings the seven query rows, which stay in the slots 56 .. 62) and every lane computes one
+// distance, straight from LDS.
+//  * a candidate is ONE 64-bit key, (bits of the distance) << 32 | train row: key order is the oracle's (distance, index) order; the
+//    two best of a query's eight are reduced over its eight lanes by min / max exchanges and merged into (m0, m1), which all eight
+//    lanes carry.  The bounds need d^2, not the canonical float D the distance is the root of: sqrtf is correctly rounded, so D lies
+//    in d^2 (1 -+ 2^-22), and each use takes the side that keeps it conservative;
+//  * round 0 needs the two smallest of the 2 K keys only (its group, the verdict's bound): the heads of the two sorted key lists; the
+//    ranking by counting is made in the later rounds -- when a query is still undecided after its best group.
+// Between the rounds the ratio test may already be DECIDED (the match entry points only; the reference emits queryIdx, trainIdx and d0
+// of a survivor, never d1): with (m0, m1) the exact two best of the rows evaluated so far and lrest a lower bound on the D of every
+// other row (the groups of the next ranks, everything outside the kept groups; rows of a group skipped as `cannot` are farther than
+// the two rows that bound U anyway),
+//   verdict 1, cannot pass:  D1 <= m1 and D0 >= min(m0, lrest) >= ratio^2 (1 + 2^-20) m1;
+//   verdict 2, passes:       lrest > m0 (1 + 2^-20), so m0 IS the nearest row, and m0 (1 + 2^-18) < ratio^2 (1 + 2^-20) min(m1, lrest),
+//                            so sqrtf(m0) < ratio sqrtf(D1) whatever the second nearest turns out to be -- it is not looked for
+//                            (second index -3: "not determined, the test passes").
+// On the metric's workload nearly every survivor is a true match whose best group alone decides it: one transfer round trip.  A
+// query that ends neither certified nor decided goes on the pair's list for the threshold filter, with an upper bound of its
+// second-best d^2 as the filter's threshold.
+struct FinRerankArgs {
+    const float4 *ent;                 // the pair's survivor entries
+    int nsv;                           // ... their number
+    PairDesc pd; int p;
+    u32x4 frsrc_t, frsrc_q;            // buffer descriptors of the train / query set's float rows
+    uint32_t lds_land;                 // LDS byte address of this wave's landing zone
+    double ratio2m;
+    int32_t *knn_idx; float *knn_dist; float *knn_d2;
+    int32_t *unc_cnt, *unc_list;       // the pair's list of queries for the threshold filter
+    int32_t *counters, *audit_unc, *audit_rej; int flag_cap;
+};
+constexpr int kFinQV = 7;
+__device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v, float4 ka, float4 kb4, float4 mi)
+{
+    typedef unsigned long long u64;
+    constexpr int K = ESFM_L2X1_KEEP, GRP = ESFM_L2X1_GRP, NG = 16 / GRP, QV = kFinQV;
+    static_assert(K == 4 && GRP == 8, "an entry carries 2 x 4 keys; eight lanes evaluate the eight rows of a group");
+    constexpr u64 kNone = ~0ull;
+    constexpr float kBig = 3.0e38f;
+    constexpr uint32_t kCodeMask = (1u << ESFM_L2X1_CODE_BITS) - 1u;
+    constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));
+    const int lane = threadIdx.x & 63;
+    const int qs = lane >> 3 < QV ? lane >> 3 : QV - 1, ri = (lane & 3) + 8 * ((lane >> 2) & 1);     // row of the group this lane evaluates
+    const int nt = A.pd.nt, nq = A.pd.nq;
+    const double ratio2m = A.ratio2m;
+    const bool screen = ratio2m < 1.0e300;
+    const uint32_t lds_land = A.lds_land;
+    auto row0_of = [&](float key, int hh) {
+        const int code = (int)(__float_as_uint(key) & kCodeMask);
+        return key < 1.0e38f ? (code / NG) * 32 + (32 / NG) * (code % NG) + 4 * hh : -1;
+    };
+    auto kmin = [](u64 x, u64 y) { return x < y ? x : y; };
+    auto kmax = [](u64 x, u64 y) { return x < y ? y : x; };
+    const int nv = min(QV, A.nsv - v * QV);                      // wave-uniform: queries of this virtual set
+    const bool qvalid = (lane >> 3) < nv;
+    const int qrow = qvalid ? __float_as_int(mi.x) : nq;         // nq: past the descriptor, zeros
+    const double qn = (double)mi.y, e1 = (double)mi.z;
+    const float a_[4] = {qvalid ? ka.x : kBig, qvalid ? ka.y : kBig, qvalid ? ka.z : kBig, qvalid ? ka.w : kBig};
+    const float b_[4] = {qvalid ? kb4.x : kBig, qvalid ? kb4.y : kBig, qvalid ? kb4.z : kBig, qvalid ? kb4.w : kBig};
+    const float tau = fminf(a_[3], b_[3]);
+    // the two smallest keys (ties: half 0 first -- any fixed rule will do, the eight lanes only have to agree)
+    const bool c0 = a_[0] <= b_[0];
+    const float r0k = c0 ? a_[0] : b_[0];
+    const float r1k = fminf(c0 ? a_[1] : a_[0], c0 ? b_[0] : b_[1]);
+    const double U = (qn + (double)r1k + e1 + fabs((double)r1k) * kTrunc) * (1.0 + 1.0 / 1048576.0);
+    u64 m0 = kNone, m1 = kNone;                                  // the query's exact two best so far (the same in its eight lanes)
+    int verdict = 0;
+    int swzq[4];                                                 // byte offset of this lane's 16-B piece inside a fetched row: transfer i, (i & 3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) swzq[i] = ((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16;
+    // one round: the group (key, row0) of the query, nkey = the smallest key of the groups the later rounds would fetch.
+    // Returns false when no lane of the wave needed a row (the rounds are over).
+    auto do_round = [&](auto first, bool last, float key, int row0, float nkey) __attribute__((always_inline)) -> bool {
+        const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
+        const bool need = row0 >= 0 && qvalid && !cannot && verdict == 0;
+        if (__ballot(need) == 0ull) return false;
+        const int trow = row0 + ri;
+        const int rsel = need ? trow : nt;                       // nt: past the descriptor, zeros
+        // 16 lanes fetch one 256-B row: transfer i lands the rows of the lanes 4 i .. 4 i + 3 in the slots of the same numbers
+        // (i < 2 nv: the candidate rows; round 0: transfers 14 and 15 land the query rows of the entries 0 .. 6 in the slots 56 .. 62).
+        // All the exchanges first, ONE wait, then the transfers.
+        int rs[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) rs[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + swzq[i & 3];
+        int qsrc[2] = {0, 0};
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) qsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 32, qrow) * 256 + swzq[(14 + i) & 3];   // lane 8 e holds entry e's row
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents have been read, the exchanges done
+#pragma unroll
+        for (int i = 0; i < 14; ++i)
+            if (i < 2 * nv) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rs[i], A.frsrc_t, 0);
+        if (first) {
+            lds_dma_b128(lds_land + 14u * 1024u, qsrc[0], A.frsrc_q, 0);
+            if (nv > 4) lds_dma_b128(lds_land + 15u * 1024u, qsrc[1], A.frsrc_q, 0);
+        }
+#ifdef ESFM_FIN_TRACE
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        lds_dma_wait();
+#ifdef ESFM_FIN_TRACE
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) atomicAdd(&A.counters[12], (int)(rt1 - rt0));
+#endif
+        // the rows stay in LDS and are read piece by piece (the query rows' slots are not touched by the later rounds)
+        const float da = l2sqr64_canonical_lds(lds_land + (uint32_t)(56 + qs) * 256u, (uint32_t)((56 + qs) & 15) * 16u, lds_land + (uint32_t)lane * 256u, (uint32_t)(lane & 15) * 16u);
+        // this lane's candidate as a key (+inf, NaN, rows past the set: none); then the two best of the query's eight lanes
+        const float dda = sqrt_rn_f32(da);
+        u64 c0k = (need && trow < nt && dda < FLT_MAX) ? (((u64)__float_as_uint(dda) << 32) | (u64)(uint32_t)trow) : kNone, c1k = kNone;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const u64 p0 = __shfl_xor(c0k, o), p1 = __shfl_xor(c1k, o);
+            const u64 lo = kmin(c0k, p0), hi = kmax(c0k, p0);
+            c1k = kmin(hi, kmin(c1k, p1));
+            c0k = lo;
+        }
+        {
+            const u64 lo = kmin(m0, c0k), hi = kmax(m0, c0k);
+            m1 = kmin(hi, kmin(m1, c1k));
+            m0 = lo;
+        }
+#ifdef ESFM_FIN_TRACE
+        if (lane == 0) { atomicAdd(&A.counters[11], 1); atomicAdd(&A.counters[13], (int)(__builtin_amdgcn_s_memrealtime() - rt1)); }           // rounds, ticks after the wait
+#endif
+        if (screen && !last) {
+            const float nk = fminf(nkey, tau);                   // the smallest key of anything not evaluated yet
+            const double lrest = qn + (double)nk - e1 - fabs((double)nk) * kTrunc;
+            const double d0 = (double)__uint_as_float((uint32_t)(m0 >> 32)), d1 = (double)__uint_as_float((uint32_t)(m1 >> 32));
+            const double m0lo = d0 * d0 * (1.0 - 1.0 / 4194304.0), m0hi = d0 * d0 * (1.0 + 1.0 / 4194304.0);
+            const double m1lo = d1 * d1 * (1.0 - 1.0 / 4194304.0), m1hi = d1 * d1 * (1.0 + 1.0 / 4194304.0);
+            const bool two = m1 != kNone;
+            const double r1 = ratio2m * m1hi;
+            const bool fail = two && lrest >= r1 && m0lo >= r1;                                                    // (every compare false on NaN)
+            const double dlo = lrest < m1lo ? lrest : m1lo;
+            const bool pass = two && lrest > m0hi * (1.0 + 1.0 / 1048576.0) && m0hi * (1.0 + 1.0 / 262144.0) < ratio2m * dlo;
+            if (verdict == 0 && qvalid) verdict = fail ? 1 : (pass ? 2 : 0);
+        }
+        return true;
+    };
+    bool more = do_round(std::true_type{}, false, r0k, row0_of(r0k, c0 ? 0 : 1), r1k);
+    // the later rounds (a query still undecided after its best group): the ranking of the 2 K keys, by counting
+#pragma unroll 1
+    for (int r = 1; r < 2 * K && more; ++r) {
+        float key = kBig, nkey = kBig; int row0 = -1;
+#pragma unroll
+        for (int x = 0; x < 2 * K; ++x) {
+            const float kx = x < K ? a_[x & 3] : b_[x & 3];
+            int rank = 0;
+#pragma unroll
+            for (int y = 0; y < 2 * K; ++y) {
+                const float ky = y < K ? a_[y & 3] : b_[y & 3];
+                if (y != x) rank += (ky < kx || (ky == kx && y < x)) ? 1 : 0;
+            }
+            if (rank == r) { key = kx; row0 = row0_of(kx, x < K ? 0 : 1); }
+            if (rank == r + 1) nkey = kx;
+        }
+        more = do_round(std::false_type{}, r + 1 == 2 * K, key, row0, nkey);
+    }
+    if (qvalid && (lane & 7) == 0) {
+        const size_t o = 2 * ((size_t)A.pd.out_off + qrow);
+        const bool one = m0 != kNone, two = m1 != kNone;
+        const double d0 = (double)__uint_as_float((uint32_t)(m0 >> 32)), d1 = (double)__uint_as_float((uint32_t)(m1 >> 32));
+        const double m0lo = d0 * d0 * (1.0 - 1.0 / 4194304.0), m1hi = d1 * d1 * (1.0 + 1.0 / 4194304.0);
+        bool certified = (tau >= 1.0e38f);       // the empty-slot sentinel: every train row is a candidate (a NaN tau compares false)
+        double lmiss = 0.0;
+        if (!certified && two) {
+            const double eps = e1 + fabs((double)tau) * kTrunc;
+            lmiss = qn + (double)tau - eps;                                                    // every row outside the kept groups has D >= lmiss
+            certified = lmiss > m1hi * (1.0 + 1.0 / 2097152.0);     // false on NaN (e1 of non-finite rows)
+        }
+        // Not certified, but the ratio test is already decided: the true second-nearest has D1 <= m1, the true nearest
+        // D0 >= min(m0, lmiss); if that is >= ratio^2 (1 + 2^-20) m1 the query cannot pass whatever the other rows are.
+        const bool lost = verdict == 1 || (verdict == 0 && !certified && two && lmiss >= ratio2m * m1hi && m0lo >= ratio2m * m1hi);   // false on NaN
+        if (lost) {
+            st_coh_i(A.knn_idx + o, -2); st_coh_i(A.knn_idx + o + 1, -2);
+            st_coh_f(A.knn_dist + o, FLT_MAX); st_coh_f(A.knn_dist + o + 1, FLT_MAX);
+            if (A.audit_rej) {       // audit of the screen: what it dropped, on the global list
+                const int slot = atomicAdd(&A.counters[0], 1);
+                if (slot < A.flag_cap) { A.audit_rej[2 * slot] = A.p; A.audit_rej[2 * slot + 1] = qrow; }
+            }
+        } else {
+            st_coh_i(A.knn_idx + o, one ? (int)(uint32_t)m0 : -1); st_coh_i(A.knn_idx + o + 1, verdict == 2 ? -3 : (two ? (int)(uint32_t)m1 : -1));
+            st_coh_f(A.knn_dist + o, one ? __uint_as_float((uint32_t)(m0 >> 32)) : FLT_MAX);
+            st_coh_f(A.knn_dist + o + 1, two ? __uint_as_float((uint32_t)(m1 >> 32)) : FLT_MAX);
+        }
+        if (!certified && !lost && verdict == 0) {
+            atomicAdd(&A.counters[1], 1);
+            float u2 = two ? (float)m1hi : FLT_MAX;              // the threshold filter's bound: an upper bound of the exact second best so far
+            if (two && (double)u2 < m1hi) u2 = nextafterf(u2, FLT_MAX);
+            st_coh_f(A.knn_d2 + A.pd.out_off + qrow, u2);
+            if (A.audit_unc) {       // audit of THIS pass's certificate: its failures on the global list
+                const int slot = atomicAdd(&A.counters[0], 1);
+                if (slot < A.flag_cap) { A.audit_unc[2 * slot] = A.p; A.audit_unc[2 * slot + 1] = qrow; }
+            }
+            const int k = __hip_atomic_fetch_add(&A.unc_cnt[A.p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st_coh_i(A.unc_list + A.pd.out_off + k, qrow);
+        }
+    }
+}
+
+constexpr size_t kFinLdsBytes = (size_t)kFinWaves * 16384;      // four landing zones; the later stages' buffers alias them
+
 __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
                                                                 const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
                                                                 const float *__restrict__ rho_t, const float *__restrict__ rho_q,
-                                                                const PairDesc *__restrict__ pairs, int n_pairs, int S,
-                                                                const int32_t *__restrict__ in_cnt, const int32_t *__restrict__ in_list,
-                                                                const float *__restrict__ knn_d2, int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
+                                                                const PairDesc *__restrict__ pairs, const int32_t *__restrict__ pair_order, int n_pairs, int S,
+                                                                const int32_t *__restrict__ surv_cnt, const float4 *__restrict__ surv_list,
+                                                                int32_t *__restrict__ unc_cnt, int32_t *__restrict__ unc_list, float *__restrict__ knn_d2,
+                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                                 int32_t *__restrict__ counters, int32_t *__restrict__ flagged, int flag_cap,
-                                                                int32_t *__restrict__ pool, int32_t *__restrict__ region_cnt, int n_regions,
-                                                                int32_t *__restrict__ done, int skip_bruteforce, int do_ratio, double ratio,
+                                                                int32_t *__restrict__ done, int audit, int do_ratio, double ratio, double ratio2m,
                                                                 int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
                                                                 float *__restrict__ distance, int32_t *__restrict__ n_out)
 {
     constexpr int CAP = kFinCap, HS = 8, NW = kFinWaves;
     constexpr float kBig = 3.0e38f;
-    __shared__ int s_nhit, s_kbase, s_last;
-    __shared__ int s_h[CAP];                      // hits of the chunk: (query slot in the chunk) << 21 | train row
-    __shared__ float s_hd[CAP], s_hd2[CAP];
+    static_assert(kFinThreads == 256, "four waves: four landing zones");
+    extern __shared__ __attribute__((aligned(16))) char fin_smem[];         // kFinLdsBytes
+    // stages (2) - (4) reuse the landing zones
+    int *s_h = reinterpret_cast<int *>(fin_smem);                             // [CAP] hits of the chunk: (query slot in the chunk) << 21 | train row
+    float *s_hd = reinterpret_cast<float *>(fin_smem + 4096), *s_hd2 = reinterpret_cast<float *>(fin_smem + 8192);
+    float4 (*s_q)[16] = reinterpret_cast<float4 (*)[16]>(fin_smem + 12288);  // [32][16]
+    unsigned long long (*s_keys)[32][2] = reinterpret_cast<unsigned long long (*)[32][2]>(fin_smem + 12288 + 8192);   // [NW][32][2]
+    __shared__ int s_nhit, s_last;
     __shared__ float s_red[2 * NW];
-    __shared__ int s_part[NW];
     __shared__ int s_qrows[32];
-    __shared__ __attribute__((aligned(16))) float4 s_q[32][16];
-    __shared__ unsigned long long s_keys[NW][32][2];
     __shared__ int s_wave[NW], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    // slice 0 -- the workgroup that finishes a pair without uncertified queries on its own -- comes LAST in dispatch order: the others
-    // leave at once (or sweep their slice), and none of them waits for a CU behind three hundred ratio stages
-    const int sl = S - 1 - (int)(blockIdx.x / n_pairs), p = blockIdx.x % n_pairs;
+    // Blocks are dispatched round-robin over the XCDs; xcd_remap gives every XCD a contiguous range of logical blocks, and the logical
+    // order is pair-major over the pairs SORTED BY TRAIN SET: the S workgroups of a pair and the pairs of one train set run on one
+    // XCD, whose L2 (4 MiB) then holds the one or two train sets their row fetches go to -- the re-rank is bound by those fetches
+    // (51 k survivors x 9 rows x 256 B per step on the metric's workload).
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int sl = lb % S, p = pair_order[lb / S];
     const PairDesc pd = pairs[p];
     const int nq = pd.nq, nt = pd.nt;
-    const int cnt = min(in_cnt[p], nq);
+
+    // ---- (1) re-rank of the survivors: virtual sets dealt out over the pair's S x NW waves
+    {
+        FinRerankArgs A;
+        A.nsv = min(surv_cnt[p], nq);
+        A.ent = surv_list + 3 * (size_t)pd.out_off;
+        A.pd = pd; A.p = p;
+        A.frsrc_t = raw_buffer_rsrc(desc + (size_t)pd.t_row0 * 64, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
+        A.frsrc_q = raw_buffer_rsrc(desc + (size_t)pd.q_row0 * 64, (uint32_t)nq * 256u);
+        A.lds_land = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)fin_smem) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 16384u;
+        A.ratio2m = ratio2m;
+        A.knn_idx = knn_idx; A.knn_dist = knn_dist; A.knn_d2 = knn_d2;
+        A.unc_cnt = unc_cnt; A.unc_list = unc_list;
+        A.counters = counters; A.audit_unc = audit == 3 ? flagged : nullptr; A.audit_rej = audit == 4 ? flagged : nullptr; A.flag_cap = flag_cap;
+#ifdef ESFM_FIN_NOSTAGE1
+        const int nvs = 0;                    // (timing experiments)
+#else
+        const int nvs = (A.nsv + kFinQV - 1) / kFinQV;
+#endif
+        // (the next virtual set's entries are loaded while this one waits for its rows)
+        const int eq = lane >> 3 < kFinQV ? lane >> 3 : kFinQV - 1;
+        auto entry_of = [&](int v, int part) {
+            const int e = v * kFinQV + eq;
+            return (v < nvs && e < A.nsv) ? A.ent[3 * (size_t)e + part] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        int v = sl * NW + wave;
+        float4 e0 = entry_of(v, 0), e1 = entry_of(v, 1), e2 = entry_of(v, 2);
+#ifdef ESFM_FIN_TRACE
+        const unsigned long long ft0 = __builtin_amdgcn_s_memrealtime();
+        int nset = 0;
+#endif
+        for (; v < nvs; v += S * NW) {
+            const float4 n0 = entry_of(v + S * NW, 0), n1 = entry_of(v + S * NW, 1), n2 = entry_of(v + S * NW, 2);
+            finish_rerank_vset(A, v, e0, e1, e2);
+            e0 = n0; e1 = n1; e2 = n2;
+#ifdef ESFM_FIN_TRACE
+            ++nset;
+#endif
+        }
+#ifdef ESFM_FIN_TRACE
+        if (lane == 0) {      // (scratch/fin_trace.py: 10-ns ticks of stage 1 per wave, virtual sets, waves)
+            atomicAdd(&counters[8], (int)(__builtin_amdgcn_s_memrealtime() - ft0)); atomicAdd(&counters[9], nset); atomicAdd(&counters[10], 1);
+        }
+#endif
+    }
+    // arrive; the last of the pair's S workgroups goes on alone.  Every wave waits for its own write-through stores to be
+    // acknowledged before the barrier lets the arrival out.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (S > 1) {
+        if (tid == 0) s_last = __hip_atomic_fetch_add(&done[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) __hip_atomic_store(&done[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (everybody has arrived: nobody touches it again in this launch)
+    }
+    if (audit == 3 || audit == 4) return;          // the first pass alone: its answers, its own lists
+
+    // ---- (2), (3): the pair's uncertified queries, chunks of 32, the whole train set by this workgroup's four waves
+    const int cnt = min(ld_coh_i(unc_cnt + p), nq);
     if (cnt > 0) {
         const int nchunks = (cnt + 31) >> 5;
-        // first region of this pair: chunks of the pairs in front of it
-        {
-            int part = 0;
-            for (int pp = tid; pp < p; pp += kFinThreads) part += (min(in_cnt[pp], pairs[pp].nq) + 31) >> 5;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-            if (lane == 0) s_part[wave] = part;
-        }
         const float *__restrict__ tn = norms + pd.t_row0;
         const float *__restrict__ tr = rho_t + pd.t_row0;
         const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(hi_t + (size_t)pd.t_row0 * HS), 0, nt * (HS * 16), 0x00020000);
@@ -1463,24 +1589,25 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
             if (lane == 0) { s_red[wave] = m; s_red[NW + wave] = r; }
         }
         __syncthreads();
-        float tmax = 0.f, rmax = 0.f; int chunk0 = 0;
+        float tmax = 0.f, rmax = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { tmax = fmaxf(tmax, s_red[w]); rmax = fmaxf(rmax, s_red[NW + w]); chunk0 += s_part[w]; }
+        for (int w2 = 0; w2 < NW; ++w2) { tmax = fmaxf(tmax, s_red[w2]); rmax = fmaxf(rmax, s_red[NW + w2]); }
         const double sqrt_tmax = sqrt((double)tmax);
-        // this wave's share of the train set, in steps of 32 rows: part sl * NW + wave of S * NW
+        // this wave's share of the train set, in steps of 32 rows
         const int nsteps = (nt + 31) / 32;
-        const int st0 = (int)(((long long)nsteps * (sl * NW + wave)) / (S * NW)), st1 = (int)(((long long)nsteps * (sl * NW + wave + 1)) / (S * NW));
+        const int st0 = (nsteps * wave) / NW, st1 = (nsteps * (wave + 1)) / NW;
         for (int c = 0; c < nchunks; ++c) {
             if (tid == 0) s_nhit = 0;
             const int slot = c * 32 + j;
             const bool qok = slot < cnt;
-            const int qrow = qok ? in_list[pd.out_off + slot] : 0;
+            const int qrow = qok ? ld_coh_i(unc_list + pd.out_off + slot) : 0;
+            if (tid < 32) s_qrows[tid] = qrow;
             // threshold on the score: s <= U - |q|^2 + E1, rounded up
             float thr = -kBig;
             if (qok) {
                 const double qn = (double)norms[pd.q_row0 + qrow], rq = (double)rho_q[pd.q_row0 + qrow];
                 const double e1 = l2x1_e1(qn, rq, sqrt_tmax, (double)tmax, (double)rmax);
-                const double u = (double)knn_d2[pd.out_off + qrow];
+                const double u = (double)ld_coh_f(knn_d2 + pd.out_off + qrow);
                 const double x = u * (1.0 + 1.0 / 1048576.0) - qn + e1;
                 const double xs = x + fabs(x) * (1.0 / 1048576.0);
                 thr = xs < 3.0e38 ? (float)xs : kBig;                 // (NaN compares false: kBig, everything passes -> overflow -> brute force)
@@ -1542,44 +1669,12 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
                 }
             }
             __syncthreads();
-            // this workgroup's hits -> the chunk's region of the pool (a region that does not exist, or more hits than it holds:
-            // the count says "overflow" and the last workgroup brute-forces the chunk)
-            const int nloc = s_nhit, region = chunk0 + c;
-            if (tid == 0)
-                s_kbase = region < n_regions && nloc > 0
-                              ? __hip_atomic_fetch_add(&region_cnt[region], nloc > CAP ? CAP + 1 : nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            __syncthreads();
-            if (region < n_regions && nloc <= CAP) {
-                const int kb = s_kbase;
-                for (int i = tid; i < nloc; i += kFinThreads)
-                    if (kb + i < CAP) __hip_atomic_store(&pool[(size_t)region * CAP + kb + i], s_h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        }
-        // arrive; the last of the pair's S workgroups goes on.  The pool travels through relaxed agent-scope atomics (write-through
-        // stores, L2-bypassing loads: no agent-scope fence -- on this part a release is a write-back of the XCD's whole L2, an acquire
-        // an invalidation of it, and hundreds of workgroups would queue for them); every wave waits for its own stores to be
-        // acknowledged before the barrier lets the arrival out.
-        if (S > 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) s_last = __hip_atomic_fetch_add(&done[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
-            __syncthreads();
-            if (!s_last) return;
-            if (tid == 0) __hip_atomic_store(&done[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (everybody has arrived: nobody touches it again in this launch)
-        }
-        for (int c = 0; c < nchunks; ++c) {
-            const int region = chunk0 + c;
+            const int nhit = s_nhit;
             const int nqc = min(32, cnt - c * 32);
-            const int nhit = region < n_regions ? __hip_atomic_load(&region_cnt[region], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : CAP + 1;
-            if (tid < 32) s_qrows[tid] = tid < nqc ? in_list[pd.out_off + c * 32 + tid] : 0;
-            __syncthreads();
-            if (region < n_regions && tid == 0 && nhit != 0) __hip_atomic_store(&region_cnt[region], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left clean for the next call
             if (nhit <= CAP) {
                 // exact distances of the hits, the oracle's order
                 for (int k = tid; k < nhit; k += kFinThreads) {
-                    const int hk = __hip_atomic_load(&pool[(size_t)region * CAP + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_h[k] = hk;
+                    const int hk = s_h[k];
                     const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + s_qrows[hk >> 21]) * 64);
                     const float4 *tp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.t_row0 + (hk & 0x1FFFFF)) * 64);
                     float4 qa[16], tb[16];
@@ -1591,31 +1686,37 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
                 __syncthreads();
                 if (tid < nqc) {
                     const size_t o = 2 * ((size_t)pd.out_off + s_qrows[tid]);
-                    Cand b0 = {knn_dist[o], knn_idx[o], 0.f}, b1 = {knn_dist[o + 1], knn_idx[o + 1], 0.f};
+                    Cand b0 = {ld_coh_f(knn_dist + o), ld_coh_i(knn_idx + o), 0.f}, b1 = {ld_coh_f(knn_dist + o + 1), ld_coh_i(knn_idx + o + 1), 0.f};
                     if (b0.i < 0) b0.d = FLT_MAX;
                     if (b1.i < 0) b1.d = FLT_MAX;
                     for (int k = 0; k < nhit; ++k) {
                         const int hk = s_h[k], ht = hk & 0x1FFFFF;
                         if ((hk >> 21) == tid && ht != b0.i && ht != b1.i) best2_insert(b0, b1, s_hd[k], ht, s_hd2[k]);
                     }
-                    knn_idx[o] = b0.i; knn_idx[o + 1] = b1.i;
-                    knn_dist[o] = b0.d; knn_dist[o + 1] = b1.d;
+                    st_coh_i(knn_idx + o, b0.i); st_coh_i(knn_idx + o + 1, b1.i);
+                    st_coh_f(knn_dist + o, b0.d); st_coh_f(knn_dist + o + 1, b1.d);
                 }
                 __syncthreads();
             } else {
-                // too many rows inside the error bound (or no room in the pool): exact brute force of the chunk's queries
+                // too many rows inside the error bound: exact brute force of the chunk's queries
                 if (tid < nqc) {
                     const int sl2 = atomicAdd(&counters[0], 1);
                     if (sl2 < flag_cap) { flagged[2 * sl2] = p; flagged[2 * sl2 + 1] = s_qrows[tid]; }
                 }
-                if (!skip_bruteforce) finish_bruteforce_chunk(desc, pd, s_qrows, nqc, s_q, s_keys, knn_idx, knn_dist);
+                __syncthreads();
+                if (audit != 1) finish_bruteforce_chunk(desc, pd, s_qrows, nqc, s_q, s_keys, knn_idx, knn_dist);
                 __syncthreads();
             }
         }
-    } else if (sl != 0) {
-        return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the write-through stores above, before the ratio stage reads them back)
+        __syncthreads();
     }
-    if (do_ratio) ratio_compact_pair<kFinThreads, 4096 / kFinThreads>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + p, s_wave, &s_base);
+#ifdef ESFM_FIN_NORATIO
+    if (do_ratio && n_pairs < 0)          // (timing experiments)
+#else
+    if (do_ratio)
+#endif
+        ratio_compact_pair<kFinThreads, 4096 / kFinThreads, true>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + p, s_wave, &s_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2254,27 +2355,28 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
     return ESFM_OK;
 }
 
+// the ratio screen's constant: ratio^2 (1 + 2^-20); a ratio that is not a finite number >= 0 switches the screen off
+static inline double l2_ratio2m(double ratio) { return (ratio >= 0.0 && ratio < 1.0e150) ? ratio * ratio * (1.0 + 1.0 / 1048576.0) : (double)INFINITY; }
+
 int l2_x1_query_block() { return 128 * ESFM_L2X1_SETS; }
 bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS - 2)) * 32; }   // the position code names a 32-row step
 
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
-                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2, double ratio, int32_t *rejected,
-                         int32_t *zero_cnt, int zero_n, int32_t *zero_counters)
+                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
+                         int32_t *surv_cnt, void *surv_list, double ratio, int32_t *rejected,
+                         int32_t *zero_a, int32_t *zero_b, int zero_n, int32_t *zero_counters)
 {
     if (n_blocks <= 0) return ESFM_OK;
-    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of four bf16 tiles (= the tail's landing zones), their norms, two reductions
+    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of bf16 tiles, their norms, two reductions
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     // (set on every launch, like the other large-LDS kernels: the attribute belongs to the current device)
     ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_knn_bf16x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // the ratio screen's constant: ratio^2 (1 + 2^-20); a ratio that is not a finite number >= 0 switches the screen off
-    const double ratio2m = (ratio >= 0.0 && ratio < 1.0e150) ? ratio * ratio * (1.0 + 1.0 / 1048576.0) : (double)INFINITY;
     void *h = const_cast<void *>(hi);
     hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(n_blocks), dim3(256), lds, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, n_pairs, knn_idx, knn_dist, flagged, counters, flag_cap, pair_cnt, pair_list, knn_d2, ratio2m, rejected,
-                       zero_cnt, zero_n, zero_counters);
+                       pairs, n_pairs, knn_idx, knn_dist, counters, flag_cap, surv_cnt, reinterpret_cast<float4 *>(surv_list), l2_ratio2m(ratio), rejected,
+                       zero_a, zero_b, zero_n, zero_counters);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
@@ -2283,28 +2385,27 @@ int l2_finish_slices(int n_pairs)
 {
     static const int forced = [] { const char *e = getenv("ESFM_FIN_SLICES"); return e ? atoi(e) : 0; }();     // (measurement)
     if (forced > 0) return forced;
-    // (M-SURF-4k, 300 pairs, 144 uncertified queries per step, one box: S = 8: 54 us, 4: 52, 2: 47, 1: 63 -- the launch is the longest
-    // pair's chain of dependent memory round trips, and a slice more is a few workgroup dispatches more)
     return std::max(1, std::min(8, 1024 / std::max(n_pairs, 1)));
 }
 
 int launch_l2_finish(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
-                     int n_pairs, const int32_t *in_cnt, const int32_t *in_list, const float *knn_d2, int32_t *knn_idx, float *knn_dist,
-                     int32_t *counters, int32_t *flagged, int flag_cap, int32_t *pool, int32_t *region_cnt, int n_regions, int32_t *done,
-                     bool skip_bruteforce, bool do_ratio, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
+                     const int32_t *pair_order, int n_pairs, const int32_t *surv_cnt, const void *surv_list, int32_t *unc_cnt, int32_t *unc_list, float *knn_d2,
+                     int32_t *knn_idx, float *knn_dist, int32_t *counters, int32_t *flagged, int flag_cap, int32_t *done,
+                     int audit, bool do_ratio, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
 {
     if (n_pairs <= 0) return ESFM_OK;
     const int S = l2_finish_slices(n_pairs);
+    ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFinLdsBytes));
     void *h = const_cast<void *>(hi);
-    hipLaunchKernelGGL(l2_finish_kernel, dim3((unsigned)n_pairs * (unsigned)S), dim3(kFinThreads), 0, st, desc,
+    hipLaunchKernelGGL(l2_finish_kernel, dim3((unsigned)n_pairs * (unsigned)S), dim3(kFinThreads), kFinLdsBytes, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, n_pairs, S, in_cnt, in_list, knn_d2, knn_idx, knn_dist, counters, flagged, flag_cap, pool, region_cnt, n_regions, done,
-                       skip_bruteforce ? 1 : 0, do_ratio ? 1 : 0, ratio, query_idx, train_idx, distance, n_out);
+                       pairs, pair_order, n_pairs, S, surv_cnt, reinterpret_cast<const float4 *>(surv_list), unc_cnt, unc_list, knn_d2, knn_idx, knn_dist, counters, flagged,
+                       flag_cap, done, audit, do_ratio ? 1 : 0, ratio, l2_ratio2m(ratio), query_idx, train_idx, distance, n_out);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }
-size_t l2_finish_region_bytes() { return (size_t)kFinCap * sizeof(int32_t); }
+size_t l2_survivor_entry_bytes() { return 48; }
 
 int launch_l2_rescan64_pairs(hipStream_t st, const float *desc, const PairDesc *pairs, int n_pairs, const int32_t *pair_cnt,
                              const int32_t *pair_list, int32_t *knn_idx, float *knn_dist)

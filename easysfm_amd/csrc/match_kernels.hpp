@@ -32,24 +32,25 @@ int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
                        int32_t *pair_cnt, int32_t *pair_list);
-// one-product pass (64-float rows): certifies most queries, bins the rest per pair (pair_cnt / pair_list) for l2_finish_kernel's
-// threshold filter; counters[1] counts them.  flagged != NULL (audit): its failures also go to the global list, counters[0].
+// one-product pass (64-float rows): distance pass + ratio screen.  Queries that provably fail d0 < ratio d1 get train index -2 (+inf:
+// screen off); every other query leaves a survivor entry (l2_survivor_entry_bytes() each, pair p's at surv_list + out_off[p]
+// entries, surv_cnt[p] of them; counters[2] counts them).  rejected != NULL (audit): the screen's rejections on that list, counters[0].
+// zero_a / zero_b [0, zero_n), zero_counters[0, 16): the other phase's per-pair and global counters, zeroed for the next call.
 size_t l2_hi_bytes(long long total_rows);
+size_t l2_survivor_entry_bytes();
 int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
-                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
-                         int32_t *pair_cnt, int32_t *pair_list, float *knn_d2 /* one float per query: exact second-best d^2 of an uncertified query */,
-                         double ratio /* the ratio screen (queries that provably fail d0 < ratio d1 get train index -2 and no re-rank); +inf: off */,
-                         int32_t *rejected /* audit: the screen's rejections on this list (counters[0]), or NULL */,
-                         int32_t *zero_cnt, int zero_n, int32_t *zero_counters /* the other phase's per-pair and global counters, zeroed for the next call */);
-// everything behind the one-product pass in one launch (l2_finish_kernel): the threshold-filter second pass over its uncertified
-// queries (in_cnt / in_list; hits through `pool`, one region of l2_finish_region_bytes() per chunk of 32 queries, region_cnt /
-// done zero on entry and on exit), the exact brute force of overflowed chunks (counted in counters[0], listed in `flagged`;
-// skip_bruteforce: audit), and -- do_ratio -- the ratio test + ordered compaction of every pair
+                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
+                         int32_t *surv_cnt, void *surv_list, double ratio, int32_t *rejected,
+                         int32_t *zero_a, int32_t *zero_b, int zero_n, int32_t *zero_counters);
+// everything behind it in one launch (l2_finish_kernel): exact re-rank of the survivors (uncertified / undecided ones on unc_cnt /
+// unc_list with their thresholds in knn_d2; counters[1] counts them), threshold-filter second pass, brute force of overflowed chunks
+// (counters[0], listed in `flagged`), and -- do_ratio -- the ratio test + ordered compaction of every pair.  `done` zero on entry and
+// on exit.  audit: 0 product path, 1 no brute force, 3 / 4 stop after the re-rank (its uncertified queries / the ratio verdicts'
+// rejections appended to `flagged`)
 int launch_l2_finish(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
-                     int n_pairs, const int32_t *in_cnt, const int32_t *in_list, const float *knn_d2, int32_t *knn_idx, float *knn_dist,
-                     int32_t *counters, int32_t *flagged, int flag_cap, int32_t *pool, int32_t *region_cnt, int n_regions, int32_t *done,
-                     bool skip_bruteforce, bool do_ratio, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
-size_t l2_finish_region_bytes();
+                     const int32_t *pair_order /* the pair indices sorted by train set */, int n_pairs, const int32_t *surv_cnt, const void *surv_list, int32_t *unc_cnt, int32_t *unc_list, float *knn_d2,
+                     int32_t *knn_idx, float *knn_dist, int32_t *counters, int32_t *flagged, int flag_cap, int32_t *done,
+                     int audit, bool do_ratio, double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
 int l2_x1_query_block();
 bool l2_x1_supported(int max_nt);          // train sets the front pass's position code covers
 bool l2_one_product_pass();   // ESFM_L2_PASS=bf16x3 in the environment switches the one-product front pass off (measurement)

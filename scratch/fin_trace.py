@@ -1,0 +1,15 @@
+# stage-1 (re-rank) times of l2_finish_kernel per wave (build with -DESFM_FIN_TRACE, ESFM_LIB=...): s_memrealtime ticks of 10 ns
+import sys; sys.path.insert(0, '.')
+import ctypes as C, numpy as np, easysfm_amd as E
+from easysfm_amd import synth, _lib
+pairs = synth.all_pairs(25)
+sets = synth.surf_like_sets(25, 4096, pool=16384, seed_base=1000)
+pm = E.PairMatcher(E.DescriptorBank(sets, E.ESFM_L2_F32), pairs)
+for _ in range(3): pm.match(0.5)
+pm.ctx.synchronize()
+out = (C.c_int32 * 16)()
+_lib.check(_lib.lib().esfm_match_debug_counters(pm.ctx.handle, out))
+c = list(out)
+print('survivors', c[2], 'waves', c[10], 'virtual sets', c[9], 'rounds', c[11], 'rounds/set %.2f' % (c[11] / max(c[9], 1)))
+print('stage 1 per wave %.2f us, per virtual set %.2f us' % (c[8] / max(c[10], 1) / 100, c[8] / max(c[9], 1) / 100))
+print('per round: transfer wait %.2f us, distance + reduce %.2f us' % (c[12] / max(c[11], 1) / 100, c[13] / max(c[11], 1) / 100))
