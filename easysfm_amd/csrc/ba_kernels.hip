@@ -1213,7 +1213,12 @@ __global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { smin = min(smin, __shfl_xor(smin, o)); smax = max(smax, __shfl_xor(smax, o)); }
         const int R0 = __builtin_amdgcn_readfirstlane((6 * smin) / 16), R1 = __builtin_amdgcn_readfirstlane((6 * smax + 5) / 16);
-        // (the wave's own LDS writes are visible to its later reads: DS operations of a wave execute in order)
+        // The wave's own LDS writes are visible to its later reads (DS operations of a wave execute in order); the fence pair says so
+        // to the COMPILER -- other lanes' stores above, a data-dependent gather below: without it nothing forbids hoisting the loads
+        // (no instruction is emitted for a wavefront-scope fence).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int pq = 0; pq < npts; ++pq) {
             double fa[kMfBR], fb[kMfBR];
 #pragma unroll
@@ -1235,6 +1240,8 @@ __global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the table has been read before the next batch overwrites it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (... and the compiler may not sink this batch's reads below the next one's stores)
+        __builtin_amdgcn_wave_barrier();
     }
     // the chunk's G: the waves' tiles added in wave order (fixed), lower block triangle, in the staging area
     __syncthreads();

@@ -77,3 +77,28 @@ def test_exact_accumulation_matches_oracle_trace(gpu_ctx, oracle_lib):
     assert summ.num_iterations == rs.num_iterations
     for a, b in zip(summ.log(), oracle_lib.iterations(rs)):
         assert abs(a.cost - b.cost) <= 1e-9 * b.cost, a.iteration
+
+
+@pytest.mark.parametrize("n_cam,n_pt,per,reps,iters", [(512, 300000, 10, 4, 6), (107, 9000, 6, 20, 6), (43, 4000, 6, 25, 5), (200, 40000, 8, 8, 6)])
+def test_dataflow_cholesky_repeat_solves_bit_identical(gpu_ctx, n_cam, n_pt, per, reps, iters):
+    """VERDICT r03 "weak" 11 / "next" 4c: the tiled dataflow Cholesky (chol3_kernel / chol2_back_kernel, ba_chol_large.hip) hands
+    tiles between workgroups through flags and assumes that a workgroup it waits for has been dispatched (bounded spins turn a
+    broken launch into an error, not a hang).  scratch/chol_stress.py's repeat-solve check as a test: many solves of the same
+    problem on one resident esfm_ba_problem -- every flag, counter and buffer re-used -- must give bit-identical parameters and
+    iteration counts, at BA-512's 48 block columns and at three mid sizes (2 - 19 block columns)."""
+    sc = synth.ba_scene(n_cam, n_pt, per, radius=40.0 if n_cam > 150 else 15.0, extent=8.0 if n_cam > 150 else 3.0, seed=5000 + n_cam)
+    prob = E.BAProblem(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, gpu_ctx)
+    opt = E.default_options(); opt.function_tolerance = 0; opt.parameter_tolerance = 0; opt.gradient_tolerance = 0; opt.max_num_iterations = iters
+    ref = None
+    try:
+        for r in range(reps):
+            prob.set_params(sc.cams0, sc.pts0)
+            s = prob.solve(opt); gpu_ctx.synchronize()
+            cams, pts = prob.get_params()
+            sig = (s.final_cost, s.num_iterations, s.num_successful_steps, cams.tobytes(), pts.tobytes())
+            if ref is None:
+                ref = sig
+            assert sig == ref, (n_cam, r, s.final_cost, ref[0])
+        assert ref[1] == iters and np.isfinite(ref[0])
+    finally:
+        prob.close()
