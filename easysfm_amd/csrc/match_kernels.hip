@@ -1004,6 +1004,10 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     for (int b = 1; b < RING; ++b) dma_tile(b, b);
     if (RING == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (RING - 1) tiles of TT / 32 pieces
     __syncthreads();
+#ifdef ESFM_X1_STAGGER
+    // (experiment: the two workgroups of a CU out of phase by a fraction of a tile, so that their hand-overs do not coincide)
+    if (((blockIdx.x >> 3) >> 5) & 1) __builtin_amdgcn_s_sleep(ESFM_X1_STAGGER);
+#endif
 
     if (ntiles > 0) {
         asm volatile(ESFM_L2X1_SEGMENT_ASM

@@ -235,6 +235,48 @@ def test_match_pairs_host_pointer_batch_equals_single_calls(gpu_ctx, oracle_lib)
     assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(_bits(d), _bits(rd))
 
 
+def test_alternating_pair_lists_on_one_context(gpu_ctx, oracle_lib):
+    """Round 4: the matcher's per-pair counters live in two phases (a call fills one, its first kernel zeroes the other for the next
+    call) and the bf16 operand images are kept per prepared buffer.  Calls that alternate between banks and pair lists of different
+    lengths on ONE context -- 45 pairs, 3, 190, match and knn2 mixed, an audit call in between -- must each give the oracle's result."""
+    rng = np.random.default_rng(31)
+
+    def bank(n_sets, n_rows, seed):
+        r = np.random.default_rng(seed)
+        base = r.standard_normal((256, 64)).astype(np.float32)
+        out = []
+        for k in range(n_sets):
+            x = r.standard_normal((n_rows + 7 * k, 64)).astype(np.float32)
+            x[:100] = base[r.integers(0, 256, 100)] + np.float32(0.02) * r.standard_normal((100, 64)).astype(np.float32)
+            out.append(np.ascontiguousarray(x / np.linalg.norm(x, axis=1, keepdims=True)))
+        return out
+    cases = [(bank(10, 300, 1), None), (bank(3, 900, 2), None), (bank(20, 120, 3), None)]
+    pms = []
+    for sets, _ in cases:
+        pairs = synth.all_pairs(len(sets))
+        pms.append((sets, pairs, E.PairMatcher(E.DescriptorBank(sets, E.ESFM_L2_F32), pairs, gpu_ctx)))
+    order = [0, 1, 2, 1, 0, 2, 2, 0]
+    for step, k in enumerate(order):
+        sets, pairs, pm = pms[k]
+        pm.prepare()                                   # (another bank was prepared in between)
+        if step % 3 == 2:
+            idx, dist = pm.knn2(); pm.ctx.synchronize()
+            idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+            off = pm.offset
+            for p, (i, j) in enumerate(pairs):
+                ridx, rdist = oracle_lib.knn2_l2(sets[i], sets[j])
+                sl = slice(int(off[p]), int(off[p + 1]))
+                assert np.array_equal(idx[sl], ridx) and np.array_equal(_bits(dist[sl]), _bits(rdist)), (step, k, i, j)
+        else:
+            ratio = (0.5, 0.8, 0.65)[step % 3]
+            res = pm.match(ratio).to_host()
+            for (i, j), (q, t, d) in zip(pairs, res):
+                rq, rt, rd = oracle_lib.match_l2(sets[i], sets[j], ratio)
+                assert np.array_equal(q, rq) and np.array_equal(t, rt) and np.array_equal(_bits(d), _bits(rd)), (step, k, i, j)
+        if step == 3:                                  # an audit call leaves its lists behind: the next call must not see them
+            pm.set_l2_audit(4); pm.match(0.5); pm.ctx.synchronize(); assert len(pm.flagged()) > 0; pm.set_l2_audit(0)
+
+
 def test_many_pairs_heavy_rescan(gpu_ctx, oracle_lib):
     """The re-scan of uncertified queries works pair by pair, in chunks of the pair's list (l2_rescan64_pairs_kernel); launches
     of 2048 pairs and more use the large chunks and ONE workgroup per pair that loops over them.  70 small sets full of
