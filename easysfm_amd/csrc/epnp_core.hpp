@@ -37,15 +37,21 @@ template <int N> ESFM_HD void jacobi_sym(double *A, double *V)
 }
 
 // eigenvectors as ROWS of ut, eigenvalues descending (the layout cvSVD(..., CV_SVD_U_T) returns for a symmetric matrix)
-template <int N> ESFM_HD void sym_eig_desc(const double *A_in, double *ut, double *d)
+// (the `_ws` forms take their large work arrays from the caller: pnp_solve_kernel keeps them in LDS -- as thread-private arrays indexed
+// inside loops they live in scratch memory, one memory round trip per access: 17 ms per launch for 1024 hypotheses)
+template <int N> ESFM_HD void sym_eig_desc_ws(const double *A_in, double *ut, double *d, double *A /* N x N */, double *V /* N x N */)
 {
-    double A[N * N], V[N * N];
     int o[N];
     for (int i = 0; i < N * N; ++i) A[i] = A_in[i];
     jacobi_sym<N>(A, V);
     for (int i = 0; i < N; ++i) o[i] = i;
     for (int i = 1; i < N; ++i) { const int v = o[i]; int j = i - 1; while (j >= 0 && A[o[j] * N + o[j]] < A[v * N + v]) { o[j + 1] = o[j]; --j; } o[j + 1] = v; }
     for (int k = 0; k < N; ++k) { d[k] = A[o[k] * N + o[k]]; for (int a = 0; a < N; ++a) ut[k * N + a] = V[a * N + o[k]]; }
+}
+template <int N> ESFM_HD void sym_eig_desc(const double *A_in, double *ut, double *d)
+{
+    double A[N * N], V[N * N];
+    sym_eig_desc_ws<N>(A_in, ut, d, A, V);
 }
 
 // minimum-norm least squares through the eigen-decomposition of A'A (what cvSolve(CV_SVD) / the QR of epnp.cpp minimise)
@@ -119,10 +125,10 @@ ESFM_HD void m_rows(const Cam &cam, const double as[4], double u, double v, doub
 
 // From M'M and the control points: the four null-space vectors v[k][12] and the three beta candidates (approximations 1-3, each
 // after 5 Gauss-Newton steps): compute_L_6x10, compute_rho, find_betas_approx_{1,2,3}, gauss_newton of epnp.cpp.
-ESFM_HD void betas_from_mtm(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4])
+ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4], double *ws /* 3 x 144: ut, A, V */)
 {
-    double ut[144], d[12];
-    sym_eig_desc<12>(MtM, ut, d);
+    double *ut = ws, d[12];
+    sym_eig_desc_ws<12>(MtM, ut, d, ws + 144, ws + 288);
     for (int k = 0; k < 4; ++k) for (int a = 0; a < 12; ++a) v[k][a] = ut[12 * (11 - k) + a];
     double dv[4][6][3], L[60], rho[6];
     for (int i = 0; i < 4; ++i) {
@@ -195,6 +201,12 @@ ESFM_HD void betas_from_mtm(const double MtM[144], const double cws[4][3], doubl
     }
 }
 
+ESFM_HD void betas_from_mtm(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4])
+{
+    double ws[3 * 144];
+    betas_from_mtm_ws(MtM, cws, v, betas, ws);
+}
+
 // camera-frame control points for one beta vector (compute_ccs)
 ESFM_HD void ccs_of(const double b[4], const double v[4][12], double ccs[4][3])
 {
@@ -239,13 +251,14 @@ ESFM_HD double reproj_dist(const Cam &cam, const double R[9], const double t[3],
 }
 
 // epnp::compute_pose for K points held by one thread (the RANSAC kernel: K = 5)
-template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, const double *us, double R[9], double t[3])
+template <int K> ESFM_HD double solve_small_ws(const Cam &cam, const double *pws, const double *us, double R[9], double t[3], double *ws /* 4 x 144 doubles */)
 {
     double sum_pw[3] = {0, 0, 0}, sum_pwpw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { sum_pw[a] += pws[3 * i + a]; for (int b = 0; b < 3; ++b) sum_pwpw[3 * a + b] += pws[3 * i + a] * pws[3 * i + b]; }
     double cws[4][3], CCi[9];
     control_points(sum_pw, sum_pwpw, K, cws, CCi);
-    double alphas[K][4], MtM[144];
+    double alphas[K][4];
+    double *MtM = ws;
     for (int a = 0; a < 144; ++a) MtM[a] = 0.0;
     for (int i = 0; i < K; ++i) {
         alphas_of(cws[0], CCi, pws + 3 * i, alphas[i]);
@@ -254,7 +267,7 @@ template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, c
         for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) MtM[12 * a + b] += m1[a] * m1[b] + m2[a] * m2[b];
     }
     double v[4][12], betas[3][4];
-    betas_from_mtm(MtM, cws, v, betas);
+    betas_from_mtm_ws(MtM, cws, v, betas, ws + 144);
     double best_err = 0.0;
     for (int N = 0; N < 3; ++N) {
         double ccs[4][3];
@@ -272,6 +285,11 @@ template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, c
         if (N == 0 || e < best_err) { best_err = e; for (int a = 0; a < 9; ++a) R[a] = Rn[a]; for (int a = 0; a < 3; ++a) t[a] = tn[a]; }
     }
     return best_err;
+}
+template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, const double *us, double R[9], double t[3])
+{
+    double ws[4 * 144];
+    return solve_small_ws<K>(cam, pws, us, R, t, ws);
 }
 
 }  // namespace epnp

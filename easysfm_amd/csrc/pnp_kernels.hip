@@ -20,11 +20,18 @@ namespace esfm {
 
 using epnp::Cam;
 
-__global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
-                                                       const int32_t *__restrict__ samples, int n_hyp, double *__restrict__ poses,
-                                                       int32_t *__restrict__ valid)
+// A hypothesis is one thread (EPnP is a chain of small dense factorisations; the arithmetic and its order are the host routines', so the
+// oracle's iteration counts and masks are reproduced), but its four 12 x 12 work arrays -- M'M, the eigenvectors, the Jacobi
+// iteration's A and V, all indexed inside loops -- live in LDS, kPnpThreads threads per workgroup, 577 doubles apart (2 banks per
+// thread: conflict-free).  As thread-private arrays they sat in scratch memory: 16.9 ms per launch of 1024 hypotheses, 152 of the
+// 180 ms of GPU time of a run_fountain_small.sh reconstruction.
+constexpr int kPnpThreads = 8, kPnpWsStride = 4 * 144 + 1;
+__global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
+                                                                const int32_t *__restrict__ samples, int n_hyp, double *__restrict__ poses,
+                                                                int32_t *__restrict__ valid)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
+    __shared__ double ws_all[kPnpThreads * kPnpWsStride];
+    const int g = blockIdx.x * kPnpThreads + threadIdx.x;
     if (g >= n_hyp) return;
     const int32_t *id = samples + 5 * (size_t)g;
     double pw[15], us[10];
@@ -35,7 +42,7 @@ __global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const floa
     }
     const Cam cam = {pb.fu, pb.fv, pb.uc, pb.vc};
     double R[9], t[3];
-    epnp::solve_small<5>(cam, pw, us, R, t);
+    epnp::solve_small_ws<5>(cam, pw, us, R, t, ws_all + threadIdx.x * kPnpWsStride);
     bool ok = true;
     for (int k = 0; k < 9; ++k) ok = ok && isfinite(R[k]);
     for (int k = 0; k < 3; ++k) ok = ok && isfinite(t[k]);
@@ -189,7 +196,7 @@ int launch_pnp_chunk(hipStream_t st, const PnpProblem &pb, const float *p3, cons
 {
     if (n_hyp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + 63) / 64), dim3(64), 0, st, pb, p3, p2, samples, n_hyp, poses, valid);
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + kPnpThreads - 1) / kPnpThreads), dim3(kPnpThreads), 0, st, pb, p3, p2, samples, n_hyp, poses, valid);
     LAUNCH_OK();
     hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp), dim3(256), 0, st, pb, p3, p2, poses, valid, counts);
     LAUNCH_OK();

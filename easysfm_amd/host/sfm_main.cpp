@@ -94,7 +94,7 @@ int main(int argc, char **argv)
         FeatureMatching fm;
         MotionEstimator ee;
         std::vector<frame_t> frames;
-        double t_import = 0, t_detect = 0, t_match = 0, t_verify = 0, t_tracks = 0, t_ba = 0, t_register = 0, t_sor = 0;
+        double t_import = 0, t_detect = 0, t_match = 0, t_verify = 0, t_tracks = 0, t_ba = 0, t_register = 0, t_sor = 0, t_pnp = 0, t_next = 0;
         int n_ba = 0;
         StageClock total_clock, clk;
         if (!io.importImageFilenames(image_list_path, image_data_path, frames) || frames.size() < 2) { std::cerr << "need at least two images" << std::endl; return 3; }
@@ -227,12 +227,15 @@ int main(int argc, char **argv)
 
         // ---- register the remaining frames (sfm.cpp:262-321)
         int remaining = frame_number - 2;
+        double t_next_prev = 0;
         double reproj = ransac_reproj_distance;
         while (remaining > 0) {
             int nxt = -1;
             fm.findNextFrame(track, todo, cloud.unique_point_ids, nxt);
             if (nxt < 0) break;                      // no unregistered frame sees the map (the reference would index with an uninitialised value)
+            t_next += clk.lap(); t_register += t_next - t_next_prev; t_next_prev = t_next;
             const bool ok = ee.estimate2D3D_P3P_RANSAC(frames[size_t(nxt)], cloud, reproj);
+            { const double dt = clk.lap(); t_pnp += dt; t_register += dt; }
             reproj += 1.0;
             for (int i = 0; i < frame_number; ++i) {
                 if (todo[size_t(i)]) continue;
@@ -264,7 +267,7 @@ int main(int argc, char **argv)
         t_sor += clk.lap();
         if (!io.writePlyFile(output_file_path, filtered)) return 3;
         std::cout << "stage seconds: import+undistort " << t_import << " detect " << t_detect << " match " << t_match << " verify " << t_verify << " tracks " << t_tracks
-                  << " register " << t_register << " ba " << t_ba << " ba_calls " << n_ba << " sor " << t_sor << " total " << total_clock.lap()
+                  << " register " << t_register << " register_next_frame " << t_next << " register_pnp " << t_pnp << " ba " << t_ba << " ba_calls " << n_ba << " sor " << t_sor << " total " << total_clock.lap()
                   << " frames " << frame_number << " pairs " << frame_number * (frame_number - 1) / 2 << " batched " << (pair_by_pair ? 0 : 1) << std::endl;
     } catch (const std::exception &e) {       // 1 is the reference's SUCCESS status: a failure must not look like one
         std::cerr << "sfm_native: " << e.what() << std::endl;
