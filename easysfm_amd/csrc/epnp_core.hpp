@@ -39,11 +39,14 @@ template <int N> ESFM_HD void jacobi_sym(double *A, double *V)
 // eigenvectors as ROWS of ut, eigenvalues descending (the layout cvSVD(..., CV_SVD_U_T) returns for a symmetric matrix)
 // (the `_ws` forms take their large work arrays from the caller: pnp_solve_kernel keeps them in LDS -- as thread-private arrays indexed
 // inside loops they live in scratch memory, one memory round trip per access: 17 ms per launch for 1024 hypotheses)
-template <int N> ESFM_HD void sym_eig_desc_ws(const double *A_in, double *ut, double *d, double *A /* N x N */, double *V /* N x N */)
+template <int N> struct JacobiSerial { ESFM_HD void operator()(double *A, double *V) const { jacobi_sym<N>(A, V); } };
+// JAC: what diagonalises A in place and leaves the rotations in V -- jacobi_sym<N>, or a form that shares the same rotations' row /
+// column updates among the lanes of a wave (pnp_kernels.hip): the same operations on the same operands in the same order
+template <int N, class JAC> ESFM_HD void sym_eig_desc_ws(const double *A_in, double *ut, double *d, double *A /* N x N */, double *V /* N x N */, JAC jac)
 {
     int o[N];
     for (int i = 0; i < N * N; ++i) A[i] = A_in[i];
-    jacobi_sym<N>(A, V);
+    jac(A, V);
     for (int i = 0; i < N; ++i) o[i] = i;
     for (int i = 1; i < N; ++i) { const int v = o[i]; int j = i - 1; while (j >= 0 && A[o[j] * N + o[j]] < A[v * N + v]) { o[j + 1] = o[j]; --j; } o[j + 1] = v; }
     for (int k = 0; k < N; ++k) { d[k] = A[o[k] * N + o[k]]; for (int a = 0; a < N; ++a) ut[k * N + a] = V[a * N + o[k]]; }
@@ -51,7 +54,7 @@ template <int N> ESFM_HD void sym_eig_desc_ws(const double *A_in, double *ut, do
 template <int N> ESFM_HD void sym_eig_desc(const double *A_in, double *ut, double *d)
 {
     double A[N * N], V[N * N];
-    sym_eig_desc_ws<N>(A_in, ut, d, A, V);
+    sym_eig_desc_ws<N>(A_in, ut, d, A, V, JacobiSerial<N>());
 }
 
 // minimum-norm least squares through the eigen-decomposition of A'A (what cvSolve(CV_SVD) / the QR of epnp.cpp minimise)
@@ -125,10 +128,11 @@ ESFM_HD void m_rows(const Cam &cam, const double as[4], double u, double v, doub
 
 // From M'M and the control points: the four null-space vectors v[k][12] and the three beta candidates (approximations 1-3, each
 // after 5 Gauss-Newton steps): compute_L_6x10, compute_rho, find_betas_approx_{1,2,3}, gauss_newton of epnp.cpp.
-ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4], double *ws /* 3 x 144: ut, A, V */)
+template <class JAC>
+ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4], double *ws /* 3 x 144: ut, A, V */, JAC jac)
 {
     double *ut = ws, d[12];
-    sym_eig_desc_ws<12>(MtM, ut, d, ws + 144, ws + 288);
+    sym_eig_desc_ws<12>(MtM, ut, d, ws + 144, ws + 288, jac);
     for (int k = 0; k < 4; ++k) for (int a = 0; a < 12; ++a) v[k][a] = ut[12 * (11 - k) + a];
     double dv[4][6][3], L[60], rho[6];
     for (int i = 0; i < 4; ++i) {
@@ -204,7 +208,7 @@ ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], do
 ESFM_HD void betas_from_mtm(const double MtM[144], const double cws[4][3], double v[4][12], double betas[3][4])
 {
     double ws[3 * 144];
-    betas_from_mtm_ws(MtM, cws, v, betas, ws);
+    betas_from_mtm_ws(MtM, cws, v, betas, ws, JacobiSerial<12>());
 }
 
 // camera-frame control points for one beta vector (compute_ccs)
@@ -251,7 +255,7 @@ ESFM_HD double reproj_dist(const Cam &cam, const double R[9], const double t[3],
 }
 
 // epnp::compute_pose for K points held by one thread (the RANSAC kernel: K = 5)
-template <int K> ESFM_HD double solve_small_ws(const Cam &cam, const double *pws, const double *us, double R[9], double t[3], double *ws /* 4 x 144 doubles */)
+template <int K, class JAC> ESFM_HD double solve_small_ws(const Cam &cam, const double *pws, const double *us, double R[9], double t[3], double *ws /* 4 x 144 doubles */, JAC jac)
 {
     double sum_pw[3] = {0, 0, 0}, sum_pwpw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { sum_pw[a] += pws[3 * i + a]; for (int b = 0; b < 3; ++b) sum_pwpw[3 * a + b] += pws[3 * i + a] * pws[3 * i + b]; }
@@ -267,7 +271,7 @@ template <int K> ESFM_HD double solve_small_ws(const Cam &cam, const double *pws
         for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) MtM[12 * a + b] += m1[a] * m1[b] + m2[a] * m2[b];
     }
     double v[4][12], betas[3][4];
-    betas_from_mtm_ws(MtM, cws, v, betas, ws + 144);
+    betas_from_mtm_ws(MtM, cws, v, betas, ws + 144, jac);
     double best_err = 0.0;
     for (int N = 0; N < 3; ++N) {
         double ccs[4][3];
@@ -289,7 +293,7 @@ template <int K> ESFM_HD double solve_small_ws(const Cam &cam, const double *pws
 template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, const double *us, double R[9], double t[3])
 {
     double ws[4 * 144];
-    return solve_small_ws<K>(cam, pws, us, R, t, ws);
+    return solve_small_ws<K>(cam, pws, us, R, t, ws, JacobiSerial<12>());
 }
 
 }  // namespace epnp

@@ -20,18 +20,58 @@ namespace esfm {
 
 using epnp::Cam;
 
-// A hypothesis is one thread (EPnP is a chain of small dense factorisations; the arithmetic and its order are the host routines', so the
-// oracle's iteration counts and masks are reproduced), but its four 12 x 12 work arrays -- M'M, the eigenvectors, the Jacobi
-// iteration's A and V, all indexed inside loops -- live in LDS, kPnpThreads threads per workgroup, 577 doubles apart (2 banks per
-// thread: conflict-free).  As thread-private arrays they sat in scratch memory: 16.9 ms per launch of 1024 hypotheses, 152 of the
-// 180 ms of GPU time of a run_fountain_small.sh reconstruction.
-constexpr int kPnpThreads = 8, kPnpWsStride = 4 * 144 + 1;
-__global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
-                                                                const int32_t *__restrict__ samples, int n_hyp, double *__restrict__ poses,
-                                                                int32_t *__restrict__ valid)
+// A hypothesis is SIXTEEN lanes (round 4).  EPnP is a chain of small dense factorisations whose arithmetic and order are the host
+// routines' (epnp_core.hpp), so that the oracle's iteration counts and masks are reproduced; all sixteen lanes run that chain
+// redundantly -- same operands, same results, same stores -- except inside the one expensive step, the Jacobi diagonalisation of the
+// 12 x 12 M'M (66 rotations per sweep, ~8 sweeps, 36 element updates per rotation), where lane r takes row / column r of a rotation's
+// three update loops (Jacobi12Coop): the same operations on the same operands, three LDS round trips per rotation instead of 144.
+// The four 12 x 12 work arrays (M'M, the eigenvectors, the iteration's A and V) live in LDS, one arena per hypothesis.
+// History: one thread per hypothesis with the arrays as thread-private scratch memory 16.9 ms per launch of 1024 hypotheses (152 of
+// the 180 ms of GPU time of a run_fountain_small.sh reconstruction); the arrays in LDS, still one thread: 9.9 ms.
+constexpr int kPnpLanes = 16, kPnpHypPerBlock = 64 / kPnpLanes, kPnpWsStride = 4 * 144 + 1;
+struct Jacobi12Coop {
+    int l;      // lane of the hypothesis' group
+    __device__ __forceinline__ void operator()(double *A, double *V) const
+    {
+        constexpr int N = 12;
+        // the group's lanes exchange rows and columns through the arena: DS operations of a wave execute in order; the fences keep the
+        // compiler from moving accesses across (no instruction is emitted for a wavefront-scope fence)
+        auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+        const bool mine = l < N;
+        const int r = mine ? l : 0;
+        sync();
+        if (mine) for (int j = 0; j < N; ++j) V[r * N + j] = r == j ? 1.0 : 0.0;
+        sync();
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0.0, diag = 0.0;
+            for (int i = 0; i < N; ++i) { diag += A[i * N + i] * A[i * N + i]; for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j]; }
+            if (off <= 1e-36 * diag || off == 0.0) break;
+            for (int p = 0; p < N - 1; ++p)
+                for (int q = p + 1; q < N; ++q) {
+                    const double apq = A[p * N + q];
+                    if (apq == 0.0) continue;
+                    const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
+                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    sync();
+                    if (mine) { const double x = A[r * N + p], y = A[r * N + q]; A[r * N + p] = c * x - s * y; A[r * N + q] = s * x + c * y; }
+                    sync();
+                    if (mine) { const double x = A[p * N + r], y = A[q * N + r]; A[p * N + r] = c * x - s * y; A[q * N + r] = s * x + c * y; }
+                    sync();
+                    if (mine) { const double x = V[r * N + p], y = V[r * N + q]; V[r * N + p] = c * x - s * y; V[r * N + q] = s * x + c * y; }
+                    sync();
+                }
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
+                                                       const int32_t *__restrict__ samples, int n_hyp, double *__restrict__ poses,
+                                                       int32_t *__restrict__ valid)
 {
-    __shared__ double ws_all[kPnpThreads * kPnpWsStride];
-    const int g = blockIdx.x * kPnpThreads + threadIdx.x;
+    __shared__ double ws_all[kPnpHypPerBlock * kPnpWsStride];
+    const int grp = threadIdx.x / kPnpLanes, l = threadIdx.x % kPnpLanes;
+    const int g = blockIdx.x * kPnpHypPerBlock + grp;
     if (g >= n_hyp) return;
     const int32_t *id = samples + 5 * (size_t)g;
     double pw[15], us[10];
@@ -42,7 +82,8 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpProblem pb, c
     }
     const Cam cam = {pb.fu, pb.fv, pb.uc, pb.vc};
     double R[9], t[3];
-    epnp::solve_small_ws<5>(cam, pw, us, R, t, ws_all + threadIdx.x * kPnpWsStride);
+    epnp::solve_small_ws<5>(cam, pw, us, R, t, ws_all + grp * kPnpWsStride, Jacobi12Coop{l});
+    if (l != 0) return;
     bool ok = true;
     for (int k = 0; k < 9; ++k) ok = ok && isfinite(R[k]);
     for (int k = 0; k < 3; ++k) ok = ok && isfinite(t[k]);
@@ -196,7 +237,7 @@ int launch_pnp_chunk(hipStream_t st, const PnpProblem &pb, const float *p3, cons
 {
     if (n_hyp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + kPnpThreads - 1) / kPnpThreads), dim3(kPnpThreads), 0, st, pb, p3, p2, samples, n_hyp, poses, valid);
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + kPnpHypPerBlock - 1) / kPnpHypPerBlock), dim3(64), 0, st, pb, p3, p2, samples, n_hyp, poses, valid);
     LAUNCH_OK();
     hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp), dim3(256), 0, st, pb, p3, p2, poses, valid, counts);
     LAUNCH_OK();
