@@ -55,6 +55,10 @@ import sys
 KEEP = int(os.environ.get("ESFM_GEN_KEEP", "4"))
 NOFOLD = int(os.environ.get("ESFM_GEN_NOFOLD", "0"))      # timing experiments only: no fold / no MFMA
 NOMFMA = int(os.environ.get("ESFM_GEN_NOMFMA", "0"))
+NOBAR = int(os.environ.get("ESFM_GEN_NOBAR", "0"))        # timing experiments only (wrong results): no barrier / no wait for the
+NOVMWAIT = int(os.environ.get("ESFM_GEN_NOVMWAIT", "0"))  # wave's transfers at a hand-over, no waits for LDS reads inside a step,
+NOLGKM = int(os.environ.get("ESFM_GEN_NOLGKM", "0"))      # no LDS reads at all
+NOLDSRD = int(os.environ.get("ESFM_GEN_NOLDSRD", "0"))
 NS = 4
 GRP = int(os.environ.get("ESFM_GEN_GRP", "8"))            # results per fold group: 4 (round 3) or 8 (round 4: 4.5 instead of 7 VALU per MFMA at K = 4)
 assert GRP in (4, 8)
@@ -215,7 +219,7 @@ def gen():
         (buffer nbuf, step nstep).  extra: instruction lists issued behind slots 4 .. 8 (the hand-over's transfers)."""
         extra = list(extra or [])
         for slot, (s, ks) in enumerate(ORDER):
-            if slot in WAITS:
+            if slot in WAITS and not NOLGKM and not NOLDSRD:
                 e(f"s_waitcnt lgkmcnt({WAITS[slot]})")
             if slot == 10:
                 # the step being folded from now on is this one
@@ -232,7 +236,7 @@ def gen():
             which, fs, fg = GAP[slot]
             for x in fold_group(fs, fg, spar if which == "cur" else spar ^ 1):
                 e(x)
-            if slot in READS:
+            if slot in READS and not NOLDSRD:
                 kind, k = READS[slot]
                 if kind == "start":
                     for g in range(4):
@@ -255,7 +259,8 @@ def gen():
             step(st & 1, st & 1, buf, st + 1)
         # ---- last step: hand-over first
         e("s_waitcnt lgkmcnt(0)")                               # every read of this tile has landed
-        e(f"s_waitcnt vmcnt({(RING - 2) * NP})")               # this wave's transfers of tile + 1 have landed (younger tiles may fly;
+        if not NOVMWAIT:
+            e(f"s_waitcnt vmcnt({(RING - 2) * NP})")           # this wave's transfers of tile + 1 have landed (younger tiles may fly;
         #                                                         counted in pieces only: the caller's first tiles come without norm loads)
         # norms of tile + 1 -> LDS, rows past nt as kBig (the first RING tiles' norms were written by the caller)
         e(f"s_cmp_lt_u32 s40, {RING - 1}")
@@ -270,7 +275,8 @@ def gen():
         e(f"ds_write_b32 v{NLDS}, v{SCR + 1} offset:{nb * TT * 4}")
         e("s_waitcnt lgkmcnt(0)")
         e(f"L_nonorm_{tag}_%=:")
-        e("s_barrier")
+        if not NOBAR:
+            e("s_barrier")
         e(f"s_add_u32 s48, s40, {RING}")
         e(f"s_mul_i32 s51, s48, {TT * 4}")                      # (tile + RING) * TT * 4: its norms
         e(f"s_mul_i32 s48, s48, {TILE_BYTES}")                  # ... its rows

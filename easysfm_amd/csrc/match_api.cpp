@@ -14,6 +14,7 @@ namespace {
 
 struct PairPlan {
     std::vector<PairDesc> tab;
+    std::vector<int32_t> blk_pair;   // the pair of every 512-query block of the one-product front pass (its workgroups look their work up here)
     std::vector<int32_t> by_train;   // pair indices sorted by train set (l2_finish_kernel walks the pairs in this order: the workgroups that
                                      // fetch rows of one train set run next to each other, on one XCD, and find them in its L2)
     int n_blocks = 0;
@@ -50,6 +51,7 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
         blk += (d.nq + query_block - 1) / query_block;
         blk2 += (d.nq + qb2 - 1) / qb2;
         ESFM_REQUIRE(blk < (int64_t)1 << 31, "too many workgroups for one launch; split the pair list");
+        plan->blk_pair.resize((size_t)blk2, p);
     }
     if (out_offset) out_offset[n_pairs] = off;
     plan->by_train.resize((size_t)n_pairs);
@@ -66,12 +68,14 @@ int make_plan(const int32_t *set_row_offset, int n_sets, const int32_t *pairs, i
 // an identical pair list (the common case in a loop over the same frames) is not re-sent.
 int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
 {
-    // one blob: the pair table, then the pairs' indices sorted by train set (pair_order_of below)
-    const size_t tab_bytes = plan.tab.size() * sizeof(PairDesc), bytes = tab_bytes + plan.by_train.size() * sizeof(int32_t);
+    // one blob: the pair table, then the pairs' indices sorted by train set (pair_order_of below), then the front pass's block table
+    const size_t tab_bytes = plan.tab.size() * sizeof(PairDesc), ord_bytes = plan.by_train.size() * sizeof(int32_t);
+    const size_t bytes = tab_bytes + ord_bytes + plan.blk_pair.size() * sizeof(int32_t);
     if (bytes == 0) { *dev_tab = nullptr; return ESFM_OK; }
     std::vector<char> blob(bytes);
     memcpy(blob.data(), plan.tab.data(), tab_bytes);
-    memcpy(blob.data() + tab_bytes, plan.by_train.data(), bytes - tab_bytes);
+    memcpy(blob.data() + tab_bytes, plan.by_train.data(), ord_bytes);
+    if (!plan.blk_pair.empty()) memcpy(blob.data() + tab_bytes + ord_bytes, plan.blk_pair.data(), bytes - tab_bytes - ord_bytes);
     if (ctx->pair_tab.cap >= bytes && ctx->pinned_cap >= bytes && ctx->last_pair_bytes == bytes &&
         memcmp(ctx->pinned, blob.data(), bytes) == 0) {
         *dev_tab = ctx->pair_tab.as<PairDesc>();
@@ -89,6 +93,7 @@ int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
     return ESFM_OK;
 }
 inline const int32_t *pair_order_of(const PairDesc *dev_tab, int n_pairs) { return reinterpret_cast<const int32_t *>(dev_tab + n_pairs); }
+inline const int32_t *blk_pair_of(const PairDesc *dev_tab, int n_pairs) { return pair_order_of(dev_tab, n_pairs) + n_pairs; }
 
 // Where the ratio test's survivors go (the match entry points); NULL: the raw 2-NN table is the result.
 struct MatchOut { int32_t *query_idx, *train_idx; float *distance; int32_t *n_out; };
@@ -173,8 +178,8 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                 }
                 {
                     esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
-                    if (int rc = esfm::launch_l2_knn_bf16x1(st, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab, n_pairs,
-                                                            plan.n_blocks2, knn_idx, knn_dist, cur_counters, (int)cap64, cur_surv, ctx->surv_list.ptr, ratio,
+                    if (int rc = esfm::launch_l2_knn_bf16x1(st, ctx->num_cu, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab,
+                                                            blk_pair_of(dev_tab, n_pairs), plan.n_blocks2, knn_idx, knn_dist, cur_counters, (int)cap64, cur_surv, ctx->surv_list.ptr, ratio,
                                                             ctx->l2_audit == 4 ? ctx->flagged.as<int32_t>() : nullptr, oth_unc, oth_surv,
                                                             ctx->l2_phase_pairs[1 - ph], oth_counters))
                         return rc;

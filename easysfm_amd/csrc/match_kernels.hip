@@ -880,6 +880,22 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16_kernel(const float *__rest
     }
 }
 
+// max |row|^2 and max rho_t of every 256-row block of the bank (l2_knn_bf16x1_kernel takes the maxima over a train set from here: the
+// whole blocks inside the set from this table, the rows in front of and behind them one by one).  Launched behind l2_split_bf16_kernel.
+__global__ __launch_bounds__(256) void l2_blockmax_kernel(const float *__restrict__ norms, const float *__restrict__ rho_t, long long total_rows,
+                                                          float2 *__restrict__ blkmax)
+{
+    __shared__ float red[8];
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    float m = row < total_rows ? norms[row] : 0.f, r = row < total_rows ? rho_t[row] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; red[4 + (threadIdx.x >> 6)] = r; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blkmax[blockIdx.x] = make_float2(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+}
+
 // The one-product pass's bound E1 on |(|q|^2 + score) - D| for every train row (D = the canonical float d^2; see the comment of
 // l2_knn_bf16x1_kernel): operand rounding (rB T + (2 |q| + rB) R), the three-product pass's 2^-15 (|q|^2 + max |t|^2) for norms, MFMA
 // accumulation and the canonical distance, and an ABSOLUTE floor of 2^-118 for whatever is flushed to zero or loses bits as a
@@ -908,10 +924,35 @@ __device__ __forceinline__ double l2x1_e1(double qn, double rq, double sqrt_tmax
 //  * 512 queries per workgroup (four sets of 32 per wave), a ring of four 16-KiB tiles of bf16(t) rows, 13-bit position codes in
 //    the group keys (no segments, no master list): l2x1_segment_gfx950.inc is the whole main loop.  Train sets of more than
 //    65536 rows do not fit the code and skip this pass (l2_x1_supported).
+constexpr int l2x1_query_block_c = 128 * ESFM_L2X1_SETS;
+// Cross-lane moves without an address register (__shfl_xor goes through ds_bpermute_b32, whose lane addresses the compiler hoists out
+// of l2_knn_bf16x1_kernel's item loop and then has to keep in scratch memory across the main loop's asm block).
+// max over the wave, the same value in every lane: rotations inside the rows of 16 lanes (DPP), then the four rows through SGPRs
+__device__ __forceinline__ float wave_max_dpp(float x)
+{
+#define ESFM_ROR(n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + (n), 0xF, 0xF, false))
+    x = fmaxf(x, ESFM_ROR(8)); x = fmaxf(x, ESFM_ROR(4)); x = fmaxf(x, ESFM_ROR(2)); x = fmaxf(x, ESFM_ROR(1));
+#undef ESFM_ROR
+    const int xi = __float_as_int(x);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(xi, 0)), b = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(xi, 32)), d = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+// the value of lane ^ 32 (v_permlane32_swap, gfx950: the upper half of its first operand changes places with the lower half of the
+// second); upper = this lane is in the upper half
+__device__ __forceinline__ float other_half(float x, bool upper)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(upper ? r[0] : r[1]);
+}
+// One unit of the one-product pass's work: 512 queries (block qblk) of pair pi against the pair's whole train set.
+struct X1Item { int32_t q_row0, nq, t_row0, nt; int64_t out_off; int32_t pi, qblk; };
+
 __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
                                                                const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
                                                                const float *__restrict__ rho_t, const float *__restrict__ rho_q,
-                                                               const PairDesc *__restrict__ pairs, int n_pairs,
+                                                               const float2 *__restrict__ blkmax,
+                                                               const PairDesc *__restrict__ pairs, const int32_t *__restrict__ blk_pair, int n_blocks,
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                                int32_t *__restrict__ counters, int flag_cap,
                                                                int32_t *__restrict__ surv_cnt, float4 *__restrict__ surv_list,
@@ -927,183 +968,288 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     constexpr int QB = 128 * NS, HS = 8;                         // HS: 16-B slots per row of the hi images
     constexpr int TILE_BYTES = TT * HS * 16;
     static_assert(NS == 4, "operand list below is written for four query sets");
+    static_assert(RING * TT == 2 * 256, "a thread stages two norms of the ring's first tiles");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [RING][TT * HS]: 64 KiB, later four landing zones
+    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);                         // [RING][TT * HS]: 64 KiB; the main loop leaves the keys here
     float *lds_norm = reinterpret_cast<float *>(smem + RING * TILE_BYTES);     // [RING][TT]   (the asm block assumes norms right behind the ring)
-    float *lds_red = lds_norm + RING * TT;                                     // [8]
+    float *lds_red = lds_norm + RING * TT;                                     // [2][8]: max |t|^2 and max rho_t of an item's train set, per wave
+    float *lds_qn = lds_red + 16;                                              // [2][QB]: |q|^2 of an item's queries
+    float *lds_rq = lds_qn + 2 * QB;                                           // [2][QB]: their residual norms
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    int pi;
-    {
-        int lo = 0, hi = n_pairs - 1;  // last p with blk_off2[p] <= lb
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (pairs[mid].blk_off2 <= lb) lo = mid; else hi = mid - 1;
-        }
-        pi = lo;
-    }
-    const PairDesc pd = pairs[pi];
-    const int nq = pd.nq, nt = pd.nt;
-    const float *__restrict__ tn = norms + pd.t_row0;
-    const float *__restrict__ tr = rho_t + pd.t_row0;
-    const int qbase = (lb - pd.blk_off2) * QB + wave * 32 * NS;
-
-    constexpr float kBig = 3.0e38f;
-    const int ntiles = (nt + TT - 1) / TT;
-    const u32x4 trsrc = raw_buffer_rsrc(hi_t + (size_t)pd.t_row0 * HS, (uint32_t)nt * (HS * 16));   // reads past it return 0
-    const u32x4 nrsrc = raw_buffer_rsrc(tn, (uint32_t)nt * 4u);
-    const uint32_t lds_tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_tile);   // LDS byte address
+    // Nothing that depends on the thread index may stay live across the main loop's asm block (64 operand registers in, 184
+    // clobbered: whatever the compiler keeps it keeps in scratch memory and fetches back in the tail's critical path): the thread's
+    // coordinates are re-derived from an opaque copy of the index behind every pass of the block.
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    // LDS-DMA of one tile: wave w stages rows [32 w, 32 w + 32), 8 rows = 1 KiB per instruction, lane l -> byte 16 l of the piece:
-    // row l >> 3, physical slot l & 7, which holds logical slot (l & 7) ^ ((row >> 1) & 7) (the asm's reads use the same map)
-    auto dma_tile = [&](int tile, int buf) {
-#pragma unroll
-        for (int i = 0; i < TT / 32; ++i) {
-            const int row = wave_s * (TT / 4) + 8 * i + (lane >> 3);
-            const int voff = row * (HS * 16) + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
-            lds_dma_b128(lds_tile_addr + (uint32_t)(buf * TILE_BYTES + (wave_s * (TT / 4) + 8 * i) * (HS * 16)), voff, trsrc, tile * TILE_BYTES);
-        }
+    auto rederive = [&]() {
+        int l;             // (the lane index from scratch: not even the thread index has to survive the block)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        lane = l; wave = wave_s; tid = wave_s * 64 + l; j = l & 31; h = l >> 5;
     };
-    // Uninitialised LDS under rows that are never transferred (past nt in the last tile) must at least not hold huge finite values
-    if (ntiles * TT != nt || ntiles < RING) {
-        for (int i = tid; i < RING * TT * HS; i += 256) lds_tile[i] = u32x4{0u, 0u, 0u, 0u};
-        __syncthreads();
-    }
+    const uint32_t lds_tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_tile);   // LDS byte address
 
-    // B operands: bf16(-2 q), this lane's 8 features of every K-step
-    u32x4 bq[NS][4];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int qrow = qbase + 32 * s + j;
-        const bool ok = qrow < nq;
-        const u32x4 *qp = hi_q + ((size_t)pd.q_row0 + (ok ? qrow : 0)) * HS + h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            u32x4 v = qp[2 * ks];
-            if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-            bq[s][ks] = v;
+    // ---- A PERSISTENT workgroup (round 4).  The grid is two workgroups per CU; workgroup b takes the 512-query blocks b, b + G,
+    // b + 2 G, ... of the launch (G = gridDim.x, a multiple of 8 when there is more than one round: all of a workgroup's blocks map to
+    // its XCD's contiguous range of the numbering, xcd_remap) and overlaps the memory round trips of block k + 1's set-up -- query
+    // operands, the ring's first tiles, norms, maxima -- with block k's tail.  One workgroup per block (until the middle of round 4)
+    // spent 16 us in front of and 9 us behind an 83-us main loop waiting for four or five dependent round trips (s_memrealtime
+    // stamps), with one other workgroup per CU to fill the matrix pipe meanwhile: 66 % MFMA busy over the launch, 84 % inside the loop.
+    const int G = gridDim.x;
+    auto lb_of = [&](int k) -> int {
+        const long long v = (long long)blockIdx.x + (long long)k * G;
+        return v < (long long)n_blocks ? xcd_remap((int)v, n_blocks) : -1;
+    };
+    auto make_item = [&](int lb, int pi) -> X1Item {
+        X1Item it = {0, 0, 0, 0, 0, -1, 0};
+        if (pi >= 0) {
+            const PairDesc d = pairs[pi];
+            it = X1Item{__builtin_amdgcn_readfirstlane(d.q_row0), __builtin_amdgcn_readfirstlane(d.nq), __builtin_amdgcn_readfirstlane(d.t_row0),
+                        __builtin_amdgcn_readfirstlane(d.nt),
+                        (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)d.out_off >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)d.out_off)),
+                        pi, lb - __builtin_amdgcn_readfirstlane(d.blk_off2)};
         }
-    }
-    // norms of the first RING tiles straight to LDS, rows past nt as kBig (the asm block takes over from tile RING on: it writes a
-    // tile's norms at the hand-over that publishes it)
-    for (int t = tid; t < RING * TT; t += 256) lds_norm[t] = t < nt ? tn[t] : kBig;
-    // max |t|^2 and max rho_t over the train set (the certificate's bound needs both in the tail)
-    {
+        return it;
+    };
+
+    // what the set-up of an item leaves in registers until its round trip is over
+    u32x4 bq[NS][4];                     // B operands: bf16(-2 q), this lane's 8 features of every K-step
+    float st_norm[2], st_qn[2], st_rq[2], st_m, st_r;
+    // set-up, part 1: every load of the item goes out (and the ring's first tiles: LDS-DMA, wave w rows [TT/4 w, TT/4 (w + 1)) of a
+    // tile, 8 rows = 1 KiB per instruction, lane l -> row l >> 3, physical slot l & 7 = logical slot (l & 7) ^ ((row >> 1) & 7))
+    auto stage_issue = [&](const X1Item &it) {
+        const int nt = it.nt, nq = it.nq;
+        const int ntiles = (nt + TT - 1) / TT;
+        const u32x4 trsrc = raw_buffer_rsrc(hi_t + (size_t)it.t_row0 * HS, (uint32_t)nt * (HS * 16));   // reads past it return 0
+        // LDS under rows that are never transferred (past nt in the last tile) must not hold huge values (the previous item's keys)
+        if (ntiles * TT != nt || ntiles < RING) {
+            uint32_t z;          // (as a hoisted constant vector the zeros would be carried through the main loop's asm block)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            for (int i = tid; i < RING * TT * HS; i += 256) lds_tile[i] = u32x4{z, z, z, z};
+            __syncthreads();
+        }
+#pragma unroll
+        for (int b = 0; b < RING; ++b) {
+#pragma unroll
+            for (int i = 0; i < TT / 32; ++i) {
+                const int row = wave_s * (TT / 4) + 8 * i + (lane >> 3);
+                const int voff = row * (HS * 16) + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+                lds_dma_b128(lds_tile_addr + (uint32_t)(b * TILE_BYTES + (wave_s * (TT / 4) + 8 * i) * (HS * 16)), voff, trsrc, b * TILE_BYTES);
+            }
+        }
+        const int qbase = it.qblk * QB + wave * 32 * NS;
+        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(hi_q + (size_t)it.q_row0 * HS), 0, nq * (HS * 16), 0x00020000);   // rows past nq read as zeros
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int voff = (qbase + 32 * s + j) * (HS * 16) + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bq[s][ks] = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, voff + 32 * ks, 0, 0);
+        }
+        const float *__restrict__ tn = norms + it.t_row0;
+        const float *__restrict__ tr = rho_t + it.t_row0;
+        float big;           // (kBig out of an SGPR written here: as a hoisted constant it would be one more register to carry through the block)
+        asm volatile("s_mov_b32 %0, 0x7f61b1e6" : "=s"(big));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + 256 * u, q = it.qblk * QB + t;
+            st_norm[u] = t < nt ? tn[t] : big;            // norms of the ring's first tiles, rows past nt as kBig
+            st_qn[u] = norms[it.q_row0 + (q < nq ? q : 0)];
+            st_rq[u] = rho_q[it.q_row0 + (q < nq ? q : 0)];
+        }
+        // max |t|^2 and max rho_t over the train set (the certificate's bound needs both in the tail): whole 256-row blocks of the
+        // bank from l2_blockmax_kernel's table, the rows in front of and behind them one by one
         float m = 0.f, r = 0.f;
-        for (int t = tid; t < nt; t += 256) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); r = fmaxf(r, __shfl_xor(r, o)); }
-        if (lane == 0) { lds_red[wave] = m; lds_red[4 + wave] = r; }
-    }
-    // the ring's first tiles (a tile that does not exist reads zeros through the descriptor); tile 0 must have landed
-    // before the main loop starts -- the younger transfers may stay in flight
-    dma_tile(0, 0);
-#pragma unroll
-    for (int b = 1; b < RING; ++b) dma_tile(b, b);
-    if (RING == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (RING - 1) tiles of TT / 32 pieces
-    __syncthreads();
-#ifdef ESFM_X1_STAGGER
-    // (experiment: the two workgroups of a CU out of phase by a fraction of a tile, so that their hand-overs do not coincide)
-    if (((blockIdx.x >> 3) >> 5) & 1) __builtin_amdgcn_s_sleep(ESFM_X1_STAGGER);
-#endif
-
-    if (ntiles > 0) {
-        asm volatile(ESFM_L2X1_SEGMENT_ASM
-                     :
-                     : "v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[0][2]), "v"(bq[0][3]), "v"(bq[1][0]), "v"(bq[1][1]), "v"(bq[1][2]), "v"(bq[1][3]),
-                       "v"(bq[2][0]), "v"(bq[2][1]), "v"(bq[2][2]), "v"(bq[2][3]), "v"(bq[3][0]), "v"(bq[3][1]), "v"(bq[3][2]), "v"(bq[3][3]),
-                       "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
-                     : ESFM_L2X1_SEGMENT_CLOBBERS);
-    }
-    // the block left this thread's keys in LDS: key i of set s at float (K s + i) * 256 + tid  (read unconditionally -- sixteen
-    // `ntiles > 0 ? read : kBig` had become sixteen branches -- and replaced when no tile ran)
-    float keys[NS][K];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const float v = reinterpret_cast<const float *>(smem)[(K * s + i) * 256 + tid];
-            keys[s][i] = ntiles > 0 ? v : kBig;
+        const int t0 = it.t_row0, t1 = t0 + nt, b0 = (t0 + 255) >> 8, b1 = t1 >> 8;
+        if (b0 >= b1) {
+            for (int t = tid; t < nt; t += 256) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }      // < 512 rows
+        } else {
+            if (tid < b0 * 256 - t0) { m = fmaxf(m, tn[tid]); r = fmaxf(r, tr[tid]); }
+            if (tid < t1 - b1 * 256) { m = fmaxf(m, norms[b1 * 256 + tid]); r = fmaxf(r, rho_t[b1 * 256 + tid]); }
+            for (int b = b0 + tid; b < b1; b += 256) { const float2 v = blkmax[b]; m = fmaxf(m, v.x); r = fmaxf(r, v.y); }
         }
-    }
-    const float tmax = fmaxf(fmaxf(lds_red[0], lds_red[1]), fmaxf(lds_red[2], lds_red[3]));
-    const float rmax = fmaxf(fmaxf(lds_red[4], lds_red[5]), fmaxf(lds_red[6], lds_red[7]));
+        st_m = m; st_r = r;
+    };
+    // set-up, part 2 (every load has landed): what the main loop and the tail read from LDS
+    auto stage_commit = [&](int par) {
+        lds_norm[tid] = st_norm[0]; lds_norm[tid + 256] = st_norm[1];
+        lds_qn[par * QB + tid] = st_qn[0]; lds_qn[par * QB + tid + 256] = st_qn[1];
+        lds_rq[par * QB + tid] = st_rq[0]; lds_rq[par * QB + tid + 256] = st_rq[1];
+        const float m = wave_max_dpp(st_m), r = wave_max_dpp(st_r);
+        if (lane == 0) { lds_red[par * 8 + wave] = m; lds_red[par * 8 + 4 + wave] = r; }
+    };
 
-    // ---- the RATIO SCREEN (round 4), all that is left of this kernel's tail.  The reference keeps a query only if d0 < ratio d1
-    // (feature_matching.cpp:133); everything else is dropped one kernel later, and on the metric's workload that is > 90 % of the
-    // queries.  With k0 <= kb the two smallest of a query's 2 K group keys (two groups, hence two different train rows: the groups'
-    // minima) and E1 the pass's bound on |(|q|^2 + score) - D| (D = the canonical float d^2), kTrunc the key's truncation:
-    //     every train row has   D >= L0 = |q|^2 + k0 - kTrunc |k0| - E1        (k0 is the smallest key of all groups),
-    //     two rows have         D <= U1 = |q|^2 + kb + kTrunc |kb| + E1,
-    // so the nearest has D0 >= L0 and the second nearest D1 <= U1.  If L0 >= ratio^2 (1 + 2^-20) U1 then sqrtf(D0) >= ratio sqrtf(D1)
-    // whatever the two roundings of sqrtf and the double product do (their relative error is < 2^-22 together): the query cannot
-    // pass the test.  It gets a marker (train index -2) and nothing more is done for it.  A SURVIVOR leaves one 48-byte entry -- its
-    // 2 K keys, its row, |q|^2 and E1 (as a float, rounded up) -- in the pair's slice of surv_list; l2_finish_kernel re-ranks the
-    // survivors' kept groups exactly.  (Until the middle of round 4 the re-rank ran here, per wave, beside the other workgroup's
-    // main loop whose VALU and LDS ports it shares: 0.06 - 0.075 of 0.605 ms, measured against a build without it; in a kernel of its
-    // own it has the chip to itself.)  ratio2m = ratio^2 (1 + 2^-20); +inf switches the screen off (the knn2 entry points).
+    // items k, k + 1 and the pair index of item k + 2 (the table look-ups run two items ahead, the pair descriptors one)
+    int lb_c = lb_of(0), lb_n = lb_of(1), lb_nn = lb_of(2);
+    if (lb_c < 0) return;
+    int pi_nn = lb_nn >= 0 ? blk_pair[lb_nn] : -1;
+    X1Item cur = make_item(lb_c, blk_pair[lb_c]);
+    X1Item nxt = make_item(lb_n, lb_n >= 0 ? blk_pair[lb_n] : -1);
+#ifdef ESFM_X1_TRACE
+    uint64_t trA = __builtin_amdgcn_s_memrealtime();
+    const uint64_t tr_first = trA;
+    int tr_setup = 0, tr_loop = 0, tr_tail = 0, tr_clk = 0;
+#endif
+    stage_issue(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_commit(0);
+    __syncthreads();
+
     static_assert(K == 4, "a survivor entry carries a lane's keys as one 16-byte piece");
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));     // the key's mantissa bits under the position code
-    const double sqrt_tmax = sqrt((double)tmax);
-#ifdef ESFM_X1_NOTAIL
-    if (n_pairs >= 0) return;             // (timing experiments: the kernel without its tail)
+    for (int k = 0;; ++k) {
+        const int par = k & 1;
+        const int nq = cur.nq, nt = cur.nt, pi = cur.pi;
+        const int ntiles = (nt + TT - 1) / TT;
+#ifdef ESFM_X1_TRACE
+        { const uint64_t t = __builtin_amdgcn_s_memrealtime(); tr_setup += (int)(t - trA); trA = t; }
+        const uint64_t clk0 = __builtin_amdgcn_s_memtime();
 #endif
-    int nsurv = 0;
-    int myslot[NS];
-    float qn_s[NS], e1_s[NS];
-    {
-        float rq_s[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int qrow = qbase + 32 * s + j;
-            qn_s[s] = norms[pd.q_row0 + (qrow < nq ? qrow : 0)];
-            rq_s[s] = rho_q[pd.q_row0 + (qrow < nq ? qrow : 0)];
+        if (ntiles > 0) {
+            const u32x4 trsrc = raw_buffer_rsrc(hi_t + (size_t)cur.t_row0 * HS, (uint32_t)nt * (HS * 16));
+            const u32x4 nrsrc = raw_buffer_rsrc(norms + cur.t_row0, (uint32_t)nt * 4u);
+            asm volatile(ESFM_L2X1_SEGMENT_ASM
+                         :
+                         : "v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[0][2]), "v"(bq[0][3]), "v"(bq[1][0]), "v"(bq[1][1]), "v"(bq[1][2]), "v"(bq[1][3]),
+                           "v"(bq[2][0]), "v"(bq[2][1]), "v"(bq[2][2]), "v"(bq[2][3]), "v"(bq[3][0]), "v"(bq[3][1]), "v"(bq[3][2]), "v"(bq[3][3]),
+                           "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
+                         : ESFM_L2X1_SEGMENT_CLOBBERS);
         }
+        rederive();
+        st_norm[0] = st_norm[1] = st_qn[0] = st_qn[1] = st_rq[0] = st_rq[1] = st_m = st_r = 0.f;      // (dead here: not carried through the block)
+#ifdef ESFM_X1_TRACE
+        { const uint64_t t = __builtin_amdgcn_s_memrealtime(); tr_loop += (int)(t - trA); trA = t; tr_clk += (int)((__builtin_amdgcn_s_memtime() - clk0) >> 4); }
+#endif
+        // the block left this thread's keys in LDS: key i of set s at float (K s + i) * 256 + tid  (replaced when no tile ran)
+        float keys[NS][K];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int qrow = qbase + 32 * s + j;
-            const bool qvalid = qrow < nq;
-            const float v0 = keys[s][0], v1 = keys[s][1];
-            const float p0 = __shfl_xor(v0, 32), p1 = __shfl_xor(v1, 32);
-            const float k0 = fminf(v0, p0), kb = fminf(fmaxf(v0, p0), fminf(v1, p1));     // the two smallest of the 2 K keys
-            const double qn = (double)qn_s[s];
-            const double e1 = l2x1_e1(qn, (double)rq_s[s], sqrt_tmax, (double)tmax, (double)rmax);
-            const double L0 = qn + (double)k0 - e1 - fabs((double)k0) * kTrunc;
-            const double U1 = qn + (double)kb + e1 + fabs((double)kb) * kTrunc;
-            const bool rej = qvalid && (L0 >= ratio2m * U1);                              // false on NaN / inf: re-rank
-            const bool surv = qvalid && !rej;
-            const uint32_t m = (uint32_t)__ballot(surv);                                  // lanes 0 .. 31 (both halves agree)
-            myslot[s] = surv ? nsurv + __popc(m & ((1u << j) - 1u)) : -1;
-            float ef = (float)e1;
-            if ((double)ef < e1) ef = nextafterf(ef, FLT_MAX);                            // rounded up (NaN stays NaN: every compare false)
-            e1_s[s] = ef;
-            if (h == 0 && rej) {
-                const size_t o = 2 * ((size_t)pd.out_off + qrow);
-                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(-2, -2);
-                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(FLT_MAX, FLT_MAX);
-                if (rejected) {          // audit of the screen: what it dropped, on the global list
-                    const int slot = atomicAdd(&counters[0], 1);
-                    if (slot < flag_cap) { rejected[2 * slot] = pi; rejected[2 * slot + 1] = qrow; }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                keys[s][i] = reinterpret_cast<const float *>(smem)[(K * s + i) * 256 + tid];
+            }
+        }
+        if (ntiles == 0) {
+            float big;
+            asm volatile("s_mov_b32 %0, 0x7f61b1e6" : "=s"(big));
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < K; ++i) keys[s][i] = big;
+        }
+        const float tmax = fmaxf(fmaxf(lds_red[par * 8 + 0], lds_red[par * 8 + 1]), fmaxf(lds_red[par * 8 + 2], lds_red[par * 8 + 3]));
+        const float rmax = fmaxf(fmaxf(lds_red[par * 8 + 4], lds_red[par * 8 + 5]), fmaxf(lds_red[par * 8 + 6], lds_red[par * 8 + 7]));
+        const int qbase = cur.qblk * QB + wave * 32 * NS;
+        float qn_s[NS], rq_s[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { qn_s[s] = lds_qn[par * QB + wave * 32 * NS + 32 * s + j]; rq_s[s] = lds_rq[par * QB + wave * 32 * NS + 32 * s + j]; }
+        __syncthreads();                  // the ring (and the keys in it) is free: every wave has left the main loop and read its keys
+#ifdef ESFM_X1_NOTAIL
+        const bool notail = n_blocks >= 0;             // (timing experiments: the kernel without its tail)
+#else
+        const bool notail = false;
+#endif
+
+        // ---- the RATIO SCREEN (round 4), all that is left of this kernel's tail.  The reference keeps a query only if d0 < ratio d1
+        // (feature_matching.cpp:133); everything else is dropped one kernel later, and on the metric's workload that is > 90 % of the
+        // queries.  With k0 <= kb the two smallest of a query's 2 K group keys (two groups, hence two different train rows: the groups'
+        // minima) and E1 the pass's bound on |(|q|^2 + score) - D| (D = the canonical float d^2), kTrunc the key's truncation:
+        //     every train row has   D >= L0 = |q|^2 + k0 - kTrunc |k0| - E1        (k0 is the smallest key of all groups),
+        //     two rows have         D <= U1 = |q|^2 + kb + kTrunc |kb| + E1,
+        // so the nearest has D0 >= L0 and the second nearest D1 <= U1.  If L0 >= ratio^2 (1 + 2^-20) U1 then sqrtf(D0) >= ratio sqrtf(D1)
+        // whatever the two roundings of sqrtf and the double product do (their relative error is < 2^-22 together): the query cannot
+        // pass the test.  It gets a marker (train index -2) and nothing more is done for it.  A SURVIVOR leaves one 48-byte entry -- its
+        // 2 K keys, its row, |q|^2 and E1 (as a float, rounded up) -- in the pair's slice of surv_list; l2_finish_kernel re-ranks the
+        // survivors' kept groups exactly.  (Until the middle of round 4 the re-rank ran here, per wave, beside the other workgroup's
+        // main loop whose VALU and LDS ports it shares: 0.06 - 0.075 of 0.605 ms, measured against a build without it; in a kernel of its
+        // own it has the chip to itself.)  ratio2m = ratio^2 (1 + 2^-20); +inf switches the screen off (the knn2 entry points).
+        const double sqrt_tmax = sqrt((double)tmax);
+        int nsurv = 0;
+        int myslot[NS];
+        float e1_s[NS];
+        uint32_t rejmask = 0;
+        if (!notail) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int qrow = qbase + 32 * s + j;
+                const bool qvalid = qrow < nq;
+                const float v0 = keys[s][0], v1 = keys[s][1];
+                const float p0 = other_half(v0, h != 0), p1 = other_half(v1, h != 0);
+                const float k0 = fminf(v0, p0), kb = fminf(fmaxf(v0, p0), fminf(v1, p1));     // the two smallest of the 2 K keys
+                const double qn = (double)qn_s[s];
+                const double e1 = l2x1_e1(qn, (double)rq_s[s], sqrt_tmax, (double)tmax, (double)rmax);
+                const double L0 = qn + (double)k0 - e1 - fabs((double)k0) * kTrunc;
+                const double U1 = qn + (double)kb + e1 + fabs((double)kb) * kTrunc;
+                const bool rej = qvalid && (L0 >= ratio2m * U1);                              // false on NaN / inf: re-rank
+                const bool surv = qvalid && !rej;
+                const uint32_t m = (uint32_t)__ballot(surv);                                  // lanes 0 .. 31 (both halves agree)
+                myslot[s] = surv ? nsurv + __popc(m & ((1u << j) - 1u)) : -1;
+                float ef = (float)e1;
+                if ((double)ef < e1) ef = __uint_as_float(__float_as_uint(ef) + 1u);          // rounded up: e1 > 0, and ef < e1 makes ef finite (NaN: every compare false)
+                e1_s[s] = ef;
+                if (rej) rejmask |= 1u << s;
+                nsurv += __popc(m);
+            }
+        }
+        // the one round trip of the tail -- the survivors' place in the pair's slice -- and the next item's set-up share their latency
+        int base = 0;
+        if (nsurv > 0 && lane == 0) { base = atomicAdd(&surv_cnt[pi], nsurv); atomicAdd(&counters[2], nsurv); }
+        const bool more = nxt.pi >= 0;
+        const int lb_3 = lb_of(k + 3);
+        int pi_3 = -1;
+        X1Item nn = {0, 0, 0, 0, 0, -1, 0};
+        if (more) {
+            stage_issue(nxt);
+            nn = make_item(lb_nn, pi_nn);
+            pi_3 = lb_3 >= 0 ? blk_pair[lb_3] : -1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) stage_commit(par ^ 1);
+        // the tail's stores go out last: nothing waits for them (the main loop's first hand-over, eight steps on, finds them done)
+        if (!notail) {
+            float fltmax;        // (FLT_MAX out of an SGPR written here, like kBig in the set-up)
+            asm volatile("s_mov_b32 %0, 0x7f7fffff" : "=s"(fltmax));
+            int minus2;
+            asm volatile("s_mov_b32 %0, -2" : "=s"(minus2));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int qrow = qbase + 32 * s + j;
+                if (h == 0 && ((rejmask >> s) & 1u)) {
+                    const size_t o = 2 * ((size_t)cur.out_off + qrow);
+                    *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(minus2, minus2);
+                    *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(fltmax, fltmax);
+                    if (rejected) {          // audit of the screen: what it dropped, on the global list
+                        const int slot = atomicAdd(&counters[0], 1);
+                        if (slot < flag_cap) { rejected[2 * slot] = pi; rejected[2 * slot + 1] = qrow; }
+                    }
                 }
             }
-            nsurv += __popc(m);
-        }
-    }
-    if (nsurv > 0) {
-        int base = 0;
-        if (lane == 0) { base = atomicAdd(&surv_cnt[pi], nsurv); atomicAdd(&counters[2], nsurv); }
-        base = __builtin_amdgcn_readfirstlane(base);
-        float4 *ent = surv_list + 3 * ((size_t)pd.out_off + base);                       // (a pair's slice holds nq entries: it cannot overflow)
+            if (nsurv > 0) {
+                base = __builtin_amdgcn_readfirstlane(base);
+                float4 *ent = surv_list + 3 * ((size_t)cur.out_off + base);                   // (a pair's slice holds nq entries: it cannot overflow)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (myslot[s] >= 0) {
-                ent[3 * myslot[s] + h] = make_float4(keys[s][0], keys[s][1], keys[s][2], keys[s][3]);
-                if (h == 0) ent[3 * myslot[s] + 2] = make_float4(__int_as_float(qbase + 32 * s + j), qn_s[s], e1_s[s], 0.f);
+                for (int s = 0; s < NS; ++s) {
+                    if (myslot[s] >= 0) {
+                        ent[3 * myslot[s] + h] = make_float4(keys[s][0], keys[s][1], keys[s][2], keys[s][3]);
+                        if (h == 0) ent[3 * myslot[s] + 2] = make_float4(__int_as_float(qbase + 32 * s + j), qn_s[s], e1_s[s], 0.f);
+                    }
+                }
             }
         }
+#ifdef ESFM_X1_TRACE
+        { const uint64_t t = __builtin_amdgcn_s_memrealtime(); tr_tail += (int)(t - trA); trA = t; }
+#endif
+        if (!more) break;
+        __syncthreads();                  // the next item's norms, maxima and query norms are in LDS, its first tile has landed
+        cur = nxt; nxt = nn; lb_nn = lb_3; pi_nn = pi_3;
     }
+#ifdef ESFM_X1_TRACE
+    if (lane == 0) {     // per-wave stage times, 10-ns ticks (scratch/x1_trace.py)
+        atomicAdd(&counters[8], tr_setup); atomicAdd(&counters[9], tr_loop); atomicAdd(&counters[10], tr_tail); atomicAdd(&counters[11], 1);
+        atomicMax(&counters[12], (int)(trA & 0x3fffffffu)); atomicMax(&counters[13], 0x40000000 - (int)(tr_first & 0x3fffffffu));
+        atomicMax(&counters[14], (int)(trA - tr_first)); atomicAdd(&counters[15], tr_clk >> 4);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2313,11 +2459,12 @@ int l2_query_block(int dim) { return l2_bf16_pass(dim) ? 128 * kL2BfSets : 128; 
 size_t l2_split_bytes(int dim, long long total_rows) { return l2_bf16_pass(dim) ? (size_t)512 * (size_t)std::max(total_rows, 1LL) : 0; }
 
 // one-product pass scratch: [bf16(t) image: 128 B/row][bf16(-2 q) image: 128 B/row][rho_t: 4 B/row][rho_q: 4 B/row]
-size_t l2_hi_bytes(long long total_rows) { return (size_t)(128 + 128 + 4 + 4) * (size_t)std::max(total_rows, 1LL); }
+// bf16(t) image, bf16(-2 q) image (128 B per row each), rho_t, rho_q (4 B per row each), per 256-row block max |row|^2 and max rho_t
+size_t l2_hi_bytes(long long total_rows) { const size_t n = (size_t)std::max(total_rows, 1LL); return (128 + 128 + 4 + 4) * n + 8 * ((n + 255) / 256); }
 static inline char *l2_hi_part(void *hi, long long total_rows, int part)
 {
     const size_t n = (size_t)std::max(total_rows, 1LL);
-    const size_t off[4] = {0, 128 * n, 256 * n, 260 * n};
+    const size_t off[5] = {0, 128 * n, 256 * n, 260 * n, 264 * n};
     return static_cast<char *>(hi) + off[part];
 }
 bool l2_one_product_pass()
@@ -2340,6 +2487,11 @@ int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows
                        hi ? reinterpret_cast<float *>(l2_hi_part(hi, total_rows, 2)) : nullptr,
                        hi ? reinterpret_cast<float *>(l2_hi_part(hi, total_rows, 3)) : nullptr, pair_cnt2);
     ESFM_HIP_TRY(hipGetLastError());
+    if (hi && total_rows > 0) {
+        hipLaunchKernelGGL(l2_blockmax_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, norms,
+                           reinterpret_cast<const float *>(l2_hi_part(hi, total_rows, 2)), total_rows, reinterpret_cast<float2 *>(l2_hi_part(hi, total_rows, 4)));
+        ESFM_HIP_TRY(hipGetLastError());
+    }
     return ESFM_OK;
 }
 
@@ -2362,24 +2514,30 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 // the ratio screen's constant: ratio^2 (1 + 2^-20); a ratio that is not a finite number >= 0 switches the screen off
 static inline double l2_ratio2m(double ratio) { return (ratio >= 0.0 && ratio < 1.0e150) ? ratio * ratio * (1.0 + 1.0 / 1048576.0) : (double)INFINITY; }
 
-int l2_x1_query_block() { return 128 * ESFM_L2X1_SETS; }
+int l2_x1_query_block() { return l2x1_query_block_c; }
 bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS - 2)) * 32; }   // the position code names a 32-row step
 
-int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
-                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
+int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                         const int32_t *blk_pair, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
                          int32_t *surv_cnt, void *surv_list, double ratio, int32_t *rejected,
                          int32_t *zero_a, int32_t *zero_b, int zero_n, int32_t *zero_counters)
 {
     if (n_blocks <= 0) return ESFM_OK;
-    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 32;   // ring of bf16 tiles, their norms, two reductions
+    // ring of bf16 tiles, their norms, two sets of reductions, two sets of query norms and residual norms
+    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 64 + 4 * l2x1_query_block_c * 4;
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     // (set on every launch, like the other large-LDS kernels: the attribute belongs to the current device)
     ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_knn_bf16x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void *h = const_cast<void *>(hi);
-    hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(n_blocks), dim3(256), lds, st, desc,
+    // persistent workgroups, two per CU; the grid a multiple of 8 so that a workgroup's later blocks stay on its XCD
+    static const int forced = [] { const char *e = getenv("ESFM_X1_GRID"); return e ? atoi(e) : 0; }();     // (measurement)
+    const int cap = forced > 0 ? forced : std::max(8, 2 * num_cu / 8 * 8);
+    const int grid = n_blocks <= cap ? n_blocks : cap;
+    hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(grid), dim3(256), lds, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
-                       pairs, n_pairs, knn_idx, knn_dist, counters, flag_cap, surv_cnt, reinterpret_cast<float4 *>(surv_list), l2_ratio2m(ratio), rejected,
+                       reinterpret_cast<const float2 *>(l2_hi_part(h, total_rows, 4)),
+                       pairs, blk_pair, n_blocks, knn_idx, knn_dist, counters, flag_cap, surv_cnt, reinterpret_cast<float4 *>(surv_list), l2_ratio2m(ratio), rejected,
                        zero_a, zero_b, zero_n, zero_counters);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;

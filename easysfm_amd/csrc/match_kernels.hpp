@@ -38,8 +38,10 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 // zero_a / zero_b [0, zero_n), zero_counters[0, 16): the other phase's per-pair and global counters, zeroed for the next call.
 size_t l2_hi_bytes(long long total_rows);
 size_t l2_survivor_entry_bytes();
-int launch_l2_knn_bf16x1(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
-                         int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
+// blk_pair[b]: the pair of the launch's b-th 512-query block (pair p owns blocks [blk_off2[p], blk_off2[p + 1])); the grid is
+// min(n_blocks, 2 num_cu) persistent workgroups.
+int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
+                         const int32_t *blk_pair, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
                          int32_t *surv_cnt, void *surv_list, double ratio, int32_t *rejected,
                          int32_t *zero_a, int32_t *zero_b, int zero_n, int32_t *zero_counters);
 // everything behind it in one launch (l2_finish_kernel): exact re-rank of the survivors (uncertified / undecided ones on unc_cnt /

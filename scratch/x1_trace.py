@@ -1,4 +1,4 @@
-# per-wave stage times of l2_knn_bf16x1_kernel's tail (build with -DESFM_X1_TRACE, ESFM_LIB=...): s_memrealtime ticks of 10 ns
+# per-wave stage times of l2_knn_bf16x1_kernel (build with -DESFM_X1_TRACE, ESFM_LIB=...): s_memrealtime ticks of 10 ns
 import sys; sys.path.insert(0, '.')
 import ctypes as C, numpy as np, easysfm_amd as E
 from easysfm_amd import synth, _lib
@@ -10,5 +10,8 @@ pm.ctx.synchronize()
 out = (C.c_int32 * 16)()
 _lib.check(_lib.lib().esfm_match_debug_counters(pm.ctx.handle, out))
 c = list(out); w = max(c[11], 1)
-print('waves', c[11], 'virtual sets/wave', c[12] / w, 'survivors/wave', c[13] / w)
-print('us per wave: keys+barrier %.2f  phase A %.2f  phase B %.2f' % (c[8] / w / 100, c[9] / w / 100, c[10] / w / 100))
+print('waves', c[11])
+n = 2400 * 4   # items x waves
+print('us per item and wave: set-up wait %.2f  main loop %.2f  tail + next set-up %.2f' % (c[8] / n / 100, c[9] / n / 100, c[10] / n / 100))
+print('first wave start -> last wave end %.1f us; longest wave %.1f us' % ((c[12] - (0x40000000 - c[13])) / 100, c[14] / 100))
+print('s_memtime ticks per 10-ns tick inside the main loop: %.3f' % (c[15] * 256.0 / c[9]))
