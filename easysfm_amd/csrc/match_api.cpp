@@ -180,6 +180,7 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
                     esfm::KernelTimer tm(ctx, ESFM_K_L2_KNN);
                     if (int rc = esfm::launch_l2_knn_bf16x1(st, ctx->num_cu, desc, ctx->l2_hi.ptr, plan.total_rows, ctx->norms.as<float>(), dev_tab,
                                                             blk_pair_of(dev_tab, n_pairs), plan.n_blocks2, knn_idx, knn_dist, cur_counters, (int)cap64, cur_surv, ctx->surv_list.ptr, ratio,
+                                                            /* markers: only where something reads the table itself */ mo == nullptr || ctx->l2_audit == 3 || ctx->l2_audit == 4,
                                                             ctx->l2_audit == 4 ? ctx->flagged.as<int32_t>() : nullptr, oth_unc, oth_surv,
                                                             ctx->l2_phase_pairs[1 - ph], oth_counters))
                         return rc;

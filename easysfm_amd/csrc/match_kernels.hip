@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
                                                                int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist,
                                                                int32_t *__restrict__ counters, int flag_cap,
                                                                int32_t *__restrict__ surv_cnt, float4 *__restrict__ surv_list,
-                                                               double ratio2m, int32_t *__restrict__ rejected,
+                                                               double ratio2m, int markers, int32_t *__restrict__ rejected,
                                                                int32_t *__restrict__ zero_a, int32_t *__restrict__ zero_b, int zero_n,
                                                                int32_t *__restrict__ zero_counters)
 {
@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int qrow = qbase + 32 * s + j;
-                if (h == 0 && ((rejmask >> s) & 1u)) {
+                if (markers && h == 0 && ((rejmask >> s) & 1u)) {
                     const size_t o = 2 * ((size_t)cur.out_off + qrow);
                     *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(minus2, minus2);
                     *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(fltmax, fltmax);
@@ -1340,6 +1340,70 @@ __device__ __forceinline__ void ratio_compact_pair(const PairDesc &pd, const int
 #pragma unroll
         for (int u = 0; u < kRatioPer; ++u) {
             if (pass[u]) { query_idx[o] = qa + u; train_idx[o] = ti[u]; distance[o] = d0[u]; ++o; }
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < THREADS / 64; ++w) t += s_wave[w]; *s_base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out_p = *s_base;
+}
+
+// The same over the ratio screen's SURVIVORS only (l2_finish_kernel when the screen ran): whatever is not on the pair's survivor list
+// has been dropped by the screen and has no record at all (the one-product pass writes no markers outside the audit modes: 16 bytes
+// per query it does not store and this stage does not read -- 19.6 of 19.7 MB per step on the metric's workload).  A sweep of
+// THREADS * 16 queries: the survivors' rows set bits in an LDS bitmap, a thread looks at its 16 consecutive queries' bits and reads
+// the records of the set ones; order and compaction as above.
+template <int THREADS>
+__device__ __forceinline__ void ratio_compact_pair_sparse(const PairDesc &pd, const float4 *__restrict__ ent, int nsv,
+                                                          const int32_t *__restrict__ knn_idx, const float *__restrict__ knn_dist,
+                                                          double ratio, int32_t *__restrict__ query_idx, int32_t *__restrict__ train_idx,
+                                                          float *__restrict__ distance, int32_t *__restrict__ n_out_p,
+                                                          uint32_t *s_bits /* [THREADS / 2] */, int *s_wave /* [THREADS / 64] */, int *s_base)
+{
+    constexpr int PER = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *s_base = 0;
+    for (int q0 = 0; q0 < pd.nq; q0 += THREADS * PER) {
+        for (int w = tid; w < THREADS / 2; w += THREADS) s_bits[w] = 0u;
+        __syncthreads();
+        for (int k = tid; k < nsv; k += THREADS) {
+            const uint32_t r = (uint32_t)(__float_as_int(ent[3 * (size_t)k + 2].x) - q0);
+            if (r < (uint32_t)(THREADS * PER)) atomicOr(&s_bits[r >> 5], 1u << (r & 31));
+        }
+        __syncthreads();
+        const int qa = q0 + tid * PER;
+        uint32_t bits = (s_bits[tid >> 1] >> ((tid & 1) * PER)) & 0xFFFFu;
+        int ti[PER]; float d0[PER];
+        uint32_t passm = 0;
+        for (uint32_t b = bits; b; b &= b - 1) {
+            const int u = __ffs(b) - 1;
+            const size_t o = 2 * ((size_t)pd.out_off + qa + u);
+            uint32_t iv[4];          // (records written by other workgroups of this launch: read past this XCD's L2)
+            asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(*reinterpret_cast<uint2 *>(iv)), "=&v"(*reinterpret_cast<uint2 *>(iv + 2)) : "v"(knn_idx + o), "v"(knn_dist + o) : "memory");
+            const int i0 = (int)iv[0], i1 = (int)iv[1];
+            const float dd0 = __uint_as_float(iv[2]), dd1 = __uint_as_float(iv[3]);
+            const bool pass = qa + u < pd.nq && (i0 >= 0) && (i1 == -3 || (i1 >= 0 && (double)dd0 < ratio * (double)dd1));
+            // (static indexing keeps ti / d0 in registers)
+#pragma unroll
+            for (int e = 0; e < PER; ++e) if (e == u) { ti[e] = i0; d0[e] = dd0; }
+            passm |= pass ? (1u << u) : 0u;
+        }
+        const int cnt = __popc(passm);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = *s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        size_t o = (size_t)pd.out_off + off + (incl - cnt);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if ((passm >> u) & 1u) { query_idx[o] = qa + u; train_idx[o] = ti[u]; distance[o] = d0[u]; ++o; }
         }
         __syncthreads();
         if (tid == 0) { int t = 0; for (int w = 0; w < THREADS / 64; ++w) t += s_wave[w]; *s_base += t; }
@@ -1866,7 +1930,13 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
 #else
     if (do_ratio)
 #endif
-        ratio_compact_pair<kFinThreads, 4096 / kFinThreads, true>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + p, s_wave, &s_base);
+    {
+        if (ratio2m < 1.0e300)            // the screen ran: only its survivors have records
+            ratio_compact_pair_sparse<kFinThreads>(pd, surv_list + 3 * (size_t)pd.out_off, min(surv_cnt[p], nq), knn_idx, knn_dist, ratio, query_idx, train_idx,
+                                                   distance, n_out + p, reinterpret_cast<uint32_t *>(fin_smem), s_wave, &s_base);
+        else
+            ratio_compact_pair<kFinThreads, 4096 / kFinThreads, true>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + p, s_wave, &s_base);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2519,7 +2589,7 @@ bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS -
 
 int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          const int32_t *blk_pair, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
-                         int32_t *surv_cnt, void *surv_list, double ratio, int32_t *rejected,
+                         int32_t *surv_cnt, void *surv_list, double ratio, bool markers, int32_t *rejected,
                          int32_t *zero_a, int32_t *zero_b, int zero_n, int32_t *zero_counters)
 {
     if (n_blocks <= 0) return ESFM_OK;
@@ -2537,7 +2607,7 @@ int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const vo
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),
                        reinterpret_cast<const float2 *>(l2_hi_part(h, total_rows, 4)),
-                       pairs, blk_pair, n_blocks, knn_idx, knn_dist, counters, flag_cap, surv_cnt, reinterpret_cast<float4 *>(surv_list), l2_ratio2m(ratio), rejected,
+                       pairs, blk_pair, n_blocks, knn_idx, knn_dist, counters, flag_cap, surv_cnt, reinterpret_cast<float4 *>(surv_list), l2_ratio2m(ratio), markers ? 1 : 0, rejected,
                        zero_a, zero_b, zero_n, zero_counters);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;

@@ -32,7 +32,8 @@ int launch_l2_split_bf16(hipStream_t st, const float *desc, long long total_rows
 int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, long long total_rows, const float *norms, const PairDesc *pairs,
                        int n_pairs, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *flagged, int32_t *counters, int flag_cap,
                        int32_t *pair_cnt, int32_t *pair_list);
-// one-product pass (64-float rows): distance pass + ratio screen.  Queries that provably fail d0 < ratio d1 get train index -2 (+inf:
+// one-product pass (64-float rows): distance pass + ratio screen.  Queries that provably fail d0 < ratio d1 get train index -2 if
+// `markers` is set -- otherwise nothing: l2_finish_kernel's ratio stage walks the survivors only -- (+inf:
 // screen off); every other query leaves a survivor entry (l2_survivor_entry_bytes() each, pair p's at surv_list + out_off[p]
 // entries, surv_cnt[p] of them; counters[2] counts them).  rejected != NULL (audit): the screen's rejections on that list, counters[0].
 // zero_a / zero_b [0, zero_n), zero_counters[0, 16): the other phase's per-pair and global counters, zeroed for the next call.
@@ -42,7 +43,7 @@ size_t l2_survivor_entry_bytes();
 // min(n_blocks, 2 num_cu) persistent workgroups.
 int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          const int32_t *blk_pair, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
-                         int32_t *surv_cnt, void *surv_list, double ratio, int32_t *rejected,
+                         int32_t *surv_cnt, void *surv_list, double ratio, bool markers, int32_t *rejected,
                          int32_t *zero_a, int32_t *zero_b, int zero_n, int32_t *zero_counters);
 // everything behind it in one launch (l2_finish_kernel): exact re-rank of the survivors (uncertified / undecided ones on unc_cnt /
 // unc_list with their thresholds in knn_d2; counters[1] counts them), threshold-filter second pass, brute force of overflowed chunks
