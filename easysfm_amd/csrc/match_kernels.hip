@@ -907,23 +907,24 @@ __device__ __forceinline__ double l2x1_e1(double qn, double rq, double sqrt_tmax
 }
 
 // ---------------------------------------------------------------------------------------------
-// The ONE-product distance pass (round 3): q.t ~ bf16(q).bf16(t), four v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64 tile instead of
-// twelve.  Everything else is the machinery of l2_knn_bf16_kernel -- group-of-four fold, exact re-rank of the kept groups in the
-// oracle's order, certificate -- with these changes:
-//  * the operand rounding is part of the certificate's bound.  With B = bf16(-2 q), a = bf16(t), rB = |(-2 q) - B|_2 and
+// The ONE-product distance pass (round 3; reshaped in round 4): q.t ~ bf16(q).bf16(t), four v_mfma_f32_32x32x16_bf16 per 32 x 32 x 64
+// tile instead of the three-product pass's twelve, a fused fold that keeps the K = ESFM_L2X1_KEEP smallest GROUP keys per lane and
+// query set (groups of ESFM_L2X1_GRP results, the position in the low mantissa bits), and a ratio screen on those keys.
+//  * the operand rounding is part of every bound.  With B = bf16(-2 q), a = bf16(t), rB = |(-2 q) - B|_2 and
 //    rho_t = |t - a|_2 (both measured per row by l2_split_bf16_kernel):  |(-2 q).t - B.a| <= rB |t| + |B| rho_t, so
-//        E1 = (rB T + (2 |q| + rB) R) (1 + 2^-9) + 2^-15 (|q|^2 + max|t|^2),    T = max |t|,  R = max rho_t  over the train set,
-//    bounds |(|q|^2 + score) - d^2| for every train row (the 2^-15 term is the three-product pass's whole budget: norms, MFMA
-//    accumulation, the canonical distance; it has room to spare now that the dropped split terms are gone).  For unit-norm
-//    descriptors E1 ~ 0.008 against 6e-5: the pass keeps K = ESFM_L2X1_KEEP groups per lane instead of 3, which pushes tau -- the
+//        E1 = (rB T + (2 |q| + rB) R) (1 + 2^-9) + 2^-15 (|q|^2 + max|t|^2) + 2^-118,   T = max |t|,  R = max rho_t  over the train set,
+//    bounds |(|q|^2 + score) - d^2| for every train row (l2x1_e1; the 2^-15 term is the three-product pass's whole budget: norms, MFMA
+//    accumulation, the canonical distance).  For unit-norm descriptors E1 ~ 0.008 against 6e-5: K = 4 groups per lane push tau -- the
 //    bound on every row outside the kept groups -- about as many ranks out as the larger error needs (simulated on M-SURF-4k,
 //    scratch/sim_bf16x1_cert.py: K = 3 leaves 6.9 % of the queries uncertified, K = 4 0.6 %, K = 6 0.01 %; the reference's own
 //    fountain descriptors 37 % / 15 % / 3.6 %);
-//  * what it cannot certify goes to the pair's list and from there through l2_knn_bf16_kernel<LIST> (three products, eps 2^-15),
-//    whose own failures take the exact re-scan as before -- the result stays bit-identical to the oracle whatever the data;
-//  * 512 queries per workgroup (four sets of 32 per wave), a ring of four 16-KiB tiles of bf16(t) rows, 13-bit position codes in
-//    the group keys (no segments, no master list): l2x1_segment_gfx950.inc is the whole main loop.  Train sets of more than
-//    65536 rows do not fit the code and skip this pass (l2_x1_supported).
+//  * this kernel ends with the keys: the screen drops the queries that provably fail the ratio test, every other query leaves a
+//    48-byte survivor entry.  l2_finish_kernel does the rest -- exact re-rank of the kept groups in the oracle's order, certificate,
+//    threshold-filter pass over what stays uncertified, brute force of what overflows that, ratio test and compaction -- so the
+//    result stays bit-identical to the oracle whatever the data;
+//  * 512 queries per item (four sets of 32 per wave), a ring of two 32-KiB tiles of bf16(t) rows fed by LDS-DMA, 12-bit position
+//    codes in the group keys: l2x1_segment_gfx950.inc (gen_l2x1_segment_asm.py) is the whole main loop.  Train sets the code cannot
+//    number skip this pass (l2_x1_supported).
 constexpr int l2x1_query_block_c = 128 * ESFM_L2X1_SETS;
 // Cross-lane moves without an address register (__shfl_xor goes through ds_bpermute_b32, whose lane addresses the compiler hoists out
 // of l2_knn_bf16x1_kernel's item loop and then has to keep in scratch memory across the main loop's asm block).
@@ -1413,7 +1414,7 @@ __device__ __forceinline__ void ratio_compact_pair_sparse(const PairDesc &pd, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// Everything behind the one-product pass's main loop and ratio screen in ONE launch (round 4; round 3 had three: l2_refine_kernel,
+// Everything behind the one-product pass's main loop and ratio screen in ONE launch (round 4; round 3 had three: a threshold-filter kernel,
 // l2_rescan64_pairs_kernel, ratio_compact_kernel, and every launch boundary costs 5 - 10 us on this part):
 //   (1) the exact RE-RANK of the screen's survivors (surv_cnt / surv_list: one 48-byte entry per survivor): the rows of the kept
 //       groups in the oracle's order, the certificate, and the ratio verdicts that make most second neighbours unnecessary

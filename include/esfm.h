@@ -88,7 +88,7 @@ typedef enum esfm_kernel_id {
     ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
     ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
     ESFM_K_ORB_FAST = 12,     /* orb_fast_kernel: FAST-9/16 score of every pyramid pixel          */
-    ESFM_K_L2_SECOND = 13,    /* l2_refine_kernel: threshold-filter pass over the queries the one-product pass left uncertified */
+    ESFM_K_L2_SECOND = 13,    /* l2_finish_kernel: everything behind the one-product pass (re-rank of the ratio screen's survivors, threshold filter, ratio test, compaction) */
     ESFM_K_COUNT = 14
 } esfm_kernel_id;
 int esfm_ctx_set_kernel_timing(esfm_ctx *ctx, int enable);
@@ -186,7 +186,7 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
  * exactly (see DESIGN.md "certified re-rank").  For tests and profiling. */
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned);
 /* 64-float descriptors: queries the one-product bf16 pass could not certify and handed to the threshold-filter
- * pass (l2_refine_kernel), of which n_rescanned went on to the exact re-scan.  0 for other widths.  Queries the
+ * pass (inside l2_finish_kernel), of which n_rescanned went on to the exact re-scan.  0 for other widths.  Queries the
  * ratio screen dropped (esfm_match_*: provably d0 >= ratio d1) are in neither count. */
 int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass);
 
