@@ -1514,6 +1514,9 @@ __device__ __forceinline__ void finish_bruteforce_chunk(const float *__restrict_
 // On the metric's workload nearly every survivor is a true match whose best group alone decides it: one transfer round trip.  A
 // query that ends neither certified nor decided goes on the pair's list for the threshold filter, with an upper bound of its
 // second-best d^2 as the filter's threshold.
+#ifdef ESFM_FIN_TRACE
+__shared__ int s_fin_tr[4][4];         // per wave: ticks waiting for transfers, ticks behind the wait, rounds (flushed once per wave: atomics per round distort what they measure)
+#endif
 struct FinRerankArgs {
     const float4 *ent;                 // the pair's survivor entries
     int nsv;                           // ... their number
@@ -1597,7 +1600,7 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
         lds_dma_wait();
 #ifdef ESFM_FIN_TRACE
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) atomicAdd(&A.counters[12], (int)(rt1 - rt0));
+        if (lane == 0) s_fin_tr[threadIdx.x >> 6][0] += (int)(rt1 - rt0);
 #endif
         // the rows stay in LDS and are read piece by piece (the query rows' slots are not touched by the later rounds)
         const float da = l2sqr64_canonical_lds(lds_land + (uint32_t)(56 + qs) * 256u, (uint32_t)((56 + qs) & 15) * 16u, lds_land + (uint32_t)lane * 256u, (uint32_t)(lane & 15) * 16u);
@@ -1617,7 +1620,7 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
             m0 = lo;
         }
 #ifdef ESFM_FIN_TRACE
-        if (lane == 0) { atomicAdd(&A.counters[11], 1); atomicAdd(&A.counters[13], (int)(__builtin_amdgcn_s_memrealtime() - rt1)); }           // rounds, ticks after the wait
+        if (lane == 0) { s_fin_tr[threadIdx.x >> 6][2] += 1; s_fin_tr[threadIdx.x >> 6][1] += (int)(__builtin_amdgcn_s_memrealtime() - rt1); }           // rounds, ticks after the wait
 #endif
         if (screen && !last) {
             const float nk = fminf(nkey, tau);                   // the smallest key of anything not evaluated yet
@@ -1727,6 +1730,9 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
     // order is pair-major over the pairs SORTED BY TRAIN SET: the S workgroups of a pair and the pairs of one train set run on one
     // XCD, whose L2 (4 MiB) then holds the one or two train sets their row fetches go to -- the re-rank is bound by those fetches
     // (51 k survivors x 9 rows x 256 B per step on the metric's workload).
+#ifdef ESFM_FIN_TRACE
+    const unsigned long long ft_in = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int sl = lb % S, p = pair_order[lb / S];
     const PairDesc pd = pairs[p];
@@ -1759,7 +1765,9 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
         int v = sl * NW + wave;
         float4 e0 = entry_of(v, 0), e1 = entry_of(v, 1), e2 = entry_of(v, 2);
 #ifdef ESFM_FIN_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the entries have landed: the set-up chain ends here)
         const unsigned long long ft0 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { s_fin_tr[wave][0] = 0; s_fin_tr[wave][1] = 0; s_fin_tr[wave][2] = 0; }
         int nset = 0;
 #endif
         for (; v < nvs; v += S * NW) {
@@ -1773,16 +1781,24 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
 #ifdef ESFM_FIN_TRACE
         if (lane == 0) {      // (scratch/fin_trace.py: 10-ns ticks of stage 1 per wave, virtual sets, waves)
             atomicAdd(&counters[8], (int)(__builtin_amdgcn_s_memrealtime() - ft0)); atomicAdd(&counters[9], nset); atomicAdd(&counters[10], 1);
+            atomicAdd(&counters[12], s_fin_tr[wave][0]); atomicAdd(&counters[13], s_fin_tr[wave][1]); atomicAdd(&counters[11], s_fin_tr[wave][2]);
+            atomicAdd(&counters[14], (int)(ft0 - ft_in));
         }
 #endif
     }
     // arrive; the last of the pair's S workgroups goes on alone.  Every wave waits for its own write-through stores to be
     // acknowledged before the barrier lets the arrival out.
+#ifdef ESFM_FIN_TRACE
+    const unsigned long long ft_arr = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (S > 1) {
         if (tid == 0) s_last = __hip_atomic_fetch_add(&done[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
         __syncthreads();
+#ifdef ESFM_FIN_TRACE
+        if (lane == 0) atomicAdd(&counters[15], (int)(__builtin_amdgcn_s_memrealtime() - ft_arr));
+#endif
         if (!s_last) return;
         if (tid == 0) __hip_atomic_store(&done[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (everybody has arrived: nobody touches it again in this launch)
     }

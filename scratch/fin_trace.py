@@ -13,3 +13,4 @@ c = list(out)
 print('survivors', c[2], 'waves', c[10], 'virtual sets', c[9], 'rounds', c[11], 'rounds/set %.2f' % (c[11] / max(c[9], 1)))
 print('stage 1 per wave %.2f us, per virtual set %.2f us' % (c[8] / max(c[10], 1) / 100, c[8] / max(c[9], 1) / 100))
 print('per round: transfer wait %.2f us, distance + reduce %.2f us' % (c[12] / max(c[11], 1) / 100, c[13] / max(c[11], 1) / 100))
+print('per wave: kernel entry -> entries landed %.2f us; stores acknowledged + barrier + arrival atomic %.2f us' % (c[14] / max(c[10], 1) / 100, c[15] / max(c[10], 1) / 100))
