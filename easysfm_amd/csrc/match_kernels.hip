@@ -990,12 +990,16 @@ __global__ __launch_bounds__(256, 2) void l2_knn_bf16x1_kernel(const float *__re
     };
     const uint32_t lds_tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_tile);   // LDS byte address
 
-    // ---- A PERSISTENT workgroup (round 4).  The grid is two workgroups per CU; workgroup b takes the 512-query blocks b, b + G,
-    // b + 2 G, ... of the launch (G = gridDim.x, a multiple of 8 when there is more than one round: all of a workgroup's blocks map to
-    // its XCD's contiguous range of the numbering, xcd_remap) and overlaps the memory round trips of block k + 1's set-up -- query
-    // operands, the ring's first tiles, norms, maxima -- with block k's tail.  One workgroup per block (until the middle of round 4)
-    // spent 16 us in front of and 9 us behind an 83-us main loop waiting for four or five dependent round trips (s_memrealtime
-    // stamps), with one other workgroup per CU to fill the matrix pipe meanwhile: 66 % MFMA busy over the launch, 84 % inside the loop.
+    // ---- A workgroup takes the 512-query blocks b, b + G, b + 2 G, ... of the launch (G = gridDim.x, a multiple of 8 when there is
+    // more than one round: all of a workgroup's blocks map to its XCD's contiguous range of the numbering, xcd_remap) and overlaps the
+    // memory round trips of block k + 1's set-up -- query operands, the ring's first tiles, norms, maxima -- with block k's tail.
+    // The launcher's default is G = number of blocks (one block per workgroup, the loop runs once): persistent workgroups, two per
+    // CU, were measured 2 - 4 % SLOWER on the metric's workload and on config 4 (0.517 - 0.540 against 0.498 - 0.513 ms; 191.5 against
+    // 187.9 ms) although they take a block's set-up from 16 us to one round trip -- the hardware's dispatcher refills a CU the
+    // moment a workgroup leaves, whatever the other one is doing, and a lone workgroup runs its main loop 60 % faster, so the set-up
+    // was hidden already; what the static schedule adds is the last round's imbalance.  (ESFM_X1_GRID sets G for measurements; what
+    // the restructuring did buy is the short set-up itself: a block -> pair table instead of nine dependent loads of a binary search,
+    // maxima from a per-256-row table, 5 % on the launch.)
     const int G = gridDim.x;
     auto lb_of = [&](int k) -> int {
         const long long v = (long long)blockIdx.x + (long long)k * G;
@@ -2616,10 +2620,10 @@ int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const vo
     // (set on every launch, like the other large-LDS kernels: the attribute belongs to the current device)
     ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_knn_bf16x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void *h = const_cast<void *>(hi);
-    // persistent workgroups, two per CU; the grid a multiple of 8 so that a workgroup's later blocks stay on its XCD
+    // one workgroup per block by default (see the kernel); ESFM_X1_GRID = persistent workgroups (a multiple of 8, e.g. 2 x CUs)
     static const int forced = [] { const char *e = getenv("ESFM_X1_GRID"); return e ? atoi(e) : 0; }();     // (measurement)
-    const int cap = forced > 0 ? forced : std::max(8, 2 * num_cu / 8 * 8);
-    const int grid = n_blocks <= cap ? n_blocks : cap;
+    (void)num_cu;
+    const int grid = forced > 0 && forced < n_blocks ? std::max(8, forced / 8 * 8) : n_blocks;
     hipLaunchKernelGGL(l2_knn_bf16x1_kernel, dim3(grid), dim3(256), lds, st, desc,
                        reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 0)), reinterpret_cast<const u32x4 *>(l2_hi_part(h, total_rows, 1)), norms,
                        reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 2)), reinterpret_cast<const float *>(l2_hi_part(h, total_rows, 3)),

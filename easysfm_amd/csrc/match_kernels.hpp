@@ -40,7 +40,7 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 size_t l2_hi_bytes(long long total_rows);
 size_t l2_survivor_entry_bytes();
 // blk_pair[b]: the pair of the launch's b-th 512-query block (pair p owns blocks [blk_off2[p], blk_off2[p + 1])); the grid is
-// min(n_blocks, 2 num_cu) persistent workgroups.
+// one workgroup per block (ESFM_X1_GRID: that many persistent workgroups instead -- measurements).
 int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          const int32_t *blk_pair, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,
                          int32_t *surv_cnt, void *surv_list, double ratio, bool markers, int32_t *rejected,
