@@ -160,6 +160,36 @@ __device__ __forceinline__ float l2sqr64_canonical_regs(const float4 (&a)[16], c
     d = __fadd_rn(d, s2);
     return __fadd_rn(d, s3);
 }
+// The same with a row spread over SIXTEEN LANES (lane l of a 16-lane DPP row holds floats 4 l .. 4 l + 3 of both operands): float
+// 4 l + x belongs to chain c = 4 (l & 1) + x at step j = l >> 1, so a chain runs over the lanes of equal parity in lane order --
+// seven `row_shr:2` additions  A_k[l] = A_(k-1)[l - 2] + d[l]  (A_0 = d; the chain's 0 + d_0 is d_0) leave chains 0 .. 3 in lane 14
+// and 4 .. 7 in lane 15; lane 15 then forms s_x = acc[x] + acc[x + 4] and ((s0 + s1) + s2) + s3.  The result is valid in lane 15
+// of every row (four rows per wave).  Same operations on the same operands in the same order as l2sqr64_canonical_regs.
+__device__ __forceinline__ float dpp_row_shr_f(float v, int n_is_2)
+{
+    return n_is_2 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true))
+                  : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float l2sqr64_canonical_row16(const u32x4 a, const u32x4 b)
+{
+    float d[4], acc[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const float t = __fsub_rn(__uint_as_float(a[x]), __uint_as_float(b[x]));
+        d[x] = __fmul_rn(t, t);
+        acc[x] = d[x];
+    }
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[x] = __fadd_rn(dpp_row_shr_f(acc[x], 1), d[x]);
+    float sx[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) sx[x] = __fadd_rn(dpp_row_shr_f(acc[x], 0), acc[x]);      // lane 15: acc[x] of lane 14 + acc[x + 4] of its own
+    float r = __fadd_rn(sx[0], sx[1]);
+    r = __fadd_rn(r, sx[2]);
+    return __fadd_rn(r, sx[3]);
+}
 // The same on two rows that sit in LDS as 16 x 16 B with their slots XOR-swizzled (slot c of a row at piece c ^ sw): the pieces are
 // read as they are used, so neither row has to be held in 64 registers.  a_row / b_row: LDS byte address of the row, a_sw16 / b_sw16:
 // 16 sw.  The 32 piece addresses are formed HERE, every time, from operands the compiler cannot see through (one v_xad_u32 each): as
@@ -1525,8 +1555,7 @@ struct FinRerankArgs {
     const float4 *ent;                 // the pair's survivor entries
     int nsv;                           // ... their number
     PairDesc pd; int p;
-    u32x4 frsrc_t, frsrc_q;            // buffer descriptors of the train / query set's float rows
-    uint32_t lds_land;                 // LDS byte address of this wave's landing zone
+    __amdgpu_buffer_rsrc_t frsrc_t, frsrc_q;   // buffer descriptors of the train / query set's float rows (rows past a set read as zeros)
     double ratio2m;
     int32_t *knn_idx; float *knn_dist; float *knn_d2;
     int32_t *unc_cnt, *unc_list;       // the pair's list of queries for the threshold filter
@@ -1543,11 +1572,10 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
     constexpr uint32_t kCodeMask = (1u << ESFM_L2X1_CODE_BITS) - 1u;
     constexpr double kTrunc = 1.0001 / (double)(1 << (23 - ESFM_L2X1_CODE_BITS));
     const int lane = threadIdx.x & 63;
-    const int qs = lane >> 3 < QV ? lane >> 3 : QV - 1, ri = (lane & 3) + 8 * ((lane >> 2) & 1);     // row of the group this lane evaluates
+    const int ri = (lane & 3) + 8 * ((lane >> 2) & 1);     // row of the group this lane evaluates (lanes 8 e .. 8 e + 7: entry e of the virtual set)
     const int nt = A.pd.nt, nq = A.pd.nq;
     const double ratio2m = A.ratio2m;
     const bool screen = ratio2m < 1.0e300;
-    const uint32_t lds_land = A.lds_land;
     auto row0_of = [&](float key, int hh) {
         const int code = (int)(__float_as_uint(key) & kCodeMask);
         return key < 1.0e38f ? (code / NG) * 32 + (32 / NG) * (code % NG) + 4 * hh : -1;
@@ -1568,9 +1596,6 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
     const double U = (qn + (double)r1k + e1 + fabs((double)r1k) * kTrunc) * (1.0 + 1.0 / 1048576.0);
     u64 m0 = kNone, m1 = kNone;                                  // the query's exact two best so far (the same in its eight lanes)
     int verdict = 0;
-    int swzq[4];                                                 // byte offset of this lane's 16-B piece inside a fetched row: transfer i, (i & 3)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) swzq[i] = ((lane & 15) ^ ((4 * i + (lane >> 4)) & 15)) * 16;
     // one round: the group (key, row0) of the query, nkey = the smallest key of the groups the later rounds would fetch.
     // Returns false when no lane of the wave needed a row (the rounds are over).
     auto do_round = [&](auto first, bool last, float key, int row0, float nkey) __attribute__((always_inline)) -> bool {
@@ -1579,35 +1604,39 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
         if (__ballot(need) == 0ull) return false;
         const int trow = row0 + ri;
         const int rsel = need ? trow : nt;                       // nt: past the descriptor, zeros
-        // 16 lanes fetch one 256-B row: transfer i lands the rows of the lanes 4 i .. 4 i + 3 in the slots of the same numbers
-        // (i < 2 nv: the candidate rows; round 0: transfers 14 and 15 land the query rows of the entries 0 .. 6 in the slots 56 .. 62).
-        // All the exchanges first, ONE wait, then the transfers.
+        // 16 lanes fetch one 256-B row INTO REGISTERS: load i brings the rows of the lanes 4 i .. 4 i + 3 (i < 2 nv: the candidate
+        // rows), lane l of the wave its 16-byte piece l & 15 of the row of lane 4 i + (l >> 4); the query rows of the entries
+        // 0 .. nv - 1 the same way (every 16-lane row holds a copy).  Distances across the 16 lanes of a row in the oracle's order
+        // (l2sqr64_canonical_row16), handed to the lane that owns the candidate by one ds_bpermute per load.
+        // (Until the end of round 4 the rows landed in a 16-KiB LDS zone per wave -- LDS-DMA -- and every lane summed its own row
+        // from there: eight waves per CU, 56 queries in flight, and the zone idle for 60 % of a virtual set's 10 us.  Registers
+        // hold the same 14 KiB per wave, but sixteen waves fit a CU.)
         int rs[14];
 #pragma unroll
-        for (int i = 0; i < 14; ++i) rs[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + swzq[i & 3];
-        int qsrc[2] = {0, 0};
-        if (first) {
+        for (int i = 0; i < 14; ++i) rs[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 4, rsel) * 256 + (lane & 15) * 16;
+        u32x4 qv[QV], rowv[14];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) qsrc[i] = __builtin_amdgcn_ds_bpermute((4 * i + (lane >> 4)) * 32, qrow) * 256 + swzq[(14 + i) & 3];   // lane 8 e holds entry e's row
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the zone's previous contents have been read, the exchanges done
+        for (int e = 0; e < QV; ++e)
+            if (e < nv) qv[e] = __builtin_amdgcn_raw_buffer_load_b128(A.frsrc_q, __builtin_amdgcn_readlane(qrow, 8 * e) * 256 + (lane & 15) * 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 14; ++i)
-            if (i < 2 * nv) lds_dma_b128(lds_land + (uint32_t)i * 1024u, rs[i], A.frsrc_t, 0);
-        if (first) {
-            lds_dma_b128(lds_land + 14u * 1024u, qsrc[0], A.frsrc_q, 0);
-            if (nv > 4) lds_dma_b128(lds_land + 15u * 1024u, qsrc[1], A.frsrc_q, 0);
-        }
+            if (i < 2 * nv) rowv[i] = __builtin_amdgcn_raw_buffer_load_b128(A.frsrc_t, rs[i], 0, 0);
 #ifdef ESFM_FIN_TRACE
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        lds_dma_wait();
-#ifdef ESFM_FIN_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) s_fin_tr[threadIdx.x >> 6][0] += (int)(rt1 - rt0);
 #endif
-        // the rows stay in LDS and are read piece by piece (the query rows' slots are not touched by the later rounds)
-        const float da = l2sqr64_canonical_lds(lds_land + (uint32_t)(56 + qs) * 256u, (uint32_t)((56 + qs) & 15) * 16u, lds_land + (uint32_t)lane * 256u, (uint32_t)(lane & 15) * 16u);
+        float da = 0.f;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            if (i < 2 * nv) {
+                const float dr = l2sqr64_canonical_row16(qv[i >> 1], rowv[i]);
+                const float got = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 3) * 16 + 15) * 4, __float_as_int(dr)));
+                if ((lane >> 2) == i) da = got;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (one row group at a time: interleaved, the fourteen chains took 296 registers)
+        }
         // this lane's candidate as a key (+inf, NaN, rows past the set: none); then the two best of the query's eight lanes
         const float dda = sqrt_rn_f32(da);
         u64 c0k = (need && trow < nt && dda < FLT_MAX) ? (((u64)__float_as_uint(dda) << 32) | (u64)(uint32_t)trow) : kNone, c1k = kNone;
@@ -1702,9 +1731,13 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
     }
 }
 
-constexpr size_t kFinLdsBytes = (size_t)kFinWaves * 16384;      // four landing zones; the later stages' buffers alias them
+constexpr size_t kFinLdsBytes = 12288 + 8192 + (size_t)kFinWaves * 32 * 2 * 8;      // the buffers of stages (2) - (4) (the re-rank keeps its rows in registers)
 
-__global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
+#ifndef ESFM_FIN_OCC
+#define ESFM_FIN_OCC 3            // workgroups per CU the register budget is cut for: 3 = 168 registers, no spill in the re-rank (64.5 us per step;
+                                  // 1: 342 registers, 113 us; 2: 76 us; 4: 128 registers, 42 spills in the re-rank, 80 - 87 us; the query rows parked in LDS: 66 / 84 us at 3 / 4)
+#endif
+__global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(const float *__restrict__ desc, const u32x4 *__restrict__ hi_t,
                                                                 const u32x4 *__restrict__ hi_q, const float *__restrict__ norms,
                                                                 const float *__restrict__ rho_t, const float *__restrict__ rho_q,
                                                                 const PairDesc *__restrict__ pairs, const int32_t *__restrict__ pair_order, int n_pairs, int S,
@@ -1718,7 +1751,7 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
 {
     constexpr int CAP = kFinCap, HS = 8, NW = kFinWaves;
     constexpr float kBig = 3.0e38f;
-    static_assert(kFinThreads == 256, "four waves: four landing zones");
+    static_assert(kFinThreads == 256, "the later stages' buffers are laid out for four waves");
     extern __shared__ __attribute__((aligned(16))) char fin_smem[];         // kFinLdsBytes
     // stages (2) - (4) reuse the landing zones
     int *s_h = reinterpret_cast<int *>(fin_smem);                             // [CAP] hits of the chunk: (query slot in the chunk) << 21 | train row
@@ -1748,9 +1781,8 @@ __global__ __launch_bounds__(kFinThreads) void l2_finish_kernel(const float *__r
         A.nsv = min(surv_cnt[p], nq);
         A.ent = surv_list + 3 * (size_t)pd.out_off;
         A.pd = pd; A.p = p;
-        A.frsrc_t = raw_buffer_rsrc(desc + (size_t)pd.t_row0 * 64, (uint32_t)nt * 256u);   // rows past the set read as zeros, no memory access
-        A.frsrc_q = raw_buffer_rsrc(desc + (size_t)pd.q_row0 * 64, (uint32_t)nq * 256u);
-        A.lds_land = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)fin_smem) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 16384u;
+        A.frsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(desc + (size_t)pd.t_row0 * 64), 0, nt * 256, 0x00020000);   // rows past the set read as zeros, no memory access
+        A.frsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(desc + (size_t)pd.q_row0 * 64), 0, nq * 256, 0x00020000);
         A.ratio2m = ratio2m;
         A.knn_idx = knn_idx; A.knn_dist = knn_dist; A.knn_d2 = knn_d2;
         A.unc_cnt = unc_cnt; A.unc_list = unc_list;
@@ -2638,7 +2670,7 @@ int l2_finish_slices(int n_pairs)
 {
     static const int forced = [] { const char *e = getenv("ESFM_FIN_SLICES"); return e ? atoi(e) : 0; }();     // (measurement)
     if (forced > 0) return forced;
-    return std::max(1, std::min(8, 1024 / std::max(n_pairs, 1)));
+    return std::max(1, std::min(8, 1536 / std::max(n_pairs, 1)));      // (300 pairs, three workgroups per CU: 5 slices 64.5 us, 3: 68, 2: 70, 8: 65.5)
 }
 
 int launch_l2_finish(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
