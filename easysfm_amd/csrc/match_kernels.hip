@@ -1553,7 +1553,7 @@ __shared__ int s_fin_tr[4][4];         // per wave: ticks waiting for transfers,
 #endif
 struct FinRerankArgs {
     const float4 *ent;                 // the pair's survivor entries
-    int nsv;                           // ... their number
+    int nsv, per;                      // ... their number; entries per virtual set (<= kFinQV)
     PairDesc pd; int p;
     __amdgpu_buffer_rsrc_t frsrc_t, frsrc_q;   // buffer descriptors of the train / query set's float rows (rows past a set read as zeros)
     double ratio2m;
@@ -1582,7 +1582,7 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
     };
     auto kmin = [](u64 x, u64 y) { return x < y ? x : y; };
     auto kmax = [](u64 x, u64 y) { return x < y ? y : x; };
-    const int nv = min(QV, A.nsv - v * QV);                      // wave-uniform: queries of this virtual set
+    const int nv = min(A.per, A.nsv - v * A.per);                // wave-uniform: queries of this virtual set
     const bool qvalid = (lane >> 3) < nv;
     const int qrow = qvalid ? __float_as_int(mi.x) : nq;         // nq: past the descriptor, zeros
     const double qn = (double)mi.y, e1 = (double)mi.z;
@@ -1779,6 +1779,9 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
     {
         FinRerankArgs A;
         A.nsv = min(surv_cnt[p], nq);
+        // the survivors dealt out EVENLY over the pair's S x NW waves while a wave's share fits one virtual set (a set costs its
+        // latency chain whatever it holds: 25 sets of seven for 20 waves made five of them -- and their workgroups -- last twice as long)
+        A.per = max(1, min(kFinQV, (A.nsv + S * NW - 1) / (S * NW)));
         A.ent = surv_list + 3 * (size_t)pd.out_off;
         A.pd = pd; A.p = p;
         A.frsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(desc + (size_t)pd.t_row0 * 64), 0, nt * 256, 0x00020000);   // rows past the set read as zeros, no memory access
@@ -1790,12 +1793,12 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
 #ifdef ESFM_FIN_NOSTAGE1
         const int nvs = 0;                    // (timing experiments)
 #else
-        const int nvs = (A.nsv + kFinQV - 1) / kFinQV;
+        const int nvs = (A.nsv + A.per - 1) / A.per;
 #endif
         // (the next virtual set's entries are loaded while this one waits for its rows)
         const int eq = lane >> 3 < kFinQV ? lane >> 3 : kFinQV - 1;
         auto entry_of = [&](int v, int part) {
-            const int e = v * kFinQV + eq;
+            const int e = v * A.per + eq;
             return (v < nvs && e < A.nsv) ? A.ent[3 * (size_t)e + part] : make_float4(0.f, 0.f, 0.f, 0.f);
         };
         int v = sl * NW + wave;
@@ -2670,7 +2673,7 @@ int l2_finish_slices(int n_pairs)
 {
     static const int forced = [] { const char *e = getenv("ESFM_FIN_SLICES"); return e ? atoi(e) : 0; }();     // (measurement)
     if (forced > 0) return forced;
-    return std::max(1, std::min(8, 1536 / std::max(n_pairs, 1)));      // (300 pairs, three workgroups per CU: 5 slices 64.5 us, 3: 68, 2: 70, 8: 65.5)
+    return std::max(1, std::min(8, 2304 / std::max(n_pairs, 1)));      // (300 pairs, three workgroups per CU, survivors dealt evenly: 7 slices 60 us, 4: 70, 5: 65, 6: 66, 8: 63)
 }
 
 int launch_l2_finish(hipStream_t st, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
