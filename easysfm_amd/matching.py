@@ -301,7 +301,7 @@ class PairMatcher:
 
 
     def second_pass(self) -> int:
-        """Queries of the last L2 call the one-product bf16 pass handed to the three-product pass (64-float descriptors); synchronises."""
+        """Queries of the last L2 call the one-product bf16 pass could not certify and handed to the threshold-filter stage of l2_finish_kernel (64-float descriptors); synchronises."""
         a = C.c_int64(0)
         check(lib().esfm_match_last_second_pass(self.ctx.handle, C.byref(a)))
         return a.value

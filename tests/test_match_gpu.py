@@ -203,6 +203,46 @@ def test_batched_pairs_match_single_calls(gpu_ctx, oracle_lib):
     assert 0 <= n_rescan <= n_q
 
 
+@pytest.mark.parametrize("heavy_at", ["first", "last", "block_edges", "neighbours_only"])
+def test_train_set_maxima_at_unaligned_set_boundaries(gpu_ctx, oracle_lib, heavy_at):
+    """The one-product pass takes max |t|^2 / max rho_t of a train set from a table with one entry per 256 rows of the BANK plus the
+    rows in front of and behind the whole blocks (l2_blockmax_kernel).  Sets that start and end off the 256-row grid, with rows of
+    50 x the usual norm exactly at the set's first / last row, at the rows next to the table's block boundaries, or only in the
+    NEIGHBOURING sets (which must not leak into the bound's correctness either way): a maximum that misses a row makes the
+    certificate's bound too small, and the 2-NN / match lists would differ from the oracle's."""
+    rng = np.random.default_rng(11)
+    sizes = [300, 1000, 77, 700, 40]                       # set 1 = rows 300 .. 1299, set 3 = rows 1377 .. 2076 of the bank
+    sets = []
+    for n in sizes:
+        x = rng.standard_normal((n, 64)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        sets.append(x)
+    for s_ in (0, 2, 3, 4):                                # correspondences into the two big train sets
+        k = min(len(sets[s_]), 40)
+        sets[s_][:k] = sets[1][:k] + 0.03 * rng.standard_normal((k, 64)).astype(np.float32)
+    heavy = {"first": {1: [0], 3: [0]}, "last": {1: [999], 3: [699]},
+             "block_edges": {1: [211, 212, 467, 468, 979, 980], 3: [158, 159, 414, 415, 670, 671]},     # bank rows 511 / 512, 767 / 768, 1279 / 1280; 1535 / 1536 ...
+             "neighbours_only": {0: [299], 2: [0, 76], 4: [0]}}[heavy_at]
+    for s_, rows in heavy.items():
+        for r in rows:
+            sets[s_][r] *= 50.0
+    pairs = [(0, 1), (2, 1), (3, 1), (4, 1), (0, 3), (1, 3), (2, 3), (4, 3)]
+    bank = E.DescriptorBank(sets, E.ESFM_L2_F32)
+    pm = E.PairMatcher(bank, pairs)
+    for ratio in (0.6, 1.0):
+        res = pm.match(ratio).to_host()
+        for (i, j), (qi, ti, d) in zip(pairs, res):
+            rq, rt, rd = oracle_lib.match_l2(sets[i], sets[j], ratio)
+            assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(_bits(d), _bits(rd)), (heavy_at, i, j, ratio)
+    idx, dist = pm.knn2()
+    pm.ctx.synchronize()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    for k, (i, j) in enumerate(pairs):
+        o = int(pm.offset[k])
+        ridx, rdist = oracle_lib.knn2_l2(sets[i], sets[j])
+        assert np.array_equal(idx[o:o + len(sets[i])], ridx) and np.array_equal(_bits(dist[o:o + len(sets[i])]), _bits(rdist)), (heavy_at, i, j)
+
+
 def test_match_pairs_host_pointer_batch_equals_single_calls(gpu_ctx, oracle_lib):
     """esfm_match_pairs (round 4: the batched pair loop through HOST pointers, what the C++ driver calls once for sfm.cpp:140-161):
     ragged sets incl. an empty one, L2 and Hamming, every pair's list equal to the single-pair entry point's and the oracle's."""
