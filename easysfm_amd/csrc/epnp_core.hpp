@@ -10,6 +10,9 @@
 
 #define ESFM_HD __host__ __device__ inline
 
+#ifndef EPNP_MARK
+#define EPNP_MARK(k) do { } while (0)      // (pnp_kernels.hip -DESFM_PNP_TRACE: stage stamps of the device chain)
+#endif
 namespace esfm {
 namespace epnp {
 
@@ -133,6 +136,7 @@ ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], do
 {
     double *ut = ws, d[12];
     sym_eig_desc_ws<12>(MtM, ut, d, ws + 144, ws + 288, jac);
+    EPNP_MARK(2);
     for (int k = 0; k < 4; ++k) for (int a = 0; a < 12; ++a) v[k][a] = ut[12 * (11 - k) + a];
     double dv[4][6][3], L[60], rho[6];
     for (int i = 0; i < 4; ++i) {
@@ -158,6 +162,7 @@ ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], do
             rho[j] = s; ++b; if (b > 3) { ++a; b = a + 1; }
         }
     }
+    EPNP_MARK(3);
     {   // approximation 1: B11 B12 B13 B14
         double A[24], x[4];
         for (int i = 0; i < 6; ++i) { A[4 * i] = L[10 * i]; A[4 * i + 1] = L[10 * i + 1]; A[4 * i + 2] = L[10 * i + 3]; A[4 * i + 3] = L[10 * i + 6]; }
@@ -186,6 +191,7 @@ ESFM_HD void betas_from_mtm_ws(const double MtM[144], const double cws[4][3], do
         if (x[1] < 0) b[0] = -b[0];
         b[2] = x[3] / b[0]; b[3] = 0.0;
     }
+    EPNP_MARK(4);
     for (int N = 0; N < 3; ++N) {
         double *b = betas[N];
         for (int it = 0; it < 5; ++it) {
@@ -261,6 +267,7 @@ template <int K, class JAC> ESFM_HD double solve_small_ws(const Cam &cam, const 
     for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { sum_pw[a] += pws[3 * i + a]; for (int b = 0; b < 3; ++b) sum_pwpw[3 * a + b] += pws[3 * i + a] * pws[3 * i + b]; }
     double cws[4][3], CCi[9];
     control_points(sum_pw, sum_pwpw, K, cws, CCi);
+    EPNP_MARK(0);
     double alphas[K][4];
     double *MtM = ws;
     for (int a = 0; a < 144; ++a) MtM[a] = 0.0;
@@ -271,7 +278,9 @@ template <int K, class JAC> ESFM_HD double solve_small_ws(const Cam &cam, const 
         for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) MtM[12 * a + b] += m1[a] * m1[b] + m2[a] * m2[b];
     }
     double v[4][12], betas[3][4];
+    EPNP_MARK(1);
     betas_from_mtm_ws(MtM, cws, v, betas, ws + 144, jac);
+    EPNP_MARK(5);
     double best_err = 0.0;
     for (int N = 0; N < 3; ++N) {
         double ccs[4][3];
@@ -288,6 +297,7 @@ template <int K, class JAC> ESFM_HD double solve_small_ws(const Cam &cam, const 
         e /= K;
         if (N == 0 || e < best_err) { best_err = e; for (int a = 0; a < 9; ++a) R[a] = Rn[a]; for (int a = 0; a < 3; ++a) t[a] = tn[a]; }
     }
+    EPNP_MARK(6);
     return best_err;
 }
 template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, const double *us, double R[9], double t[3])

@@ -12,6 +12,14 @@
 //                       epnp_core.hpp routines
 // The sample stream and the best-model / adaptive-iteration bookkeeping are replayed on the host exactly as for the
 // essential-matrix RANSAC (ransac_api.cpp).
+#ifdef ESFM_PNP_TRACE
+// stage stamps of pnp_solve_kernel's chain (hypothesis 0 of workgroup 0 prints them): s_memrealtime ticks of 10 ns
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_pnp_mark[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPNP_MARK(k) do { g_pnp_mark[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#endif
 #include "pnp_kernels.hpp"
 
 #include <float.h>
@@ -82,7 +90,16 @@ __global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const floa
     }
     const Cam cam = {pb.fu, pb.fv, pb.uc, pb.vc};
     double R[9], t[3];
+#ifdef ESFM_PNP_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     epnp::solve_small_ws<5>(cam, pw, us, R, t, ws_all + grp * kPnpWsStride, Jacobi12Coop{l});
+#ifdef ESFM_PNP_TRACE
+    if (g == 0 && l == 0)
+        printf("pnp_solve [10 ns]: control points %llu  M'M %llu  eig12 %llu  L/rho %llu  betas %llu  gauss-newton %llu  candidates %llu\n", g_pnp_mark[0] - tr0,
+               g_pnp_mark[1] - g_pnp_mark[0], g_pnp_mark[2] - g_pnp_mark[1], g_pnp_mark[3] - g_pnp_mark[2], g_pnp_mark[4] - g_pnp_mark[3], g_pnp_mark[5] - g_pnp_mark[4],
+               g_pnp_mark[6] - g_pnp_mark[5]);
+#endif
     if (l != 0) return;
     bool ok = true;
     for (int k = 0; k < 9; ++k) ok = ok && isfinite(R[k]);
