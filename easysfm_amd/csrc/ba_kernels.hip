@@ -314,8 +314,11 @@ constexpr int kLinThreadsLarge = 512, kLinThreadsSmall = 256;
 constexpr int kLinSmallObs = 1 << 20;
 constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
 
+#ifndef ESFM_LIN_OCC
+#define ESFM_LIN_OCC 1
+#endif
 template <bool PRIV, bool CALIB, int kLinThreads>
-__global__ __launch_bounds__(kLinThreads) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, ScalBase sbase, double *__restrict__ slabs,
+__global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1) void ba_linearize_kernel(BADev d, double cauchy_a, int use_scaling, ScalBase sbase, double *__restrict__ slabs,
                                                                    int prov_rexp)
 {
     // prov_rexp != INT_MIN (PRIV, several observations per thread: BA-512): PROVISIONAL fixed-point exponents -- the previous
@@ -785,7 +788,10 @@ __global__ __launch_bounds__(64) void ba_point_prep_kernel(BADev d, double radiu
 // idle (22 workgroups for 25 cameras; a latency-bound walk over the tracks), so back to back they cost 8 + 12 us of a 180-us
 // LM iteration on BA-25 and together 12.  The first n_red workgroups are ba_camacc_reduce_kernel's, the others take 256 points
 // each (the singular-point count is an integer-valued sum and the gradient maximum a maximum: the wider workgroup changes no bit).
-__global__ __launch_bounds__(256) void ba_point_prep_camacc_kernel(BADev d, double radius, double min_diag, double max_diag, ScalBase sbase,
+#ifndef ESFM_PREP_OCC
+#define ESFM_PREP_OCC 1
+#endif
+__global__ __launch_bounds__(256, ESFM_PREP_OCC) void ba_point_prep_camacc_kernel(BADev d, double radius, double min_diag, double max_diag, ScalBase sbase,
                                                                    const double *__restrict__ slabs, int n_slabs, int with_gradient, int n_red)
 {
     __shared__ double lds[256];
@@ -1143,7 +1149,10 @@ constexpr int kMfWaveDoubles = 64 * kMfYPitch + kMfMaxPts * 16 / 2;     // Y | W
 constexpr size_t kMfLdsBytes = sizeof(double) * (4 * kMfWaveDoubles + 6 * kSchurMfCams);
 static_assert(4 * kMfWaveDoubles >= kMfRows * (kMfRows + 1), "the staging area is reused for the 80 x 81 result");
 
-__global__ __launch_bounds__(256, 2) void ba_schur_mfma_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs, const int2 *__restrict__ slot_pc,
+#ifndef ESFM_SCHUR_OCC
+#define ESFM_SCHUR_OCC 2
+#endif
+__global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs, const int2 *__restrict__ slot_pc,
                                                                const int32_t *__restrict__ batch_slot, const int32_t *__restrict__ chunk_batch0,
                                                                const int32_t *__restrict__ chunk_cam0, int rot)
 {
@@ -1678,8 +1687,14 @@ __device__ __forceinline__ void candidate_cost(const BADev &d, int k, const doub
     cost += 0.5 * rho0;
 }
 
+// (register budget: four workgroups per CU.  The WITH_COST form had been compiled to 198 registers -- two waves per SIMD for a kernel
+// that streams; at 128 BA-25's iteration went 0.136 -> 0.133 ms.  The same audit found nothing else: the sweep at three / four
+// workgroups per CU spills, 25.7 / 36 us against 22.5; the f64-MFMA Schur kernel at one / three: 462 / 640 us against 294.)
+#ifndef ESFM_BACKSUB_OCC
+#define ESFM_BACKSUB_OCC 4
+#endif
 template <bool WITH_COST>
-__global__ __launch_bounds__(kPtChunkObs) void ba_backsub_chunk_kernel(BADev d, ScalBase sbase, double cauchy_a)
+__global__ __launch_bounds__(kPtChunkObs, ESFM_BACKSUB_OCC) void ba_backsub_chunk_kernel(BADev d, ScalBase sbase, double cauchy_a)
 {
     __shared__ double red[8];
     __shared__ double tE[kPtChunkObs][3];
