@@ -243,6 +243,38 @@ def test_train_set_maxima_at_unaligned_set_boundaries(gpu_ctx, oracle_lib, heavy
         assert np.array_equal(idx[o:o + len(sets[i])], ridx) and np.array_equal(_bits(dist[o:o + len(sets[i])]), _bits(rdist)), (heavy_at, i, j)
 
 
+def test_persistent_workgroup_form_of_the_one_product_pass(gpu_ctx):
+    """ESFM_X1_GRID (a measurement knob, read once per process): the one-product pass as persistent workgroups that take several
+    512-query blocks each and prefetch the next block's operands -- not the default (measured slower), but the loop is in the
+    kernel; ESFM_FIN_SLICES = 1: a pair's whole re-rank in one workgroup (several virtual sets per wave).  A child process with
+    the knobs set matches a ragged pair list and compares every list with the oracle."""
+    import os, subprocess, sys
+    code = r'''
+import sys; sys.path.insert(0, ".")
+import numpy as np, easysfm_amd as E, oracle
+from easysfm_amd import synth
+rng = np.random.default_rng(5)
+sizes = [1500, 700, 2300, 513, 40]
+sets = []
+for n in sizes:
+    x = rng.standard_normal((n, 64)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True); sets.append(x)
+for s_ in range(1, 5):
+    k = min(len(sets[s_]), 300); sets[s_][:k] = sets[0][:k] + 0.03 * rng.standard_normal((k, 64)).astype(np.float32)
+pairs = synth.all_pairs(len(sizes))
+pm = E.PairMatcher(E.DescriptorBank(sets, E.ESFM_L2_F32), pairs)
+for ratio in (0.6, 1.0):
+    res = pm.match(ratio).to_host()
+    for (i, j), (qi, ti, d) in zip(pairs, res):
+        rq, rt, rd = oracle.match_l2(sets[i], sets[j], ratio)
+        assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(d.view(np.uint32), rd.view(np.uint32)), (i, j, ratio)
+print("ok")
+'''
+    env = dict(os.environ, ESFM_X1_GRID="16", ESFM_FIN_SLICES="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_match_pairs_host_pointer_batch_equals_single_calls(gpu_ctx, oracle_lib):
     """esfm_match_pairs (round 4: the batched pair loop through HOST pointers, what the C++ driver calls once for sfm.cpp:140-161):
     ragged sets incl. an empty one, L2 and Hamming, every pair's list equal to the single-pair entry point's and the oracle's."""
