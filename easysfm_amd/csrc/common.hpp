@@ -68,6 +68,7 @@ struct esfm_ctx {
     // norms / hm_exp belong to this descriptor buffer and are not recomputed by the match calls
     const void *prep_desc = nullptr;
     int prep_metric = 0, prep_width = 0;
+    bool prep_hm_fp4 = false;          // Hamming: hm_exp holds the FP4 form's nibble images (hamming_fp4_kernel), not the byte image of the i8 form
     int64_t prep_rows = 0;
     esfm::DevBuf knn_d2;   // exact second-best d^2 of the queries the one-product pass left uncertified (the refine pass's thresholds)
     esfm::DevBuf l2_hi;    // one-product pass: bf16(t) and bf16(-2 q) images (128 B per row each) and the two residual norms per row

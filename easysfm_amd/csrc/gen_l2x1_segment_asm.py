@@ -59,6 +59,9 @@ NOBAR = int(os.environ.get("ESFM_GEN_NOBAR", "0"))        # timing experiments o
 NOVMWAIT = int(os.environ.get("ESFM_GEN_NOVMWAIT", "0"))  # wave's transfers at a hand-over, no waits for LDS reads inside a step,
 NOLGKM = int(os.environ.get("ESFM_GEN_NOLGKM", "0"))      # no LDS reads at all
 NOLDSRD = int(os.environ.get("ESFM_GEN_NOLDSRD", "0"))
+MFMA = os.environ.get("ESFM_GEN_MFMA", "bf16")            # "fp4": v_mfma_f32_32x32x64_f8f6f4 on e2m1 nibbles -- the 256-bit Hamming matcher: a row of
+assert MFMA in ("bf16", "fp4")                            # 256 nibbles is 128 B, four K-steps of 64, a lane's 16-B slot 2 ks + h its fragment: the same shapes
+PREFIX = os.environ.get("ESFM_GEN_PREFIX", "ESFM_L2X1")   # macro prefix of the generated file
 NS = 4
 GRP = int(os.environ.get("ESFM_GEN_GRP", "8"))            # results per fold group: 4 (round 3) or 8 (round 4: 4.5 instead of 7 VALU per MFMA at K = 4)
 assert GRP in (4, 8)
@@ -229,7 +232,11 @@ def gen():
                     e(f"s_add_u32 s{44 + g}, s41, {g}")
             if not NOMFMA:
                 a = accr(s, spar)
-                e(f"v_mfma_f32_32x32x16_bf16 {a}, {fr(ks, par)}, {OP_B(s, ks)}, {'v[96:111]' if ks == 0 else a}")
+                c_in = 'v[96:111]' if ks == 0 else a
+                if MFMA == "fp4":
+                    e(f"v_mfma_f32_32x32x64_f8f6f4 {a}, {fr(ks, par)}, {OP_B(s, ks)}, {c_in} cbsz:4 blgp:4")
+                else:
+                    e(f"v_mfma_f32_32x32x16_bf16 {a}, {fr(ks, par)}, {OP_B(s, ks)}, {c_in}")
             if slot >= 4 and extra:
                 for x in extra.pop(0):
                     e(x)
@@ -325,17 +332,17 @@ def main():
     lines = gen()
     clob = [f"v{i}" for i in range(N_CLOBBER)] + [f"s{i}" for i in range(40, 54)] + ["scc", "vcc", "memory"]
     out = ["// GENERATED by gen_l2x1_segment_asm.py -- do not edit; see that file for the schedule and the register map",
-           f"#define ESFM_L2X1_KEEP {KEEP}",
-           f"#define ESFM_L2X1_SETS {NS}",
-           f"#define ESFM_L2X1_CODE_BITS {CODE_BITS}",
-           f"#define ESFM_L2X1_GRP {GRP}",
-           f"#define ESFM_L2X1_TT {TT}",
-           f"#define ESFM_L2X1_RING {RING}",
-           "#define ESFM_L2X1_SEGMENT_ASM \\"]
+           f"#define {PREFIX}_KEEP {KEEP}",
+           f"#define {PREFIX}_SETS {NS}",
+           f"#define {PREFIX}_CODE_BITS {CODE_BITS}",
+           f"#define {PREFIX}_GRP {GRP}",
+           f"#define {PREFIX}_TT {TT}",
+           f"#define {PREFIX}_RING {RING}",
+           f"#define {PREFIX}_SEGMENT_ASM \\"]
     for l in lines:
         out.append(f'    "{l}\\n" \\')
     out.append('    ""')
-    out.append("#define ESFM_L2X1_SEGMENT_CLOBBERS " + ", ".join(f'"{c}"' for c in clob))
+    out.append(f"#define {PREFIX}_SEGMENT_CLOBBERS " + ", ".join(f'"{c}"' for c in clob))
     open(sys.argv[1] if len(sys.argv) > 1 else "l2x1_segment_gfx950.inc", "w").write("\n".join(out) + "\n")
     n_mfma = sum("v_mfma" in l for l in lines)
     print(f"{len(lines)} instructions, {n_mfma} MFMAs, KEEP = {KEEP}, GRP = {GRP}")

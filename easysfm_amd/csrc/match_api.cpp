@@ -253,13 +253,20 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             esfm::set_error("hamming descriptors must be 16, 32 or 64 bytes (got %d)", width);
             return ESFM_ERR_UNSUPPORTED;
         }
-        if (!prepared) {
+        // 256-bit descriptors: the FP4-MFMA form while the train sets fit its position code, else the byte-per-bit i8 form; what
+        // esfm_match_prepare_dev left in hm_exp counts only if it is the form this call runs
+        const bool fp4 = esfm::hamming_fp4_supported(width, plan.max_nt);
+        const bool have = prepared && ctx->prep_hm_fp4 == fp4;
+        if (!have) {
             ctx->prep_desc = nullptr;
             if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, plan.total_rows))) return rc;
         }
         esfm::KernelTimer tm(ctx, ESFM_K_HAMMING_KNN);
+        if (fp4)
+            return esfm::launch_hamming_fp4(st, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, blk_pair_of(dev_tab, n_pairs), plan.n_blocks2, knn_idx,
+                                            knn_dist, ratio, /*expanded=*/have);
         return esfm::launch_hamming_knn(st, width, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, n_pairs, plan.n_blocks, knn_idx,
-                                        knn_dist, /*expanded=*/prepared);
+                                        knn_dist, /*expanded=*/have);
     }
     esfm::set_error("unknown metric %d", (int)metric);
     return ESFM_ERR_INVALID_ARG;
@@ -467,7 +474,10 @@ int esfm_match_prepare_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_d
             return rc;
     } else if (metric == ESFM_HAMMING && esfm::hamming_supported(width) && esfm::hamming_expanded_bytes(width, total_rows) > 0) {
         if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, total_rows))) return rc;
-        if (int rc = esfm::launch_hamming_expand(st, width, desc_dev, total_rows, ctx->hm_exp.ptr)) return rc;
+        // (the FP4 form's images unless it is switched off: a later call whose train sets do not fit its position code re-derives)
+        ctx->prep_hm_fp4 = esfm::hamming_fp4_supported(width, 0);
+        if (ctx->prep_hm_fp4) { if (int rc = esfm::launch_hamming_expand_fp4(st, desc_dev, total_rows, ctx->hm_exp.ptr)) return rc; }
+        else if (int rc = esfm::launch_hamming_expand(st, width, desc_dev, total_rows, ctx->hm_exp.ptr)) return rc;
     } else {
         return ESFM_OK;       // nothing to derive for this metric / width: the match calls work on the rows themselves
     }

@@ -30,6 +30,7 @@
 #define ESFM_L2X1_SEGMENT_INC "l2x1_segment_gfx950.inc"
 #endif
 #include ESFM_L2X1_SEGMENT_INC         // ESFM_L2X1_SEGMENT_ASM, ESFM_L2X1_KEEP: the one-product pass's main loop (gen_l2x1_segment_asm.py)
+#include "hmx1_segment_gfx950.inc"     // ESFM_HMX1_SEGMENT_ASM: the same loop around v_mfma_f32_32x32x64_f8f6f4 on FP4 operands (256-bit Hamming)
 
 #include <float.h>
 #include <type_traits>
@@ -2543,6 +2544,197 @@ __global__ __launch_bounds__(256, 2) void hamming_knn_mfma_kernel(const unsigned
 }
 
 // ---------------------------------------------------------------------------------------------
+// 256-bit Hamming on the FP4 matrix cores (round 4).  hamming(q, t) = pop(q) + pop(t) - 2 q.t, and q.t over 0/1 bits is a dot product
+// of 256 NIBBLES: t's bits as e2m1 1.0 (0x2), q's as -2.0 (0xC), accumulated in f32 on top of a start value pop(t) + 512 --
+// exact small integers, positive, with 14 zero bits at the low end of the mantissa.  A row of 256 nibbles is 128 B = four K-steps of
+// v_mfma_f32_32x32x64_f8f6f4 (cbsz = blgp = 4: FP4 x FP4, 16 B per lane and K-step): byte for byte the shapes of the one-product L2
+// pass, so the whole main loop -- LDS-DMA ring of two 256-row tiles, four query sets per wave, fold groups of eight with the
+// position in the low mantissa bits -- is that pass's generator with another instruction (hmx1_segment_gfx950.inc).  The FP4
+// instruction moves 64 K per 8 passes where v_mfma_i32_32x32x32_i8 moves 32 (measured 7.7 against 4.2 Pop/s,
+// scratch/ubench/mfma_fp4.hip, which also checks the products exact), at half the operand bytes of the byte-per-bit form.
+// No certificate: the scores are exact, a group key IS the group's smallest score.  With code order = row order inside a lane half,
+// the nearest row sits in the half's smallest key's group and the second nearest in one of its two smallest (a group in front of it
+// would hold a row in front of it in (distance, index) order, and there is only one such row), and a group whose score exceeds the
+// second smallest score of all eight keys holds neither.  The tail counts the bits of those groups' rows exactly on the packed
+// descriptors, in (distance, index) order.  Ratio screen as in the L2 pass, exact here: d0 = score(k0) - 512 + pop(q) is the nearest
+// distance, the second smallest key bounds the second nearest from above, and (double) d0 >= ratio (double) U1 rejects (marker -2).
+typedef int i32x4h __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hamming_expand_fp4_kernel(const uint32_t *__restrict__ desc, long long n_words, u32x4 *__restrict__ img_t,
+                                                                 u32x4 *__restrict__ img_q, float *__restrict__ start)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t w = i < n_words ? desc[i] : 0u;
+    int pop = __popc(w);
+    pop += __shfl_xor(pop, 1);
+    pop += __shfl_xor(pop, 2);
+    pop += __shfl_xor(pop, 4);
+    if (i >= n_words) return;
+    if ((i & 7) == 0) start[i >> 3] = (float)(pop + 512);
+    u32x4 t, q;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t b = (w >> (8 * d)) & 0xFFu, x = 0u;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) x |= ((b >> n) & 1u) << (4 * n + 1);      // nibble n = bit 8 d + n as 0x2 (e2m1 1.0)
+        t[d] = x; q[d] = x * 6u;                                              // 0x2 -> 0xC (-2.0): no carries between nibbles
+    }
+    img_t[i] = t; img_q[i] = q;
+}
+
+__global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__restrict__ packed, const u32x4 *__restrict__ img_t,
+                                                             const u32x4 *__restrict__ img_q, const float *__restrict__ start,
+                                                             const PairDesc *__restrict__ pairs, const int32_t *__restrict__ blk_pair, int n_blocks,
+                                                             int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist, double ratio)
+{
+    constexpr int TT = ESFM_HMX1_TT, NS = ESFM_HMX1_SETS, K = ESFM_HMX1_KEEP, RING = ESFM_HMX1_RING, GRP = ESFM_HMX1_GRP, NG = 16 / GRP;
+    constexpr int QB = 128 * NS, HS = 8;
+    constexpr int TILE_BYTES = TT * HS * 16;
+    static_assert(NS == 4 && GRP == 8 && RING * TT == 512 && K >= 2, "written for the L2 one-product pass's shapes");
+    constexpr uint32_t kCodeMask = (1u << ESFM_HMX1_CODE_BITS) - 1u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);
+    float *lds_norm = reinterpret_cast<float *>(smem + RING * TILE_BYTES);
+    int lane = threadIdx.x & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tid = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const uint32_t lds_tile_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_tile);
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pi = blk_pair[lb];
+    const PairDesc pd = pairs[pi];
+    const int nq = __builtin_amdgcn_readfirstlane(pd.nq), nt = __builtin_amdgcn_readfirstlane(pd.nt);
+    const int q_row0 = __builtin_amdgcn_readfirstlane(pd.q_row0), t_row0 = __builtin_amdgcn_readfirstlane(pd.t_row0);
+    const int qblk = lb - __builtin_amdgcn_readfirstlane(pd.blk_off2);
+    const int ntiles = (nt + TT - 1) / TT;
+    const float *__restrict__ tn = start + t_row0;
+    const u32x4 trsrc = raw_buffer_rsrc(img_t + (size_t)t_row0 * HS, (uint32_t)nt * (HS * 16));
+    const u32x4 nrsrc = raw_buffer_rsrc(tn, (uint32_t)nt * 4u);
+    if (ntiles * TT != nt || ntiles < RING) {
+        for (int i = tid; i < RING * TT * HS; i += 256) lds_tile[i] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < RING; ++b) {
+#pragma unroll
+        for (int i = 0; i < TT / 32; ++i) {
+            const int row = wave_s * (TT / 4) + 8 * i + (lane >> 3);
+            const int voff = row * (HS * 16) + (((lane & 7) ^ ((row >> 1) & 7)) * 16);
+            lds_dma_b128(lds_tile_addr + (uint32_t)(b * TILE_BYTES + (wave_s * (TT / 4) + 8 * i) * (HS * 16)), voff, trsrc, b * TILE_BYTES);
+        }
+    }
+    u32x4 bq[NS][4];
+    {
+        const __amdgpu_buffer_rsrc_t qrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(img_q + (size_t)q_row0 * HS), 0, nq * (HS * 16), 0x00020000);
+        const int qbase0 = qblk * QB + wave_s * 32 * NS;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int voff = (qbase0 + 32 * s + j) * (HS * 16) + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bq[s][ks] = __builtin_amdgcn_raw_buffer_load_b128(qrsrc, voff + 32 * ks, 0, 0);
+        }
+    }
+    {
+        float big;
+        asm volatile("s_mov_b32 %0, 0x7f61b1e6" : "=s"(big));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int t = tid + 256 * u; lds_norm[t] = t < nt ? tn[t] : big; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntiles > 0) {
+        asm volatile(ESFM_HMX1_SEGMENT_ASM
+                     :
+                     : "v"(bq[0][0]), "v"(bq[0][1]), "v"(bq[0][2]), "v"(bq[0][3]), "v"(bq[1][0]), "v"(bq[1][1]), "v"(bq[1][2]), "v"(bq[1][3]),
+                       "v"(bq[2][0]), "v"(bq[2][1]), "v"(bq[2][2]), "v"(bq[2][3]), "v"(bq[3][0]), "v"(bq[3][1]), "v"(bq[3][2]), "v"(bq[3][3]),
+                       "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
+                     : ESFM_HMX1_SEGMENT_CLOBBERS);
+    }
+    {   // (nothing thread-dependent lives across the block: see l2_knn_bf16x1_kernel)
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        lane = l; tid = wave_s * 64 + l; j = l & 31; h = l >> 5;
+    }
+    float key0[NS], key1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        key0[s] = reinterpret_cast<const float *>(smem)[(K * s + 0) * 256 + tid];
+        key1[s] = reinterpret_cast<const float *>(smem)[(K * s + 1) * 256 + tid];
+    }
+    if (ntiles == 0) {
+        float big;
+        asm volatile("s_mov_b32 %0, 0x7f61b1e6" : "=s"(big));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { key0[s] = big; key1[s] = big; }
+    }
+    // ---- tail: exact (distance, index)-first two rows of every query that the screen lets through
+    constexpr uint32_t kNone = 0xFFFFFFFFu, kIdxMask = 0x1FFFFFu;
+    auto key_insert_min = [](uint32_t &k1, uint32_t &k2, uint32_t key) {
+        const uint32_t hi = max(k1, key);
+        k1 = min(k1, key);
+        k2 = min(k2, hi);
+    };
+    const u32x4 *P = reinterpret_cast<const u32x4 *>(packed);
+    const int qbase = qblk * QB + wave_s * 32 * NS;
+    float fltmax; int minus2;
+    asm volatile("s_mov_b32 %0, 0x7f7fffff" : "=s"(fltmax));
+    asm volatile("s_mov_b32 %0, -2" : "=s"(minus2));
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+        const int qrow = qbase + 32 * s + j;
+        const bool qvalid = qrow < nq;
+        const float v0 = s == 0 ? key0[0] : (s == 1 ? key0[1] : (s == 2 ? key0[2] : key0[3]));
+        const float v1 = s == 0 ? key1[0] : (s == 1 ? key1[1] : (s == 2 ? key1[2] : key1[3]));
+        const float p0 = other_half(v0, h != 0), p1 = other_half(v1, h != 0);
+        const float k0 = fminf(v0, p0), kb = fminf(fmaxf(v0, p0), fminf(v1, p1));           // the two smallest of the eight keys
+        const float thr = __uint_as_float(__float_as_uint(kb) & ~kCodeMask);                   // ... the second one's score
+        const float qpop = start[q_row0 + (qvalid ? qrow : 0)] - 512.f;
+        // ratio screen (exact): d0 and an upper bound of d1
+        const double d0 = (double)(__uint_as_float(__float_as_uint(k0) & ~kCodeMask) - 512.f + qpop), U1 = (double)(thr - 512.f + qpop);
+        const bool rej = qvalid && kb < 1.0e38f && d0 >= ratio * U1;                           // (+inf ratio: never; one row only: re-rank)
+        uint32_t k1 = kNone, k2 = kNone;
+        const u32x4 *qp = P + ((size_t)q_row0 + (qvalid ? qrow : 0)) * 2;
+        const u32x4 q0 = qp[0], q1 = qp[1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float key = i == 0 ? v0 : v1;
+            const float score = __uint_as_float(__float_as_uint(key) & ~kCodeMask);
+            const bool need = qvalid && !rej && key < 1.0e38f && score <= thr;
+            if (need) {
+                const int code = (int)(__float_as_uint(key) & kCodeMask);
+                const int row0 = (code / NG) * 32 + (32 / NG) * (code % NG) + 4 * h;
+                u32x4 t0[8], t1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = min(row0 + (u & 3) + 8 * (u >> 2), max(nt - 1, 0));
+                    const u32x4 *tp = P + ((size_t)t_row0 + t) * 2;
+                    t0[u] = tp[0]; t1[u] = tp[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = row0 + (u & 3) + 8 * (u >> 2);
+                    const int dist = __popc(q0[0] ^ t0[u][0]) + __popc(q0[1] ^ t0[u][1]) + __popc(q0[2] ^ t0[u][2]) + __popc(q0[3] ^ t0[u][3]) +
+                                     __popc(q1[0] ^ t1[u][0]) + __popc(q1[1] ^ t1[u][1]) + __popc(q1[2] ^ t1[u][2]) + __popc(q1[3] ^ t1[u][3]);
+                    key_insert_min(k1, k2, t < nt ? (((uint32_t)dist << 21) | (uint32_t)t) : kNone);
+                }
+            }
+        }
+        const uint32_t o1 = __float_as_uint(other_half(__uint_as_float(k1), h != 0)), o2 = __float_as_uint(other_half(__uint_as_float(k2), h != 0));
+        key_insert_min(k1, k2, o1);
+        key_insert_min(k1, k2, o2);
+        if (h == 0 && qvalid) {
+            const size_t o = 2 * ((size_t)pd.out_off + qrow);
+            if (rej) {
+                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(minus2, minus2);
+                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(fltmax, fltmax);
+            } else {
+                const bool h0 = k1 != kNone, h1 = k2 != kNone;
+                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(h0 ? (int)(k1 & kIdxMask) : -1, h1 ? (int)(k2 & kIdxMask) : -1);
+                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(h0 ? (float)(k1 >> 21) : fltmax, h1 ? (float)(k2 >> 21) : fltmax);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The ratio test + compaction as a launch of its own (ratio_compact_pair above): one workgroup per pair.  The 64-float L2 path does
 // it inside l2_finish_kernel; this serves Hamming and the other L2 passes.
 constexpr int kRatioThreads = 1024;     // 4096 queries per sweep of the workgroup: one round of loads for a 4096-row set
@@ -2794,6 +2986,46 @@ int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long t
         set_error("hamming kernel is built for 16/32/64-byte descriptors (got %d)", nbytes);
         return ESFM_ERR_UNSUPPORTED;
     }
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+bool hamming_fp4_pass()
+{
+    static const bool off = [] { const char *e = getenv("ESFM_HM_PASS"); return e && strcmp(e, "i8") == 0; }();
+    return !off;
+}
+bool hamming_fp4_supported(int nbytes, int max_nt) { return nbytes == 32 && hamming_fp4_pass() && max_nt <= (1 << (ESFM_HMX1_CODE_BITS - 1)) * 32 && max_nt < (1 << 21); }
+
+// the FP4 form's operands: nibble images of every row in both roles (128 B each) and pop(row) + 512 as a float -- the same 260 B per
+// row as the byte image + start value of the i8 form (hamming_expanded_bytes)
+int launch_hamming_expand_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch)
+{
+    if (!exp_scratch || total_rows <= 0) return ESFM_OK;
+    const long long n_words = total_rows * 8;
+    unsigned char *base = static_cast<unsigned char *>(exp_scratch);
+    const size_t n = (size_t)std::max(total_rows, 1LL);
+    hipLaunchKernelGGL(hamming_expand_fp4_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(desc), n_words,
+                       reinterpret_cast<u32x4 *>(base), reinterpret_cast<u32x4 *>(base + 128 * n), reinterpret_cast<float *>(base + 256 * n));
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs, const int32_t *blk_pair,
+                       int n_blocks, int32_t *knn_idx, float *knn_dist, double ratio, bool expanded)
+{
+    if (n_blocks <= 0) return ESFM_OK;
+    if (!expanded)
+        if (int rc = launch_hamming_expand_fp4(st, desc, total_rows, exp_scratch)) return rc;
+    constexpr size_t lds = 4 * 128 * 128 + 4 * 128 * 4 + 64;      // ring of nibble tiles, their start values (the keys leave through the ring)
+    ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&hamming_fp4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned char *base = static_cast<unsigned char *>(exp_scratch);
+    const size_t n = (size_t)std::max(total_rows, 1LL);
+    // (the ratio test's own compare is `(double) d0 < ratio * (double) d1`: a NaN or negative ratio rejects nothing here)
+    const double r = (ratio >= 0.0 && ratio < 1.0e150) ? ratio : (double)INFINITY;
+    hipLaunchKernelGGL(hamming_fp4_kernel, dim3(n_blocks), dim3(256), lds, st, reinterpret_cast<const uint32_t *>(desc), reinterpret_cast<const u32x4 *>(base),
+                       reinterpret_cast<const u32x4 *>(base + 128 * n), reinterpret_cast<const float *>(base + 256 * n), pairs, blk_pair, n_blocks, knn_idx,
+                       knn_dist, r);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

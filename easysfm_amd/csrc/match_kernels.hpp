@@ -70,6 +70,13 @@ int hamming_query_block(int nbytes);
 size_t hamming_expanded_bytes(int nbytes, long long total_rows);
 int launch_hamming_expand(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch);
 // expanded: exp_scratch already holds this buffer's expansion (esfm_match_prepare_dev)
+// 256-bit descriptors, train sets the position code can number: the FP4-MFMA form (hamming_fp4_kernel: nibble-per-bit operands, the
+// one-product L2 pass's main loop, exact tail, exact ratio screen -- queries that fail d0 < ratio d1 whatever d1 is get train index -2;
+// +inf: none).  blk_pair / n_blocks: the 512-query block numbering (PairDesc::blk_off2).  ESFM_HM_PASS=i8 keeps the byte-per-bit kernel.
+bool hamming_fp4_supported(int nbytes, int max_nt);
+int launch_hamming_expand_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch);
+int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs, const int32_t *blk_pair,
+                       int n_blocks, int32_t *knn_idx, float *knn_dist, double ratio, bool expanded);
 int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch,
                        const PairDesc *pairs, int n_pairs, int n_blocks,
                        int32_t *knn_idx, float *knn_dist, bool expanded);

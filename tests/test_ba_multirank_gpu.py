@@ -72,7 +72,7 @@ def _run(world, backend, constrained=False):
     procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, constrained)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
+    res = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
