@@ -157,6 +157,47 @@ def test_hamming_forced_ties(gpu_ctx, oracle_lib):
         assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
 
 
+@pytest.mark.parametrize("case", ["dups_everywhere", "dups_late", "all_ones", "one_bit_apart", "ragged_batch"])
+def test_hamming_fp4_adversarial(gpu_ctx, oracle_lib, case):
+    """The FP4-MFMA form of the 256-bit matcher (hamming_fp4_kernel): exact scores, so the only thing to get wrong is WHICH rows
+    the tail looks at -- ties for first and second place spread over more fold groups than a lane keeps keys, duplicates whose
+    lowest indices sit late in the set, all-ones rows (the largest scores), neighbours one bit apart, and a ragged pair list
+    (train sets of 1, 7, 300, 513 and 2300 rows: fewer rows than a ring tile, partial last tiles)."""
+    rng = np.random.default_rng(21)
+    ratios = (0.5, 0.8, 1.0)
+    if case == "ragged_batch":
+        sizes = [1, 7, 300, 513, 2300, 40]
+        sets = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in sizes]
+        sets[4][:200] = sets[2][:200]; sets[4][200:260, 3] ^= 1          # exact copies and one-bit neighbours across sets
+        pairs = synth.all_pairs(len(sizes))
+        pm = E.PairMatcher(E.DescriptorBank(sets, E.ESFM_HAMMING), pairs)
+        for ratio in ratios:
+            res = pm.match(ratio).to_host()
+            for (i, j), (qi, ti, d) in zip(pairs, res):
+                rq, rt, rd = oracle_lib.match_hamming(sets[i], sets[j], ratio)
+                assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(d, rd), (i, j, ratio)
+        return
+    nt = 3000
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    base = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    if case == "dups_everywhere":
+        t[rng.choice(nt, 400, replace=False)] = base                    # 400 copies: ties for both places in dozens of groups
+    elif case == "dups_late":
+        t[[2990, 2995, 1501, 2047, 2048]] = base
+    elif case == "all_ones":
+        t[::7] = 0xFF
+    elif case == "one_bit_apart":
+        for k in range(0, nt, 5):
+            t[k] = base; t[k, (k // 5) % 32] ^= np.uint8(1 << (k % 8))
+    q = np.concatenate([base, base ^ np.uint8(1), rng.integers(0, 256, (600, 32), dtype=np.uint8), np.full((3, 32), 0xFF, np.uint8), np.zeros((2, 32), np.uint8)])
+    idx, dist = E.knn_match_hamming(q, t, gpu_ctx)
+    ridx, rdist = oracle_lib.knn2_hamming(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    for ratio in ratios:
+        a = E.match_hamming(q, t, ratio, gpu_ctx); b = oracle_lib.match_hamming(q, t, ratio)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), ratio
+
+
 def test_hamming_match_orb_like(gpu_ctx, oracle_lib):
     o = synth.orb_like_sets(2, 2000, pool=4096, seed_base=300)
     a = E.match_hamming(o[1], o[0], 0.8, gpu_ctx); b = oracle_lib.match_hamming(o[1], o[0], 0.8)
