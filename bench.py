@@ -650,12 +650,15 @@ def main() -> int:
             h_ms, h_n = octx.kernel_time(_lib.K_HAMMING_KNN)
             octx.set_kernel_timing(False)
             h_s = h_ms / max(h_n, 1) * 1e-3
-            ops = 2.0 * len(opairs) * N_FEATS * N_FEATS * 256          # i8 MAC ops of the byte-per-bit formulation
+            ops = 2.0 * len(opairs) * N_FEATS * N_FEATS * 256          # multiply-adds x 2 of the element-per-bit formulation
+            fp4 = os.environ.get("ESFM_HM_PASS", "") != "i8"            # round 4: nibble-per-bit operands on the FP4 matrix instruction (exact: products 0 / -2)
             out["orb"] = {"metric": "image-pairs matched/s (4096 ORB feats/img)", "value": len(opairs) * n_rep / o_el, "unit": "image-pairs/s",
                           "config": {"workload": "M-ORB-4k all-pairs ORB-256b match (2-NN + ratio 0.8), 25 imgs x 4096 feats x 32 B, 300 pairs/step"},
-                          "kernel": "hamming_expand_kernel + hamming_knn_mfma_kernel", "avg_launch_ms": h_s * 1e3,
-                          "roofline": {"bound": "mfma", "achieved": ops / h_s / 1e12, "peak": 3944.0, "unit": "TOP/s (i8)",
-                                       "frac": ops / h_s / 1e12 / 3944.0},
+                          "kernel": "hamming_fp4_kernel (v_mfma_f32_32x32x64_f8f6f4, FP4 x FP4)" if fp4 else "hamming_knn_mfma_kernel (v_mfma_i32_32x32x32_i8)",
+                          "avg_launch_ms": h_s * 1e3,
+                          "roofline": {"bound": "mfma", "achieved": ops / h_s / 1e12, "peak": 10000.0 if fp4 else 3944.0,
+                                       "unit": "TOP/s (FP4 dense, MI355X_MICROARCH.md)" if fp4 else "TOP/s (i8)",
+                                       "frac": ops / h_s / 1e12 / (10000.0 if fp4 else 3944.0)},
                           "valu_equivalent_lane_ops_per_s": 2.0 * len(opairs) * N_FEATS * N_FEATS * 8 / h_s}
             if not args.no_cpu_baseline:
                 import oracle
