@@ -78,7 +78,7 @@ NP = TT // 32                         # LDS-DMA pieces (8 rows = 1 KiB) per wave
 WROWS = TT // 4                       # rows of a tile staged by one wave
 TILE_BYTES = TT * ROW_BYTES          # 16 / 32 KiB
 NORM_BASE = RING * TILE_BYTES        # the ring's norms sit behind the tiles: RING x TT floats
-assert 3 <= KEEP <= 6
+assert (2 if os.environ.get('ESFM_GEN_MFMA', 'bf16') == 'fp4' else 3) <= KEEP <= 6      # (exact scores need no certificate: two keys per lane half are enough)
 
 OP_B = lambda s, ks: f"%{4 * s + ks}"
 OP_NTILES, OP_NT, OP_TRSRC, OP_NRSRC, OP_LDS, OP_WAVE = (f"%{16 + i}" for i in range(6))
