@@ -262,9 +262,18 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
             if (int rc = ctx->hm_exp.reserve(esfm::hamming_expanded_bytes(width, plan.total_rows))) return rc;
         }
         esfm::KernelTimer tm(ctx, ESFM_K_HAMMING_KNN);
-        if (fp4)
-            return esfm::launch_hamming_fp4(st, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, blk_pair_of(dev_tab, n_pairs), plan.n_blocks2, knn_idx,
-                                            knn_dist, ratio, /*expanded=*/have);
+        if (fp4) {
+            // the match entry points: ratio test + compaction inside the same launch (the last block of a pair does it)
+            const bool fused = mo != nullptr && ratio_done != nullptr;
+            if (fused) { if (int rc = reserve_zeroed(ctx->fin_done, sizeof(int32_t) * (size_t)n_pairs, st)) return rc; }
+            if (int rc = esfm::launch_hamming_fp4(st, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, blk_pair_of(dev_tab, n_pairs), plan.n_blocks2, knn_idx,
+                                                  knn_dist, ratio, /*expanded=*/have, fused ? ctx->fin_done.as<int32_t>() : nullptr, n_pairs,
+                                                  fused ? mo->query_idx : nullptr, fused ? mo->train_idx : nullptr, fused ? mo->distance : nullptr,
+                                                  fused ? mo->n_out : nullptr))
+                return rc;
+            if (fused) *ratio_done = true;
+            return ESFM_OK;
+        }
         return esfm::launch_hamming_knn(st, width, desc_dev, plan.total_rows, ctx->hm_exp.ptr, dev_tab, n_pairs, plan.n_blocks, knn_idx,
                                         knn_dist, /*expanded=*/have);
     }

@@ -2584,8 +2584,12 @@ __global__ __launch_bounds__(256) void hamming_expand_fp4_kernel(const uint32_t 
 __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__restrict__ packed, const u32x4 *__restrict__ img_t,
                                                              const u32x4 *__restrict__ img_q, const float *__restrict__ start,
                                                              const PairDesc *__restrict__ pairs, const int32_t *__restrict__ blk_pair, int n_blocks,
-                                                             int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist, double ratio)
+                                                             int32_t *__restrict__ knn_idx, float *__restrict__ knn_dist, double ratio,
+                                                             int32_t *__restrict__ done, int n_pairs, int32_t *__restrict__ query_idx,
+                                                             int32_t *__restrict__ train_idx, float *__restrict__ distance, int32_t *__restrict__ n_out)
 {
+    // (a pair without queries has no block: nobody would write its count)
+    if (done && blockIdx.x == 0) for (int p = threadIdx.x; p < n_pairs; p += 256) if (pairs[p].nq == 0) n_out[p] = 0;
     constexpr int TT = ESFM_HMX1_TT, NS = ESFM_HMX1_SETS, K = ESFM_HMX1_KEEP, RING = ESFM_HMX1_RING, GRP = ESFM_HMX1_GRP, NG = 16 / GRP;
     constexpr int QB = 128 * NS, HS = 8;
     constexpr int TILE_BYTES = TT * HS * 16;
@@ -2722,15 +2726,29 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
         key_insert_min(k1, k2, o2);
         if (h == 0 && qvalid) {
             const size_t o = 2 * ((size_t)pd.out_off + qrow);
-            if (rej) {
-                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(minus2, minus2);
-                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(fltmax, fltmax);
+            const bool h0 = !rej && k1 != kNone, h1 = !rej && k2 != kNone;
+            const int i0 = rej ? minus2 : (h0 ? (int)(k1 & kIdxMask) : -1), i1 = rej ? minus2 : (h1 ? (int)(k2 & kIdxMask) : -1);
+            const float f0 = h0 ? (float)(k1 >> 21) : fltmax, f1 = h1 ? (float)(k2 >> 21) : fltmax;
+            if (done) {       // another workgroup of this launch reads the records (the ratio stage below): write-through stores
+                st_coh_i(knn_idx + o, i0); st_coh_i(knn_idx + o + 1, i1); st_coh_f(knn_dist + o, f0); st_coh_f(knn_dist + o + 1, f1);
             } else {
-                const bool h0 = k1 != kNone, h1 = k2 != kNone;
-                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(h0 ? (int)(k1 & kIdxMask) : -1, h1 ? (int)(k2 & kIdxMask) : -1);
-                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(h0 ? (float)(k1 >> 21) : fltmax, h1 ? (float)(k2 >> 21) : fltmax);
+                *reinterpret_cast<int2 *>(knn_idx + o) = make_int2(i0, i1);
+                *reinterpret_cast<float2 *>(knn_dist + o) = make_float2(f0, f1);
             }
         }
+    }
+    // ---- the match entry points: ratio test + ordered compaction of the pair by the workgroup that brings its last block (the
+    // protocol of l2_finish_kernel: stores acknowledged, barrier, one relaxed agent-scope arrival; `done` reads 0 again afterwards)
+    if (done) {
+        __shared__ int s_last, s_wave[4], s_base;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nblk = (nq + QB - 1) / QB;
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&done[pi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (threadIdx.x == 0) __hip_atomic_store(&done[pi], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ratio_compact_pair<256, 16, true>(pd, knn_idx, knn_dist, ratio, query_idx, train_idx, distance, n_out + pi, s_wave, &s_base);
     }
 }
 
@@ -3012,7 +3030,8 @@ int launch_hamming_expand_fp4(hipStream_t st, const void *desc, long long total_
 }
 
 int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs, const int32_t *blk_pair,
-                       int n_blocks, int32_t *knn_idx, float *knn_dist, double ratio, bool expanded)
+                       int n_blocks, int32_t *knn_idx, float *knn_dist, double ratio, bool expanded, int32_t *done, int n_pairs, int32_t *query_idx,
+                       int32_t *train_idx, float *distance, int32_t *n_out)
 {
     if (n_blocks <= 0) return ESFM_OK;
     if (!expanded)
@@ -3025,7 +3044,7 @@ int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, v
     const double r = (ratio >= 0.0 && ratio < 1.0e150) ? ratio : (double)INFINITY;
     hipLaunchKernelGGL(hamming_fp4_kernel, dim3(n_blocks), dim3(256), lds, st, reinterpret_cast<const uint32_t *>(desc), reinterpret_cast<const u32x4 *>(base),
                        reinterpret_cast<const u32x4 *>(base + 128 * n), reinterpret_cast<const float *>(base + 256 * n), pairs, blk_pair, n_blocks, knn_idx,
-                       knn_dist, r);
+                       knn_dist, done ? ratio : r, done, n_pairs, query_idx, train_idx, distance, n_out);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -76,7 +76,10 @@ int launch_hamming_expand(hipStream_t st, int nbytes, const void *desc, long lon
 bool hamming_fp4_supported(int nbytes, int max_nt);
 int launch_hamming_expand_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch);
 int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, void *exp_scratch, const PairDesc *pairs, const int32_t *blk_pair,
-                       int n_blocks, int32_t *knn_idx, float *knn_dist, double ratio, bool expanded);
+                       int n_blocks, int32_t *knn_idx, float *knn_dist, double ratio, bool expanded, int32_t *done, int n_pairs, int32_t *query_idx,
+                       int32_t *train_idx, float *distance, int32_t *n_out);
+// done != NULL (n_pairs zeroed counters, left zero): the launch also runs the ratio test + ordered compaction, pair by pair, in the
+// workgroup that finishes a pair's last block (query_idx / train_idx / distance / n_out as for launch_ratio_compact)
 int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch,
                        const PairDesc *pairs, int n_pairs, int n_blocks,
                        int32_t *knn_idx, float *knn_dist, bool expanded);
