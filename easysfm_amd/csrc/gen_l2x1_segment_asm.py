@@ -66,7 +66,8 @@ NS = 4
 GRP = int(os.environ.get("ESFM_GEN_GRP", "8"))            # results per fold group: 4 (round 3) or 8 (round 4: 4.5 instead of 7 VALU per MFMA at K = 4)
 assert GRP in (4, 8)
 NG = 16 // GRP                                            # groups per lane and 32-train step
-CODE_BITS = 11 + (2 if GRP == 4 else 1)                   # position code: 11 bits step, 2 / 1 bits group
+STEP_BITS = int(os.environ.get("ESFM_GEN_STEP_BITS", "11"))   # (the FP4 Hamming form's scores leave 14 zero mantissa bits: 13 step bits = 262 144 rows)
+CODE_BITS = STEP_BITS + (2 if GRP == 4 else 1)           # position code: step, 2 / 1 bits group
 KBIG = 0x7F61B1E6          # 3.0e38f
 NKBIG = 0xFF61B1E6
 TT = int(os.environ.get("ESFM_GEN_TT", "256"))            # train rows per tile (128 or 256)

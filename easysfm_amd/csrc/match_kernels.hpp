@@ -70,7 +70,7 @@ int hamming_query_block(int nbytes);
 size_t hamming_expanded_bytes(int nbytes, long long total_rows);
 int launch_hamming_expand(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch);
 // expanded: exp_scratch already holds this buffer's expansion (esfm_match_prepare_dev)
-// 256-bit descriptors, train sets the position code can number: the FP4-MFMA form (hamming_fp4_kernel: nibble-per-bit operands, the
+// 256-bit descriptors, train sets the position code can number (262 144 rows): the FP4-MFMA form (hamming_fp4_kernel: nibble-per-bit operands, the
 // one-product L2 pass's main loop, exact tail, exact ratio screen -- queries that fail d0 < ratio d1 whatever d1 is get train index -2;
 // +inf: none).  blk_pair / n_blocks: the 512-query block numbering (PairDesc::blk_off2).  ESFM_HM_PASS=i8 keeps the byte-per-bit kernel.
 bool hamming_fp4_supported(int nbytes, int max_nt);

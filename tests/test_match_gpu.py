@@ -198,6 +198,22 @@ def test_hamming_fp4_adversarial(gpu_ctx, oracle_lib, case):
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), ratio
 
 
+def test_hamming_fp4_large_train_set(gpu_ctx, oracle_lib):
+    """A train set beyond the L2 pass's 32 768 rows: the FP4 Hamming form numbers 262 144 (its scores leave 14 zero mantissa bits
+    for the position code); winners and ties placed in the last steps of the set."""
+    rng = np.random.default_rng(33)
+    nt = 70001
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t[[69990, 70000, 40000, 32768, 32767]] = q[0]              # five exact copies of query 0: the two lowest indices win
+    t[65536] = q[1]; t[65537] = q[1]; t[65537, 0] ^= 1
+    idx, dist = E.knn_match_hamming(q, t, gpu_ctx)
+    ridx, rdist = oracle_lib.knn2_hamming(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    a = E.match_hamming(q, t, 0.8, gpu_ctx); b = oracle_lib.match_hamming(q, t, 0.8)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_hamming_match_orb_like(gpu_ctx, oracle_lib):
     o = synth.orb_like_sets(2, 2000, pool=4096, seed_base=300)
     a = E.match_hamming(o[1], o[0], 0.8, gpu_ctx); b = oracle_lib.match_hamming(o[1], o[0], 0.8)
