@@ -2851,7 +2851,7 @@ int launch_l2_knn_bf16(hipStream_t st, const float *desc, const void *split, lon
 static inline double l2_ratio2m(double ratio) { return (ratio >= 0.0 && ratio < 1.0e150) ? ratio * ratio * (1.0 + 1.0 / 1048576.0) : (double)INFINITY; }
 
 int l2_x1_query_block() { return l2x1_query_block_c; }
-bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS - 2)) * 32; }   // the position code names a 32-row step
+bool l2_x1_supported(int max_nt) { return max_nt <= (1 << (ESFM_L2X1_CODE_BITS - (ESFM_L2X1_GRP == 4 ? 2 : 1))) * 32; }   // the position code names a 32-row step and one of its 16 / GRP groups
 
 int launch_l2_knn_bf16x1(hipStream_t st, int num_cu, const float *desc, const void *hi, long long total_rows, const float *norms, const PairDesc *pairs,
                          const int32_t *blk_pair, int n_blocks, int32_t *knn_idx, float *knn_dist, int32_t *counters, int flag_cap,

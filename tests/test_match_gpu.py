@@ -198,6 +198,22 @@ def test_hamming_fp4_adversarial(gpu_ctx, oracle_lib, case):
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), ratio
 
 
+def test_l2_one_product_pass_at_its_largest_train_set(gpu_ctx, oracle_lib):
+    """65 536 train rows: the last size the one-product pass's 12-bit position code numbers (11 bits of 32-row steps, one bit for the
+    step's two fold groups); neighbours planted in the last steps, duplicates across the set's ends."""
+    rng = np.random.default_rng(44)
+    nt = 65536
+    t = rng.standard_normal((nt, 64)).astype(np.float32); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    q = rng.standard_normal((256, 64)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t[65535] = q[0]; t[65500] = q[0]; t[3] = q[0]                       # three exact copies: rows 3 and 65500 win
+    t[65520] = q[1] + 0.01 * rng.standard_normal(64).astype(np.float32)
+    t[40000] = q[2] + 0.02 * rng.standard_normal(64).astype(np.float32)
+    _check_knn_l2(gpu_ctx, oracle_lib, q, t)
+    for ratio in (0.6, 0.9):
+        a = E.match_l2(q, t, ratio, gpu_ctx); b = oracle_lib.match_l2(q, t, ratio)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(_bits(a[2]), _bits(b[2]))
+
+
 def test_hamming_fp4_large_train_set(gpu_ctx, oracle_lib):
     """A train set beyond the L2 pass's 32 768 rows: the FP4 Hamming form numbers 262 144 (its scores leave 14 zero mantissa bits
     for the position code); winners and ties placed in the last steps of the set."""
