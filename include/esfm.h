@@ -76,7 +76,7 @@ void *esfm_ctx_stream(esfm_ctx *ctx);
  * *total_ms / *launches (caller zero-initialises) and recycles the events. */
 typedef enum esfm_kernel_id {
     ESFM_K_L2_KNN = 0,        /* l2_knn_bf16x1_kernel (dim 64) / l2_knn_mfma_kernel: MFMA distance pass + fused top-k + re-rank */
-    ESFM_K_HAMMING_KNN = 1,   /* hamming_expand_kernel + hamming_knn_mfma_kernel / hamming_knn_kernel */
+    ESFM_K_HAMMING_KNN = 1,   /* hamming_fp4_kernel (256 bit; + its expansion when the buffer is not prepared) / hamming_knn_mfma_kernel / hamming_knn_kernel */
     ESFM_K_BA_LINEARIZE = 2,  /* ba_linearize_kernel: the Jacobian sweep                        */
     ESFM_K_BA_SCHUR = 3,      /* ba_schur_kernel                                                */
     ESFM_K_BA_SOLVE = 4,      /* ba_chol_solve_kernel                                           */
@@ -164,7 +164,7 @@ int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host,
 /*
  * Optional, once per resident descriptor buffer: derive and keep what the matcher computes from the rows before it can start --
  * for 64-float L2 descriptors the bf16 operand images, |row|^2 and the rounding residual norms of every row (l2_split_bf16_kernel),
- * for 32-byte Hamming descriptors the 0/1 byte image -- so that the esfm_match_pairs_dev / esfm_knn2_pairs_dev calls that follow
+ * for 32-byte Hamming descriptors the nibble-per-bit images of the FP4 matrix-core form -- so that the esfm_match_pairs_dev / esfm_knn2_pairs_dev calls that follow
  * on the SAME (desc_dev, total rows, width) skip that launch.  The reference has no counterpart: it re-reads cv::Mat rows in every
  * knnMatch call (feature_matching.cpp:80,125); here the frames' descriptors are uploaded once for the whole pair loop
  * (sfm.cpp:140-161) and this is part of the upload.  The caller promises not to modify the rows while they are prepared;
