@@ -64,10 +64,10 @@ assert MFMA in ("bf16", "fp4")                            # 256 nibbles is 128 B
 PREFIX = os.environ.get("ESFM_GEN_PREFIX", "ESFM_L2X1")   # macro prefix of the generated file
 NS = 4
 GRP = int(os.environ.get("ESFM_GEN_GRP", "8"))            # results per fold group: 4 (round 3) or 8 (round 4: 4.5 instead of 7 VALU per MFMA at K = 4)
-assert GRP in (4, 8)
+assert GRP in (4, 8, 16)                                  # (16: the Hamming form only -- a kept group costs the exact tail 16 rows of 32 B there, of 256 B in the L2 pass)
 NG = 16 // GRP                                            # groups per lane and 32-train step
 STEP_BITS = int(os.environ.get("ESFM_GEN_STEP_BITS", "11"))   # (the FP4 Hamming form's scores leave 14 zero mantissa bits: 13 step bits = 262 144 rows)
-CODE_BITS = STEP_BITS + (2 if GRP == 4 else 1)           # position code: step, 2 / 1 bits group
+CODE_BITS = STEP_BITS + {4: 2, 8: 1, 16: 0}[GRP]          # position code: step, 2 / 1 / 0 bits group
 KBIG = 0x7F61B1E6          # 3.0e38f
 NKBIG = 0xFF61B1E6
 TT = int(os.environ.get("ESFM_GEN_TT", "256"))            # train rows per tile (128 or 256)
@@ -188,6 +188,24 @@ def gen():
                 out.append(f"v_med3_f32 {KEY(s, i)}, {KEY(s, i - 1)}, {KEY(s, i)}, v{key}")
             out.append(f"v_med3_f32 {KEY(s, 0)}, {KEY(s, 0)}, v{key}, s53")
             return out
+        if GRP == 16:
+            # one group per lane, set and step: quarters 0 / 1 the minimum of its registers 0..7 / 8..15 (4 v_min3 each), quarter 2 the code
+            # and the K v_med3, quarter 3 nothing: 9 + K VALU per 16 results
+            t, key = FTMP + 2 * (s & 1), FTMP + 1 + 2 * (s & 1)
+            b = acc(s, par) + 8 * g
+            if g == 0:
+                return [f"v_min3_f32 v{t}, v{b}, s52, v{b + 1}", f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
+                        f"v_min3_f32 v{t}, v{t}, v{b + 4}, v{b + 5}", f"v_min3_f32 v{t}, v{t}, v{b + 6}, v{b + 7}"]
+            if g == 1:
+                return [f"v_min3_f32 v{t}, v{t}, v{b}, v{b + 1}", f"v_min3_f32 v{t}, v{t}, v{b + 2}, v{b + 3}",
+                        f"v_min3_f32 v{t}, v{t}, v{b + 4}, v{b + 5}", f"v_min3_f32 v{t}, v{t}, v{b + 6}, v{b + 7}"]
+            if g == 3:
+                return []
+            out = [f"v_and_or_b32 v{key}, v{t}, v{MASK}, s44"]
+            for i in range(KEEP - 1, 0, -1):
+                out.append(f"v_med3_f32 {KEY(s, i)}, {KEY(s, i - 1)}, {KEY(s, i)}, v{key}")
+            out.append(f"v_med3_f32 {KEY(s, 0)}, {KEY(s, 0)}, v{key}, s53")
+            return out
         G, half = g >> 1, g & 1
         t, key = FTMP + 2 * (s & 1), FTMP + 1 + 2 * (s & 1)        # sets of equal parity never have a fold in flight at the same time
         if half == 0:
@@ -227,7 +245,7 @@ def gen():
                 e(f"s_waitcnt lgkmcnt({WAITS[slot]})")
             if slot == 10:
                 # the step being folded from now on is this one
-                e(f"s_lshl_b32 s41, s42, {2 if GRP == 4 else 1}")
+                e(f"s_lshl_b32 s41, s42, {CODE_BITS - STEP_BITS}")
                 e("s_add_u32 s42, s42, 1")
                 for g in range(NG):
                     e(f"s_add_u32 s{44 + g}, s41, {g}")

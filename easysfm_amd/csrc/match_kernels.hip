@@ -2593,7 +2593,7 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
     constexpr int TT = ESFM_HMX1_TT, NS = ESFM_HMX1_SETS, K = ESFM_HMX1_KEEP, RING = ESFM_HMX1_RING, GRP = ESFM_HMX1_GRP, NG = 16 / GRP;
     constexpr int QB = 128 * NS, HS = 8;
     constexpr int TILE_BYTES = TT * HS * 16;
-    static_assert(NS == 4 && GRP == 8 && RING * TT == 512 && K >= 2, "written for the L2 one-product pass's shapes");
+    static_assert(NS == 4 && (GRP == 8 || GRP == 16) && RING * TT == 512 && K >= 2, "written for the L2 one-product pass's shapes");
     constexpr uint32_t kCodeMask = (1u << ESFM_HMX1_CODE_BITS) - 1u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4 *lds_tile = reinterpret_cast<u32x4 *>(smem);
@@ -2705,19 +2705,22 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
             if (need) {
                 const int code = (int)(__float_as_uint(key) & kCodeMask);
                 const int row0 = (code / NG) * 32 + (32 / NG) * (code % NG) + 4 * h;
-                u32x4 t0[8], t1[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = min(row0 + (u & 3) + 8 * (u >> 2), max(nt - 1, 0));
-                    const u32x4 *tp = P + ((size_t)t_row0 + t) * 2;
-                    t0[u] = tp[0]; t1[u] = tp[1];
-                }
+                for (int hb = 0; hb < GRP / 8; ++hb) {         // eight rows at a time: rows {0..3, 8..11} (+ 16 hb) of the step, + 4 h
+                    u32x4 t0[8], t1[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = row0 + (u & 3) + 8 * (u >> 2);
-                    const int dist = __popc(q0[0] ^ t0[u][0]) + __popc(q0[1] ^ t0[u][1]) + __popc(q0[2] ^ t0[u][2]) + __popc(q0[3] ^ t0[u][3]) +
-                                     __popc(q1[0] ^ t1[u][0]) + __popc(q1[1] ^ t1[u][1]) + __popc(q1[2] ^ t1[u][2]) + __popc(q1[3] ^ t1[u][3]);
-                    key_insert_min(k1, k2, t < nt ? (((uint32_t)dist << 21) | (uint32_t)t) : kNone);
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = min(row0 + 16 * hb + (u & 3) + 8 * (u >> 2), max(nt - 1, 0));
+                        const u32x4 *tp = P + ((size_t)t_row0 + t) * 2;
+                        t0[u] = tp[0]; t1[u] = tp[1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = row0 + 16 * hb + (u & 3) + 8 * (u >> 2);
+                        const int dist = __popc(q0[0] ^ t0[u][0]) + __popc(q0[1] ^ t0[u][1]) + __popc(q0[2] ^ t0[u][2]) + __popc(q0[3] ^ t0[u][3]) +
+                                         __popc(q1[0] ^ t1[u][0]) + __popc(q1[1] ^ t1[u][1]) + __popc(q1[2] ^ t1[u][2]) + __popc(q1[3] ^ t1[u][3]);
+                        key_insert_min(k1, k2, t < nt ? (((uint32_t)dist << 21) | (uint32_t)t) : kNone);
+                    }
                 }
             }
         }
