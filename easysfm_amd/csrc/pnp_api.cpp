@@ -98,7 +98,12 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
         ESFM_HIP_TRY(hipMemsetAsync(d_mask, 1, nn, st));
     } else {
         while (iter < niters) {
-            const int n_hyp = std::min(kPnpChunk, niters - iter);
+            // The first rounds are small: with the usual inlier ratios the adaptive count falls below 64 after the first good hypothesis,
+            // and a launch lasts as long as its SLOWEST hypothesis (a degenerate sample runs the 12 x 12 Jacobi into its 60-sweep cap:
+            // ~2 ms) -- one of 64 samples is rarely that, one of 1024 nearly always.  Which hypotheses count is decided by `iter <
+            // niters` below, in the sample stream's order: the chunking changes no result.
+            const int chunk = iter == 0 ? 64 : (iter < 320 ? 256 : kPnpChunk);
+            const int n_hyp = std::min(chunk, niters - iter);
             for (int k = 0; k < n_hyp; ++k) rs::draw_subset(rng, n, &samples[5 * (size_t)k]);
             ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * 5 * (size_t)n_hyp, hipMemcpyHostToDevice, st));
             if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, n_hyp, d_poses, d_valid, d_counts, ctx)) return rc;
