@@ -518,10 +518,14 @@ __global__ __launch_bounds__(256) void l2_knn_mfma_kernel(const float *__restric
 // queries (half the L2 -> LDS traffic of the f32 kernel).  The fold of step n runs in the shadow of step n+1's MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef ESFM_BF16_DROP
+#define ESFM_BF16_DROP 0         // (experiment: mantissa bits dropped from the bf16 operands -- fewer toggling bits, a higher clock? the bounds follow the stored values)
+#endif
 __device__ __forceinline__ uint32_t bf16_rne_bits(float a)
 {
     const uint32_t u = __float_as_uint(a);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    constexpr int S = 16 + ESFM_BF16_DROP;
+    return ((u + ((1u << (S - 1)) - 1u) + ((u >> S) & 1u)) >> S) << ESFM_BF16_DROP;
 }
 // hi / lo halves of 2 consecutive floats packed into one dword each (element 0 in the low half)
 __device__ __forceinline__ void bf16_split2(float a0, float a1, uint32_t &hi, uint32_t &lo)
@@ -1846,7 +1850,22 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
 
     // ---- (2), (3): the pair's uncertified queries, chunks of 32, the whole train set by this workgroup's four waves
     const int cnt = min(ld_coh_i(unc_cnt + p), nq);
-    if (cnt > 0) {
+#ifndef ESFM_FIN_SMALL
+#define ESFM_FIN_SMALL 8       // uncertified queries of a pair up to which the exact brute force beats the threshold filter's fixed ~100-us chain
+#endif
+    if (cnt > 0 && cnt <= ESFM_FIN_SMALL && audit != 1) {
+        // a handful of queries: their exact 2-NN over the whole train set straight away (the threshold filter below is a chain of
+        // nt / 128 dependent MFMA steps per chunk of 32 whatever the chunk holds: ~100 us for ONE query; this: a few us per query)
+        if (tid < 32) s_qrows[tid] = tid < cnt ? ld_coh_i(unc_list + pd.out_off + tid) : 0;
+        __syncthreads();
+        if (tid < cnt) {
+            const int sl2 = atomicAdd(&counters[0], 1);
+            if (sl2 < flag_cap) { flagged[2 * sl2] = p; flagged[2 * sl2 + 1] = s_qrows[tid]; }
+        }
+        finish_bruteforce_chunk(desc, pd, s_qrows, cnt, s_q, s_keys, knn_idx, knn_dist);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else if (cnt > 0) {
         const int nchunks = (cnt + 31) >> 5;
         const float *__restrict__ tn = norms + pd.t_row0;
         const float *__restrict__ tr = rho_t + pd.t_row0;
