@@ -24,7 +24,7 @@ BA_MAX_LOG = 256
 
 STATUS_NAMES = {
     0: "ESFM_OK", -1: "ESFM_ERR_INVALID_ARG", -2: "ESFM_ERR_NO_DEVICE", -3: "ESFM_ERR_HIP", -4: "ESFM_ERR_OOM",
-    -5: "ESFM_ERR_UNSUPPORTED", -6: "ESFM_ERR_NUMERIC", -7: "ESFM_ERR_COMM",
+    -5: "ESFM_ERR_UNSUPPORTED", -6: "ESFM_ERR_NUMERIC", -7: "ESFM_ERR_COMM", -8: "ESFM_ERR_STALE_PREPARED",
 }
 
 # every symbol include/esfm.h declares (tests/test_abi.py checks the .so exports all of them)
@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "esfm_version", "esfm_last_error", "esfm_device_count", "esfm_ctx_create", "esfm_ctx_destroy",
     "esfm_ctx_synchronize", "esfm_ctx_stream", "esfm_ctx_set_kernel_timing", "esfm_ctx_kernel_time",
     "esfm_knn2_l2_f32", "esfm_knn2_hamming", "esfm_match_l2_f32", "esfm_match_hamming",
-    "esfm_match_pairs_dev", "esfm_match_pairs", "esfm_knn2_pairs_dev", "esfm_match_prepare_dev", "esfm_match_debug_counters", "esfm_match_release_prepared", "esfm_match_last_stats", "esfm_match_last_second_pass", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
+    "esfm_match_pairs_dev", "esfm_match_pairs", "esfm_knn2_pairs_dev", "esfm_knn2_pairs_screened_dev", "esfm_match_prepare_dev", "esfm_match_debug_counters", "esfm_match_release_prepared", "esfm_ctx_set_prepared_check", "esfm_match_last_stats", "esfm_match_last_second_pass", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
     "esfm_shard_pair_list",
     "esfm_comm_get_unique_id", "esfm_comm_create", "esfm_comm_destroy", "esfm_comm_rank", "esfm_comm_world", "esfm_comm_allreduce",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
@@ -124,10 +124,12 @@ def lib() -> C.CDLL:
     L.esfm_match_hamming.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, i32p]
     L.esfm_match_pairs_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp]
     L.esfm_knn2_pairs_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.esfm_knn2_pairs_screened_dev.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp]
     L.esfm_match_debug_counters.argtypes = [vp, vp]
     L.esfm_match_pairs.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp]
     L.esfm_match_prepare_dev.argtypes = [vp, C.c_int, vp, C.c_int64, C.c_int]
     L.esfm_match_release_prepared.argtypes = [vp]
+    L.esfm_ctx_set_prepared_check.argtypes = [vp, C.c_int]
     L.esfm_match_last_stats.argtypes = [vp, i64p, i64p]
     L.esfm_match_last_second_pass.argtypes = [vp, i64p]
     L.esfm_ctx_set_l2_audit.argtypes = [vp, C.c_int]

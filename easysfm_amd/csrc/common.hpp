@@ -70,6 +70,10 @@ struct esfm_ctx {
     int prep_metric = 0, prep_width = 0;
     bool prep_hm_fp4 = false;          // Hamming: hm_exp holds the FP4 form's nibble images (hamming_fp4_kernel), not the byte image of the i8 form
     int64_t prep_rows = 0;
+    // esfm_ctx_set_prepared_check: the prepared buffer's fingerprint ([0] at prepare, [1] re-derived by every match call that relies on it)
+    int prep_check = 0;
+    bool prep_has_sum = false;
+    esfm::DevBuf prep_sum;
     esfm::DevBuf knn_d2;   // exact second-best d^2 of the queries the one-product pass left uncertified (the refine pass's thresholds)
     esfm::DevBuf l2_hi;    // one-product pass: bf16(t) and bf16(-2 q) images (128 B per row each) and the two residual norms per row
     esfm::DevBuf hm_exp;   // expanded descriptor image: 0/1 bytes + start values (Hamming MFMA) or bf16 hi/lo halves (L2), 256 B per row

@@ -1,4 +1,5 @@
 // Context / error plumbing of libesfm_hip.so (include/esfm.h, "library / context").
+#include <cstdlib>
 #include "common.hpp"
 
 namespace esfm {
@@ -145,6 +146,7 @@ int esfm_ctx_create(int device, void *hip_stream, esfm_ctx **out)
     }
     if (hipSetDevice(device) != hipSuccess) { esfm::set_error("hipSetDevice(%d) failed", device); return ESFM_ERR_NO_DEVICE; }
     esfm_ctx *c = new esfm_ctx();
+    if (const char *e = getenv("ESFM_CHECK_PREPARED")) c->prep_check = (e[0] != '\0' && e[0] != '0') ? 1 : 0;
     c->device = device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream) {
@@ -169,7 +171,7 @@ int esfm_ctx_destroy(esfm_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     esfm::DevBuf *bufs[] = {&ctx->norms, &ctx->pair_tab, &ctx->knn_idx, &ctx->knn_dist, &ctx->flagged, &ctx->counters,
                             &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->stage_e, &ctx->hm_exp, &ctx->pair_cnt, &ctx->pair_list,
-                            &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi, &ctx->knn_d2, &ctx->pair_cnt2b, &ctx->fin_done, &ctx->bank, &ctx->surv_cnt, &ctx->surv_cntb, &ctx->surv_list};
+                            &ctx->pair_cnt2, &ctx->pair_list2, &ctx->l2_hi, &ctx->knn_d2, &ctx->pair_cnt2b, &ctx->fin_done, &ctx->bank, &ctx->surv_cnt, &ctx->surv_cntb, &ctx->surv_list, &ctx->prep_sum};
     for (auto *b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_rounds) (void)hipHostFree(ctx->pinned_rounds);

@@ -114,6 +114,31 @@ bool is_prepared(const esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, 
            ctx->prep_width == width;
 }
 
+size_t desc_bytes(esfm_metric metric, int64_t total_rows, int width)
+{
+    return (size_t)total_rows * (metric == ESFM_L2_F32 ? sizeof(float) * (size_t)width : (size_t)width);
+}
+
+// esfm_ctx_set_prepared_check(ctx, 1): a call that is about to rely on prepared operands first re-derives the buffer's fingerprint
+// and compares it with the one taken at prepare time (one read of the buffer + one host round trip per call: a debugging aid, off
+// by default).  A buffer that was rewritten in place -- or freed and replaced by another allocation at the same address -- fails
+// the call with ESFM_ERR_STALE_PREPARED and ends the prepared state, instead of matching against the old rows' images.
+int verify_prepared(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int64_t total_rows, int width)
+{
+    if (!ctx->prep_check) return ESFM_OK;
+    if (!ctx->prep_has_sum) { ctx->prep_desc = nullptr; return ESFM_OK; }      // prepared before the check was switched on: re-derive
+    unsigned long long *sums = ctx->prep_sum.as<unsigned long long>();
+    if (int rc = esfm::launch_buffer_checksum(ctx->stream, desc_dev, desc_bytes(metric, total_rows, width), sums + 1)) return rc;
+    unsigned long long h[2] = {0ull, 0ull};
+    ESFM_HIP_TRY(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (h[0] == h[1]) return ESFM_OK;
+    ctx->prep_desc = nullptr;
+    esfm::set_error("the descriptor buffer %p was modified (or replaced by another allocation at the same address) after esfm_match_prepare_dev: "
+                    "call esfm_match_prepare_dev again, or esfm_match_release_prepared before rewriting / freeing a prepared buffer", desc_dev);
+    return ESFM_ERR_STALE_PREPARED;
+}
+
 // 2-NN table for every query of every pair, written to knn_idx/knn_dist (device, 2 per query).
 // `ratio`: the caller will only keep the queries with d0 < ratio d1 (the match entry points), so the one-product pass may drop the
 // ones that provably fail (train index -2, see l2_knn_bf16x1_kernel); INFINITY: every query's exact 2-NN (the knn2 entry points).
@@ -125,6 +150,8 @@ int knn2_core(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int width
     const int n_pairs = (int)plan.tab.size();
     if (n_pairs == 0 || plan.total_queries == 0) return ESFM_OK;
     hipStream_t st = ctx->stream;
+    if (is_prepared(ctx, metric, desc_dev, plan.total_rows, width))
+        if (int rc = verify_prepared(ctx, metric, desc_dev, plan.total_rows, width)) return rc;
     const bool prepared = is_prepared(ctx, metric, desc_dev, plan.total_rows, width);
     if (metric == ESFM_L2_F32) {
         const float *desc = reinterpret_cast<const float *>(desc_dev);
@@ -380,9 +407,9 @@ int esfm_match_hamming(esfm_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t
     return single_pair(ctx, ESFM_HAMMING, q, nq, t, nt, nbytes, true, ratio, query_idx, train_idx, distance, n_out);
 }
 
-int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
-                        int width, const int32_t *pairs, int n_pairs, int32_t *knn_idx_dev, float *knn_dist_dev,
-                        int64_t *out_offset)
+static int knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
+                         int width, const int32_t *pairs, int n_pairs, double ratio, int32_t *knn_idx_dev, float *knn_dist_dev,
+                         int64_t *out_offset)
 {
     if (int rc = check_common(ctx, metric, width)) return rc;
     ESFM_REQUIRE(out_offset != nullptr, "out_offset is NULL");
@@ -394,7 +421,25 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
     ESFM_REQUIRE(desc_dev && knn_idx_dev && knn_dist_dev, "device pointer is NULL");
     const PairDesc *dev_tab = nullptr;
     if (int rc = upload_pairs(ctx, plan, &dev_tab)) return rc;
-    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev, (double)INFINITY, nullptr, nullptr);
+    return knn2_core(ctx, metric, desc_dev, width, plan, dev_tab, knn_idx_dev, knn_dist_dev, ratio, nullptr, nullptr);
+}
+
+int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
+                        int width, const int32_t *pairs, int n_pairs, int32_t *knn_idx_dev, float *knn_dist_dev,
+                        int64_t *out_offset)
+{
+    return knn2_pairs_dev(ctx, metric, desc_dev, set_row_offset, n_sets, width, pairs, n_pairs, (double)INFINITY, knn_idx_dev, knn_dist_dev, out_offset);
+}
+
+// Audit of the Hamming matcher's ratio screen (tests): the raw table of a call that screens with `ratio` -- the queries the pass
+// dropped as "cannot pass d0 < ratio d1" carry train index -2 in both slots, every other query its exact 2-NN.
+int esfm_knn2_pairs_screened_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
+                                 int width, const int32_t *pairs, int n_pairs, double ratio, int32_t *knn_idx_dev, float *knn_dist_dev,
+                                 int64_t *out_offset)
+{
+    if (metric != ESFM_HAMMING) { esfm::set_error("esfm_knn2_pairs_screened_dev: Hamming only (the L2 screen is audited through esfm_ctx_set_l2_audit mode 4)"); return ESFM_ERR_UNSUPPORTED; }
+    if (!(ratio == ratio)) { esfm::set_error("ratio is NaN"); return ESFM_ERR_INVALID_ARG; }
+    return knn2_pairs_dev(ctx, metric, desc_dev, set_row_offset, n_sets, width, pairs, n_pairs, ratio, knn_idx_dev, knn_dist_dev, out_offset);
 }
 
 int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, const int32_t *set_row_offset, int n_sets,
@@ -490,7 +535,20 @@ int esfm_match_prepare_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_d
     } else {
         return ESFM_OK;       // nothing to derive for this metric / width: the match calls work on the rows themselves
     }
+    ctx->prep_has_sum = false;
+    if (ctx->prep_check) {
+        if (int rc = ctx->prep_sum.reserve(2 * sizeof(unsigned long long))) return rc;
+        if (int rc = esfm::launch_buffer_checksum(st, desc_dev, desc_bytes(metric, total_rows, width), ctx->prep_sum.as<unsigned long long>())) return rc;
+        ctx->prep_has_sum = true;
+    }
     ctx->prep_desc = desc_dev; ctx->prep_metric = (int)metric; ctx->prep_rows = total_rows; ctx->prep_width = width;
+    return ESFM_OK;
+}
+
+int esfm_ctx_set_prepared_check(esfm_ctx *ctx, int enable)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    ctx->prep_check = enable ? 1 : 0;
     return ESFM_OK;
 }
 

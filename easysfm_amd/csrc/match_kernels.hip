@@ -3071,6 +3071,33 @@ int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, v
     return ESFM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fingerprint of a resident descriptor buffer (esfm_ctx_set_prepared_check): a position-keyed 64-bit sum over its 4-byte words --
+// integer addition, so the order in which the waves arrive does not matter.  One word of `out` is added to (zeroed by the caller).
+__global__ __launch_bounds__(256) void buffer_checksum_kernel(const uint32_t *__restrict__ p, long long n_words, unsigned long long *__restrict__ out)
+{
+    unsigned long long h = 0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long long)gridDim.x * 256) {
+        unsigned long long x = ((unsigned long long)p[i] << 32 | (unsigned long long)(uint32_t)i) ^ ((unsigned long long)(i >> 32) << 17);
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;      // (murmur3's finaliser)
+        h += x;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
+int launch_buffer_checksum(hipStream_t st, const void *buf, size_t bytes, unsigned long long *out)
+{
+    ESFM_HIP_TRY(hipMemsetAsync(out, 0, sizeof(unsigned long long), st));
+    const long long n_words = (long long)(bytes / 4);
+    if (n_words <= 0) return ESFM_OK;
+    const int grid = (int)std::min<long long>((n_words + 255) / 256, 2048);
+    hipLaunchKernelGGL(buffer_checksum_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(buf), n_words, out);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
 int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
                          double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out)
 {

@@ -83,6 +83,7 @@ int launch_hamming_fp4(hipStream_t st, const void *desc, long long total_rows, v
 int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long total_rows, void *exp_scratch,
                        const PairDesc *pairs, int n_pairs, int n_blocks,
                        int32_t *knn_idx, float *knn_dist, bool expanded);
+int launch_buffer_checksum(hipStream_t st, const void *buf, size_t bytes, unsigned long long *out);
 int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
                          double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
 

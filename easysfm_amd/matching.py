@@ -220,10 +220,44 @@ class DescriptorBank:
         host = np.concatenate(sets, axis=0) if sets else np.zeros((0, self.width), dt)
         self.device = torch.device(device)
         self.data = torch.from_numpy(host).to(self.device)
+        self._matchers = []          # live PairMatchers (weak): update() re-prepares them
 
     @property
     def n_sets(self) -> int:
         return len(self.rows)
+
+    def update(self, sets: Sequence[np.ndarray]) -> None:
+        """Replace the rows IN PLACE (same set sizes: the buffer and every PairMatcher's output slices stay as they are).  The
+        operand images a PairMatcher derived from the old rows are stale after this: every matcher of this bank is re-prepared
+        (esfm.h: a prepared buffer must be prepared again before a match call relies on it)."""
+        import torch
+        dt = np.float32 if self.metric == ESFM_L2_F32 else np.uint8
+        sets = [_as_desc(s, dt) for s in sets]
+        if [s.shape[0] for s in sets] != list(self.rows) or any(s.shape[1] != self.width for s in sets):
+            raise ValueError("update() keeps the bank's shape: same number of sets, rows per set and width")
+        for m in list(self._matchers):
+            m.release()
+        if len(sets) and int(self.row_offset[-1]):
+            self.data.copy_(torch.from_numpy(np.concatenate(sets, axis=0)))
+            torch.cuda.synchronize(self.device)
+        for m in list(self._matchers):
+            m.prepare()
+
+
+class _WeakCall:
+    """A weak reference that forwards attribute access to its referent (DescriptorBank keeps its matchers without owning them)."""
+
+    def __init__(self, ref):
+        self._ref = ref
+
+    def __call__(self):
+        return self._ref()
+
+    def __getattr__(self, name):
+        obj = self._ref()
+        if obj is None:
+            return lambda *a, **k: None
+        return getattr(obj, name)
 
 
 class PairMatcher:
@@ -250,13 +284,43 @@ class PairMatcher:
         self.knn_idx = None
         self.knn_dist = None
         torch.cuda.synchronize(dev)   # the bank upload ran on torch's stream; kernels run on ctx's
+        import weakref
+        bank._matchers = [m for m in bank._matchers if m() is not None]
+        self._ref = weakref.ref(self)
+        bank._matchers.append(_WeakCall(self._ref))
         self.prepare()
 
     def prepare(self) -> None:
         """Part of the upload: the per-row operands the matcher derives from the resident descriptors (esfm_match_prepare_dev) --
-        computed once here instead of at the head of every match() / knn2() call."""
+        computed once here instead of at the head of every match() / knn2() call.  ONE prepared buffer per context (esfm.h): a
+        second PairMatcher on the same Context takes the prepared state over, and the first one's calls re-derive the operands
+        every time (correct, slower) until its prepare() is called again.  The bank's rows must not change while prepared:
+        DescriptorBank.update() is the way to rewrite them."""
         b = self.bank
         check(lib().esfm_match_prepare_dev(self.ctx.handle, b.metric, C.c_void_p(b.data.data_ptr()), int(b.row_offset[-1]), b.width))
+
+    def release(self) -> None:
+        """esfm_match_release_prepared: to be called before the bank's buffer is freed or rewritten (close() / garbage collection /
+        DescriptorBank.update() do) -- a later allocation at the same address must not inherit this one's operand images."""
+        try:
+            h = self.ctx.handle
+        except RuntimeError:
+            return
+        check(lib().esfm_match_release_prepared(h))
+
+    def close(self) -> None:
+        self.release()
+        self.bank._matchers = [m for m in self.bank._matchers if m() is not None and m() is not self]
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def set_prepared_check(self, enable: bool) -> None:
+        """esfm_ctx_set_prepared_check: fingerprint the prepared buffer and verify it on every call (a debugging aid)."""
+        check(lib().esfm_ctx_set_prepared_check(self.ctx.handle, 1 if enable else 0))
 
     def match(self, ratio: float) -> PairMatches:
         """Enqueue the whole pair list; does not synchronise."""
@@ -280,6 +344,18 @@ class PairMatcher:
             _ptr(self.pairs), len(self.pairs), C.c_void_p(self.knn_idx.data_ptr()), C.c_void_p(self.knn_dist.data_ptr()),
             _ptr(self.offset)))
         return self.knn_idx, self.knn_dist
+
+    def knn2_screened(self, ratio: float):
+        """Hamming only (esfm_knn2_pairs_screened_dev): the raw table of a pass that screens with `ratio` -- train index -2 marks
+        the queries it dropped as unable to pass d0 < ratio d1."""
+        torch = self.torch
+        b = self.bank
+        idx = torch.empty((max(self.total_queries, 1), 2), dtype=torch.int32, device=b.device)
+        dist = torch.empty((max(self.total_queries, 1), 2), dtype=torch.float32, device=b.device)
+        check(lib().esfm_knn2_pairs_screened_dev(
+            self.ctx.handle, b.metric, C.c_void_p(b.data.data_ptr()), _ptr(b.row_offset), b.n_sets, b.width,
+            _ptr(self.pairs), len(self.pairs), float(ratio), C.c_void_p(idx.data_ptr()), C.c_void_p(dist.data_ptr()), _ptr(self.offset)))
+        return idx, dist
 
     def set_l2_audit(self, mode: int) -> None:
         """Certificate audit (tests): 0 product path, 1 skip the exact re-scan, 2 brute-force every query, 3 the one-product pass alone (esfm.h)."""

@@ -45,7 +45,9 @@ typedef enum esfm_status {
     ESFM_ERR_OOM = -4,
     ESFM_ERR_UNSUPPORTED = -5, /* e.g. descriptor width the kernels are not built for     */
     ESFM_ERR_NUMERIC = -6,     /* BA: non-finite input or an unusable linear system       */
-    ESFM_ERR_COMM = -7         /* BA: the all-reduce callback reported failure             */
+    ESFM_ERR_COMM = -7,        /* BA: the all-reduce callback reported failure             */
+    ESFM_ERR_STALE_PREPARED = -8 /* matching: a prepared descriptor buffer no longer holds the rows it was prepared from
+                                    (only detected under esfm_ctx_set_prepared_check)       */
 } esfm_status;
 
 typedef struct esfm_ctx esfm_ctx;
@@ -172,6 +174,15 @@ int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host,
  */
 int esfm_match_prepare_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int64_t total_rows, int width);
 int esfm_match_release_prepared(esfm_ctx *ctx);
+/* The prepared state is keyed on (desc_dev, metric, total_rows, width) and there is ONE per context: a second prepare replaces the
+ * first.  The library cannot see a hipFree or an in-place rewrite, and a same-size hipMalloc routinely returns the address just
+ * freed: a prepared buffer MUST be released (esfm_match_release_prepared) or prepared again BEFORE it is freed, rewritten or
+ * replaced -- otherwise the next match call on that address runs on the old rows' operand images and returns wrong matches
+ * without an error.  esfm_ctx_set_prepared_check(ctx, 1) is the debugging aid for exactly that: prepare then also keeps a 64-bit
+ * fingerprint of the buffer, and every match call that is about to rely on the prepared operands re-derives it first (one read of
+ * the buffer and one host round trip per call) and fails with ESFM_ERR_STALE_PREPARED -- ending the prepared state -- when the rows
+ * have changed.  Off by default; the environment variable ESFM_CHECK_PREPARED=1 switches it on for every new context. */
+int esfm_ctx_set_prepared_check(esfm_ctx *ctx, int enable);
 
 /* Same pass, but returns the raw 2-NN table instead of the filtered list:
  * knn_idx_dev / knn_dist_dev hold 2 entries per query row, pair p at
@@ -180,6 +191,15 @@ int esfm_knn2_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
                         const int32_t *set_row_offset, int n_sets, int width,
                         const int32_t *pairs, int n_pairs,
                         int32_t *knn_idx_dev, float *knn_dist_dev, int64_t *out_offset);
+
+/* Audit of the Hamming matcher's ratio screen (tests only; metric must be ESFM_HAMMING -- the L2 screen is audited through
+ * esfm_ctx_set_l2_audit mode 4): the raw table of a pass that screens with `ratio` as esfm_match_pairs_dev's does.  A query
+ * the pass dropped as "cannot pass d0 < ratio d1" (feature_matching.cpp:88) carries train index -2 in both slots; every other
+ * query its exact 2-NN.  Every dropped query must fail the reference's test on the unscreened table. */
+int esfm_knn2_pairs_screened_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev,
+                                 const int32_t *set_row_offset, int n_sets, int width,
+                                 const int32_t *pairs, int n_pairs, double ratio,
+                                 int32_t *knn_idx_dev, float *knn_dist_dev, int64_t *out_offset);
 
 /* Counters of the last L2 batched call on this context (after a synchronise):
  * queries whose MFMA candidate list could not be certified and were re-scanned
