@@ -9,7 +9,7 @@ from ._lib import BAOptions, BASummary, Context, EsfmError, ESFM_HAMMING, ESFM_L
 from .types import DMatch, Frame, SparsePointCloud  # noqa: F401
 from .matching import (DescriptorBank, FeatureMatching, PairMatcher, knn_match_hamming, knn_match_l2,  # noqa: F401
                        match_hamming, match_l2, match_pairs_host, shard_pair_list)
-from .ba import (BAProblem, BundleAdjustment, Comm, ba_solve, ba_solve_ex, ba_sweep_bytes_per_obs, default_options, line_search_next_step, shard_points,  # noqa: F401
+from .ba import (BAProblem, BundleAdjustment, Comm, ba_solve, ba_solve_ex, ba_sweep_bytes_per_obs, default_options, line_search_next_step, reduced_plan, shard_points,  # noqa: F401
                  torch_allreduce_callback)
 
 from .cloud import CProceesing, read_ply_vertices, sor_filter, write_ply  # noqa: F401

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "esfm_comm_get_unique_id", "esfm_comm_create", "esfm_comm_destroy", "esfm_comm_rank", "esfm_comm_world", "esfm_comm_allreduce",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
     "esfm_ba_problem_solve", "esfm_ba_problem_get_params", "esfm_ba_problem_destroy", "esfm_ba_problem_cost",
-    "esfm_ba_shard_points", "esfm_ba_problem_create_free_calib", "esfm_ba_problem_set_calib", "esfm_ba_problem_get_calib",
+    "esfm_ba_shard_points", "esfm_ba_reduced_plan", "esfm_ba_problem_create_free_calib", "esfm_ba_problem_set_calib", "esfm_ba_problem_get_calib",
     "esfm_ba_problem_fix_camera", "esfm_ba_solve_ex", "esfm_ba_line_search_next_step",
     "esfm_sor_filter", "esfm_sor_mean_distances_dev", "esfm_triangulate_points", "esfm_triangulate_pairs",
     "esfm_find_essential_mat", "esfm_find_essential_pairs", "esfm_recover_pose", "esfm_recover_pose_pairs", "esfm_ransac_sample_stream",
@@ -173,6 +173,7 @@ def lib() -> C.CDLL:
     L.esfm_ba_problem_destroy.argtypes = [vp]
     L.esfm_ba_problem_cost.argtypes = [vp, C.c_double, f64p]
     L.esfm_ba_shard_points.argtypes = [C.c_int, C.c_int, vp, C.c_int, vp]
+    L.esfm_ba_reduced_plan.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("esfm_device_count",):

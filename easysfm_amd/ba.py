@@ -233,6 +233,20 @@ def shard_points(n_pt: int, pt_idx, world: int) -> np.ndarray:
     return out[:n_pt]
 
 
+def reduced_plan(n_cam: int, n_pt: int, cam_idx, pt_idx, leaf_max: int = 0) -> dict:
+    """esfm_ba_reduced_plan (host-only, no GPU): the structure-aware plan of the reduced camera system for an observation list --
+    nested-dissection order of the cameras (col_src: original unknown of every permuted, tile-padded column; -1 = padding), the
+    tiles of the symbolic fill, the dependency chain length.  What the tiled solve builds for itself; for tests and tools."""
+    cam_idx = np.ascontiguousarray(cam_idx, np.int32); pt_idx = np.ascontiguousarray(pt_idx, np.int32)
+    info = np.zeros(8, np.int32)
+    check(lib().esfm_ba_reduced_plan(int(n_cam), int(n_pt), len(cam_idx), _p(cam_idx), _p(pt_idx), int(leaf_max), None, 0, None, 0, _p(info)))
+    col_src = np.zeros(max(int(info[0]) * 64, 1), np.int32); tiles = np.zeros((max(int(info[1]), 1), 2), np.int32)
+    check(lib().esfm_ba_reduced_plan(int(n_cam), int(n_pt), len(cam_idx), _p(cam_idx), _p(pt_idx), int(leaf_max), _p(col_src), len(col_src),
+                                     _p(tiles), len(tiles), _p(info)))
+    return dict(nb=int(info[0]), col_src=col_src[:int(info[0]) * 64], tiles=tiles[:int(info[1])], chain=int(info[2]), dense_nb=int(info[3]),
+                worthwhile=bool(info[4]), update_steps=int(info[5]), supernodes=int(info[6]), workgroups=int(info[7]))
+
+
 # ------------------------------------------------------------------------------------------------
 # cv::Rodrigues as the reference uses it (ba.cpp:82 matrix -> vector, :239 vector -> matrix).
 def rotation_to_angle_axis(R: np.ndarray) -> np.ndarray:

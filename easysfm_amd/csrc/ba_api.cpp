@@ -15,6 +15,8 @@
 
 #include "ba_kernels.hpp"
 #include "ba_linesearch.hpp"
+#include "ba_sparse_plan.hpp"
+#include "ba_chol_sparse.hpp"
 
 using esfm::BADev;
 
@@ -31,6 +33,15 @@ struct esfm_ba_problem {
     esfm::ScalParts parts{};    // per-workgroup scalar partials pending on the device (BADev::parts points here)
     double *h_scal = nullptr;   // pinned host copy of the scalar slots: the LM loop reads them back twice per iteration
     unsigned long long seq = 0; // sequence number of the last publication (the flag sits behind the scalars)
+    // structure of the reduced camera system (ba_sparse_plan.hpp): this rank's co-visible camera pairs, from the observation list at
+    // creation; the plan and its device tables are built by the first solve that can use them (several ranks: from the union of
+    // the ranks' pairs) and kept
+    std::vector<uint8_t> pair_flags;
+    std::vector<int32_t> h_pt_start, h_obs_cam;
+    esfm::SparseSolve *sparse = nullptr;
+    int sparse_key = -1;        // what `sparse` was planned for: 0 one rank, 1 several ranks; -1 not planned yet
+    int sparse_leaf_max = 0;
+    bool sparse_worthwhile = false;
 };
 
 namespace {
@@ -150,6 +161,51 @@ struct Solver {
     }
 };
 
+// Structure of the reduced camera system for this solve (see ba_sparse_plan.hpp).  Camera blocks (a, b) of S are non-zero only where
+// a and b observe a common point; when that leaves at most half of the dense factorisation's tiles -- or half its dependency chain
+// -- the tiled solve visits only the tiles of the symbolic fill (ba_chol_sparse.hip).  Several ranks: every rank holds the
+// observations of ITS points, so the ranks' pair sets are united first (one small all-reduce per solve; four 13-bit counters per
+// double, exact for up to 8191 ranks), every rank plans from the same union and the plans are identical.  ESFM_BA_SOLVE=dense keeps the
+// dense path, =sparse takes the plan even where it does not pay (tests); ESFM_BA_LEAF_MAX: cameras per undissected leaf.
+int plan_reduced_structure(esfm_ba_problem *P, Solver &S, bool multi)
+{
+    BADev &d = P->d;
+    d.sparse = nullptr;
+    const char *mode = getenv("ESFM_BA_SOLVE");
+    const bool force_dense = mode && mode[0] == 'd', force_sparse = mode && mode[0] == 's';
+    if (force_dense || d.has_calib || !esfm::ba_solve_is_tiled(d.n_cam) || P->h_pt_start.empty()) return ESFM_OK;
+    const char *lm = getenv("ESFM_BA_LEAF_MAX");
+    const int leaf_max = lm && atoi(lm) > 0 ? atoi(lm) : 32;
+    const int key = multi ? 1 : 0;
+    if (P->sparse_key != key || P->sparse_leaf_max != leaf_max) {
+        esfm::ba_sparse_destroy(P->sparse); P->sparse = nullptr;
+        if (P->pair_flags.empty()) P->pair_flags = esfm::cam_pair_flags(d.n_real_cam, d.n_pt, P->h_pt_start.data(), P->h_obs_cam.data());
+        std::vector<uint8_t> all;
+        if (multi) {
+            const size_t nf = P->pair_flags.size(), nd = (nf + 3) / 4;
+            std::vector<double> pk(nd, 0.0);
+            for (size_t k = 0; k < nf; ++k) if (P->pair_flags[k]) pk[k / 4] += (double)(1ull << (13 * (k % 4)));
+            double *dev = nullptr;
+            ESFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(double) * std::max<size_t>(nd, 1)));
+            int rc = ESFM_OK;
+            if (hipMemcpyAsync(dev, pk.data(), sizeof(double) * nd, hipMemcpyHostToDevice, S.st) != hipSuccess || hipStreamSynchronize(S.st) != hipSuccess) rc = ESFM_ERR_HIP;
+            if (rc == ESFM_OK) rc = S.allreduce(dev, (int64_t)nd, ESFM_REDUCE_SUM);
+            if (rc == ESFM_OK && (hipMemcpyAsync(pk.data(), dev, sizeof(double) * nd, hipMemcpyDeviceToHost, S.st) != hipSuccess || hipStreamSynchronize(S.st) != hipSuccess)) rc = ESFM_ERR_HIP;
+            (void)hipFree(dev);
+            if (rc != ESFM_OK) { if (rc == ESFM_ERR_HIP) esfm::set_error("exchange of the camera co-visibility failed"); return rc; }
+            all.assign(nf, 0);
+            for (size_t k = 0; k < nf; ++k) all[k] = (((unsigned long long)pk[k / 4] >> (13 * (k % 4))) & 0x1FFFull) ? 1 : 0;
+        }
+        const esfm::CamGraph g = esfm::cam_graph_from_tracks(d.n_real_cam, d.n_pt, P->h_pt_start.data(), P->h_obs_cam.data(), multi ? &all : nullptr);
+        const esfm::SparsePlan plan = esfm::make_sparse_plan(g, leaf_max);
+        P->sparse_worthwhile = plan.worthwhile();
+        if (int rc = esfm::ba_sparse_create(S.st, plan, g, &P->sparse)) return rc;
+        P->sparse_key = key; P->sparse_leaf_max = leaf_max;
+    }
+    if (P->sparse && (P->sparse_worthwhile || force_sparse)) d.sparse = P->sparse;
+    return ESFM_OK;
+}
+
 int fill_ones(hipStream_t st, double *dst, size_t n)
 {
     std::vector<double> ones(n, 1.0);
@@ -205,6 +261,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         s_uv[2 * (size_t)t] = obs_uv[2 * (size_t)k]; s_uv[2 * (size_t)t + 1] = obs_uv[2 * (size_t)k + 1];
         P->cam_nobs_local[(size_t)cam_idx[k]] += 1.0;
     }
+    if (!calib && esfm::ba_solve_is_tiled(n_cam)) { P->h_pt_start = pt_start; P->h_obs_cam = s_cam; }   // (for the reduced system's structure)
     BADev &d = P->d;
     d.n_cam = n_cam; d.n_pt = n_pt; d.n_obs = n_obs;
     d.n_real_cam = n_real; d.has_calib = calib ? 1 : 0;
@@ -502,6 +559,7 @@ int esfm_ba_problem_destroy(esfm_ba_problem *P)
     if (!P) return ESFM_OK;
     if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
     for (void *p : P->allocs) (void)hipFree(p);
+    esfm::ba_sparse_destroy(P->sparse);
     if (P->h_scal) (void)hipHostFree(P->h_scal);
     delete P;
     return ESFM_OK;
@@ -553,6 +611,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     if (d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(d.cam_nobs, P->cam_nobs_local.data(), sizeof(double) * (size_t)d.n_cam, hipMemcpyHostToDevice, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     if (int rc = S.allreduce(d.cam_nobs, d.n_cam, ESFM_REDUCE_SUM)) return rc;
+    if (int rc = plan_reduced_structure(P, S, multi)) return rc;
     if (int rc = fill_ones(st, d.scale_c, (size_t)6 * d.n_cam)) return rc;
     if (int rc = fill_ones(st, d.scale_p, (size_t)3 * d.n_pt)) return rc;
     if (multi && d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(d.x0_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
@@ -686,7 +745,11 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             if (int rc = esfm::ba_schur(st, d, P->ctx->num_cu, d.slabs, d.slab_cap, rhs_bound)) return finish(rc);
             if (int rc = esfm::ba_schur_calib(st, d, rhs_bound)) return finish(rc);
         }
-        if (multi) {
+        if (multi && d.sparse) {
+            // one exchange per LM iteration, of the co-visible camera blocks and the right-hand side only (BA-512: 1.4 MB instead of 37.8)
+            if (int rc = esfm::ba_sparse_pack(st, d, d.sparse, d.red_packed)) return finish(rc);
+            if (int rc = S.allreduce(d.red_packed, (int64_t)esfm::ba_sparse_packed_doubles(d.sparse, d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
+        } else if (multi) {
             // one exchange per LM iteration: the block-lower-triangular S and the right-hand side, packed
             if (int rc = esfm::ba_red_pack(st, d, d.red_packed, false)) return finish(rc);
             if (int rc = S.allreduce(d.red_packed, (int64_t)esfm::ba_red_packed_doubles(d.n_cam), ESFM_REDUCE_SUM)) return finish(rc);
@@ -895,6 +958,38 @@ int esfm_ba_shard_points(int n_pt, int n_obs, const int32_t *pt_idx, int world, 
         shard_of_point[p] = shard;
         acc += cnt[(size_t)p];
     }
+    return ESFM_OK;
+}
+
+// Host-only: the structure-aware plan of the reduced camera system for this observation list (ba_sparse_plan.hpp) -- what
+// esfm_ba_problem_solve builds for itself; exported for tests and tools.
+int esfm_ba_reduced_plan(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, int leaf_max,
+                         int32_t *col_src, int col_cap, int32_t *tiles, int tile_cap, int32_t *info)
+{
+    if (n_cam < 0 || n_pt < 0 || n_obs < 0 || (n_obs && (!cam_idx || !pt_idx)) || !info || col_cap < 0 || tile_cap < 0) {
+        esfm::set_error("esfm_ba_reduced_plan: bad arguments");
+        return ESFM_ERR_INVALID_ARG;
+    }
+    std::vector<int32_t> pt_start((size_t)n_pt + 1, 0), s_cam((size_t)n_obs);
+    for (int k = 0; k < n_obs; ++k) {
+        if (cam_idx[k] < 0 || cam_idx[k] >= n_cam || pt_idx[k] < 0 || pt_idx[k] >= n_pt) { esfm::set_error("observation index out of range"); return ESFM_ERR_INVALID_ARG; }
+        pt_start[(size_t)pt_idx[k] + 1]++;
+    }
+    for (int p = 0; p < n_pt; ++p) pt_start[(size_t)p + 1] += pt_start[(size_t)p];
+    {
+        std::vector<int32_t> fill(pt_start.begin(), pt_start.end() - 1);
+        for (int k = 0; k < n_obs; ++k) s_cam[(size_t)fill[(size_t)pt_idx[k]]++] = cam_idx[k];
+    }
+    const esfm::CamGraph g = esfm::cam_graph_from_tracks(n_cam, n_pt, pt_start.data(), s_cam.data());
+    const esfm::SparsePlan pl = esfm::make_sparse_plan(g, leaf_max > 0 ? leaf_max : 32);
+    info[0] = pl.nb; info[1] = (int32_t)pl.tiles.size(); info[2] = pl.chain; info[3] = pl.dense_nb; info[4] = pl.worthwhile() ? 1 : 0;
+    info[5] = (int32_t)std::min<long long>(pl.update_steps, INT32_MAX); info[6] = (int32_t)pl.node_kind.size(); info[7] = (int32_t)pl.wgs.size();
+    if ((size_t)col_cap < pl.col_src.size() || (size_t)tile_cap < pl.tiles.size()) {
+        if (col_src || tiles) { esfm::set_error("esfm_ba_reduced_plan: output arrays too small (need %zu columns, %zu tiles)", pl.col_src.size(), pl.tiles.size()); return ESFM_ERR_INVALID_ARG; }
+        return ESFM_OK;          // sizing call
+    }
+    if (col_src) for (size_t k = 0; k < pl.col_src.size(); ++k) col_src[k] = pl.col_src[k];
+    if (tiles) for (size_t k = 0; k < pl.tiles.size(); ++k) { tiles[2 * k] = pl.tiles[k].I; tiles[2 * k + 1] = pl.tiles[k].J; }
     return ESFM_OK;
 }
 

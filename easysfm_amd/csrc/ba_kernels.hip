@@ -16,6 +16,7 @@
 #include <array>
 
 #include "ba_kernels.hpp"
+#include "ba_chol_sparse.hpp"
 
 #include <float.h>
 
@@ -2177,8 +2178,9 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
         hipLaunchKernelGGL(ba_schur_kernel, dim3(div_up(d.n_obs, 256)), dim3(256), 0, st, d, rhs_exp, (const int32_t *)nullptr, 0);
         LAUNCH_CHECK();
     }
-    if (finish && d.parts->single_rank && ba_solve_is_tiled(d.n_cam)) {
-        // the tiled solve's assembly kernel reads red next: it converts on the way and clears what it has read
+    if (finish && ba_solve_is_tiled(d.n_cam) && (d.parts->single_rank || d.sparse)) {
+        // the tiled solve's assembly kernel reads red next: it converts on the way and clears what it has read (the structure-aware
+        // solve of several ranks: its pack kernel does)
         d.parts->red_fixed = true; d.parts->red_rhs_exp = rhs_exp;
         return ESFM_OK;
     }
@@ -2197,6 +2199,7 @@ int ba_solve_reduced(hipStream_t st, const BADev &d, double radius, double min_d
     const int n = 6 * d.n_cam;
     const size_t bytes = sizeof(double) * ((size_t)(n + 1) * (n + 2) / 2 + n + 2);
     if (ba_chol_small_fits(d.n_cam)) return ba_solve_reduced_small(st, d, radius, min_diag, max_diag);
+    if (d.sparse) return ba_solve_reduced_sparse(st, d, d.sparse, radius, min_diag, max_diag);
     if (bytes <= 150 * 1024) {
         ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_chol_solve_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

@@ -39,6 +39,7 @@ struct ScalParts {                             // host-side bookkeeping of one p
     bool red_clean = false;                    // red is all zeros: the next ba_schur need not clear it
     int red_rhs_exp = 0;
 };
+struct SparseSolve;                            // the structure-aware reduced solve of one problem (ba_chol_sparse.hpp); host object
 // does ba_solve_reduced take the tiled path (ba_solve_reduced_large) for this camera count?
 bool ba_solve_is_tiled(int n_cam);
 struct ScalCounts { int n[SC_SUM_COUNT]; };   // kernel argument: how many partials each slot has pending
@@ -115,6 +116,7 @@ struct BADev {
     double *scal_part = nullptr;        // [SC_SUM_COUNT][scal_cap]
     int scal_cap = 0;
     ScalParts *parts = nullptr;         // HOST memory (esfm_ba_problem): partials pending per slot; never dereferenced on the device
+    SparseSolve *sparse = nullptr;      // HOST memory: set while the running solve takes the structure-aware reduced solve (ba_chol_sparse.hip)
     // Exact, hence order-independent, accumulation of the Schur complement: d.red is accumulated as 64-bit FIXED-POINT integers
     // (LDS / global u64 atomics, slab sums: integer addition is associative) and converted to f64 once, before the solve.  Entry
     // (r, c) is scaled by 2^(60 - qexp[r] - qexp[c]) with sqrt(diag(F'F)_i) < 2^qexp[i]:  Cauchy-Schwarz with E M^-1 E' <= I bounds

@@ -416,6 +416,19 @@ double esfm_ba_line_search_next_step(double f0, double g0, double x_prev, double
  * order), writing shard_of_point[n_pt].  Observations follow their point. */
 int esfm_ba_shard_points(int n_pt, int n_obs, const int32_t *pt_idx, int world, int32_t *shard_of_point);
 
+/* Host-only (no GPU): the structure-aware plan of the reduced camera system for an observation list -- what esfm_ba_problem_solve
+ * builds for itself when the camera count takes the tiled solve.  Block (a, b) of the reduced system is structurally non-zero only
+ * if cameras a and b observe a common point (the reference adds one residual block per observation, cpp_code/src/ba.cpp:140-151,
+ * and lets DENSE_SCHUR, :201, ignore that).  The cameras are ordered by nested dissection of that co-visibility graph, every
+ * supernode padded to whole 64-column tiles; the factorisation visits only the tiles of the symbolic fill.
+ *   col_src[k]   original unknown 6 cam + a of permuted column k, -1 for identity padding (nb * 64 entries)
+ *   tiles[2 t]   block row / column of tile t of the factor (lower triangle, fill included; block row nb = the right-hand side)
+ *   info[0..7]   nb, tiles, longest dependency chain in tile columns, tile columns of the dense path, 1 if the solve would use
+ *                the plan (at most half the dense path's tiles or half its dependency chain), 64^3 products, supernodes, workgroups
+ * col_src / tiles may be NULL (with capacity 0) to size the arrays from info first.  leaf_max <= 0: the library's default. */
+int esfm_ba_reduced_plan(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, int leaf_max,
+                         int32_t *col_src, int col_cap, int32_t *tiles, int tile_cap, int32_t *info /*8*/);
+
 /* ---- sparse-cloud statistical outlier removal ------------------------
  * CProceesing::SORFilter (cpp_code/include/cloudprocessing.hpp:24-36, called on the final cloud at
  * cpp_code/test/sfm.cpp:333) = pcl::StatisticalOutlierRemoval with MeanK (50) and StddevMulThresh (2.0):
