@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "esfm_knn2_l2_f32", "esfm_knn2_hamming", "esfm_match_l2_f32", "esfm_match_hamming",
     "esfm_match_pairs_dev", "esfm_match_pairs", "esfm_knn2_pairs_dev", "esfm_knn2_pairs_screened_dev", "esfm_match_prepare_dev", "esfm_match_debug_counters", "esfm_match_release_prepared", "esfm_ctx_set_prepared_check", "esfm_match_last_stats", "esfm_match_last_second_pass", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
     "esfm_shard_pair_list",
-    "esfm_comm_get_unique_id", "esfm_comm_create", "esfm_comm_destroy", "esfm_comm_rank", "esfm_comm_world", "esfm_comm_allreduce",
+    "esfm_comm_get_unique_id", "esfm_comm_create", "esfm_comm_destroy", "esfm_comm_rank", "esfm_comm_world", "esfm_comm_rccl_ranks", "esfm_comm_allreduce",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
     "esfm_ba_problem_solve", "esfm_ba_problem_get_params", "esfm_ba_problem_destroy", "esfm_ba_problem_cost",
     "esfm_ba_shard_points", "esfm_ba_reduced_plan", "esfm_ba_problem_create_free_calib", "esfm_ba_problem_set_calib", "esfm_ba_problem_get_calib",
@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
     L.esfm_comm_destroy.argtypes = [vp]
     L.esfm_comm_rank.argtypes = [vp]
     L.esfm_comm_world.argtypes = [vp]
+    L.esfm_comm_rccl_ranks.argtypes = [vp]
     L.esfm_comm_allreduce.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
     L.esfm_ba_options_default.argtypes = [C.POINTER(BAOptions)]
     L.esfm_ba_options_default.restype = None

@@ -93,6 +93,10 @@ class Comm:
     def handle(self) -> C.c_void_p:
         return self._h
 
+    def rccl_ranks(self) -> int:
+        """ncclCommCount of the communicator: the ranks RCCL itself sees."""
+        return int(lib().esfm_comm_rccl_ranks(self._h))
+
     def allreduce_(self, dev_ptr: int, count: int, op: int = ESFM_REDUCE_SUM) -> None:
         """In-place all-reduce of `count` doubles at a device pointer on the context's stream (tests)."""
         rc = lib().esfm_comm_allreduce(self._h, C.c_void_p(dev_ptr), int(count), int(op), C.c_void_p(self.ctx.stream))
@@ -238,13 +242,13 @@ def reduced_plan(n_cam: int, n_pt: int, cam_idx, pt_idx, leaf_max: int = 0) -> d
     nested-dissection order of the cameras (col_src: original unknown of every permuted, tile-padded column; -1 = padding), the
     tiles of the symbolic fill, the dependency chain length.  What the tiled solve builds for itself; for tests and tools."""
     cam_idx = np.ascontiguousarray(cam_idx, np.int32); pt_idx = np.ascontiguousarray(pt_idx, np.int32)
-    info = np.zeros(8, np.int32)
+    info = np.zeros(10, np.int32)
     check(lib().esfm_ba_reduced_plan(int(n_cam), int(n_pt), len(cam_idx), _p(cam_idx), _p(pt_idx), int(leaf_max), None, 0, None, 0, _p(info)))
     col_src = np.zeros(max(int(info[0]) * 64, 1), np.int32); tiles = np.zeros((max(int(info[1]), 1), 2), np.int32)
     check(lib().esfm_ba_reduced_plan(int(n_cam), int(n_pt), len(cam_idx), _p(cam_idx), _p(pt_idx), int(leaf_max), _p(col_src), len(col_src),
                                      _p(tiles), len(tiles), _p(info)))
     return dict(nb=int(info[0]), col_src=col_src[:int(info[0]) * 64], tiles=tiles[:int(info[1])], chain=int(info[2]), dense_nb=int(info[3]),
-                worthwhile=bool(info[4]), update_steps=int(info[5]), supernodes=int(info[6]), workgroups=int(info[7]))
+                worthwhile=bool(info[4]), update_steps=int(info[5]), supernodes=int(info[6]), workgroups=int(info[7]), covisible_blocks=int(info[8]))
 
 
 # ------------------------------------------------------------------------------------------------

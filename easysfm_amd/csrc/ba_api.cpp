@@ -984,6 +984,8 @@ int esfm_ba_reduced_plan(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx,
     const esfm::SparsePlan pl = esfm::make_sparse_plan(g, leaf_max > 0 ? leaf_max : 32);
     info[0] = pl.nb; info[1] = (int32_t)pl.tiles.size(); info[2] = pl.chain; info[3] = pl.dense_nb; info[4] = pl.worthwhile() ? 1 : 0;
     info[5] = (int32_t)std::min<long long>(pl.update_steps, INT32_MAX); info[6] = (int32_t)pl.node_kind.size(); info[7] = (int32_t)pl.wgs.size();
+    info[8] = (int32_t)(g.adj.size() / 2 + (size_t)n_cam);       // camera blocks (a, b <= a) that can be non-zero: what several ranks exchange
+    info[9] = 0;
     if ((size_t)col_cap < pl.col_src.size() || (size_t)tile_cap < pl.tiles.size()) {
         if (col_src || tiles) { esfm::set_error("esfm_ba_reduced_plan: output arrays too small (need %zu columns, %zu tiles)", pl.col_src.size(), pl.tiles.size()); return ESFM_ERR_INVALID_ARG; }
         return ESFM_OK;          // sizing call

@@ -24,6 +24,16 @@
 
 namespace esfm {
 
+#ifdef ESFM_SPARSE_TRACE
+// timing-only build (scratch/build_variant_sparse.sh NAME -DESFM_SPARSE_TRACE): every workgroup of chol_sparse_kernel leaves
+// s_memrealtime stamps (10 ns ticks) at its stages; scratch/sparse_trace.py reads them through esfm_debug_sparse_trace
+__device__ unsigned long long g_sparse_trace[4096 * 8];
+#define SP_T(q) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sparse_trace[blockIdx.x * 8 + (q)] = wall_clock64(); } while (0)
+extern "C" int esfm_debug_sparse_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sparse_trace), sizeof(g_sparse_trace)); }
+#else
+#define SP_T(q) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // element (hi, lo) of the reduced system, hi >= lo original unknowns, from the fixed-point buffer; what is read is cleared
 __device__ __forceinline__ double take_fixed(unsigned long long *redq, size_t idx, int sh)
@@ -50,11 +60,13 @@ template <bool PACKED>
 __global__ __launch_bounds__(256) void chol_sparse_assemble_kernel(BADev d, SparseDev sp, double radius, double min_diag, double max_diag, int rhs_exp,
                                                                    const double *__restrict__ packed)
 {
-    const int slot = blockIdx.x, tid = threadIdx.x;
+    // four workgroups per tile (16 rows each): the kernel is a few dependent loads per element, and 249 workgroups (BA-512) left most
+    // of the chip without one (28.6 us; now see DESIGN.md)
+    const int slot = blockIdx.x >> 2, quarter = blockIdx.x & 3, tid = threadIdx.x;
     const int I = sp.tile_ij[2 * slot], J = sp.tile_ij[2 * slot + 1];
     const int n = 6 * d.n_cam, nb = sp.nb;
-    if (tid == 0) sp.xready[slot] = 0;
-    if (I == J) {
+    if (tid == 0 && quarter == 0) sp.xready[slot] = 0;
+    if (I == J && quarter == 0) {
         if (tid < CB) reinterpret_cast<unsigned long long *>(sp.ybuf)[J * CB + tid] = kYPending;
         if (tid == 64) sp.ready[J] = 0;
         if (tid == 65) sp.rpart[J] = 0;
@@ -63,9 +75,9 @@ __global__ __launch_bounds__(256) void chol_sparse_assemble_kernel(BADev d, Spar
     double *W = sp.W + (size_t)slot * (CB * CB);
     const int c = tid & 63;
     const int ic = sp.col_src[J * CB + c];
-#pragma unroll 4
-    for (int q = 0; q < CB * CB / 256; ++q) {
-        const int r = (tid >> 6) + 4 * q;
+#pragma unroll
+    for (int q = 0; q < CB * CB / 1024; ++q) {
+        const int r = 16 * quarter + (tid >> 6) + 4 * q;
         double v = 0.0;
         if (I == nb) {                                         // right-hand side: row 0 of the tile
             if (r == 0 && ic >= 0) {
@@ -122,10 +134,13 @@ __global__ __launch_bounds__(256) void ba_sparse_pack_kernel(BADev d, SparseDev 
 //   kind 0  C = A_IJ - sum_K X_I,K X_J,K' over its update list (each operand awaited through its tile's flag), then wait for
 //           L_JJ^-1, X_IJ = C L_JJ^-T, store, raise xready[slot]
 //   kind 3  the same for the right-hand side's row (block row nb)
-//   kind 2  the LAST off-diagonal tile of block row I: as kind 0, and then it finishes diagonal tile (I, I) itself -- the other
-//           updates of that tile first (dupd list: they come from columns further left, finished long ago or in a sibling subtree),
-//           its own X_IJ straight from LDS -- factors it and inverts the factor: along a chain of the elimination tree the next
-//           column's inverse is one workgroup away from this column's, as in chol3_kernel
+//   kind 2  the LAST off-diagonal tile of block row I ("chain" workgroup): as kind 0, and then it finishes diagonal tile (I, I)
+//           itself -- its operand list holds EVERY X_I,K, K < J, and each one is subtracted (X X') from the diagonal tile while it
+//           sits in LDS for the own tile's update; its own X_IJ straight from LDS last -- factors it and inverts the factor: along a
+//           chain of the elimination tree the next column's inverse is one workgroup away from this column's, as in chol3_kernel.
+//           (First build: the diagonal tile's updates in a loop of their own AFTER the own tile's, in column order -- a separator's
+//           workgroup then did a dozen long-available tiles behind the one it had really been waiting for: 217 us on BA-512, of
+//           which 110 us were such queues, scratch/sparse_trace.py.)
 __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *__restrict__ scal)
 {
     __shared__ __attribute__((aligned(16))) double Xi[CB * ULD];
@@ -136,6 +151,7 @@ __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *
     const SparseWg w = sp.wgs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) fail = 0;
+    SP_T(0);
     // thread 0 polls (relaxed) until every flag of the list reads >= at_least (block == false: looks once); then a workgroup-scope acquire
     auto wait2 = [&](const int *fa, const int *fb, int at_least, bool block) -> bool {
         if (tid == 0) {
@@ -174,37 +190,6 @@ __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *
                 acc[cb][g] = A[r * CB + c];                 // (a diagonal tile's upper part was assembled as zeros)
             }
     }
-    // update loop, software-pipelined through registers: the loads of step u + 1 are in flight during the MFMAs of step u
-    {
-        double rx[CB * CB / 256], ry[CB * CB / 256];
-        auto avail = [&](int u, bool block) { return wait2(&sp.xready[sp.upd[2 * u]], &sp.xready[sp.upd[2 * u + 1]], 1, block); };
-        auto fetch = [&](int u) {
-            const double *xa = sp.W2 + (size_t)sp.upd[2 * u] * (CB * CB), *xb = sp.W2 + (size_t)sp.upd[2 * u + 1] * (CB * CB);
-#pragma unroll
-            for (int q = 0; q < CB * CB / 256; ++q) { rx[q] = xa[tid + 256 * q]; ry[q] = xb[tid + 256 * q]; }
-        };
-        bool fetched = false;
-        for (int u = w.upd0; u < w.upd1; ++u) {
-            if (!fetched) { avail(u, true); fetch(u); }
-#pragma unroll
-            for (int q = 0; q < CB * CB / 256; ++q) {
-                const int e = tid + 256 * q, r = e / CB, c = e % CB;
-                Xi[r * ULD + c] = rx[q]; Xj[r * ULD + c] = ry[q];
-            }
-            __syncthreads();
-            fetched = u + 1 < w.upd1 && avail(u + 1, false);
-            if (fetched) fetch(u + 1);
-            strip_pqt64<true>(acc, Xi, Xj, wave, lane);
-            __syncthreads();               // every wave is past its reads of Xi / Xj
-        }
-    }
-    if (diag) {
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
-        __syncthreads();
-        factor_and_publish(Xi, Xj, w.J);
-        return;
-    }
     // The ten lower 16 x 16 blocks of the next diagonal tile over the four waves as 3 + 3 + 3 + 1 (see chol3_kernel)
     const bool chain = w.kind == 2;
     const int dbi[3] = {wave == 3 ? 3 : wave, wave == 2 ? 2 : (wave == 1 ? 1 : 3), wave == 2 ? 2 : 3};
@@ -229,20 +214,51 @@ __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *
                 const int r = 16 * dbi[q] + (lane >> 4) + 4 * g, c = 16 * dbj[q] + (lane & 15);
                 if (q < dnb) dacc[q][g] = A[r * CB + c];
             }
-        // the diagonal tile's updates from the columns left of this one (Xj is free until the inverse arrives)
-        for (int u = w.dupd0; u < w.dupd1; ++u) {
-            wait2(&sp.xready[sp.dupd[u]], nullptr, 1, true);
-            const double *xa = sp.W2 + (size_t)sp.dupd[u] * (CB * CB);
-            double rx[CB * CB / 256];
+    }
+    // Update loop over the operand list (in the plan's order of expected availability), software-pipelined through registers: the
+    // loads of step u + 1 are in flight during the MFMAs of step u.  Step u brings X_I,K and -- second slot >= 0 -- X_J,K: the own
+    // tile loses X_I,K X_J,K'; a chain workgroup's diagonal tile (I, I) loses X_I,K X_I,K' from the same LDS copy of X_I,K.
+    {
+        double2 rx[CB * CB / 512], ry[CB * CB / 512];      // 16-byte loads: thread t's q-th piece is elements 2 (t + 256 q), 2 (t + 256 q) + 1 of the tile
+        auto avail = [&](int u, bool block) {
+            const int sb = sp.upd[2 * u + 1];
+            return wait2(&sp.xready[sp.upd[2 * u]], sb >= 0 ? &sp.xready[sb] : nullptr, 1, block);
+        };
+        auto fetch = [&](int u) {
+            const int sb = sp.upd[2 * u + 1];
+            const double2 *xa = reinterpret_cast<const double2 *>(sp.W2 + (size_t)sp.upd[2 * u] * (CB * CB));
+            const double2 *xb = reinterpret_cast<const double2 *>(sp.W2 + (size_t)max(sb, 0) * (CB * CB));
 #pragma unroll
-            for (int q = 0; q < CB * CB / 256; ++q) rx[q] = xa[tid + 256 * q];
+            for (int q = 0; q < CB * CB / 512; ++q) { rx[q] = xa[tid + 256 * q]; if (sb >= 0) ry[q] = xb[tid + 256 * q]; }
+        };
+        bool fetched = false;
+        for (int u = w.upd0; u < w.upd1; ++u) {
+            if (!fetched) { avail(u, true); fetch(u); }
+            const bool own = sp.upd[2 * u + 1] >= 0;
 #pragma unroll
-            for (int q = 0; q < CB * CB / 256; ++q) { const int e = tid + 256 * q; Xj[(e / CB) * ULD + (e % CB)] = rx[q]; }
+            for (int q = 0; q < CB * CB / 512; ++q) {
+                const int e = 2 * (tid + 256 * q), r = e / CB, c = e % CB;
+                *reinterpret_cast<double2 *>(&Xi[r * ULD + c]) = rx[q];
+                if (own) *reinterpret_cast<double2 *>(&Xj[r * ULD + c]) = ry[q];
+            }
             __syncthreads();
-            diag_update(Xj);
-            __syncthreads();
+            fetched = u + 1 < w.upd1 && avail(u + 1, false);
+            if (fetched) fetch(u + 1);
+            if (own) strip_pqt64<true>(acc, Xi, Xj, wave, lane);
+            if (chain) diag_update(Xi);
+            __syncthreads();               // every wave is past its reads of Xi / Xj
         }
     }
+    SP_T(1);                                           // updates done
+    if (diag) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
+        __syncthreads();
+        factor_and_publish(Xi, Xj, w.J);
+        SP_T(7);
+        return;
+    }
+    SP_T(2);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) store_d16(Xi + (16 * wave) * ULD + 16 * cb, ULD, acc[cb], lane);
     // X_IJ = C L_JJ^-T once the inverse is there: all 32 KB in flight at once, the first 16 KB (rows 0..31) as soon as the factoring
@@ -250,10 +266,14 @@ __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *
     {
         const double2 *Lk = reinterpret_cast<const double2 *>(sp.Ldiag + (size_t)w.J * LSLOT + LINV_OFF);
         double2 lv[CB * CB / 512];
-        wait2(&sp.rpart[w.J], nullptr, 3, true);
+        // (a tile whose updates ended long after the inverse was published -- every separator row -- finds `ready` set and skips the
+        // first poll: one memory round trip less on its way)
+        const bool there = wait2(&sp.ready[w.J], nullptr, 1, false);
+        if (!there) wait2(&sp.rpart[w.J], nullptr, 3, true);
 #pragma unroll
         for (int q = 0; q < 4; ++q) lv[q] = Lk[tid + 256 * q];
-        wait2(&sp.ready[w.J], nullptr, 1, true);
+        if (!there) wait2(&sp.ready[w.J], nullptr, 1, true);
+        SP_T(3);                                       // inverse of the column's diagonal tile seen
 #pragma unroll
         for (int q = 4; q < CB * CB / 512; ++q) lv[q] = Lk[tid + 256 * q];
 #pragma unroll
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *
             const int r = 16 * wave + (lane >> 4) + 4 * g, c = 16 * cb + (lane & 15);
             st_coh(&Xout[r * CB + c], x[cb][g]);
         }
-    if (!chain) { publish_flag(&sp.xready[w.slot]); return; }
+    if (!chain) { publish_flag(&sp.xready[w.slot]); SP_T(5); return; }
     // chain: X also goes to LDS as the operand of diagonal tile (I, I)'s last update; its flag is raised once the factorisation
     // below has its operands (nobody on the critical chain waits for it)
     __syncthreads();                                    // every wave is past its reads of Xi (C) and Xj (L^-1)
@@ -295,8 +315,11 @@ __global__ __launch_bounds__(256) void chol_sparse_kernel(SparseDev sp, double *
     for (int q = 0; q < 3; ++q)
         if (q < dnb) store_d16(Xj + (16 * dbi[q]) * ULD + 16 * dbj[q], ULD, dacc[q], lane);
     __syncthreads();
+    SP_T(4);                                           // X in LDS, diagonal tile complete
     publish_flag(&sp.xready[w.slot]);                   // (the X stores above have long been acknowledged)
+    SP_T(5);
     factor_and_publish(Xj, Xi, w.I);
+    SP_T(7);
 }
 
 // Backward substitution L' y = z down the elimination tree.  Workgroup for column b (dispatched in descending b): z_b = row 0 of
@@ -400,7 +423,7 @@ int ba_sparse_create(hipStream_t st, const SparsePlan &plan, const CamGraph &g, 
     std::vector<SparseWg> wgs(P.wgs.size());
     for (size_t k = 0; k < P.wgs.size(); ++k) {
         const SparsePlan::Wg &a = P.wgs[k];
-        wgs[k] = SparseWg{a.I, a.J, a.slot, a.upd0 / 2, a.upd1 / 2, a.dupd0, a.dupd1, a.dslot, a.kind};
+        wgs[k] = SparseWg{a.I, a.J, a.slot, a.upd0 / 2, a.upd1 / 2, a.dslot, a.kind};
     }
     // the exchange's block list: for camera a its neighbours b <= a (a itself last), ascending
     std::vector<int32_t> cov_start((size_t)g.n + 1, 0), cov_adj, cov_row;
@@ -421,7 +444,7 @@ int ba_sparse_create(hipStream_t st, const SparsePlan &plan, const CamGraph &g, 
         *dst = reinterpret_cast<std::remove_pointer_t<std::remove_reference_t<decltype(*dst)>> *>(p);
         if (!vec.empty() && hipMemcpyAsync(p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("plan upload failed"); rc = ESFM_ERR_HIP; }
     };
-    up(&dv.col_src, P.col_src); up(&dv.tile_ij, tile_ij); up(&dv.wgs, wgs); up(&dv.upd, P.upd); up(&dv.dupd, P.dupd);
+    up(&dv.col_src, P.col_src); up(&dv.tile_ij, tile_ij); up(&dv.wgs, wgs); up(&dv.upd, P.upd);
     up(&dv.back0, P.back0); up(&dv.back, P.back); up(&dv.rhs_slot, rhs_slot);
     up(&dv.cov_start, cov_start); up(&dv.cov_adj, cov_adj); up(&dv.cov_row, cov_row);
     auto A = [&](auto **dst, size_t count) {
@@ -456,11 +479,11 @@ int ba_solve_reduced_sparse(hipStream_t st, const BADev &d, SparseSolve *S, doub
 {
     const SparseDev &dv = S->dev;
     if (S->packed_source) {
-        hipLaunchKernelGGL(chol_sparse_assemble_kernel<true>, dim3(dv.n_tiles), dim3(256), 0, st, d, dv, radius, min_diag, max_diag, 0, S->packed);
+        hipLaunchKernelGGL(chol_sparse_assemble_kernel<true>, dim3(4 * dv.n_tiles), dim3(256), 0, st, d, dv, radius, min_diag, max_diag, 0, S->packed);
         S->packed_source = false;
     } else {
         if (!d.parts->red_fixed) { set_error("structure-aware solve: the Schur buffer is not in fixed point"); return ESFM_ERR_INVALID_ARG; }
-        hipLaunchKernelGGL(chol_sparse_assemble_kernel<false>, dim3(dv.n_tiles), dim3(256), 0, st, d, dv, radius, min_diag, max_diag, d.parts->red_rhs_exp,
+        hipLaunchKernelGGL(chol_sparse_assemble_kernel<false>, dim3(4 * dv.n_tiles), dim3(256), 0, st, d, dv, radius, min_diag, max_diag, d.parts->red_rhs_exp,
                            (const double *)nullptr);
         d.parts->red_fixed = false; d.parts->red_clean = true;
     }

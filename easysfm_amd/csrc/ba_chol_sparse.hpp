@@ -8,7 +8,7 @@
 namespace esfm {
 
 struct SparseWg {            // one workgroup of chol_sparse_kernel (SparsePlan::Wg with upd0 / upd1 counted in pairs)
-    int32_t I, J, slot, upd0, upd1, dupd0, dupd1, dslot, kind;
+    int32_t I, J, slot, upd0, upd1, dslot, kind;
 };
 
 struct SparseDev {           // kernel argument: the plan's tables and the solve's work areas, all device memory
@@ -16,8 +16,7 @@ struct SparseDev {           // kernel argument: the plan's tables and the solve
     int32_t *col_src = nullptr;      // [nb * 64] original unknown of a permuted column, -1: padding
     int32_t *tile_ij = nullptr;      // [2 n_tiles] block row / column of a slot
     SparseWg *wgs = nullptr;         // [n_wgs] in dispatch order
-    int32_t *upd = nullptr;          // pairs (slot of X_I,K, slot of X_J,K)
-    int32_t *dupd = nullptr;         // slots of X_I,K for the diagonal tile a chain workgroup finishes
+    int32_t *upd = nullptr;          // pairs (slot of X_I,K, slot of X_J,K or -1: the chain workgroup's diagonal tile only)
     int32_t *back0 = nullptr, *back = nullptr;   // backward substitution: per column [back0[b], back0[b + 1]) pairs (block row i, slot of (i, b))
     int32_t *rhs_slot = nullptr;     // [nb] slot of the right-hand side's tile of a column
     // the exchange of several ranks: co-visible camera blocks (a, b <= a): block k = (cov_row[k], cov_adj[k]), camera a's at cov_start[a] ..

@@ -242,24 +242,38 @@ SparsePlan make_sparse_plan(const CamGraph &g, int leaf_max)
         fin[(size_t)j] = f + 1;
         P.chain = std::max(P.chain, f + 1);
     }
+    // A workgroup's operand tiles are listed in the order they are expected to BECOME AVAILABLE -- by the depth fin[K] of their
+    // column in the dependency chain, then by column -- not by column alone: subtrees of the elimination tree run side by side, and
+    // a separator's workgroup that waited for an early separator's tile with a dozen long-finished leaf tiles queued behind it
+    // did all of them AFTER the tile it was really waiting for (BA-512: 110 of the kernel's 217 us).  The order is part of the plan,
+    // so the sums keep a fixed order.
+    std::vector<int32_t> ks;
+    auto by_availability = [&](std::vector<int32_t> &v) {
+        std::stable_sort(v.begin(), v.end(), [&](int32_t a, int32_t b) { return fin[(size_t)a] != fin[(size_t)b] ? fin[(size_t)a] < fin[(size_t)b] : a < b; });
+    };
     for (int j = 0; j < nb; ++j) {
-        if (klast[(size_t)j] < 0) P.wgs.push_back({j, j, slot(j, j), (int32_t)P.upd.size(), (int32_t)P.upd.size(), 0, 0, -1, 1});
+        if (klast[(size_t)j] < 0) P.wgs.push_back({j, j, slot(j, j), (int32_t)P.upd.size(), (int32_t)P.upd.size(), -1, 1});
         for (int i = j + 1; i <= nb; ++i) {
             if (i < nb && !L[(size_t)i * nb + j]) continue;
             SparsePlan::Wg w;
             w.I = i; w.J = j; w.slot = slot(i, j);
-            w.upd0 = (int32_t)P.upd.size();
-            for (int k = 0; k < j; ++k)
-                if (L[(size_t)j * nb + k] && (i == nb || L[(size_t)i * nb + k])) { P.upd.push_back(slot(i, k)); P.upd.push_back(slot(j, k)); ++P.update_steps; }
-            w.upd1 = (int32_t)P.upd.size();
-            w.dupd0 = w.dupd1 = (int32_t)P.dupd.size(); w.dslot = -1;
+            w.dslot = -1;
             w.kind = i == nb ? 3 : 0;
-            if (i < nb && klast[(size_t)i] == j) {
-                w.kind = 2; w.dslot = slot(i, i);
-                for (int k = 0; k < j; ++k) if (L[(size_t)i * nb + k]) { P.dupd.push_back(slot(i, k)); ++P.update_steps; }
-                w.dupd1 = (int32_t)P.dupd.size();
-                ++P.update_steps;
+            const bool chain = i < nb && klast[(size_t)i] == j;
+            // operand columns K < J: those both block rows have (the tile's own updates); a chain workgroup also takes every other
+            // column of block row I (updates of diagonal tile (I, I) only: second slot -1)
+            ks.clear();
+            for (int k = 0; k < j; ++k)
+                if ((i == nb || L[(size_t)i * nb + k]) && (L[(size_t)j * nb + k] || chain)) ks.push_back(k);
+            by_availability(ks);
+            w.upd0 = (int32_t)P.upd.size();
+            for (int k : ks) {
+                const bool own = L[(size_t)j * nb + k] != 0;
+                P.upd.push_back(slot(i, k)); P.upd.push_back(own ? slot(j, k) : -1);
+                P.update_steps += (own ? 1 : 0) + (chain ? 1 : 0);
             }
+            w.upd1 = (int32_t)P.upd.size();
+            if (chain) { w.kind = 2; w.dslot = slot(i, i); ++P.update_steps; }
             P.wgs.push_back(w);
         }
     }

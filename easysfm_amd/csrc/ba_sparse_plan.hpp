@@ -37,18 +37,18 @@ struct SparsePlan {
     std::vector<Tile> tiles;
     std::vector<int32_t> slot_of;       // [(nb + 1) * nb] slot of tile (I, J), -1 outside the fill
     // workgroups of the factorisation in dispatch order (column by column).  A workgroup owns tile (I, J), subtracts
-    // X_I,K X_J,K' for its update list, then -- diagonal tile of a column nothing precedes: factors it -- or waits for
-    // L_JJ^-1 and stores X_IJ; the LAST off-diagonal tile of block row I goes on to finish and factor diagonal tile (I, I)
-    // (its other updates first: dupd list).
+    // X_I,K X_J,K' for its operand list, then -- diagonal tile of a column nothing precedes: factors it -- or waits for
+    // L_JJ^-1 and stores X_IJ; the LAST off-diagonal tile of block row I (a "chain" workgroup) goes on to finish and factor
+    // diagonal tile (I, I): every X_I,K of its list is also subtracted (X X') from that tile, and the list holds ALL columns
+    // K < J of block row I -- those block row J lacks with second slot -1 (no update of the own tile).
     struct Wg {
         int32_t I, J, slot;
-        int32_t upd0, upd1;             // range in upd: pairs (slot of X_I,K, slot of X_J,K), K ascending
-        int32_t dupd0, dupd1;           // chain workgroups: range in dupd: slots of X_I,K (K < J) the diagonal tile (I, I) still needs
+        int32_t upd0, upd1;             // range in upd: pairs (slot of X_I,K, slot of X_J,K or -1), in expected order of availability
         int32_t dslot;                  // chain workgroups: slot of diagonal tile (I, I); -1 otherwise
         int32_t kind;                   // 0 off-diagonal, 1 stand-alone diagonal, 2 chain (off-diagonal + next diagonal), 3 right-hand-side row
     };
     std::vector<Wg> wgs;
-    std::vector<int32_t> upd, dupd;
+    std::vector<int32_t> upd;
     // backward substitution: column b folds y_i for the rows i of its column structure (back0[b] .. back0[b + 1]): pairs (i, slot of (i, b))
     std::vector<int32_t> back0, back;
     int chain = 0;                      // longest dependency chain in tile columns

@@ -26,6 +26,7 @@ struct Rccl {
     int (*GetUniqueId)(rcclUniqueId *) = nullptr;
     int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
     int (*CommDestroy)(rcclComm_t) = nullptr;
+    int (*CommCount)(const rcclComm_t, int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
@@ -46,6 +47,7 @@ Rccl &rccl()
         R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
         R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
         R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.CommCount = reinterpret_cast<decltype(R.CommCount)>(sym("ncclCommCount"));
         R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(sym("ncclAllReduce"));
         R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
     });
@@ -108,6 +110,13 @@ int esfm_comm_destroy(esfm_comm *c)
 
 int esfm_comm_rank(const esfm_comm *c) { return c ? c->rank : -1; }
 int esfm_comm_world(const esfm_comm *c) { return c ? c->world : 0; }
+// the number of ranks RCCL itself reports for the communicator (ncclCommCount), not what the caller passed at creation
+int esfm_comm_rccl_ranks(const esfm_comm *c)
+{
+    if (!c || !c->comm || !rccl().CommCount) return -1;
+    int n = -1;
+    return rccl().CommCount(c->comm, &n) == rcclSuccess ? n : -1;
+}
 
 // esfm_allreduce_fn: user = esfm_comm*
 int esfm_comm_allreduce(void *user, double *buf_dev, int64_t count, int op, void *hip_stream)

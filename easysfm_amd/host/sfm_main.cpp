@@ -18,6 +18,8 @@
 #include <iostream>
 #include <atomic>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -110,8 +112,9 @@ int main(int argc, char **argv)
         // first frame's import otherwise also waits for the GPU's first-touch initialisation): frame i is taken when its decode is done,
         // messages and failures appear where the reference's sequential loop has them.
         std::vector<std::string> decode_err((size_t)frame_number);
-        std::vector<std::atomic<int>> decoded((size_t)frame_number);
-        for (auto &d : decoded) d.store(0);
+        std::vector<char> decoded((size_t)frame_number, 0);
+        std::mutex decode_mu;
+        std::condition_variable decode_cv;
         std::atomic<int> next_decode{0};
         std::vector<std::thread> decoders;
         {
@@ -121,14 +124,26 @@ int main(int argc, char **argv)
                     for (int i = next_decode++; i < frame_number; i = next_decode++) {
                         ImageMat &img = frames[size_t(i)].rgb_image;
                         img.channels = 3;
-                        decode_err[size_t(i)] = read_image_bgr(frames[size_t(i)].image_file_path, img.rows, img.cols, img.data);
-                        decoded[size_t(i)].store(1, std::memory_order_release);
+                        std::string err;
+                        // a malformed or huge header must end as this frame's "No more images", not as std::terminate in a worker
+                        try { err = read_image_bgr(frames[size_t(i)].image_file_path, img.rows, img.cols, img.data); }
+                        catch (const std::exception &e) { err = std::string("decoder failed: ") + e.what(); }
+                        catch (...) { err = "decoder failed"; }
+                        {
+                            std::lock_guard<std::mutex> lk(decode_mu);
+                            decode_err[size_t(i)] = err;
+                            decoded[size_t(i)] = 1;
+                        }
+                        decode_cv.notify_all();
                     }
                 });
         }
         struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{decoders};
         auto import_decoded = [&](int i) {
-            while (!decoded[size_t(i)].load(std::memory_order_acquire)) std::this_thread::yield();
+            {
+                std::unique_lock<std::mutex> lk(decode_mu);
+                decode_cv.wait(lk, [&] { return decoded[size_t(i)] != 0; });
+            }
             if (!decode_err[size_t(i)].empty()) {          // (DataIO::importImages' message)
                 frames[size_t(i)].rgb_image = ImageMat();
                 std::cout << "No more images" << " (" << decode_err[size_t(i)] << ")" << std::endl;
@@ -196,7 +211,22 @@ int main(int argc, char **argv)
             std::vector<Matrix4f> Ts;
             std::vector<double> depths;
             std::vector<char> ok;
-            if (!ee.estimate2D2D_E5P_RANSAC_pairs(frames, jobs, job_matches, inliers, Ts, depths, ok, ransac_reproj_distance)) return 3;
+            if (!ee.estimate2D2D_E5P_RANSAC_pairs(frames, jobs, job_matches, inliers, Ts, depths, ok, ransac_reproj_distance)) {
+                // A batch entry point fails as a whole when ONE pair is unusable (a non-finite essential matrix, say); the reference's
+                // loop -- and ESFM_PAIR_BY_PAIR=1 above -- only loses that pair (estimate_motion.cpp:27-97 returns false, sfm.cpp:165
+                // carries on).  Same here: the batch's pairs are verified one by one, a failing pair is skipped.
+                std::cout << "batched verification failed (" << esfm_last_error() << "): verifying pair by pair" << std::endl;
+                inliers.assign(jobs.size(), {}); Ts.assign(jobs.size(), Matrix4f::Identity()); depths.assign(jobs.size(), 1.0); ok.assign(jobs.size(), 0);
+                for (size_t p = 0; p < jobs.size(); ++p) {
+                    frame_t &fi = frames[size_t(jobs[p].first)], &fj = frames[size_t(jobs[p].second)];
+                    Matrix4f T = Matrix4f::Identity();
+                    if (!ee.estimate2D2D_E5P_RANSAC(fi, fj, job_matches[p], inliers[p], T, ransac_reproj_distance)) continue;
+                    double depth = 1.0;
+                    Ts[p] = T;
+                    if (ee.getDepthFast(fi, fj, T, inliers[p], depth)) depths[p] = depth;
+                    ok[p] = 1;
+                }
+            }
             for (size_t p = 0; p < jobs.size(); ++p) {
                 if (!ok[p]) continue;
                 frame_pair_t &g = graph[size_t(jobs[p].first)][size_t(jobs[p].second)];

@@ -45,6 +45,33 @@ def surf_like_sets(n_images: int, n_feats: int, pool: int = 16384, seed_base: in
     return sets
 
 
+def surf_resampled_sets(desc_pool: np.ndarray, n_images: int, n_feats: int, seed_base: int = 6000, track_frac: float = 0.5,
+                        track_noise: float = 0.02, fresh_noise: float = 0.06) -> List[np.ndarray]:
+    """"M-SURF-4k-hard": REAL SURF descriptors resampled to the metric's shape.  `desc_pool` holds the descriptors a SURF detector
+    produced on real images (bench.py / the tests: the reference's 11 fountain images at minHessian 300, ~30 k rows) -- clustered,
+    with repeated structure (window frames, bricks), which is what makes the second nearest neighbour close to the first and a
+    bf16 candidate list hard to certify; surf_like_sets' "fresh" rows are isotropic and give the ratio screen nothing to decide.
+    Every image takes `track_frac` of its rows from a shared set of `n_feats` pool rows (the tracks: the same scene point seen
+    again, perturbed by N(0, track_noise^2) per component and re-normalised) and the rest from other pool rows perturbed by
+    `fresh_noise` (near real descriptors, not copies).  Rows shuffled.  Deterministic in (pool, seed_base)."""
+    pool = np.ascontiguousarray(desc_pool, np.float32)
+    n_pool, dim = pool.shape
+    base = np.random.default_rng(np.random.PCG64(seed_base - 1))
+    track_ids = base.choice(n_pool, size=min(n_feats, n_pool), replace=False)
+    sets = []
+    for i in range(n_images):
+        rng = np.random.default_rng(np.random.PCG64(seed_base + i))
+        n_trk = int(n_feats * track_frac)
+        ids = rng.choice(track_ids, size=min(n_trk, len(track_ids)), replace=False)
+        a = pool[ids].astype(np.float64) + track_noise * rng.standard_normal((len(ids), dim))
+        other = rng.choice(n_pool, size=n_feats - len(ids), replace=n_pool < n_feats)
+        b = pool[other].astype(np.float64) + fresh_noise * rng.standard_normal((len(other), dim))
+        d = _unit_rows(np.concatenate([a, b], axis=0))
+        rng.shuffle(d, axis=0)
+        sets.append(np.ascontiguousarray(d, np.float32))
+    return sets
+
+
 def orb_like_sets(n_images: int, n_feats: int, pool: int = 16384, seed_base: int = 3000,
                   nbytes: int = 32, flip: float = 0.08) -> List[np.ndarray]:
     """ORB-like 256-bit descriptors: half re-observes a pool with each bit flipped w.p. `flip`."""

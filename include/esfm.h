@@ -324,6 +324,8 @@ int esfm_comm_create(esfm_ctx *ctx, const void *id /*ESFM_COMM_ID_BYTES*/, int r
 int esfm_comm_destroy(esfm_comm *comm);
 int esfm_comm_rank(const esfm_comm *comm);
 int esfm_comm_world(const esfm_comm *comm);
+/* ranks of the communicator as RCCL reports them (ncclCommCount; -1 on failure): "did RCCL see N ranks" for logs and bench lines */
+int esfm_comm_rccl_ranks(const esfm_comm *comm);
 int esfm_comm_allreduce(void *comm, double *buf_dev, int64_t count, int op, void *hip_stream);
 
 /*
@@ -423,11 +425,12 @@ int esfm_ba_shard_points(int n_pt, int n_obs, const int32_t *pt_idx, int world, 
  * supernode padded to whole 64-column tiles; the factorisation visits only the tiles of the symbolic fill.
  *   col_src[k]   original unknown 6 cam + a of permuted column k, -1 for identity padding (nb * 64 entries)
  *   tiles[2 t]   block row / column of tile t of the factor (lower triangle, fill included; block row nb = the right-hand side)
- *   info[0..7]   nb, tiles, longest dependency chain in tile columns, tile columns of the dense path, 1 if the solve would use
- *                the plan (at most half the dense path's tiles or half its dependency chain), 64^3 products, supernodes, workgroups
+ *   info[0..9]   nb, tiles, longest dependency chain in tile columns, tile columns of the dense path, 1 if the solve would use
+ *                the plan (at most half the dense path's tiles or half its dependency chain), 64^3 products, supernodes, workgroups,
+ *                co-visible camera blocks (a, b <= a) = what several ranks exchange per LM iteration (36 doubles each), 0
  * col_src / tiles may be NULL (with capacity 0) to size the arrays from info first.  leaf_max <= 0: the library's default. */
 int esfm_ba_reduced_plan(int n_cam, int n_pt, int n_obs, const int32_t *cam_idx, const int32_t *pt_idx, int leaf_max,
-                         int32_t *col_src, int col_cap, int32_t *tiles, int tile_cap, int32_t *info /*8*/);
+                         int32_t *col_src, int col_cap, int32_t *tiles, int tile_cap, int32_t *info /*10*/);
 
 /* ---- sparse-cloud statistical outlier removal ------------------------
  * CProceesing::SORFilter (cpp_code/include/cloudprocessing.hpp:24-36, called on the final cloud at

@@ -29,7 +29,7 @@ def test_self_launcher_two_ranks_dry_run():
     j = lines[0]
     assert j["n_gpus"] == 2 and j["ranks_seen"] == [0, 1] and j["ok"] and j["steps"] == 3 and j["warmup"] == 1
     assert j["torch_imported"] is False
-    assert sum(j["pairs_per_rank"]) == j["pairs_total"] >= 600          # weak scaling: >= 300 pairs per rank
+    assert j["scaling"] == "strong" and j["pairs_per_rank"] == [150, 150] and j["pairs_total"] == 300      # M-SURF-4k's own list, split
     for rk in (0, 1):
         assert f"RANK={rk} LOCAL_RANK={rk} WORLD_SIZE=2 MASTER=127.0.0.1:" in r.stderr
 
@@ -57,3 +57,30 @@ def test_single_rank_dry_run_is_the_metric_workload():
     assert r.returncode == 0
     j = _json_lines(r.stdout)[0]
     assert j["n_gpus"] == 1 and j["pairs_total"] == 300
+
+
+def test_self_launcher_eight_ranks_dry_run_shares():
+    """What `bench.py --gpus 8` does rank by rank before anything is timed (DESIGN.md section 5's checklist), without a GPU: eight
+    ranks meet, the headline's 300 pairs fall 38 / 37 per rank, config 4's 32 640 pairs 4 080 per rank, the weak side
+    leg takes 70 images (2 415 pairs >= 300 x 8)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"], env=_clean_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    j = _json_lines(r.stdout)[0]
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == list(range(8)) and j["ok"] and j["torch_imported"] is False
+    assert j["pairs_per_rank"] == [38, 38, 38, 38, 37, 37, 37, 37] and j["pairs_total"] == 300
+    assert j["config4_pairs_per_rank"] == [4080] * 8
+    assert j["weak_leg_frames"] == 70
+    for rk in range(8):
+        assert f"RANK={rk} LOCAL_RANK={rk} WORLD_SIZE=8" in r.stderr
+
+
+def test_dry_run_shares_are_the_librarys():
+    """The dry run's round-robin stand-in against esfm_shard_pair_list itself (host-only) for equal-cost pairs."""
+    import numpy as np
+    import easysfm_amd as E
+    for n_img, world in ((25, 8), (25, 2), (256, 8)):
+        rows = np.full(n_img, 4096, np.int32)
+        mine = [len(E.shard_pair_list(n_img, rows, r, world)) for r in range(world)]
+        n_pairs = n_img * (n_img - 1) // 2
+        assert mine == [len(range(r, n_pairs, world)) for r in range(world)]
