@@ -2600,6 +2600,16 @@ __global__ __launch_bounds__(256) void hamming_expand_fp4_kernel(const uint32_t 
     img_t[i] = t; img_q[i] = q;
 }
 
+#ifdef ESFM_HMX1_TRACE
+// timing-only build (scratch/build_variant.sh NAME -DESFM_HMX1_TRACE): per-wave stage times of hamming_fp4_kernel in s_memrealtime ticks
+// (10 ns) and the shader clock inside the main loop (s_memtime); scratch/hmx1_trace.py reads them through esfm_debug_hmx1_trace
+__device__ int g_hmx1_trace[8];
+extern "C" int esfm_debug_hmx1_trace(int *out, int reset)
+{
+    if (reset) { int z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_hmx1_trace), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hmx1_trace), sizeof(g_hmx1_trace));
+}
+#endif
 __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__restrict__ packed, const u32x4 *__restrict__ img_t,
                                                              const u32x4 *__restrict__ img_q, const float *__restrict__ start,
                                                              const PairDesc *__restrict__ pairs, const int32_t *__restrict__ blk_pair, int n_blocks,
@@ -2609,6 +2619,9 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
 {
     // (a pair without queries has no block: nobody would write its count)
     if (done && blockIdx.x == 0) for (int p = threadIdx.x; p < n_pairs; p += 256) if (pairs[p].nq == 0) n_out[p] = 0;
+#ifdef ESFM_HMX1_TRACE
+    const uint64_t tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int TT = ESFM_HMX1_TT, NS = ESFM_HMX1_SETS, K = ESFM_HMX1_KEEP, RING = ESFM_HMX1_RING, GRP = ESFM_HMX1_GRP, NG = 16 / GRP;
     constexpr int QB = 128 * NS, HS = 8;
     constexpr int TILE_BYTES = TT * HS * 16;
@@ -2663,6 +2676,9 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef ESFM_HMX1_TRACE
+    const uint64_t tr1 = __builtin_amdgcn_s_memrealtime(), clk1 = __builtin_amdgcn_s_memtime();
+#endif
     if (ntiles > 0) {
         asm volatile(ESFM_HMX1_SEGMENT_ASM
                      :
@@ -2671,6 +2687,9 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
                        "s"(ntiles), "s"(nt), "s"(trsrc), "s"(nrsrc), "s"(lds_tile_addr), "s"(wave_s)
                      : ESFM_HMX1_SEGMENT_CLOBBERS);
     }
+#ifdef ESFM_HMX1_TRACE
+    const uint64_t tr2 = __builtin_amdgcn_s_memrealtime(), clk2 = __builtin_amdgcn_s_memtime();
+#endif
     {   // (nothing thread-dependent lives across the block: see l2_knn_bf16x1_kernel)
         int l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
@@ -2759,6 +2778,13 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
             }
         }
     }
+#ifdef ESFM_HMX1_TRACE
+    if (lane == 0) {
+        const uint64_t tr3 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_hmx1_trace[0], (int)(tr1 - tr0)); atomicAdd(&g_hmx1_trace[1], (int)(tr2 - tr1)); atomicAdd(&g_hmx1_trace[2], (int)(tr3 - tr2));
+        atomicAdd(&g_hmx1_trace[3], 1); atomicAdd(&g_hmx1_trace[4], (int)((clk2 - clk1) >> 8));
+    }
+#endif
     // ---- the match entry points: ratio test + ordered compaction of the pair by the workgroup that brings its last block (the
     // protocol of l2_finish_kernel: stores acknowledged, barrier, one relaxed agent-scope arrival; `done` reads 0 again afterwards)
     if (done) {

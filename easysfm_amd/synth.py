@@ -7,6 +7,7 @@ All generators are numpy ``default_rng(PCG64(seed))``; nothing here touches the 
   M-SURF-4k  25 x 4096 x 64 f32   surf_like_sets(25, 4096, pool=16384, seed_base=1000)
   M-SURF-8k  256 x 8192 x 64 f32  surf_like_sets(256, 8192, pool=65536, seed_base=2000)
   M-ORB-4k   25 x 4096 x 32 u8    orb_like_sets(25, 4096, pool=16384, seed_base=3000)
+  M-SURF-4k-hard 25 x 4096 x 64   msurf4k_hard_sets(SURF-300 descriptors of the fountain images): real, clustered descriptors resampled
   BA-25      25 cams, 30k pts, 8 obs/pt    ba_scene(25, 30000, 8, radius=10, extent=2, seed=4000)
   BA-512     512 cams, 300k pts, 10 obs/pt ba_scene(512, 300000, 10, radius=40, extent=8, seed=5000)
 """
@@ -70,6 +71,18 @@ def surf_resampled_sets(desc_pool: np.ndarray, n_images: int, n_feats: int, seed
         rng.shuffle(d, axis=0)
         sets.append(np.ascontiguousarray(d, np.float32))
     return sets
+
+
+HARD_POOL_ROWS, HARD_TRACK_NOISE, HARD_FRESH_NOISE = 8192, 0.005, 0.01
+
+
+def msurf4k_hard_sets(fountain_descriptors: np.ndarray, n_images: int = 25, n_feats: int = 4096) -> List[np.ndarray]:
+    """Workload "M-SURF-4k-hard" (bench.py's `hard` leg, tests/test_metric_workloads_gpu.py): surf_resampled_sets on the first 8192
+    SURF descriptors of the reference's fountain images (minHessian 300, image order), seeds 6000 + image.  Measured on MI355X at the
+    reference's ratio 0.5: 34 % of the queries survive the matcher's ratio screen (M-SURF-4k: 3.7 %), 1.4 % reach its second pass
+    (M-SURF-4k: none); at ratio 0.8: 62 % and 3.3 %."""
+    return surf_resampled_sets(np.ascontiguousarray(fountain_descriptors[:HARD_POOL_ROWS]), n_images, n_feats, seed_base=6000,
+                               track_noise=HARD_TRACK_NOISE, fresh_noise=HARD_FRESH_NOISE)
 
 
 def orb_like_sets(n_images: int, n_feats: int, pool: int = 16384, seed_base: int = 3000,

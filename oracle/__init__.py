@@ -176,8 +176,34 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
+def usable_cpus() -> int:
+    """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota (cgroup v2 cpu.max, v1 cfs quota).
+    os.cpu_count() alone is the machine's logical CPU count -- 256 on the GPU boxes, whose containers are capped at 16 CPUs' worth of
+    time: 256 OpenMP threads there run at a fraction of 16 threads' speed (round 4's "256-core" CPU baseline: 193 pairs/s; 16
+    threads: 436)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()[:2]
+            quota = None if a == "max" else float(a) / float(b)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except Exception:
+            quota = None
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return max(1, n)
+
+
 def set_num_threads(n: int) -> None:
-    load().esfm_ref_set_num_threads(int(n))
+    """OpenMP threads of the oracle's parallel regions, capped at usable_cpus() (callers pass os.cpu_count())."""
+    load().esfm_ref_set_num_threads(max(1, min(int(n), usable_cpus())))
 
 
 def num_threads() -> int:

@@ -128,3 +128,34 @@ def test_config2_fountain_fullres_all_pairs(gpu_ctx, oracle_lib):
     # neighbouring views of the fountain share hundreds of features
     assert total > 2000
     print(f"\nconfig 2: {[len(s) for s in sets]} SURF features per image, {total} ratio-test matches over 55 pairs")
+
+
+def test_msurf4k_hard_all_pairs_and_audits(gpu_ctx, oracle_lib):
+    """M-SURF-4k-hard: the metric's shape from the fountain images' own SURF descriptors, resampled
+    (synth.msurf4k_hard_sets) -- a third of the queries survives the ratio screen, more than 1 % reach the second pass (M-SURF-4k:
+    3.7 % and none).  All 300 pairs at the reference's ratio 0.5 and at 0.8 against the oracle, the certificate audit
+    (certified_but_wrong == 0) and the screen audit (rejected_but_would_pass == 0)."""
+    from test_certificate_audit_gpu import _audit, _audit_screen
+    imgs = np.load(os.path.join(GOLD, "fountain11_gray.npz"))["images"]
+    pool = np.concatenate([E.surf_detect_and_compute(im, 300.0, None, gpu_ctx)[1] for im in imgs])
+    assert len(pool) >= synth.HARD_POOL_ROWS
+    sets = synth.msurf4k_hard_sets(pool)
+    pairs = synth.all_pairs(25)
+    oracle_lib.set_num_threads(os.cpu_count() or 1)
+    pm = E.PairMatcher(E.DescriptorBank(sets, E.ESFM_L2_F32), pairs)
+    for ratio in (0.5, 0.8):
+        res = pm.match(ratio).to_host()
+        n_q, n_rescan = pm.stats(); n_second = pm.second_pass()
+        ref = oracle_lib.match_pairs_l2(sets, pairs, ratio)
+        bad = [p for p, (a, b) in enumerate(zip(res, ref))
+               if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(_bits(a[2]), _bits(b[2])))]
+        assert not bad, (ratio, bad[:8])
+        print(f"\nM-SURF-4k-hard, ratio {ratio}: {sum(len(a[0]) for a in res)} matches over 300 pairs == oracle; second pass {n_second} "
+              f"({100.0 * n_second / n_q:.2f} %), re-scanned {n_rescan}")
+        if ratio == 0.5:
+            assert n_second >= n_q // 100                     # the workload does what it was built for
+    pm.close()
+    n_q, n_flag, n_front = _audit(sets, pairs, label="M-SURF-4k-hard")
+    assert n_front >= n_q // 100
+    scr = _audit_screen(sets, pairs, label="M-SURF-4k-hard")
+    assert scr[0.5][0] - scr[0.5][1] >= n_q // 10             # at least 10 % of the queries survive the screen
