@@ -1633,6 +1633,7 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
         if (lane == 0) s_fin_tr[threadIdx.x >> 6][0] += (int)(rt1 - rt0);
 #endif
         float da = 0.f;
+#ifdef ESFM_FIN_EAGER_SELECT
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
             if (i < 2 * nv) {
@@ -1642,6 +1643,24 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
             }
             __builtin_amdgcn_sched_barrier(0);       // (one row group at a time: interleaved, the fourteen chains took 296 registers)
         }
+#else
+        // (round 5: the hand-over of a row group's distances is only CONSUMED behind the last group -- as written until then, every
+        // group waited for its own ds_bpermute before the next one's 43 VALU could start: fourteen exposed LDS round trips per round,
+        // seen once a wave had a dozen virtual sets instead of one -- M-SURF-4k-hard, scratch/fin_trace_hard.py)
+        float got[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            got[i] = 0.f;
+            if (i < 2 * nv) {
+                const float dr = l2sqr64_canonical_row16(qv[i >> 1], rowv[i]);
+                got[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 3) * 16 + 15) * 4, __float_as_int(dr)));
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (one row group at a time: interleaved, the fourteen chains took 296 registers)
+        }
+#pragma unroll
+        for (int i = 0; i < 14; ++i)
+            if ((lane >> 2) == i) da = got[i];
+#endif
         // this lane's candidate as a key (+inf, NaN, rows past the set: none); then the two best of the query's eight lanes
         const float dda = sqrt_rn_f32(da);
         u64 c0k = (need && trow < nt && dda < FLT_MAX) ? (((u64)__float_as_uint(dda) << 32) | (u64)(uint32_t)trow) : kNone, c1k = kNone;
@@ -1849,7 +1868,11 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
     if (audit == 3 || audit == 4) return;          // the first pass alone: its answers, its own lists
 
     // ---- (2), (3): the pair's uncertified queries, chunks of 32, the whole train set by this workgroup's four waves
+#ifdef ESFM_FIN_NOSTAGE2
+    const int cnt = 0;                        // (timing experiments: wrong results for uncertified queries)
+#else
     const int cnt = min(ld_coh_i(unc_cnt + p), nq);
+#endif
 #ifndef ESFM_FIN_SMALL
 #define ESFM_FIN_SMALL 8       // uncertified queries of a pair up to which the exact brute force beats the threshold filter's fixed ~100-us chain
 #endif

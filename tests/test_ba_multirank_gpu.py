@@ -23,7 +23,16 @@ def _free_port():
 CALIB0 = [703.67, 376.37, 677.22, 254.22]     # shared intrinsics start, ~2 % off the scene's
 
 
-def _worker(rank, world, port, backend, q, constrained=False):
+SCENES = {"small": (8, 600, 5, 21, 10.0, 2.0), "loop200": (200, 12000, 8, 34, 15.0, 3.0)}     # n_cam, n_pt, obs per point, seed, radius, extent
+
+
+def _scene(name):
+    from easysfm_amd import synth
+    n_cam, n_pt, k, seed, radius, extent = SCENES[name]
+    return synth.ba_scene(n_cam, n_pt, k, radius=radius, extent=extent, seed=seed)
+
+
+def _worker(rank, world, port, backend, q, constrained=False, scene="small"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -37,7 +46,7 @@ def _worker(rank, world, port, backend, q, constrained=False):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         import easysfm_amd as E
         from easysfm_amd import synth
-        sc = synth.ba_scene(8, 600, 5, seed=21)
+        sc = _scene(scene)
         shard = E.shard_points(sc.n_pt, sc.pt_idx, world)
         keep = shard[sc.pt_idx] == rank
         ctx = E.Context.on_torch_stream(0)
@@ -64,12 +73,12 @@ def _worker(rank, world, port, backend, q, constrained=False):
             dist.destroy_process_group()
 
 
-def _run(world, backend, constrained=False):
+def _run(world, backend, constrained=False, scene="small"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, constrained)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q, constrained, scene)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in range(world)]
@@ -79,10 +88,9 @@ def _run(world, backend, constrained=False):
     return sorted(res, key=lambda r: r[0])
 
 
-def _single():
+def _single(scene="small"):
     import easysfm_amd as E
-    from easysfm_amd import synth
-    sc = synth.ba_scene(8, 600, 5, seed=21)
+    sc = _scene(scene)
     opt = E.default_options(); opt.max_num_iterations = 6
     return sc, E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, E.Context(0, None))
 
@@ -153,4 +161,44 @@ def test_native_rccl_communicator_single_rank(gpu_ctx):
     # a one-rank sum is the identity and the solver is bit-reproducible: equal, not close
     assert [it.cost for it in s2.log()] == [it.cost for it in summ.log()]
     # (cameras are replicated; the sharded solve returns points as x0 + all-reduce(x - x0), one rounding away from x)
+    assert np.array_equal(c, cams) and np.allclose(p, pts, rtol=0.0, atol=4e-15)
+
+
+def test_sharded_structure_aware_solve_two_ranks_matches_single(gpu_ctx):
+    """A loop of 200 cameras: the reduced camera system takes the structure-aware solve (ba_chol_sparse.hip).  Two ranks hold
+    half of the points each, so NEITHER rank's own observations show the whole co-visibility: the ranks unite their camera-pair
+    sets at the start of the solve, plan identically, and exchange only the co-visible camera blocks per LM iteration
+    (ba_sparse_pack_kernel -> all-reduce -> chol_sparse_assemble_kernel<PACKED>).  Cost trace and parameters must follow the
+    single-GPU solve; the replicated cameras must agree bit for bit across the ranks."""
+    import easysfm_amd as E
+    sc, (cams, pts, summ) = _single("loop200")
+    plan = E.reduced_plan(sc.n_cam, sc.n_pt, sc.cam_idx, sc.pt_idx)
+    assert plan["worthwhile"]                                          # (this test is about the structure-aware path)
+    shard = E.shard_points(sc.n_pt, sc.pt_idx, 2)
+    for r in range(2):                                                  # a rank's own pair set is smaller than the union
+        keep = shard[sc.pt_idx] == r
+        assert E.reduced_plan(sc.n_cam, sc.n_pt, sc.cam_idx[keep], sc.pt_idx[keep])["covisible_blocks"] <= plan["covisible_blocks"]
+    res = _run(2, "gloo", scene="loop200")
+    ref_cost = [it.cost for it in summ.log()]
+    for rank, _, c, p, costs, n_active, _cal, _ls in res:
+        assert len(costs) == len(ref_cost) and np.allclose(costs, ref_cost, rtol=1e-9)
+        assert np.allclose(c, cams, rtol=1e-6, atol=1e-6) and np.allclose(p, pts, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(res[0][2], res[1][2])
+    assert res[0][5] + res[1][5] == sc.n_pt
+
+
+def test_native_rccl_communicator_single_rank_structure_aware(gpu_ctx):
+    """The structure-aware exchange through the library's own RCCL communicator, one rank: the packed co-visible blocks are this
+    rank's fixed-point sums converted exactly as the one-rank assembly converts them, so the solve is bit-identical to the single-GPU one."""
+    import torch
+    import easysfm_amd as E
+    sc, (cams, pts, summ) = _single("loop200")
+    ctx = E.Context.on_torch_stream(0)
+    comm = E.Comm(ctx, E.Comm.unique_id(), 0, 1)
+    assert comm.rccl_ranks() == 1
+    with torch.cuda.stream(ctx.torch_stream):
+        opt = E.default_options(); opt.max_num_iterations = 6
+        c, p, s2 = E.ba_solve(sc.cam_idx, sc.pt_idx, sc.uv, sc.K4, sc.cams0, sc.pts0, opt, ctx, allreduce=comm)
+    comm.close()
+    assert [it.cost for it in s2.log()] == [it.cost for it in summ.log()]
     assert np.array_equal(c, cams) and np.allclose(p, pts, rtol=0.0, atol=4e-15)
