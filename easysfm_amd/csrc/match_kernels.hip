@@ -1474,7 +1474,7 @@ __device__ __forceinline__ void ratio_compact_pair_sparse(const PairDesc &pd, co
 #ifndef ESFM_FIN_THREADS
 #define ESFM_FIN_THREADS 256
 #endif
-constexpr int kFinThreads = ESFM_FIN_THREADS, kFinCap = 1024, kFinWaves = kFinThreads / 64;
+constexpr int kFinThreads = ESFM_FIN_THREADS, kFinCap = 2048, kFinWaves = kFinThreads / 64;
 
 // exact 2-NN of up to 32 listed queries of one pair by the whole workgroup, the oracle's arithmetic and (distance, index) order:
 // thread = train row (16 x 16 B in registers), the queries as LDS broadcasts; the 64 keys of a wave's rows are reduced to the two
@@ -1755,7 +1755,101 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
     }
 }
 
-constexpr size_t kFinLdsBytes = 12288 + 8192 + (size_t)kFinWaves * 32 * 2 * 8;      // the buffers of stages (2) - (4) (the re-rank keeps its rows in registers)
+// Stage (2)'s sweep over a wave's share [st0, st1) of the train set's 32-row steps, for the (up to) 64 queries of a sweep: the same
+// bf16(-2 q) . bf16(t) product as the pass on the matrix cores, every score compared with its query's threshold, the rows that pass
+// appended to the workgroup's hit list ((query slot) << 21 | train row).  Lane j of either half-wave owns the queries j and 32 + j.
+// Branch-free loads through buffer descriptors (rows past nt read as zeros; their norms become kBig), the next step's eight loads in
+// flight during this step's MFMAs.  (The first version guarded every load with `row < nt`: hipcc turned each into a branch and waited
+// for every fragment before its MFMA -- 6.5 us per step.)  A function of its OWN, not inlined: inside l2_finish_kernel's body the
+// register allocator -- 168 registers for three workgroups per CU, cut for the re-rank -- kept the operands of this loop in scratch
+// memory and re-loaded them in front of every matrix instruction (6 us per step on M-SURF-4k-hard, round 5).
+__device__ __noinline__ void finish_filter_sweep(const u32x4 *hi_rows /* the train set's bf16 images */, const float *tn /* its |row|^2 */, int st0, int st1, int nt_, int j,
+                                                 int h, bool two, const bf16x8 (&bq_)[2][4], const float (&thr2_)[2], int *s_nhit, int *s_h)
+{
+    constexpr int HS = 8, CAP = kFinCap;
+    constexpr float kBig = 3.0e38f;
+    // (arguments of a non-inlined function arrive in vector registers: the descriptors are rebuilt from values the compiler can see
+    // are wave-uniform, or every buffer load becomes a waterfall loop)
+    auto uniform_ptr = [](const void *p) {
+        const unsigned long long v = (unsigned long long)(uintptr_t)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<void *>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+    };
+    const int nt = __builtin_amdgcn_readfirstlane(nt_);
+    st0 = __builtin_amdgcn_readfirstlane(st0); st1 = __builtin_amdgcn_readfirstlane(st1);
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(hi_rows), 0, nt * (HS * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(tn), 0, nt * 4, 0x00020000);
+    // the query operands and thresholds arrive by reference, i.e. in the caller's scratch memory: into registers ONCE (left as
+    // references, every matrix instruction of every step re-loaded its operand with a flat load: 2.7 us per step)
+    bf16x8 lbq[2][4]; float lthr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float tv = thr2_[u];
+        asm volatile("" : "+v"(tv));
+        lthr[u] = tv;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 v = __builtin_bit_cast(u32x4, bq_[u][ks]);
+            asm volatile("" : "+v"(v));
+            lbq[u][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    const bf16x8 (&bq)[2][4] = lbq; const float (&thr2)[2] = lthr;
+    auto load_step = [&](int st, u32x4 (&a)[4], u32x4 (&nv)[4]) {
+        const int voff = (st * 32 + j) * (HS * 16) + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, voff + 32 * ks, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nv[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (st * 32 + 8 * g + 4 * h) * 4, 0, 0);
+    };
+    // one step: scores of the step's 32 rows against the sweep's queries, the rows under a query's threshold appended to the hit list
+    auto step = [&](int st, const u32x4 (&ca)[4], const u32x4 (&cn)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;                       // (workgroup-uniform: a sweep of at most 32 queries runs one accumulator)
+            floatx16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[4 * g + x] = (st * 32 + 8 * g + 4 * h + x) < nt ? __uint_as_float(cn[g][x]) : kBig;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca[ks]), bq[u][ks], acc, 0, 0, 0);
+            float m = kBig;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fminf(m, acc[r]);       // (fminf drops NaN scores: never neighbours)
+            if (__ballot(m <= thr2[u]) != 0ull) {
+                uint32_t mask = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    mask |= (acc[r] <= thr2[u] && t < nt) ? (1u << r) : 0u;
+                }
+                if (mask) {                         // one atomic per lane with hits, then its slots in order
+                    int k = atomicAdd(s_nhit, __popc(mask));
+                    while (mask) {
+                        const int r = __ffs(mask) - 1;
+                        mask &= mask - 1;
+                        if (k < CAP) s_h[k] = ((32 * u + j) << 21) | (st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                        ++k;
+                    }
+                }
+            }
+        }
+    };
+    // two operand sets: the loads of step s + 2 are issued right behind the use of step s.  (A ring of three was measured: the third
+    // set pushes two of the query operands into scratch memory, re-loaded in front of their matrix instructions: slower.)
+    u32x4 a0[4], n0[4], a1[4], n1[4];
+    load_step(st0, a0, n0); load_step(st0 + 1, a1, n1);      // (steps past the set read zeros; past st1 they are not used)
+    for (int st = st0; st < st1; st += 2) {
+        step(st, a0, n0);
+        if (st + 2 < st1) load_step(st + 2, a0, n0);
+        if (st + 1 < st1) { step(st + 1, a1, n1); if (st + 3 < st1) load_step(st + 3, a1, n1); }
+    }
+}
+
+constexpr size_t kFinLdsBytes = 8192 + 8192 + (size_t)kFinWaves * 32 * 2 * 8;       // the buffers of stages (2) - (4) (the re-rank keeps its rows in registers)
 
 #ifndef ESFM_FIN_OCC
 #define ESFM_FIN_OCC 3            // workgroups per CU the register budget is cut for: 3 = 168 registers, no spill in the re-rank (64.5 us per step;
@@ -1778,13 +1872,14 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
     static_assert(kFinThreads == 256, "the later stages' buffers are laid out for four waves");
     extern __shared__ __attribute__((aligned(16))) char fin_smem[];         // kFinLdsBytes
     // stages (2) - (4) reuse the landing zones
-    int *s_h = reinterpret_cast<int *>(fin_smem);                             // [CAP] hits of the chunk: (query slot in the chunk) << 21 | train row
-    float *s_hd = reinterpret_cast<float *>(fin_smem + 4096), *s_hd2 = reinterpret_cast<float *>(fin_smem + 8192);
-    float4 (*s_q)[16] = reinterpret_cast<float4 (*)[16]>(fin_smem + 12288);  // [32][16]
-    unsigned long long (*s_keys)[32][2] = reinterpret_cast<unsigned long long (*)[32][2]>(fin_smem + 12288 + 8192);   // [NW][32][2]
+    int *s_h = reinterpret_cast<int *>(fin_smem);                             // [CAP] hits of the sweep: (query slot in the sweep) << 21 | train row
+    float4 (*s_q)[16] = reinterpret_cast<float4 (*)[16]>(fin_smem + 8192);   // [32][16]
+    unsigned long long (*s_keys)[32][2] = reinterpret_cast<unsigned long long (*)[32][2]>(fin_smem + 8192 + 8192);   // [NW][32][2]
     __shared__ int s_nhit, s_last;
     __shared__ float s_red[2 * NW];
-    __shared__ int s_qrows[32];
+    __shared__ int s_qrows[64];
+    __shared__ unsigned long long s_best[2][64];                              // stage 2: the running (distance, index) keys of a sweep's queries
+
     __shared__ int s_wave[NW], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     // Blocks are dispatched round-robin over the XCDs; xcd_remap gives every XCD a contiguous range of logical blocks, and the logical
@@ -1849,6 +1944,10 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
         }
 #endif
     }
+    // (Round 5, measured and not kept: every workgroup settling ITS OWN uncertified queries by exact brute force right here instead
+    // of leaving them to the pair's last workgroup -- M-SURF-4k-hard: 16 695 such queries per step, the finish kernel 1.43 -> 1.71 ms:
+    // 4096 exact distances per query are as many VALU instructions again as the whole re-rank; the threshold filter's MFMA pass is
+    // what keeps the second pass cheap, and what it needed was a shorter serial tail, see stage (2).)
     // arrive; the last of the pair's S workgroups goes on alone.  Every wave waits for its own write-through stores to be
     // acknowledged before the barrier lets the arrival out.
 #ifdef ESFM_FIN_TRACE
@@ -1889,11 +1988,14 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else if (cnt > 0) {
-        const int nchunks = (cnt + 31) >> 5;
+        // Round 5: a sweep over the train set serves SIXTY-FOUR queries (two MFMA accumulators per operand load) and the hits are merged
+        // by 64-bit LDS atomic minima of (distance, index) keys.  Until then a sweep took 32 queries and one thread per query walked the
+        // whole hit list: on real descriptors (M-SURF-4k-hard: 55 uncertified queries per pair, 13 hits per query) the pair's last
+        // workgroup spent 2.2 x (104 us of sweep + 68 us of hits) here while every other workgroup of the pair had left.
+        typedef unsigned long long u64;
+        const int nchunks = (cnt + 63) >> 6;
         const float *__restrict__ tn = norms + pd.t_row0;
         const float *__restrict__ tr = rho_t + pd.t_row0;
-        const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(hi_t + (size_t)pd.t_row0 * HS), 0, nt * (HS * 16), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tn), 0, nt * 4, 0x00020000);
         {   // max |t|^2 and max rho_t over the train set
             float m = 0.f, r = 0.f;
             for (int t = tid; t < nt; t += kFinThreads) { m = fmaxf(m, tn[t]); r = fmaxf(r, tr[t]); }
@@ -1909,115 +2011,112 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
         // this wave's share of the train set, in steps of 32 rows
         const int nsteps = (nt + 31) / 32;
         const int st0 = (nsteps * wave) / NW, st1 = (nsteps * (wave + 1)) / NW;
+        auto key_of = [](float d, int t) { return (t >= 0 && d < FLT_MAX) ? (((u64)__float_as_uint(d) << 32) | (u64)(uint32_t)t) : ~0ull; };   // FLT_MAX, +inf, NaN: never a neighbour
         for (int c = 0; c < nchunks; ++c) {
+#ifdef ESFM_FIN_TRACE2
+            const unsigned long long t2a = __builtin_amdgcn_s_memrealtime();
+#endif
             if (tid == 0) s_nhit = 0;
-            const int slot = c * 32 + j;
-            const bool qok = slot < cnt;
-            const int qrow = qok ? ld_coh_i(unc_list + pd.out_off + slot) : 0;
-            if (tid < 32) s_qrows[tid] = qrow;
-            // threshold on the score: s <= U - |q|^2 + E1, rounded up
-            float thr = -kBig;
-            if (qok) {
-                const double qn = (double)norms[pd.q_row0 + qrow], rq = (double)rho_q[pd.q_row0 + qrow];
-                const double e1 = l2x1_e1(qn, rq, sqrt_tmax, (double)tmax, (double)rmax);
-                const double u = (double)ld_coh_f(knn_d2 + pd.out_off + qrow);
-                const double x = u * (1.0 + 1.0 / 1048576.0) - qn + e1;
-                const double xs = x + fabs(x) * (1.0 / 1048576.0);
-                thr = xs < 3.0e38 ? (float)xs : kBig;                 // (NaN compares false: kBig, everything passes -> overflow -> brute force)
-                if (!(xs < 3.0e38)) thr = kBig;
-                if ((double)thr < xs) thr = nextafterf(thr, kBig);
-            }
-            bf16x8 bq[4];
+            const int nqc = min(64, cnt - c * 64);
+            // lane j of either half-wave owns the queries j and 32 + j of the sweep
+            int qrow2[2]; float thr2[2]; bf16x8 bq[2][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                u32x4 v = qok ? hi_q[((size_t)pd.q_row0 + qrow) * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
-                bq[ks] = __builtin_bit_cast(bf16x8, v);
+            for (int u = 0; u < 2; ++u) {
+                const int slot = c * 64 + 32 * u + j;
+                const bool qok = slot < cnt;
+                const int qrow = qok ? ld_coh_i(unc_list + pd.out_off + slot) : 0;
+                qrow2[u] = qrow;
+                // threshold on the score: s <= U - |q|^2 + E1, rounded up
+                float thr = -kBig;
+                if (qok) {
+                    const double qn = (double)norms[pd.q_row0 + qrow], rq = (double)rho_q[pd.q_row0 + qrow];
+                    const double e1 = l2x1_e1(qn, rq, sqrt_tmax, (double)tmax, (double)rmax);
+                    const double uu = (double)ld_coh_f(knn_d2 + pd.out_off + qrow);
+                    const double x = uu * (1.0 + 1.0 / 1048576.0) - qn + e1;
+                    const double xs = x + fabs(x) * (1.0 / 1048576.0);
+                    thr = xs < 3.0e38 ? (float)xs : kBig;                 // (NaN compares false: kBig, everything passes -> overflow -> brute force)
+                    if (!(xs < 3.0e38)) thr = kBig;
+                    if ((double)thr < xs) thr = nextafterf(thr, kBig);
+                }
+                thr2[u] = thr;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    u32x4 v = qok ? hi_q[((size_t)pd.q_row0 + qrow) * HS + 2 * ks + h] : u32x4{0u, 0u, 0u, 0u};
+                    bq[u][ks] = __builtin_bit_cast(bf16x8, v);
+                }
+            }
+            if (tid < 32) { s_qrows[tid] = qrow2[0]; s_qrows[32 + tid] = qrow2[1]; }
+            // the running two best of every query of the sweep start from what the re-rank left
+            if (tid < nqc) {
+                const size_t o = 2 * ((size_t)pd.out_off + ld_coh_i(unc_list + pd.out_off + c * 64 + tid));
+                s_best[0][tid] = key_of(ld_coh_f(knn_dist + o), ld_coh_i(knn_idx + o));
+                s_best[1][tid] = key_of(ld_coh_f(knn_dist + o + 1), ld_coh_i(knn_idx + o + 1));
             }
             __syncthreads();
-            // Branch-free loads through buffer descriptors (rows past nt read as zeros; their norms become kBig), the next step's
-            // eight loads in flight during this step's MFMAs.  (The first version guarded every load with `row < nt`: hipcc turned
-            // each into a branch and waited for every fragment before its MFMA -- 6.5 us per step, 52 us per chunk.)
-            auto load_step = [&](int st, u32x4 (&a)[4], u32x4 (&nv)[4]) {
-                const int voff = (st * 32 + j) * (HS * 16) + h * 16;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_t, voff + 32 * ks, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) nv[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (st * 32 + 8 * g + 4 * h) * 4, 0, 0);
-            };
-            u32x4 fa[4], fn[4];
-            if (st0 < st1) load_step(st0, fa, fn);
-            for (int st = st0; st < st1; ++st) {
-                u32x4 ca[4], cn[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { ca[k] = fa[k]; cn[k] = fn[k]; }
-                if (st + 1 < st1) load_step(st + 1, fa, fn);
-                floatx16 acc;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[4 * g + u] = (st * 32 + 8 * g + 4 * h + u) < nt ? __uint_as_float(cn[g][u]) : kBig;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca[ks]), bq[ks], acc, 0, 0, 0);
-                float m = kBig;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fminf(m, acc[r]);       // (fminf drops NaN scores: never neighbours)
-                if (__ballot(m <= thr) != 0ull) {
-                    uint32_t mask = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int t = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        mask |= (acc[r] <= thr && t < nt) ? (1u << r) : 0u;
-                    }
-                    if (mask) {                         // one atomic per lane with hits, then its slots in order
-                        int k = atomicAdd(&s_nhit, __popc(mask));
-                        while (mask) {
-                            const int r = __ffs(mask) - 1;
-                            mask &= mask - 1;
-                            if (k < CAP) s_h[k] = (j << 21) | (st * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                            ++k;
-                        }
-                    }
-                }
-            }
+            finish_filter_sweep(hi_t + (size_t)pd.t_row0 * HS, tn, st0, st1, nt, j, h, nqc > 32, bq, thr2, &s_nhit, s_h);
             __syncthreads();
             const int nhit = s_nhit;
-            const int nqc = min(32, cnt - c * 32);
+#ifdef ESFM_FIN_TRACE2
+            const unsigned long long t2b = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) { atomicAdd(&counters[4], (int)(t2b - t2a)); atomicAdd(&counters[5], nhit); atomicAdd(&counters[6], 1); atomicMax(&counters[3], nhit); }
+#endif
             if (nhit <= CAP) {
-                // exact distances of the hits, the oracle's order
-                for (int k = tid; k < nhit; k += kFinThreads) {
-                    const int hk = s_h[k];
-                    const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + s_qrows[hk >> 21]) * 64);
-                    const float4 *tp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.t_row0 + (hk & 0x1FFFFF)) * 64);
-                    float4 qa[16], tb[16];
+                // exact distances of the hits in the oracle's order (a thread per hit), merged as (distance, index) keys: the smallest
+                // key of a query by a 64-bit LDS atomic minimum, then the smallest of the others (two different rows never share a key;
+                // a hit that IS one of the two rows the re-rank left carries that row's key and changes nothing)
+                u64 keyv[CAP / kFinThreads];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { qa[e] = qp[e]; tb[e] = tp[e]; }
-                    const float d2 = l2sqr64_canonical_regs(qa, tb);
-                    s_hd2[k] = d2; s_hd[k] = sqrt_rn_f32(d2);
+                for (int x = 0; x < CAP / kFinThreads; ++x) {
+                    const int k = tid + kFinThreads * x;
+                    keyv[x] = ~0ull;
+                    if (k < nhit) {
+                        const int hk = s_h[k];
+                        const float4 *qp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.q_row0 + s_qrows[hk >> 21]) * 64);
+                        const float4 *tp = reinterpret_cast<const float4 *>(desc + ((size_t)pd.t_row0 + (hk & 0x1FFFFF)) * 64);
+                        float4 qa[16], tb[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { qa[e] = qp[e]; tb[e] = tp[e]; }
+                        keyv[x] = key_of(sqrt_rn_f32(l2sqr64_canonical_regs(qa, tb)), hk & 0x1FFFFF);
+                    }
                 }
+                u64 init0 = ~0ull;
+                if (tid < nqc) init0 = s_best[0][tid];
+                __syncthreads();
+#pragma unroll
+                for (int x = 0; x < CAP / kFinThreads; ++x) {
+                    const int k = tid + kFinThreads * x;
+                    if (k < nhit && keyv[x] != ~0ull) atomicMin(&s_best[0][s_h[k] >> 21], keyv[x]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int x = 0; x < CAP / kFinThreads; ++x) {
+                    const int k = tid + kFinThreads * x;
+                    if (k < nhit && keyv[x] != ~0ull && keyv[x] != s_best[0][s_h[k] >> 21]) atomicMin(&s_best[1][s_h[k] >> 21], keyv[x]);
+                }
+                if (tid < nqc && init0 != s_best[0][tid]) atomicMin(&s_best[1][tid], init0);      // (the re-rank's best, displaced by a hit)
                 __syncthreads();
                 if (tid < nqc) {
                     const size_t o = 2 * ((size_t)pd.out_off + s_qrows[tid]);
-                    Cand b0 = {ld_coh_f(knn_dist + o), ld_coh_i(knn_idx + o), 0.f}, b1 = {ld_coh_f(knn_dist + o + 1), ld_coh_i(knn_idx + o + 1), 0.f};
-                    if (b0.i < 0) b0.d = FLT_MAX;
-                    if (b1.i < 0) b1.d = FLT_MAX;
-                    for (int k = 0; k < nhit; ++k) {
-                        const int hk = s_h[k], ht = hk & 0x1FFFFF;
-                        if ((hk >> 21) == tid && ht != b0.i && ht != b1.i) best2_insert(b0, b1, s_hd[k], ht, s_hd2[k]);
-                    }
-                    st_coh_i(knn_idx + o, b0.i); st_coh_i(knn_idx + o + 1, b1.i);
-                    st_coh_f(knn_dist + o, b0.d); st_coh_f(knn_dist + o + 1, b1.d);
+                    const u64 k0 = s_best[0][tid], k1 = s_best[1][tid];
+                    st_coh_i(knn_idx + o, k0 != ~0ull ? (int)(uint32_t)k0 : -1); st_coh_i(knn_idx + o + 1, k1 != ~0ull ? (int)(uint32_t)k1 : -1);
+                    st_coh_f(knn_dist + o, k0 != ~0ull ? __uint_as_float((uint32_t)(k0 >> 32)) : FLT_MAX);
+                    st_coh_f(knn_dist + o + 1, k1 != ~0ull ? __uint_as_float((uint32_t)(k1 >> 32)) : FLT_MAX);
                 }
                 __syncthreads();
+#ifdef ESFM_FIN_TRACE2
+                if (tid == 0) atomicAdd(&counters[7], (int)(__builtin_amdgcn_s_memrealtime() - t2b));
+#endif
             } else {
-                // too many rows inside the error bound: exact brute force of the chunk's queries
+                // too many rows inside the error bound: exact brute force of the sweep's queries, 32 at a time
                 if (tid < nqc) {
                     const int sl2 = atomicAdd(&counters[0], 1);
                     if (sl2 < flag_cap) { flagged[2 * sl2] = p; flagged[2 * sl2 + 1] = s_qrows[tid]; }
                 }
                 __syncthreads();
-                if (audit != 1) finish_bruteforce_chunk(desc, pd, s_qrows, nqc, s_q, s_keys, knn_idx, knn_dist);
+                if (audit != 1) {
+                    finish_bruteforce_chunk(desc, pd, s_qrows, min(32, nqc), s_q, s_keys, knn_idx, knn_dist);
+                    if (nqc > 32) finish_bruteforce_chunk(desc, pd, s_qrows + 32, nqc - 32, s_q, s_keys, knn_idx, knn_dist);
+                }
                 __syncthreads();
             }
         }
