@@ -1567,7 +1567,23 @@ struct FinRerankArgs {
     int32_t *counters, *audit_unc, *audit_rej; int flag_cap;
 };
 constexpr int kFinQV = 7;
-__device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v, float4 ka, float4 kb4, float4 mi)
+// What the re-rank keeps of a query between two rounds: its survivor entry (two half-waves' K keys, row / |q|^2 / E1) and the exact
+// two best rows so far.  64 bytes.
+struct FinPending { float4 ka, kb, mi; unsigned long long m0, m1; };
+#ifndef ESFM_FIN_PEND
+#define ESFM_FIN_PEND 112
+#endif
+constexpr int kFinPend = ESFM_FIN_PEND;        // pending queries of a wave (16 virtual sets' worth): 7 KiB of LDS per wave
+
+// Stage (1) for ONE WAVE's share of a pair's survivors: the virtual sets v0, v0 + vstride, ... < nvs.
+// Round 5 -- COMPACTION BY ROUND.  Until then a virtual set of seven ran all of its rounds together and advanced at the pace of its
+// slowest query: on real, clustered descriptors (M-SURF-4k-hard) a set took 3.24 rounds for queries that needed 1.8 on average, and
+// every round costs the same whatever it holds.  Now round 0 runs over the wave's sets as before; a query that is neither decided
+// nor out of groups afterwards is parked in the wave's LDS list (FinPending); the later rounds are run over that list, seven
+// queries at a time, each round re-packing what is still undecided.  A query's arithmetic depends on nothing but its own state, so
+// the results are bit-identical; on the metric's workload (one set per wave, 1.6 rounds) nothing changes.
+template <bool SINGLE>
+__device__ __forceinline__ void finish_rerank_wave(const FinRerankArgs &A, int v0, int vstride, int nvs, FinPending *pend)
 {
     typedef unsigned long long u64;
     constexpr int K = ESFM_L2X1_KEEP, GRP = ESFM_L2X1_GRP, NG = 16 / GRP, QV = kFinQV;
@@ -1587,26 +1603,54 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
     };
     auto kmin = [](u64 x, u64 y) { return x < y ? x : y; };
     auto kmax = [](u64 x, u64 y) { return x < y ? y : x; };
-    const int nv = min(A.per, A.nsv - v * A.per);                // wave-uniform: queries of this virtual set
-    const bool qvalid = (lane >> 3) < nv;
-    const int qrow = qvalid ? __float_as_int(mi.x) : nq;         // nq: past the descriptor, zeros
-    const double qn = (double)mi.y, e1 = (double)mi.z;
-    const float a_[4] = {qvalid ? ka.x : kBig, qvalid ? ka.y : kBig, qvalid ? ka.z : kBig, qvalid ? ka.w : kBig};
-    const float b_[4] = {qvalid ? kb4.x : kBig, qvalid ? kb4.y : kBig, qvalid ? kb4.z : kBig, qvalid ? kb4.w : kBig};
-    const float tau = fminf(a_[3], b_[3]);
-    // the two smallest keys (ties: half 0 first -- any fixed rule will do, the eight lanes only have to agree)
-    const bool c0 = a_[0] <= b_[0];
-    const float r0k = c0 ? a_[0] : b_[0];
-    const float r1k = fminf(c0 ? a_[1] : a_[0], c0 ? b_[0] : b_[1]);
-    const double U = (qn + (double)r1k + e1 + fabs((double)r1k) * kTrunc) * (1.0 + 1.0 / 1048576.0);
-    u64 m0 = kNone, m1 = kNone;                                  // the query's exact two best so far (the same in its eight lanes)
+    // ---- the state of the query this lane works for (the same in its eight lanes)
+    int nv = 0;                                                  // wave-uniform: queries of the current set
+    bool qvalid = false;
+    int qrow = 0;
+    double qn = 0.0, e1 = 0.0, U = 0.0;
+    float a_[4], b_[4], tau = kBig;
+    float4 s_ka, s_kb, s_mi;                                     // (the entry as it came: what is parked when the query stays undecided)
+    u64 m0 = kNone, m1 = kNone;                                  // the query's exact two best so far
     int verdict = 0;
-    // one round: the group (key, row0) of the query, nkey = the smallest key of the groups the later rounds would fetch.
-    // Returns false when no lane of the wave needed a row (the rounds are over).
-    auto do_round = [&](auto first, bool last, float key, int row0, float nkey) __attribute__((always_inline)) -> bool {
+    auto take = [&](float4 ka, float4 kb4, float4 mi, bool valid, u64 b0, u64 b1) {
+        s_ka = ka; s_kb = kb4; s_mi = mi;
+        qvalid = valid;
+        qrow = qvalid ? __float_as_int(mi.x) : nq;               // nq: past the descriptor, zeros
+        qn = (double)mi.y; e1 = (double)mi.z;
+        a_[0] = qvalid ? ka.x : kBig; a_[1] = qvalid ? ka.y : kBig; a_[2] = qvalid ? ka.z : kBig; a_[3] = qvalid ? ka.w : kBig;
+        b_[0] = qvalid ? kb4.x : kBig; b_[1] = qvalid ? kb4.y : kBig; b_[2] = qvalid ? kb4.z : kBig; b_[3] = qvalid ? kb4.w : kBig;
+        tau = fminf(a_[3], b_[3]);
+        // the two smallest keys (ties: half 0 first -- any fixed rule will do, the eight lanes only have to agree)
+        const bool c0 = a_[0] <= b_[0];
+        const float r1k = fminf(c0 ? a_[1] : a_[0], c0 ? b_[0] : b_[1]);
+        U = (qn + (double)r1k + e1 + fabs((double)r1k) * kTrunc) * (1.0 + 1.0 / 1048576.0);
+        m0 = b0; m1 = b1; verdict = 0;
+    };
+    // the group of rank r among the query's 2 K keys (by counting), and the smallest key behind it
+    auto rank_group = [&](int r, float &key, int &row0, float &nkey) {
+        key = kBig; nkey = kBig; row0 = -1;
+#pragma unroll
+        for (int x = 0; x < 2 * K; ++x) {
+            const float kx = x < K ? a_[x & 3] : b_[x & 3];
+            int rank = 0;
+#pragma unroll
+            for (int y = 0; y < 2 * K; ++y) {
+                const float ky = y < K ? a_[y & 3] : b_[y & 3];
+                if (y != x) rank += (ky < kx || (ky == kx && y < x)) ? 1 : 0;
+            }
+            if (rank == r) { key = kx; row0 = row0_of(kx, x < K ? 0 : 1); }
+            if (rank == r + 1) nkey = kx;
+        }
+    };
+    // does a round on the group (key, row0) still have to look at rows?  (false once: false for every later rank -- the keys ascend)
+    auto wanted = [&](float key, int row0) {
         const bool cannot = (qn + (double)key - e1 - fabs((double)key) * kTrunc) > U;   // false on NaN: re-rank
-        const bool need = row0 >= 0 && qvalid && !cannot && verdict == 0;
-        if (__ballot(need) == 0ull) return false;
+        return row0 >= 0 && qvalid && !cannot && verdict == 0;
+    };
+    // one round: the group (key, row0) of the query, nkey = the smallest key of the groups the later rounds would fetch
+    auto do_round = [&](bool last, float key, int row0, float nkey) __attribute__((always_inline)) {
+        const bool need = wanted(key, row0);
+        if (__ballot(need) == 0ull) return;
         const int trow = row0 + ri;
         const int rsel = need ? trow : nt;                       // nt: past the descriptor, zeros
         // 16 lanes fetch one 256-B row INTO REGISTERS: load i brings the rows of the lanes 4 i .. 4 i + 3 (i < 2 nv: the candidate
@@ -1633,20 +1677,6 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
         if (lane == 0) s_fin_tr[threadIdx.x >> 6][0] += (int)(rt1 - rt0);
 #endif
         float da = 0.f;
-#ifdef ESFM_FIN_EAGER_SELECT
-#pragma unroll
-        for (int i = 0; i < 14; ++i) {
-            if (i < 2 * nv) {
-                const float dr = l2sqr64_canonical_row16(qv[i >> 1], rowv[i]);
-                const float got = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 3) * 16 + 15) * 4, __float_as_int(dr)));
-                if ((lane >> 2) == i) da = got;
-            }
-            __builtin_amdgcn_sched_barrier(0);       // (one row group at a time: interleaved, the fourteen chains took 296 registers)
-        }
-#else
-        // (round 5: the hand-over of a row group's distances is only CONSUMED behind the last group -- as written until then, every
-        // group waited for its own ds_bpermute before the next one's 43 VALU could start: fourteen exposed LDS round trips per round,
-        // seen once a wave had a dozen virtual sets instead of one -- M-SURF-4k-hard, scratch/fin_trace_hard.py)
         float got[14];
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
@@ -1660,7 +1690,6 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
 #pragma unroll
         for (int i = 0; i < 14; ++i)
             if ((lane >> 2) == i) da = got[i];
-#endif
         // this lane's candidate as a key (+inf, NaN, rows past the set: none); then the two best of the query's eight lanes
         const float dda = sqrt_rn_f32(da);
         u64 c0k = (need && trow < nt && dda < FLT_MAX) ? (((u64)__float_as_uint(dda) << 32) | (u64)(uint32_t)trow) : kNone, c1k = kNone;
@@ -1692,28 +1721,9 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
             const bool pass = two && lrest > m0hi * (1.0 + 1.0 / 1048576.0) && m0hi * (1.0 + 1.0 / 262144.0) < ratio2m * dlo;
             if (verdict == 0 && qvalid) verdict = fail ? 1 : (pass ? 2 : 0);
         }
-        return true;
     };
-    bool more = do_round(std::true_type{}, false, r0k, row0_of(r0k, c0 ? 0 : 1), r1k);
-    // the later rounds (a query still undecided after its best group): the ranking of the 2 K keys, by counting
-#pragma unroll 1
-    for (int r = 1; r < 2 * K && more; ++r) {
-        float key = kBig, nkey = kBig; int row0 = -1;
-#pragma unroll
-        for (int x = 0; x < 2 * K; ++x) {
-            const float kx = x < K ? a_[x & 3] : b_[x & 3];
-            int rank = 0;
-#pragma unroll
-            for (int y = 0; y < 2 * K; ++y) {
-                const float ky = y < K ? a_[y & 3] : b_[y & 3];
-                if (y != x) rank += (ky < kx || (ky == kx && y < x)) ? 1 : 0;
-            }
-            if (rank == r) { key = kx; row0 = row0_of(kx, x < K ? 0 : 1); }
-            if (rank == r + 1) nkey = kx;
-        }
-        more = do_round(std::false_type{}, r + 1 == 2 * K, key, row0, nkey);
-    }
-    if (qvalid && (lane & 7) == 0) {
+    // the query is through: its record, and -- neither certified nor decided -- its place on the pair's list for the threshold filter
+    auto finalize = [&]() {
         const size_t o = 2 * ((size_t)A.pd.out_off + qrow);
         const bool one = m0 != kNone, two = m1 != kNone;
         const double d0 = (double)__uint_as_float((uint32_t)(m0 >> 32)), d1 = (double)__uint_as_float((uint32_t)(m1 >> 32));
@@ -1752,6 +1762,86 @@ __device__ __forceinline__ void finish_rerank_vset(const FinRerankArgs &A, int v
             const int k = __hip_atomic_fetch_add(&A.unc_cnt[A.p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st_coh_i(A.unc_list + A.pd.out_off + k, qrow);
         }
+    };
+    // after round r: a query whose group of rank r + 1 is still wanted is parked at pend[*npend ...] (the leaders of the wave's
+    // queries take consecutive slots), every other one is finalised
+    auto park_or_finalize = [&](int r, int *npend) {
+        float key = kBig, nkey; int row0 = -1;
+        if (r + 1 < 2 * K) rank_group(r + 1, key, row0, nkey);
+        const bool leader = qvalid && (lane & 7) == 0;
+        const bool again = leader && r + 1 < 2 * K && wanted(key, row0);
+        const unsigned long long bal = __ballot(again);
+        if (again) {
+            FinPending &dst = pend[*npend + __popcll(bal & ((1ull << lane) - 1ull))];
+            dst.ka = s_ka; dst.kb = s_kb; dst.mi = s_mi; dst.m0 = m0; dst.m1 = m1;
+        }
+        if (leader && !again) finalize();
+        *npend += __popcll(bal);
+    };
+    // the later rounds over the parked queries, seven at a time, re-packed in place after every round (a set is read into
+    // registers before anything of it is written back, and what is written never passes what has been read)
+    auto drain = [&](int npend) {
+#pragma unroll 1
+        for (int r = 1; r < 2 * K && npend > 0; ++r) {
+            int nout = 0;
+#pragma unroll 1
+            for (int k = 0; k < npend; k += QV) {
+                nv = min(QV, npend - k);
+                const int e = lane >> 3;
+                const FinPending src = pend[k + min(e, nv - 1)];
+                __builtin_amdgcn_wave_barrier();
+                take(src.ka, src.kb, src.mi, e < nv, src.m0, src.m1);
+                float key, nkey; int row0;
+                rank_group(r, key, row0, nkey);
+                do_round(r + 1 == 2 * K, key, row0, nkey);
+                park_or_finalize(r, &nout);
+                __builtin_amdgcn_wave_barrier();
+            }
+            npend = nout;
+        }
+    };
+    // ---- round 0 over the wave's virtual sets (the next set's entries are loaded while this one waits for its rows)
+    const int eq = lane >> 3 < QV ? lane >> 3 : QV - 1;
+    auto entry_of = [&](int v, int part) {
+        const int e = v * A.per + eq;
+        return (v < nvs && e < A.nsv) ? A.ent[3 * (size_t)e + part] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int npend = 0;
+    int v = v0;
+    float4 e0 = entry_of(v, 0), e1v = entry_of(v, 1), e2 = entry_of(v, 2);
+#pragma unroll 1
+    for (; v < nvs; v += vstride) {
+        const float4 n0 = entry_of(v + vstride, 0), n1 = entry_of(v + vstride, 1), n2 = entry_of(v + vstride, 2);
+        nv = min(A.per, A.nsv - v * A.per);                      // wave-uniform: queries of this virtual set
+        take(e0, e1v, e2, (lane >> 3) < nv, kNone, kNone);
+        {
+            const bool c0 = a_[0] <= b_[0];
+            const float r0k = c0 ? a_[0] : b_[0];
+            const float r1k = fminf(c0 ? a_[1] : a_[0], c0 ? b_[0] : b_[1]);
+            do_round(false, r0k, row0_of(r0k, c0 ? 0 : 1), r1k);
+        }
+        if (SINGLE) {
+            // the wave's only set (the metric's workload: a pair's survivors are one set per wave): its later rounds straight away, in
+            // the registers the state is in -- parking and re-loading five queries costs more than their idle lanes do.  (SINGLE is a
+            // template parameter, the kernel branches once per wave: compiled into one body with the parking form, this path -- round
+            // 4's, instruction for instruction -- came out 3 us slower per launch.)
+#pragma unroll 1
+            for (int r = 1; r < 2 * K; ++r) {
+                float key, nkey; int row0;
+                rank_group(r, key, row0, nkey);
+                if (__ballot(wanted(key, row0)) == 0ull) break;
+                do_round(r + 1 == 2 * K, key, row0, nkey);
+            }
+            if (qvalid && (lane & 7) == 0) finalize();
+        } else {
+            park_or_finalize(0, &npend);
+            if (npend + QV > kFinPend) { __builtin_amdgcn_wave_barrier(); drain(npend); npend = 0; }
+        }
+        e0 = n0; e1v = n1; e2 = n2;
+    }
+    if (!SINGLE) {
+        __builtin_amdgcn_wave_barrier();
+        drain(npend);
     }
 }
 
@@ -1849,7 +1939,8 @@ __device__ __noinline__ void finish_filter_sweep(const u32x4 *hi_rows /* the tra
     }
 }
 
-constexpr size_t kFinLdsBytes = 8192 + 8192 + (size_t)kFinWaves * 32 * 2 * 8;       // the buffers of stages (2) - (4) (the re-rank keeps its rows in registers)
+constexpr size_t kFinTailLds = 8192 + 8192 + (size_t)kFinWaves * 32 * 2 * 8;        // the buffers of stages (2) - (4)
+constexpr size_t kFinLdsBytes = kFinTailLds + (size_t)kFinWaves * kFinPend * sizeof(FinPending);   // + the re-rank's parked queries (its rows live in registers)
 
 #ifndef ESFM_FIN_OCC
 #define ESFM_FIN_OCC 3            // workgroups per CU the register budget is cut for: 3 = 168 registers, no spill in the re-rank (64.5 us per step;
@@ -1914,28 +2005,15 @@ __global__ __launch_bounds__(kFinThreads, ESFM_FIN_OCC) void l2_finish_kernel(co
 #else
         const int nvs = (A.nsv + A.per - 1) / A.per;
 #endif
-        // (the next virtual set's entries are loaded while this one waits for its rows)
-        const int eq = lane >> 3 < kFinQV ? lane >> 3 : kFinQV - 1;
-        auto entry_of = [&](int v, int part) {
-            const int e = v * A.per + eq;
-            return (v < nvs && e < A.nsv) ? A.ent[3 * (size_t)e + part] : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        int v = sl * NW + wave;
-        float4 e0 = entry_of(v, 0), e1 = entry_of(v, 1), e2 = entry_of(v, 2);
 #ifdef ESFM_FIN_TRACE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the entries have landed: the set-up chain ends here)
         const unsigned long long ft0 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { s_fin_tr[wave][0] = 0; s_fin_tr[wave][1] = 0; s_fin_tr[wave][2] = 0; }
-        int nset = 0;
+        const int nset = (nvs - (sl * NW + wave) + S * NW - 1) / (S * NW);
 #endif
-        for (; v < nvs; v += S * NW) {
-            const float4 n0 = entry_of(v + S * NW, 0), n1 = entry_of(v + S * NW, 1), n2 = entry_of(v + S * NW, 2);
-            finish_rerank_vset(A, v, e0, e1, e2);
-            e0 = n0; e1 = n1; e2 = n2;
-#ifdef ESFM_FIN_TRACE
-            ++nset;
-#endif
-        }
+        if (sl * NW + wave + S * NW >= nvs)      // (wave-uniform) at most one virtual set for this wave
+            finish_rerank_wave<true>(A, sl * NW + wave, S * NW, nvs, nullptr);
+        else
+            finish_rerank_wave<false>(A, sl * NW + wave, S * NW, nvs, reinterpret_cast<FinPending *>(fin_smem + kFinTailLds) + wave * kFinPend);
 #ifdef ESFM_FIN_TRACE
         if (lane == 0) {      // (scratch/fin_trace.py: 10-ns ticks of stage 1 per wave, virtual sets, waves)
             atomicAdd(&counters[8], (int)(__builtin_amdgcn_s_memrealtime() - ft0)); atomicAdd(&counters[9], nset); atomicAdd(&counters[10], 1);
