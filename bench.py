@@ -455,7 +455,8 @@ def main() -> int:
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
-            traffic = tj.get("l2_knn_bf16x1_kernel_bytes_per_launch", tj.get("l2_knn_bf16_kernel_bytes_per_launch"))
+            # (the committed figure is the 300-pair launch's: at N > 1 a rank launches its share of the list, for which no counter pass exists)
+            traffic = tj.get("l2_knn_bf16x1_kernel_bytes_per_launch", tj.get("l2_knn_bf16_kernel_bytes_per_launch")) if world == 1 else None
             traffic_ba = {"ba": tj.get("ba_linearize_kernel_bytes_per_launch"), "config5": tj.get("ba512_linearize_kernel_bytes_per_launch")}
         except Exception:
             traffic = traffic_ba = None
@@ -468,7 +469,7 @@ def main() -> int:
     roofline = {"bound": "mfma", "kernel": "l2_knn_bf16x1_kernel", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)" if traffic else None,
-                "avg_launch_ms": avg_kernel_s * 1e3, "launches": k_n,
+                "avg_launch_ms": avg_kernel_s * 1e3, "launches": k_n, "pairs_per_launch_rank0": int(len(pairs)),
                 "algorithmic_flops_per_launch": flops_per_launch,
                 "executed_mfma_flops_per_step": exec_flops, "products_per_f32_product": 1,
                 "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
