@@ -158,7 +158,10 @@ struct Dissector {
 // The dense path stays when the structure saves less than half of its tiles AND less than half of its dependency chain (BA-25, the
 // fountain: every camera sees every other one).  The chain is what the dense factorisation is bound by (one tile column every
 // ~15 us), so halving it pays even where the tile count does not halve (200 cameras of a loop: chain 7 against 19, 108 of 209 tiles).
-bool SparsePlan::worthwhile() const { return nb > 0 && (2 * (long long)tiles.size() <= dense_tiles() || 2 * chain <= dense_nb); }
+bool SparsePlan::worthwhile() const
+{
+    return nb > 0 && (2 * (long long)tiles.size() <= dense_tiles() || (2 * chain <= dense_nb && (long long)tiles.size() <= 2 * dense_tiles()));
+}
 
 SparsePlan make_sparse_plan(const CamGraph &g, int leaf_max)
 {
@@ -168,9 +171,17 @@ SparsePlan make_sparse_plan(const CamGraph &g, int leaf_max)
     P.dense_nb = (6 * g.n + T - 1) / T;
     if (g.n <= 0) return P;
     Dissector D{g, std::max(leaf_max, 1), std::vector<int32_t>((size_t)g.n, 0), 1, {}, {}, std::vector<int32_t>((size_t)g.n, -1)};
-    // connected components of the whole graph first (id 0 = "not yet assigned")
+    // connected components of the whole graph first (id 0 = "not yet assigned").  Components of at most leaf_max cameras -- cameras
+    // without observations, small groups that share nothing with the rest -- are packed TOGETHER into leaves of at most leaf_max
+    // cameras: they do not touch each other, so sharing tiles costs nothing, and a tile of padding per isolated camera is saved.
     {
-        std::vector<int32_t> comp, stack;
+        std::vector<int32_t> comp, stack, small;
+        auto flush_small = [&]() {
+            if (small.empty()) return;
+            D.nodes.push_back(small); D.kinds.push_back(0);
+            for (int v : small) D.comp_of[(size_t)v] = -1;
+            small.clear();
+        };
         for (int s = 0; s < g.n; ++s) {
             if (D.comp_of[(size_t)s] != 0) continue;
             const int nc = D.next_comp++;
@@ -185,9 +196,15 @@ SparsePlan make_sparse_plan(const CamGraph &g, int leaf_max)
                 }
             }
             std::sort(comp.begin(), comp.end());
+            if ((int)comp.size() <= D.leaf_max) {
+                if ((int)(small.size() + comp.size()) > D.leaf_max) flush_small();
+                small.insert(small.end(), comp.begin(), comp.end());
+                continue;
+            }
             const std::vector<int32_t> mine = comp;
             D.dissect(mine, nc);
         }
+        flush_small();
     }
     // columns: supernode by supernode, each padded to whole tiles
     std::vector<int32_t> cam_tile0((size_t)g.n, 0), cam_tile1((size_t)g.n, 0);      // first / last tile holding columns of the camera

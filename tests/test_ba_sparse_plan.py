@@ -113,5 +113,9 @@ def test_dense_covisibility_is_left_to_the_dense_path():
 def test_degenerate_inputs():
     plan = E.reduced_plan(0, 0, np.zeros(0, np.int32), np.zeros(0, np.int32))
     assert plan["nb"] == 0 and not plan["worthwhile"]
-    plan, _ = _check_plan(3, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))   # no observation at all: three isolated cameras
-    assert plan["nb"] == 3 and plan["chain"] == 1
+    plan, _ = _check_plan(3, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))   # no observation at all: three isolated cameras share one leaf
+    assert plan["nb"] == 1 and plan["chain"] == 1 and plan["supernodes"] == 1
+    # a hundred cameras of which only the first forty see anything (a loop): the sixty others are packed into leaves of 32, not a tile each
+    sc = synth.ba_scene(40, 400, 5, seed=9)
+    plan, _ = _check_plan(100, 400, sc.cam_idx, sc.pt_idx, seed=1)
+    assert plan["nb"] <= (6 * 100 + 63) // 64 + plan["supernodes"]
