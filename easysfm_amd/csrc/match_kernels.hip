@@ -2919,7 +2919,7 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(const uint32_t *__r
     float fltmax; int minus2;
     asm volatile("s_mov_b32 %0, 0x7f7fffff" : "=s"(fltmax));
     asm volatile("s_mov_b32 %0, -2" : "=s"(minus2));
-#pragma unroll 1
+#pragma unroll 1                         // (unrolled by 2 / 4 -- the four sets' row loads in flight together -- measured: 0.442 / 0.441 ms against 0.443)
     for (int s = 0; s < NS; ++s) {
         const int qrow = qbase + 32 * s + j;
         const bool qvalid = qrow < nq;
