@@ -187,54 +187,60 @@ public:
         return run(cur_frame_1, cur_frame_2, matches, ratio_thre, false, "SURF");
     }
 
-    // feature_matching.cpp:160-229 (defaults feature_matching.h:26).  appro_depth[i][j] = img_match_graph[i][j].appro_depth.
+    // Which two frames start the reconstruction (the contract of feature_matching.cpp:160-229, defaults feature_matching.h:26): every
+    // track weighs as many frames as see it; a pair (i, j < i) scores the summed weight of the tracks BOTH frames see; pairs whose
+    // depth / baseline ratio exceeds the limit are out; the best score of at least min_track_num_init wins, the LATER pair on ties.
+    // appro_depth[i][j] = img_match_graph[i][j].appro_depth.  Written over per-frame track lists: a frame's weights are laid out once
+    // and every earlier frame sums over its own list -- O(frames x observations) where the reference walks frames^2 x tracks.
     bool findInitializeFramePair(std::vector<std::vector<bool>> &feature_track_matrix, std::vector<frame_t> &frames,
                                  const std::vector<std::vector<double>> &appro_depth, int &initialization_frame_1,
                                  int &initialization_frame_2, double &depth_init, int min_track_num_init = 100,
                                  double max_depth_baseline_ratio_init = 50.0)
     {
-        initialization_frame_1 = 0; initialization_frame_2 = 0;
-        const int frame_number = int(frames.size());
-        const int num_unique_points = int(feature_track_matrix[0].size());
-        std::vector<int> point_track_frame_num(size_t(num_unique_points), 0);
-        for (int i = 0; i < frame_number; ++i) {
-            feature_track_matrix[size_t(i)].resize(size_t(num_unique_points));
-            for (int j = 0; j < num_unique_points; ++j) point_track_frame_num[size_t(j)] += feature_track_matrix[size_t(i)][size_t(j)];
+        const size_t n_frames = frames.size(), n_tracks = feature_track_matrix.empty() ? 0 : feature_track_matrix[0].size();
+        std::vector<int> weight(n_tracks, 0);
+        std::vector<std::vector<int>> seen(n_frames);            // track ids per frame
+        for (size_t f = 0; f < n_frames; ++f) {
+            feature_track_matrix[f].resize(n_tracks);
+            for (size_t t = 0; t < n_tracks; ++t)
+                if (feature_track_matrix[f][t]) { ++weight[t]; seen[f].push_back(int(t)); }
         }
-        int max_sum_track_frame_num = min_track_num_init;
-        double depth_baseline_ratio_init = 0.0;
-        for (int i = 0; i < frame_number; ++i) {
-            for (int j = 0; j < i; ++j) {
-                const double ratio = appro_depth[size_t(i)][size_t(j)];
-                if (ratio > max_depth_baseline_ratio_init) continue;  // baseline too short (:193-194)
-                int sum = 0;
-                for (int k = 0; k < num_unique_points; ++k)
-                    if (feature_track_matrix[size_t(i)][size_t(k)] && feature_track_matrix[size_t(j)][size_t(k)]) sum += point_track_frame_num[size_t(k)];
-                if (sum >= max_sum_track_frame_num) {  // later pair wins ties (:203)
-                    max_sum_track_frame_num = sum; depth_baseline_ratio_init = ratio;
-                    initialization_frame_1 = i; initialization_frame_2 = j;
-                }
+        long long best = min_track_num_init;
+        int first = 0, second = 0;
+        double best_ratio = 0.0;
+        std::vector<int> laid(n_tracks, 0);                        // the weights of the tracks frame i sees, 0 elsewhere
+        for (size_t i = 0; i < n_frames; ++i) {
+            for (int t : seen[i]) laid[size_t(t)] = weight[size_t(t)];
+            for (size_t j = 0; j < i; ++j) {
+                const double ratio = appro_depth[i][j];
+                if (ratio > max_depth_baseline_ratio_init) continue;
+                long long score = 0;
+                for (int t : seen[j]) score += laid[size_t(t)];
+                if (score >= best) { best = score; best_ratio = ratio; first = int(i); second = int(j); }
             }
+            for (int t : seen[i]) laid[size_t(t)] = 0;
         }
-        if (initialization_frame_1 == initialization_frame_2) {
+        if (first == second) {
             if (!quiet) std::cout << "Failed to find proper frame pair for initialization. Use default frame [1] and frame [0]" << std::endl;
             initialization_frame_1 = 1; initialization_frame_2 = 0;
-            return false;  // depth_init untouched, as in the reference (:217-223)
+            return false;                                           // depth_init keeps the caller's value, as in the reference (:217-223)
         }
-        depth_init = depth_baseline_ratio_init;
+        initialization_frame_1 = first; initialization_frame_2 = second;
+        depth_init = best_ratio;
         return true;
     }
 
-    // feature_matching.cpp:231-268
+    // The frame to register next (the contract of feature_matching.cpp:231-268): among the frames still to process the one that sees
+    // most of the tracks that already have a 3-D point; the FIRST such frame on ties; `next_frame` untouched when none sees any.
     bool findNextFrame(std::vector<std::vector<bool>> &feature_track_matrix, std::vector<bool> &frames_to_process,
                        std::vector<int> &unique_3d_point_ids, int &next_frame)
     {
-        int max_common_point_num = 0;
-        for (size_t i = 0; i < frames_to_process.size(); ++i) {
-            if (!frames_to_process[i]) continue;
-            int common = 0;
-            for (int id : unique_3d_point_ids) common += feature_track_matrix[i][size_t(id)] ? 1 : 0;
-            if (common > max_common_point_num) { max_common_point_num = common; next_frame = int(i); }
+        int most = 0;
+        for (size_t f = 0; f < frames_to_process.size(); ++f) {
+            if (!frames_to_process[f]) continue;
+            const std::vector<bool> &row = feature_track_matrix[f];
+            const int shared = int(std::count_if(unique_3d_point_ids.begin(), unique_3d_point_ids.end(), [&](int id) { return bool(row[size_t(id)]); }));
+            if (shared > most) { most = shared; next_frame = int(f); }
         }
         return true;
     }
