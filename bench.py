@@ -978,6 +978,71 @@ def main() -> int:
         except Exception as e:
             out["geometry"] = {"error": repr(e)}
 
+    # ---------------------------------------------------------------- the "next" rows that had no leg yet (f-1: PnP RANSAC, triangulation; f-2: ORB), rank 0 at N = 1
+    if rank == 0 and world == 1 and not args.no_ba:
+        try:
+            gold = os.path.join(ROOT, "tests", "golden", "fountain11_gray.npz")
+            oimg = np.load(gold)["images"][3]
+            xctx = E.Context(local_rank, None)
+            okp, odesc = E.orb_detect_and_compute(oimg, 8000, None, xctx)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                okp, odesc = E.orb_detect_and_compute(oimg, 8000, None, xctx)
+            o_el = (time.perf_counter() - t0) / 10
+            out["orb_detect"] = {"metric": "images/s, ORB detect + describe (768 x 512, 8000 features asked for)", "value": 1.0 / o_el, "unit": "images/s",
+                                 "keypoints": int(len(okp)), "ms_per_image": o_el * 1e3, "includes": "host<->device copies, host selection of the best responses"}
+            if not args.no_cpu_baseline:
+                import oracle
+                t0 = time.perf_counter(); rk_, rd_ = oracle.orb(oimg, 8000); t1 = time.perf_counter() - t0
+                out["orb_detect"]["verified_vs_oracle"] = bool(np.array_equal(okp.view(np.uint32), rk_.view(np.uint32)) and np.array_equal(odesc, rd_))
+                out["orb_detect"]["cpu_baseline"] = {"value": 1.0 / t1, "unit": "images/s", "cores": 1, "kind": "port", "sample": f"the same image in {t1:.2f}s (sequential restatement, one core)"}
+        except Exception as e:
+            out["orb_detect"] = {"error": repr(e)}
+        try:
+            rng = np.random.default_rng(4500)
+            K4p = np.array(synth.FOUNTAIN_K4, np.float32)
+            n3 = 2000
+            Rt = synth.aa_to_R(rng.normal(0, 0.2, 3)); tt_ = np.array([0.3, -0.1, 0.5])
+            X3 = (rng.uniform(-2, 2, (n3, 3)) + np.array([0, 0, 8.0])).astype(np.float32)
+            Xc = X3.astype(np.float64) @ Rt.T + tt_
+            pix = np.stack([Xc[:, 0] / Xc[:, 2] * K4p[0] + K4p[1], Xc[:, 1] / Xc[:, 2] * K4p[2] + K4p[3]], 1) + rng.normal(0, 0.5, (n3, 2))
+            bad = rng.choice(n3, n3 // 4, replace=False); pix[bad] += rng.uniform(-80, 80, (len(bad), 2))
+            pix = pix.astype(np.float32)
+            pctx = E.Context(local_rank, None)
+            E.solve_pnp_ransac(X3, pix, K4p, 100, 8.0, 0.99, pctx)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                rv_, tv_, R_, m_, it_p = E.solve_pnp_ransac(X3, pix, K4p, 100, 8.0, 0.99, pctx)
+            p_el = (time.perf_counter() - t0) / 10
+            out["pnp"] = {"metric": "frames registered/s (solvePnPRansac EPnP, 2000 2-D/3-D pairs, 25 % outliers)", "value": 1.0 / p_el, "unit": "frames/s",
+                          "ms_per_frame": p_el * 1e3, "ransac_iterations": int(it_p), "inliers": int(m_.sum()), "includes": "host<->device copies, host replay of OpenCV's RNG"}
+            if not args.no_cpu_baseline:
+                import oracle
+                t0 = time.perf_counter(); ok_, rR, rt_, rrv, rm, rit = oracle.solve_pnp_ransac(X3, pix, K4p, 100, 8.0, 0.99); t1 = time.perf_counter() - t0
+                out["pnp"]["verified_vs_oracle"] = bool(ok_ and rit == it_p and np.array_equal(rm, m_) and np.allclose(rR, R_, atol=1e-9) and np.allclose(rt_, tv_, atol=1e-9))
+                out["pnp"]["cpu_baseline"] = {"value": 1.0 / t1, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"the same problem in {t1 * 1e3:.1f} ms (sequential restatement, one core)"}
+            # two-view triangulation of the inliers (cv::triangulatePoints: DLT per point)
+            P1 = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32); P2 = np.hstack([Rt, tt_[:, None]]).astype(np.float32)
+            n_t = 200000
+            Xt = rng.uniform(-2, 2, (n_t, 3)) + np.array([0, 0, 8.0]); Xt2 = Xt @ Rt.T + tt_
+            a_ = (Xt[:, :2] / Xt[:, 2:3]).astype(np.float32); b_ = (Xt2[:, :2] / Xt2[:, 2:3]).astype(np.float32)
+            E.triangulate_points(P1, P2, a_, b_, pctx)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                X4 = E.triangulate_points(P1, P2, a_, b_, pctx)
+            t_el = (time.perf_counter() - t0) / 10
+            out["triangulate"] = {"metric": "points triangulated/s (cv::triangulatePoints, two views)", "value": n_t / t_el, "unit": "points/s", "points": n_t,
+                                  "ms_per_call": t_el * 1e3, "includes": "host<->device copies (PCIe-bound: 16 B in, 16 B out per point)"}
+            if not args.no_cpu_baseline:
+                import oracle
+                t0 = time.perf_counter(); rX4 = oracle.triangulate_points(P1, P2, a_, b_); t1 = time.perf_counter() - t0
+                # (the SVD's sign is arbitrary and its float iteration differs in the last bits: the tolerance of tests/test_geometry_gpu.py)
+                out["triangulate"]["verified_vs_oracle"] = bool(np.allclose(X4 * np.sign(X4[:, 3:4]), rX4 * np.sign(rX4[:, 3:4]), rtol=0, atol=2e-6))
+                out["triangulate"]["cpu_baseline"] = {"value": n_t / t1, "unit": "points/s", "cores": 1, "kind": "port", "sample": f"the same {n_t} points in {t1:.2f}s (sequential restatement, one core)"}
+        except Exception as e:
+            out.setdefault("pnp", {"error": repr(e)})
+            out.setdefault("triangulate", {"error": repr(e)})
+
     # ---------------------------------------------------------------- BASELINE configs 1 and 3 end to end (rank 0 at N = 1)
     if rank == 0 and world == 1 and not args.no_ba and not args.no_e2e:
         for tag, feat, par in (("config1", "S", 300), ("config3", "O", 8000)):
