@@ -375,18 +375,72 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
     const bool single = single_launch;
     double keepJ[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, keepR0 = 0.0, keepR1 = 0.0;
     int keepC = -1;
-    for (int k = blockIdx.x * kLinThreads + tid; k < n_obs; k += gridDim.x * kLinThreads) {
-        const int c = d.obs_cam[k], p = d.obs_pt[k];
-        const float2 uv = d.obs_uv[k];
+    // The loop is software-pipelined by hand.  A wave's loads and stores retire through ONE counter (vmcnt) in issue order: with
+    // the next observation's index loads and parameter gathers issued AFTER this observation's 20 stores, "wait for the loads" meant
+    // "wait until the stores have drained" -- two dependent round trips behind a write burst per iteration, 15 us of a 20-us iteration
+    // idle at the two waves per SIMD the LDS sums leave room for.  Now the indices of observation k + 2 strides and the parameters of
+    // k + stride are requested in front of the ARITHMETIC of k: they are ahead of its stores in the queue, their latency runs beside
+    // 1 200 instructions, and the wait in front of the next iteration leaves the stores in flight.
+    // (Unconditional loads at clamped indices: a load under `if (k + stride < n_obs)` merges with the old value, and the merge is a
+    // register copy that has to wait for the load -- in front of the stores.  The camera's float calibration is converted where it
+    // is used, for the same reason.)
+    struct LinIdx { int c, p; float2 uv; };
+    struct LinPar { float4 K; double kd[4], cam[6], X[3], sc[6], sp[3]; };
+    auto load_idx = [&](int k, LinIdx &o) { o.c = d.obs_cam[k]; o.p = d.obs_pt[k]; o.uv = d.obs_uv[k]; };
+    auto load_par = [&](const LinIdx &ix, LinPar &o) {
+        if (CALIB) {         // (== d.has_calib: the free block rides behind the real cameras, load_intrinsics)
+            const double *kp = d.x_c + 6 * (size_t)d.n_real_cam;
+            o.kd[0] = kp[0]; o.kd[1] = kp[1]; o.kd[2] = kp[2]; o.kd[3] = kp[3];
+        } else {
+            o.K = d.K4[ix.c];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o.cam[i] = d.x_c[6 * (size_t)ix.c + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.X[i] = d.x_p[3 * (size_t)ix.p + i];
+        if (use_scaling) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o.sc[i] = d.scale_c[6 * (size_t)ix.c + i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o.sp[i] = d.scale_p[3 * (size_t)ix.p + i];
+        }
+    };
+    double kscale[4] = {1.0, 1.0, 1.0, 1.0};      // the free intrinsics' column scales: the same for every observation, read once
+    if (CALIB && use_scaling) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kscale[i] = d.scale_c[6 * (size_t)d.n_real_cam + i];
+    }
+    const int kstride = gridDim.x * kLinThreads;
+    const int k_first = blockIdx.x * kLinThreads + tid;
+    auto clamped = [&](long long k) { return (int)(k < n_obs ? k : n_obs - 1); };
+    LinIdx ix_cur = {0, 0, make_float2(0.f, 0.f)}, ix_nxt = ix_cur;
+    LinPar par_cur = {};
+    if (n_obs > 0) {
+        load_idx(clamped(k_first), ix_cur); load_par(ix_cur, par_cur);
+        load_idx(clamped((long long)k_first + kstride), ix_nxt);
+        // (vmcnt(0) here, once: the compiler's wait-count bookkeeping merges the loop's two entries, and with these loads pending on
+        // the way in it would wait for "all but two" memory operations in EVERY iteration -- the stores again)
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    for (int k = k_first; k < n_obs; k += kstride) {
+        // the next observation's parameters and the indices of the one after: requested in front of this observation's arithmetic
+        // (and so ahead of its stores in the queue)
+        // (with free intrinsics the kernel has no registers left for that: there the requests go out after the arithmetic, in front
+        // of the stores)
+        LinPar par_nxt;
+        LinIdx ix_nn;
+        if (!CALIB) {
+            load_par(ix_nxt, par_nxt);
+            load_idx(clamped((long long)k + 2 * (long long)kstride), ix_nn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int c = ix_cur.c;
+        const float2 uv = ix_cur.uv;
         double in4[4];
-        load_intrinsics(d, d.x_c, c, in4);
-        double cam[6], X[3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cam[i] = d.x_c[6 * (size_t)c + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) X[i] = d.x_p[3 * (size_t)p + i];
+        if (CALIB) { in4[0] = par_cur.kd[0]; in4[1] = par_cur.kd[1]; in4[2] = par_cur.kd[2]; in4[3] = par_cur.kd[3]; }
+        else { in4[0] = (double)par_cur.K.x; in4[1] = (double)par_cur.K.y; in4[2] = (double)par_cur.K.z; in4[3] = (double)par_cur.K.w; }
         double r0, r1, Jc[12], Jp[6], xn, yn;
-        reproject_jac(cam, X, in4, uv, r0, r1, Jc, Jp, xn, yn);
+        reproject_jac(par_cur.cam, par_cur.X, in4, uv, r0, r1, Jc, Jp, xn, yn);
         // intrinsics columns (ba.h:199-206): u = x fx + cx, v = y fy + cy
         double Jk[4] = {-xn, -1.0, -yn, -1.0};
         const double s = r0 * r0 + r1 * r1;
@@ -412,17 +466,17 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
             r0 *= sq; r1 *= sq;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const double sc = use_scaling ? sq * d.scale_c[6 * (size_t)c + i] : sq;
+                const double sc = use_scaling ? sq * par_cur.sc[i] : sq;
                 Jc[i] *= sc; Jc[6 + i] *= sc;
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const double sp = use_scaling ? sq * d.scale_p[3 * (size_t)p + i] : sq;
+                const double sp = use_scaling ? sq * par_cur.sp[i] : sq;
                 Jp[i] *= sp; Jp[3 + i] *= sp;
             }
             if (CALIB) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Jk[i] *= use_scaling ? sq * d.scale_c[6 * (size_t)d.n_real_cam + i] : sq;
+                for (int i = 0; i < 4; ++i) Jk[i] *= sq * kscale[i];
             }
         }
         if (CALIB) {
@@ -435,23 +489,42 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
                 kacc[6] += Jk[0] * r0; kacc[7] += Jk[1] * r0; kacc[8] += Jk[2] * r1; kacc[9] += Jk[3] * r1;
             }
         }
+        if (CALIB) {
+            load_par(ix_nxt, par_nxt);
+            load_idx(clamped((long long)k + 2 * (long long)kstride), ix_nn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if defined(ESFM_EXP_LIN) && (ESFM_EXP_LIN & 4)
+        if (cauchy_a == -12345.0)
+#endif
+        {
 #pragma unroll
         for (int i = 0; i < 12; ++i) d.Jc[(size_t)i * n_obs + k] = Jc[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.Jp[(size_t)i * n_obs + k] = Jp[i];
         d.res[k] = r0; d.res[(size_t)n_obs + k] = r1;
+        }
         if (PRIV) {
+#if defined(ESFM_EXP_LIN) && (ESFM_EXP_LIN & 2)
+            if (cauchy_a == -12345.0)
+#endif
+            {
             atomicAdd(&cnt[c], 1);
 #pragma unroll
             for (int a = 0; a < 6; ++a) atomicMax(&mx[c * 7 + a], (unsigned long long)__double_as_longlong(Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]));
             atomicMax(&mx[c * 7 + 6], (unsigned long long)__double_as_longlong(r0 * r0 + r1 * r1));
+            }
             if (single) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) keepJ[i] = Jc[i];
                 keepR0 = r0; keepR1 = r1; keepC = c;
             }
+#if defined(ESFM_EXP_LIN) && (ESFM_EXP_LIN & 1)
+            if (cauchy_a == -12345.0)
+#endif
             if (prov && !CALIB) add_rows(c, Jc, r0, r1);
         }
+        ix_cur = ix_nxt; ix_nxt = ix_nn; par_cur = par_nxt;
     }
     {
         const int slots[2] = {SC_COST, SC_LIN_BAD};
