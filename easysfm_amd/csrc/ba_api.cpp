@@ -355,7 +355,14 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
                     mchunk_cam0[tb].push_back(lo[(size_t)p]); cw = lo[(size_t)p]; in_chunk = 0;
                 }
                 if (new_chunk || in_batch + t > 64 || pts_batch >= 16) { mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size()); in_batch = 0; pts_batch = 0; }
+                // a point's observations in ascending camera-slot order (the kernel finds "the observation with slot s" by counting
+                // the lower bits of the point's slot mask); in the seam's table that is the ROTATED index
+                const size_t at = mslot_obs[tb].size();
                 for (int k = pt_start[(size_t)p]; k < pt_start[(size_t)p + 1]; ++k) mslot_obs[tb].push_back(k);
+                std::sort(mslot_obs[tb].begin() + (std::ptrdiff_t)at, mslot_obs[tb].end(), [&](int32_t a, int32_t b) {
+                    const int ca = tb ? rotated(s_cam[(size_t)a]) : s_cam[(size_t)a], cb = tb ? rotated(s_cam[(size_t)b]) : s_cam[(size_t)b];
+                    return ca < cb;
+                });
                 in_batch += t; ++pts_batch; in_chunk += t;
             }
             mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size());

@@ -1219,35 +1219,85 @@ __global__ __launch_bounds__(1024) void ba_schur_window_kernel(BADev d, int rhs_
 // batch's loads one batch ahead changed nothing (345 against 341 us, 47 spilled registers) and neither did a scene whose points are
 // numbered by lowest camera, i.e. contiguous reads (465 against 487 us on a slower box: the kernel also varies 340 - 490 us box to box).
 constexpr int kMfRows = 80, kMfBR = 5, kMfYPitch = 37, kMfMaxPts = 16;
-constexpr int kMfWaveDoubles = 64 * kMfYPitch + kMfMaxPts * 16 / 2;     // Y | W table (36 doubles per observation, pitch 37) + slot -> lane table (ints)
-constexpr size_t kMfLdsBytes = sizeof(double) * (4 * kMfWaveDoubles + 6 * kSchurMfCams);
+constexpr int kMfWaveDoubles = 65 * kMfYPitch + kMfMaxPts;     // Y | W table (36 doubles per observation, pitch 37; row 64 = zeros) + per-point slot masks and first lanes (ints)
+constexpr size_t kMfLdsBytes = sizeof(double) * (4 * kMfWaveDoubles + 6 * kSchurMfCams + kMfRows / 2);     // ... + right-hand side (u64) + the window's exponents (ints)
 static_assert(4 * kMfWaveDoubles >= kMfRows * (kMfRows + 1), "the staging area is reused for the 80 x 81 result");
+static_assert(kSchurMfCams <= 16 && 6 * kSchurMfCams <= kMfRows, "slot masks are 16 bits; the window's rows fit the tile grid");
 
 #ifndef ESFM_SCHUR_OCC
 #define ESFM_SCHUR_OCC 2
 #endif
-__global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADev d, int rhs_exp, const int32_t *__restrict__ slot_obs, const int2 *__restrict__ slot_pc,
-                                                               const int32_t *__restrict__ batch_slot, const int32_t *__restrict__ chunk_batch0,
-                                                               const int32_t *__restrict__ chunk_cam0, int rot)
+#ifdef ESFM_SCHUR_TRACE
+// timing-only build (scratch/build_variant_ba.sh NAME -DESFM_SCHUR_TRACE): s_memrealtime ticks (10 ns) per stage, summed over the waves:
+// [0] waiting for a batch's rows, [1] W / Y into LDS, [2] matrix products, [3] batches, [4] the workgroup's sum + flush, [5] workgroups
+__device__ unsigned long long g_schur_trace[8];
+extern "C" int esfm_debug_schur_trace(unsigned long long *out, int reset)
 {
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_schur_trace), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_schur_trace), sizeof(g_schur_trace));
+}
+#define SCH_T0() unsigned long long sch_t = __builtin_amdgcn_s_memrealtime()
+#define SCH_T(q) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); sch_acc[q] += t_ - sch_t; sch_t = t_; } while (0)
+#else
+#define SCH_T0() do { } while (0)
+#define SCH_T(q) do { } while (0)
+#endif
+// Both tables in ONE launch (round 5): workgroups [0, n_plain) take the plain numbering's chunks, the rest the seam's (camera indices
+// rotated by `rot_seam`).  The seam's table is 2 % of BA-512's observations in ~100 short chunks whose fixed costs -- zeroing 120
+// accumulator registers, the 80 x 81 sum through LDS, 3 240 fixed-point atomics -- made a launch of their own last 47 us; behind the
+// plain chunks they fill the launch's tail.
+struct SchurMfTables {
+    const int32_t *slot_obs[2]; const int2 *slot_pc[2]; const int32_t *batch_slot[2]; const int32_t *chunk_batch0[2]; const int32_t *chunk_cam0[2];
+    int n_plain, rot_seam;
+};
+__global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADev d, int rhs_exp, SchurMfTables tabs)
+{
+    const int tb = (int)blockIdx.x >= tabs.n_plain ? 1 : 0;
+    const int32_t *__restrict__ slot_obs = tabs.slot_obs[tb];
+    const int2 *__restrict__ slot_pc = tabs.slot_pc[tb];
+    const int32_t *__restrict__ batch_slot = tabs.batch_slot[tb];
+    const int32_t *__restrict__ chunk_batch0 = tabs.chunk_batch0[tb];
+    const int32_t *__restrict__ chunk_cam0 = tabs.chunk_cam0[tb];
+    const int rot = tb ? tabs.rot_seam : 0;
     typedef double doublex4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double sl[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *Yw = sl + (size_t)wave * kMfWaveDoubles;                               // [64][kMfYPitch]
-    int *s2o = reinterpret_cast<int *>(Yw + 64 * kMfYPitch);                       // [kMfMaxPts][16]: camera slot -> lane of the point's observation
+    double *Yw = sl + (size_t)wave * kMfWaveDoubles;                               // [65][kMfYPitch]; row 64 stays zero
+    unsigned int *pmask = reinterpret_cast<unsigned int *>(Yw + 65 * kMfYPitch);   // [kMfMaxPts] camera slots the point is seen from (bit = slot)
+    int *pfirst = reinterpret_cast<int *>(pmask) + kMfMaxPts;                      // [kMfMaxPts] lane of the point's first observation
     unsigned long long *srhs = reinterpret_cast<unsigned long long *>(sl + 4 * (size_t)kMfWaveDoubles);   // [6 * kSchurMfCams]
+    int *s_qe = reinterpret_cast<int *>(srhs + 6 * kSchurMfCams);                  // [kMfRows] fixed-point exponents of the window's rows
     const int n = 6 * d.n_cam, nrc = d.n_real_cam;
     const size_t n_obs = d.n_obs;
-    const int chunk = blockIdx.x;
+    const int chunk = (int)blockIdx.x - (tb ? tabs.n_plain : 0);
     const int cw = chunk_cam0[chunk];
     const int b0 = chunk_batch0[chunk], b1 = chunk_batch0[chunk + 1];
     auto rotated = [&](int c) { const int r = c + rot; return r >= nrc ? r - nrc : r; };
+    auto true_cam = [&](int w) { int c = cw + w - rot; if (c < 0) c += nrc; return c; };
     for (int e = tid; e < 6 * kSchurMfCams; e += 256) srhs[e] = 0ull;
+    // the exponents the flush converts with: fetched now, read from LDS after the batches (round 5: the flush's 25 entries per thread
+    // each waited for two dependent global loads -- 58 us per workgroup, a fifth of the launch)
+    if (tid < kMfRows) { const int c = true_cam(tid / 6); s_qe[tid] = (tid < 6 * kSchurMfCams && c < nrc) ? d.qexp[6 * c + tid % 6] : 0; }
+    if (lane < kMfYPitch) Yw[64 * kMfYPitch + lane] = 0.0;
     __syncthreads();
     doublex4 acc[kMfBR * (kMfBR + 1) / 2];
 #pragma unroll
     for (int t = 0; t < kMfBR * (kMfBR + 1) / 2; ++t) acc[t] = doublex4{0.0, 0.0, 0.0, 0.0};
     const int r16 = lane & 15, m4 = lane >> 4;          // this lane's row inside a block row, and its K index (point column; 3 = zero)
+    // What a lane gathers for block row R does not depend on the point: camera slot sc = row / 6 and entry 3 a + k of the observation's
+    // 36-double record.  WHICH observation is the point's business: a point's observations sit in consecutive lanes in ascending slot
+    // order (the host builds the tables that way), so the one with slot sc is lane  first + popcount(mask & ((1 << sc) - 1))  if bit
+    // sc of the point's slot mask is set, and the zero row otherwise -- two wave-uniform words per point (v_readlane) instead of a
+    // slot -> lane table in LDS whose lookup stood in front of every fragment read (round 5: 0.84 us per point for 15 matrix
+    // instructions; the products were 5.4 of a batch's 10 us).
+    int fr_sc[kMfBR], fr_off[kMfBR]; unsigned int fr_low[kMfBR];
+#pragma unroll
+    for (int R = 0; R < kMfBR; ++R) {
+        const int row = 16 * R + r16, sc = row / 6, a = row - 6 * sc;
+        fr_sc[R] = (sc < kSchurMfCams && m4 < 3) ? sc : 31;          // bit 31 of a slot mask is never set
+        fr_off[R] = 3 * a + (m4 < 3 ? m4 : 0);
+        fr_low[R] = (1u << (sc < kSchurMfCams ? sc : 0)) - 1u;
+    }
     // A lane's observation, point and camera come from slot-ordered tables (contiguous, one load level) and are fetched one batch
     // AHEAD: the Jacobian rows / point block / exponents they address can then be requested the moment a batch starts -- one
     // round trip to memory per batch where the chain  slot -> observation -> point, camera -> rows  made three (8 us per batch).
@@ -1259,29 +1309,61 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
         const int sl_ = s0 + (lane < nx_nob ? lane : 0);
         nx_i = slot_obs[sl_]; nx_pc = slot_pc[sl_];
     };
+    // ... and the ROWS of a batch are requested while the batch before it is in its matrix products (round 5; they land in the same
+    // registers the products do not need: nothing is held twice).  Before that a wave waited 2.9 us per batch for them -- a third
+    // of a batch's time, at the two waves per SIMD the accumulators leave room for.
+    double Jc[12], Jp[6], Mi[6], ag[3];
+    int qe[6];
+    auto fetch_rows = [&]() {           // of the batch whose ids fetch_ids left in nx_*
+        const int i = nx_i, p = nx_pc.x, ci = nx_pc.y;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) Jc[q] = d.Jc[q * n_obs + i];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jp[q] = d.Jp[q * n_obs + i];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Mi[q] = d.Minv[6 * (size_t)p + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ag[q] = d.Aig[3 * (size_t)p + q];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) qe[a] = d.qexp[6 * ci + a];
+    };
     fetch_ids(b0 + wave);
+    fetch_rows();
+#ifdef ESFM_SCHUR_TRACE
+    unsigned long long sch_acc[5] = {0, 0, 0, 0, 0};
+#endif
+    SCH_T0();
     for (int b = b0 + wave; b < b1; b += 4) {
         const int nob = nx_nob;
         const bool valid = lane < nob;
-        const int i = nx_i, p = nx_pc.x, ci = nx_pc.y;
+        const int p = nx_pc.x, ci = nx_pc.y;
         fetch_ids(b + 4);
         const int slot = rotated(ci) - cw;                                          // 0 .. kSchurMfCams - 1 by construction
         // local index of the lane's point inside the batch (the batch is whole points, in order)
         const int pprev = __shfl_up(p, 1);
-        const unsigned long long starts = __ballot(valid && (lane == 0 || pprev != p));
+        const bool first = valid && (lane == 0 || pprev != p);
+        const unsigned long long starts = __ballot(first);
         const int q = __popcll(starts & ((2ull << lane) - 1ull)) - 1;
         const int npts = __popcll(starts);
-        for (int e = lane; e < kMfMaxPts * 16; e += 64) s2o[e] = -1;
-        double W[18];
-        load_W(d, n_obs, i, W);
-        const double *Mi = d.Minv + 6 * (size_t)p;
+        double W[18];                   // W_i = F_i'E_i (load_W's arithmetic)
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) W[3 * a + m] = Jc[a] * Jp[m] + Jc[6 + a] * Jp[3 + m];
         const double M[9] = {Mi[0], Mi[1], Mi[2], Mi[1], Mi[3], Mi[4], Mi[2], Mi[4], Mi[5]};
-        const double ag0 = d.Aig[3 * (size_t)p], ag1 = d.Aig[3 * (size_t)p + 1], ag2 = d.Aig[3 * (size_t)p + 2];
+        const double ag0 = ag[0], ag1 = ag[1], ag2 = ag[2];
+        if (lane < kMfMaxPts) pmask[lane] = 0u;
+#ifdef ESFM_SCHUR_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        SCH_T(0);
+#endif
         if (valid) {
+            atomicOr(&pmask[q], 1u << slot);
+            if (first) pfirst[q] = lane;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 const double w0 = W[3 * a], w1 = W[3 * a + 1], w2 = W[3 * a + 2];
-                const int ei = kFxBits - d.qexp[6 * ci + a];
+                const int ei = kFxBits - qe[a];
                 atomicAdd(&srhs[6 * slot + a], fx64(-(w0 * ag0 + w1 * ag1 + w2 * ag2), ei - rhs_exp));
                 double *y = Yw + lane * kMfYPitch + 3 * a;
                 y[0] = w0 * M[0] + w1 * M[3] + w2 * M[6];
@@ -1289,7 +1371,6 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
                 y[2] = w0 * M[2] + w1 * M[5] + w2 * M[8];
                 y[18] = w0; y[19] = w1; y[20] = w2;
             }
-            s2o[q * 16 + slot] = lane;
         }
         // block rows the batch touches (wave-uniform)
         int smin = valid ? slot : kSchurMfCams, smax = valid ? slot : 0;
@@ -1302,16 +1383,32 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int pq = 0; pq < npts; ++pq) {
-            double fa[kMfBR], fb[kMfBR];
+        const unsigned int my_mask = pmask[lane & (kMfMaxPts - 1)];
+        const int my_first = pfirst[lane & (kMfMaxPts - 1)];
+        fetch_rows();                   // the next batch's (its ids were requested at the top; clamped to lane 0's slot past the end)
+#ifdef ESFM_SCHUR_TRACE
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        SCH_T(1);
+#endif
+        // the fragments of point pq (A: rows of Y, B: rows of W).  No branch: a slot the point does not have -- any slot of a block
+        // row the batch does not touch is one -- reads the zero row.
+        auto gather = [&](int pq, double (&fa)[kMfBR], double (&fb)[kMfBR]) {
+            const unsigned int pm = (unsigned int)__builtin_amdgcn_readlane((int)my_mask, pq);
+            const int pf = __builtin_amdgcn_readlane(my_first, pq);
 #pragma unroll
             for (int R = 0; R < kMfBR; ++R) {
-                const int row = 16 * R + r16, sc = row / 6, a = row - 6 * sc;
-                const int o = (sc < kSchurMfCams && m4 < 3 && R >= R0 && R <= R1) ? s2o[pq * 16 + sc] : -1;
-                const double *y = Yw + (o >= 0 ? o : 0) * kMfYPitch + 3 * a + (m4 < 3 ? m4 : 0);
-                fa[R] = o >= 0 ? y[0] : 0.0;
-                fb[R] = o >= 0 ? y[18] : 0.0;
+                const int have = (int)((pm >> fr_sc[R]) & 1u);
+                const int o = 64 + have * (pf + (int)__popc(pm & fr_low[R]) - 64);
+                const double *y = Yw + o * kMfYPitch + fr_off[R];
+                fa[R] = y[0]; fb[R] = y[18];
             }
+        };
+        // the tiles of the lower block triangle the batch can touch.  (The matrix pipe is what this loop waits for: a 16 x 16 x 4 f64
+        // product occupies it for 64 cycles on this part -- its f64 matrix rate equals its f64 vector rate -- and a point of ten
+        // cameras needs 10 - 15 of them: 2.6 us per batch of 6.4 points, with two waves per SIMD 5.4 us per batch and wave measured.
+        // A second set of fragment registers to fetch the next point's rows under this point's products spilled at two waves per
+        // SIMD and lost at one: measured, not kept.)
+        auto products = [&](const double (&fa)[kMfBR], const double (&fb)[kMfBR]) {
 #pragma unroll
             for (int R = 0; R < kMfBR; ++R) {
                 if (R < R0 || R > R1) continue;
@@ -1321,10 +1418,18 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
                     acc[R * (R + 1) / 2 + C] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[R], fb[C], acc[R * (R + 1) / 2 + C], 0, 0, 0);
                 }
             }
+        };
+        for (int pq = 0; pq < npts; ++pq) {
+            double fa[kMfBR], fb[kMfBR];
+            gather(pq, fa, fb);
+            products(fa, fb);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the table has been read before the next batch overwrites it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (... and the compiler may not sink this batch's reads below the next one's stores)
         __builtin_amdgcn_wave_barrier();
+#ifdef ESFM_SCHUR_TRACE
+        SCH_T(2); sch_acc[3] += 1;
+#endif
     }
     // the chunk's G: the waves' tiles added in wave order (fixed), lower block triangle, in the staging area
     __syncthreads();
@@ -1344,7 +1449,6 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
     }
     // S -= G on the entry's fixed-point grid.  Window order (row >= col) is not camera order once the indices are rotated: the stored
     // triangle wants row camera >= column camera in TRUE indices, a diagonal camera block in full.
-    auto true_cam = [&](int w) { int c = cw + w - rot; if (c < 0) c += nrc; return c; };
     unsigned long long *redq = reinterpret_cast<unsigned long long *>(d.red);
     for (int e = tid; e < kMfRows * kMfRows; e += 256) {
         const int row = e / kMfRows, col = e - row * kMfRows;
@@ -1356,7 +1460,7 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
         const int ci = true_cam(si), cj = true_cam(sj);
         if (ci >= nrc || cj >= nrc) continue;
         const int ri = 6 * ci + a, rj = 6 * cj + b2;
-        const unsigned long long qv = fx64(-v, kFxBits - d.qexp[ri] - d.qexp[rj]);
+        const unsigned long long qv = fx64(-v, kFxBits - s_qe[row] - s_qe[col]);
         if (ci > cj) atomicAdd(&redq[(size_t)ri * n + rj], qv);
         else if (ci < cj) atomicAdd(&redq[(size_t)rj * n + ri], qv);
         else { atomicAdd(&redq[(size_t)ri * n + rj], qv); if (a != b2) atomicAdd(&redq[(size_t)rj * n + ri], qv); }
@@ -1367,6 +1471,13 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
         const int c = true_cam(e / 6);
         if (c < nrc) atomicAdd(&redq[(size_t)n * n + 6 * c + e % 6], v);
     }
+#ifdef ESFM_SCHUR_TRACE
+    SCH_T(4);
+    if (lane == 0) {
+        for (int q = 0; q < 5; ++q) atomicAdd(&g_schur_trace[q], sch_acc[q]);
+        if (wave == 0) atomicAdd(&g_schur_trace[5], 1ull);
+    }
+#endif
 }
 
 // Free intrinsics: the block row of the reduced system that belongs to fx, cx, fy, cy (block index n_real_cam).
@@ -2220,12 +2331,15 @@ int ba_schur(hipStream_t st, const BADev &d, int num_cu, double *slabs, size_t s
     const bool tables = d.n_mchunks[0] + d.n_mchunks[1] + d.n_chunks + d.n_chunks_b + d.n_wide_obs > 0;
     if (tables) {
         // narrow tracks (nearly all of them in a sequence capture): the matrix-core kernel, plain and rotated camera numbering
-        for (int tb = 0; tb < 2; ++tb) {
-            if (d.n_mchunks[tb] <= 0) continue;
+        if (d.n_mchunks[0] + d.n_mchunks[1] > 0) {
+            SchurMfTables tabs;
+            for (int tb = 0; tb < 2; ++tb) {
+                tabs.slot_obs[tb] = d.mslot_obs[tb]; tabs.slot_pc[tb] = reinterpret_cast<const int2 *>(d.mslot_pc[tb]); tabs.batch_slot[tb] = d.mbatch_slot[tb];
+                tabs.chunk_batch0[tb] = d.mchunk_batch0[tb]; tabs.chunk_cam0[tb] = d.mchunk_cam0[tb];
+            }
+            tabs.n_plain = d.n_mchunks[0]; tabs.rot_seam = d.n_real_cam / 2;
             ESFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ba_schur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMfLdsBytes));
-            hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(d.n_mchunks[tb]), dim3(256), kMfLdsBytes, st, d, rhs_exp, d.mslot_obs[tb],
-                               reinterpret_cast<const int2 *>(d.mslot_pc[tb]), d.mbatch_slot[tb],
-                               d.mchunk_batch0[tb], d.mchunk_cam0[tb], tb ? d.n_real_cam / 2 : 0);
+            hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(d.n_mchunks[0] + d.n_mchunks[1]), dim3(256), kMfLdsBytes, st, d, rhs_exp, tabs);
             LAUNCH_CHECK();
         }
         constexpr size_t win_bytes = sizeof(double) * (kWinBlocks * kSchurPitch + 6 * kWinCams);
