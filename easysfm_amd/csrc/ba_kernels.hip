@@ -1284,18 +1284,17 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
 #pragma unroll
     for (int t = 0; t < kMfBR * (kMfBR + 1) / 2; ++t) acc[t] = doublex4{0.0, 0.0, 0.0, 0.0};
     const int r16 = lane & 15, m4 = lane >> 4;          // this lane's row inside a block row, and its K index (point column; 3 = zero)
-    // What a lane gathers for block row R does not depend on the point: camera slot sc = row / 6 and entry 3 a + k of the observation's
-    // 36-double record.  WHICH observation is the point's business: a point's observations sit in consecutive lanes in ascending slot
-    // order (the host builds the tables that way), so the one with slot sc is lane  first + popcount(mask & ((1 << sc) - 1))  if bit
-    // sc of the point's slot mask is set, and the zero row otherwise -- two wave-uniform words per point (v_readlane) instead of a
-    // slot -> lane table in LDS whose lookup stood in front of every fragment read (round 5: 0.84 us per point for 15 matrix
-    // instructions; the products were 5.4 of a batch's 10 us).
+    // What a lane gathers for block row R does not depend on the point: camera slot sc = row / 6 and entry 3 a + column of the
+    // observation's 36-double record.  WHICH observation is the point's business: a point's observations sit in consecutive lanes in
+    // ascending slot order (the host builds the tables that way), so the one with slot sc is lane  first + popcount(mask & ((1 << sc) - 1))
+    // if bit sc of the point's slot mask is set, and the zero row otherwise -- two words per point instead of a slot -> lane table
+    // whose 80 entries per point had to be cleared, written and looked up (round 5).
     int fr_sc[kMfBR], fr_off[kMfBR]; unsigned int fr_low[kMfBR];
 #pragma unroll
     for (int R = 0; R < kMfBR; ++R) {
         const int row = 16 * R + r16, sc = row / 6, a = row - 6 * sc;
-        fr_sc[R] = (sc < kSchurMfCams && m4 < 3) ? sc : 31;          // bit 31 of a slot mask is never set
-        fr_off[R] = 3 * a + (m4 < 3 ? m4 : 0);
+        fr_sc[R] = sc < kSchurMfCams ? sc : 31;                      // bit 31 of a slot mask is never set
+        fr_off[R] = 3 * a;
         fr_low[R] = (1u << (sc < kSchurMfCams ? sc : 0)) - 1u;
     }
     // A lane's observation, point and camera come from slot-ordered tables (contiguous, one load level) and are fetched one batch
@@ -1383,32 +1382,36 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned int my_mask = pmask[lane & (kMfMaxPts - 1)];
-        const int my_first = pfirst[lane & (kMfMaxPts - 1)];
         fetch_rows();                   // the next batch's (its ids were requested at the top; clamped to lane 0's slot past the end)
 #ifdef ESFM_SCHUR_TRACE
         __builtin_amdgcn_s_waitcnt(0xc07f);
         SCH_T(1);
 #endif
-        // the fragments of point pq (A: rows of Y, B: rows of W).  No branch: a slot the point does not have -- any slot of a block
-        // row the batch does not touch is one -- reads the zero row.
-        auto gather = [&](int pq, double (&fa)[kMfBR], double (&fb)[kMfBR]) {
-            const unsigned int pm = (unsigned int)__builtin_amdgcn_readlane((int)my_mask, pq);
-            const int pf = __builtin_amdgcn_readlane(my_first, pq);
+        // The K = 4 slices of one matrix instruction are four consecutive (point, column) pairs of the batch -- slice 4 t + k is column
+        // (4 t + k) % 3 of point (4 t + k) / 3 -- not "three columns of one point and a zero": 3/4 of the instructions, and the matrix
+        // pipe is what this loop waits for (a 16 x 16 x 4 f64 product occupies it for 64 cycles on this part -- its f64 matrix rate
+        // equals its f64 vector rate -- and a ten-camera point touched 10 - 15 tiles: 2.6 us per batch of 6.4 points, 5.4 us per batch
+        // and wave measured with two waves per SIMD).  A lane's slice decides its point: the point's mask and first lane come from
+        // LDS by a per-lane address.  No branch: a slot the point does not have -- any slot of a block row the batch does not touch
+        // is one -- and a slice past the batch's last point read the zero row.
+        // (A second set of fragment registers to fetch the next step's rows under this step's products spilled at two waves per SIMD
+        // and lost at one: measured, not kept.)
+        const int nsteps = (3 * npts + 3) >> 2;
+        for (int t = 0; t < nsteps; ++t) {
+            const int sigma = 4 * t + m4;
+            const int pq = (sigma * 43) >> 7;                    // sigma / 3 for sigma < 128
+            const int col = sigma - 3 * pq;
+            const bool live = pq < npts;
+            const unsigned int pm = live ? pmask[pq & (kMfMaxPts - 1)] : 0u;
+            const int pf = pfirst[pq & (kMfMaxPts - 1)];
+            double fa[kMfBR], fb[kMfBR];
 #pragma unroll
             for (int R = 0; R < kMfBR; ++R) {
                 const int have = (int)((pm >> fr_sc[R]) & 1u);
                 const int o = 64 + have * (pf + (int)__popc(pm & fr_low[R]) - 64);
-                const double *y = Yw + o * kMfYPitch + fr_off[R];
+                const double *y = Yw + o * kMfYPitch + fr_off[R] + col;
                 fa[R] = y[0]; fb[R] = y[18];
             }
-        };
-        // the tiles of the lower block triangle the batch can touch.  (The matrix pipe is what this loop waits for: a 16 x 16 x 4 f64
-        // product occupies it for 64 cycles on this part -- its f64 matrix rate equals its f64 vector rate -- and a point of ten
-        // cameras needs 10 - 15 of them: 2.6 us per batch of 6.4 points, with two waves per SIMD 5.4 us per batch and wave measured.
-        // A second set of fragment registers to fetch the next point's rows under this point's products spilled at two waves per
-        // SIMD and lost at one: measured, not kept.)
-        auto products = [&](const double (&fa)[kMfBR], const double (&fb)[kMfBR]) {
 #pragma unroll
             for (int R = 0; R < kMfBR; ++R) {
                 if (R < R0 || R > R1) continue;
@@ -1418,11 +1421,6 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
                     acc[R * (R + 1) / 2 + C] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[R], fb[C], acc[R * (R + 1) / 2 + C], 0, 0, 0);
                 }
             }
-        };
-        for (int pq = 0; pq < npts; ++pq) {
-            double fa[kMfBR], fb[kMfBR];
-            gather(pq, fa, fb);
-            products(fa, fb);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the table has been read before the next batch overwrites it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (... and the compiler may not sink this batch's reads below the next one's stores)
@@ -1450,6 +1448,9 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
     // S -= G on the entry's fixed-point grid.  Window order (row >= col) is not camera order once the indices are rotated: the stored
     // triangle wants row camera >= column camera in TRUE indices, a diagonal camera block in full.
     unsigned long long *redq = reinterpret_cast<unsigned long long *>(d.red);
+#ifdef ESFM_EXP_SCHUR_NOFLUSH
+    if (rhs_exp == 12345)
+#endif
     for (int e = tid; e < kMfRows * kMfRows; e += 256) {
         const int row = e / kMfRows, col = e - row * kMfRows;
         if (col > row) continue;
