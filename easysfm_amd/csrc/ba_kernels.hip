@@ -311,6 +311,14 @@ __device__ __forceinline__ int qexp_of(double diag)
 // threads per workgroup of the sweep: 512 from 2^20 observations on, 256 below (BA-25, 240 k observations, two per thread: 28.7 -> 22.8
 // us -- finer workgroups get out of each other's phase and finish unevenly loaded CUs sooner; 128: 36 us, the slab count doubles;
 // 1024: 33 us.  BA-512: 223 us with 512, 313 with 256)
+// Round 5, BA-512 (11.4 observations per thread, two waves per SIMD -- the LDS sums of 512 cameras leave room for one workgroup per
+// CU): the loop's loads are issued one observation AHEAD of its stores (see the loop): 228 -> 187 us.  What is left is issue time:
+// timing-only builds without the 20 stores AND without the 35 LDS atomics take 177 us; the loop is 1 266 instructions per observation
+// (349 v_add_f64, 278 v_mul_f64, 67 fused: sincos, log, three divisions, two square roots, the 27 fixed-point conversions; 125
+// register moves, 84 address computations), 52.7 M wave-level VALU instructions per launch = 86 us at four cycles each, 122 us at
+// the 5.7 cycles per instruction the counters show.  Allowing fused multiply-adds in the geometry removes 8 % of them (measured: not
+// worth a second rounding behaviour).  A pure copy of the same 18 + 18 arrays runs at 5.9 TB/s in ANY layout (SoA of doubles as here,
+// double2, tiles of 64: scratch/ubench/soa_stream.hip), so the layout is not what holds the sweep at 2.6 TB/s.
 constexpr int kLinThreadsLarge = 512, kLinThreadsSmall = 256;
 constexpr int kLinSmallObs = 1 << 20;
 constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
@@ -494,34 +502,21 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
             load_idx(clamped((long long)k + 2 * (long long)kstride), ix_nn);
             __builtin_amdgcn_sched_barrier(0);
         }
-#if defined(ESFM_EXP_LIN) && (ESFM_EXP_LIN & 4)
-        if (cauchy_a == -12345.0)
-#endif
-        {
 #pragma unroll
         for (int i = 0; i < 12; ++i) d.Jc[(size_t)i * n_obs + k] = Jc[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.Jp[(size_t)i * n_obs + k] = Jp[i];
         d.res[k] = r0; d.res[(size_t)n_obs + k] = r1;
-        }
         if (PRIV) {
-#if defined(ESFM_EXP_LIN) && (ESFM_EXP_LIN & 2)
-            if (cauchy_a == -12345.0)
-#endif
-            {
             atomicAdd(&cnt[c], 1);
 #pragma unroll
             for (int a = 0; a < 6; ++a) atomicMax(&mx[c * 7 + a], (unsigned long long)__double_as_longlong(Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]));
             atomicMax(&mx[c * 7 + 6], (unsigned long long)__double_as_longlong(r0 * r0 + r1 * r1));
-            }
             if (single) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) keepJ[i] = Jc[i];
                 keepR0 = r0; keepR1 = r1; keepC = c;
             }
-#if defined(ESFM_EXP_LIN) && (ESFM_EXP_LIN & 1)
-            if (cauchy_a == -12345.0)
-#endif
             if (prov && !CALIB) add_rows(c, Jc, r0, r1);
         }
         ix_cur = ix_nxt; ix_nxt = ix_nn; par_cur = par_nxt;
@@ -1448,9 +1443,6 @@ __global__ __launch_bounds__(256, ESFM_SCHUR_OCC) void ba_schur_mfma_kernel(BADe
     // S -= G on the entry's fixed-point grid.  Window order (row >= col) is not camera order once the indices are rotated: the stored
     // triangle wants row camera >= column camera in TRUE indices, a diagonal camera block in full.
     unsigned long long *redq = reinterpret_cast<unsigned long long *>(d.red);
-#ifdef ESFM_EXP_SCHUR_NOFLUSH
-    if (rhs_exp == 12345)
-#endif
     for (int e = tid; e < kMfRows * kMfRows; e += 256) {
         const int row = e / kMfRows, col = e - row * kMfRows;
         if (col > row) continue;
