@@ -308,6 +308,50 @@ def test_ba_tiled_cholesky_sizes(gpu_ctx, oracle_lib, n_cam, n_pt, k, seed):
     assert np.allclose(cams, rc, rtol=RTOL_PAR, atol=ATOL_PAR) and np.allclose(pts, rp, rtol=RTOL_PAR, atol=ATOL_PAR)
 
 
+def test_schur_matrix_core_kernel_mixed_tracks(gpu_ctx, oracle_lib):
+    """Every path of ba_schur_mfma_kernel's gather (round 5: slot masks + popcount instead of a slot -> lane table, K slices packed
+    across points) on one problem: 120 cameras on a loop; a point is seen from a RANDOM subset (1 .. 13 cameras) of a 13-camera window
+    at a random position -- gaps inside the window (absent slots read the zero row), windows that wrap the seam (the rotated table),
+    one-observation points (batches of 16 points, K slices that straddle points), narrow tracks (batches that touch one or two block
+    rows) -- plus points wider than the window in both numberings (the window / plain kernels) and one that sees a camera twice.
+    Trace and parameters against the oracle; the structure-aware and the dense reduced solves."""
+    import os
+    rng = np.random.default_rng(2025)
+    n_cam, n_pt = 120, 9000
+    base = synth.ba_scene(n_cam, n_pt, 6, radius=20.0, extent=3.0, seed=41)
+    cam, pt = [], []
+    for p in range(n_pt):
+        if p % 53 == 0:                                  # wide in both numberings
+            cams = rng.choice(n_cam, size=rng.integers(2, 6), replace=False)
+        else:
+            c0 = rng.integers(0, n_cam)
+            m = rng.integers(1, 14) if p % 7 else 1
+            cams = (c0 + rng.choice(13, size=m, replace=False)) % n_cam
+        cams = np.sort(cams)
+        if p == 17:
+            cams = np.concatenate([cams, cams[:1]])      # the same camera twice: not a matrix-core point
+        cam += list(cams); pt += [p] * len(cams)
+    cam = np.array(cam, np.int32); pt = np.array(pt, np.int32)
+    Rs = np.stack([synth.aa_to_R(base.cams_gt[c, :3]) for c in range(n_cam)])
+    Pc = np.einsum("nij,nj->ni", Rs[cam], base.pts_gt[pt]) + base.cams_gt[cam, 3:]
+    K = synth.FOUNTAIN_K4
+    uv = (np.stack([Pc[:, 0] / Pc[:, 2] * K[0] + K[1], Pc[:, 1] / Pc[:, 2] * K[2] + K[3]], 1) + 0.5 * rng.standard_normal((len(cam), 2))).astype(np.float32)
+    opt = E.default_options(); opt.max_num_iterations = 4
+    ropt = oracle_lib.ba_default_options(); ropt.max_num_iterations = 4
+    rc, rp, rs = oracle_lib.ba_solve(cam, pt, uv, base.K4, base.cams0, base.pts0, ropt)
+    old = os.environ.get("ESFM_BA_SOLVE")
+    try:
+        for mode in ("dense", "sparse"):
+            os.environ["ESFM_BA_SOLVE"] = mode
+            cs, ps, ss = E.ba_solve(cam, pt, uv, base.K4, base.cams0, base.pts0, opt, gpu_ctx)
+            _compare(ss, rs, oracle_lib)
+            assert np.allclose(cs, rc, rtol=RTOL_PAR, atol=ATOL_PAR) and np.allclose(ps, rp, rtol=RTOL_PAR, atol=ATOL_PAR), mode
+    finally:
+        os.environ.pop("ESFM_BA_SOLVE", None)
+        if old is not None:
+            os.environ["ESFM_BA_SOLVE"] = old
+
+
 def test_ba_512_full_size_properties(gpu_ctx, oracle_lib):
     """BASELINE config 5 size on one GPU (512 cams, 300k pts, 3M obs; reduced system 3072 x 3072): too big for
     an oracle solve in the CPU test budget, so size-independent properties: every LM step the solver accepts
