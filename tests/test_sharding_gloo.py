@@ -1,4 +1,4 @@
-"""Multi-rank behaviour of the two shardable stages, world_size 2 over gloo on CPU.
+"""Multi-rank behaviour of the two shardable stages, world sizes 2 and 4 over gloo on CPU.
 
 The HIP kernels cannot run here, so the per-rank compute is stood in for by the oracle (test
 infrastructure); what is under test is the decomposition the product uses:
@@ -80,8 +80,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharding_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharding_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
