@@ -893,6 +893,16 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_point_prep_chunk_kernel(BADev 
     const size_t n = d.n_obs;
     double gmax = 0.0, sing = 0.0;
     const bool small = nobs <= kPtChunkObs;
+    // what the point phase needs from memory is requested NOW, in front of the rows (round 5): behind the barrier it was two more
+    // dependent round trips in a workgroup whose whole life is five, with 9 of 10 threads idle
+    const bool is_pt = tid < p1 - p0;
+    int pt_b = 0, pt_e = 0;
+    double pt_sc[3] = {1.0, 1.0, 1.0};
+    if (is_pt) {
+        pt_b = d.pt_start[p0 + tid]; pt_e = d.pt_start[p0 + tid + 1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pt_sc[q] = d.scale_p[3 * (size_t)(p0 + tid) + q];
+    }
     if (small && tid < nobs) {
         const int k = k0 + tid;
         const double j0 = d.Jp[k], j1 = d.Jp[n + k], j2 = d.Jp[2 * n + k];
@@ -903,9 +913,9 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_point_prep_chunk_kernel(BADev 
         prod[tid][6] = j0 * r0 + j3 * r1; prod[tid][7] = j1 * r0 + j4 * r1; prod[tid][8] = j2 * r0 + j5 * r1;
     }
     __syncthreads();
-    if (tid < p1 - p0) {
+    if (is_pt) {
         const int p = p0 + tid;
-        const int b = d.pt_start[p], e = d.pt_start[p + 1];
+        const int b = pt_b, e = pt_e;
         if (e > b) {
             double A[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
             if (small) {
@@ -930,7 +940,7 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_point_prep_chunk_kernel(BADev 
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 d.Etr[3 * (size_t)p + q] = g[q];
-                gmax = fmax(gmax, fabs(g[q] / d.scale_p[3 * (size_t)p + q]));  // gradient of the unscaled problem
+                gmax = fmax(gmax, fabs(g[q] / pt_sc[q]));  // gradient of the unscaled problem
             }
             sing = point_block_invert(d, p, A, g, radius, min_diag, max_diag);
         }
@@ -1889,6 +1899,21 @@ __global__ __launch_bounds__(kPtChunkObs, ESFM_BACKSUB_OCC) void ba_backsub_chun
 #pragma unroll
         for (int a = 0; a < 4; ++a) yk[a] = d.y_c[6 * d.n_real_cam + a];
     }
+    auto point_step_pre = [&](int p, const double g[3], const double (&Mi)[6], const double (&xq)[3], const double (&scq)[3]) {   // the same from operands already in registers
+        double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]), -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
+                        -(Mi[2] * g[0] + Mi[4] * g[1] + Mi[5] * g[2])};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double xp = xq[a];
+            const double dl = sp[a] * scq[a];
+            const double cnd = xp + dl;
+            const double df = xp - cnd;
+            ssq += df * df; csq += cnd * cnd;
+            d.cand_p[3 * (size_t)p + a] = cnd;
+            if (d.constrained) { d.delta_p[3 * (size_t)p + a] = dl; dmax = fmax(dmax, fabs(dl)); }
+        }
+        return std::array<double, 3>{sp[0], sp[1], sp[2]};
+    };
     auto point_step = [&](int p, const double g[3]) {       // s_p, candidate point, norms
         const double *Mi = d.Minv + 6 * (size_t)p;
         double sp[3] = {-(Mi[0] * g[0] + Mi[1] * g[1] + Mi[2] * g[2]), -(Mi[1] * g[0] + Mi[3] * g[1] + Mi[4] * g[2]),
@@ -1910,6 +1935,18 @@ __global__ __launch_bounds__(kPtChunkObs, ESFM_BACKSUB_OCC) void ba_backsub_chun
         const int k = k0 + (has ? tid : 0);
         double Jp[6], f0 = 0.0, f1 = 0.0, r0 = 0.0, r1 = 0.0;
         int pl = 0;
+        // the point phase's operands are requested in front of the rows (see ba_point_prep_chunk_kernel)
+        const bool is_pt = tid < p1 - p0;
+        int pt_b = 0, pt_e = 0;
+        double pt_g[3] = {0.0, 0.0, 0.0}, pt_M[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, pt_x[3] = {0.0, 0.0, 0.0}, pt_sc[3] = {0.0, 0.0, 0.0};
+        if (is_pt) {
+            const size_t p = (size_t)(p0 + tid);
+            pt_b = d.pt_start[p] - k0; pt_e = d.pt_start[p + 1] - k0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { pt_g[a] = d.Etr[3 * p + a]; pt_x[a] = d.x_p[3 * p + a]; pt_sc[a] = d.scale_p[3 * p + a]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) pt_M[a] = d.Minv[6 * p + a];
+        }
         if (has) {
             const int c = d.obs_cam[k];
             pl = d.obs_pt[k] - p0;
@@ -1929,13 +1966,13 @@ __global__ __launch_bounds__(kPtChunkObs, ESFM_BACKSUB_OCC) void ba_backsub_chun
             for (int a = 0; a < 3; ++a) tE[tid][a] = Jp[a] * f0 + Jp[3 + a] * f1;
         }
         __syncthreads();
-        if (tid < p1 - p0) {
+        if (is_pt) {
             const int p = p0 + tid;
-            const int b = d.pt_start[p] - k0, e = d.pt_start[p + 1] - k0;
+            const int b = pt_b, e = pt_e;
             if (e > b) {
-                double g[3] = {d.Etr[3 * (size_t)p], d.Etr[3 * (size_t)p + 1], d.Etr[3 * (size_t)p + 2]};
+                double g[3] = {pt_g[0], pt_g[1], pt_g[2]};
                 for (int o = b; o < e; ++o) { g[0] -= tE[o][0]; g[1] -= tE[o][1]; g[2] -= tE[o][2]; }
-                const auto sp = point_step(p, g);
+                const auto sp = point_step_pre(p, g, pt_M, pt_x, pt_sc);
                 sps[tid][0] = sp[0]; sps[tid][1] = sp[1]; sps[tid][2] = sp[2];
                 if (WITH_COST) {
 #pragma unroll
@@ -1944,7 +1981,7 @@ __global__ __launch_bounds__(kPtChunkObs, ESFM_BACKSUB_OCC) void ba_backsub_chun
             } else {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    d.cand_p[3 * (size_t)p + a] = d.x_p[3 * (size_t)p + a];
+                    d.cand_p[3 * (size_t)p + a] = pt_x[a];
                     if (d.constrained) d.delta_p[3 * (size_t)p + a] = 0.0;
                 }
             }
