@@ -291,6 +291,17 @@ __device__ __forceinline__ int qexp_of(double diag)
     return (sd > 1e-120 && sd < 1e120) ? ilogb(sd) + 1 : -400;   // a zero column only ever contributes zeros
 }
 
+#ifdef ESFM_LIN_TRACE
+// timing-only build (scratch/build_variant_ba.sh NAME -DESFM_LIN_TRACE): s_memrealtime ticks (10 ns) summed over the waves of ba_linearize_kernel:
+// [0] prologue (LDS clear, exponents, first loads), [1] the loop, [2] everything behind it, [3] waves, [4] loop iterations
+__device__ unsigned long long g_lin_trace[8];
+extern "C" int esfm_debug_lin_trace(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lin_trace), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_trace), sizeof(g_lin_trace));
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Jacobian sweep: 16 B in, 160 B out per observation (+ 32 B with free intrinsics), and the per-camera sums F'F / F'r.
 //
@@ -311,14 +322,16 @@ __device__ __forceinline__ int qexp_of(double diag)
 // threads per workgroup of the sweep: 512 from 2^20 observations on, 256 below (BA-25, 240 k observations, two per thread: 28.7 -> 22.8
 // us -- finer workgroups get out of each other's phase and finish unevenly loaded CUs sooner; 128: 36 us, the slab count doubles;
 // 1024: 33 us.  BA-512: 223 us with 512, 313 with 256)
-// Round 5, BA-512 (11.4 observations per thread, two waves per SIMD -- the LDS sums of 512 cameras leave room for one workgroup per
-// CU): the loop's loads are issued one observation AHEAD of its stores (see the loop): 228 -> 187 us.  What is left is issue time:
-// timing-only builds without the 20 stores AND without the 35 LDS atomics take 177 us; the loop is 1 266 instructions per observation
-// (349 v_add_f64, 278 v_mul_f64, 67 fused: sincos, log, three divisions, two square roots, the 27 fixed-point conversions; 125
-// register moves, 84 address computations), 52.7 M wave-level VALU instructions per launch = 86 us at four cycles each, 122 us at
-// the 5.7 cycles per instruction the counters show.  Allowing fused multiply-adds in the geometry removes 8 % of them (measured: not
-// worth a second rounding behaviour).  A pure copy of the same 18 + 18 arrays runs at 5.9 TB/s in ANY layout (SoA of doubles as here,
-// double2, tiles of 64: scratch/ubench/soa_stream.hip), so the layout is not what holds the sweep at 2.6 TB/s.
+// Round 5, BA-512 (two waves per SIMD -- 250 registers; the LDS sums of 512 cameras leave room for one workgroup per CU anyway): the
+// loop's loads are issued one observation AHEAD of its stores (see the loop): 228 -> 187 us; ONE workgroup per CU instead of two in
+// sequence (each paid a 9-us prologue -- LDS clear, exponents -- and an 8-us epilogue): -> 161 - 167 us.  What the loop waits for is
+// neither memory nor issue slots but ITSELF (-DESFM_LIN_TRACE, scratch/lin_trace.py: 5.6 us per iteration and wave = 13 400 cycles
+// for 2 x 1 266 instructions): timing-only builds without the 20 stores AND the 35 LDS atomics take 177 us against 186; a build that
+// takes sin / cos / 1/theta from a per-camera table -- 1 080 instructions instead of 1 266, bit-identical results -- takes exactly as
+// long (5.58 against 5.60 us per iteration: measured, not kept); allowing fused multiply-adds removes 8 % of the instructions.  The
+// f64 dependency chains of one observation (division -> Jacobian -> scaling -> products -> fixed point) at two waves per SIMD are the
+// critical path; more waves would need the kernel in 128 registers.  A pure copy of the same 18 + 18 arrays runs at 5.9 TB/s in ANY
+// layout (SoA of doubles as here, double2, tiles of 64: scratch/ubench/soa_stream.hip), so the layout is not what holds the sweep back.
 constexpr int kLinThreadsLarge = 512, kLinThreadsSmall = 256;
 constexpr int kLinSmallObs = 1 << 20;
 constexpr int kLinLdsPerCam = 27 * 8 + 7 * 8 + 4 + 7 * 4;   // acc, maxima, count, exponents
@@ -337,6 +350,10 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
     // and column: if one fails (a first linearisation, a problem that changed under the solver) the workgroup clears its sums and
     // runs the two-pass form below.  Either way the integers are exact sums on the grid the slab is converted with.  (Round 3: the
     // re-read of pass 2 was 336 MB of BA-512's sweep.)
+#ifdef ESFM_LIN_TRACE
+    const unsigned long long lt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long lt_iters = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *red = reinterpret_cast<double *>(lds_raw);                                  // [8] reduction scratch, [10] intrinsics-block sums
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(lds_raw) + 18;     // PRIV: [n_real_cam * 27]
@@ -430,7 +447,13 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
         // the way in it would wait for "all but two" memory operations in EVERY iteration -- the stores again)
         __builtin_amdgcn_s_waitcnt(0x0f70);
     }
+#ifdef ESFM_LIN_TRACE
+    const unsigned long long lt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int k = k_first; k < n_obs; k += kstride) {
+#ifdef ESFM_LIN_TRACE
+        ++lt_iters;
+#endif
         // the next observation's parameters and the indices of the one after: requested in front of this observation's arithmetic
         // (and so ahead of its stores in the queue)
         // (with free intrinsics the kernel has no registers left for that: there the requests go out after the arithmetic, in front
@@ -521,6 +544,19 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
         }
         ix_cur = ix_nxt; ix_nxt = ix_nn; par_cur = par_nxt;
     }
+#ifdef ESFM_LIN_TRACE
+    const unsigned long long lt2 = __builtin_amdgcn_s_memrealtime();
+    struct LinTraceEnd {
+        unsigned long long t0, t1, t2, it;
+        __device__ ~LinTraceEnd() {
+            if ((threadIdx.x & 63) == 0) {
+                const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+                atomicAdd(&g_lin_trace[0], t1 - t0); atomicAdd(&g_lin_trace[1], t2 - t1); atomicAdd(&g_lin_trace[2], t3 - t2);
+                atomicAdd(&g_lin_trace[3], 1ull); atomicAdd(&g_lin_trace[4], it);
+            }
+        }
+    } lin_trace_end{lt0, lt1, lt2, lt_iters};
+#endif
     {
         const int slots[2] = {SC_COST, SC_LIN_BAD};
         const double vals[2] = {cost, bad};
@@ -2238,7 +2274,10 @@ int ba_linearize(hipStream_t st, const BADev &d, int num_cu, double cauchy_a, bo
     const size_t priv_bytes = 18 * sizeof(double) + (size_t)d.n_real_cam * kLinLdsPerCam;
     const bool small = d.n_obs < kLinSmallObs;
     const int kLinThreads = small ? kLinThreadsSmall : kLinThreadsLarge;
-    const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * 2);
+    // (the 512-thread form fills a CU's registers with ONE workgroup -- 250 registers x 8 waves -- so a second workgroup per CU only runs
+    // after the first, paying the 9-us prologue (LDS clear, exponents) and the 8-us epilogue (guard, slab) again: one per CU)
+    static const int grid_mul = getenv("ESFM_LIN_GRID_MUL") ? atoi(getenv("ESFM_LIN_GRID_MUL")) : 0;       // developer switch (A/B)
+    const int grid = std::min(div_up(d.n_obs, kLinThreads), std::max(1, num_cu) * (grid_mul > 0 ? grid_mul : (small ? 2 : 1)));
     const bool priv = priv_bytes <= 160 * 1024 && d.lin_slabs && (size_t)grid * d.n_cam * 27 <= d.lin_slab_cap;
     ScalBase sbase;
     { const int slots[2] = {SC_COST, SC_LIN_BAD}; if (int rc = scal_reserve<2>(st, d, slots, grid, sbase)) return rc; }
