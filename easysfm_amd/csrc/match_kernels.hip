@@ -3313,6 +3313,28 @@ __global__ __launch_bounds__(256) void buffer_checksum_kernel(const uint32_t *__
     if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
 }
 
+// esfm_match_pairs (host pointers): the pairs' match lists, each at its own offset in three sum(nq)-long arrays, packed back to
+// back so that the read-back moves the matches and not the gaps.  tab: per pair {source offset, packed offset} (int64) and count.
+__global__ __launch_bounds__(256) void pack_match_lists_kernel(const long long *__restrict__ tab, const int32_t *__restrict__ n_out, int n_pairs,
+                                                               const int32_t *__restrict__ sq, const int32_t *__restrict__ stn, const float *__restrict__ sd,
+                                                               int32_t *__restrict__ dq, int32_t *__restrict__ dtn, float *__restrict__ dd)
+{
+    for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+        const long long so = tab[2 * (size_t)p], dof = tab[2 * (size_t)p + 1];
+        const int n = n_out[p];
+        for (int e = threadIdx.x; e < n; e += 256) { dq[dof + e] = sq[so + e]; dtn[dof + e] = stn[so + e]; dd[dof + e] = sd[so + e]; }
+    }
+}
+
+int launch_pack_match_lists(hipStream_t st, const long long *tab, const int32_t *n_out, int n_pairs, const int32_t *sq, const int32_t *stn, const float *sd,
+                            int32_t *dq, int32_t *dtn, float *dd)
+{
+    if (n_pairs <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(pack_match_lists_kernel, dim3(std::min(n_pairs, 4096)), dim3(256), 0, st, tab, n_out, n_pairs, sq, stn, sd, dq, dtn, dd);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
 int launch_buffer_checksum(hipStream_t st, const void *buf, size_t bytes, unsigned long long *out)
 {
     ESFM_HIP_TRY(hipMemsetAsync(out, 0, sizeof(unsigned long long), st));

@@ -84,6 +84,8 @@ int launch_hamming_knn(hipStream_t st, int nbytes, const void *desc, long long t
                        const PairDesc *pairs, int n_pairs, int n_blocks,
                        int32_t *knn_idx, float *knn_dist, bool expanded);
 int launch_buffer_checksum(hipStream_t st, const void *buf, size_t bytes, unsigned long long *out);
+int launch_pack_match_lists(hipStream_t st, const long long *tab, const int32_t *n_out, int n_pairs, const int32_t *sq, const int32_t *stn, const float *sd,
+                            int32_t *dq, int32_t *dtn, float *dd);
 int launch_ratio_compact(hipStream_t st, const PairDesc *pairs, int n_pairs, const int32_t *knn_idx, const float *knn_dist,
                          double ratio, int32_t *query_idx, int32_t *train_idx, float *distance, int32_t *n_out);
 

@@ -156,7 +156,9 @@ int esfm_match_pairs_dev(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev
 /* The same with HOST pointers in and out (what a C++ host without a device allocator of its own calls once for the whole pair loop,
  * sfm.cpp:140-161): `desc_host` holds the rows of all sets back to back; they are uploaded once, prepared (below) once, every pair is
  * matched in one launch sequence and the per-pair slices come back in one read-back.  query_idx / train_idx / distance need
- * sum(nq_p) entries, n_out n_pairs, out_offset n_pairs + 1 (all host).  Synchronises. */
+ * sum(nq_p) entries, n_out n_pairs, out_offset n_pairs + 1 (all host).  Synchronises.
+ * Only the first n_out[p] entries of a pair's range are written (sparse results are packed on the device before the read-back: the
+ * transfer is proportional to the matches, not to the queries); the rest of the range is left as the caller passed it. */
 int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host,
                      const int32_t *set_row_offset, int n_sets, int width /*dim or nbytes*/,
                      const int32_t *pairs, int n_pairs, double ratio,
