@@ -340,33 +340,70 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
             else if (hi_b[(size_t)p] - lo_b[(size_t)p] < esfm::kSchurMfCams) { mperm[1].push_back(p); taken[(size_t)p] = 1; }
         }
         for (int tb = 0; tb < 2; ++tb) {
-            std::vector<int32_t> &perm = mperm[tb];
-            const std::vector<int32_t> &lo = tb ? lo_b : lo_a, &hi = tb ? hi_b : hi_a;
-            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return lo[(size_t)a] < lo[(size_t)b]; });
-            int64_t total = 0;
-            for (int p : perm) total += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
-            const int64_t per = std::max<int64_t>(512, (total + 2 * ctx->num_cu - 1) / (2 * ctx->num_cu));
-            int64_t in_chunk = 0; int cw = 0, in_batch = 0, pts_batch = 0;
-            for (int p : perm) {
-                const int t = pt_start[(size_t)p + 1] - pt_start[(size_t)p];
-                const bool new_chunk = mchunk_cam0[tb].empty() || in_chunk >= per || hi[(size_t)p] - cw >= esfm::kSchurMfCams;
-                if (new_chunk) {
-                    mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size());
-                    mchunk_cam0[tb].push_back(lo[(size_t)p]); cw = lo[(size_t)p]; in_chunk = 0;
+            const std::vector<int32_t> &lo = tb ? lo_b : lo_a;
+            std::stable_sort(mperm[tb].begin(), mperm[tb].end(), [&](int a, int b) { return lo[(size_t)a] < lo[(size_t)b]; });
+        }
+        int64_t total_all = 0;
+        for (int tb = 0; tb < 2; ++tb) for (int p : mperm[tb]) total_all += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+        // chunks of `per` observations, both tables; returns the number of chunks (= workgroups of the one launch)
+        auto build_chunks = [&](int64_t per) {
+            for (int tb = 0; tb < 2; ++tb) {
+                mslot_obs[tb].clear(); mbatch_slot[tb].clear(); mchunk_batch0[tb].clear(); mchunk_cam0[tb].clear();
+                const std::vector<int32_t> &perm = mperm[tb];
+                const std::vector<int32_t> &lo = tb ? lo_b : lo_a, &hi = tb ? hi_b : hi_a;
+                int64_t in_chunk = 0; int cw = 0, in_batch = 0, pts_batch = 0;
+                for (int p : perm) {
+                    const int t = pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+                    const bool new_chunk = mchunk_cam0[tb].empty() || in_chunk >= per || hi[(size_t)p] - cw >= esfm::kSchurMfCams;
+                    if (new_chunk) {
+                        mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size());
+                        mchunk_cam0[tb].push_back(lo[(size_t)p]); cw = lo[(size_t)p]; in_chunk = 0;
+                    }
+                    if (new_chunk || in_batch + t > 64 || pts_batch >= 16) { mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size()); in_batch = 0; pts_batch = 0; }
+                    // a point's observations in ascending camera-slot order (the kernel finds "the observation with slot s" by counting
+                    // the lower bits of the point's slot mask); in the seam's table that is the ROTATED index
+                    const size_t at = mslot_obs[tb].size();
+                    for (int k = pt_start[(size_t)p]; k < pt_start[(size_t)p + 1]; ++k) mslot_obs[tb].push_back(k);
+                    std::sort(mslot_obs[tb].begin() + (std::ptrdiff_t)at, mslot_obs[tb].end(), [&](int32_t a, int32_t b) {
+                        const int ca = tb ? rotated(s_cam[(size_t)a]) : s_cam[(size_t)a], cb = tb ? rotated(s_cam[(size_t)b]) : s_cam[(size_t)b];
+                        return ca < cb;
+                    });
+                    in_batch += t; ++pts_batch; in_chunk += t;
                 }
-                if (new_chunk || in_batch + t > 64 || pts_batch >= 16) { mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size()); in_batch = 0; pts_batch = 0; }
-                // a point's observations in ascending camera-slot order (the kernel finds "the observation with slot s" by counting
-                // the lower bits of the point's slot mask); in the seam's table that is the ROTATED index
-                const size_t at = mslot_obs[tb].size();
-                for (int k = pt_start[(size_t)p]; k < pt_start[(size_t)p + 1]; ++k) mslot_obs[tb].push_back(k);
-                std::sort(mslot_obs[tb].begin() + (std::ptrdiff_t)at, mslot_obs[tb].end(), [&](int32_t a, int32_t b) {
-                    const int ca = tb ? rotated(s_cam[(size_t)a]) : s_cam[(size_t)a], cb = tb ? rotated(s_cam[(size_t)b]) : s_cam[(size_t)b];
-                    return ca < cb;
-                });
-                in_batch += t; ++pts_batch; in_chunk += t;
+                mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size());
+                mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size() - 1);
             }
-            mbatch_slot[tb].push_back((int32_t)mslot_obs[tb].size());
-            mchunk_batch0[tb].push_back((int32_t)mbatch_slot[tb].size() - 1);
+            return (int64_t)mchunk_cam0[0].size() + (int64_t)mchunk_cam0[1].size();
+        };
+        // Both tables run in ONE launch of two workgroups per CU (ba_schur_mfma_kernel: 78 KB of LDS, 244 registers): every chunk should
+        // be resident from the start -- a chunk dispatched behind the others adds its whole length to the launch (round 5: the seam's
+        // table had its own, much smaller `per`: a hundred short chunks behind 512 long ones, 20 us of tail).  One `per` for both, raised
+        // by 1 % until the chunks fit the slots; camera windows can force more chunks than that (wide, scattered tracks): then the
+        // first `per` stands.
+        {
+            auto count_chunks = [&](int64_t per) {          // build_chunks' chunk boundaries without the lists
+                int64_t n = 0;
+                for (int tb = 0; tb < 2; ++tb) {
+                    const std::vector<int32_t> &lo = tb ? lo_b : lo_a, &hi = tb ? hi_b : hi_a;
+                    int64_t in_chunk = 0; int cw = 0; bool any = false;
+                    for (int p : mperm[tb]) {
+                        if (!any || in_chunk >= per || hi[(size_t)p] - cw >= esfm::kSchurMfCams) { ++n; cw = lo[(size_t)p]; in_chunk = 0; any = true; }
+                        in_chunk += pt_start[(size_t)p + 1] - pt_start[(size_t)p];
+                    }
+                }
+                return n;
+            };
+            const int64_t slots = 2 * (int64_t)std::max(1, ctx->num_cu);
+            const int64_t per0 = std::max<int64_t>(512, (total_all + slots - 1) / slots);
+            int64_t per = per0;
+            bool fits = false;
+            for (int it = 0; it < 64 && !fits; ++it) {
+                fits = count_chunks(per) <= slots;
+                if (!fits) per += std::max<int64_t>(1, per / 100);
+            }
+            build_chunks(fits ? per : per0);
+        }
+        for (int tb = 0; tb < 2; ++tb) {
             d.n_mchunks[tb] = (int)mchunk_cam0[tb].size();
             if (d.n_mchunks[tb]) {
                 mslot_pc[tb].resize(2 * mslot_obs[tb].size());
