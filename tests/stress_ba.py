@@ -34,7 +34,10 @@ def trace_equal(summ, rs, constrained):
     for a, b in zip(a_log, b_log):
         assert a.step_is_valid == b.step_is_valid, a.iteration
         # (round-off differences between two correct f64 solvers grow along the free gauge by ~1/damping per iteration: tight early, looser later)
-        assert abs(a.cost - b.cost) <= (1e-9 if a.iteration <= 3 else 1e-5) * max(abs(b.cost), 1.0), (a.iteration, a.cost, b.cost)
+        # (free intrinsics on a handful of cameras with an active bound are worse still: the ORACLE's own cost after one iteration moves by
+        # 2.6e-9 when the initial points are perturbed by 1e-13 relative -- seed 8, case 1059 of round 5's open-ended run: 3 cameras, 111 observations)
+        tight = 1e-8 if constrained else 1e-9
+        assert abs(a.cost - b.cost) <= (tight if a.iteration <= 3 else 1e-5) * max(abs(b.cost), 1.0), (a.iteration, a.cost, b.cost)
         assert abs(a.trust_region_radius - b.trust_region_radius) <= (1e-6 if a.iteration <= 4 else 1e-3) * b.trust_region_radius, (a.iteration, 'radius', a.trust_region_radius, b.trust_region_radius)
 
 t_end = time.time() + budget
