@@ -3,8 +3,9 @@ duplicated / clustered / scaled / zero rows, ratios 0.3 .. 1.0, L2 with 64 and 1
 tables bit for bit -- and tests/stress_ba.py -- camera counts across every kernel-path threshold, random track structure, shuffled
 observation order, free intrinsics, dense / structure-aware reduced solve, the LM trace within the tolerances of tests/test_ba_gpu.py
 (loosened past iteration 3: with no camera held, round-off grows along the gauge by ~1 / damping per iteration).  A fixed number of
-cases per seed, so the content does not depend on the machine; the same scripts run open-ended with --seconds (11 709 matcher cases /
-115 M queries and 8 000 BA cases in round 5: nothing but two conditioning artefacts of the BA tolerances, now as stated above)."""
+cases per seed, so the content does not depend on the machine; the same scripts run open-ended with --seconds (26 865 matcher cases /
+264 M queries and ~12 000 BA cases in round 5: nothing but conditioning artefacts of the BA tolerances -- DESIGN.md section 2 has the five
+cases and the oracle's own sensitivity on them)."""
 import os
 import subprocess
 import sys
