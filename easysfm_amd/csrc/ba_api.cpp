@@ -463,6 +463,13 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         pchunk_pt0.push_back(n_pt);
         d.n_pchunks = (int)pchunk_pt0.size() - 1;
         A(&d.pchunk_pt0, pchunk_pt0.size());
+        A(&d.pchunk_info, (size_t)std::max(d.n_pchunks, 1));
+    }
+    std::vector<int32_t> pchunk_info(4 * (size_t)std::max(d.n_pchunks, 1), 0);
+    for (int c = 0; c < d.n_pchunks; ++c) {
+        const int p0 = pchunk_pt0[(size_t)c], p1 = pchunk_pt0[(size_t)c + 1];
+        pchunk_info[4 * (size_t)c] = p0; pchunk_info[4 * (size_t)c + 1] = p1;
+        pchunk_info[4 * (size_t)c + 2] = pt_start[(size_t)p0]; pchunk_info[4 * (size_t)c + 3] = pt_start[(size_t)p1];
     }
     if (rc != ESFM_OK) { esfm_ba_problem_destroy(P); return rc; }
     hipStream_t st = ctx->stream;
@@ -497,6 +504,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
         up(d.chunk_cam0_b, chunk_cam0_b.data(), sizeof(int32_t) * chunk_cam0_b.size());
     }
     up(d.pchunk_pt0, pchunk_pt0.data(), sizeof(int32_t) * pchunk_pt0.size());
+    up(d.pchunk_info, pchunk_info.data(), sizeof(int32_t) * pchunk_info.size());
     up(d.cam_obs, cam_obs.data(), sizeof(int32_t) * no);
     up(d.cchunk_cam, cchunk_cam.data(), sizeof(int32_t) * cchunk_cam.size()); up(d.cchunk_beg, cchunk_beg.data(), sizeof(int32_t) * cchunk_beg.size());
     up(d.cchunk_end, cchunk_end.data(), sizeof(int32_t) * cchunk_end.size()); up(d.cam_chunk0, cam_chunk0.data(), sizeof(int32_t) * cam_chunk0.size());

@@ -923,8 +923,8 @@ __global__ __launch_bounds__(kPtChunkObs) void ba_point_prep_chunk_kernel(BADev 
     __shared__ double red[8];
     __shared__ double prod[kPtChunkObs][9];
     const int tid = threadIdx.x;
-    const int p0 = d.pchunk_pt0[blockIdx.x], p1 = d.pchunk_pt0[blockIdx.x + 1];
-    const int k0 = d.pt_start[p0], k1 = d.pt_start[p1];
+    const int4 ci4 = d.pchunk_info[blockIdx.x];          // (one load where p0 / p1, then pt_start[p0] / pt_start[p1], were two dependent ones)
+    const int p0 = ci4.x, p1 = ci4.y, k0 = ci4.z, k1 = ci4.w;
     const int nobs = k1 - k0;
     const size_t n = d.n_obs;
     double gmax = 0.0, sing = 0.0;
@@ -1925,8 +1925,8 @@ __global__ __launch_bounds__(kPtChunkObs, ESFM_BACKSUB_OCC) void ba_backsub_chun
     __shared__ double sps[kPtChunkObs][3];
     __shared__ double cnd[kPtChunkObs][3];      // WITH_COST: the candidate points of the chunk
     const int tid = threadIdx.x;
-    const int p0 = d.pchunk_pt0[blockIdx.x], p1 = d.pchunk_pt0[blockIdx.x + 1];
-    const int k0 = d.pt_start[p0], k1 = d.pt_start[p1];
+    const int4 ci4 = d.pchunk_info[blockIdx.x];          // (one load where p0 / p1, then pt_start[p0] / pt_start[p1], were two dependent ones)
+    const int p0 = ci4.x, p1 = ci4.y, k0 = ci4.z, k1 = ci4.w;
     const int nobs = k1 - k0;
     const size_t n = d.n_obs;
     double mc = 0.0, ssq = 0.0, csq = 0.0, gd = 0.0, dmax = 0.0, ccost = 0.0, cbad = 0.0;

@@ -128,6 +128,7 @@ struct BADev {
     int32_t *qexp = nullptr;            // [6 n_cam]
     // point chunks of the back-substitution (and of the per-point normal blocks): consecutive points, <= 256 observations each
     int32_t *pchunk_pt0 = nullptr;      // [n_pchunks + 1]
+    int4 *pchunk_info = nullptr;        // [n_pchunks] {first point, end point, first observation, end observation}: what a chunk's workgroup needs before it can request anything else, in ONE load
     int n_pchunks = 0;
 };
 constexpr int kCamChunk = 256, kCamPart = 37;
