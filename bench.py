@@ -536,11 +536,36 @@ def main() -> int:
     bctx = E.Context.on_torch_stream(local_rank)
     comm = None
     if world > 1:
-        box = [E.Comm.unique_id() if rank == 0 else None]
+        # every step may fail on a node this code has never seen (no round had more than one GPU): the ranks AGREE on the outcome
+        # (MIN over an ok flag through torch's process group) and, if the library's communicator is not there on all of them, the
+        # sharded BA legs go through torch.distributed's own RCCL group instead (easysfm_amd.ba.torch_allreduce_callback) -- the
+        # line says which (`ba_allreduce_via`).  The matching legs need no communicator at all.
+        uid, err = None, None
+        try:
+            uid = E.Comm.unique_id() if rank == 0 else None
+        except Exception as e:
+            err = repr(e)
+        box = [uid]
         dist.broadcast_object_list(box, src=0)
-        comm = E.Comm(bctx, box[0], rank, world)
-        out["rccl_ranks"] = comm.rccl_ranks()            # ncclCommCount of the library's own communicator: did RCCL see N ranks
+        if box[0] is not None:
+            try:
+                comm = E.Comm(bctx, box[0], rank, world)
+            except Exception as e:
+                err = repr(e)
+        okf = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if float(okf.item()) < 1.0:
+            if comm is not None:
+                comm = None                              # (left to process teardown: a collective destroy could wait for the failed ranks)
+            from easysfm_amd.ba import torch_allreduce_callback
+            comm = torch_allreduce_callback()
+            out["rccl_ranks"] = dist.get_world_size()
+            out["ba_allreduce_via"] = f"torch.distributed nccl group (esfm_comm_create failed on a rank: {err})"
+        else:
+            out["rccl_ranks"] = comm.rccl_ranks()        # ncclCommCount of the library's own communicator: did RCCL see N ranks
+            out["ba_allreduce_via"] = "esfm_comm (library's own RCCL communicator)"
         roofline["rccl_ranks"] = out["rccl_ranks"]
+        roofline["ba_allreduce_via"] = out["ba_allreduce_via"]
 
     def ba_leg(scene, iters, name, workload):
         """LM iterations/s on `scene`, points (hence observations) sharded over the ranks; returns the leg's JSON object."""
@@ -596,7 +621,7 @@ def main() -> int:
             "lm_iterations": summ.num_iterations, "seconds": ba_el, "ms_per_iteration": ba_el / max(summ.num_iterations, 1) * 1e3,
             "n_gpus": world, "scaling": "strong",
             "config": {"workload": workload, "obs_sharded_by_point": world > 1,
-                       "allreduce": (f"RCCL (esfm_comm_allreduce) sum of the packed reduced camera system"
+                       "allreduce": (f"RCCL ({'esfm_comm_allreduce' if isinstance(comm, E.Comm) else 'torch.distributed all_reduce'}) sum of the packed reduced camera system"
                                      f"{' (co-visible camera blocks only)' if sparse else ''}, {exch_mb:.2f} MB per LM iteration") if world > 1 else None},
             "reduced_solve": ({"kind": "structure-aware (nested dissection, tiles of the symbolic fill)", "tile_columns": plan["nb"], "tiles": len(plan["tiles"]),
                                "dependency_chain_tile_columns": plan["chain"], "dense_tile_columns": plan["dense_nb"],
@@ -1069,7 +1094,7 @@ def main() -> int:
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     emit()
-    if comm is not None:
+    if isinstance(comm, E.Comm):
         comm.close()
     if world > 1:
         dist.barrier()
