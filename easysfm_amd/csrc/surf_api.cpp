@@ -152,30 +152,41 @@ int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, 
     }
     const int n_kp = n_cand;
     std::vector<int64_t> win_off((size_t)n_kp + 1, 0);
+    std::vector<int32_t> win_of((size_t)n_kp);
     for (int k = 0; k < n_kp; ++k) {
         const float s = kps[(size_t)k].size * 1.2f / 9.0f;
         const int64_t w = (int64_t)((esfm::kSurfPatch + 1) * s);
-        ESFM_REQUIRE(w < 1024, "keypoint scale beyond the descriptor window the kernel is built for");
-        win_off[(size_t)k + 1] = win_off[(size_t)k] + ((w * w + 15) / 16) * 16;
+        ESFM_REQUIRE(w < 1024, "keypoint scale beyond the descriptor window the kernels are built for");
+        win_of[(size_t)k] = (int32_t)w;
+        win_off[(size_t)k + 1] = win_off[(size_t)k] + (int64_t)esfm::surf_scratch_bytes((int)w);
     }
-    // launch order: widest windows first (a window of 600 x 600 samples takes a workgroup a hundred times longer than one of 42 x 42)
+    // block tables of the two per-sample stages (256 items of ONE keypoint per block), widest windows first: their chunks are the
+    // longest items, so they start first
     std::vector<int32_t> order((size_t)n_kp);
     for (int k = 0; k < n_kp; ++k) order[(size_t)k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return win_off[(size_t)a + 1] - win_off[(size_t)a] > win_off[(size_t)b + 1] - win_off[(size_t)b];
-    });
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return win_of[(size_t)a] > win_of[(size_t)b]; });
+    std::vector<esfm::SurfBlk> blk_win, blk_row;
+    for (int32_t k : order) {
+        const int w = win_of[(size_t)k];
+        const int n_win = w * esfm::surf_window_chunks(w), n_row = w * (esfm::kSurfPatch + 1);
+        for (int f = 0; f < n_win; f += 256) blk_win.push_back({k, f});
+        for (int f = 0; f < n_row; f += 256) blk_row.push_back({k, f});
+    }
     const size_t off_bytes = sizeof(int64_t) * ((size_t)n_kp + 1), desc_bytes = sizeof(float) * 64 * (size_t)n_kp;
-    const size_t order_bytes = ((sizeof(int32_t) * (size_t)n_kp + 15) / 16) * 16;
-    if (int rc = b_win.reserve((size_t)win_off[(size_t)n_kp] + off_bytes + desc_bytes + order_bytes + 128)) return rc;
+    const size_t bw_bytes = esfm::surf_align16(sizeof(esfm::SurfBlk) * blk_win.size()), br_bytes = esfm::surf_align16(sizeof(esfm::SurfBlk) * blk_row.size());
+    if (int rc = b_win.reserve((size_t)win_off[(size_t)n_kp] + off_bytes + desc_bytes + bw_bytes + br_bytes + 128)) return rc;
     uint8_t *d_win = b_win.as<uint8_t>();
-    int64_t *d_off = reinterpret_cast<int64_t *>(d_win + ((win_off[(size_t)n_kp] + 15) / 16) * 16);
-    float *d_desc = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(d_off) + off_bytes);
-    int32_t *d_order = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(d_desc) + ((desc_bytes + 15) / 16) * 16);
+    int64_t *d_off = reinterpret_cast<int64_t *>(d_win + esfm::surf_align16((size_t)win_off[(size_t)n_kp]));
+    float *d_desc = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(d_off) + esfm::surf_align16(off_bytes));
+    esfm::SurfBlk *d_bw = reinterpret_cast<esfm::SurfBlk *>(reinterpret_cast<uint8_t *>(d_desc) + esfm::surf_align16(desc_bytes));
+    esfm::SurfBlk *d_br = reinterpret_cast<esfm::SurfBlk *>(reinterpret_cast<uint8_t *>(d_bw) + bw_bytes);
     ESFM_HIP_TRY(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
     ESFM_HIP_TRY(hipMemcpyAsync(d_cand, kps.data(), sizeof(SurfKeypoint) * (size_t)n_kp, hipMemcpyHostToDevice, st));
     ESFM_HIP_TRY(hipMemcpyAsync(d_off, win_off.data(), off_bytes, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(d_order, order.data(), sizeof(int32_t) * (size_t)n_kp, hipMemcpyHostToDevice, st));
-    if (int rc = esfm::launch_surf_describe(st, d_P, d_T, d_gray, d_sum, d_cand, n_kp, d_off, d_order, d_win, d_desc, ctx)) return rc;
+    if (!blk_win.empty()) ESFM_HIP_TRY(hipMemcpyAsync(d_bw, blk_win.data(), sizeof(esfm::SurfBlk) * blk_win.size(), hipMemcpyHostToDevice, st));
+    if (!blk_row.empty()) ESFM_HIP_TRY(hipMemcpyAsync(d_br, blk_row.data(), sizeof(esfm::SurfBlk) * blk_row.size(), hipMemcpyHostToDevice, st));
+    if (int rc = esfm::launch_surf_describe(st, d_P, d_T, d_gray, d_sum, d_cand, n_kp, d_off, d_bw, (int)blk_win.size(), d_br, (int)blk_row.size(), d_win,
+                                            d_desc, ctx)) return rc;
     std::vector<float> desc(64 * (size_t)n_kp);
     ESFM_HIP_TRY(hipMemcpyAsync(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_kp, hipMemcpyDeviceToHost, st));
     ESFM_HIP_TRY(hipMemcpyAsync(desc.data(), d_desc, desc_bytes, hipMemcpyDeviceToHost, st));

@@ -9,8 +9,10 @@
 //   surf_integral_*_kernel    32-bit integral image, one row / column larger than the image (row scan, then column scan)
 //   surf_det_trace_kernel     box-filter Hessian determinant and trace of every pyramid layer (one thread per sample)
 //   surf_maxima_kernel        3 x 3 x 3 non-maximum suppression + quadratic refinement on the middle layers
-//   surf_describe_kernel      one workgroup per keypoint: dominant orientation, rotated window, area shrink to 21 x 21,
-//                             weighted gradients, 4 x 4 x 4 sums, normalisation
+//   surf_orient_kernel        one workgroup per keypoint: dominant orientation, start of every row of the rotated window
+//   surf_window_kernel        rotated window, one thread per chunk of a window row (all keypoints in one grid)
+//   surf_rowsum_kernel        horizontal pass of the area shrink to 21 x 21, one thread per (window row, output column)
+//   surf_vector_kernel        one workgroup per keypoint: vertical pass, weighted gradients, 4 x 4 x 4 sums, normalisation
 #include "surf_kernels.hpp"
 
 #include <float.h>
@@ -175,29 +177,36 @@ __global__ __launch_bounds__(256) void surf_maxima_kernel(const SurfParams *__re
     if (slot < P->max_candidates) cand[slot] = kp;
 }
 
-// One wave per keypoint (SURFInvoker::operator()).
-constexpr int kSurfDescThreads = 1024;   // a keypoint's window holds up to 633 x 633 samples: the widest workgroup
-__global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
-                                                           const uint8_t *__restrict__ gray, const int32_t *__restrict__ sum,
-                                                           SurfKeypoint *__restrict__ kps, const int64_t *__restrict__ win_offset,
-                                                           const int32_t *__restrict__ order, uint8_t *__restrict__ win_scratch,
-                                                           float *__restrict__ desc)
+// ---- descriptors (SURFInvoker::operator()) in four launches.  A keypoint's window holds up to 633 x 633 samples and the widest
+// windows of an image hold most of its samples: with one workgroup per keypoint (rounds 2 - 5) a launch lasted as long as ONE
+// compute unit needed for the widest window (fountain image: 607 x 607 samples x ~80 instructions = 0.4 of the 0.53 ms), with the
+// rest of the chip idle.  Now the per-sample stages are spread over the chip by ITEMS (a chunk of a window row; a row sum), looked
+// up through host-built block tables; the per-keypoint stages (orientation; 21 x 21 patch -> 64 floats) are one narrow
+// workgroup each.  Every position / sum that OpenCV forms sequentially is still formed sequentially by one thread, on the same
+// operands in the same order: the split changes who computes what, not a single bit.
+//   per-keypoint scratch (win_offset[k]):  window bytes | 21 row sums per window row (float) | (x, y) start of every window row (float)
+__device__ __forceinline__ float *surf_rowsum_ptr(uint8_t *win, int win_size) { return reinterpret_cast<float *>(win + surf_align16((size_t)win_size * win_size)); }
+__device__ __forceinline__ float *surf_start_ptr(uint8_t *win, int win_size)
+{
+    return reinterpret_cast<float *>(win + surf_align16((size_t)win_size * win_size) + surf_align16(sizeof(float) * (kSurfPatch + 1) * (size_t)win_size));
+}
+
+// (1) dominant orientation + the window rows' start positions: one workgroup of 128 per keypoint
+constexpr int kSurfOriThreads = 128;
+__global__ __launch_bounds__(kSurfOriThreads) void surf_orient_kernel(const SurfParams *__restrict__ P, const SurfDescTables *__restrict__ T,
+                                                                      const int32_t *__restrict__ sum, SurfKeypoint *__restrict__ kps,
+                                                                      const int64_t *__restrict__ win_offset, uint8_t *__restrict__ win_scratch)
 {
     __shared__ float sX[kSurfOriSamples], sY[kSurfOriSamples], sAng[kSurfOriSamples];
     __shared__ float sMod[72], sSumX[72], sSumY[72];
-    __shared__ float sStartX[1024], sStartY[1024];
-    __shared__ uint8_t sPatch[kSurfPatch + 1][kSurfPatch + 1];
-    __shared__ float sDX[kSurfPatch][kSurfPatch], sDY[kSurfPatch][kSurfPatch];
-    __shared__ float sVec[64];
     __shared__ float sDir;
     __shared__ int sN;
-    const int k = order[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // largest windows first: they set the kernel's length
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SurfKeypoint kp = kps[k];
     const int rows = P->rows, cols = P->cols, sr = rows + 1, sc = cols + 1;
     const float s = kp.size * 1.2f / 9.0f;
     const int grad_wav_size = 2 * cv_round_f(2 * s);
     if (sr < grad_wav_size || sc < grad_wav_size) { if (tid == 0) kps[k].valid = 0; return; }
-    // ---- dominant orientation
     SurfHF dx_t[2], dy_t[2];
     {
         const int gx[2][5] = {{0, 0, 2, 4, -1}, {2, 0, 4, 4, 1}}, gy[2][5] = {{0, 0, 4, 2, 1}, {0, 2, 4, 4, -1}};
@@ -213,29 +222,29 @@ __global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const S
     }
     int nangle = 0;
     if (wave == 0) {   // one wave: the ballot compaction keeps the sample order, in which the window sums below add
-    for (int base = 0; base < T->n_ori; base += 64) {
-        const int kk = base + lane;
-        bool ok = false;
-        float vx = 0.f, vy = 0.f;
-        if (kk < T->n_ori) {
-            const int x = cv_round_f(kp.x + T->aptx[kk] * s - (float)(grad_wav_size - 1) / 2), y = cv_round_f(kp.y + T->apty[kk] * s - (float)(grad_wav_size - 1) / 2);
-            ok = !(y < 0 || y >= sr - grad_wav_size || x < 0 || x >= sc - grad_wav_size);
-            if (ok) {
-                const int32_t *ptr = sum + (size_t)y * sc + x;
-                vx = calc_haar(ptr, dx_t, 2) * T->aptw[kk]; vy = calc_haar(ptr, dy_t, 2) * T->aptw[kk];
+        for (int base = 0; base < T->n_ori; base += 64) {
+            const int kk = base + lane;
+            bool ok = false;
+            float vx = 0.f, vy = 0.f;
+            if (kk < T->n_ori) {
+                const int x = cv_round_f(kp.x + T->aptx[kk] * s - (float)(grad_wav_size - 1) / 2), y = cv_round_f(kp.y + T->apty[kk] * s - (float)(grad_wav_size - 1) / 2);
+                ok = !(y < 0 || y >= sr - grad_wav_size || x < 0 || x >= sc - grad_wav_size);
+                if (ok) {
+                    const int32_t *ptr = sum + (size_t)y * sc + x;
+                    vx = calc_haar(ptr, dx_t, 2) * T->aptw[kk]; vy = calc_haar(ptr, dy_t, 2) * T->aptw[kk];
+                }
             }
+            const unsigned long long m = __ballot(ok);
+            const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok) { sX[pos] = vx; sY[pos] = vy; sAng[pos] = fast_atan2(vy, vx); }
+            nangle += __popcll(m);
         }
-        const unsigned long long m = __ballot(ok);
-        const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
-        if (ok) { sX[pos] = vx; sY[pos] = vy; sAng[pos] = fast_atan2(vy, vx); }
-        nangle += __popcll(m);
-    }
-    if (lane == 0) sN = nangle;
+        if (lane == 0) sN = nangle;
     }
     __syncthreads();
     nangle = sN;
     if (nangle == 0) { if (tid == 0) kps[k].valid = 0; return; }
-    for (int w = tid; w < 72; w += kSurfDescThreads) {
+    for (int w = tid; w < 72; w += kSurfOriThreads) {
         const int i = 5 * w;
         float sumx = 0.f, sumy = 0.f;
         for (int j = 0; j < nangle; ++j) {
@@ -252,79 +261,147 @@ __global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const S
         kps[k].angle = sDir;
     }
     __syncthreads();
-    // ---- rotated window of (int)(21 s) pixels, bilinear.  OpenCV walks each row with double accumulators (pixel_x += cos, pixel_y
-    // -= sin); a row is cut into chunks and the thread of a chunk first replays the additions up to its start, so every position
-    // is the same sum of the same terms in the same order, and a keypoint's 256 threads share its (up to 600 x 600) window
+    // start of every row of the rotated window: OpenCV walks them with float accumulators (start_x += sin, start_y += cos) -- four
+    // threads share the walk only in the sense that each replays it up to its own first row
     const int win_size = (int)((kSurfPatch + 1) * s);
-    uint8_t *win = win_scratch + win_offset[k];
+    float *start = surf_start_ptr(win_scratch + win_offset[k], win_size);
     const float ddir = sDir * (float)(3.14159265358979323846 / 180);
     const float sin_dir = -(float)sin((double)ddir), cos_dir = (float)cos((double)ddir);
-    if (tid == 0) {
-        const float win_off = -(float)(win_size - 1) / 2;
-        float sx = kp.x + win_off * cos_dir + win_off * sin_dir, sy = kp.y - win_off * sin_dir + win_off * cos_dir;
-        for (int i = 0; i < win_size; ++i, sx += sin_dir, sy += cos_dir) { sStartX[i] = sx; sStartY[i] = sy; }
+    {
+        const int per = (win_size + kSurfOriThreads - 1) / kSurfOriThreads, i0 = tid * per, i1 = i0 + per < win_size ? i0 + per : win_size;
+        if (i0 < win_size) {
+            const float win_off = -(float)(win_size - 1) / 2;
+            float sx = kp.x + win_off * cos_dir + win_off * sin_dir, sy = kp.y - win_off * sin_dir + win_off * cos_dir;
+            for (int i = 0; i < i0; ++i) { sx += sin_dir; sy += cos_dir; }
+            for (int i = i0; i < i1; ++i, sx += sin_dir, sy += cos_dir) { start[2 * i] = sx; start[2 * i + 1] = sy; }
+        }
     }
-    __syncthreads();
+}
+
+// (2) rotated window of (int)(21 s) pixels, bilinear.  OpenCV walks each row with double accumulators (pixel_x += cos, pixel_y
+// -= sin); a row is cut into chunks of about kSurfWinChunk samples and the thread of a chunk first replays the additions up to its
+// start, so every position is the same sum of the same terms in the same order.  One thread per chunk, chunks of all keypoints
+// in one grid (block table: 256 consecutive chunks of one keypoint).
+__global__ __launch_bounds__(256) void surf_window_kernel(const SurfParams *__restrict__ P, const uint8_t *__restrict__ gray,
+                                                          const SurfKeypoint *__restrict__ kps, const int64_t *__restrict__ win_offset,
+                                                          const SurfBlk *__restrict__ blks, uint8_t *__restrict__ win_scratch)
+{
+    const SurfBlk bk = blks[blockIdx.x];
+    const int k = bk.k, item = bk.first + (int)threadIdx.x;
+    const SurfKeypoint kp = kps[k];
+    if (!kp.valid) return;
+    const int rows = P->rows, cols = P->cols;
+    const float s = kp.size * 1.2f / 9.0f;
+    const int win_size = (int)((kSurfPatch + 1) * s);
+    const int nch = surf_window_chunks(win_size), clen = (win_size + nch - 1) / nch;
+    if (item >= win_size * nch) return;
+    uint8_t *win = win_scratch + win_offset[k];
+    const float *start = surf_start_ptr(win, win_size);
+    const float ddir = kp.angle * (float)(3.14159265358979323846 / 180);
+    const float sin_dir = -(float)sin((double)ddir), cos_dir = (float)cos((double)ddir);
     const int ncols1 = cols - 1, nrows1 = rows - 1;
-    {
-        int nch = (4 * kSurfDescThreads + win_size / 2) / win_size;           // about four work items per thread
-        nch = nch < 1 ? 1 : (nch > 16 ? 16 : nch);
-        const int clen = (win_size + nch - 1) / nch;
-        for (int item = tid; item < win_size * nch; item += kSurfDescThreads) {
-            const int i = item / nch, j0 = (item % nch) * clen, j1 = j0 + clen < win_size ? j0 + clen : win_size;
-            double pixel_x = sStartX[i], pixel_y = sStartY[i];
-            for (int j = 0; j < j0; ++j) { pixel_x += cos_dir; pixel_y -= sin_dir; }
-            uint8_t *wrow = win + (size_t)i * win_size;
-            for (int j = j0; j < j1; ++j, pixel_x += cos_dir, pixel_y -= sin_dir) {
-                const int ix = (int)floor(pixel_x), iy = (int)floor(pixel_y);
-                if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
-                    const float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
-                    const uint8_t *p = gray + (size_t)iy * cols + ix;
-                    wrow[j] = (uint8_t)cv_round_f(p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) + p[cols] * (1.f - a) * b + p[cols + 1] * a * b);
-                } else {
-                    int x = (int)rint(pixel_x), y = (int)rint(pixel_y);
-                    x = x < 0 ? 0 : (x > ncols1 ? ncols1 : x); y = y < 0 ? 0 : (y > nrows1 ? nrows1 : y);
-                    wrow[j] = gray[(size_t)y * cols + x];
-                }
-            }
+    const int i = item / nch, j0 = (item % nch) * clen, j1 = j0 + clen < win_size ? j0 + clen : win_size;
+    double pixel_x = start[2 * i], pixel_y = start[2 * i + 1];
+    for (int j = 0; j < j0; ++j) { pixel_x += cos_dir; pixel_y -= sin_dir; }
+    uint8_t *wrow = win + (size_t)i * win_size;
+    // The lanes of a wave sit a chunk apart: every memory instruction touches 64 cache lines, and the kernel is bound by how many of
+    // them (and how much f64 position arithmetic) it issues -- so a sample's four taps are two 16-bit loads (any alignment) and
+    // four samples leave in one 32-bit store.  Measured and not kept: eight positions per trip with their taps requested together
+    // (59 -> 82 us: more instructions, and latency was not what it waited for); chunk-major items, equal replay lengths in a wave
+    // (59 -> 107 us: the lanes' stores and taps then lie a whole window row apart).
+    auto sample = [&](double px, double py) -> uint32_t {
+        const int ix = (int)floor(px), iy = (int)floor(py);
+        if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+            const float a = (float)(px - ix), b = (float)(py - iy);
+            const uint8_t *p = gray + (size_t)iy * cols + ix;
+            uint16_t u0, u1;
+            __builtin_memcpy(&u0, p, 2); __builtin_memcpy(&u1, p + cols, 2);
+            const int p00 = u0 & 255, p01 = u0 >> 8, p10 = u1 & 255, p11 = u1 >> 8;
+            return (uint32_t)(uint8_t)cv_round_f(p00 * (1.f - a) * (1.f - b) + p01 * a * (1.f - b) + p10 * (1.f - a) * b + p11 * a * b);
         }
+        int x = (int)rint(px), y = (int)rint(py);
+        x = x < 0 ? 0 : (x > ncols1 ? ncols1 : x); y = y < 0 ? 0 : (y > nrows1 ? nrows1 : y);
+        return gray[(size_t)y * cols + x];
+    };
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u, pixel_x += cos_dir, pixel_y -= sin_dir) v |= sample(pixel_x, pixel_y) << (8 * u);
+        __builtin_memcpy(wrow + j, &v, 4);
     }
-    __threadfence_block();
-    __syncthreads();
-    // ---- INTER_AREA shrink to 21 x 21: out = sum_y beta_y (sum_x alpha_x S[y][x]), one lane per output pixel
-    {
-        const int D = kSurfPatch + 1;
-        const double scale = (double)win_size / D;
-        auto cell_of = [&](int dd, int &s1, int &s2, float &a_first, float &a_mid, float &a_last, bool &has_first, bool &has_last) {
-            const double f1 = dd * scale, f2 = f1 + scale, cell = fmin(scale, win_size - f1);
-            s1 = (int)ceil(f1); s2 = (int)floor(f2);
-            s2 = s2 < win_size - 1 ? s2 : win_size - 1; s1 = s1 < s2 ? s1 : s2;
-            has_first = s1 - f1 > 1e-3; has_last = f2 - s2 > 1e-3;
-            a_first = (float)((s1 - f1) / cell); a_mid = (float)(1.0 / cell); a_last = (float)(fmin(fmin(f2 - s2, 1.), cell) / cell);
-        };
-        for (int o = tid; o < D * D; o += kSurfDescThreads) {
-            const int dy = o / D, dx = o % D;
-            int x1, x2, y1, y2; float axf, axm, axl, ayf, aym, ayl; bool hxf, hxl, hyf, hyl;
-            cell_of(dx, x1, x2, axf, axm, axl, hxf, hxl);
-            cell_of(dy, y1, y2, ayf, aym, ayl, hyf, hyl);
-            float acc = 0.f;
-            auto row_sum = [&](int sy) {
-                const uint8_t *row = win + (size_t)sy * win_size;
-                float buf = 0.f;
-                if (hxf) buf += row[x1 - 1] * axf;
-                for (int sx = x1; sx < x2; ++sx) buf += row[sx] * axm;
-                if (hxl) buf += row[x2] * axl;
-                return buf;
-            };
-            if (hyf) acc += row_sum(y1 - 1) * ayf;
-            for (int sy = y1; sy < y2; ++sy) acc += row_sum(sy) * aym;
-            if (hyl) acc += row_sum(y2) * ayl;
-            int v = cv_round_f(acc);
-            sPatch[dy][dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-        }
+    for (; j < j1; ++j, pixel_x += cos_dir, pixel_y -= sin_dir) wrow[j] = (uint8_t)sample(pixel_x, pixel_y);
+}
+
+// INTER_AREA shrink of the window to 21 x 21: out = sum_y beta_y (sum_x alpha_x S[y][x]).  cell d of an axis covers the source
+// interval [d scale, (d + 1) scale): a fractional first sample, whole samples s1 .. s2 - 1, a fractional last one
+struct SurfCell { int s1, s2; float a_first, a_mid, a_last; bool has_first, has_last; };
+__device__ __forceinline__ SurfCell surf_area_cell(int dd, int win_size)
+{
+    const int D = kSurfPatch + 1;
+    const double scale = (double)win_size / D;
+    const double f1 = dd * scale, f2 = f1 + scale, cell = fmin(scale, win_size - f1);
+    SurfCell c;
+    c.s1 = (int)ceil(f1); c.s2 = (int)floor(f2);
+    c.s2 = c.s2 < win_size - 1 ? c.s2 : win_size - 1; c.s1 = c.s1 < c.s2 ? c.s1 : c.s2;
+    c.has_first = c.s1 - f1 > 1e-3; c.has_last = f2 - c.s2 > 1e-3;
+    c.a_first = (float)((c.s1 - f1) / cell); c.a_mid = (float)(1.0 / cell); c.a_last = (float)(fmin(fmin(f2 - c.s2, 1.), cell) / cell);
+    return c;
+}
+
+// (3) the shrink's horizontal pass: one thread per (window row, output column) forms that row's weighted sum sequentially, as
+// OpenCV's row pass does (21 of them per window row, whichever output rows use them)
+__global__ __launch_bounds__(256) void surf_rowsum_kernel(const SurfKeypoint *__restrict__ kps, const int64_t *__restrict__ win_offset,
+                                                          const SurfBlk *__restrict__ blks, uint8_t *__restrict__ win_scratch)
+{
+    const int D = kSurfPatch + 1;
+    const SurfBlk bk = blks[blockIdx.x];
+    const int k = bk.k, item = bk.first + (int)threadIdx.x;
+    const SurfKeypoint kp = kps[k];
+    if (!kp.valid) return;
+    const float s = kp.size * 1.2f / 9.0f;
+    const int win_size = (int)((kSurfPatch + 1) * s);
+    if (item >= win_size * D) return;
+    uint8_t *win = win_scratch + win_offset[k];
+    const int sy = item / D, dx = item % D;
+    const SurfCell c = surf_area_cell(dx, win_size);
+    const uint8_t *row = win + (size_t)sy * win_size;
+    float buf = 0.f;
+    if (c.has_first) buf += row[c.s1 - 1] * c.a_first;
+    for (int sx = c.s1; sx < c.s2; ++sx) buf += row[sx] * c.a_mid;
+    if (c.has_last) buf += row[c.s2] * c.a_last;
+    surf_rowsum_ptr(win, win_size)[item] = buf;
+}
+
+// (4) vertical pass -> 21 x 21 patch, weighted gradients, 4 x 4 x 4 sums, normalisation: one workgroup per keypoint
+constexpr int kSurfVecThreads = 512;     // 441 output pixels, each a sequential sum over its window rows
+__global__ __launch_bounds__(kSurfVecThreads) void surf_vector_kernel(const SurfDescTables *__restrict__ T, const SurfKeypoint *__restrict__ kps,
+                                                                      const int64_t *__restrict__ win_offset, uint8_t *__restrict__ win_scratch,
+                                                                      float *__restrict__ desc)
+{
+    __shared__ uint8_t sPatch[kSurfPatch + 1][kSurfPatch + 1];
+    __shared__ float sDX[kSurfPatch][kSurfPatch], sDY[kSurfPatch][kSurfPatch];
+    __shared__ float sVec[64];
+    __shared__ float sInv;
+    const int D = kSurfPatch + 1;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const SurfKeypoint kp = kps[k];
+    if (!kp.valid) return;
+    const float s = kp.size * 1.2f / 9.0f;
+    const int win_size = (int)((kSurfPatch + 1) * s);
+    const float *rsum = surf_rowsum_ptr(win_scratch + win_offset[k], win_size);
+    for (int o = tid; o < D * D; o += kSurfVecThreads) {
+        const int dy = o / D, dx = o % D;
+        const SurfCell c = surf_area_cell(dy, win_size);
+        float acc = 0.f;
+        if (c.has_first) acc += rsum[(c.s1 - 1) * D + dx] * c.a_first;
+        for (int sy = c.s1; sy < c.s2; ++sy) acc += rsum[sy * D + dx] * c.a_mid;
+        if (c.has_last) acc += rsum[c.s2 * D + dx] * c.a_last;
+        const int v = cv_round_f(acc);
+        sPatch[dy][dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
     __syncthreads();
-    for (int o = tid; o < kSurfPatch * kSurfPatch; o += kSurfDescThreads) {
+    for (int o = tid; o < kSurfPatch * kSurfPatch; o += kSurfVecThreads) {
         const int i = o / kSurfPatch, j = o % kSurfPatch;
         const float dw = T->DW[o];
         sDX[i][j] = (sPatch[i][j + 1] - sPatch[i][j] + sPatch[i + 1][j + 1] - sPatch[i + 1][j]) * dw;
@@ -342,10 +419,10 @@ __global__ __launch_bounds__(kSurfDescThreads) void surf_describe_kernel(const S
     if (tid == 0) {
         double square_mag = 0.0;
         for (int q = 0; q < 64; ++q) square_mag += sVec[q] * sVec[q];
-        sDir = (float)(1. / (sqrt(square_mag) + DBL_EPSILON));
+        sInv = (float)(1. / (sqrt(square_mag) + DBL_EPSILON));
     }
     __syncthreads();
-    if (tid < 64) desc[64 * (size_t)k + tid] = sVec[tid] * sDir;
+    if (tid < 64) desc[64 * (size_t)k + tid] = sVec[tid] * sInv;
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
@@ -389,12 +466,17 @@ int launch_surf_maxima(hipStream_t st, const SurfParams *params_dev, const SurfP
 }
 
 int launch_surf_describe(hipStream_t st, const SurfParams *params_dev, const SurfDescTables *tables_dev, const uint8_t *gray, const int32_t *sum,
-                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, const int32_t *order, uint8_t *win_scratch, float *desc,
-                         esfm_ctx *timing_ctx)
+                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, const SurfBlk *win_blocks, int n_win_blocks,
+                         const SurfBlk *row_blocks, int n_row_blocks, uint8_t *win_scratch, float *desc, esfm_ctx *timing_ctx)
 {
     if (n_kp <= 0) return ESFM_OK;
-    KernelTimer tm(timing_ctx, ESFM_K_SURF_DESC);
-    hipLaunchKernelGGL(surf_describe_kernel, dim3(n_kp), dim3(kSurfDescThreads), 0, st, params_dev, tables_dev, gray, sum, kps, win_offset, order, win_scratch, desc);
+    KernelTimer tm(timing_ctx, ESFM_K_SURF_DESC);     // (the four launches together)
+    hipLaunchKernelGGL(surf_orient_kernel, dim3(n_kp), dim3(kSurfOriThreads), 0, st, params_dev, tables_dev, sum, kps, win_offset, win_scratch);
+    if (n_win_blocks > 0)
+        hipLaunchKernelGGL(surf_window_kernel, dim3(n_win_blocks), dim3(256), 0, st, params_dev, gray, kps, win_offset, win_blocks, win_scratch);
+    if (n_row_blocks > 0)
+        hipLaunchKernelGGL(surf_rowsum_kernel, dim3(n_row_blocks), dim3(256), 0, st, kps, win_offset, row_blocks, win_scratch);
+    hipLaunchKernelGGL(surf_vector_kernel, dim3(n_kp), dim3(kSurfVecThreads), 0, st, tables_dev, kps, win_offset, win_scratch, desc);
     LAUNCH_OK();
     return ESFM_OK;
 }

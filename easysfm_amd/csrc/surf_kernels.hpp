@@ -40,7 +40,17 @@ int launch_surf_det_trace(hipStream_t st, const SurfParams *params_dev, const Su
                           esfm_ctx *timing_ctx);
 int launch_surf_maxima(hipStream_t st, const SurfParams *params_dev, const SurfParams &params_host, const float *det, const float *trace,
                        SurfKeypoint *cand, int32_t *n_cand);
+// per-keypoint descriptor scratch: window bytes | 21 row sums per window row | (x, y) start of every window row
+struct SurfBlk { int32_t k, first; };          // a 256-thread block of a keypoint's item list: the keypoint, the block's first item
+constexpr int kSurfWinChunk = 48;              // samples of a window row per work item (about)
+__host__ __device__ inline size_t surf_align16(size_t n) { return (n + 15) / 16 * 16; }
+__host__ __device__ inline int surf_window_chunks(int win_size) { return win_size <= 0 ? 1 : (win_size + kSurfWinChunk - 1) / kSurfWinChunk; }
+__host__ __device__ inline size_t surf_scratch_bytes(int win_size)
+{
+    return surf_align16((size_t)win_size * win_size) + surf_align16(sizeof(float) * (kSurfPatch + 1) * (size_t)win_size) + surf_align16(sizeof(float) * 2 * (size_t)win_size);
+}
 int launch_surf_describe(hipStream_t st, const SurfParams *params_dev, const SurfDescTables *tables_dev, const uint8_t *gray, const int32_t *sum,
-                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, const int32_t *order, uint8_t *win_scratch, float *desc, esfm_ctx *timing_ctx);
+                         SurfKeypoint *kps, int n_kp, const int64_t *win_offset, const SurfBlk *win_blocks, int n_win_blocks,
+                         const SurfBlk *row_blocks, int n_row_blocks, uint8_t *win_scratch, float *desc, esfm_ctx *timing_ctx);
 
 }  // namespace esfm
