@@ -188,9 +188,9 @@ int plan_reduced_structure(esfm_ba_problem *P, Solver &S, bool multi)
             double *dev = nullptr;
             ESFM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(double) * std::max<size_t>(nd, 1)));
             int rc = ESFM_OK;
-            if (hipMemcpyAsync(dev, pk.data(), sizeof(double) * nd, hipMemcpyHostToDevice, S.st) != hipSuccess || hipStreamSynchronize(S.st) != hipSuccess) rc = ESFM_ERR_HIP;
+            if (esfm::copy_h2d(dev, pk.data(), sizeof(double) * nd, S.st) != hipSuccess || hipStreamSynchronize(S.st) != hipSuccess) rc = ESFM_ERR_HIP;
             if (rc == ESFM_OK) rc = S.allreduce(dev, (int64_t)nd, ESFM_REDUCE_SUM);
-            if (rc == ESFM_OK && (hipMemcpyAsync(pk.data(), dev, sizeof(double) * nd, hipMemcpyDeviceToHost, S.st) != hipSuccess || hipStreamSynchronize(S.st) != hipSuccess)) rc = ESFM_ERR_HIP;
+            if (rc == ESFM_OK && (esfm::copy_d2h(pk.data(), dev, sizeof(double) * nd, S.st) != hipSuccess || hipStreamSynchronize(S.st) != hipSuccess)) rc = ESFM_ERR_HIP;
             (void)hipFree(dev);
             if (rc != ESFM_OK) { if (rc == ESFM_ERR_HIP) esfm::set_error("exchange of the camera co-visibility failed"); return rc; }
             all.assign(nf, 0);
@@ -210,7 +210,7 @@ int fill_ones(hipStream_t st, double *dst, size_t n)
 {
     std::vector<double> ones(n, 1.0);
     if (n == 0) return ESFM_OK;
-    ESFM_HIP_TRY(hipMemcpyAsync(dst, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(dst, ones.data(), sizeof(double) * n, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
 }
@@ -475,7 +475,7 @@ int create_impl(esfm_ctx *ctx, int n_real, int n_pt, int n_obs, const int32_t *c
     hipStream_t st = ctx->stream;
     auto up = [&](void *dst, const void *src, size_t bytes) {
         if (rc == ESFM_OK && bytes) {
-            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+            hipError_t e = esfm::copy_h2d(dst, src, bytes, st);
             if (e != hipSuccess) { esfm::set_error("hipMemcpyAsync H2D failed: %s", hipGetErrorString(e)); rc = ESFM_ERR_HIP; }
         }
     };
@@ -548,7 +548,7 @@ int esfm_ba_problem_set_calib(esfm_ba_problem *P, const double *calib4, double c
     if (int rc = esfm::set_device(P->ctx)) return rc;
     for (int i = 0; i < 4; ++i) P->calib_center[i] = calib4[i];
     P->calib_tol = calib_tolerance;
-    ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_c + 6 * (size_t)P->d.n_real_cam, calib4, sizeof(double) * 4, hipMemcpyHostToDevice, P->ctx->stream));
+    ESFM_HIP_TRY(esfm::copy_h2d(P->d.x_c + 6 * (size_t)P->d.n_real_cam, calib4, sizeof(double) * 4, P->ctx->stream));
     ESFM_HIP_TRY(hipStreamSynchronize(P->ctx->stream));
     return ESFM_OK;
 }
@@ -558,7 +558,7 @@ int esfm_ba_problem_get_calib(esfm_ba_problem *P, double *calib4)
     if (!P || !calib4) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
     ESFM_REQUIRE(P->d.has_calib, "problem was created with fixed intrinsics");
     if (int rc = esfm::set_device(P->ctx)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(calib4, P->d.x_c + 6 * (size_t)P->d.n_real_cam, sizeof(double) * 4, hipMemcpyDeviceToHost, P->ctx->stream));
+    ESFM_HIP_TRY(esfm::copy_d2h(calib4, P->d.x_c + 6 * (size_t)P->d.n_real_cam, sizeof(double) * 4, P->ctx->stream));
     ESFM_HIP_TRY(hipStreamSynchronize(P->ctx->stream));
     return ESFM_OK;
 }
@@ -589,8 +589,8 @@ int esfm_ba_problem_set_params(esfm_ba_problem *P, const double *cams, const dou
     if (!P || (!cams && P->d.n_real_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(P->ctx)) return rc;
     hipStream_t st = P->ctx->stream;
-    if (P->d.n_real_cam) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_c, cams, sizeof(double) * 6 * (size_t)P->d.n_real_cam, hipMemcpyHostToDevice, st));
-    if (P->d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(P->d.x_p, pts, sizeof(double) * 3 * (size_t)P->d.n_pt, hipMemcpyHostToDevice, st));
+    if (P->d.n_real_cam) ESFM_HIP_TRY(esfm::copy_h2d(P->d.x_c, cams, sizeof(double) * 6 * (size_t)P->d.n_real_cam, st));
+    if (P->d.n_pt) ESFM_HIP_TRY(esfm::copy_h2d(P->d.x_p, pts, sizeof(double) * 3 * (size_t)P->d.n_pt, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
 }
@@ -600,8 +600,8 @@ int esfm_ba_problem_get_params(esfm_ba_problem *P, double *cams, double *pts)
     if (!P || (!cams && P->d.n_real_cam) || (!pts && P->d.n_pt)) { esfm::set_error("NULL argument"); return ESFM_ERR_INVALID_ARG; }
     if (int rc = esfm::set_device(P->ctx)) return rc;
     hipStream_t st = P->ctx->stream;
-    if (P->d.n_real_cam) ESFM_HIP_TRY(hipMemcpyAsync(cams, P->d.x_c, sizeof(double) * 6 * (size_t)P->d.n_real_cam, hipMemcpyDeviceToHost, st));
-    if (P->d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(pts, P->d.x_p, sizeof(double) * 3 * (size_t)P->d.n_pt, hipMemcpyDeviceToHost, st));
+    if (P->d.n_real_cam) ESFM_HIP_TRY(esfm::copy_d2h(cams, P->d.x_c, sizeof(double) * 6 * (size_t)P->d.n_real_cam, st));
+    if (P->d.n_pt) ESFM_HIP_TRY(esfm::copy_d2h(pts, P->d.x_p, sizeof(double) * 3 * (size_t)P->d.n_pt, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
 }
@@ -627,7 +627,7 @@ int esfm_ba_problem_cost(esfm_ba_problem *P, double cauchy_a, double *cost)
     if (int rc = esfm::ba_cost(st, P->d, P->ctx->num_cu, P->d.x_c, P->d.x_p, cauchy_a, esfm::SC_CAND_COST, esfm::SC_CAND_BAD)) return rc;
     if (int rc = esfm::ba_scal_reduce(st, P->d)) return rc;
     double h[esfm::SC_COUNT];
-    ESFM_HIP_TRY(hipMemcpyAsync(h, P->d.scal, sizeof(h), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(h, P->d.scal, sizeof(h), st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     *cost = h[esfm::SC_CAND_BAD] > 0.0 ? DBL_MAX : h[esfm::SC_CAND_COST];
     return ESFM_OK;
@@ -660,7 +660,7 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     if (multi && !d.red_packed) { if (int rc = dev_alloc(P, &d.red_packed, esfm::ba_red_packed_doubles(d.n_cam))) return rc; }
 
     // camera observation counts over all shards; Jacobi scaling starts at 1
-    if (d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(d.cam_nobs, P->cam_nobs_local.data(), sizeof(double) * (size_t)d.n_cam, hipMemcpyHostToDevice, st));
+    if (d.n_cam) ESFM_HIP_TRY(esfm::copy_h2d(d.cam_nobs, P->cam_nobs_local.data(), sizeof(double) * (size_t)d.n_cam, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     if (int rc = S.allreduce(d.cam_nobs, d.n_cam, ESFM_REDUCE_SUM)) return rc;
     if (int rc = plan_reduced_structure(P, S, multi)) return rc;
@@ -669,9 +669,9 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     if (multi && d.n_pt) ESFM_HIP_TRY(hipMemcpyAsync(d.x0_p, d.x_p, sizeof(double) * 3 * (size_t)d.n_pt, hipMemcpyDeviceToDevice, st));
     {
         std::vector<double> cn((size_t)d.n_cam);
-        if (d.n_cam) ESFM_HIP_TRY(hipMemcpyAsync(cn.data(), d.cam_nobs, sizeof(double) * (size_t)d.n_cam, hipMemcpyDeviceToHost, st));
+        if (d.n_cam) ESFM_HIP_TRY(esfm::copy_d2h(cn.data(), d.cam_nobs, sizeof(double) * (size_t)d.n_cam, st));
         std::vector<int32_t> ps((size_t)d.n_pt + 1);
-        ESFM_HIP_TRY(hipMemcpyAsync(ps.data(), d.pt_start, sizeof(int32_t) * ((size_t)d.n_pt + 1), hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(ps.data(), d.pt_start, sizeof(int32_t) * ((size_t)d.n_pt + 1), st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         for (int c = 0; c < d.n_real_cam; ++c) sum->num_active_cameras += cn[(size_t)c] > 0.0;
         for (int p = 0; p < d.n_pt; ++p) sum->num_active_points += ps[(size_t)p + 1] > ps[(size_t)p];
@@ -690,8 +690,8 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
             d.constrained = 1;
         }
         if (d.n_cam) {
-            ESFM_HIP_TRY(hipMemcpyAsync(d.lo_c, lo.data(), sizeof(double) * lo.size(), hipMemcpyHostToDevice, st));
-            ESFM_HIP_TRY(hipMemcpyAsync(d.up_c, up.data(), sizeof(double) * up.size(), hipMemcpyHostToDevice, st));
+            ESFM_HIP_TRY(esfm::copy_h2d(d.lo_c, lo.data(), sizeof(double) * lo.size(), st));
+            ESFM_HIP_TRY(esfm::copy_h2d(d.up_c, up.data(), sizeof(double) * up.size(), st));
             ESFM_HIP_TRY(hipStreamSynchronize(st));
         }
     }

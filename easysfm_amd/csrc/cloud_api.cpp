@@ -36,12 +36,12 @@ int esfm_sor_filter(esfm_ctx *ctx, const float *points, int n, int stride_floats
     const size_t in_bytes = sizeof(float) * (size_t)n * (size_t)stride_floats;
     if (int rc = ctx->stage_a.reserve(in_bytes)) return rc;
     if (int rc = ctx->stage_b.reserve(sizeof(float) * (size_t)n)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(ctx->stage_a.ptr, points, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ESFM_HIP_TRY(esfm::copy_h2d(ctx->stage_a.ptr, points, in_bytes, ctx->stream));
     if (int rc = esfm::launch_sor_knn_mean(ctx->stream, ctx->stage_a.as<float>(), n, stride_floats, mean_k, ctx->stage_b.as<float>(), ctx)) return rc;
     std::vector<float> local;
     float *md = mean_dist;
     if (!md) { local.resize((size_t)n); md = local.data(); }
-    ESFM_HIP_TRY(hipMemcpyAsync(md, ctx->stage_b.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    ESFM_HIP_TRY(esfm::copy_d2h(md, ctx->stage_b.ptr, sizeof(float) * (size_t)n, ctx->stream));
     ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     // statistical_outlier_removal.hpp: mean and standard deviation of the distance vector, then the cut
     int valid = 0;

@@ -36,6 +36,33 @@ const char *get_error();
         }                                           \
     } while (0)
 
+// Host <-> device copies of caller-owned memory (ordered on `st` like hipMemcpyAsync; pageable memory makes them synchronous).
+// The HIP runtime PINS a pageable buffer of 1 MiB or more for the transfer -- a userptr registration with the kernel driver -- and
+// the driver stops every queue of the process while it re-validates such a registration after ordinary heap activity in the same
+// mapping (malloc / free trimming the heap): bin/sfm_native's 768 x 512 x 3 images (1.18 MB) stalled a third of the frames for
+// 20 - 38 ms each, ten times what their detection takes (scratch/e2e_hiplog.sh: the time sits inside hipMemcpyAsync; with
+// GPU_PINNED_MIN_XFER_SIZE raised the stalls are gone).  Pieces below that size go through the runtime's own staging buffer
+// instead, whatever the process' environment says.
+constexpr size_t kCopyPiece = 512u << 10;
+inline hipError_t copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st)
+{
+    for (size_t off = 0; off < bytes; off += kCopyPiece) {
+        const size_t n = bytes - off < kCopyPiece ? bytes - off : kCopyPiece;
+        const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst_dev) + off, static_cast<const char *>(src_host) + off, n, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+inline hipError_t copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st)
+{
+    for (size_t off = 0; off < bytes; off += kCopyPiece) {
+        const size_t n = bytes - off < kCopyPiece ? bytes - off : kCopyPiece;
+        const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst_host) + off, static_cast<const char *>(src_dev) + off, n, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // A grow-only device buffer (scratch reused across calls; 288 GB of HBM makes
 // holding on to the high-water mark the right trade).
 struct DevBuf {

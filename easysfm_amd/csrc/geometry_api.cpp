@@ -50,13 +50,13 @@ int esfm_triangulate_pairs(esfm_ctx *ctx, int n_pairs, const float *proj1, const
     if (int rc = ctx->stage_b.reserve(pb)) return rc;
     if (int rc = ctx->stage_c.reserve(sizeof(float) * 4 * (size_t)n_total)) return rc;
     if (int rc = ctx->stage_d.reserve(sizeof(HostJob) * jobs.size())) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(ctx->stage_a.ptr, pts1, pb, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(ctx->stage_b.ptr, pts2, pb, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(ctx->stage_d.ptr, jobs.data(), sizeof(HostJob) * jobs.size(), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(ctx->stage_a.ptr, pts1, pb, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(ctx->stage_b.ptr, pts2, pb, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(ctx->stage_d.ptr, jobs.data(), sizeof(HostJob) * jobs.size(), st));
     if (int rc = esfm::launch_triangulate(st, ctx->stage_d.ptr, (int)jobs.size(), ctx->stage_a.as<float>(), ctx->stage_b.as<float>(), n_total,
                                           ctx->stage_c.as<float>(), ctx))
         return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(points4d, ctx->stage_c.ptr, sizeof(float) * 4 * (size_t)n_total, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(points4d, ctx->stage_c.ptr, sizeof(float) * 4 * (size_t)n_total, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
 }

@@ -87,7 +87,7 @@ int upload_pairs(esfm_ctx *ctx, const PairPlan &plan, const PairDesc **dev_tab)
     if (int rc = ctx->pin(bytes)) return rc;
     if (int rc = ctx->pair_tab.reserve(bytes)) return rc;
     memcpy(ctx->pinned, blob.data(), bytes);
-    ESFM_HIP_TRY(hipMemcpyAsync(ctx->pair_tab.ptr, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ESFM_HIP_TRY(esfm::copy_h2d(ctx->pair_tab.ptr, ctx->pinned, bytes, ctx->stream));
     ctx->last_pair_bytes = bytes;
     *dev_tab = ctx->pair_tab.as<PairDesc>();
     return ESFM_OK;
@@ -130,7 +130,7 @@ int verify_prepared(esfm_ctx *ctx, esfm_metric metric, const void *desc_dev, int
     unsigned long long *sums = ctx->prep_sum.as<unsigned long long>();
     if (int rc = esfm::launch_buffer_checksum(ctx->stream, desc_dev, desc_bytes(metric, total_rows, width), sums + 1)) return rc;
     unsigned long long h[2] = {0ull, 0ull};
-    ESFM_HIP_TRY(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    ESFM_HIP_TRY(esfm::copy_d2h(h, sums, sizeof(h), ctx->stream));
     ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (h[0] == h[1]) return ESFM_OK;
     ctx->prep_desc = nullptr;
@@ -332,8 +332,8 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
     if (int rc = ctx->stage_a.reserve(tb + qb + 16)) return rc;
     hipStream_t st = ctx->stream;
     char *d = ctx->stage_a.as<char>();
-    if (tb) ESFM_HIP_TRY(hipMemcpyAsync(d, t, tb, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(d + tb, q, qb, hipMemcpyHostToDevice, st));
+    if (tb) ESFM_HIP_TRY(esfm::copy_h2d(d, t, tb, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d + tb, q, qb, st));
     const int32_t offs[3] = {0, nt, nt + nq};
     const int32_t pr[2] = {1, 0};
     int64_t out_off[2];
@@ -355,8 +355,8 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
                            filtered ? &mo : nullptr, &ratio_done))
         return rc;
     if (!filtered) {
-        ESFM_HIP_TRY(hipMemcpyAsync(o_a, ctx->knn_idx.ptr, sizeof(int32_t) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(o_c, ctx->knn_dist.ptr, sizeof(float) * 2 * (size_t)nq, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(o_a, ctx->knn_idx.ptr, sizeof(int32_t) * 2 * (size_t)nq, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(o_c, ctx->knn_dist.ptr, sizeof(float) * 2 * (size_t)nq, st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         return ESFM_OK;
     }
@@ -365,12 +365,12 @@ int single_pair(esfm_ctx *ctx, esfm_metric metric, const void *q, int nq, const 
                                                 mo.query_idx, mo.train_idx, mo.distance, mo.n_out))
             return rc;
     int32_t n = 0;
-    ESFM_HIP_TRY(hipMemcpyAsync(&n, ctx->stage_e.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(&n, ctx->stage_e.ptr, sizeof(int32_t), st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     if (n > 0) {
-        ESFM_HIP_TRY(hipMemcpyAsync(o_a, ctx->stage_b.ptr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(o_b, ctx->stage_c.ptr, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(o_c, ctx->stage_d.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(o_a, ctx->stage_b.ptr, sizeof(int32_t) * (size_t)n, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(o_b, ctx->stage_c.ptr, sizeof(int32_t) * (size_t)n, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(o_c, ctx->stage_d.ptr, sizeof(float) * (size_t)n, st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
     }
     if (n_out) *n_out = n;
@@ -492,7 +492,7 @@ int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host, c
     const size_t bytes = row_bytes * (size_t)plan.total_rows;
     ctx->prep_desc = nullptr;                      // the bank below is rewritten: whatever was prepared from it is stale
     if (int rc = ctx->bank.reserve(bytes + 16)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(ctx->bank.ptr, desc_host, bytes, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(ctx->bank.ptr, desc_host, bytes, st));
     if (int rc = esfm_match_prepare_dev(ctx, metric, ctx->bank.ptr, plan.total_rows, width)) return rc;
     const size_t nq = (size_t)plan.total_queries;
     if (int rc = ctx->stage_b.reserve(sizeof(int32_t) * nq)) return rc;
@@ -503,7 +503,7 @@ int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host, c
     if (int rc = esfm_match_pairs_dev(ctx, metric, ctx->bank.ptr, set_row_offset, n_sets, width, pairs, n_pairs, ratio, ctx->stage_b.as<int32_t>(),
                                       ctx->stage_c.as<int32_t>(), ctx->stage_d.as<float>(), ctx->stage_e.as<int32_t>(), off2.data()))
         return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(n_out, ctx->stage_e.ptr, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(n_out, ctx->stage_e.ptr, sizeof(int32_t) * (size_t)n_pairs, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     // The lists sit at out_offset[p] in arrays of sum(nq) slots; a ratio test keeps a few per cent of the queries.  When the matches
     // are less than a quarter of the slots they are packed on the device, read back as three dense arrays and placed from a host
@@ -512,9 +512,9 @@ int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host, c
     for (int p = 0; p < n_pairs; ++p) total += (size_t)n_out[p];
     if (total == 0) return ESFM_OK;
     if (total * 4 >= nq) {
-        ESFM_HIP_TRY(hipMemcpyAsync(query_idx, ctx->stage_b.ptr, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(train_idx, ctx->stage_c.ptr, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(distance, ctx->stage_d.ptr, sizeof(float) * nq, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(query_idx, ctx->stage_b.ptr, sizeof(int32_t) * nq, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(train_idx, ctx->stage_c.ptr, sizeof(int32_t) * nq, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(distance, ctx->stage_d.ptr, sizeof(float) * nq, st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         return ESFM_OK;
     }
@@ -528,14 +528,14 @@ int esfm_match_pairs(esfm_ctx *ctx, esfm_metric metric, const void *desc_host, c
     char *base = ctx->stage_a.as<char>();
     int32_t *dq = reinterpret_cast<int32_t *>(base + tab_bytes), *dtn = dq + total;
     float *dd = reinterpret_cast<float *>(dtn + total);
-    ESFM_HIP_TRY(hipMemcpyAsync(base, tab.data(), sizeof(long long) * tab.size(), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(base, tab.data(), sizeof(long long) * tab.size(), st));
     if (int rc = esfm::launch_pack_match_lists(st, reinterpret_cast<const long long *>(base), ctx->stage_e.as<int32_t>(), n_pairs, ctx->stage_b.as<int32_t>(),
                                                ctx->stage_c.as<int32_t>(), ctx->stage_d.as<float>(), dq, dtn, dd))
         return rc;
     std::vector<int32_t> hq(2 * total);
     std::vector<float> hd(total);
-    ESFM_HIP_TRY(hipMemcpyAsync(hq.data(), dq, sizeof(int32_t) * 2 * total, hipMemcpyDeviceToHost, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(hd.data(), dd, sizeof(float) * total, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(hq.data(), dq, sizeof(int32_t) * 2 * total, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(hd.data(), dd, sizeof(float) * total, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     for (int p = 0; p < n_pairs; ++p) {
         const size_t n = (size_t)n_out[p], so = (size_t)tab[2 * (size_t)p], dof = (size_t)tab[2 * (size_t)p + 1];
@@ -601,7 +601,7 @@ int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanne
     if (int rc = esfm::set_device(ctx)) return rc;
     int32_t c = 0;
     if (ctx->counters_cur) {
-        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters_cur, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(esfm::copy_d2h(&c, ctx->counters_cur, sizeof(int32_t), ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (n_queries) *n_queries = ctx->last_n_queries;
@@ -615,7 +615,7 @@ int esfm_match_last_second_pass(esfm_ctx *ctx, int64_t *n_second_pass)
     if (int rc = esfm::set_device(ctx)) return rc;
     int32_t c[2] = {0, 0};
     if (ctx->counters_cur) {
-        ESFM_HIP_TRY(hipMemcpyAsync(c, ctx->counters_cur, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(esfm::copy_d2h(c, ctx->counters_cur, sizeof(c), ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     *n_second_pass = c[1];
@@ -628,7 +628,7 @@ int esfm_match_debug_counters(esfm_ctx *ctx, int32_t *out16)
     if (int rc = esfm::set_device(ctx)) return rc;
     for (int i = 0; i < 16; ++i) out16[i] = 0;
     if (ctx->counters_cur) {
-        ESFM_HIP_TRY(hipMemcpyAsync(out16, ctx->counters_cur, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(esfm::copy_d2h(out16, ctx->counters_cur, 16 * sizeof(int32_t), ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return ESFM_OK;
@@ -647,13 +647,13 @@ int esfm_match_last_flagged(esfm_ctx *ctx, int32_t *out, int64_t cap, int64_t *n
     if (int rc = esfm::set_device(ctx)) return rc;
     int32_t c = 0;
     if (ctx->counters_cur) {
-        ESFM_HIP_TRY(hipMemcpyAsync(&c, ctx->counters_cur, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(esfm::copy_d2h(&c, ctx->counters_cur, sizeof(int32_t), ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     *n = c;
     const int64_t k = std::min<int64_t>(std::min<int64_t>(c, cap), (int64_t)(ctx->flagged.cap / (2 * sizeof(int32_t))));
     if (k > 0) {
-        ESFM_HIP_TRY(hipMemcpyAsync(out, ctx->flagged.ptr, sizeof(int32_t) * 2 * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+        ESFM_HIP_TRY(esfm::copy_d2h(out, ctx->flagged.ptr, sizeof(int32_t) * 2 * (size_t)k, ctx->stream));
         ESFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return ESFM_OK;

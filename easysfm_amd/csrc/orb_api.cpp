@@ -131,13 +131,13 @@ int esfm_orb_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, i
 
     OrbTables T;
     make_tables(&T);
-    ESFM_HIP_TRY(hipMemcpyAsync(d_tab, &T, sizeof(T), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_tab, &T, sizeof(T), st));
     ESFM_HIP_TRY(hipMemsetAsync(d_ncand, 0, 64, st));
     if (channels == 3) {
-        ESFM_HIP_TRY(hipMemcpyAsync(b_img.ptr, image, n_px * 3, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(b_img.ptr, image, n_px * 3, st));
         if (int rc = esfm::launch_surf_gray(st, b_img.as<uint8_t>(), (int)n_px, d_pyr)) return rc;
     } else {
-        ESFM_HIP_TRY(hipMemcpyAsync(d_pyr, image, n_px, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_pyr, image, n_px, st));
     }
     for (int l = 1; l < NL; ++l)
         if (int rc = esfm::launch_orb_resize(st, d_pyr + L.offset[l - 1], L.rows[l - 1], L.cols[l - 1], d_pyr + L.offset[l], L.rows[l], L.cols[l])) return rc;
@@ -146,12 +146,12 @@ int esfm_orb_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, i
     if (int rc = esfm::launch_orb_fast(st, L, d_pyr, d_score, ctx)) return rc;
     if (int rc = esfm::launch_orb_nms(st, L, d_score, d_cand, d_ncand, cap)) return rc;
     int32_t n_cand = 0;
-    ESFM_HIP_TRY(hipMemcpyAsync(&n_cand, d_ncand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(&n_cand, d_ncand, sizeof(int32_t), st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     if (n_cand > cap) { esfm::set_error("ORB candidate buffer overflow (%d > %d)", n_cand, cap); return ESFM_ERR_NUMERIC; }
     if (n_cand == 0 || max_keypoints == 0) return ESFM_OK;
     std::vector<OrbCand> all((size_t)n_cand);
-    ESFM_HIP_TRY(hipMemcpyAsync(all.data(), d_cand, sizeof(OrbCand) * (size_t)n_cand, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(all.data(), d_cand, sizeof(OrbCand) * (size_t)n_cand, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
 
     // first selection: per level, the best 2 n_l by FAST score (the device appended in no particular order)
@@ -165,9 +165,9 @@ int esfm_orb_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, i
         sel.insert(sel.end(), lvl[l].begin(), lvl[l].end());
     }
     if (sel.empty()) return ESFM_OK;
-    ESFM_HIP_TRY(hipMemcpyAsync(d_cand, sel.data(), sizeof(OrbCand) * sel.size(), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_cand, sel.data(), sizeof(OrbCand) * sel.size(), st));
     if (int rc = esfm::launch_orb_harris(st, L, d_pyr, d_cand, (int)sel.size())) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(sel.data(), d_cand, sizeof(OrbCand) * sel.size(), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(sel.data(), d_cand, sizeof(OrbCand) * sel.size(), st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     // second selection: per level, the best n_l by Harris response
     std::vector<OrbCand> fin;
@@ -190,10 +190,10 @@ int esfm_orb_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, i
     OrbKp *d_kp = ctx->knn_dist.as<OrbKp>();
     float *d_ang = reinterpret_cast<float *>(ctx->knn_dist.as<uint8_t>() + ((kp_bytes + 63) / 64) * 64);
     uint8_t *d_desc = reinterpret_cast<uint8_t *>(d_ang) + ((ang_bytes + 63) / 64) * 64;
-    ESFM_HIP_TRY(hipMemcpyAsync(d_cand, fin.data(), sizeof(OrbCand) * (size_t)n_kp, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_cand, fin.data(), sizeof(OrbCand) * (size_t)n_kp, st));
     if (int rc = esfm::launch_orb_angles(st, L, d_tab, d_pyr, d_cand, n_kp, d_ang)) return rc;
     std::vector<float> ang((size_t)n_kp);
-    ESFM_HIP_TRY(hipMemcpyAsync(ang.data(), d_ang, ang_bytes, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(ang.data(), d_ang, ang_bytes, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     std::vector<OrbKp> kps((size_t)n_kp);
     for (int k = 0; k < n_kp; ++k) {
@@ -208,9 +208,9 @@ int esfm_orb_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, i
         q.cx = cv_round_f(px * inv); q.cy = cv_round_f(py * inv); q.level = c.level; q.pad = 0;
         q.a = (float)std::cos(a); q.b = (float)std::sin(a);
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(d_kp, kps.data(), kp_bytes, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_kp, kps.data(), kp_bytes, st));
     if (int rc = esfm::launch_orb_describe(st, L, d_tab, d_blur, d_kp, n_kp, d_desc)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(descriptors, d_desc, 32 * (size_t)n_kp, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(descriptors, d_desc, 32 * (size_t)n_kp, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     *n_keypoints = n_kp;
     return ESFM_OK;

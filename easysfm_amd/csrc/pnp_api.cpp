@@ -78,8 +78,8 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
     double *d_poses = ctx->stage_d.as<double>();
     double *d_small = d_poses + 12 * (size_t)kPnpChunk;   // [0,12): best pose | [16, 16+64): geo in | [96, 96+96): sums out
     uint8_t *d_mask = ctx->stage_e.as<uint8_t>();
-    ESFM_HIP_TRY(hipMemcpyAsync(d_p3, pts3d, sizeof(float) * 3 * nn, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(d_p2, pts2d, sizeof(float) * 2 * nn, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_p3, pts3d, sizeof(float) * 3 * nn, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_p2, pts2d, sizeof(float) * 2 * nn, st));
 
     // ---- RANSAC over EPnP hypotheses
     rs::CvRng rng;
@@ -89,10 +89,10 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
     if (n == rs::kModelPoints) {
         // count == modelPoints: the kernel runs once on all points and every point is an inlier
         for (int j = 0; j < 5; ++j) samples[(size_t)j] = j;
-        ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * 5, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_samples, samples.data(), sizeof(int32_t) * 5, st));
         if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, 1, d_poses, d_valid, d_counts, ctx)) return rc;
         int32_t ok = 0;
-        ESFM_HIP_TRY(hipMemcpyAsync(&ok, d_valid, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(&ok, d_valid, sizeof(int32_t), st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         if (ok) { ESFM_HIP_TRY(hipMemcpyAsync(d_small, d_poses, sizeof(double) * 12, hipMemcpyDeviceToDevice, st)); have_best = true; max_good = n; }
         ESFM_HIP_TRY(hipMemsetAsync(d_mask, 1, nn, st));
@@ -105,9 +105,9 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
             const int chunk = iter == 0 ? 64 : (iter < 320 ? 256 : kPnpChunk);
             const int n_hyp = std::min(chunk, niters - iter);
             for (int k = 0; k < n_hyp; ++k) rs::draw_subset(rng, n, &samples[5 * (size_t)k]);
-            ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * 5 * (size_t)n_hyp, hipMemcpyHostToDevice, st));
+            ESFM_HIP_TRY(esfm::copy_h2d(d_samples, samples.data(), sizeof(int32_t) * 5 * (size_t)n_hyp, st));
             if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, n_hyp, d_poses, d_valid, d_counts, ctx)) return rc;
-            ESFM_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, sizeof(int32_t) * (size_t)n_hyp, hipMemcpyDeviceToHost, st));
+            ESFM_HIP_TRY(esfm::copy_d2h(counts.data(), d_counts, sizeof(int32_t) * (size_t)n_hyp, st));
             ESFM_HIP_TRY(hipStreamSynchronize(st));
             int best_k = -1;
             for (int k = 0; k < n_hyp && iter < niters; ++k, ++iter) {
@@ -130,21 +130,21 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
         return ESFM_ERR_NUMERIC;   // OpenCV returns false and releases `inliers`
     }
     std::vector<uint8_t> mask(nn);
-    ESFM_HIP_TRY(hipMemcpyAsync(mask.data(), d_mask, nn, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(mask.data(), d_mask, nn, st));
 
     // ---- EPnP on all inliers (solvePnP(opoints_inliers, ipoints_inliers, ..., SOLVEPNP_EPNP))
     double *d_geo = d_small + 16, *d_sums = d_small + 96;
     double h[96];
     if (int rc = esfm::launch_pnp_moment_sums(st, pb, d_p3, d_mask, d_sums)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(h, d_sums, sizeof(double) * 13, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(h, d_sums, sizeof(double) * 13, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     const int m = (int)std::lrint(h[12]);
     double sum_pw[3] = {h[0], h[1], h[2]}, cws[4][3], geo[51];
     ep::control_points(sum_pw, h + 3, m, cws, geo + 3);
     for (int k = 0; k < 3; ++k) geo[k] = cws[0][k];
-    ESFM_HIP_TRY(hipMemcpyAsync(d_geo, geo, sizeof(double) * 12, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_geo, geo, sizeof(double) * 12, st));
     if (int rc = esfm::launch_pnp_mtm_sums(st, pb, d_p3, d_p2, d_mask, d_geo, d_sums)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(h, d_sums, sizeof(double) * 78, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(h, d_sums, sizeof(double) * 78, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     double MtM[144];
     {
@@ -168,15 +168,15 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
         const double z0 = a0[0] * ccs[0][2] + a0[1] * ccs[1][2] + a0[2] * ccs[2][2] + a0[3] * ccs[3][2];
         geo[48 + c] = z0 < 0.0 ? -1.0 : 1.0;
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(d_geo, geo, sizeof(double) * 51, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_geo, geo, sizeof(double) * 51, st));
     if (int rc = esfm::launch_pnp_rt_sums(st, pb, d_p3, d_mask, d_geo, d_sums)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(h, d_sums, sizeof(double) * 36, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(h, d_sums, sizeof(double) * 36, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     double poses3[36];
     for (int c = 0; c < 3; ++c) ep::rt_from_sums(m, h + 12 * c, sum_pw, h + 12 * c + 3, poses3 + 12 * c, poses3 + 12 * c + 9);
-    ESFM_HIP_TRY(hipMemcpyAsync(d_geo, poses3, sizeof(double) * 36, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_geo, poses3, sizeof(double) * 36, st));
     if (int rc = esfm::launch_pnp_reproj_sums(st, pb, d_p3, d_p2, d_mask, d_geo, d_sums)) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(h, d_sums, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(h, d_sums, sizeof(double) * 3, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     int N = 0;   // compute_pose: candidate 1, then 2 / 3 only if strictly better
     if (h[1] / m < h[0] / m) N = 1;

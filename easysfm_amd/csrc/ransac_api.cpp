@@ -162,12 +162,12 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
     double *d_npts = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(d_best + 9 * (size_t)n_pairs) + 31) & ~(uintptr_t)31);   // (double4 records)
     uint8_t *d_mask = reinterpret_cast<uint8_t *>(d_npts + 4 * (size_t)std::max(n_total, 1));
     if (n_total > 0) {
-        ESFM_HIP_TRY(hipMemcpyAsync(d_p1, pts1, sizeof(float) * 2 * (size_t)n_total, hipMemcpyHostToDevice, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(d_p2, pts2, sizeof(float) * 2 * (size_t)n_total, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_p1, pts1, sizeof(float) * 2 * (size_t)n_total, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_p2, pts2, sizeof(float) * 2 * (size_t)n_total, st));
     }
     ESFM_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(double) * 9 * (size_t)n_pairs, st));
     // the correspondences in normalised coordinates, once for all rounds (the table's geometry does not change between rounds)
-    ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, st));
     if (int rc = esfm::launch_essential_normalise(st, d_tab, n_pairs, d_p1, d_p2, d_npts)) return rc;
 
     // the per-round tables in pinned memory (pageable copies of 0.4 MB up and 0.85 MB down per round were staged by the runtime)
@@ -189,11 +189,11 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
             }
         }
         if (!any) break;
-        ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(d_samples, samples, sizeof(int32_t) * 5 * n_slots, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_samples, samples, sizeof(int32_t) * 5 * n_slots, st));
         ESFM_HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * 10 * n_slots, st));
         if (int rc = esfm::launch_essential_chunk(st, d_tab, n_pairs, d_p1, d_p2, d_npts, d_samples, kChunk, d_models, d_nmodels, d_counts, ctx)) return rc;
-        ESFM_HIP_TRY(hipMemcpyAsync(nmodels, d_nmodels, sizeof(int32_t) * 11 * n_slots, hipMemcpyDeviceToHost, st));   // n_models | counts
+        ESFM_HIP_TRY(esfm::copy_d2h(nmodels, d_nmodels, sizeof(int32_t) * 11 * n_slots, st));   // n_models | counts
         ESFM_HIP_TRY(hipStreamSynchronize(st));
         // replay RANSACPointSetRegistrator::run over this chunk
         int n_take = 0;
@@ -224,7 +224,7 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
         // the pairs' new best models in ONE launch (a 72-byte device-to-device copy per pair was 300 API calls per round: most of the
         // batch's host time once the solver stopped being it)
         if (n_take > 0) {
-            ESFM_HIP_TRY(hipMemcpyAsync(d_take, take, sizeof(int32_t) * 3 * (size_t)n_take, hipMemcpyHostToDevice, st));
+            ESFM_HIP_TRY(esfm::copy_h2d(d_take, take, sizeof(int32_t) * 3 * (size_t)n_take, st));
             if (int rc = esfm::launch_essential_take_best(st, d_take, n_take, d_models, d_best)) return rc;
         }
     }
@@ -233,12 +233,12 @@ int esfm_find_essential_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_o
         status[p] = S[(size_t)p].max_good > 0 ? 1 : 0;
         if (iterations) iterations[p] = S[(size_t)p].iter;
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, st));
     if (n_total > 0) {
         if (int rc = esfm::launch_essential_mask(st, d_tab, n_pairs, d_p1, d_p2, d_best, d_mask)) return rc;
-        ESFM_HIP_TRY(hipMemcpyAsync(mask, d_mask, (size_t)n_total, hipMemcpyDeviceToHost, st));
+        ESFM_HIP_TRY(esfm::copy_d2h(mask, d_mask, (size_t)n_total, st));
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(E_out, d_best, sizeof(double) * 9 * (size_t)n_pairs, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(E_out, d_best, sizeof(double) * 9 * (size_t)n_pairs, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     for (int p = 0; p < n_pairs; ++p) {
         if (status[p]) {
@@ -296,17 +296,17 @@ int esfm_recover_pose_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_off
     uint8_t *d_cand = ctx->stage_e.as<uint8_t>();
     uint8_t *d_in = d_cand + 4 * nt;
     if (n_total > 0) {
-        ESFM_HIP_TRY(hipMemcpyAsync(d_p1, pts1, sizeof(float) * 2 * (size_t)n_total, hipMemcpyHostToDevice, st));
-        ESFM_HIP_TRY(hipMemcpyAsync(d_p2, pts2, sizeof(float) * 2 * (size_t)n_total, hipMemcpyHostToDevice, st));
-        if (mask) ESFM_HIP_TRY(hipMemcpyAsync(d_in, mask, (size_t)n_total, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_p1, pts1, sizeof(float) * 2 * (size_t)n_total, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_p2, pts2, sizeof(float) * 2 * (size_t)n_total, st));
+        if (mask) ESFM_HIP_TRY(esfm::copy_h2d(d_in, mask, (size_t)n_total, st));
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(d_poses, poses.data(), sizeof(double) * poses.size(), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_tab, tab.data(), sizeof(RansacPair) * (size_t)n_pairs, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_poses, poses.data(), sizeof(double) * poses.size(), st));
     if (int rc = esfm::launch_pose_cheirality(st, d_tab, n_pairs, d_p1, d_p2, d_poses, mask ? d_in : nullptr, (int)nt, d_cand, d_good)) return rc;
     std::vector<int32_t> g4(4 * (size_t)n_pairs);
     std::vector<uint8_t> cand(mask ? 4 * nt : 0);
-    ESFM_HIP_TRY(hipMemcpyAsync(g4.data(), d_good, sizeof(int32_t) * g4.size(), hipMemcpyDeviceToHost, st));
-    if (mask && n_total > 0) ESFM_HIP_TRY(hipMemcpyAsync(cand.data(), d_cand, 4 * nt, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(g4.data(), d_good, sizeof(int32_t) * g4.size(), st));
+    if (mask && n_total > 0) ESFM_HIP_TRY(esfm::copy_d2h(cand.data(), d_cand, 4 * nt, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     for (int p = 0; p < n_pairs; ++p) {
         const int32_t *g = &g4[4 * (size_t)p];

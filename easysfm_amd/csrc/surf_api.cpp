@@ -117,24 +117,24 @@ int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, 
     SurfKeypoint *d_cand = reinterpret_cast<SurfKeypoint *>(misc + sizeof(SurfParams) + sizeof(SurfDescTables) + 64);
 
     if (channels == 3) {
-        ESFM_HIP_TRY(hipMemcpyAsync(d_bgr, image, n_px * 3, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_bgr, image, n_px * 3, st));
         if (int rc = esfm::launch_surf_gray(st, d_bgr, (int)n_px, d_gray)) return rc;
     } else {
-        ESFM_HIP_TRY(hipMemcpyAsync(d_gray, image, n_px, hipMemcpyHostToDevice, st));
+        ESFM_HIP_TRY(esfm::copy_h2d(d_gray, image, n_px, st));
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(d_P, &P, sizeof(P), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_P, &P, sizeof(P), st));
     ESFM_HIP_TRY(hipMemsetAsync(d_det, 0, sizeof(float) * 2 * (size_t)total, st));
     ESFM_HIP_TRY(hipMemsetAsync(d_ncand, 0, 64, st));
     if (int rc = esfm::launch_surf_integral(st, d_gray, rows, cols, d_sum)) return rc;
     if (int rc = esfm::launch_surf_det_trace(st, d_P, P, d_sum, d_det, d_trace, ctx)) return rc;
     if (int rc = esfm::launch_surf_maxima(st, d_P, P, d_det, d_trace, d_cand, d_ncand)) return rc;
     int32_t n_cand = 0;
-    ESFM_HIP_TRY(hipMemcpyAsync(&n_cand, d_ncand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(&n_cand, d_ncand, sizeof(int32_t), st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     if (n_cand > P.max_candidates) { esfm::set_error("SURF candidate buffer overflow (%d > %d)", n_cand, P.max_candidates); return ESFM_ERR_NUMERIC; }
     if (n_cand == 0 || max_keypoints == 0) return ESFM_OK;
     std::vector<SurfKeypoint> kps((size_t)n_cand);
-    ESFM_HIP_TRY(hipMemcpyAsync(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_cand, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_cand, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     std::sort(kps.begin(), kps.end(), kp_greater);   // the device appends in no particular order; OpenCV sorts too
 
@@ -180,16 +180,16 @@ int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, 
     float *d_desc = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(d_off) + esfm::surf_align16(off_bytes));
     esfm::SurfBlk *d_bw = reinterpret_cast<esfm::SurfBlk *>(reinterpret_cast<uint8_t *>(d_desc) + esfm::surf_align16(desc_bytes));
     esfm::SurfBlk *d_br = reinterpret_cast<esfm::SurfBlk *>(reinterpret_cast<uint8_t *>(d_bw) + bw_bytes);
-    ESFM_HIP_TRY(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(d_cand, kps.data(), sizeof(SurfKeypoint) * (size_t)n_kp, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(d_off, win_off.data(), off_bytes, hipMemcpyHostToDevice, st));
-    if (!blk_win.empty()) ESFM_HIP_TRY(hipMemcpyAsync(d_bw, blk_win.data(), sizeof(esfm::SurfBlk) * blk_win.size(), hipMemcpyHostToDevice, st));
-    if (!blk_row.empty()) ESFM_HIP_TRY(hipMemcpyAsync(d_br, blk_row.data(), sizeof(esfm::SurfBlk) * blk_row.size(), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_T, &T, sizeof(T), st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_cand, kps.data(), sizeof(SurfKeypoint) * (size_t)n_kp, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(d_off, win_off.data(), off_bytes, st));
+    if (!blk_win.empty()) ESFM_HIP_TRY(esfm::copy_h2d(d_bw, blk_win.data(), sizeof(esfm::SurfBlk) * blk_win.size(), st));
+    if (!blk_row.empty()) ESFM_HIP_TRY(esfm::copy_h2d(d_br, blk_row.data(), sizeof(esfm::SurfBlk) * blk_row.size(), st));
     if (int rc = esfm::launch_surf_describe(st, d_P, d_T, d_gray, d_sum, d_cand, n_kp, d_off, d_bw, (int)blk_win.size(), d_br, (int)blk_row.size(), d_win,
                                             d_desc, ctx)) return rc;
     std::vector<float> desc(64 * (size_t)n_kp);
-    ESFM_HIP_TRY(hipMemcpyAsync(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_kp, hipMemcpyDeviceToHost, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(desc.data(), d_desc, desc_bytes, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_kp, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(desc.data(), d_desc, desc_bytes, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     int n_out = 0;
     for (int k = 0; k < n_kp && n_out < max_keypoints; ++k) {

@@ -76,14 +76,14 @@ int esfm_undistort(esfm_ctx *ctx, const uint8_t *image, int rows, int cols, int 
     if (int rc = b_src.reserve(n_bytes + 16)) return rc;
     if (int rc = b_dst.reserve(n_bytes + 16)) return rc;
     if (int rc = b_seq.reserve(sizeof(double) * seq.size())) return rc;
-    ESFM_HIP_TRY(hipMemcpyAsync(b_src.ptr, image, n_bytes, hipMemcpyHostToDevice, st));
-    ESFM_HIP_TRY(hipMemcpyAsync(b_seq.ptr, seq.data(), sizeof(double) * seq.size(), hipMemcpyHostToDevice, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(b_src.ptr, image, n_bytes, st));
+    ESFM_HIP_TRY(esfm::copy_h2d(b_seq.ptr, seq.data(), sizeof(double) * seq.size(), st));
     const double *d_seq = b_seq.as<double>();
     {
         esfm::KernelTimer tm(ctx, ESFM_K_UNDISTORT);
         if (int rc = esfm::launch_undistort(st, P, b_src.as<uint8_t>(), d_seq, d_seq + cols, d_seq + cols + rows, b_dst.as<uint8_t>())) return rc;
     }
-    ESFM_HIP_TRY(hipMemcpyAsync(out, b_dst.ptr, n_bytes, hipMemcpyDeviceToHost, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(out, b_dst.ptr, n_bytes, st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
     return ESFM_OK;
 }

@@ -22,6 +22,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <memory>
 #include <vector>
 
 #include "../../include/esfm.h"
@@ -128,11 +129,14 @@ public:
         (void)show;
         const ImageMat &img = cur_frame.rgb_image;
         if (img.empty()) { std::cerr << "frame has no image" << std::endl; return false; }
+        // room for every possible maximum (a quarter of the pixels), NOT zero-filled (the library writes the n rows it returns and
+        // nothing else: a value-initialised std::vector of these 28 MB cost 7 - 8 ms per 768 x 512 image in page faults) and KEPT
+        // between frames: the device-to-host copies land here, the runtime pins what it copies into, and unmapping pinned pages at the
+        // end of every call showed up as 15 - 35 ms stalls in the next frames' calls
         const int cap = img.rows * img.cols / 4 + 1024;
-        std::vector<float> kp(size_t(7) * size_t(cap)), desc(size_t(64) * size_t(cap));
+        float *kp = scratch_f32(kp_buf_, kp_cap_, size_t(7) * size_t(cap)), *desc = scratch_f32(desc_buf_, desc_cap_, size_t(64) * size_t(cap));
         int32_t n = 0;
-        if (esfm_surf_detect_and_compute(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, double(minHessian), cap, kp.data(),
-                                         desc.data(), &n) != ESFM_OK) {
+        if (esfm_surf_detect_and_compute(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, double(minHessian), cap, kp, desc, &n) != ESFM_OK) {
             std::cerr << esfm_last_error() << std::endl;
             return false;
         }
@@ -143,7 +147,7 @@ public:
             q.pt.x = v[0]; q.pt.y = v[1]; q.size = v[2]; q.angle = v[3]; q.response = v[4]; q.octave = int(v[5]); q.class_id = int(v[6]);
         }
         cur_frame.descriptors.create(n, 64, DescMat::F32);
-        if (n) std::memcpy(cur_frame.descriptors.ptr<float>(), desc.data(), sizeof(float) * size_t(64) * size_t(n));
+        if (n) std::memcpy(cur_frame.descriptors.ptr<float>(), desc, sizeof(float) * size_t(64) * size_t(n));
         if (!quiet) std::cout << "Found " << n << " features." << std::endl;
         return true;
     }
@@ -155,11 +159,10 @@ public:
         const ImageMat &img = cur_frame.rgb_image;
         if (img.empty()) { std::cerr << "frame has no image" << std::endl; return false; }
         const int cap = 2 * max_num + 4096;       // retainBest keeps ties
-        std::vector<float> kp(size_t(7) * size_t(cap));
-        std::vector<uint8_t> desc(size_t(32) * size_t(cap));
+        float *kp = scratch_f32(kp_buf_, kp_cap_, size_t(7) * size_t(cap));                       // (kept between frames: see detectFeaturesSURF)
+        uint8_t *desc = reinterpret_cast<uint8_t *>(scratch_f32(desc_buf_, desc_cap_, size_t(8) * size_t(cap)));
         int32_t n = 0;
-        if (esfm_orb_detect_and_compute(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, max_num, cap, kp.data(), desc.data(),
-                                        &n) != ESFM_OK) {
+        if (esfm_orb_detect_and_compute(default_ctx(), img.data.data(), img.rows, img.cols, img.channels, max_num, cap, kp, desc, &n) != ESFM_OK) {
             std::cerr << esfm_last_error() << std::endl;
             return false;
         }
@@ -170,7 +173,7 @@ public:
             q.pt.x = v[0]; q.pt.y = v[1]; q.size = v[2]; q.angle = v[3]; q.response = v[4]; q.octave = int(v[5]); q.class_id = int(v[6]);
         }
         cur_frame.descriptors.create(n, 32, DescMat::U8);
-        if (n) std::memcpy(cur_frame.descriptors.ptr<uint8_t>(), desc.data(), size_t(32) * size_t(n));
+        if (n) std::memcpy(cur_frame.descriptors.ptr<uint8_t>(), desc, size_t(32) * size_t(n));
         if (!quiet) std::cout << "Found " << n << " features" << std::endl;
         return true;
     }
@@ -294,6 +297,15 @@ public:
     }
 
 private:
+    // detection outputs' landing buffers, uninitialised, grown on demand, kept for the object's life
+    std::unique_ptr<float[]> kp_buf_, desc_buf_;
+    size_t kp_cap_ = 0, desc_cap_ = 0;
+    static float *scratch_f32(std::unique_ptr<float[]> &buf, size_t &cap, size_t n)
+    {
+        if (n > cap) { buf.reset(new float[n]); cap = n; }
+        return buf.get();
+    }
+
     bool run(frame_t &f1, frame_t &f2, std::vector<DMatch> &matches, double ratio, bool hamming, const char *tag)
     {
         const DescMat &q = f1.descriptors, &t = f2.descriptors;

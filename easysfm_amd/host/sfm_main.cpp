@@ -154,17 +154,23 @@ int main(int argc, char **argv)
 
         // ---- per frame: import, undistort, SURF (sfm.cpp:84-126)
         std::cout << "Begin feature extraction" << std::endl;
+        const bool frame_trace = std::getenv("ESFM_FRAME_TRACE") != nullptr;       // per-frame milliseconds on stderr (diagnosis of first-touch costs)
         for (int i = 0; i < frame_number; ++i) {
             clk.lap();
             if (!import_decoded(i)) return 3;
+            const double t_wait = clk.lap();
             frames[size_t(i)].K_cam = K_mat;
             if (!ee.doUnDistort(frames[size_t(i)], distort_coeff)) return 3;
-            t_import += clk.lap();
+            const double t_und = clk.lap();
+            t_import += t_wait + t_und;
             std::cout << "Feature extraction of Frame [ " << i << " ]" << std::endl;
             if (using_feature == 'O' ? !fm.detectFeaturesORB(frames[size_t(i)], feature_extract_parameter)          // sfm.cpp:112-117
                                      : !fm.detectFeaturesSURF(frames[size_t(i)], feature_extract_parameter)) return 3;
             frames[size_t(i)].init_pixel_ids();
-            t_detect += clk.lap();
+            const double t_det = clk.lap();
+            t_detect += t_det;
+            if (frame_trace)
+                std::cerr << "[frame " << i << "] decode wait " << t_wait * 1e3 << " ms, undistort " << t_und * 1e3 << " ms, detect " << t_det * 1e3 << " ms" << std::endl;
         }
         std::cout << "Feature extraction done" << std::endl;
 
