@@ -49,6 +49,23 @@ def test_undistort_accepts_camera_matrix_and_mirror(gpu_ctx, oracle_lib):
         E.undistort(img, np.array([[150, 1, 80], [0, 150, 60], [0, 0, 1.0]]), coeff, gpu_ctx)     # skew
 
 
+@pytest.mark.parametrize("rows,cols", [(2048, 3072), (512, 768), (33, 64), (7, 4)])
+def test_undistort_four_pixel_form_at_image_borders_matches_oracle(gpu_ctx, oracle_lib, rows, cols):
+    """Three channels and a width that is a multiple of four take the four-pixels-per-thread kernel (8-byte tap loads inside the image,
+    byte taps on its border, one 12-byte store): the reference's image sizes against the oracle, with a principal point far off
+    centre and coefficients that send whole bands of the destination outside the source (every mix of in / on / outside taps within
+    one thread's four pixels)."""
+    rng = np.random.default_rng(rows * 7 + cols)
+    img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    f = 0.9 * max(rows, cols)
+    for K4, dist in (([f, cols / 2, f, rows / 2], [-0.12, 0.03, 0.001, -0.0005]),
+                     ([f, 0.2 * cols, 1.3 * f, 0.9 * rows], [0.6, 0.4, -0.03, 0.05]),
+                     ([0.5 * f, cols - 1.0, 0.5 * f, 0.0], [-1.5, 2.0, 0.1, -0.1]),
+                     ([f, -40.0, f, rows + 25.0], [0.05, 0.0, 0.0, 0.0])):
+        out = E.undistort(img, K4, dist, gpu_ctx)
+        assert np.array_equal(out, oracle_lib.undistort(img, K4, dist)), (K4, dist)
+
+
 def test_undistort_full_size_properties(gpu_ctx):
     """The reference's image size (fountain: 2048 x 3072 BGR).  Zero coefficients are an exact identity (what every BASELINE
     configuration runs); a radial model leaves the principal point's neighbourhood in place, is symmetric under a 180-degree
