@@ -20,6 +20,12 @@
  *   - "host" pointers are ordinary CPU memory; "_dev" entry points take HIP
  *     device pointers that are already resident in HBM and enqueue all work on
  *     the context's stream without synchronising (the caller synchronises).
+ *     Host buffers travel in 512-KiB pieces through the runtime's staging
+ *     buffer (the runtime would otherwise pin buffers of 1 MiB and more in
+ *     place, which stalls the process' queues when the heap around them
+ *     changes); a buffer the caller has registered (hipHostRegister) or
+ *     allocated with hipHostMalloc goes in one DMA transfer -- worth doing for
+ *     images and descriptor banks that are handed over repeatedly.
  *   - one esfm_ctx per host thread and per GPU; a context is not thread-safe.
  *   - there is NO CPU fallback: without a usable gfx950 device every compute
  *     entry point fails with ESFM_ERR_NO_DEVICE.
