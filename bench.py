@@ -1082,7 +1082,7 @@ def main() -> int:
                 X4 = E.triangulate_points(P1, P2, a_, b_, pctx)
             t_el = (time.perf_counter() - t0) / 10
             out["triangulate"] = {"metric": "points triangulated/s (cv::triangulatePoints, two views)", "value": n_t / t_el, "unit": "points/s", "points": n_t,
-                                  "ms_per_call": t_el * 1e3, "includes": "host<->device copies (PCIe-bound: 16 B in, 16 B out per point)"}
+                                  "ms_per_call": t_el * 1e3, "includes": "host<->device copies from pageable memory in 512-KiB pieces (host-copy-bound: 16 B in, 16 B out per point)"}
             if not args.no_cpu_baseline:
                 import oracle
                 t0 = time.perf_counter(); rX4 = oracle.triangulate_points(P1, P2, a_, b_); t1 = time.perf_counter() - t0
