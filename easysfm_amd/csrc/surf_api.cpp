@@ -128,14 +128,24 @@ int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, 
     if (int rc = esfm::launch_surf_integral(st, d_gray, rows, cols, d_sum)) return rc;
     if (int rc = esfm::launch_surf_det_trace(st, d_P, P, d_sum, d_det, d_trace, ctx)) return rc;
     if (int rc = esfm::launch_surf_maxima(st, d_P, P, d_det, d_trace, d_cand, d_ncand)) return rc;
-    int32_t n_cand = 0;
-    ESFM_HIP_TRY(esfm::copy_d2h(&n_cand, d_ncand, sizeof(int32_t), st));
+    // the candidate count and the first candidates in ONE transfer (the count's 64-byte slot sits right in front of the list): the
+    // usual image needs no second round trip for the list
+    constexpr int kFirstCand = 4096;
+    static_assert(sizeof(SurfKeypoint) == 32, "candidate records are 32 bytes");
+    const int first_cap = std::min(kFirstCand, P.max_candidates);
+    std::vector<uint8_t> head(64 + sizeof(SurfKeypoint) * (size_t)first_cap);
+    ESFM_HIP_TRY(esfm::copy_d2h(head.data(), d_ncand, head.size(), st));
     ESFM_HIP_TRY(hipStreamSynchronize(st));
+    int32_t n_cand = 0;
+    memcpy(&n_cand, head.data(), sizeof(int32_t));
     if (n_cand > P.max_candidates) { esfm::set_error("SURF candidate buffer overflow (%d > %d)", n_cand, P.max_candidates); return ESFM_ERR_NUMERIC; }
     if (n_cand == 0 || max_keypoints == 0) return ESFM_OK;
     std::vector<SurfKeypoint> kps((size_t)n_cand);
-    ESFM_HIP_TRY(esfm::copy_d2h(kps.data(), d_cand, sizeof(SurfKeypoint) * (size_t)n_cand, st));
-    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    memcpy(kps.data(), head.data() + 64, sizeof(SurfKeypoint) * (size_t)std::min(n_cand, first_cap));
+    if (n_cand > first_cap) {
+        ESFM_HIP_TRY(esfm::copy_d2h(kps.data() + first_cap, d_cand + first_cap, sizeof(SurfKeypoint) * (size_t)(n_cand - first_cap), st));
+        ESFM_HIP_TRY(hipStreamSynchronize(st));
+    }
     std::sort(kps.begin(), kps.end(), kp_greater);   // the device appends in no particular order; OpenCV sorts too
 
     // ---- descriptor tables and window scratch
@@ -172,19 +182,27 @@ int esfm_surf_detect_and_compute(esfm_ctx *ctx, const uint8_t *image, int rows, 
         for (int f = 0; f < n_win; f += 256) blk_win.push_back({k, f});
         for (int f = 0; f < n_row; f += 256) blk_row.push_back({k, f});
     }
+    // device layout behind the window scratch: descriptors | tables (Gaussian tables, scratch offsets, the two block tables) -- the
+    // tables are packed on the host in the same layout and go up in one transfer
     const size_t off_bytes = sizeof(int64_t) * ((size_t)n_kp + 1), desc_bytes = sizeof(float) * 64 * (size_t)n_kp;
+    const size_t t_bytes = esfm::surf_align16(sizeof(SurfDescTables)), o_bytes = esfm::surf_align16(off_bytes);
     const size_t bw_bytes = esfm::surf_align16(sizeof(esfm::SurfBlk) * blk_win.size()), br_bytes = esfm::surf_align16(sizeof(esfm::SurfBlk) * blk_row.size());
-    if (int rc = b_win.reserve((size_t)win_off[(size_t)n_kp] + off_bytes + desc_bytes + bw_bytes + br_bytes + 128)) return rc;
+    const size_t tab_bytes = t_bytes + o_bytes + bw_bytes + br_bytes;
+    if (int rc = b_win.reserve((size_t)win_off[(size_t)n_kp] + desc_bytes + tab_bytes + 128)) return rc;
     uint8_t *d_win = b_win.as<uint8_t>();
-    int64_t *d_off = reinterpret_cast<int64_t *>(d_win + esfm::surf_align16((size_t)win_off[(size_t)n_kp]));
-    float *d_desc = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(d_off) + esfm::surf_align16(off_bytes));
-    esfm::SurfBlk *d_bw = reinterpret_cast<esfm::SurfBlk *>(reinterpret_cast<uint8_t *>(d_desc) + esfm::surf_align16(desc_bytes));
-    esfm::SurfBlk *d_br = reinterpret_cast<esfm::SurfBlk *>(reinterpret_cast<uint8_t *>(d_bw) + bw_bytes);
-    ESFM_HIP_TRY(esfm::copy_h2d(d_T, &T, sizeof(T), st));
+    float *d_desc = reinterpret_cast<float *>(d_win + esfm::surf_align16((size_t)win_off[(size_t)n_kp]));
+    uint8_t *d_tab = reinterpret_cast<uint8_t *>(d_desc) + esfm::surf_align16(desc_bytes);
+    std::vector<uint8_t> tab(tab_bytes);
+    memcpy(tab.data(), &T, sizeof(T));
+    memcpy(tab.data() + t_bytes, win_off.data(), off_bytes);
+    if (!blk_win.empty()) memcpy(tab.data() + t_bytes + o_bytes, blk_win.data(), sizeof(esfm::SurfBlk) * blk_win.size());
+    if (!blk_row.empty()) memcpy(tab.data() + t_bytes + o_bytes + bw_bytes, blk_row.data(), sizeof(esfm::SurfBlk) * blk_row.size());
+    d_T = reinterpret_cast<SurfDescTables *>(d_tab);
+    const int64_t *d_off = reinterpret_cast<const int64_t *>(d_tab + t_bytes);
+    const esfm::SurfBlk *d_bw = reinterpret_cast<const esfm::SurfBlk *>(d_tab + t_bytes + o_bytes);
+    const esfm::SurfBlk *d_br = reinterpret_cast<const esfm::SurfBlk *>(d_tab + t_bytes + o_bytes + bw_bytes);
+    ESFM_HIP_TRY(esfm::copy_h2d(d_tab, tab.data(), tab_bytes, st));
     ESFM_HIP_TRY(esfm::copy_h2d(d_cand, kps.data(), sizeof(SurfKeypoint) * (size_t)n_kp, st));
-    ESFM_HIP_TRY(esfm::copy_h2d(d_off, win_off.data(), off_bytes, st));
-    if (!blk_win.empty()) ESFM_HIP_TRY(esfm::copy_h2d(d_bw, blk_win.data(), sizeof(esfm::SurfBlk) * blk_win.size(), st));
-    if (!blk_row.empty()) ESFM_HIP_TRY(esfm::copy_h2d(d_br, blk_row.data(), sizeof(esfm::SurfBlk) * blk_row.size(), st));
     if (int rc = esfm::launch_surf_describe(st, d_P, d_T, d_gray, d_sum, d_cand, n_kp, d_off, d_bw, (int)blk_win.size(), d_br, (int)blk_row.size(), d_win,
                                             d_desc, ctx)) return rc;
     std::vector<float> desc(64 * (size_t)n_kp);
