@@ -38,7 +38,9 @@ using epnp::Cam;
 // the 180 ms of GPU time of a run_fountain_small.sh reconstruction); the arrays in LDS, still one thread: 9.9 ms.
 constexpr int kPnpLanes = 16, kPnpHypPerBlock = 64 / kPnpLanes, kPnpWsStride = 4 * 144 + 1;
 struct Jacobi12Coop {
-    int l;      // lane of the hypothesis' group
+    int l;            // lane of the hypothesis' group
+    int sweep_cap;    // 60 = the routine's own cap; less: a first pass that gives up on the few matrices whose off-diagonal norm stalls
+    bool *gave_up;    // ... and says so here (the caller discards the hypothesis and, if the RANSAC replay needs it, solves it again in full)
     __device__ __forceinline__ void operator()(double *A, double *V) const
     {
         constexpr int N = 12;
@@ -54,6 +56,7 @@ struct Jacobi12Coop {
             double off = 0.0, diag = 0.0;
             for (int i = 0; i < N; ++i) { diag += A[i * N + i] * A[i * N + i]; for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j]; }
             if (off <= 1e-36 * diag || off == 0.0) break;
+            if (sweep >= sweep_cap) { *gave_up = true; break; }
             for (int p = 0; p < N - 1; ++p)
                 for (int q = p + 1; q < N; ++q) {
                     const double apq = A[p * N + q];
@@ -75,7 +78,7 @@ struct Jacobi12Coop {
 
 __global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
                                                        const int32_t *__restrict__ samples, int n_hyp, double *__restrict__ poses,
-                                                       int32_t *__restrict__ valid)
+                                                       int32_t *__restrict__ valid, int sweep_cap)
 {
     __shared__ double ws_all[kPnpHypPerBlock * kPnpWsStride];
     const int grp = threadIdx.x / kPnpLanes, l = threadIdx.x % kPnpLanes;
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const floa
 #ifdef ESFM_PNP_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    epnp::solve_small_ws<5>(cam, pw, us, R, t, ws_all + grp * kPnpWsStride, Jacobi12Coop{l});
+    bool gave_up = false;
+    epnp::solve_small_ws<5>(cam, pw, us, R, t, ws_all + grp * kPnpWsStride, Jacobi12Coop{l, sweep_cap, &gave_up});
 #ifdef ESFM_PNP_TRACE
     if (g == 0 && l == 0)
         printf("pnp_solve [10 ns]: control points %llu  M'M %llu  eig12 %llu  L/rho %llu  betas %llu  gauss-newton %llu  candidates %llu\n", g_pnp_mark[0] - tr0,
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const floa
                g_pnp_mark[6] - g_pnp_mark[5]);
 #endif
     if (l != 0) return;
+    if (gave_up) { valid[g] = kPnpUnfinished; return; }      // (what the chain made of the half-diagonalised matrix is discarded)
     bool ok = true;
     for (int k = 0; k < 9; ++k) ok = ok && isfinite(R[k]);
     for (int k = 0; k < 3; ++k) ok = ok && isfinite(t[k]);
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(PnpProblem pb, const flo
 {
     __shared__ int red[4];
     const int g = blockIdx.x;
+    if (valid[g] == kPnpUnfinished) { if (threadIdx.x == 0) counts[g] = -1; return; }
     if (!valid[g]) { if (threadIdx.x == 0) counts[g] = 0; return; }
     double P[12];
 #pragma unroll
@@ -250,11 +256,12 @@ __global__ __launch_bounds__(256) void pnp_reproj_sums_kernel(PnpProblem pb, con
 #define LAUNCH_OK() ESFM_HIP_TRY(hipGetLastError())
 
 int launch_pnp_chunk(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const int32_t *samples, int n_hyp, double *poses,
-                     int32_t *valid, int32_t *counts, esfm_ctx *timing_ctx)
+                     int32_t *valid, int32_t *counts, int sweep_cap, esfm_ctx *timing_ctx)
 {
     if (n_hyp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + kPnpHypPerBlock - 1) / kPnpHypPerBlock), dim3(64), 0, st, pb, p3, p2, samples, n_hyp, poses, valid);
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + kPnpHypPerBlock - 1) / kPnpHypPerBlock), dim3(64), 0, st, pb, p3, p2, samples, n_hyp, poses, valid,
+                       sweep_cap);
     LAUNCH_OK();
     hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp), dim3(256), 0, st, pb, p3, p2, poses, valid, counts);
     LAUNCH_OK();

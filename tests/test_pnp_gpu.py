@@ -38,6 +38,20 @@ def test_solve_pnp_ransac_matches_oracle(gpu_ctx, oracle_lib, n, frac, iters, se
         assert abs(np.linalg.det(Rg) - 1) < 1e-9
 
 
+@pytest.mark.parametrize("n,frac,seed", [(800, 0.6, 21), (400, 0.65, 22), (1500, 0.55, 23)])
+def test_solve_pnp_ransac_many_iterations_through_the_deferred_hypotheses(gpu_ctx, oracle_lib, n, frac, seed):
+    """Hundreds of RANSAC iterations (55 - 65 % gross outliers): about one hypothesis in a hundred stalls in the 12 x 12 Jacobi
+    diagonalisation; the first pass gives up on those after ten sweeps and the replay has them solved in full when it reaches them
+    (pnp_api.cpp) -- with this many iterations it does.  Iteration counts and masks exact, as everywhere."""
+    rng = np.random.default_rng(seed)
+    X, pix, R, t, bad = _scene(rng, n, frac)
+    ok, Rr, tr, rvr, mr, itr = oracle_lib.solve_pnp_ransac(X, pix, K4, 50000, 2.5, 0.99)
+    assert ok and itr > 150
+    rv, tv, Rg, mg, itg = E.solve_pnp_ransac(X, pix, K4, 50000, 2.5, 0.99, gpu_ctx)
+    assert itg == itr and np.array_equal(mg, mr)
+    assert np.allclose(Rg, Rr, atol=1e-7) and np.allclose(tv, tr, atol=1e-6) and np.allclose(rv, rvr, atol=1e-7)
+
+
 def test_pnp_exactly_five_and_too_few(gpu_ctx, oracle_lib):
     rng = np.random.default_rng(9)
     X, pix, R, t, _ = _scene(rng, 5, 0.0, noise=0.0)
