@@ -90,7 +90,7 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
         // count == modelPoints: the kernel runs once on all points and every point is an inlier
         for (int j = 0; j < 5; ++j) samples[(size_t)j] = j;
         ESFM_HIP_TRY(esfm::copy_h2d(d_samples, samples.data(), sizeof(int32_t) * 5, st));
-        if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, 1, d_poses, d_valid, d_counts, esfm::kPnpFullSweeps, ctx)) return rc;
+        if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, 1, d_poses, d_valid, d_counts, esfm::kPnpFullSweeps, false, ctx)) return rc;
         int32_t ok = 0;
         ESFM_HIP_TRY(esfm::copy_d2h(&ok, d_valid, sizeof(int32_t), st));
         ESFM_HIP_TRY(hipStreamSynchronize(st));
@@ -109,15 +109,18 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
             // first pass with a short sweep budget: the one hypothesis in a hundred whose diagonalisation stalls (60 sweeps: ~2 ms against
             // 0.5) comes back unfinished (count -1) instead of holding the launch, and is solved in full below only if the replay reaches it
             // before the adaptive count ends the search -- the same arithmetic on the same sample then, so nothing changes but the time
-            if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, n_hyp, d_poses, d_valid, d_counts, esfm::kPnpFirstSweeps, ctx)) return rc;
+            if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, n_hyp, d_poses, d_valid, d_counts, esfm::kPnpFirstSweeps, false, ctx)) return rc;
             ESFM_HIP_TRY(esfm::copy_d2h(counts.data(), d_counts, sizeof(int32_t) * (size_t)n_hyp, st));
             ESFM_HIP_TRY(hipStreamSynchronize(st));
             int best_k = -1;
             for (int k = 0; k < n_hyp && iter < niters; ++k, ++iter) {
                 if (counts[(size_t)k] < 0) {
-                    if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples + 5 * (size_t)k, 1, d_poses + 12 * (size_t)k, d_valid + k, d_counts + k,
-                                                        esfm::kPnpFullSweeps, ctx)) return rc;
-                    ESFM_HIP_TRY(esfm::copy_d2h(&counts[(size_t)k], d_counts + k, sizeof(int32_t), st));
+                    // every unfinished hypothesis the replay can still reach -- niters only ever shrinks -- in ONE launch (side by side, as
+                    // they ran before they were deferred; one after the other they would cost 2 ms each)
+                    const int reach = std::min(n_hyp - k, niters - iter);
+                    if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples + 5 * (size_t)k, reach, d_poses + 12 * (size_t)k, d_valid + k, d_counts + k,
+                                                        esfm::kPnpFullSweeps, true, ctx)) return rc;
+                    ESFM_HIP_TRY(esfm::copy_d2h(&counts[(size_t)k], d_counts + k, sizeof(int32_t) * (size_t)reach, st));
                     ESFM_HIP_TRY(hipStreamSynchronize(st));
                 }
                 const int good = counts[(size_t)k];   // 0 for a sample whose pose is not finite (runKernel returned no model)

@@ -78,12 +78,13 @@ struct Jacobi12Coop {
 
 __global__ __launch_bounds__(64) void pnp_solve_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
                                                        const int32_t *__restrict__ samples, int n_hyp, double *__restrict__ poses,
-                                                       int32_t *__restrict__ valid, int sweep_cap)
+                                                       int32_t *__restrict__ valid, int sweep_cap, int only_unfinished)
 {
     __shared__ double ws_all[kPnpHypPerBlock * kPnpWsStride];
     const int grp = threadIdx.x / kPnpLanes, l = threadIdx.x % kPnpLanes;
     const int g = blockIdx.x * kPnpHypPerBlock + grp;
     if (g >= n_hyp) return;
+    if (only_unfinished && valid[g] != kPnpUnfinished) return;      // the completion launch: everything else of the range is settled
     const int32_t *id = samples + 5 * (size_t)g;
     double pw[15], us[10];
     for (int k = 0; k < 5; ++k) {
@@ -128,10 +129,12 @@ __device__ __forceinline__ bool pnp_inlier(const PnpProblem &pb, const double *P
 }
 
 __global__ __launch_bounds__(256) void pnp_score_kernel(PnpProblem pb, const float *__restrict__ p3, const float *__restrict__ p2,
-                                                        const double *__restrict__ poses, const int32_t *__restrict__ valid, int32_t *__restrict__ counts)
+                                                        const double *__restrict__ poses, const int32_t *__restrict__ valid, int32_t *__restrict__ counts,
+                                                        int only_unscored)
 {
     __shared__ int red[4];
     const int g = blockIdx.x;
+    if (only_unscored && counts[g] >= 0) return;
     if (valid[g] == kPnpUnfinished) { if (threadIdx.x == 0) counts[g] = -1; return; }
     if (!valid[g]) { if (threadIdx.x == 0) counts[g] = 0; return; }
     double P[12];
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(256) void pnp_reproj_sums_kernel(PnpProblem pb, con
 #define LAUNCH_OK() ESFM_HIP_TRY(hipGetLastError())
 
 int launch_pnp_chunk(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const int32_t *samples, int n_hyp, double *poses,
-                     int32_t *valid, int32_t *counts, int sweep_cap, esfm_ctx *timing_ctx)
+                     int32_t *valid, int32_t *counts, int sweep_cap, bool only_unfinished, esfm_ctx *timing_ctx)
 {
     if (n_hyp <= 0) return ESFM_OK;
     KernelTimer tm(timing_ctx, ESFM_K_RANSAC);
     hipLaunchKernelGGL(pnp_solve_kernel, dim3((n_hyp + kPnpHypPerBlock - 1) / kPnpHypPerBlock), dim3(64), 0, st, pb, p3, p2, samples, n_hyp, poses, valid,
-                       sweep_cap);
+                       sweep_cap, only_unfinished ? 1 : 0);
     LAUNCH_OK();
-    hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp), dim3(256), 0, st, pb, p3, p2, poses, valid, counts);
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp), dim3(256), 0, st, pb, p3, p2, poses, valid, counts, only_unfinished ? 1 : 0);
     LAUNCH_OK();
     return ESFM_OK;
 }

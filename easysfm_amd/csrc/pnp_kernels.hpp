@@ -16,11 +16,12 @@ struct PnpProblem {
 
 // Solve + score n_hyp hypotheses.  sweep_cap < kPnpFullSweeps: the 12 x 12 Jacobi diagonalisation gives up after that many sweeps
 // (valid = kPnpUnfinished, count = -1) -- about one matrix in a hundred never reaches the routine's threshold and runs into its cap of
-// 60 sweeps, ten times a usual solve, and a launch lasts as long as its slowest hypothesis; the caller solves such a hypothesis again
-// with kPnpFullSweeps only if the RANSAC replay gets as far as needing it.
+// 60 sweeps, ten times a usual solve, and a launch lasts as long as its slowest hypothesis; the caller has such hypotheses solved again
+// with kPnpFullSweeps (only_unfinished: the launch touches nothing but the entries marked kPnpUnfinished / count -1 of the range it is
+// given) only if the RANSAC replay gets as far as needing one.
 constexpr int kPnpFullSweeps = 60, kPnpFirstSweeps = 10, kPnpUnfinished = 2;
 int launch_pnp_chunk(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const int32_t *samples, int n_hyp, double *poses,
-                     int32_t *valid, int32_t *counts, int sweep_cap, esfm_ctx *timing_ctx);
+                     int32_t *valid, int32_t *counts, int sweep_cap, bool only_unfinished, esfm_ctx *timing_ctx);
 int launch_pnp_mask(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const double *pose, uint8_t *mask);
 int launch_pnp_moment_sums(hipStream_t st, const PnpProblem &pb, const float *p3, const uint8_t *mask, double *out /*13*/);
 int launch_pnp_mtm_sums(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const uint8_t *mask, const double *geo /*12*/,

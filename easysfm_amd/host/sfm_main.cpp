@@ -251,19 +251,26 @@ int main(int argc, char **argv)
         for (const frame_t &f : frames) total_kp += f.keypoints.size();
         std::vector<std::vector<bool>> track(nf, std::vector<bool>(std::max<size_t>(total_kp, 1), false));
         int cur_id = 0;
+        std::vector<char> id_in_frame(std::max<size_t>(total_kp, 1), 0);     // which ids the current frame's keypoints hold (ids < total_kp)
         for (int i = 0; i < frame_number; ++i) {
             frame_t &fi = frames[size_t(i)];
+            // the reference walks the frame's whole id list for every match ("is this id used already?", sfm.cpp:190-199):
+            // O(matches x keypoints) per frame.  The same question from a flag per id that follows every assignment.
+            std::vector<int> held;
             for (int j = 0; j < i; ++j) {
                 const frame_t &fj = frames[size_t(j)];
                 for (const DMatch &m : graph[size_t(i)][size_t(j)].matches) {
                     const int tid = fj.unique_pixel_ids[size_t(m.trainIdx)];
                     int &mine = fi.unique_pixel_ids[size_t(m.queryIdx)];
                     if (mine >= 0 && mine == tid) continue;
-                    bool is_duplicated = false;
-                    for (int v : fi.unique_pixel_ids) if (v == tid) { is_duplicated = true; break; }
-                    if (!is_duplicated) { mine = tid; fi.unique_pixel_has_match[size_t(m.queryIdx)] = true; }
+                    if (!id_in_frame[size_t(tid)]) {
+                        if (mine >= 0) id_in_frame[size_t(mine)] = 0;      // (this keypoint was the only holder of its old id)
+                        mine = tid; id_in_frame[size_t(tid)] = 1; held.push_back(tid);
+                        fi.unique_pixel_has_match[size_t(m.queryIdx)] = true;
+                    }
                 }
             }
+            for (int v : held) id_in_frame[size_t(v)] = 0;
             int fresh = 0;
             for (size_t k = 0; k < fi.unique_pixel_ids.size(); ++k) {
                 if (fi.unique_pixel_ids[k] < 0) fi.unique_pixel_ids[k] = cur_id + fresh++;
