@@ -23,7 +23,9 @@ using esfm::BADev;
 struct esfm_ba_problem {
     esfm_ctx *ctx = nullptr;
     BADev d;
-    std::vector<void *> allocs;
+    std::vector<void *> allocs;          // the chunks dev_alloc carves the problem's arrays from
+    char *arena_cur = nullptr;            // free space of the newest chunk
+    size_t arena_left = 0;
     std::vector<double> cam_nobs_local;  // this rank's observation count per camera-side block
     bool params_swapped = false;
     // box bounds (reference ba.cpp:155-162 reference camera, ba.cpp:190-194 intrinsics); +-inf where there is none
@@ -57,17 +59,30 @@ long readback_timeout_s()
     return v;
 }
 
+// A problem's ~45 device arrays are carved from a few chunks (256-byte aligned, 256 spare bytes behind each array) instead of one
+// hipMalloc each: for the small problems of an incremental reconstruction -- a BA call every ba_frequency frames, a dozen cameras and
+// a few thousand observations -- 45 hipMalloc + 45 synchronising hipFree per call were most of the call (config 1: 4 ms per call,
+// of which the LM iterations themselves are about one).  An array that does not fit the current chunk's rest opens a chunk of its own
+// size (at least kArenaChunk): the large arrays of BA-512 still get one allocation each.
+constexpr size_t kArenaChunk = size_t(4) << 20;
 template <class T> int dev_alloc(esfm_ba_problem *p, T **out, size_t count)
 {
-    void *ptr = nullptr;
-    const size_t bytes = sizeof(T) * std::max<size_t>(count, 1);
-    hipError_t e = hipMalloc(&ptr, bytes);
-    if (e != hipSuccess) {
-        esfm::set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        return e == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;
+    const size_t bytes = (sizeof(T) * std::max<size_t>(count, 1) + 255) / 256 * 256 + 256;
+    if (bytes > p->arena_left) {
+        void *ptr = nullptr;
+        const size_t chunk = std::max(bytes, kArenaChunk);
+        hipError_t e = hipMalloc(&ptr, chunk);
+        if (e != hipSuccess) {
+            esfm::set_error("hipMalloc(%zu) failed: %s", chunk, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;
+        }
+        p->allocs.push_back(ptr);
+        p->arena_cur = static_cast<char *>(ptr);
+        p->arena_left = chunk;
     }
-    p->allocs.push_back(ptr);
-    *out = reinterpret_cast<T *>(ptr);
+    *out = reinterpret_cast<T *>(p->arena_cur);
+    p->arena_cur += bytes;
+    p->arena_left -= bytes;
     return ESFM_OK;
 }
 
