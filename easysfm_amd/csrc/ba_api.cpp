@@ -60,10 +60,11 @@ long readback_timeout_s()
 }
 
 // A problem's ~45 device arrays are carved from a few chunks (256-byte aligned, 256 spare bytes behind each array) instead of one
-// hipMalloc each: for the small problems of an incremental reconstruction -- a BA call every ba_frequency frames, a dozen cameras and
-// a few thousand observations -- 45 hipMalloc + 45 synchronising hipFree per call were most of the call (config 1: 4 ms per call,
-// of which the LM iterations themselves are about one).  An array that does not fit the current chunk's rest opens a chunk of its own
-// size (at least kArenaChunk): the large arrays of BA-512 still get one allocation each.
+// hipMalloc each: the small problems of an incremental reconstruction -- a BA call every ba_frequency frames, a dozen cameras and a
+// few thousand observations -- are set up and torn down once per call (scratch/ba_small_time.py: set-up 0.3 - 0.9 ms, tear-down 0.4 -
+// 0.9 ms with one or two chunks; the call's 4 - 5 ms are its up to 50 LM iterations of 0.075 - 0.087 ms, a launch-latency chain).  An
+// array that does not fit the current chunk's rest opens a chunk of its own size (at least kArenaChunk): the large arrays of BA-512
+// still get one allocation each.
 constexpr size_t kArenaChunk = size_t(4) << 20;
 template <class T> int dev_alloc(esfm_ba_problem *p, T **out, size_t count)
 {
