@@ -66,6 +66,27 @@ def test_undistort_four_pixel_form_at_image_borders_matches_oracle(gpu_ctx, orac
         assert np.array_equal(out, oracle_lib.undistort(img, K4, dist)), (K4, dist)
 
 
+def test_undistort_registered_host_memory_takes_the_single_transfer_path(gpu_ctx):
+    """common.hpp copy_h2d / copy_d2h: caller-owned pageable buffers travel in 512-KiB pieces, buffers the caller registered with HIP
+    (here: torch's pinned allocator = hipHostMalloc) in one transfer -- same image either way, also when input and output differ in kind."""
+    import ctypes as C
+    import torch
+    from easysfm_amd._lib import lib, check
+    rng = np.random.default_rng(77)
+    rows, cols = 1024, 1536                                      # 4.7 MB: nine pieces each way from pageable memory
+    img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    k4 = np.array([1400.0, 760.0, 1410.0, 500.0]); d4 = np.array([-0.2, 0.05, 0.001, -0.002])
+    ref = E.undistort(img, k4, d4, gpu_ctx)
+    pin_in = torch.empty((rows, cols, 3), dtype=torch.uint8).pin_memory(); pin_in.numpy()[:] = img
+    pin_out = torch.empty((rows, cols, 3), dtype=torch.uint8).pin_memory()
+    out_pageable = np.empty_like(img)
+    for src, dst in ((pin_in.data_ptr(), pin_out.data_ptr()), (pin_in.data_ptr(), out_pageable.ctypes.data), (img.ctypes.data, pin_out.data_ptr())):
+        pin_out.zero_(); out_pageable[:] = 0
+        check(lib().esfm_undistort(gpu_ctx.handle, C.c_void_p(src), rows, cols, 3, C.c_void_p(k4.ctypes.data), C.c_void_p(d4.ctypes.data), C.c_void_p(dst)))
+        got = pin_out.numpy() if dst == pin_out.data_ptr() else out_pageable
+        assert np.array_equal(got, ref)
+
+
 def test_undistort_full_size_properties(gpu_ctx):
     """The reference's image size (fountain: 2048 x 3072 BGR).  Zero coefficients are an exact identity (what every BASELINE
     configuration runs); a radial model leaves the principal point's neighbourhood in place, is symmetric under a 180-degree
