@@ -85,6 +85,17 @@ def test_undistort_registered_host_memory_takes_the_single_transfer_path(gpu_ctx
         check(lib().esfm_undistort(gpu_ctx.handle, C.c_void_p(src), rows, cols, 3, C.c_void_p(k4.ctypes.data), C.c_void_p(d4.ctypes.data), C.c_void_p(dst)))
         got = pin_out.numpy() if dst == pin_out.data_ptr() else out_pageable
         assert np.array_equal(got, ref)
+    # a cv::Mat-style buffer the host registered itself (hipHostRegister), as INTEGRATION.md suggests for large images
+    hip = C.CDLL("libamdhip64.so")
+    reg_in, reg_out = img.copy(), np.zeros_like(img)
+    assert hip.hipHostRegister(C.c_void_p(reg_in.ctypes.data), C.c_size_t(reg_in.nbytes), C.c_uint(0)) == 0
+    assert hip.hipHostRegister(C.c_void_p(reg_out.ctypes.data), C.c_size_t(reg_out.nbytes), C.c_uint(0)) == 0
+    try:
+        check(lib().esfm_undistort(gpu_ctx.handle, C.c_void_p(reg_in.ctypes.data), rows, cols, 3, C.c_void_p(k4.ctypes.data), C.c_void_p(d4.ctypes.data),
+                                   C.c_void_p(reg_out.ctypes.data)))
+        assert np.array_equal(reg_out, ref)
+    finally:
+        hip.hipHostUnregister(C.c_void_p(reg_in.ctypes.data)); hip.hipHostUnregister(C.c_void_p(reg_out.ctypes.data))
 
 
 def test_undistort_full_size_properties(gpu_ctx):
