@@ -93,7 +93,7 @@ typedef enum esfm_kernel_id {
     ESFM_K_TRIANGULATE = 7,   /* triangulate_dlt_kernel                                         */
     ESFM_K_RANSAC = 8,        /* essential_setup + _roots + _score kernels (one chunk)         */
     ESFM_K_SURF_DET = 9,      /* surf_det_trace_kernel                                          */
-    ESFM_K_SURF_DESC = 10,    /* surf_describe_kernel                                           */
+    ESFM_K_SURF_DESC = 10,    /* the four descriptor launches: surf_orient / window / rowsum / vector */
     ESFM_K_UNDISTORT = 11,    /* undistort_remap_kernel                                         */
     ESFM_K_ORB_FAST = 12,     /* orb_fast_kernel: FAST-9/16 score of every pyramid pixel          */
     ESFM_K_L2_SECOND = 13,    /* l2_finish_kernel: everything behind the one-product pass (re-rank of the ratio screen's survivors, threshold filter, ratio test, compaction) */
