@@ -23,7 +23,7 @@ using esfm::BADev;
 struct esfm_ba_problem {
     esfm_ctx *ctx = nullptr;
     BADev d;
-    std::vector<void *> allocs;          // the chunks dev_alloc carves the problem's arrays from
+    std::vector<esfm_ctx::BaChunk> allocs;   // the chunks dev_alloc carves the problem's arrays from
     char *arena_cur = nullptr;            // free space of the newest chunk
     size_t arena_left = 0;
     std::vector<double> cam_nobs_local;  // this rank's observation count per camera-side block
@@ -62,7 +62,8 @@ long readback_timeout_s()
 // A problem's ~45 device arrays are carved from a few chunks (256-byte aligned, 256 spare bytes behind each array) instead of one
 // hipMalloc each: the small problems of an incremental reconstruction -- a BA call every ba_frequency frames, a dozen cameras and a
 // few thousand observations -- are set up and torn down once per call (scratch/ba_small_time.py: set-up 0.3 - 0.9 ms, tear-down 0.4 -
-// 0.9 ms with one or two chunks; the call's 4 - 5 ms are its up to 50 LM iterations of 0.075 - 0.087 ms, a launch-latency chain).  An
+// 0.9 ms with one or two chunks; 0.14 / 0.0 ms once the chunks come from and go back to the context, below; the call's 4 - 5 ms are
+// its up to 50 LM iterations of 0.075 - 0.087 ms, a launch-latency chain).  An
 // array that does not fit the current chunk's rest opens a chunk of its own size (at least kArenaChunk): the large arrays of BA-512
 // still get one allocation each.
 constexpr size_t kArenaChunk = size_t(4) << 20;
@@ -71,13 +72,24 @@ template <class T> int dev_alloc(esfm_ba_problem *p, T **out, size_t count)
     const size_t bytes = (sizeof(T) * std::max<size_t>(count, 1) + 255) / 256 * 256 + 256;
     if (bytes > p->arena_left) {
         void *ptr = nullptr;
-        const size_t chunk = std::max(bytes, kArenaChunk);
-        hipError_t e = hipMalloc(&ptr, chunk);
-        if (e != hipSuccess) {
-            esfm::set_error("hipMalloc(%zu) failed: %s", chunk, hipGetErrorString(e));
-            return e == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;
+        size_t chunk = std::max(bytes, kArenaChunk);
+        // a chunk the context kept from a destroyed problem, the smallest that fits (esfm_ba_problem_destroy synchronised the stream
+        // before it handed the chunk over)
+        auto &pool = p->ctx->ba_chunks;
+        int best = -1;
+        for (int i = 0; i < (int)pool.size(); ++i)
+            if (pool[(size_t)i].bytes >= bytes && (best < 0 || pool[(size_t)i].bytes < pool[(size_t)best].bytes)) best = i;
+        if (best >= 0) {
+            ptr = pool[(size_t)best].ptr; chunk = pool[(size_t)best].bytes;
+            pool.erase(pool.begin() + best);
+        } else {
+            hipError_t e = hipMalloc(&ptr, chunk);
+            if (e != hipSuccess) {
+                esfm::set_error("hipMalloc(%zu) failed: %s", chunk, hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? ESFM_ERR_OOM : ESFM_ERR_HIP;
+            }
         }
-        p->allocs.push_back(ptr);
+        p->allocs.push_back({ptr, chunk});
         p->arena_cur = static_cast<char *>(ptr);
         p->arena_left = chunk;
     }
@@ -626,9 +638,17 @@ int esfm_ba_problem_destroy(esfm_ba_problem *P)
 {
     if (!P) return ESFM_OK;
     if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
-    for (void *p : P->allocs) (void)hipFree(p);
+    // small chunks and the mailbox stay with the context for its next problem (at most kKeepChunks chunks of at most kKeepBytes)
+    constexpr size_t kKeepChunks = 6, kKeepBytes = size_t(64) << 20;
+    for (const auto &c : P->allocs) {
+        if (P->ctx && c.bytes <= kKeepBytes && P->ctx->ba_chunks.size() < kKeepChunks) P->ctx->ba_chunks.push_back(c);
+        else (void)hipFree(c.ptr);
+    }
     esfm::ba_sparse_destroy(P->sparse);
-    if (P->h_scal) (void)hipHostFree(P->h_scal);
+    if (P->h_scal) {
+        if (P->ctx && P->ctx->ba_mailboxes.size() < 2) P->ctx->ba_mailboxes.push_back(P->h_scal);
+        else (void)hipHostFree(P->h_scal);
+    }
     delete P;
     return ESFM_OK;
 }
@@ -659,6 +679,11 @@ int esfm_ba_problem_solve(esfm_ba_problem *P, const esfm_ba_options *options, es
     memset(sum, 0, sizeof(*sum));
     Solver S;
     S.P = P; S.ar = allreduce; S.ar_user = allreduce_user; S.st = P->ctx->stream;
+    if (!P->h_scal && !P->ctx->ba_mailboxes.empty()) {
+        P->h_scal = static_cast<double *>(P->ctx->ba_mailboxes.back());
+        P->ctx->ba_mailboxes.pop_back();
+        memset(P->h_scal, 0, sizeof(double) * (esfm::SC_COUNT + 2));
+    }
     if (!P->h_scal) {
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&P->h_scal), sizeof(double) * (esfm::SC_COUNT + 2), hipHostMallocCoherent);   // explicit: the host spins on a device-written flag
         if (e == hipSuccess) memset(P->h_scal, 0, sizeof(double) * (esfm::SC_COUNT + 2));

@@ -121,6 +121,11 @@ struct esfm_ctx {
     void *pinned_rounds = nullptr;
     size_t pinned_rounds_cap = 0;
     int pin_rounds(size_t bytes);
+    // device chunks and pinned scalar mailboxes of destroyed BA problems, kept for the next problem of this context (an incremental
+    // reconstruction sets one up and tears it down every ba_frequency frames: ba_api.cpp dev_alloc / esfm_ba_problem_destroy)
+    struct BaChunk { void *ptr; size_t bytes; };
+    std::vector<BaChunk> ba_chunks;
+    std::vector<void *> ba_mailboxes;
     // optional per-kernel hipEvent timing (esfm_ctx_set_kernel_timing)
     bool timing = false;
     struct TimedLaunch { int id; hipEvent_t a, b; };

@@ -175,6 +175,8 @@ int esfm_ctx_destroy(esfm_ctx *ctx)
     for (auto *b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_rounds) (void)hipHostFree(ctx->pinned_rounds);
+    for (auto &c : ctx->ba_chunks) (void)hipFree(c.ptr);
+    for (void *m : ctx->ba_mailboxes) (void)hipHostFree(m);
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
