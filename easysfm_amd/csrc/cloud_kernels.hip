@@ -13,7 +13,7 @@
 // VALU-bound (N^2 / 64 wave-steps); HBM traffic is the cloud itself once per workgroup (L2-resident).
 //
 // From 4096 points on (round 3) the candidates no longer are "every point": the cloud is sorted along the longest axis of its bounding
-// box (one device radix sort of (coordinate, index) pairs -- rocPRIM through hipCUB, plumbing like the copies around it; "x" below is
+// box (one device radix sort of (coordinate, index) pairs -- rocPRIM through hipCUB, in cloud_sort.hip; plumbing like the copies around it; "x" below is
 // that coordinate), a workgroup takes 64 CONSECUTIVE queries of that
 // order and sweeps a window of the sorted cloud outwards from them, 1024 candidates at a time, alternately right and left, until
 // every one of its queries is certified: the 64th-smallest squared distance it holds is <= (x_q - x_edge)^2 at both edges of the
@@ -30,9 +30,11 @@
 #include <math.h>
 #include <stdlib.h>
 
-#include <hipcub/hipcub.hpp>
-
 namespace esfm {
+
+// cloud_sort.hip (the radix sort lives in its own code object)
+int sor_sort_scratch_bytes(int n, size_t *bytes, hipStream_t st);
+int sor_sort_pairs(void *tmp, size_t tmp_bytes, const float *keys_in, float *keys_out, const int32_t *idx_in, int32_t *idx_out, int n, hipStream_t st);
 
 constexpr int kSorWaves = 16;
 constexpr int kSorThreads = kSorWaves * 64;
@@ -354,7 +356,7 @@ int launch_sor_knn_mean(hipStream_t st, const float *pts_dev, int n, int stride,
     }
     // sorted by the key: bounding box | keys | idx | perm | planes (4 n: the sorted keys, x, y, z) | radix-sort scratch
     size_t tmp_bytes = 0;
-    ESFM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const float *)nullptr, (float *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr, n, 0, 32, st));
+    if (int rc = sor_sort_scratch_bytes(n, &tmp_bytes, st)) return rc;
     const size_t words = 8 * (size_t)n + 8;
     if (int rc = ctx->stage_e.reserve(sizeof(float) * words + tmp_bytes + 256)) return rc;
     unsigned int *bb = ctx->stage_e.as<unsigned int>();
@@ -371,7 +373,7 @@ int launch_sor_knn_mean(hipStream_t st, const float *pts_dev, int n, int stride,
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sor_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts_dev, n, stride, bb, keys, idx);
     ESFM_HIP_TRY(hipGetLastError());
-    ESFM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, planes, idx, perm, n, 0, 32, st));
+    if (int rc = sor_sort_pairs(tmp, tmp_bytes, keys, planes, idx, perm, n, st)) return rc;
     hipLaunchKernelGGL(sor_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pts_dev, n, stride, perm, planes);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sor_knn_mean_kernel<true>, dim3(grid), dim3(kSorThreads), 0, st, planes, n, stride, mean_k, mean_dist_dev, perm, kSorMaxTiles,
