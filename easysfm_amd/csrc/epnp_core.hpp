@@ -18,20 +18,40 @@ namespace epnp {
 
 struct Cam { double fu, fv, uc, vc; };
 
+// the stopping rule of the CPU restatement's jacobi_sym (oracle/pnp_ref.c), to the letter: EPnP reads the FOUR SMALLEST eigenpairs of M'M,
+// which sit at the rounding level of the largest, and a sweep more or less changes them in the fifth digit.  Until round 5 this side
+// stopped at 60 sweeps / 1e-36 and the oracle at 100 sweeps / 1e-40: a random sweep (tests/stress_pnp.py) found 3.7 % of the RANSAC
+// problems choosing differently, and both thresholds were beyond what double arithmetic delivers for 1 - 2.5 % of the matrices, which
+// then ran into the cap.  Both sides now stop where cvSVD's Jacobi routine does: 10 DBL_EPSILON, at most max(m, 30) sweeps.
+constexpr int kJacobiSweeps = 30;       // (cvSVD's Jacobi routine: max(m, 30) sweeps)
+constexpr double kJacobiOff = 4.9303806576313238e-30;      // (10 DBL_EPSILON)^2: the scale of cvSVD's own convergence test
+// cos / sin of a rotation from th = (a_qq - a_pp) / (2 a_pq):  t = sign(th) / (|th| + sqrt(1 + th^2)),  c = 1 / sqrt(1 + t^2),  s = t c.
+// For 2^27 <= |th| <= 2^500 the chain collapses EXACTLY, in IEEE double arithmetic: th^2 >= 2^54, so 1 + th^2 rounds to th^2;
+// sqrt of a correctly rounded square is |th| (radix 2, no overflow below 2^511); |th| + |th| is exact; so t is the same division
+// sign / (2 |th|) either way, |t| <= 2^-28, 1 + t^2 rounds to 1, c = 1 and s = t.  Two long-latency operations instead of five --
+// what the sweeps of a nearly diagonal matrix (the last sweeps of every diagonalisation, all 30 of a stalled one) consist of.
+// Checked against the CPU restatement's full chain on 20 000 five-point samples, bit for bit through every stage of the solve.
+ESFM_HD void jacobi_cs(double th, double &c, double &s)
+{
+    const double ath = fabs(th);
+    if (ath >= 134217728.0 && ath <= 0x1p500) { c = 1.0; s = (th >= 0.0 ? 1.0 : -1.0) / (ath + ath); return; }
+    const double t = (th >= 0.0 ? 1.0 : -1.0) / (ath + sqrt(1.0 + th * th));
+    c = 1.0 / sqrt(1.0 + t * t); s = t * c;
+}
 template <int N> ESFM_HD void jacobi_sym(double *A, double *V)
 {
     for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) V[i * N + j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
+    for (int sweep = 0; sweep < kJacobiSweeps; ++sweep) {
         double off = 0.0, diag = 0.0;
         for (int i = 0; i < N; ++i) { diag += A[i * N + i] * A[i * N + i]; for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j]; }
-        if (off <= 1e-36 * diag || off == 0.0) break;
+        if (off <= kJacobiOff * diag || off == 0.0) break;
         for (int p = 0; p < N - 1; ++p)
             for (int q = p + 1; q < N; ++q) {
                 const double apq = A[p * N + q];
                 if (apq == 0.0) continue;
                 const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
-                const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                double c, s;
+                jacobi_cs(th, c, s);
                 for (int r = 0; r < N; ++r) { const double x = A[r * N + p], y = A[r * N + q]; A[r * N + p] = c * x - s * y; A[r * N + q] = s * x + c * y; }
                 for (int r = 0; r < N; ++r) { const double x = A[p * N + r], y = A[q * N + r]; A[p * N + r] = c * x - s * y; A[q * N + r] = s * x + c * y; }
                 for (int r = 0; r < N; ++r) { const double x = V[r * N + p], y = V[r * N + q]; V[r * N + p] = c * x - s * y; V[r * N + q] = s * x + c * y; }
@@ -87,11 +107,32 @@ ESFM_HD double det3(const double *M) { return M[0] * (M[4] * M[8] - M[5] * M[7])
 
 // choose_control_points + the inverse used by compute_barycentric_coordinates.  sum_pw = sum of the points, sum_pwpw = sum of
 // pw pw' (raw second moments, row-major 3 x 3).
+// (the tail both forms share: cws[0] = the centroid and C = the scatter matrix about it are in)
+ESFM_HD void control_points_from_scatter(const double C[9], int n, double cws[4][3], double CCi[9]);
 ESFM_HD void control_points(const double sum_pw[3], const double sum_pwpw[9], int n, double cws[4][3], double CCi[9])
 {
     for (int j = 0; j < 3; ++j) cws[0][j] = sum_pw[j] / n;
     double C[9];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = sum_pwpw[3 * a + b] - n * cws[0][a] * cws[0][b];
+    control_points_from_scatter(C, n, cws, CCi);
+}
+// The same from the points themselves, the scatter matrix summed about the centroid in the order the CPU restatement sums it
+// (oracle/pnp_ref.c epnp_pose): what the RANSAC hypotheses use.  The moment form above is for the re-fit, whose sums over thousands of
+// correspondences are device reductions and agree with a serial loop to rounding only; a 5-point hypothesis has no such excuse, and
+// EPnP amplifies a last-bit difference of C into pose differences that move threshold-borderline correspondences in and out of the
+// inlier set (a random sweep against the oracle: 3.7 % of the problems picked another of two nearly equal hypotheses).
+ESFM_HD void control_points_centred_n(const double *pws, int n, double cws[4][3], double CCi[9])
+{
+    for (int j = 0; j < 3; ++j) cws[0][j] = 0.0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) cws[0][j] += pws[3 * i + j];
+    for (int j = 0; j < 3; ++j) cws[0][j] /= n;
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] += (pws[3 * i + a] - cws[0][a]) * (pws[3 * i + b] - cws[0][b]);
+    control_points_from_scatter(C, n, cws, CCi);
+}
+template <int K> ESFM_HD void control_points_centred(const double *pws, double cws[4][3], double CCi[9]) { control_points_centred_n(pws, K, cws, CCi); }
+ESFM_HD void control_points_from_scatter(const double C[9], int n, double cws[4][3], double CCi[9])
+{
     double uct[9], dc[3];
     sym_eig_desc<3>(C, uct, dc);
     for (int i = 1; i < 4; ++i) { const double k = sqrt(fmax(dc[i - 1], 0.0) / n); for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * uct[3 * (i - 1) + j]; }
@@ -224,11 +265,26 @@ ESFM_HD void ccs_of(const double b[4], const double v[4][12], double ccs[4][3])
 }
 
 // estimate_R_and_t from the raw sums over the correspondences: sum_pc, sum_pw (3), sum_pcpw = sum pc pw' (3 x 3)
+ESFM_HD void rt_from_cross_covariance(const double pc0[3], const double pw0[3], const double ABt[9], double R[9], double t[3]);
 ESFM_HD void rt_from_sums(int n, const double sum_pc[3], const double sum_pw[3], const double sum_pcpw[9], double R[9], double t[3])
 {
     double pc0[3], pw0[3], ABt[9];
     for (int j = 0; j < 3; ++j) { pc0[j] = sum_pc[j] / n; pw0[j] = sum_pw[j] / n; }
     for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) ABt[3 * j + k] = sum_pcpw[3 * j + k] - n * pc0[j] * pw0[k];
+    rt_from_cross_covariance(pc0, pw0, ABt, R, t);
+}
+// estimate_R_and_t from the points themselves, centred sums in the CPU restatement's order (the hypotheses; see control_points_centred)
+ESFM_HD void rt_centred_n(const double *pcs /* n x 3 */, const double *pws /* n x 3 */, int n, double R[9], double t[3])
+{
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0}, ABt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) { pc0[j] += pcs[3 * i + j]; pw0[j] += pws[3 * i + j]; }
+    for (int j = 0; j < 3; ++j) { pc0[j] /= n; pw0[j] /= n; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) ABt[3 * j + k] += (pcs[3 * i + j] - pc0[j]) * (pws[3 * i + k] - pw0[k]);
+    rt_from_cross_covariance(pc0, pw0, ABt, R, t);
+}
+template <int K> ESFM_HD void rt_centred(const double *pcs /* K x 3 */, const double *pws /* K x 3 */, double R[9], double t[3]) { rt_centred_n(pcs, pws, K, R, t); }
+ESFM_HD void rt_from_cross_covariance(const double pc0[3], const double pw0[3], const double ABt[9], double R[9], double t[3])
+{
     double G[9], V[9];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { G[3 * a + b] = 0.0; for (int k = 0; k < 3; ++k) G[3 * a + b] += ABt[3 * k + a] * ABt[3 * k + b]; }
     jacobi_sym<3>(G, V);
@@ -263,10 +319,8 @@ ESFM_HD double reproj_dist(const Cam &cam, const double R[9], const double t[3],
 // epnp::compute_pose for K points held by one thread (the RANSAC kernel: K = 5)
 template <int K, class JAC> ESFM_HD double solve_small_ws(const Cam &cam, const double *pws, const double *us, double R[9], double t[3], double *ws /* 4 x 144 doubles */, JAC jac)
 {
-    double sum_pw[3] = {0, 0, 0}, sum_pwpw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { sum_pw[a] += pws[3 * i + a]; for (int b = 0; b < 3; ++b) sum_pwpw[3 * a + b] += pws[3 * i + a] * pws[3 * i + b]; }
     double cws[4][3], CCi[9];
-    control_points(sum_pw, sum_pwpw, K, cws, CCi);
+    control_points_centred<K>(pws, cws, CCi);
     EPNP_MARK(0);
     double alphas[K][4];
     double *MtM = ws;
@@ -287,17 +341,46 @@ template <int K, class JAC> ESFM_HD double solve_small_ws(const Cam &cam, const 
         ccs_of(betas[N], v, ccs);
         double pcs[K][3];
         for (int i = 0; i < K; ++i) for (int j = 0; j < 3; ++j) pcs[i][j] = alphas[i][0] * ccs[0][j] + alphas[i][1] * ccs[1][j] + alphas[i][2] * ccs[2][j] + alphas[i][3] * ccs[3][j];
-        const double sg = pcs[0][2] < 0.0 ? -1.0 : 1.0;   // solve_for_sign
-        double sum_pc[3] = {0, 0, 0}, sum_pcpw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < K; ++i) for (int a = 0; a < 3; ++a) { const double pc = sg * pcs[i][a]; sum_pc[a] += pc; for (int b = 0; b < 3; ++b) sum_pcpw[3 * a + b] += pc * pws[3 * i + b]; }
+        if (pcs[0][2] < 0.0) for (int i = 0; i < K; ++i) for (int j = 0; j < 3; ++j) pcs[i][j] = -pcs[i][j];   // solve_for_sign
         double Rn[9], tn[3];
-        rt_from_sums(K, sum_pc, sum_pw, sum_pcpw, Rn, tn);
+        rt_centred<K>(&pcs[0][0], pws, Rn, tn);
         double e = 0.0;
         for (int i = 0; i < K; ++i) e += reproj_dist(cam, Rn, tn, pws + 3 * i, us[2 * i], us[2 * i + 1]);
         e /= K;
         if (N == 0 || e < best_err) { best_err = e; for (int a = 0; a < 9; ++a) R[a] = Rn[a]; for (int a = 0; a < 3; ++a) t[a] = tn[a]; }
     }
     EPNP_MARK(6);
+    return best_err;
+}
+// epnp::compute_pose on n points from the points themselves, every sum serial and in index order: the CPU restatement's epnp_pose to the
+// letter (the re-fit of a SMALL inlier set on the host, pnp_api.cpp: such sets are the ill-conditioned ones, where the device
+// reductions' rounding was amplified into visibly different poses).  alphas: 4 n doubles of scratch, pcs: 3 n.
+inline double solve_n(const Cam &cam, const double *pws, const double *us, int n, double *alphas, double *pcs, double R[9], double t[3])
+{
+    double cws[4][3], CCi[9], MtM[144];
+    control_points_centred_n(pws, n, cws, CCi);
+    for (int a = 0; a < 144; ++a) MtM[a] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        alphas_of(cws[0], CCi, pws + 3 * i, alphas + 4 * i);
+        double m1[12], m2[12];
+        m_rows(cam, alphas + 4 * i, us[2 * i], us[2 * i + 1], m1, m2);
+        for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) MtM[12 * a + b] += m1[a] * m1[b] + m2[a] * m2[b];
+    }
+    double v[4][12], betas[3][4];
+    betas_from_mtm(MtM, cws, v, betas);
+    double best_err = 0.0;
+    for (int N = 0; N < 3; ++N) {
+        double ccs[4][3];
+        ccs_of(betas[N], v, ccs);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) { const double *a = alphas + 4 * i; pcs[3 * i + j] = a[0] * ccs[0][j] + a[1] * ccs[1][j] + a[2] * ccs[2][j] + a[3] * ccs[3][j]; }
+        if (pcs[2] < 0.0) for (int i = 0; i < 3 * n; ++i) pcs[i] = -pcs[i];   // solve_for_sign
+        double Rn[9], tn[3];
+        rt_centred_n(pcs, pws, n, Rn, tn);
+        double e = 0.0;
+        for (int i = 0; i < n; ++i) e += reproj_dist(cam, Rn, tn, pws + 3 * i, us[2 * i], us[2 * i + 1]);
+        e /= n;
+        if (N == 0 || e < best_err) { best_err = e; for (int a = 0; a < 9; ++a) R[a] = Rn[a]; for (int a = 0; a < 3; ++a) t[a] = tn[a]; }
+    }
     return best_err;
 }
 template <int K> ESFM_HD double solve_small(const Cam &cam, const double *pws, const double *us, double R[9], double t[3])

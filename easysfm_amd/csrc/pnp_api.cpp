@@ -7,6 +7,7 @@
 // correspondences run on the GPU and whose fixed-size algebra (3 x 3, 12 x 12 eigen-decompositions, betas) runs here from
 // the same epnp_core.hpp the kernels use; finally cv::Rodrigues of the rotation.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -19,6 +20,7 @@ namespace ep = esfm::epnp;
 
 namespace {
 
+constexpr int kPnpHostRefit = 1024; // inlier sets up to this size are re-fitted on the host (serial sums, the oracle's order)
 constexpr int kPnpChunk = 1024;   // hypotheses per round (one problem at a time: the chunk is what fills the GPU)
 
 // cv::Rodrigues, matrix -> vector [upstream calib3d.cpp]
@@ -109,7 +111,8 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
             // first pass with a short sweep budget: the one hypothesis in a hundred whose diagonalisation stalls (60 sweeps: ~2 ms against
             // 0.5) comes back unfinished (count -1) instead of holding the launch, and is solved in full below only if the replay reaches it
             // before the adaptive count ends the search -- the same arithmetic on the same sample then, so nothing changes but the time
-            if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, n_hyp, d_poses, d_valid, d_counts, esfm::kPnpFirstSweeps, false, ctx)) return rc;
+            static const int first_sweeps = [] { const char *e = getenv("ESFM_PNP_FIRST_SWEEPS"); return e ? std::max(1, atoi(e)) : esfm::kPnpFirstSweeps; }();   // (60: no deferral -- A/B and tests)
+            if (int rc = esfm::launch_pnp_chunk(st, pb, d_p3, d_p2, d_samples, n_hyp, d_poses, d_valid, d_counts, first_sweeps, false, ctx)) return rc;
             ESFM_HIP_TRY(esfm::copy_d2h(counts.data(), d_counts, sizeof(int32_t) * (size_t)n_hyp, st));
             ESFM_HIP_TRY(hipStreamSynchronize(st));
             int best_k = -1;
@@ -143,8 +146,33 @@ int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d,
     }
     std::vector<uint8_t> mask(nn);
     ESFM_HIP_TRY(esfm::copy_d2h(mask.data(), d_mask, nn, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
 
     // ---- EPnP on all inliers (solvePnP(opoints_inliers, ipoints_inliers, ..., SOLVEPNP_EPNP))
+    // A small inlier set is re-fitted here on the host, every sum serial and in index order (epnp::solve_n = the CPU restatement's
+    // epnp_pose to the letter): small sets are the ill-conditioned ones -- a dozen correspondences, half of them poor -- and there the
+    // last-bit differences of the device reductions below were amplified into poses a percent apart (tests/stress_pnp.py); it also saves
+    // the four reduction round trips.  Large sets are well conditioned and stay on the device (agreement to 1e-7).
+    {
+        int m_host = 0;
+        for (size_t i = 0; i < nn; ++i) m_host += mask[i] ? 1 : 0;
+        if (m_host >= rs::kModelPoints && m_host <= kPnpHostRefit) {
+            std::vector<double> w(3 * (size_t)m_host), px(2 * (size_t)m_host), al(4 * (size_t)m_host), pc(3 * (size_t)m_host);
+            for (size_t i = 0, k = 0; i < nn; ++i)
+                if (mask[i]) { for (int c = 0; c < 3; ++c) w[3 * k + c] = (double)pts3d[3 * i + c]; px[2 * k] = (double)pts2d[2 * i]; px[2 * k + 1] = (double)pts2d[2 * i + 1]; ++k; }
+            const ep::Cam cam = {pb.fu, pb.fv, pb.uc, pb.vc};
+            double Rb[9], tb[3];
+            ep::solve_n(cam, w.data(), px.data(), m_host, al.data(), pc.data(), Rb, tb);
+            for (int k = 0; k < 9; ++k) if (!std::isfinite(Rb[k])) { esfm::set_error("EPnP re-fit produced a non-finite pose"); return ESFM_ERR_NUMERIC; }
+            for (int k = 0; k < 3; ++k) if (!std::isfinite(tb[k])) { esfm::set_error("EPnP re-fit produced a non-finite pose"); return ESFM_ERR_NUMERIC; }
+            rodrigues_to_vec(Rb, rvec);
+            for (int k = 0; k < 3; ++k) tvec[k] = tb[k];
+            if (R_out) for (int k = 0; k < 9; ++k) R_out[k] = Rb[k];
+            if (inlier_mask) memcpy(inlier_mask, mask.data(), nn);
+            if (n_inliers) *n_inliers = m_host;
+            return ESFM_OK;
+        }
+    }
     double *d_geo = d_small + 16, *d_sums = d_small + 96;
     double h[96];
     if (int rc = esfm::launch_pnp_moment_sums(st, pb, d_p3, d_mask, d_sums)) return rc;

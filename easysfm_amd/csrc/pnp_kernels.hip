@@ -39,7 +39,7 @@ using epnp::Cam;
 constexpr int kPnpLanes = 16, kPnpHypPerBlock = 64 / kPnpLanes, kPnpWsStride = 4 * 144 + 1;
 struct Jacobi12Coop {
     int l;            // lane of the hypothesis' group
-    int sweep_cap;    // 60 = the routine's own cap; less: a first pass that gives up on the few matrices whose off-diagonal norm stalls
+    int sweep_cap;    // epnp::kJacobiSweeps = the routine's own cap; less: a first pass that gives up on the few matrices whose off-diagonal norm stalls
     bool *gave_up;    // ... and says so here (the caller discards the hypothesis and, if the RANSAC replay needs it, solves it again in full)
     __device__ __forceinline__ void operator()(double *A, double *V) const
     {
@@ -52,18 +52,18 @@ struct Jacobi12Coop {
         sync();
         if (mine) for (int j = 0; j < N; ++j) V[r * N + j] = r == j ? 1.0 : 0.0;
         sync();
-        for (int sweep = 0; sweep < 60; ++sweep) {
+        for (int sweep = 0; sweep < epnp::kJacobiSweeps; ++sweep) {
             double off = 0.0, diag = 0.0;
             for (int i = 0; i < N; ++i) { diag += A[i * N + i] * A[i * N + i]; for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j]; }
-            if (off <= 1e-36 * diag || off == 0.0) break;
+            if (off <= epnp::kJacobiOff * diag || off == 0.0) break;
             if (sweep >= sweep_cap) { *gave_up = true; break; }
             for (int p = 0; p < N - 1; ++p)
                 for (int q = p + 1; q < N; ++q) {
                     const double apq = A[p * N + q];
                     if (apq == 0.0) continue;
                     const double th = (A[q * N + q] - A[p * N + p]) / (2.0 * apq);
-                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    double c, s;
+                    epnp::jacobi_cs(th, c, s);
                     sync();
                     if (mine) { const double x = A[r * N + p], y = A[r * N + q]; A[r * N + p] = c * x - s * y; A[r * N + q] = s * x + c * y; }
                     sync();

@@ -15,11 +15,11 @@ struct PnpProblem {
 };
 
 // Solve + score n_hyp hypotheses.  sweep_cap < kPnpFullSweeps: the 12 x 12 Jacobi diagonalisation gives up after that many sweeps
-// (valid = kPnpUnfinished, count = -1) -- about one matrix in a hundred never reaches the routine's threshold and runs into its cap of
-// 60 sweeps, ten times a usual solve, and a launch lasts as long as its slowest hypothesis; the caller has such hypotheses solved again
+// (valid = kPnpUnfinished, count = -1) -- a safety net since the routine's threshold became 10 DBL_EPSILON (every matrix of a 4 096-sample
+// count converges in 5 - 7 sweeps; with the earlier 1e-36 / 1e-40 one in a hundred / forty stalled and ran into the cap), and a launch lasts as long as its slowest hypothesis; the caller has such hypotheses solved again
 // with kPnpFullSweeps (only_unfinished: the launch touches nothing but the entries marked kPnpUnfinished / count -1 of the range it is
 // given) only if the RANSAC replay gets as far as needing one.
-constexpr int kPnpFullSweeps = 60, kPnpFirstSweeps = 10, kPnpUnfinished = 2;
+constexpr int kPnpFullSweeps = epnp::kJacobiSweeps, kPnpFirstSweeps = 12, kPnpUnfinished = 2;
 int launch_pnp_chunk(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const int32_t *samples, int n_hyp, double *poses,
                      int32_t *valid, int32_t *counts, int sweep_cap, bool only_unfinished, esfm_ctx *timing_ctx);
 int launch_pnp_mask(hipStream_t st, const PnpProblem &pb, const float *p3, const float *p2, const double *pose, uint8_t *mask);

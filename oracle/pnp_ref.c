@@ -37,10 +37,17 @@ static inline int rng_uniform(cv_rng *r, int a, int b) { return a == b ? a : (in
 static void jacobi_sym(double *A, int n, double *V)
 {
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 100; ++sweep) {
+    /* at most 30 sweeps: cvSVD's Jacobi routine stops at max(m, 30) (JacobiSVDImpl_: `max_iter = std::max(m, 30)`, m <= 12 here).  A matrix
+     * that has not reached the threshold below by then never will -- its off-diagonal norm has stalled at rounding level (one M'M in
+     * forty) -- and until round 5 this restatement let such a matrix run to 100 sweeps, which decides nothing but the noise in the
+     * null-space vectors EPnP reads. */
+    for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0, diag = 0;
         for (int i = 0; i < n; ++i) { diag += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j]; }
-        if (off <= 1e-40 * diag || off == 0.0) break;
+        /* converged when the off-diagonal part is below 10 DBL_EPSILON of the diagonal part (in norm): the scale of cvSVD's own test
+         * (`eps = DBL_EPSILON * 10`, a pair is left alone once |p| <= eps sqrt(a b)).  Until round 5 this read 1e-40, which double
+         * arithmetic cannot deliver for one 12 x 12 M'M in forty: those ran into the sweep cap, deciding nothing but noise. */
+        if (off <= 4.9303806576313238e-30 * diag || off == 0.0) break;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * n + q];

@@ -33,3 +33,13 @@ def test_matcher_random_sweep(seed):
 def test_ba_random_sweep(seed):
     out = _run("stress_ba.py", "--cases", "120", "--seed", str(seed))
     assert "equal to the oracle" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_pnp_random_sweep(seed):
+    """tests/stress_pnp.py: problem sizes 6 ... 4000, 0 - 70 % outliers, coplanar sets, thresholds 1 - 8 px, iteration caps 50 ... 50 000:
+    iteration counts and inlier masks exact, poses to 1e-6.  (Round 5 found 3.7 % of such problems choosing differently from the oracle:
+    the two sides' Jacobi diagonalisations stopped by different rules, and the hypotheses' scatter matrices were summed in different forms;
+    both sides now share cvSVD's stopping rule and the hypotheses / small re-fits the oracle's summation order -- DESIGN section 4e.)"""
+    out = _run("stress_pnp.py", "--cases", "200", "--seed", str(seed))
+    assert " 0 where a threshold-borderline" in out and " 0 with a pose on one side only" in out and "(0 of them with an ill-conditioned re-fit" in out, out[-2000:]
