@@ -43,3 +43,15 @@ def test_pnp_random_sweep(seed):
     both sides now share cvSVD's stopping rule and the hypotheses / small re-fits the oracle's summation order -- DESIGN section 4e.)"""
     out = _run("stress_pnp.py", "--cases", "200", "--seed", str(seed))
     assert " 0 where a threshold-borderline" in out and " 0 with a pose on one side only" in out and "(0 of them with an ill-conditioned re-fit" in out, out[-2000:]
+
+
+def test_essential_random_sweep_rate():
+    """tests/stress_essential.py: the 5-point RANSAC's two sides evaluate a hypothesis' models along differently conditioned routes, so
+    threshold-borderline correspondences let ~2 % of random problems choose differently.  The bar is the RATE:
+    at most 4 % differ, no model on one side only -- a regression of the solver would show as a jump."""
+    import re
+    out = _run("stress_essential.py", "--cases", "1500", "--seed", "41")
+    m = re.search(r"(\d+) cases .*?(\d+) where the two sides chose differently .*?(\d+) with a model on one side only", out)
+    assert m, out[-2000:]
+    cases, differ, one_side = (int(m.group(k)) for k in (1, 2, 3))
+    assert cases == 1500 and differ <= 0.04 * cases and one_side == 0, out[-2000:]
