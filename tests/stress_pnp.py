@@ -87,3 +87,4 @@ print(f"stress_pnp seed {args.seed}: {n_cases} cases ({n_fail_both} without a po
       f"equal to the oracle's ({n_loose} of them with an ill-conditioned re-fit: poses apart, reprojection error of the inliers within {worst:.1e} relative), {n_border} where a threshold-borderline correspondence made the two sides pick differently ({n_far} of them with inlier counts more than 2 % apart), {n_one_side} with a pose on one side only")
 for b in border[:12]:
     print("  borderline:", b)
+sys.exit(1 if (n_border or n_one_side or n_loose) else 0)      # since round 5 every kind of difference is a regression
