@@ -13,7 +13,7 @@ from .ba import (BAProblem, BundleAdjustment, Comm, ba_solve, ba_solve_ex, ba_sw
                  torch_allreduce_callback)
 
 from .cloud import CProceesing, read_ply_vertices, sor_filter, write_ply  # noqa: F401
-from .motion import (MotionEstimator, find_essential_mat, find_essential_pairs, pixel2cam, ransac_sample_stream, recover_pose,  # noqa: F401
+from .motion import (MotionEstimator, find_essential_mat, find_essential_pairs, five_point_models, pixel2cam, ransac_sample_stream, recover_pose,  # noqa: F401
                      recover_pose_pairs, solve_pnp_ransac, triangulate_pairs, triangulate_points)
 
 from .features import detectFeaturesORB, detectFeaturesSURF, import_distort, orb_detect_and_compute, surf_detect_and_compute, undistort  # noqa: F401

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "esfm_ba_shard_points", "esfm_ba_reduced_plan", "esfm_ba_problem_create_free_calib", "esfm_ba_problem_set_calib", "esfm_ba_problem_get_calib",
     "esfm_ba_problem_fix_camera", "esfm_ba_solve_ex", "esfm_ba_line_search_next_step",
     "esfm_sor_filter", "esfm_sor_mean_distances_dev", "esfm_triangulate_points", "esfm_triangulate_pairs",
-    "esfm_find_essential_mat", "esfm_find_essential_pairs", "esfm_recover_pose", "esfm_recover_pose_pairs", "esfm_ransac_sample_stream",
+    "esfm_find_essential_mat", "esfm_find_essential_pairs", "esfm_recover_pose", "esfm_recover_pose_pairs", "esfm_ransac_sample_stream", "esfm_five_point_models", "esfm_five_point_models_host",
     "esfm_solve_pnp_ransac", "esfm_surf_detect_and_compute", "esfm_orb_detect_and_compute", "esfm_undistort",
 ]
 
@@ -164,6 +164,8 @@ def lib() -> C.CDLL:
     L.esfm_recover_pose.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, i32p]
     L.esfm_recover_pose_pairs.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.esfm_ransac_sample_stream.argtypes = [C.c_int, C.c_int, vp]
+    L.esfm_five_point_models.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+    L.esfm_five_point_models_host.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.esfm_surf_detect_and_compute.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, i32p]
     L.esfm_orb_detect_and_compute.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i32p]
     L.esfm_undistort.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <vector>
 
+#include "five_point_core.hpp"
 #include "ransac_host.hpp"
 #include "ransac_kernels.hpp"
 
@@ -330,6 +331,62 @@ int esfm_recover_pose(esfm_ctx *ctx, const double *E, const float *pts1, const f
     if (n < 0) { esfm::set_error("negative point count"); return ESFM_ERR_INVALID_ARG; }
     const int32_t off[2] = {0, n};
     return esfm_recover_pose_pairs(ctx, 1, off, pts1, pts2, K4, E, mask, R, t, good);
+}
+
+// The 5-point kernel alone on the GPU: setup + roots kernels on n_samples samples of five normalised correspondences.
+int esfm_five_point_models(esfm_ctx *ctx, const double *q1, const double *q2, int n_samples, double *E_out, int32_t *n_models, double *stages)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    ESFM_REQUIRE(n_samples >= 0, "negative sample count");
+    if (n_samples == 0) return ESFM_OK;
+    ESFM_REQUIRE(q1 && q2 && E_out && n_models, "NULL argument");
+    if (int rc = esfm::set_device(ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)n_samples;
+    std::vector<double> q(20 * n), mod(90 * n), dbg(stages ? 32 * n : 0);
+    for (size_t g = 0; g < n; ++g) for (int k = 0; k < 10; ++k) { q[20 * g + k] = q1[10 * g + k]; q[20 * g + 10 + k] = q2[10 * g + k]; }
+    if (int rc = ctx->stage_e.reserve(sizeof(double) * (20 + 90 + 32) * n)) return rc;
+    if (int rc = ctx->stage_d.reserve(sizeof(int32_t) * n)) return rc;
+    double *d_q = ctx->stage_e.as<double>(), *d_models = d_q + 20 * n, *d_dbg = d_models + 90 * n;
+    int32_t *d_nm = ctx->stage_d.as<int32_t>();
+    ESFM_HIP_TRY(esfm::copy_h2d(d_q, q.data(), sizeof(double) * 20 * n, st));
+    ESFM_HIP_TRY(hipMemsetAsync(d_models, 0, sizeof(double) * 90 * n, st));
+    if (int rc = esfm::launch_five_point_setup_samples(st, d_q, n_samples, d_models, d_nm)) return rc;
+    if (stages) {
+        ESFM_HIP_TRY(esfm::copy_d2h(mod.data(), d_models, sizeof(double) * 90 * n, st));
+        ESFM_HIP_TRY(hipMemsetAsync(d_dbg, 0, sizeof(double) * 32 * n, st));
+    }
+    if (int rc = esfm::launch_five_point_roots(st, n_samples, d_models, d_nm, stages ? d_dbg : nullptr)) return rc;
+    ESFM_HIP_TRY(esfm::copy_d2h(E_out, d_models, sizeof(double) * 90 * n, st));
+    ESFM_HIP_TRY(esfm::copy_d2h(n_models, d_nm, sizeof(int32_t) * n, st));
+    if (stages) ESFM_HIP_TRY(esfm::copy_d2h(dbg.data(), d_dbg, sizeof(double) * 32 * n, st));
+    ESFM_HIP_TRY(hipStreamSynchronize(st));
+    if (stages)
+        for (size_t g = 0; g < n; ++g) {
+            double *s = stages + 117 * g;
+            const double *w = &mod[90 * g], *d = &dbg[32 * g];
+            for (int k = 0; k < 117; ++k) s[k] = 0.0;
+            for (int k = 0; k < 36; ++k) s[k] = w[esfm::fivept::kSetupN + k];
+            s[116] = -1.0;
+            if (d[30] < 0.0) continue;                    // degenerate sample / no degree-10 term: the CPU sides leave the rest zero too
+            for (int k = 0; k < 50; ++k) s[36 + k] = w[k];
+            for (int k = 0; k < 30; ++k) s[86 + k] = d[k];
+            s[116] = d[30];
+        }
+    return ESFM_OK;
+}
+
+// ... and the host build of the same header, estimate after estimate (no GPU): what the CPU suite compares with the oracle bit for bit.
+int esfm_five_point_models_host(const double *q1, const double *q2, int n_samples, double *E_out, int32_t *n_models, double *stages)
+{
+    if (n_samples < 0 || (n_samples && !(q1 && q2 && E_out && n_models))) { esfm::set_error("esfm_five_point_models_host: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    for (size_t g = 0; g < (size_t)n_samples; ++g) {
+        int sweeps = -1;
+        for (int k = 0; k < 90; ++k) E_out[90 * g + k] = 0.0;
+        n_models[g] = esfm::fivept::five_point_models_host(q1 + 10 * g, q2 + 10 * g, E_out + 90 * g, stages ? stages + 117 * g : nullptr, &sweeps);
+        if (stages) stages[117 * g + 116] = (double)sweeps;
+    }
+    return ESFM_OK;
 }
 
 // The index stream alone (host arithmetic, no GPU): the first n_samples 5-subsets getSubset draws for `count` points.

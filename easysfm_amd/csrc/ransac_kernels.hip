@@ -18,201 +18,22 @@
 // All arithmetic in f64 like OpenCV; the error is rounded to float before the threshold test like
 // RANSACPointSetRegistrator::findInliers.
 #include "ransac_kernels.hpp"
+#include "five_point_core.hpp"
 
 #include <float.h>
 #include <math.h>
 
 namespace esfm {
 
-// ---- trivariate polynomial bookkeeping -------------------------------------------------------------------------------
-// cubic monomials in the solver's column order: x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1
-// quadratic order: x2 y2 z2 xy xz yz x y z 1        linear order: x y z 1
-// (constexpr, not __constant__: with the loops unrolled every index below is a compile-time number, so the small arrays live in registers)
-__device__ constexpr signed char kLinLin[4][4] = {      // product of two linear monomials -> quadratic index
-    {0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
-__device__ constexpr signed char kQuadLin[10][4] = {    // quadratic monomial x linear monomial -> cubic column
-    /* x2 */ {0, 2, 4, 5},   /* y2 */ {3, 1, 6, 7},   /* z2 */ {10, 13, 16, 17}, /* xy */ {2, 3, 8, 9}, /* xz */ {4, 8, 10, 11},
-    /* yz */ {8, 6, 13, 14}, /* x  */ {5, 9, 11, 12}, /* y  */ {9, 7, 14, 15},   /* z  */ {11, 14, 17, 18}, /* 1 */ {12, 15, 18, 19}};
-
-__device__ __forceinline__ void quad_mul_acc(const double *a, const double *b, double s, double *q)   // q += s * a * b (linear x linear)
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) q[kLinLin[i][j]] += s * a[i] * b[j];
-}
-
-// The solver's big arrays live in LDS, one column of kSetupLanes lanes per entry (entry e of this lane: lds[e * kSetupLanes + lane]):
-// their rows and columns are picked by data (pivots), which in registers means scratch memory -- 1 400 scratch loads and 1 500 stores
-// in the one-lane-per-hypothesis kernel of rounds 1-2, each a dependent memory round trip.
+// The 5-point kernel's arithmetic is five_point_core.hpp (host + device; restated to the letter by oracle/ransac_ref.c): the kernels
+// below only decide which lane runs which piece of it.
+using fivept::kSetupDet;
+using fivept::kSetupN;
+using fivept::kSetupP;
+using fivept::kSetupQ;
+using fivept::kSetupR;
 constexpr int kSetupLanes = 32;
-struct LdsVec {
-    double *base;                                          // &lds[lane]
-    __device__ __forceinline__ double &operator()(int e) const { return base[e * kSetupLanes]; }
-};
-
-template <typename Row>
-__device__ __forceinline__ void cubic_mul_acc(const double *q, const double *l, double s, Row c)  // c += s * q * l (quadratic x linear)
-{
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const double qi = s * q[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c(kQuadLin[i][j]) += qi * l[j];
-    }
-}
-
-// EMEstimatorCallback::runKernel [upstream five-point.cpp]: q1, q2 = 5 normalised correspondences -> up to 10 unit-norm essential
-// matrices (row-major), each with its largest-magnitude entry positive, in ascending order of E[0][0] (a basis-independent order;
-// OpenCV's is whatever cv::solvePoly and its SVD basis produce).
-// Split in two since round 3 (see essential_roots_kernel): this part -- null space, the 10 x 20 elimination, B(z) and its determinant
-// -- is one hypothesis per lane and leaves det[11], P[3][4], Qp[3][4], R[3][5], N[4][9] (86 values) in `w`; false = no model.
-constexpr int kSetupDet = 0, kSetupP = 11, kSetupQ = 23, kSetupR = 35, kSetupN = 50;   // (86 values: they fit the 90 doubles a hypothesis owns in `models`)
-__device__ bool five_point_setup(const double *q1, const double *q2, double *w, LdsVec lds)
-{
-    // null space of the 5 x 9 epipolar system by Gauss-Jordan with complete pivoting: 4 basis vectors N[k][9]
-    auto Q = [&](int r, int c) -> double & { return lds(9 * r + c); };              // 45 entries (the 10 x 20 system takes their place later)
-    for (int i = 0; i < 5; ++i) {
-        const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
-        Q(i, 0) = x2 * x1; Q(i, 1) = x2 * y1; Q(i, 2) = x2; Q(i, 3) = y2 * x1; Q(i, 4) = y2 * y1; Q(i, 5) = y2; Q(i, 6) = x1; Q(i, 7) = y1; Q(i, 8) = 1.0;
-    }
-    int colperm = 0x876543210 & 0xffffffff;              // nine 4-bit column numbers packed (column 8 in `cp8`): no indexed int array either
-    int cp8 = 8;
-    auto cp_get = [&](int k) { return k == 8 ? cp8 : (colperm >> (4 * k)) & 15; };
-    auto cp_set = [&](int k, int v) { if (k == 8) cp8 = v; else colperm = (colperm & ~(15 << (4 * k))) | (v << (4 * k)); };
-    for (int k = 0; k < 5; ++k) {
-        int pr = k, pc = k; double best = -1.0;
-        for (int r = k; r < 5; ++r) for (int c = k; c < 9; ++c) { const double v = fabs(Q(r, c)); if (v > best) { best = v; pr = r; pc = c; } }
-        if (!(best > 1e-300)) return false;
-        for (int c = 0; c < 9; ++c) { const double t = Q(k, c); Q(k, c) = Q(pr, c); Q(pr, c) = t; }
-        for (int r = 0; r < 5; ++r) { const double t = Q(r, k); Q(r, k) = Q(r, pc); Q(r, pc) = t; }
-        { const int t = cp_get(k); cp_set(k, cp_get(pc)); cp_set(pc, t); }
-        const double inv = 1.0 / Q(k, k);
-        for (int c = 0; c < 9; ++c) Q(k, c) *= inv;
-        for (int r = 0; r < 5; ++r) {
-            if (r == k) continue;
-            const double f = Q(r, k);
-            for (int c = 0; c < 9; ++c) Q(r, c) -= f * Q(k, c);
-        }
-    }
-    auto N = [&](int k, int a) -> double & { return lds(48 + 9 * k + a); };         // 36 entries behind Q
-    for (int k = 0; k < 4; ++k) {
-        double nn = 1.0;
-        for (int a = 0; a < 9; ++a) N(k, a) = 0.0;
-        N(k, cp_get(5 + k)) = 1.0;
-        for (int r = 0; r < 5; ++r) { const double v = -Q(r, 5 + k); N(k, cp_get(r)) = v; nn += v * v; }
-        nn = 1.0 / sqrt(nn);
-        for (int a = 0; a < 9; ++a) N(k, a) *= nn;
-    }
-    // E(x, y, z) = x N0 + y N1 + z N2 + N3: entry (r, c) as the linear polynomial L[r][c][4]; N itself goes out to the roots kernel
-    double L[3][3][4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { L[r][c][k] = N(k, 3 * r + c); w[kSetupN + 9 * k + 3 * r + c] = L[r][c][k]; }
-    // G = E E' (6 unique quadratic entries; (r, c) with r <= c is formed as sum_k L[r][k] L[c][k], in that operand order) and its trace
-    auto gram = [&](int r, int c, double (&g)[10]) {
-        const int lo = r < c ? r : c, hi = r < c ? c : r;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) g[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) quad_mul_acc(L[lo][k], L[hi][k], 1.0, g);
-    };
-    double tr[10];
-    {
-        double g0[10], g1[10], g2[10];
-        gram(0, 0, g0); gram(1, 1, g1); gram(2, 2, g2);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) tr[k] = g0[k] + g1[k] + g2[k];
-    }
-    // the 10 x 20 system M (LDS: entry 20 r + c; Q and N above are dead)
-    auto Mrow = [&](int r) { return LdsVec{&lds(20 * r)}; };
-    for (int e = 0; e < 200; ++e) lds(e) = 0.0;
-    // row 0: det E = sum_c E[0][c] * cofactor(0, c)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-        double cof[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) cof[k] = 0.0;
-        quad_mul_acc(L[1][c1], L[2][c2], 1.0, cof);
-        quad_mul_acc(L[1][c2], L[2][c1], -1.0, cof);
-        cubic_mul_acc(cof, L[0][c], 1.0, Mrow(0));
-    }
-    // rows 1..9: 2 (E E') E - tr(E E') E   (row r of E E' formed when its three rows of M are)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double G[3][10];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gram(r, k, G[k]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const LdsVec row = Mrow(1 + 3 * r + c);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) cubic_mul_acc(G[k], L[k][c], 2.0, row);
-            cubic_mul_acc(tr, L[r][c], -1.0, row);
-        }
-    }
-    auto M = [&](int r, int c) -> double & { return lds(20 * r + c); };
-    // Gauss-Jordan on the first ten columns
-    for (int col = 0; col < 10; ++col) {
-        int piv = col; double best = fabs(M(col, col));
-        for (int r = col + 1; r < 10; ++r) { const double v = fabs(M(r, col)); if (v > best) { best = v; piv = r; } }
-        if (!(best > 1e-300)) return false;
-        if (piv != col) for (int c = 0; c < 20; ++c) { const double t = M(col, c); M(col, c) = M(piv, c); M(piv, c) = t; }
-        const double inv = 1.0 / M(col, col);
-        double prow[20];                                   // the pivot row in registers for the eliminations (c < col: not used)
-#pragma unroll
-        for (int c = 0; c < 20; ++c) { prow[c] = c >= col ? M(col, c) * inv : 0.0; if (c >= col) M(col, c) = prow[c]; }
-        for (int r = 0; r < 10; ++r) {
-            if (r == col) continue;
-            const double f = M(r, col);
-            if (f == 0.0) continue;
-#pragma unroll
-            for (int c = 0; c < 20; ++c) if (c >= col) M(r, c) -= f * prow[c];
-        }
-    }
-    // B(z): rows (4,5), (6,7), (8,9); P, Qp degree 3 and R degree 4, lowest degree first
-    double P[3][4], Qp[3][4], R[3][5];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double a[10], b[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) { a[k] = M(2 * i + 4, 10 + k); b[k] = M(2 * i + 5, 10 + k); }
-        P[i][3] = -b[0]; P[i][2] = a[0] - b[1]; P[i][1] = a[1] - b[2]; P[i][0] = a[2];
-        Qp[i][3] = -b[3]; Qp[i][2] = a[3] - b[4]; Qp[i][1] = a[4] - b[5]; Qp[i][0] = a[5];
-        R[i][4] = -b[6]; R[i][3] = a[6] - b[7]; R[i][2] = a[7] - b[8]; R[i][1] = a[8] - b[9]; R[i][0] = a[9];
-    }
-    double det[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) det[k] = 0.0;
-    constexpr int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
-    constexpr double sgn[6] = {1, -1, -1, 1, 1, -1};
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int a = perm[s][0], b = perm[s][1], c = perm[s][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double pq = sgn[s] * P[a][i] * Qp[b][j];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) det[i + j + k] += pq * R[c][k];
-            }
-    }
-#pragma unroll
-    for (int k = 0; k < 11; ++k) w[kSetupDet + k] = det[k];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { w[kSetupP + 4 * i + k] = P[i][k]; w[kSetupQ + 4 * i + k] = Qp[i][k]; }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) w[kSetupR + 5 * i + k] = R[i][k];
-    }
-    return true;
-}
+using LdsVec = fivept::Store<kSetupLanes>;              // entry e of this lane: lds[e * kSetupLanes + lane]
 
 __device__ __forceinline__ void normalise_pt(const RansacPair &pr, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int i,
                                              double &x1, double &y1, double &x2, double &y2)
@@ -240,9 +61,9 @@ __device__ __forceinline__ double row16_bcast(double v)
 template <int J>
 __device__ __forceinline__ void dk_factor(double re, double im, int i, double &dr, double &di)
 {
-    const double ar = re - row16_bcast<J>(re), ai = im - row16_bcast<J>(im);
-    const double tt = dr * ar - di * ai, ti = dr * ai + di * ar;
-    dr = J == i ? dr : tt; di = J == i ? di : ti;
+    double tr = dr, ti = di;
+    fivept::dk_times(tr, ti, re - row16_bcast<J>(re), im - row16_bcast<J>(im));
+    dr = J == i ? dr : tr; di = J == i ? di : ti;
 }
 
 // one thread per (pair, iteration of this chunk): the polynomial system of its sample -> models[90 g ..] (86 values);
@@ -260,7 +81,23 @@ __global__ __launch_bounds__(kSetupLanes) void essential_setup_kernel(const Rans
     if (!pr.active || id[0] < 0) { n_models[g] = -1; return; }
     double q1[10], q2[10];
     for (int k = 0; k < 5; ++k) normalise_pt(pr, p1, p2, id[k], q1[2 * k], q1[2 * k + 1], q2[2 * k], q2[2 * k + 1]);
-    n_models[g] = five_point_setup(q1, q2, models + 90 * (size_t)g, LdsVec{lds + threadIdx.x}) ? 1 : -1;
+    const LdsVec mine{lds + threadIdx.x};
+    fivept::null_space(q1, q2, mine);
+    n_models[g] = fivept::determinant_polynomial(models + 90 * (size_t)g, mine) ? 1 : -1;
+}
+
+// the same for samples given directly as normalised coordinates (esfm_five_point_models: the solver alone, q[20 g ..] = q1[10], q2[10])
+__global__ __launch_bounds__(kSetupLanes) void essential_setup_samples_kernel(const double *__restrict__ q, int n, double *__restrict__ models,
+                                                                              int32_t *__restrict__ n_models)
+{
+    __shared__ double lds[200 * kSetupLanes];
+    const int g = blockIdx.x * kSetupLanes + threadIdx.x;
+    if (g >= n) return;
+    double q1[10], q2[10];
+    for (int k = 0; k < 10; ++k) { q1[k] = q[20 * (size_t)g + k]; q2[k] = q[20 * (size_t)g + 10 + k]; }
+    const LdsVec mine{lds + threadIdx.x};
+    fivept::null_space(q1, q2, mine);
+    n_models[g] = fivept::determinant_polynomial(models + 90 * (size_t)g, mine) ? 1 : -1;
 }
 
 // Roots of the degree-10 determinant and the models they give: SIXTEEN LANES PER HYPOTHESIS, lane i = root estimate i (ten of them).
@@ -275,7 +112,8 @@ __global__ __launch_bounds__(kSetupLanes) void essential_setup_kernel(const Rans
 // on the real axis if it is real to 1e-8 (Newton), back-substitutes (x, y from the null vector of B(z)), forms E and takes the
 // output slot given by its rank in (E[0][0], z, i) among the group's valid lanes -- the order the sequential code produced by
 // sorting the roots, then the models.
-__global__ __launch_bounds__(256) void essential_roots_kernel(int n, double *__restrict__ models, int32_t *__restrict__ n_models)
+// (dbg, or NULL: 32 doubles per hypothesis for the stage tests -- cc[10], the estimates' re[10], im[10] after the iteration, its sweeps)
+__global__ __launch_bounds__(256) void essential_roots_kernel(int n, double *__restrict__ models, int32_t *__restrict__ n_models, double *__restrict__ dbg)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int g = t >> 4, i = t & 15, grp = (threadIdx.x & 63) >> 4;
@@ -288,114 +126,45 @@ __global__ __launch_bounds__(256) void essential_roots_kernel(int n, double *__r
     double cc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) cc[k] = have ? w[kSetupDet + k] / c10 : 0.0;
-    // start: a spiral around the origin (no symmetry of the polynomial can be a symmetry of the start)
     double re, im;
-    {
-        // start radius: half of Fujiwara's bound 2 max_k |c_{n-k}|^(1/k) (every root lies within it).  Cauchy's 1 + max |c_k|, used
-        // until round 3, is looser by orders of magnitude here, and the estimates approach from outside by a factor ~ 9/10 per sweep:
-        // mean sweeps per hypothesis 75 -> 45, median 60 -> 28 (scratch/dk_hist.py), the same RANSAC outcome on every test
-        double fuji = 0.0, sn, cs;
-#pragma unroll
-        for (int k = 1; k <= 10; ++k) fuji = fmax(fuji, pow(fabs(cc[10 - k]) * (k == 10 ? 0.5 : 1.0), 1.0 / k));
-        double r = fuji;
-        if (!(r > 1e-300)) r = 1.0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) r = k < i ? r * 0.9 : r;
-        sincos(2.0 * 3.14159265358979323846 * (i < 10 ? i : 0) / 10.0 + 0.4, &sn, &cs);
-        re = r * cs; im = r * sn;
-    }
+    fivept::start_point(fivept::start_radius(cc), i < 10 ? i : 0, re, im);
     bool active = have;                                   // (uniform over the group)
-    double best_mv = 1e300;
-    int stale = 0;
-#ifdef ESFM_DK_HIST
+    fivept::Rest rest;
     int my_sweeps = 0;
-#endif
-    for (int it = 0; it < 300; ++it) {
+    for (int it = 0; it < fivept::kMaxSweeps; ++it) {
         if (!__any(active)) break;
-#ifdef ESFM_DK_HIST
         my_sweeps += active ? 1 : 0;
-#endif
-        double pr = 1.0, pim = 0.0;                       // p(z_i), monic, by Horner
-#pragma unroll
-        for (int k = 9; k >= 0; --k) { const double tt = pr * re - pim * im + cc[k]; pim = pr * im + pim * re; pr = tt; }
+        double pr, pim, qr, qi;
+        fivept::poly_eval(cc, re, im, pr, pim);
         double dr = 1.0, di = 0.0;                        // prod_{j != i} (z_i - z_j), j ascending
         dk_factor<0>(re, im, i, dr, di); dk_factor<1>(re, im, i, dr, di); dk_factor<2>(re, im, i, dr, di); dk_factor<3>(re, im, i, dr, di);
         dk_factor<4>(re, im, i, dr, di); dk_factor<5>(re, im, i, dr, di); dk_factor<6>(re, im, i, dr, di); dk_factor<7>(re, im, i, dr, di);
         dk_factor<8>(re, im, i, dr, di); dk_factor<9>(re, im, i, dr, di);
-        const double den = dr * dr + di * di;
-        const double inv = den > 0.0 ? 1.0 / den : 0.0;
-        const double qr = (pr * dr + pim * di) * inv, qi = (pim * dr - pr * di) * inv;
+        fivept::dk_step(pr, pim, dr, di, qr, qi);
         const bool upd = active && i < 10;
         re = upd ? re - qr : re; im = upd ? im - qi : im;
-        // An estimate is at rest when its step is below 1e-13 of its magnitude -- or when it has reached the noise of its own
-        // evaluation: an ill-conditioned root of this degree-10 polynomial never gets its step under 1e-13 (5.4 % of the hypotheses
-        // used to run into the cap of 300 sweeps for that), it jitters at 1e-12 .. 1e-9 instead.  So: a step that is already small
-        // (< 1e-7) and has not halved for twelve sweeps is noise.  Linear convergence at a cluster (ratio (m - 1) / m <= 0.9 per
-        // sweep) halves within seven and goes on; the approach from the start circle has steps of ~0.1 and is not affected.
-        const double mv = (fabs(qr) + fabs(qi)) / (fabs(re) + fabs(im) + 1e-300);
-        const bool better = mv < 0.5 * best_mv;
-        best_mv = better ? mv : best_mv;
-        stale = better ? 0 : stale + 1;
-        const bool still = upd && !(mv <= 1e-13) && !(stale >= 12 && best_mv < 1e-7);
+        const bool still = fivept::dk_moving(rest, qr, qi, re, im) && upd;      // (the at-rest rule: five_point_core.hpp)
         const unsigned long long moving = __ballot(still);
         if (((moving >> (16 * grp)) & 0xffffull) == 0ull) active = false;
     }
 #ifdef ESFM_DK_HIST
     if (have && i == 0) atomicAdd(&g_dk_hist[my_sweeps], 1u);
 #endif
-    // near-real estimates: Newton on the real axis
-    const bool is_real = have && i < 10 && !(fabs(im) > 1e-8 * fmax(1.0, fabs(re)));
-    double z = re;
-    for (int nit = 0; nit < 4; ++nit) {
-        double pz = 1.0, dz = 0.0;
-#pragma unroll
-        for (int k = 9; k >= 0; --k) { dz = dz * z + pz; pz = pz * z + cc[k]; }
-        if (dz == 0.0) break;
-        z -= pz / dz;
+    if (dbg && in && i < 10) {
+        double *d = dbg + 32 * (size_t)g;
+        d[i] = cc[i]; d[10 + i] = re; d[20 + i] = im;
+        if (i == 0) d[30] = have ? (double)my_sweeps : -1.0;
     }
-    // B(z), its null vector, E
-    double Bz[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double *P = w + kSetupP + 4 * j, *Q = w + kSetupQ + 4 * j, *R = w + kSetupR + 5 * j;
-        Bz[j][0] = ((P[3] * z + P[2]) * z + P[1]) * z + P[0];
-        Bz[j][1] = ((Q[3] * z + Q[2]) * z + Q[1]) * z + Q[0];
-        Bz[j][2] = (((R[4] * z + R[3]) * z + R[2]) * z + R[1]) * z + R[0];
-    }
-    double bx = 0, by = 0, bw = 0, bn = -1.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int b = (a + 1) % 3;
-        const double cx = Bz[a][1] * Bz[b][2] - Bz[a][2] * Bz[b][1], cy = Bz[a][2] * Bz[b][0] - Bz[a][0] * Bz[b][2],
-                     cw = Bz[a][0] * Bz[b][1] - Bz[a][1] * Bz[b][0];
-        const double nn = cx * cx + cy * cy + cw * cw;
-        if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
-    }
-    const bool valid = is_real && bn > 0.0 && !(fabs(bw) < 1e-10 * sqrt(bn));
-    const double x = bx / bw, y = by / bw;
-    double Ev[9], nrm = 0.0;
-#pragma unroll
-    for (int a = 0; a < 9; ++a) {
-        Ev[a] = x * w[kSetupN + a] + y * w[kSetupN + 9 + a] + z * w[kSetupN + 18 + a] + w[kSetupN + 27 + a];
-        nrm += Ev[a] * Ev[a];
-    }
-    nrm = 1.0 / sqrt(nrm);
-    int big = 0;
-#pragma unroll
-    for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
-    double ebig = Ev[0];
-#pragma unroll
-    for (int a = 1; a < 9; ++a) ebig = a == big ? Ev[a] : ebig;
-    if (ebig < 0.0) nrm = -nrm;
-#pragma unroll
-    for (int a = 0; a < 9; ++a) Ev[a] *= nrm;
+    // the estimate's model: Newton on the real axis, B(z), its null vector, E
+    double Ev[9], z;
+    const bool valid = fivept::model_from_root(cc, w, re, im, Ev, z) && have && i < 10;
     // output slot: rank in (E[0][0], z, i) among the group's valid lanes
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
         const double k0 = __shfl(Ev[0], j, 16), kz = __shfl(z, j, 16);
         const int vj = __shfl((int)valid, j, 16);
-        rank += (vj && (k0 < Ev[0] || (k0 == Ev[0] && (kz < z || (kz == z && j < i))))) ? 1 : 0;
+        rank += (vj && fivept::model_precedes(k0, kz, j, Ev[0], z, i)) ? 1 : 0;
     }
     const unsigned long long vm = __ballot(valid);
     const int count = __popcll((vm >> (16 * grp)) & 0xffffull);
@@ -596,9 +365,25 @@ int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs,
     hipLaunchKernelGGL(essential_setup_kernel, dim3((n + kSetupLanes - 1) / kSetupLanes), dim3(kSetupLanes), 0, st, pairs, n_pairs, reinterpret_cast<const float2 *>(p1),
                        reinterpret_cast<const float2 *>(p2), samples, chunk, models, n_models);
     ESFM_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(essential_roots_kernel, dim3((16 * n + 255) / 256), dim3(256), 0, st, n, models, n_models);
+    hipLaunchKernelGGL(essential_roots_kernel, dim3((16 * n + 255) / 256), dim3(256), 0, st, n, models, n_models, (double *)nullptr);
     ESFM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(essential_score_kernel, dim3(n), dim3(256), 0, st, pairs, reinterpret_cast<const double4 *>(npts), chunk, models, n_models, counts);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_five_point_setup_samples(hipStream_t st, const double *q, int n, double *models, int32_t *n_models)
+{
+    if (n <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(essential_setup_samples_kernel, dim3((n + kSetupLanes - 1) / kSetupLanes), dim3(kSetupLanes), 0, st, q, n, models, n_models);
+    ESFM_HIP_TRY(hipGetLastError());
+    return ESFM_OK;
+}
+
+int launch_five_point_roots(hipStream_t st, int n, double *models, int32_t *n_models, double *dbg)
+{
+    if (n <= 0) return ESFM_OK;
+    hipLaunchKernelGGL(essential_roots_kernel, dim3((16 * n + 255) / 256), dim3(256), 0, st, n, models, n_models, dbg);
     ESFM_HIP_TRY(hipGetLastError());
     return ESFM_OK;
 }

@@ -18,6 +18,10 @@ struct RansacPair {       // one image pair's correspondences inside the concate
 int launch_essential_normalise(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, double *npts);
 int launch_essential_chunk(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *npts, const int32_t *samples,
                            int chunk, double *models, int32_t *n_models, int32_t *counts, esfm_ctx *timing_ctx);
+// the solver alone on samples given as normalised coordinates (q[20 g ..] = q1[10], q2[10]): setup leaves the 86 intermediate values of
+// five_point_core.hpp in models[90 g ..] and n_models[g] = 1 / -1; roots turns them into models and counts (dbg: 32 doubles per sample or NULL)
+int launch_five_point_setup_samples(hipStream_t st, const double *q, int n, double *models, int32_t *n_models);
+int launch_five_point_roots(hipStream_t st, int n, double *models, int32_t *n_models, double *dbg);
 // best[9 take[3 e]] = models[90 take[3 e + 1] + 9 take[3 e + 2]] (9 doubles) for e < n_take
 int launch_essential_take_best(hipStream_t st, const int32_t *take, int n_take, const double *models, double *best);
 int launch_essential_mask(hipStream_t st, const RansacPair *pairs, int n_pairs, const float *p1, const float *p2, const double *best, uint8_t *mask);

@@ -147,6 +147,23 @@ def ransac_sample_stream(count: int, n_samples: int) -> np.ndarray:
     return idx[:n_samples]
 
 
+def five_point_models(q1, q2, ctx: Optional[Context] = None, host: bool = False, stages: bool = False):
+    """esfm_five_point_models / esfm_five_point_models_host: the 5-point kernel alone on [n, 5, 2] normalised correspondences ->
+    (E [n, 10, 3, 3], n_models [n]) (+ stages [n, 117] with stages=True).  host=True runs the host build of the kernels' routines
+    (no GPU): the stage tests' middle leg between the GPU and the CPU restatement."""
+    a = np.ascontiguousarray(q1, np.float64).reshape(-1, 5, 2); b = np.ascontiguousarray(q2, np.float64).reshape(-1, 5, 2)
+    n = len(a)
+    Es = np.zeros((max(n, 1), 10, 3, 3)); nm = np.zeros(max(n, 1), np.int32); st = np.zeros((max(n, 1), 117)) if stages else None
+    stp = C.c_void_p(st.ctypes.data) if stages else None
+    if host:
+        check(lib().esfm_five_point_models_host(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), n, C.c_void_p(Es.ctypes.data), C.c_void_p(nm.ctypes.data), stp))
+    else:
+        ctx = ctx or default_context()
+        check(lib().esfm_five_point_models(ctx.handle, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), n, C.c_void_p(Es.ctypes.data),
+                                           C.c_void_p(nm.ctypes.data), stp))
+    return (Es[:n], nm[:n], st[:n]) if stages else (Es[:n], nm[:n])
+
+
 def pixel2cam(p: np.ndarray, K: np.ndarray) -> np.ndarray:
     """estimate_motion.h:41-46, float arithmetic on the float K: ((u - cx) / fx, (v - cy) / fy)."""
     p = np.asarray(p, np.float32).reshape(-1, 2); K = np.asarray(K, np.float32)

@@ -523,6 +523,19 @@ int esfm_recover_pose_pairs(esfm_ctx *ctx, int n_pairs, const int32_t *point_off
 int esfm_solve_pnp_ransac(esfm_ctx *ctx, const float *pts3d, const float *pts2d, int n, const float *K4, int iterations_count,
                           double reprojection_error, double confidence, double *rvec /*3*/, double *tvec /*3*/, double *R /*9 or NULL*/,
                           uint8_t *inlier_mask /*n or NULL*/, int32_t *n_inliers /*or NULL*/, int32_t *iterations /*or NULL*/);
+/* The 5-point kernel alone (EMEstimatorCallback::runKernel [upstream five-point.cpp], what cv::findEssentialMat at reference
+ * cpp_code/src/estimate_motion.cpp:49-51 runs on every RANSAC sample): n_samples samples of five correspondences in NORMALISED
+ * coordinates, q1, q2 [n_samples][5][2] doubles with x2' E x1 = 0.  E_out [n_samples][10][9]: a sample's models (row-major, unit
+ * Frobenius norm, largest-magnitude entry positive, ascending E[0][0]); n_models[n_samples] their number (0..10).  stages (or
+ * NULL) [n_samples][117]: the intermediate values for stage-by-stage tests -- null-space basis N[4][9], det[11] (lowest degree
+ * first), P[3][4], Qp[3][4], R[3][5] of B(z), the monic coefficients cc[10], the root estimates re[10], im[10], the sweeps of
+ * the root iteration (-1: no polynomial).  esfm_five_point_models runs essential_setup_kernel's and essential_roots_kernel's
+ * code on the GPU; esfm_five_point_models_host runs the host build of the same routines (easysfm_amd/csrc/five_point_core.hpp),
+ * no GPU: the two and the CPU restatement agree to the bit (tests/test_five_point_stages.py). */
+int esfm_five_point_models(esfm_ctx *ctx, const double *q1, const double *q2, int n_samples, double *E_out, int32_t *n_models,
+                           double *stages /*or NULL*/);
+int esfm_five_point_models_host(const double *q1, const double *q2, int n_samples, double *E_out, int32_t *n_models,
+                                double *stages /*or NULL*/);
 /* Host-only (no GPU): the first n_samples 5-index samples RANSAC draws for `count` points (cv::RNG replay). */
 int esfm_ransac_sample_stream(int count, int n_samples, int32_t *idx /*5 per sample*/);
 

@@ -148,6 +148,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.esfm_ref_ransac_samples.argtypes = [C.c_int, C.c_int, _i32p]
     lib.esfm_ref_five_point.restype = C.c_int
     lib.esfm_ref_five_point.argtypes = [_f64p, _f64p, _f64p]
+    lib.esfm_ref_five_point_stages.restype = C.c_int
+    lib.esfm_ref_five_point_stages.argtypes = [_f64p, _f64p, _f64p]
     lib.esfm_ref_find_essential_ransac.restype = C.c_int
     lib.esfm_ref_find_essential_ransac.argtypes = [_f32p, _f32p, C.c_int, _f32p, C.c_double, C.c_double, _f64p, _u8p,
                                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -442,6 +444,15 @@ def five_point(q1, q2) -> np.ndarray:
     out = np.zeros(90, np.float64)
     k = load().esfm_ref_five_point(a, b, out)
     return out[:9 * k].reshape(k, 3, 3)
+
+
+def five_point_stages(q1, q2):
+    """The restatement's intermediate values for one sample (esfm_ref_five_point_stages): 117 doubles in the layout of
+    include/esfm.h's esfm_five_point_models (the last one = sweeps of the root iteration, -1: no polynomial)."""
+    a = np.ascontiguousarray(q1, np.float64).reshape(10); b = np.ascontiguousarray(q2, np.float64).reshape(10)
+    out = np.zeros(117, np.float64)
+    out[116] = load().esfm_ref_five_point_stages(a, b, out[:116])
+    return out
 
 
 def find_essential_ransac(pts1, pts2, K4, prob: float = 0.99, threshold: float = 1.0):

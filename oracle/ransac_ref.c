@@ -15,16 +15,9 @@
  *                      findInliers (error <= (float)(threshold^2) on float errors); a model replaces the best iff
  *                      count > max(best, 4), then niters = RANSACUpdateNumIters(prob, outlier ratio, 5, niters)
  *   error              Sampson distance (x2'E x1)^2 / (|E x1|_xy^2 + |E' x2|_xy^2), double, stored as float
- *   5-point kernel     null space of the 5 x 9 epipolar system, the ten cubic constraints det E = 0 and
- *                      2 E E'E - tr(E E')E = 0 in the monomial order x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3
- *                      z2 z 1, Gauss-Jordan on the first ten columns, rows (4,5) (6,7) (8,9) combined to a 3 x 3 polynomial
- *                      matrix in z whose determinant is the degree-10 polynomial; its real roots (|imag| <= 1e-10) give z,
- *                      the null vector of B(z) gives x, y; E = x E1 + y E2 + z E3 + E4, scaled to unit Frobenius norm.
- *                      Deviations: OpenCV tries the models of one sample in the order cv::solvePoly emits the roots, with
- *                      the sign its SVD null-space basis happens to give -- artefacts of its iteration that only decide
- *                      ties between models of the same sample.  Here every model is given a canonical sign (its
- *                      largest-magnitude entry positive) and the models of a sample are ordered by ascending E[0][0];
- *                      the polynomial roots come from a Durand-Kerner iteration written here, not cv::solvePoly itself.
+ *   5-point kernel     EMEstimatorCallback::runKernel: see "the 5-point kernel" below -- the steps, which of them follow OpenCV and
+ *                      which are this build's own rule (model order and sign within a sample, the root iteration), and why the
+ *                      product's kernels and this file share one arithmetic
  *   recoverPose        decomposeEssentialMat (SVD, det U, det V' forced positive, W = [0 1 0; -1 0 0; 0 0 1]); the four
  *                      (R, t) candidates in OpenCV's order (R1,t) (R2,t) (R1,-t) (R2,-t); per candidate every point is
  *                      triangulated in double against [I|0] and kept iff Z W > 0, Z / W < 50 in the first camera and
@@ -89,206 +82,287 @@ static void jacobi_eig(double *A, int n, double *V)
     }
 }
 
-/* ----------------------------------------------------------------------------------------------- trivariate cubics */
-/* monomial index in the solver's column order */
-static int mono_index(int a, int b, int c)   /* x^a y^b z^c */
-{
-    static const int tab[20][3] = { {3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
-                                    {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0} };
-    for (int i = 0; i < 20; ++i) if (tab[i][0] == a && tab[i][1] == b && tab[i][2] == c) return i;
-    return -1;
-}
-static const int kMono[20][3] = { {3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
-                                  {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0} };
-typedef struct { double c[20]; } poly3;
-static poly3 p_zero(void) { poly3 p; memset(&p, 0, sizeof(p)); return p; }
-static poly3 p_lin(double x, double y, double z, double w)
-{
-    poly3 p = p_zero();
-    p.c[mono_index(1, 0, 0)] = x; p.c[mono_index(0, 1, 0)] = y; p.c[mono_index(0, 0, 1)] = z; p.c[mono_index(0, 0, 0)] = w;
-    return p;
-}
-static poly3 p_add(poly3 a, poly3 b) { for (int i = 0; i < 20; ++i) a.c[i] += b.c[i]; return a; }
-static poly3 p_sub(poly3 a, poly3 b) { for (int i = 0; i < 20; ++i) a.c[i] -= b.c[i]; return a; }
-static poly3 p_scale(poly3 a, double s) { for (int i = 0; i < 20; ++i) a.c[i] *= s; return a; }
-static poly3 p_mul(poly3 a, poly3 b)
-{
-    poly3 r = p_zero();
-    for (int i = 0; i < 20; ++i) {
-        if (a.c[i] == 0.0) continue;
-        for (int j = 0; j < 20; ++j) {
-            if (b.c[j] == 0.0) continue;
-            const int e0 = kMono[i][0] + kMono[j][0], e1 = kMono[i][1] + kMono[j][1], e2 = kMono[i][2] + kMono[j][2];
-            if (e0 + e1 + e2 > 3) continue;   /* never happens for the products formed below */
-            r.c[mono_index(e0, e1, e2)] += a.c[i] * b.c[j];
-        }
-    }
-    return r;
-}
-
-/* ----------------------------------------------------------------------------------------------- polynomial roots */
-/* all complex roots of c[0] + c[1] z + ... + c[n] z^n by Durand-Kerner; returns the real ones (|imag| <= 1e-10), ascending */
-static int real_roots(const double *c, int n, double *out)
-{
-    while (n > 0 && c[n] == 0.0) --n;
-    if (n <= 0) return 0;
-    double re[16], im[16];
-    /* start on a circle of the Cauchy bound radius */
-    double bound = 0.0;
-    for (int i = 0; i < n; ++i) bound = fmax(bound, fabs(c[i] / c[n]));
-    bound = 1.0 + bound;
-    for (int i = 0; i < n; ++i) { const double a = 2.0 * 3.14159265358979323846 * i / n + 0.4; re[i] = 0.5 * bound * cos(a) * pow(0.9, i); im[i] = 0.5 * bound * sin(a) * pow(0.9, i); }
-    for (int it = 0; it < 2000; ++it) {
-        double move = 0.0;
-        for (int i = 0; i < n; ++i) {
-            double pr = c[n], pi = 0.0;                               /* p(z_i) / c[n] by Horner */
-            for (int k = n - 1; k >= 0; --k) { const double t = pr * re[i] - pi * im[i] + c[k]; pi = pr * im[i] + pi * re[i]; pr = t; }
-            double dr = c[n], di = 0.0;                               /* c[n] * prod (z_i - z_j) */
-            for (int j = 0; j < n; ++j) {
-                if (j == i) continue;
-                const double ar = re[i] - re[j], ai = im[i] - im[j];
-                const double t = dr * ar - di * ai; di = dr * ai + di * ar; dr = t;
-            }
-            const double den = dr * dr + di * di;
-            if (den == 0.0) continue;
-            const double qr = (pr * dr + pi * di) / den, qi = (pi * dr - pr * di) / den;
-            re[i] -= qr; im[i] -= qi;
-            move = fmax(move, fabs(qr) + fabs(qi));
-        }
-        if (move <= 1e-15 * bound) break;
-    }
-    /* polish the near-real ones with Newton on the real axis */
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-        if (fabs(im[i]) > 1e-10 * fmax(1.0, fabs(re[i]))) continue;
-        double z = re[i];
-        for (int it = 0; it < 3; ++it) {
-            double p = c[n], d = 0.0;
-            for (int k = n - 1; k >= 0; --k) { d = d * z + p; p = p * z + c[k]; }
-            if (d == 0.0) break;
-            z -= p / d;
-        }
-        out[m++] = z;
-    }
-    for (int i = 1; i < m; ++i) { double v = out[i]; int j = i - 1; while (j >= 0 && out[j] > v) { out[j + 1] = out[j]; --j; } out[j + 1] = v; }
-    return m;
-}
-
 /* ----------------------------------------------------------------------------------------------- the 5-point kernel */
-/* q1, q2: 5 normalised correspondences (x2' E x1 = 0).  E_out: up to 10 matrices, row-major, unit Frobenius norm. */
-int esfm_ref_five_point(const double *q1, const double *q2, double *E_out)
+/* EMEstimatorCallback::runKernel [upstream five-point.cpp], ONE arithmetic for both sides since round 6: the product's kernels
+ * (easysfm_amd/csrc/five_point_core.hpp, run by essential_setup_kernel / essential_roots_kernel) and this file evaluate the same
+ * expressions in the same order, so a hypothesis' models agree to the bit and so do inlier counts, iteration counts and masks
+ * (until round 5 the two sides took different routes to the same models -- null space by elimination against eigenvectors of Q'Q, two
+ * different root iterations -- and 2.2 % of random RANSAC problems were decided differently by threshold-borderline correspondences).
+ * The steps, and whose rule each one is:
+ *   1  null space of the 5 x 9 epipolar system: OpenCV takes the last four right singular vectors (an orthonormal basis).  Here: the
+ *      last four columns of the orthogonal factor of a Householder QR of the system's transpose -- also orthonormal, and no
+ *      squaring of the condition number as with eigenvectors of Q'Q.  The models do not depend on the basis in exact arithmetic.
+ *   2  the ten cubic constraints det E = 0, 2 E E'E - tr(E E')E = 0 in the monomial order
+ *      x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1 (OpenCV's), products accumulated in the order written below
+ *   3  Gauss-Jordan with partial pivoting on the first ten columns (OpenCV's), rows (4,5) (6,7) (8,9) -> B(z), det B(z) (degree 10)
+ *   4  roots: cv::solvePoly is a Durand-Kerner iteration; so is this (own start points, simultaneous update, own stopping rule --
+ *      the build's rule: OpenCV's root order and accuracy are artefacts of its iteration)
+ *   5  per real root: x, y from the null vector of B(z) (cross product of two rows; OpenCV: SVD::solveZ), E = x E1 + y E2 + z E3 + E4,
+ *      unit Frobenius norm, canonical sign (largest-magnitude entry positive), a sample's models in ascending (E[0][0], z) order
+ *      (the build's rule: OpenCV tries them in solvePoly's order with its SVD's sign, which only decides ties between models of the
+ *      same sample).
+ * Only + - * / sqrt, frexp / ldexp and comparisons: every operation is correctly rounded (or exact) on both sides; no pow, no
+ * sin / cos (the start points come from a table), no fused multiply-add (both builds use -ffp-contract=off). */
+
+/* linear monomials x y z 1; quadratic x2 y2 z2 xy xz yz x y z 1; cubic: the 20 columns above */
+static const signed char kLinLin[4][4] = { {0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9} };          /* linear x linear -> quadratic */
+static const signed char kQuadLin[10][4] = {                                                                  /* quadratic x linear -> cubic column */
+    /* x2 */ {0, 2, 4, 5},   /* y2 */ {3, 1, 6, 7},   /* z2 */ {10, 13, 16, 17}, /* xy */ {2, 3, 8, 9}, /* xz */ {4, 8, 10, 11},
+    /* yz */ {8, 6, 13, 14}, /* x  */ {5, 9, 11, 12}, /* y  */ {9, 7, 14, 15},   /* z  */ {11, 14, 17, 18}, /* 1 */ {12, 15, 18, 19} };
+
+static void quad_mul_acc(const double *a, const double *b, double s, double *q)     /* q += s a b   (linear x linear) */
 {
-    /* null space of the 5 x 9 system: eigenvectors of Q'Q with the 4 smallest eigenvalues */
-    double QtQ[81]; memset(QtQ, 0, sizeof(QtQ));
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) q[kLinLin[i][j]] += s * a[i] * b[j];
+}
+static void cubic_mul_acc(const double *q, const double *l, double s, double *c)    /* c += s q l   (quadratic x linear) */
+{
+    for (int i = 0; i < 10; ++i) { const double qi = s * q[i]; for (int j = 0; j < 4; ++j) c[kQuadLin[i][j]] += qi * l[j]; }
+}
+
+/* step 1: N[k][9], k < 4: an orthonormal basis of the null space of the 5 x 9 system whose row i is
+ * (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1) of correspondence i */
+static void null_space(const double *q1, const double *q2, double N[4][9])
+{
+    double a[5][9], beta[5];                          /* a[c] = row c of the system = column c of its transpose */
     for (int i = 0; i < 5; ++i) {
         const double x1 = q1[2 * i], y1 = q1[2 * i + 1], x2 = q2[2 * i], y2 = q2[2 * i + 1];
-        const double row[9] = { x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0 };
-        for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) QtQ[a * 9 + b] += row[a] * row[b];
+        a[i][0] = x2 * x1; a[i][1] = x2 * y1; a[i][2] = x2; a[i][3] = y2 * x1; a[i][4] = y2 * y1; a[i][5] = y2; a[i][6] = x1; a[i][7] = y1; a[i][8] = 1.0;
     }
-    double V[81];
-    jacobi_eig(QtQ, 9, V);
-    int order[9];
-    for (int i = 0; i < 9; ++i) order[i] = i;
-    for (int i = 1; i < 9; ++i) { int v = order[i], j = i - 1; while (j >= 0 && QtQ[order[j] * 9 + order[j]] > QtQ[v * 9 + v]) { order[j + 1] = order[j]; --j; } order[j + 1] = v; }
-    double N[4][9];
-    for (int k = 0; k < 4; ++k) for (int a = 0; a < 9; ++a) N[k][a] = V[a * 9 + order[k]];
+    for (int j = 0; j < 5; ++j) {                     /* reflector j: v = x - alpha e_j on rows j..8, kept in a[j][j..8]; H = I - beta v v' */
+        double s = 0.0;
+        for (int r = j; r < 9; ++r) s += a[j][r] * a[j][r];
+        const double nrm = sqrt(s), x0 = a[j][j];
+        const double v0 = x0 - (x0 >= 0.0 ? -nrm : nrm);
+        a[j][j] = v0;
+        double vtv = v0 * v0;
+        for (int r = j + 1; r < 9; ++r) vtv += a[j][r] * a[j][r];
+        beta[j] = vtv > 0.0 ? 2.0 / vtv : 0.0;
+        for (int c = j + 1; c < 5; ++c) {
+            double d = 0.0;
+            for (int r = j; r < 9; ++r) d += a[j][r] * a[c][r];
+            const double f = beta[j] * d;
+            for (int r = j; r < 9; ++r) a[c][r] -= f * a[j][r];
+        }
+    }
+    for (int k = 0; k < 4; ++k) {                     /* column 5 + k of H0 H1 H2 H3 H4 */
+        double n[9];
+        for (int r = 0; r < 9; ++r) n[r] = r == 5 + k ? 1.0 : 0.0;
+        for (int j = 4; j >= 0; --j) {
+            double d = 0.0;
+            for (int r = j; r < 9; ++r) d += a[j][r] * n[r];
+            const double f = beta[j] * d;
+            for (int r = j; r < 9; ++r) n[r] -= f * a[j][r];
+        }
+        for (int r = 0; r < 9; ++r) N[k][r] = n[r];
+    }
+}
 
-    /* E(x, y, z) = x N0 + y N1 + z N2 + N3, entries are linear polynomials */
-    poly3 E[3][3];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[r][c] = p_lin(N[0][3 * r + c], N[1][3 * r + c], N[2][3 * r + c], N[3][3 * r + c]);
-    poly3 eq[10];
-    /* det E */
-    eq[0] = p_add(p_sub(p_mul(E[0][0], p_sub(p_mul(E[1][1], E[2][2]), p_mul(E[1][2], E[2][1]))),
-                        p_mul(E[0][1], p_sub(p_mul(E[1][0], E[2][2]), p_mul(E[1][2], E[2][0])))),
-                  p_mul(E[0][2], p_sub(p_mul(E[1][0], E[2][1]), p_mul(E[1][1], E[2][0]))));
-    /* 2 E E'E - tr(E E') E */
-    poly3 EEt[3][3], tr = p_zero();
+/* steps 2 + 3: det[11] (lowest degree first) and the rows P[3][4], Qp[3][4], R[3][5] of B(z) = [P(z) Qp(z) R(z)]; 0 = degenerate */
+static int determinant_polynomial(double N[4][9], double *det, double P[3][4], double Qp[3][4], double R[3][5])
+{
+    double L[3][3][4];                                /* E(x, y, z) = x N0 + y N1 + z N2 + N3: entry (r, c) as a linear polynomial */
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) for (int k = 0; k < 4; ++k) L[r][c][k] = N[k][3 * r + c];
+    double G[3][3][10], tr[10];                       /* G = E E' (entry (r, c) = sum_k L[min][k] L[max][k]), tr = its trace */
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        EEt[r][c] = p_zero();
-        for (int k = 0; k < 3; ++k) EEt[r][c] = p_add(EEt[r][c], p_mul(E[r][k], E[c][k]));
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        for (int k = 0; k < 10; ++k) G[r][c][k] = 0.0;
+        for (int k = 0; k < 3; ++k) quad_mul_acc(L[lo][k], L[hi][k], 1.0, G[r][c]);
     }
-    for (int r = 0; r < 3; ++r) tr = p_add(tr, EEt[r][r]);
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        poly3 s = p_zero();
-        for (int k = 0; k < 3; ++k) s = p_add(s, p_mul(EEt[r][k], E[k][c]));
-        eq[1 + 3 * r + c] = p_sub(p_scale(s, 2.0), p_mul(tr, E[r][c]));
-    }
-    /* Gauss-Jordan on the first ten columns (partial pivoting) */
+    for (int k = 0; k < 10; ++k) tr[k] = G[0][0][k] + G[1][1][k] + G[2][2][k];
     double M[10][20];
-    for (int r = 0; r < 10; ++r) for (int c = 0; c < 20; ++c) M[r][c] = eq[r].c[c];
-    for (int col = 0; col < 10; ++col) {
+    memset(M, 0, sizeof(M));
+    for (int c = 0; c < 3; ++c) {                     /* row 0: det E = sum_c E[0][c] cofactor(0, c) */
+        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+        double cof[10];
+        for (int k = 0; k < 10; ++k) cof[k] = 0.0;
+        quad_mul_acc(L[1][c1], L[2][c2], 1.0, cof);
+        quad_mul_acc(L[1][c2], L[2][c1], -1.0, cof);
+        cubic_mul_acc(cof, L[0][c], 1.0, M[0]);
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {      /* rows 1..9: 2 (E E') E - tr(E E') E */
+        double *row = M[1 + 3 * r + c];
+        for (int k = 0; k < 3; ++k) cubic_mul_acc(G[r][k], L[k][c], 2.0, row);
+        cubic_mul_acc(tr, L[r][c], -1.0, row);
+    }
+    for (int col = 0; col < 10; ++col) {              /* Gauss-Jordan on the first ten columns, partial pivoting */
         int piv = col; double best = fabs(M[col][col]);
-        for (int r = col + 1; r < 10; ++r) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
-        if (best < 1e-300) return 0;
+        for (int r = col + 1; r < 10; ++r) { const double v = fabs(M[r][col]); if (v > best) { best = v; piv = r; } }
+        if (!(best > 1e-300)) return 0;
         if (piv != col) for (int c = 0; c < 20; ++c) { const double t = M[col][c]; M[col][c] = M[piv][c]; M[piv][c] = t; }
         const double inv = 1.0 / M[col][col];
-        for (int c = 0; c < 20; ++c) M[col][c] *= inv;
+        for (int c = col; c < 20; ++c) M[col][c] *= inv;
         for (int r = 0; r < 10; ++r) {
             if (r == col) continue;
             const double f = M[r][col];
             if (f == 0.0) continue;
-            for (int c = 0; c < 20; ++c) M[r][c] -= f * M[col][c];
+            for (int c = col; c < 20; ++c) M[r][c] -= f * M[col][c];
         }
     }
-    /* B (3 x 13): row(2i+4) - z row(2i+5); layout x: z^3..z^0 (4), y: z^3..z^0 (4), 1: z^4..z^0 (5) */
-    double B[3][13];
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {                     /* B row i = row(2i + 4) - z row(2i + 5) of the reduced system; lowest degree first */
         const double *a = &M[2 * i + 4][10], *b = &M[2 * i + 5][10];
-        B[i][0] = -b[0]; B[i][1] = a[0] - b[1]; B[i][2] = a[1] - b[2]; B[i][3] = a[2];
-        B[i][4] = -b[3]; B[i][5] = a[3] - b[4]; B[i][6] = a[4] - b[5]; B[i][7] = a[5];
-        B[i][8] = -b[6]; B[i][9] = a[6] - b[7]; B[i][10] = a[7] - b[8]; B[i][11] = a[8] - b[9]; B[i][12] = a[9];
+        P[i][3] = -b[0]; P[i][2] = a[0] - b[1]; P[i][1] = a[1] - b[2]; P[i][0] = a[2];
+        Qp[i][3] = -b[3]; Qp[i][2] = a[3] - b[4]; Qp[i][1] = a[4] - b[5]; Qp[i][0] = a[5];
+        R[i][4] = -b[6]; R[i][3] = a[6] - b[7]; R[i][2] = a[7] - b[8]; R[i][1] = a[8] - b[9]; R[i][0] = a[9];
     }
-    /* determinant polynomial (coefficients lowest degree first); p, q degree 3, r degree 4 */
-    double P[3][4], Qp[3][4], R[3][5];
-    for (int i = 0; i < 3; ++i) {
-        for (int k = 0; k < 4; ++k) { P[i][k] = B[i][3 - k]; Qp[i][k] = B[i][7 - k]; }
-        for (int k = 0; k < 5; ++k) R[i][k] = B[i][12 - k];
-    }
-    double det[11]; memset(det, 0, sizeof(det));
-    static const int perm[6][3] = { {0,1,2},{0,2,1},{1,0,2},{1,2,0},{2,0,1},{2,1,0} };
-    static const int sign[6] = { 1, -1, -1, 1, 1, -1 };
-    for (int s = 0; s < 6; ++s) {   /* sum over permutations: P[row a] Q[row b] R[row c] */
+    static const int perm[6][3] = { {0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0} };
+    static const double sgn[6] = { 1, -1, -1, 1, 1, -1 };
+    for (int k = 0; k < 11; ++k) det[k] = 0.0;
+    for (int s = 0; s < 6; ++s) {                     /* sum over permutations: P[row a] Qp[row b] R[row c] */
         const int a = perm[s][0], b = perm[s][1], c = perm[s][2];
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int k = 0; k < 5; ++k) det[i + j + k] += sign[s] * P[a][i] * Qp[b][j] * R[c][k];
-    }
-    double zs[10];
-    const int nz = real_roots(det, 10, zs);
-    int count = 0;
-    for (int t = 0; t < nz && count < 10; ++t) {
-        const double z = zs[t], z2 = z * z, z3 = z2 * z, z4 = z3 * z;
-        double Bz[9];
-        for (int j = 0; j < 3; ++j) {
-            Bz[3 * j] = B[j][0] * z3 + B[j][1] * z2 + B[j][2] * z + B[j][3];
-            Bz[3 * j + 1] = B[j][4] * z3 + B[j][5] * z2 + B[j][6] * z + B[j][7];
-            Bz[3 * j + 2] = B[j][8] * z4 + B[j][9] * z3 + B[j][10] * z2 + B[j][11] * z + B[j][12];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+            const double pq = sgn[s] * P[a][i] * Qp[b][j];
+            for (int k = 0; k < 5; ++k) det[i + j + k] += pq * R[c][k];
         }
-        /* SVD::solveZ: right singular vector of the smallest singular value = eigenvector of Bz'Bz */
-        double G[9], W[9];
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { G[3 * a + b] = 0; for (int k = 0; k < 3; ++k) G[3 * a + b] += Bz[3 * k + a] * Bz[3 * k + b]; }
-        jacobi_eig(G, 3, W);
-        int m = 0;
-        for (int k = 1; k < 3; ++k) if (G[4 * k] < G[4 * m]) m = k;
-        const double vx = W[m], vy = W[3 + m], vw = W[6 + m];
-        const double vn = sqrt(vx * vx + vy * vy + vw * vw);
-        if (fabs(vw / vn) < 1e-10) continue;
-        const double x = vx / vw, y = vy / vw;
-        double Ev[9], nrm = 0.0;
-        for (int a = 0; a < 9; ++a) { Ev[a] = x * N[0][a] + y * N[1][a] + z * N[2][a] + N[3][a]; nrm += Ev[a] * Ev[a]; }
-        nrm = sqrt(nrm);
-        int big = 0;
-        for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
-        if (Ev[big] < 0) nrm = -nrm;                                   /* canonical sign */
-        for (int a = 0; a < 9; ++a) E_out[9 * count + a] = Ev[a] / nrm;
-        ++count;
     }
-    /* canonical order: ascending E[0][0] */
-    for (int i = 1; i < count; ++i) {
-        double tmp[9]; memcpy(tmp, E_out + 9 * i, sizeof(tmp));
-        int j = i - 1;
-        while (j >= 0 && E_out[9 * j] > tmp[0]) { memcpy(E_out + 9 * (j + 1), E_out + 9 * j, sizeof(tmp)); --j; }
-        memcpy(E_out + 9 * (j + 1), tmp, sizeof(tmp));
+    return 1;
+}
+
+/* step 4.  An upper estimate of a^(1/k) from exact operations only: a itself, its square root, or the power of two (in quarter
+ * steps) above the k-th root of the power of two above a */
+static double root_upper(double a, int k)
+{
+    static const double quarter[4] = { 1.0, 0x1.306fe0a31b715p+0, 0x1.6a09e667f3bcdp+0, 0x1.ae89f995ad3adp+0 };      /* 2^(j/4) */
+    if (!(a > 1e-300)) return 0.0;
+    if (k == 1) return a;
+    if (k == 2) return sqrt(a);
+    int e;
+    (void)frexp(a, &e);                               /* a = m 2^e, 1/2 <= m < 1 */
+    const int num = 4 * e;
+    int t = num / k;                                  /* ceil(4 e / k) */
+    if (t * k < num) ++t;
+    int q = t / 4;                                    /* floor(t / 4) */
+    if (4 * q > t) --q;
+    return ldexp(quarter[t - 4 * q], q);
+}
+/* start points: estimate i on the circle of radius (half of Fujiwara's bound) x 0.9^i at the angle 2 pi i / 10 + 0.4 (a spiral: no
+ * symmetry of the polynomial can be a symmetry of the start) */
+static const double kStartCos[10] = { 0x1.d7954e7dba2f8p-1, 0x1.08532eee8b103p-1, -0x1.5f2c08503a8c7p-4, -0x1.4f59d8cac4b95p-1, -0x1.f2b6774fec871p-1,
+                                      -0x1.d7954e7dba2f9p-1, -0x1.08532eee8b101p-1, 0x1.5f2c08503a8dep-4, 0x1.4f59d8cac4b97p-1, 0x1.f2b6774fec871p-1 };
+static const double kStartSin[10] = { 0x1.8ec3ae92b676bp-2, 0x1.b67e458544eb3p-1, 0x1.fe1d62c483ff6p-1, 0x1.82e3cb1245546p-1, 0x1.cf8b5a26ac140p-3,
+                                      -0x1.8ec3ae92b6767p-2, -0x1.b67e458544eb5p-1, -0x1.fe1d62c483ff6p-1, -0x1.82e3cb1245544p-1, -0x1.cf8b5a26ac134p-3 };
+
+/* the ten complex roots of z^10 + cc[9] z^9 + ... + cc[0] by the simultaneous (Jacobi-style) Durand-Kerner iteration: every sweep
+ * moves all ten estimates from the previous sweep's values.  An estimate is at rest when its step is <= 1e-13 of its magnitude, or is
+ * already < 1e-7 and has not halved for twelve sweeps (the evaluation noise of an ill-conditioned root); the iteration stops when all
+ * ten are at rest, or after 300 sweeps.  Returns the number of sweeps. */
+static int durand_kerner10(const double *cc, double *re, double *im)
+{
+    double rad = 0.0;
+    for (int k = 1; k <= 10; ++k) rad = fmax(rad, root_upper(fabs(cc[10 - k]) * (k == 10 ? 0.5 : 1.0), k));
+    if (!(rad > 1e-300)) rad = 1.0;
+    for (int i = 0; i < 10; ++i) {
+        double r = rad;
+        for (int k = 0; k < i; ++k) r = r * 0.9;
+        re[i] = r * kStartCos[i]; im[i] = r * kStartSin[i];
+    }
+    double best_mv[10]; int stale[10];
+    for (int i = 0; i < 10; ++i) { best_mv[i] = 1e300; stale[i] = 0; }
+    int it = 0;
+    for (; it < 300; ++it) {
+        double nre[10], nim[10];
+        int moving = 0;
+        for (int i = 0; i < 10; ++i) {
+            double pr = 1.0, pim = 0.0;                               /* p(z_i) by Horner */
+            for (int k = 9; k >= 0; --k) { const double tt = pr * re[i] - pim * im[i] + cc[k]; pim = pr * im[i] + pim * re[i]; pr = tt; }
+            double dr = 1.0, di = 0.0;                                /* prod_{j != i} (z_i - z_j), j ascending */
+            for (int j = 0; j < 10; ++j) {
+                if (j == i) continue;
+                const double ar = re[i] - re[j], ai = im[i] - im[j];
+                const double tt = dr * ar - di * ai, ti = dr * ai + di * ar;
+                dr = tt; di = ti;
+            }
+            const double den = dr * dr + di * di;
+            const double inv = den > 0.0 ? 1.0 / den : 0.0;
+            const double qr = (pr * dr + pim * di) * inv, qi = (pim * dr - pr * di) * inv;
+            nre[i] = re[i] - qr; nim[i] = im[i] - qi;
+            const double mv = (fabs(qr) + fabs(qi)) / (fabs(nre[i]) + fabs(nim[i]) + 1e-300);
+            const int better = mv < 0.5 * best_mv[i];
+            if (better) best_mv[i] = mv;
+            stale[i] = better ? 0 : stale[i] + 1;
+            if (!(mv <= 1e-13) && !(stale[i] >= 12 && best_mv[i] < 1e-7)) moving = 1;
+        }
+        for (int i = 0; i < 10; ++i) { re[i] = nre[i]; im[i] = nim[i]; }
+        if (!moving) { ++it; break; }
+    }
+    return it;
+}
+
+/* step 5 for root estimate (re, im): 1 and the unit-norm, sign-canonical model in Ev, with its polished root in *z_out; 0 = no model */
+static int model_from_root(const double *cc, double P[3][4], double Qp[3][4], double R[3][5], double N[4][9], double re, double im, double *Ev, double *z_out)
+{
+    const int is_real = !(fabs(im) > 1e-8 * fmax(1.0, fabs(re)));
+    double z = re;
+    for (int nit = 0; nit < 4; ++nit) {               /* Newton on the real axis */
+        double pz = 1.0, dz = 0.0;
+        for (int k = 9; k >= 0; --k) { dz = dz * z + pz; pz = pz * z + cc[k]; }
+        if (dz == 0.0) break;
+        z -= pz / dz;
+    }
+    double Bz[3][3];
+    for (int j = 0; j < 3; ++j) {
+        Bz[j][0] = ((P[j][3] * z + P[j][2]) * z + P[j][1]) * z + P[j][0];
+        Bz[j][1] = ((Qp[j][3] * z + Qp[j][2]) * z + Qp[j][1]) * z + Qp[j][0];
+        Bz[j][2] = (((R[j][4] * z + R[j][3]) * z + R[j][2]) * z + R[j][1]) * z + R[j][0];
+    }
+    double bx = 0, by = 0, bw = 0, bn = -1.0;         /* null vector of B(z): the largest of the cross products of rows (0,1) (1,2) (2,0) */
+    for (int a = 0; a < 3; ++a) {
+        const int b = (a + 1) % 3;
+        const double cx = Bz[a][1] * Bz[b][2] - Bz[a][2] * Bz[b][1], cy = Bz[a][2] * Bz[b][0] - Bz[a][0] * Bz[b][2],
+                     cw = Bz[a][0] * Bz[b][1] - Bz[a][1] * Bz[b][0];
+        const double nn = cx * cx + cy * cy + cw * cw;
+        if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
+    }
+    if (!(is_real && bn > 0.0 && !(fabs(bw) < 1e-10 * sqrt(bn)))) return 0;
+    const double x = bx / bw, y = by / bw;
+    double nrm = 0.0;
+    for (int a = 0; a < 9; ++a) { Ev[a] = x * N[0][a] + y * N[1][a] + z * N[2][a] + N[3][a]; nrm += Ev[a] * Ev[a]; }
+    nrm = 1.0 / sqrt(nrm);
+    int big = 0;
+    for (int a = 1; a < 9; ++a) if (fabs(Ev[a]) > fabs(Ev[big])) big = a;
+    if (Ev[big] < 0.0) nrm = -nrm;                    /* canonical sign */
+    for (int a = 0; a < 9; ++a) Ev[a] *= nrm;
+    *z_out = z;
+    return 1;
+}
+
+/* q1, q2: 5 normalised correspondences (x2' E x1 = 0).  E_out: up to 10 matrices, row-major, unit Frobenius norm. */
+int esfm_ref_five_point(const double *q1, const double *q2, double *E_out)
+{
+    double N[4][9], det[11], P[3][4], Qp[3][4], R[3][5];
+    null_space(q1, q2, N);
+    if (!determinant_polynomial(N, det, P, Qp, R)) return 0;
+    if (!(fabs(det[10]) > 0.0)) return 0;
+    double cc[10], re[10], im[10];
+    for (int k = 0; k < 10; ++k) cc[k] = det[k] / det[10];
+    durand_kerner10(cc, re, im);
+    double Ev[10][9], z[10];
+    int valid[10], count = 0;
+    for (int i = 0; i < 10; ++i) { valid[i] = model_from_root(cc, P, Qp, R, N, re[i], im[i], Ev[i], &z[i]); count += valid[i]; }
+    for (int i = 0; i < 10; ++i) {                    /* canonical order: rank of (E[0][0], z, i) among the models */
+        if (!valid[i]) continue;
+        int rank = 0;
+        for (int j = 0; j < 10; ++j)
+            if (valid[j] && (Ev[j][0] < Ev[i][0] || (Ev[j][0] == Ev[i][0] && (z[j] < z[i] || (z[j] == z[i] && j < i))))) ++rank;
+        memcpy(E_out + 9 * rank, Ev[i], sizeof(double) * 9);
     }
     return count;
+}
+
+/* the intermediate stages of one sample, for stage-by-stage comparison with the product's host and device builds
+ * (tests/test_five_point_stages.py): stages[0..35] = N, [36..46] = det, [47..58] = P, [59..70] = Qp, [71..85] = R, [86..95] = cc,
+ * [96..105] = re, [106..115] = im.  Returns the sweeps of the root iteration, -1 = no polynomial. */
+int esfm_ref_five_point_stages(const double *q1, const double *q2, double *stages)
+{
+    double N[4][9], det[11], P[3][4], Qp[3][4], R[3][5], cc[10], re[10], im[10];
+    memset(stages, 0, sizeof(double) * 116);
+    null_space(q1, q2, N);
+    memcpy(stages, N, sizeof(N));
+    if (!determinant_polynomial(N, det, P, Qp, R) || !(fabs(det[10]) > 0.0)) return -1;
+    memcpy(stages + 36, det, sizeof(det)); memcpy(stages + 47, P, sizeof(P)); memcpy(stages + 59, Qp, sizeof(Qp)); memcpy(stages + 71, R, sizeof(R));
+    for (int k = 0; k < 10; ++k) cc[k] = det[k] / det[10];
+    const int sweeps = durand_kerner10(cc, re, im);
+    memcpy(stages + 86, cc, sizeof(cc)); memcpy(stages + 96, re, sizeof(re)); memcpy(stages + 106, im, sizeof(im));
+    return sweeps;
 }
 
 /* ----------------------------------------------------------------------------------------------- Sampson error */

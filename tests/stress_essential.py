@@ -1,7 +1,7 @@
 """Randomised stress of the 2-D/2-D verification (5-point RANSAC: esfm_find_essential_pairs) against the oracle: 8 ... 3000 matches,
 0 - 60 % gross outliers, thresholds 0.5 - 3 px, confidence 0.99 / 0.999, planar and general scenes, small and large baselines -- iteration
-counts and inlier masks exact.  Differences are COUNTED by kind and reported (another of two nearly equal models chosen / a model on
-one side only), as tests/stress_pnp.py does: a rate, not a pass/fail on the first borderline correspondence.
+counts, inlier masks AND the essential matrix bit for bit (one arithmetic on both sides since round 6: five_point_core.hpp).
+Differences are COUNTED by kind and reported, as tests/stress_pnp.py does; any difference is a non-zero exit status.
 usage: python tests/stress_essential.py [--seconds S | --cases N] [--seed K]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -48,13 +48,14 @@ while time.time() < t_end and n_cases < max_cases:
     if not ok:
         n_none += 1; continue
     iters_total += itr
-    if itg == itr and np.array_equal(mg, mr):
+    if itg == itr and np.array_equal(mg, mr) and np.array_equal(np.asarray(Es[0]), Er):
         n_exact += 1
     else:
         n_border += 1
         if abs(int(mg.sum()) - int(mr.sum())) > max(2, 0.02 * n): n_far += 1
         border.append(tag + (itg, itr, int(mg.sum()), int(mr.sum())))
 print(f"stress_essential seed {args.seed}: {n_cases} cases ({n_none} without a model on both sides), {iters_total} RANSAC iterations: {n_exact} with iteration count and mask "
-      f"equal to the oracle's, {n_border} where the two sides chose differently ({n_far} of them with inlier counts more than 2 % apart), {n_one_side} with a model on one side only")
+      f"and matrix equal to the oracle's, {n_border} where the two sides chose differently ({n_far} of them with inlier counts more than 2 % apart), {n_one_side} with a model on one side only")
 for x in border[:12]:
     print("  differs:", x)
+sys.exit(0 if n_border == 0 and n_one_side == 0 else 1)

@@ -45,16 +45,19 @@ def test_pnp_random_sweep(seed):
     assert " 0 where a threshold-borderline" in out and " 0 with a pose on one side only" in out and "(0 of them with an ill-conditioned re-fit" in out, out[-2000:]
 
 
-def test_essential_random_sweep_rate():
-    """tests/stress_essential.py: the 5-point RANSAC's two sides evaluate a hypothesis' models along differently conditioned routes, so
-    threshold-borderline correspondences let ~2 % of random problems choose differently.  The bar is the RATE:
-    at most 4 % differ, no model on one side only -- a regression of the solver would show as a jump."""
+@pytest.mark.parametrize("seed", [41, 42])
+def test_essential_random_sweep(seed):
+    """tests/stress_essential.py: 8 ... 3000 matches, 0 - 60 % outliers, thresholds 0.5 - 3 px, planar and general scenes: iteration counts,
+    inlier masks and the essential matrix bit for bit.  (Round 5 found 2.2 % of such problems decided differently from the oracle by
+    threshold-borderline correspondences -- the two sides reached a hypothesis' models along different routes, to ~1e-8 -- and the bar was a
+    rate.  Round 6: ONE arithmetic on both sides, easysfm_amd/csrc/five_point_core.hpp == oracle/ransac_ref.c to the letter, and the bar is
+    zero)"""
     import re
-    out = _run("stress_essential.py", "--cases", "1500", "--seed", "41")
+    out = _run("stress_essential.py", "--cases", "1500", "--seed", str(seed))
     m = re.search(r"(\d+) cases .*?(\d+) where the two sides chose differently .*?(\d+) with a model on one side only", out)
     assert m, out[-2000:]
     cases, differ, one_side = (int(m.group(k)) for k in (1, 2, 3))
-    assert cases == 1500 and differ <= 0.04 * cases and one_side == 0, out[-2000:]
+    assert cases == 1500 and differ == 0 and one_side == 0, out[-2000:]
 
 
 def test_cloud_random_sweep():
