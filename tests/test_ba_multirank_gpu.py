@@ -202,6 +202,20 @@ def test_sharded_structure_aware_solve_four_ranks_matches_single(gpu_ctx):
     assert sum(r[5] for r in res) == sc.n_pt
 
 
+def test_sharded_structure_aware_solve_eight_ranks_matches_single(gpu_ctx):
+    """EIGHT ranks (the node's rank count; eight processes on the one GPU, gloo): an eighth of the points each, the union of the pair sets
+    over eight ranks, eight packed buffers summed."""
+    sc, (cams, pts, summ) = _single("loop200")
+    res = _run(8, "gloo", scene="loop200")
+    ref_cost = [it.cost for it in summ.log()]
+    for rank, _, c, p, costs, n_active, _cal, _ls in res:
+        assert len(costs) == len(ref_cost) and np.allclose(costs, ref_cost, rtol=1e-9)
+        assert np.allclose(c, cams, rtol=1e-6, atol=1e-6) and np.allclose(p, pts, rtol=1e-6, atol=1e-6)
+    for r in range(1, 8):
+        assert np.array_equal(res[0][2], res[r][2])
+    assert sum(r[5] for r in res) == sc.n_pt
+
+
 def test_native_rccl_communicator_single_rank_structure_aware(gpu_ctx):
     """The structure-aware exchange through the library's own RCCL communicator, one rank: the packed co-visible blocks are this
     rank's fixed-point sums converted exactly as the one-rank assembly converts them, so the solve is bit-identical to the single-GPU one."""
