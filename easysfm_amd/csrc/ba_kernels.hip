@@ -295,6 +295,8 @@ __device__ __forceinline__ int qexp_of(double diag)
 // timing-only build (scratch/build_variant_ba.sh NAME -DESFM_LIN_TRACE): s_memrealtime ticks (10 ns) summed over the waves of ba_linearize_kernel:
 // [0] prologue (LDS clear, exponents, first loads), [1] the loop, [2] everything behind it, [3] waves, [4] loop iterations
 __device__ unsigned long long g_lin_trace[8];
+__device__ unsigned long long g_lin_wave[512 * 8 * 5];
+extern "C" int esfm_debug_lin_waves(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_wave), sizeof(g_lin_wave)); }
 extern "C" int esfm_debug_lin_trace(unsigned long long *out, int reset)
 {
     if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lin_trace), z, sizeof(z)); }
@@ -553,6 +555,10 @@ __global__ __launch_bounds__(kLinThreads, kLinThreads == 256 ? ESFM_LIN_OCC : 1)
                 const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
                 atomicAdd(&g_lin_trace[0], t1 - t0); atomicAdd(&g_lin_trace[1], t2 - t1); atomicAdd(&g_lin_trace[2], t3 - t2);
                 atomicAdd(&g_lin_trace[3], 1ull); atomicAdd(&g_lin_trace[4], it);
+                if (blockIdx.x < 512) {       // per wave of the last launch: start, loop start, loop end, end (10-ns ticks), XCC id (scratch/lin_trace.py)
+                    unsigned long long *w = &g_lin_wave[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 5];
+                    w[0] = t0; w[1] = t1; w[2] = t2; w[3] = t3; w[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15;   // HW_REG_XCC_ID
+                }
             }
         }
     } lin_trace_end{lt0, lt1, lt2, lt_iters};
