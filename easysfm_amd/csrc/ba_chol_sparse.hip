@@ -482,7 +482,9 @@ int ba_solve_reduced_sparse(hipStream_t st, const BADev &d, SparseSolve *S, doub
         hipLaunchKernelGGL(chol_sparse_assemble_kernel<true>, dim3(4 * dv.n_tiles), dim3(256), 0, st, d, dv, radius, min_diag, max_diag, 0, S->packed);
         S->packed_source = false;
     } else {
-        if (!d.parts->red_fixed) { set_error("structure-aware solve: the Schur buffer is not in fixed point"); return ESFM_ERR_INVALID_ARG; }
+        // (a buffer of zeros is fixed point on any grid: a problem without observations -- ba_schur returns before it writes anything --
+        // still has a plan when its cameras number more than a leaf, and must solve like the dense path does)
+        if (!d.parts->red_fixed && !d.parts->red_clean) { set_error("structure-aware solve: the Schur buffer is not in fixed point"); return ESFM_ERR_INVALID_ARG; }
         hipLaunchKernelGGL(chol_sparse_assemble_kernel<false>, dim3(4 * dv.n_tiles), dim3(256), 0, st, d, dv, radius, min_diag, max_diag, d.parts->red_rhs_exp,
                            (const double *)nullptr);
         d.parts->red_fixed = false; d.parts->red_clean = true;

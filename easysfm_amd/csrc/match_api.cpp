@@ -595,6 +595,13 @@ int esfm_match_release_prepared(esfm_ctx *ctx)
     return ESFM_OK;
 }
 
+int esfm_match_release_prepared_buffer(esfm_ctx *ctx, const void *desc_dev)
+{
+    if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }
+    if (ctx->prep_desc == desc_dev) ctx->prep_desc = nullptr;
+    return ESFM_OK;
+}
+
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned)
 {
     if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }

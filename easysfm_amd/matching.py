@@ -300,13 +300,15 @@ class PairMatcher:
         check(lib().esfm_match_prepare_dev(self.ctx.handle, b.metric, C.c_void_p(b.data.data_ptr()), int(b.row_offset[-1]), b.width))
 
     def release(self) -> None:
-        """esfm_match_release_prepared: to be called before the bank's buffer is freed or rewritten (close() / garbage collection /
-        DescriptorBank.update() do) -- a later allocation at the same address must not inherit this one's operand images."""
+        """esfm_match_release_prepared_buffer: to be called before the bank's buffer is freed or rewritten (close() / garbage collection /
+        DescriptorBank.update() do) -- a later allocation at the same address must not inherit this one's operand images.  Releases
+        only if THIS bank's buffer is the one prepared on the context: an older matcher that is garbage-collected must not take the
+        prepared operands from the live one on the same Context (its calls would silently re-derive them every time)."""
         try:
             h = self.ctx.handle
         except RuntimeError:
             return
-        check(lib().esfm_match_release_prepared(h))
+        check(lib().esfm_match_release_prepared_buffer(h, C.c_void_p(self.bank.data.data_ptr())))
 
     def close(self) -> None:
         self.release()

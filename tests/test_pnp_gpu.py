@@ -1,9 +1,10 @@
 """Parity of the HIP 3-D/2-D registration (reference cv::solvePnPRansac with SOLVEPNP_EPNP at
 cpp_code/src/estimate_motion.cpp:161-162) through the C ABI against the CPU oracle.
 
-Both sides replay the same cv::RNG sample stream and bookkeeping: iteration counts and inlier masks must agree exactly;
-the pose comes from the same EPnP restatement evaluated with different summation orders (device reductions vs a serial
-loop) and agrees to 1e-7 (stated floating-point tolerance; the 12 x 12 null space amplifies rounding)."""
+Both sides replay the same cv::RNG sample stream and bookkeeping: iteration counts and inlier masks must agree exactly.  The pose:
+the EPnP re-fit on the inliers runs on the HOST in the oracle's summation order for inlier sets up to 8 192 (round 6; 1 024 before) --
+every frame this pipeline can meet -- and is then BIT-IDENTICAL to the CPU restatement's, rvec and tvec included; beyond that the
+device reductions take over and agree to 1e-7 (tests/stress_pnp.py has such sets)."""
 import numpy as np
 import pytest
 
@@ -32,7 +33,7 @@ def test_solve_pnp_ransac_matches_oracle(gpu_ctx, oracle_lib, n, frac, iters, se
     assert ok
     rv, tv, Rg, mg, itg = E.solve_pnp_ransac(X, pix, K4, iters, 2.5, 0.99, gpu_ctx)
     assert itg == itr and np.array_equal(mg, mr)
-    assert np.allclose(Rg, Rr, atol=1e-7) and np.allclose(tv, tr, atol=1e-6) and np.allclose(rv, rvr, atol=1e-7)
+    assert np.array_equal(Rg, Rr) and np.array_equal(tv, tr) and np.array_equal(rv, rvr)
     if n >= 60:
         assert np.allclose(Rg, R, atol=5e-3) and np.allclose(tv, t, atol=0.05) and mg[bad].sum() <= 0.05 * len(bad) + 2
         assert abs(np.linalg.det(Rg) - 1) < 1e-9
@@ -41,7 +42,7 @@ def test_solve_pnp_ransac_matches_oracle(gpu_ctx, oracle_lib, n, frac, iters, se
 @pytest.mark.parametrize("n,frac,seed", [(800, 0.6, 21), (400, 0.65, 22), (1500, 0.55, 23)])
 def test_solve_pnp_ransac_many_iterations_through_the_deferred_hypotheses(gpu_ctx, oracle_lib, n, frac, seed):
     """Hundreds of RANSAC iterations (55 - 65 % gross outliers): about one hypothesis in a hundred stalls in the 12 x 12 Jacobi
-    diagonalisation; the first pass gives up on those after ten sweeps and the replay has them solved in full when it reaches them
+    diagonalisation; the first pass gives up on those after twelve sweeps and the replay has them solved in full when it reaches them
     (pnp_api.cpp) -- with this many iterations it does.  Iteration counts and masks exact, as everywhere."""
     rng = np.random.default_rng(seed)
     X, pix, R, t, bad = _scene(rng, n, frac)
@@ -49,7 +50,7 @@ def test_solve_pnp_ransac_many_iterations_through_the_deferred_hypotheses(gpu_ct
     assert ok and itr > 150
     rv, tv, Rg, mg, itg = E.solve_pnp_ransac(X, pix, K4, 50000, 2.5, 0.99, gpu_ctx)
     assert itg == itr and np.array_equal(mg, mr)
-    assert np.allclose(Rg, Rr, atol=1e-7) and np.allclose(tv, tr, atol=1e-6) and np.allclose(rv, rvr, atol=1e-7)
+    assert np.array_equal(Rg, Rr) and np.array_equal(tv, tr) and np.array_equal(rv, rvr)
 
 
 def test_pnp_exactly_five_and_too_few(gpu_ctx, oracle_lib):

@@ -43,6 +43,7 @@ def test_pnp_random_sweep(seed):
     both sides now share cvSVD's stopping rule and the hypotheses / small re-fits the oracle's summation order -- DESIGN section 4e.)"""
     out = _run("stress_pnp.py", "--cases", "200", "--seed", str(seed))
     assert " 0 where a threshold-borderline" in out and " 0 with a pose on one side only" in out and "(0 of them with an ill-conditioned re-fit" in out, out[-2000:]
+    assert " 0 with a pose that is not bit-identical" in out, out[-2000:]
 
 
 @pytest.mark.parametrize("seed", [41, 42])
