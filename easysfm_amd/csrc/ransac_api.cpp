@@ -51,8 +51,8 @@ int fill_pairs(int n_pairs, const int32_t *off, const float *K4, double threshol
 void jacobi3(double A[9], double V[9])
 {
     for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5], diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    for (int sweep = 0; sweep < 100; ++sweep) {     // (the CPU restatement's jacobi_eig to the letter -- cap, stopping rule, sums: R and t come out bit-identical)
+        const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8], off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
         if (off <= 1e-40 * diag || off == 0.0) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
@@ -81,8 +81,8 @@ void decompose_essential(const double *E, double *R1, double *R2, double *t)
     double G[9], V[9];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[3 * a + b] = E[a] * E[b] + E[3 + a] * E[3 + b] + E[6 + a] * E[6 + b];
     jacobi3(G, V);
-    int o[3] = {0, 1, 2};
-    std::sort(o, o + 3, [&](int a, int b) { return G[4 * a] > G[4 * b]; });
+    int o[3] = {0, 1, 2};                           // singular values descending; equal ones keep their order (an insertion sort, as there)
+    for (int i = 1; i < 3; ++i) { const int v = o[i]; int j = i - 1; while (j >= 0 && G[4 * o[j]] < G[4 * v]) { o[j + 1] = o[j]; --j; } o[j + 1] = v; }
     double v[3][3], u[3][3];
     for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) v[k][a] = V[3 * a + o[k]];
     for (int k = 0; k < 2; ++k) {
