@@ -3,9 +3,8 @@
 // (triangulation part).
 //
 //   triangulate_dlt_kernel   one thread per correspondence: the 4 x 4 DLT matrix A in f64 (rows x P[2] - P[0], y P[2] - P[1]
-//                            per view), then the eigenvector of the smallest eigenvalue of A'A by cyclic Jacobi rotations
-//                            on the symmetric 4 x 4 (= the right singular vector of the smallest singular value, which
-//                            cvSVD returns as row 3 of V^T), written as 4 floats.
+//                            per view), then its right singular vector of the smallest singular value (cvSVD's row 3 of V^T)
+//                            by one-sided Jacobi rotations on the columns of A, written as 4 floats.
 // Embarrassingly parallel, ~600 f64 FLOP and 32 B in / 16 B out per point: latency-bound at the sizes the pipeline
 // produces (10^2 .. 10^4 correspondences per pair); the batch entry point takes many pairs in one launch.
 #include "common.hpp"
@@ -31,58 +30,48 @@ __device__ __forceinline__ void triangulate_one(const float *__restrict__ P1, co
         A[2][k] = (double)x2 * (double)P2[8 + k] - (double)P2[k];
         A[3][k] = (double)y2 * (double)P2[8 + k] - (double)P2[4 + k];
     }
-    // M = A'A (symmetric), V = I
-    double M[4][4], V[4][4];
+    // One-sided (Hestenes) Jacobi on the columns of A, rotations accumulated in V -- what OpenCV's JacobiSVD does, and the CPU
+    // restatement's loop (oracle/geometry_ref.c) to the letter: same sums, same skip rule, same sweep cap, so the vector (its sign
+    // included) comes out bit-identical.  (Until round 6: cyclic Jacobi on A'A here -- the squared condition number, another
+    // stopping rule; the two sides agreed to 2e-6 on the float vector, up to sign.)
+    double V[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double s = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s += A[r][p] * A[r][q];
-            M[p][q] = s;
-            V[p][q] = p == q ? 1.0 : 0.0;
-        }
-    // cyclic Jacobi eigenvalue iteration; 4 x 4 converges quadratically, 10 sweeps are far more than needed
-    for (int sweep = 0; sweep < 10; ++sweep) {
-        double off = 0.0, diag = 0.0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            diag += M[p][p] * M[p][p];
-#pragma unroll
-            for (int q = p + 1; q < 4; ++q) off += M[p][q] * M[p][q];
-        }
-        if (off <= 1e-32 * diag) break;
+        for (int q = 0; q < 4; ++q) V[p][q] = p == q ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool changed = false;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) {
-                const double apq = M[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                double a = 0.0, b = 0.0, c = 0.0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {   // M <- M J  (columns p, q)
-                    const double mp = M[r][p], mq = M[r][q];
-                    M[r][p] = c * mp - s * mq; M[r][q] = s * mp + c * mq;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {   // M <- J' M  (rows p, q)
-                    const double mp = M[p][r], mq = M[q][r];
-                    M[p][r] = c * mp - s * mq; M[q][r] = s * mp + c * mq;
-                }
+                for (int r = 0; r < 4; ++r) { a += A[r][p] * A[r][p]; b += A[r][q] * A[r][q]; c += A[r][p] * A[r][q]; }
+                if (fabs(c) <= DBL_EPSILON * sqrt(a * b) || c == 0.0) continue;
+                changed = true;
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double vp = V[r][p], vq = V[r][q];
-                    V[r][p] = c * vp - s * vq; V[r][q] = s * vp + c * vq;
+                    const double u = A[r][p], v = A[r][q];
+                    A[r][p] = cs * u - sn * v; A[r][q] = sn * u + cs * v;
+                    const double vu = V[r][p], vv = V[r][q];
+                    V[r][p] = cs * vu - sn * vv; V[r][q] = sn * vu + cs * vv;
                 }
             }
+        if (!changed) break;
     }
     int best = 0;
-    double bv = M[0][0];
+    double bn = DBL_MAX;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) if (M[k][k] < bv) { bv = M[k][k]; best = k; }
+    for (int k = 0; k < 4; ++k) {
+        double sq = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq += A[r][k] * A[r][k];
+        if (sq < bn) { bn = sq; best = k; }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         double v = V[r][0];

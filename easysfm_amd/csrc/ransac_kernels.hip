@@ -283,7 +283,7 @@ __device__ void triangulate_f64(const double *P, double x0, double y0, double x1
             for (int r = 0; r < 4; ++r) s += A[r][p] * A[r][q];
             M[p][q] = s; V[p][q] = p == q ? 1.0 : 0.0;
         }
-    for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int sweep = 0; sweep < 100; ++sweep) {          // (cap and stopping rule: the CPU restatement's jacobi_eig to the letter)
         double off = 0.0, diag = 0.0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -291,7 +291,7 @@ __device__ void triangulate_f64(const double *P, double x0, double y0, double x1
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) off += M[p][q] * M[p][q];
         }
-        if (off <= 1e-34 * diag) break;
+        if (off <= 1e-40 * diag || off == 0.0) break;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
