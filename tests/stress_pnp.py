@@ -2,7 +2,7 @@
 1 - 8 px, iteration caps 50 ... 50 000 -- iteration counts, inlier masks and (round 6: host re-fit up to 8 192 inliers) poses bit for bit.  What differs is COUNTED and reported,
 by kind (another of two nearly equal hypotheses chosen; a pose on one side only; an ill-conditioned re-fit whose poses drift apart), so
 that a regression shows up as a rate: round 5's first run reported 3.7 % / 0.07 % / 1 % and led to the shared Jacobi stopping rule,
-the centred sums of the hypothesis solver and the host re-fit of small inlier sets (DESIGN section 4e); since then all three are 0.
+the centred sums of the hypothesis solver and the host re-fit of small inlier sets (DESIGN section 6.3); since then all three are 0.
 usage: python tests/stress_pnp.py [--seconds S | --cases N] [--seed K]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

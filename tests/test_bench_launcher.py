@@ -60,7 +60,7 @@ def test_single_rank_dry_run_is_the_metric_workload():
 
 
 def test_self_launcher_eight_ranks_dry_run_shares():
-    """What `bench.py --gpus 8` does rank by rank before anything is timed (DESIGN.md section 5's checklist), without a GPU: eight
+    """What `bench.py --gpus 8` does rank by rank before anything is timed, without a GPU: eight
     ranks meet, the headline's 300 pairs fall 38 / 37 per rank, config 4's 32 640 pairs 4 080 per rank, the weak side
     leg takes 70 images (2 415 pairs >= 300 x 8)."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"], env=_clean_env(),

@@ -40,7 +40,7 @@ def test_pnp_random_sweep(seed):
     """tests/stress_pnp.py: problem sizes 6 ... 4000, 0 - 70 % outliers, coplanar sets, thresholds 1 - 8 px, iteration caps 50 ... 50 000:
     iteration counts and inlier masks exact, poses to 1e-6.  (Round 5 found 3.7 % of such problems choosing differently from the oracle:
     the two sides' Jacobi diagonalisations stopped by different rules, and the hypotheses' scatter matrices were summed in different forms;
-    both sides now share cvSVD's stopping rule and the hypotheses / small re-fits the oracle's summation order -- DESIGN section 4e.)"""
+    both sides now share cvSVD's stopping rule and the hypotheses / small re-fits the oracle's summation order -- DESIGN section 6.3.)"""
     out = _run("stress_pnp.py", "--cases", "200", "--seed", str(seed))
     assert " 0 where a threshold-borderline" in out and " 0 with a pose on one side only" in out and "(0 of them with an ill-conditioned re-fit" in out, out[-2000:]
     assert " 0 with a pose that is not bit-identical" in out, out[-2000:]
@@ -52,7 +52,7 @@ def test_essential_random_sweep(seed):
     inlier masks and the essential matrix bit for bit.  (Round 5 found 2.2 % of such problems decided differently from the oracle by
     threshold-borderline correspondences -- the two sides reached a hypothesis' models along different routes, to ~1e-8 -- and the bar was a
     rate.  Round 6: ONE arithmetic on both sides, easysfm_amd/csrc/five_point_core.hpp == oracle/ransac_ref.c to the letter, and the bar is
-    zero; DESIGN section 4d.)"""
+    zero; DESIGN section 6.1.)"""
     import re
     out = _run("stress_essential.py", "--cases", "1500", "--seed", str(seed))
     m = re.search(r"(\d+) cases .*?(\d+) where the two sides chose differently .*?(\d+) with a model on one side only", out)
