@@ -1682,7 +1682,17 @@ __device__ __forceinline__ void finish_rerank_wave(const FinRerankArgs &A, int v
         for (int i = 0; i < 14; ++i) {
             got[i] = 0.f;
             if (i < 2 * nv) {
+#ifdef ESFM_FIN_DIST2X      // sizing build: the canonical-order distance evaluated TWICE (same results): what the kernel gains per evaluation removed
+                float dr = l2sqr64_canonical_row16(qv[i >> 1], rowv[i]);
+                {
+                    u32x4 again = rowv[i];
+                    asm volatile("" : "+v"(again));
+                    const float dr2 = l2sqr64_canonical_row16(qv[i >> 1], again);
+                    dr = dr2 != dr2 ? dr2 : dr;
+                }
+#else
                 const float dr = l2sqr64_canonical_row16(qv[i >> 1], rowv[i]);
+#endif
                 got[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 3) * 16 + 15) * 4, __float_as_int(dr)));
             }
             __builtin_amdgcn_sched_barrier(0);       // (one row group at a time: interleaved, the fourteen chains took 296 registers)
