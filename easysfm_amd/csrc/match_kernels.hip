@@ -1612,8 +1612,15 @@ __device__ __forceinline__ void finish_rerank_wave(const FinRerankArgs &A, int v
     float4 s_ka, s_kb, s_mi;                                     // (the entry as it came: what is parked when the query stays undecided)
     u64 m0 = kNone, m1 = kNone;                                  // the query's exact two best so far
     int verdict = 0;
+    // the 2 K keys' order, once per parked query (round 6): position p of the ascending (key, index) order holds key number
+    // (ord >> 3 p) & 7 (0 .. 3: half 0's keys, 4 .. 7: half 1's); kOrdValid marks a computed order.  It travels with the parked query in
+    // the entry's unused fourth word.  (Until then every later round ranked the eight keys by counting TWICE -- once to decide whether
+    // to park, once when the round ran: 8 x 7 compares each, a third of the later rounds' instructions on clustered descriptors.)
+    constexpr int kOrdValid = 1 << 24;
+    int ord = 0;
     auto take = [&](float4 ka, float4 kb4, float4 mi, bool valid, u64 b0, u64 b1) {
         s_ka = ka; s_kb = kb4; s_mi = mi;
+        ord = __float_as_int(mi.w);                                // 0 in an entry as the pass wrote it
         qvalid = valid;
         qrow = qvalid ? __float_as_int(mi.x) : nq;               // nq: past the descriptor, zeros
         qn = (double)mi.y; e1 = (double)mi.z;
@@ -1641,6 +1648,34 @@ __device__ __forceinline__ void finish_rerank_wave(const FinRerankArgs &A, int v
             if (rank == r) { key = kx; row0 = row0_of(kx, x < K ? 0 : 1); }
             if (rank == r + 1) nkey = kx;
         }
+    };
+    auto compute_ord = [&]() {
+        int o = kOrdValid;
+#pragma unroll
+        for (int x = 0; x < 2 * K; ++x) {
+            const float kx = x < K ? a_[x & 3] : b_[x & 3];
+            int rank = 0;
+#pragma unroll
+            for (int y = 0; y < 2 * K; ++y) {
+                const float ky = y < K ? a_[y & 3] : b_[y & 3];
+                if (y != x) rank += (ky < kx || (ky == kx && y < x)) ? 1 : 0;
+            }
+            o |= x << (3 * rank);
+        }
+        ord = o;
+    };
+    auto key_number = [&](int x) {           // key number x of the query's eight (a chain of selects: a register array indexed by data would go to scratch)
+        float k = a_[0];
+        k = x == 1 ? a_[1] : k; k = x == 2 ? a_[2] : k; k = x == 3 ? a_[3] : k;
+        k = x == 4 ? b_[0] : k; k = x == 5 ? b_[1] : k; k = x == 6 ? b_[2] : k; k = x == 7 ? b_[3] : k;
+        return k;
+    };
+    // rank_group from the stored order: the same (key, row0, nkey)
+    auto ordered_group = [&](int r, float &key, int &row0, float &nkey) {
+        const int x = (ord >> (3 * r)) & 7;
+        key = key_number(x);
+        row0 = row0_of(key, x >> 2);
+        nkey = r + 1 < 2 * K ? key_number((ord >> (3 * (r + 1))) & 7) : kBig;
     };
     // does a round on the group (key, row0) still have to look at rows?  (false once: false for every later rank -- the keys ascend)
     auto wanted = [&](float key, int row0) {
@@ -1777,13 +1812,16 @@ __device__ __forceinline__ void finish_rerank_wave(const FinRerankArgs &A, int v
     // queries take consecutive slots), every other one is finalised
     auto park_or_finalize = [&](int r, int *npend) {
         float key = kBig, nkey; int row0 = -1;
-        if (r + 1 < 2 * K) rank_group(r + 1, key, row0, nkey);
+        if (r + 1 < 2 * K) {
+            if (!(ord & kOrdValid)) compute_ord();
+            ordered_group(r + 1, key, row0, nkey);
+        }
         const bool leader = qvalid && (lane & 7) == 0;
         const bool again = leader && r + 1 < 2 * K && wanted(key, row0);
         const unsigned long long bal = __ballot(again);
         if (again) {
             FinPending &dst = pend[*npend + __popcll(bal & ((1ull << lane) - 1ull))];
-            dst.ka = s_ka; dst.kb = s_kb; dst.mi = s_mi; dst.m0 = m0; dst.m1 = m1;
+            dst.ka = s_ka; dst.kb = s_kb; dst.mi = make_float4(s_mi.x, s_mi.y, s_mi.z, __int_as_float(ord)); dst.m0 = m0; dst.m1 = m1;
         }
         if (leader && !again) finalize();
         *npend += __popcll(bal);
@@ -1802,7 +1840,7 @@ __device__ __forceinline__ void finish_rerank_wave(const FinRerankArgs &A, int v
                 __builtin_amdgcn_wave_barrier();
                 take(src.ka, src.kb, src.mi, e < nv, src.m0, src.m1);
                 float key, nkey; int row0;
-                rank_group(r, key, row0, nkey);
+                ordered_group(r, key, row0, nkey);                 // (a parked query carries its order)
                 do_round(r + 1 == 2 * K, key, row0, nkey);
                 park_or_finalize(r, &nout);
                 __builtin_amdgcn_wave_barrier();
