@@ -66,6 +66,29 @@ def test_exactly_five_points_and_too_few(gpu_ctx, oracle_lib):
         E.find_essential_mat(p1[:4], p2[:4], K4, 0.99, 1.0, gpu_ctx)
 
 
+def test_degenerate_correspondences_match_oracle(gpu_ctx, oracle_lib):
+    """Inputs whose samples are degenerate for the 5-point kernel -- every correspondence the same pixel pair, all points on one image
+    line, a pure rotation (no baseline: E is not defined), identical images (zero motion), a handful of points with repeats -- must
+    come out the same on both sides: found / not found, iteration count, mask and matrix, NaNs included."""
+    rng = np.random.default_rng(33)
+    p1, p2, R, t, Egt, out = _pair(rng, 120, 0.0, noise=0.0)
+    Rrot = synth.aa_to_R(np.array([0.02, -0.1, 0.01]))
+    x1 = (p1.astype(np.float64) - [K4[1], K4[3]]) / [K4[0], K4[2]]
+    h = np.c_[x1, np.ones(len(x1))] @ Rrot.T
+    rot2 = (h[:, :2] / h[:, 2:3] * [K4[0], K4[2]] + [K4[1], K4[3]]).astype(np.float32)
+    line1 = p1.copy(); line1[:, 1] = np.float32(0.4) * line1[:, 0] + np.float32(30.0)
+    few = np.repeat(p1[:3], 4, axis=0), np.repeat(p2[:3], 4, axis=0)
+    cases = [(np.tile(p1[:1], (40, 1)), np.tile(p2[:1], (40, 1))), (line1, p2), (p1, rot2), (p1, p1.copy()), few, (p1[:5], p1[:5].copy())]
+    for k, (a, b) in enumerate(cases):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        ok, Er, mr, itr, cnt = oracle_lib.find_essential_ransac(a, b, K4, 0.99, 1.0)
+        Es, mask, status, its = E.find_essential_pairs(np.array([0, len(a)], np.int32), a, b, K4[None], 0.99, 1.0, gpu_ctx)
+        assert bool(status[0]) == bool(ok), k
+        if ok:
+            assert int(its[0]) == itr and np.array_equal(np.asarray(mask[:len(a)]).astype(bool), mr), k
+            assert np.array_equal(np.asarray(Es[0]), Er, equal_nan=True), k
+
+
 def test_batched_pairs_equal_single_calls(gpu_ctx, oracle_lib):
     rng = np.random.default_rng(11)
     jobs = [_pair(rng, n, f) for n, f in ((300, 0.3), (3, 0.0), (120, 0.5), (900, 0.1), (40, 0.7))]
