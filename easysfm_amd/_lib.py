@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "esfm_version", "esfm_last_error", "esfm_device_count", "esfm_ctx_create", "esfm_ctx_destroy",
     "esfm_ctx_synchronize", "esfm_ctx_stream", "esfm_ctx_set_kernel_timing", "esfm_ctx_kernel_time",
     "esfm_knn2_l2_f32", "esfm_knn2_hamming", "esfm_match_l2_f32", "esfm_match_hamming",
-    "esfm_match_pairs_dev", "esfm_match_pairs", "esfm_knn2_pairs_dev", "esfm_knn2_pairs_screened_dev", "esfm_match_prepare_dev", "esfm_match_debug_counters", "esfm_match_release_prepared", "esfm_match_release_prepared_buffer", "esfm_ctx_set_prepared_check", "esfm_match_last_stats", "esfm_match_last_second_pass", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
+    "esfm_match_pairs_dev", "esfm_match_pairs", "esfm_knn2_pairs_dev", "esfm_knn2_pairs_screened_dev", "esfm_match_prepare_dev", "esfm_match_debug_counters", "esfm_match_release_prepared", "esfm_match_release_prepared_buffer", "esfm_match_prepared_buffer", "esfm_ctx_set_prepared_check", "esfm_match_last_stats", "esfm_match_last_second_pass", "esfm_ctx_set_l2_audit", "esfm_match_last_flagged",
     "esfm_shard_pair_list",
     "esfm_comm_get_unique_id", "esfm_comm_create", "esfm_comm_destroy", "esfm_comm_rank", "esfm_comm_world", "esfm_comm_rccl_ranks", "esfm_comm_allreduce",
     "esfm_ba_options_default", "esfm_ba_solve", "esfm_ba_problem_create", "esfm_ba_problem_set_params",
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     L.esfm_match_prepare_dev.argtypes = [vp, C.c_int, vp, C.c_int64, C.c_int]
     L.esfm_match_release_prepared.argtypes = [vp]
     L.esfm_match_release_prepared_buffer.argtypes = [vp, vp]
+    L.esfm_match_prepared_buffer.argtypes = [vp, vp]
     L.esfm_ctx_set_prepared_check.argtypes = [vp, C.c_int]
     L.esfm_match_last_stats.argtypes = [vp, i64p, i64p]
     L.esfm_match_last_second_pass.argtypes = [vp, i64p]

@@ -602,6 +602,13 @@ int esfm_match_release_prepared_buffer(esfm_ctx *ctx, const void *desc_dev)
     return ESFM_OK;
 }
 
+int esfm_match_prepared_buffer(esfm_ctx *ctx, const void **desc_dev_out)
+{
+    if (!ctx || !desc_dev_out) { esfm::set_error("esfm_match_prepared_buffer: bad arguments"); return ESFM_ERR_INVALID_ARG; }
+    *desc_dev_out = ctx->prep_desc;
+    return ESFM_OK;
+}
+
 int esfm_match_last_stats(esfm_ctx *ctx, int64_t *n_queries, int64_t *n_rescanned)
 {
     if (!ctx) { esfm::set_error("ctx is NULL"); return ESFM_ERR_INVALID_ARG; }

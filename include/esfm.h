@@ -185,6 +185,8 @@ int esfm_match_release_prepared(esfm_ctx *ctx);
 /* The same, but only if `desc_dev` IS the buffer currently prepared on this context (a no-op otherwise): what an owner of one of
  * several descriptor buffers calls when ITS buffer goes away, without taking the prepared state from whoever holds it now. */
 int esfm_match_release_prepared_buffer(esfm_ctx *ctx, const void *desc_dev);
+/* Which buffer is prepared on this context right now (NULL: none). */
+int esfm_match_prepared_buffer(esfm_ctx *ctx, const void **desc_dev_out);
 /* The prepared state is keyed on (desc_dev, metric, total_rows, width) and there is ONE per context: a second prepare replaces the
  * first.  The library cannot see a hipFree or an in-place rewrite, and a same-size hipMalloc routinely returns the address just
  * freed: a prepared buffer MUST be released (esfm_match_release_prepared) or prepared again BEFORE it is freed, rewritten or

@@ -76,3 +76,29 @@ def test_two_matchers_one_context(oracle_lib):
         assert _same(pa.match(0.6).to_host(), _oracle_lists(oracle_lib, E.ESFM_L2_F32, a, pairs, 0.6))
         assert _same(pb.match(0.6).to_host(), _oracle_lists(oracle_lib, E.ESFM_L2_F32, b, pairs, 0.6))
     pa.close(); pb.close()
+
+
+def test_an_older_matchers_release_leaves_the_live_one_prepared(oracle_lib):
+    """PairMatcher.release() (close / garbage collection) used to clear the context's prepared state whoever owned it, so an
+    older matcher going away made the live one re-derive its operands on every call (correct, slower, and dependent on GC timing).
+    Release is by owner now (esfm_match_release_prepared_buffer)."""
+    import ctypes as C, gc
+    from easysfm_amd import _lib
+
+    def prepared(ctx):
+        out = C.c_void_p()
+        _lib.check(_lib.lib().esfm_match_prepared_buffer(ctx.handle, C.byref(out)))
+        return out.value
+    a, b = _sets(E.ESFM_L2_F32, 42), _sets(E.ESFM_L2_F32, 43)
+    pairs = synth.all_pairs(3)
+    ctx = E.Context.on_torch_stream(0)
+    bank_a, bank_b = E.DescriptorBank(a, E.ESFM_L2_F32), E.DescriptorBank(b, E.ESFM_L2_F32)
+    pa = E.PairMatcher(bank_a, pairs, ctx)
+    assert prepared(ctx) == bank_a.data.data_ptr()
+    pb = E.PairMatcher(bank_b, pairs, ctx)
+    assert prepared(ctx) == bank_b.data.data_ptr()           # one prepared buffer per context: the newer matcher's
+    pa.close(); del pa; gc.collect()
+    assert prepared(ctx) == bank_b.data.data_ptr()           # ... and it stays prepared when the older one goes
+    assert _same(pb.match(0.6).to_host(), _oracle_lists(oracle_lib, E.ESFM_L2_F32, b, pairs, 0.6))
+    pb.close()
+    assert prepared(ctx) is None
