@@ -138,3 +138,26 @@ def test_sparse_solve_repeat_solves_bit_identical(gpu_ctx):
                 first = sig
             assert sig == first, f"repeat {rep} differs"
         prob.close()
+
+
+@pytest.mark.parametrize("mode", [None, "sparse", "dense"])
+def test_no_observations_and_mostly_unobserved_cameras(gpu_ctx, oracle_lib, mode, monkeypatch):
+    """40 cameras get a structure-aware plan even when nothing is observed (isolated cameras are packed into leaves).  A
+    problem without observations must return untouched parameters on every solve path, and one where 3 of the 40 cameras see points
+    must follow the oracle."""
+    from easysfm_amd import synth
+    if mode: monkeypatch.setenv("ESFM_BA_SOLVE", mode)
+    else: monkeypatch.delenv("ESFM_BA_SOLVE", raising=False)
+    sc = synth.ba_scene(40, 50, 3, seed=3)
+    e = np.zeros(0, np.int32)
+    opt = E.default_options(); opt.max_num_iterations = 5
+    c, p, s = E.ba_solve(e, e, np.zeros((0, 2), np.float32), sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
+    assert s.num_iterations == 0 and s.initial_cost == 0.0 and np.array_equal(c, sc.cams0) and np.array_equal(p, sc.pts0)
+    keep = sc.cam_idx < 3
+    ro = oracle_lib.ba_default_options(); ro.max_num_iterations = 5
+    c, p, s = E.ba_solve(sc.cam_idx[keep], sc.pt_idx[keep], sc.uv[keep], sc.K4, sc.cams0, sc.pts0, opt, gpu_ctx)
+    rc, rp, rs = oracle_lib.ba_solve(sc.cam_idx[keep], sc.pt_idx[keep], sc.uv[keep], sc.K4, sc.cams0, sc.pts0, ro)
+    assert s.num_iterations == rs.num_iterations
+    for a, b in zip(s.log(), oracle_lib.iterations(rs)):
+        assert abs(a.cost - b.cost) <= 1e-9 * max(1.0, abs(b.cost)) and a.step_is_successful == b.step_is_successful
+    assert np.array_equal(c[3:], sc.cams0[3:])               # cameras without observations: bit-identical (SURVEY 8b iii)
